@@ -1,0 +1,42 @@
+# Build of the papr hot path for MI355X (gfx950).  No GPU is needed to build.
+#   make            -> dtv-utils_amd/libpaprhip.so, bin/papr, oracle/*
+#   make lib | cli | oracle
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+PKG     := dtv-utils_amd
+CSRC    := $(PKG)/csrc
+LIB     := $(PKG)/libpaprhip.so
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-result
+CFLAGS  := -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
+
+all: lib cli oracle
+
+lib: $(LIB)
+
+$(CSRC)/papr_host.o: $(CSRC)/papr_host.c include/papr_hip.h include/papr_synth.h
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(CSRC)/papr_kernels.o: $(CSRC)/papr_kernels.hip $(CSRC)/papr_kernels.h include/papr_synth.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/papr_runtime.o: $(CSRC)/papr_runtime.cpp $(CSRC)/papr_kernels.h include/papr_hip.h include/papr_synth.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(CSRC)/papr_kernels.o $(CSRC)/papr_runtime.o $(CSRC)/papr_host.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -lm -lpthread
+
+cli: bin/papr
+
+bin/papr: $(PKG)/host/papr_main.c include/papr_hip.h $(LIB)
+	@mkdir -p bin
+	$(CC) -O2 -ffp-contract=off -Wall -Wextra -Iinclude $< -o $@ -L$(PKG) -lpaprhip -Wl,-rpath,'$$ORIGIN/../$(PKG)' -lm -lpthread
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -f $(CSRC)/*.o $(LIB) bin/papr
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib cli oracle clean

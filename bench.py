@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — the papr hot path on N MI355X GPUs of one node.
+
+One "step" = one complete papr run over the HBM-resident shard(s): pass 1
+(power, double sum, first-index peak + I/Q extrema), the stats exchange, the
+host scalar stage (mean, PAPR, level table), pass 2 (CCDF counting) and the
+count exchange.  Workload at N=1 is BASELINE.json configs[1]: 10 GiB of
+synthetic gr_complex IQ, default mode ("peak+mean+1 dB histogram"); `--mode
+graph` gives configs[2] (0.1 dB CCDF, ~301 bins).  With N ranks every rank owns
+its own 10 GiB shard of an N x 10 GiB stream (weak scaling; N=8 is configs[3]).
+
+Launched by the driver as
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.  Inputs are already resident in HBM when the timed
+region starts (generated on the device by the shared counter-hash generator).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def cpu_baseline(pkg, mode: str, sample_gib: float):
+    """Time the reference program (oracle/_ref/papr, compiled from the reference's
+    own papr.c) — or, if it is absent, the oracle port — on a bounded sample of the
+    same synthetic workload, single thread (the reference is single-threaded)."""
+    orc = ge.load_oracle()
+    ref = orc.REF_CLI if os.path.exists(orc.REF_CLI) else None
+    binary, kind = (ref, "reference") if ref else (orc.CLI_PATH, "port")
+    if not os.path.exists(binary):
+        return None
+    n = int(sample_gib * (1 << 30)) // 8
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path = os.path.join(tmpdir, f"papr_bench_sample_{os.getpid()}.cfile")
+    try:
+        t0 = time.perf_counter()
+        subprocess.check_call([orc.MKCFILE, path, str(n), "--spike"])
+        gen_s = time.perf_counter() - t0
+        args = [binary] + (["-g"] if mode == "graph" else []) + [path]
+        subprocess.run(args, capture_output=True)  # page-cache warm, untimed
+        t0 = time.perf_counter()
+        p = subprocess.run(args, capture_output=True)
+        cpu_s = time.perf_counter() - t0
+        # same file through the GPU product (ABI path) for an in-run parity check
+        with pkg.PaprHip(int(os.environ.get("LOCAL_RANK", "0"))) as g:
+            g.load_file(path)
+            st = g.stats()
+            mean, papr, table = pkg.levels(st, mode == "graph")
+            text = pkg.format_report(st, mean, papr, g.ccdf(table), mode == "graph").encode()
+        return {"value": n / cpu_s / 1e6, "unit": "Msamples/s", "cores": 1, "kind": kind,
+                "sample": f"{sample_gib:g} GiB ({n} samples) of the same spike workload, mode={mode}, "
+                          f"levels={int(table.size)}, file in {tmpdir} (page cache warm), {cpu_s:.2f} s wall",
+                "nproc": os.cpu_count(), "gpu_stdout_identical": text == p.stdout, "mkcfile_s": round(gen_s, 2)}
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=["default", "graph"], default="default")
+    ap.add_argument("--gib", type=float, default=10.0, help="GiB of IQ per GPU")
+    ap.add_argument("--cpu-sample-gib", type=float, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus > 1 launch with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the papr product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    pkg = ge.load_package()
+    from dtv_utils_amd import exchange
+    graph = args.mode == "graph"
+
+    per_gpu = int(args.gib * (1 << 30)) // 8 // 8192 * 8192   # samples per rank, chunk aligned
+    total = per_gpu * world
+    shard = torch.empty(per_gpu * 8 + 65536, dtype=torch.uint8, device=device)   # HBM-resident shard
+    gpu = pkg.PaprHip(local_rank)
+    gpu.adopt(shard.data_ptr(), per_gpu, base_index=rank * per_gpu, keepalive=shard)
+    gpu.generate(pkg.SynthSpec.spike(total), rank * per_gpu, per_gpu)
+
+    result = {}
+
+    def step():
+        local = gpu.stats()                                         # pass 1 on this shard
+        tot = exchange.merged_stats(local, device)                  # exchange 1 (RCCL all-gather)
+        mean, papr, table = pkg.levels(tot, graph)                  # host scalars
+        counts = exchange.allreduce_counts(gpu.ccdf(table), device) # pass 2 + exchange 2 (RCCL all-reduce)
+        result.update(total=tot, mean=mean, papr=papr, table=table, counts=counts)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    gpu.set_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tm = gpu.timing()
+    gpu.set_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total * args.steps / elapsed / 1e6
+        k_stats = tm.stats_ms / max(tm.stats_launches, 1)
+        k_ccdf = tm.ccdf_ms / max(tm.ccdf_launches, 1)
+        b_stats = tm.stats_bytes / max(tm.stats_launches, 1)
+        b_ccdf = tm.ccdf_bytes / max(tm.ccdf_launches, 1)
+        gbs_stats = b_stats / (k_stats * 1e-3) / 1e9 if k_stats else 0.0
+        gbs_ccdf = b_ccdf / (k_ccdf * 1e-3) / 1e9 if k_ccdf else 0.0
+        dom, dom_gbs, dom_ms = ("papr_ccdf_kernel", gbs_ccdf, k_ccdf) if k_ccdf >= k_stats else \
+            ("papr_stats_kernel", gbs_stats, k_stats)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                ent = tj.get(dom, {}).get(args.mode if dom == "papr_ccdf_kernel" else "any")
+                if ent and abs(ent.get("gib_per_gpu", 0) - args.gib) < 1e-9:
+                    traffic, traffic_src = ent["hbm_bytes_per_launch"], tj.get("source")
+            except Exception:
+                pass
+        line = {
+            "metric": "IQ Msamples/s + achieved HBM GB/s (% of peak), 10 GiB cfile, 1/2/4/8 GPU",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"papr {'-g ' if graph else ''}on {args.gib:g} GiB synthetic gr_complex IQ per GPU "
+                                   f"({'0.1 dB CCDF' if graph else 'peak+mean+1 dB histogram'}), HBM-resident, "
+                                   f"{world}xMI355X",
+                       "mode": args.mode, "samples_per_gpu": per_gpu, "samples_total": total,
+                       "levels": int(result["table"].size), "papr_db": round(float(result["papr"]), 6),
+                       "sharding": f"sample axis, {world} contiguous shard(s)",
+                       "exchange": "RCCL all-gather(stats) + all-reduce(counts)" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
+                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": per_gpu * 8,
+                         "traffic_source": traffic_src},
+            "kernels": {"papr_stats_kernel": {"avg_ms": k_stats, "GB/s": gbs_stats, "launches": int(tm.stats_launches)},
+                        "papr_ccdf_kernel": {"avg_ms": k_ccdf, "GB/s": gbs_ccdf, "launches": int(tm.ccdf_launches)},
+                        "both_passes_frac_of_peak": (b_stats + b_ccdf) / ((k_stats + k_ccdf) * 1e-3) / 1e9 / HBM_PEAK_GBS
+                        if (k_stats + k_ccdf) else 0.0,
+                        "host_and_exchange_ms_per_step": ms_per_step - k_stats - k_ccdf},
+            "device": gpu.name,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = args.cpu_sample_gib if args.cpu_sample_gib else (1.0 if graph else 2.0)
+            sample = min(sample, args.gib)
+            try:
+                cb = cpu_baseline(pkg, args.mode, sample)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                cb = {"error": repr(e)}
+            line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+
+    gpu.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

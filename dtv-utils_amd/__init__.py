@@ -1,0 +1,315 @@
+"""ctypes binding of libpaprhip.so (include/papr_hip.h) for tests and bench.py.
+
+The product is the C ABI and the `bin/papr` host program; this module is only
+plumbing so Python harnesses can drive the same entry points.  It never
+computes anything itself and has no fallback: if the HIP library is missing or
+no GPU is usable, calls raise.
+
+The directory name (`dtv-utils_amd`) is not importable as-is; load it with
+`__graft_entry__.load_package()`, which registers it as `dtv_utils_amd`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libpaprhip.so")
+CLI_PATH = os.path.join(REPO_ROOT, "bin", "papr")
+
+MAX_OVERRIDES = 8
+NO_INDEX = 2**64 - 1
+FLAG_NAN = 1
+FLAG_ODD_TAIL = 2
+MAX_LEVELS = 16384
+
+# every symbol include/papr_hip.h declares (tests check the .so exports them all)
+ABI_SYMBOLS = (
+    "papr_hip_abi_version", "papr_hip_device_count", "papr_hip_open", "papr_hip_close",
+    "papr_hip_last_error", "papr_hip_device_name", "papr_hip_set_tuning", "papr_hip_set_timing",
+    "papr_hip_get_timing", "papr_file_samples", "papr_hip_load_file", "papr_hip_upload",
+    "papr_hip_adopt", "papr_hip_generate", "papr_hip_download", "papr_hip_stats",
+    "papr_stats_init", "papr_stats_merge", "papr_levels", "papr_hip_ccdf",
+)
+
+
+class SynthOverride(C.Structure):
+    _fields_ = [("index", C.c_uint64), ("i", C.c_float), ("q", C.c_float)]
+
+
+class SynthSpec(C.Structure):
+    """papr_synth_spec (include/papr_synth.h)."""
+    _fields_ = [("seed", C.c_uint64), ("scale", C.c_float), ("n_overrides", C.c_uint32),
+                ("ov", SynthOverride * MAX_OVERRIDES)]
+
+    @classmethod
+    def make(cls, seed: int = 0x5EED0001, scale: float = 0.0,
+             overrides: Sequence[tuple] = ()) -> "SynthSpec":
+        sp = cls()
+        sp.seed = seed
+        sp.scale = scale
+        sp.n_overrides = len(overrides)
+        for k, (idx, i, q) in enumerate(overrides):
+            sp.ov[k].index, sp.ov[k].i, sp.ov[k].q = idx, i, q
+        return sp
+
+    @classmethod
+    def spike(cls, n: int, seed: int = 0x5EED0001) -> "SynthSpec":
+        """papr_synth_spike_spec: the bench workload (two equal ~30 dB spikes)."""
+        if n < 16:
+            return cls.make(seed)
+        a = (n // 1000) * 731 + ((n % 1000) * 731) // 1000
+        b = (n // 10) * 9 + ((n % 10) * 9) // 10
+        return cls.make(seed, 0.0, [(a, 36.9375, 0.0), (b, 36.9375, 0.0)])
+
+
+class Stats(C.Structure):
+    """papr_stats (include/papr_hip.h)."""
+    _fields_ = [("sum", C.c_double), ("n", C.c_uint64), ("peak_idx", C.c_uint64),
+                ("re_pos_idx", C.c_uint64), ("re_neg_idx", C.c_uint64),
+                ("im_pos_idx", C.c_uint64), ("im_neg_idx", C.c_uint64),
+                ("nan_first_idx", C.c_uint64),
+                ("peak", C.c_float), ("re_pos", C.c_float), ("re_neg", C.c_float),
+                ("im_pos", C.c_float), ("im_neg", C.c_float),
+                ("nan_first_neg", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+    def to_bytes(self) -> bytes:
+        return bytes(memoryview(self))
+
+    @classmethod
+    def from_bytes(cls, raw: bytes) -> "Stats":
+        return cls.from_buffer_copy(raw)
+
+
+class Timing(C.Structure):
+    _fields_ = [("stats_ms", C.c_double), ("stats_launches", C.c_uint64), ("stats_bytes", C.c_uint64),
+                ("ccdf_ms", C.c_double), ("ccdf_launches", C.c_uint64), ("ccdf_bytes", C.c_uint64)]
+
+
+class Tuning(C.Structure):
+    _fields_ = [("blocks", C.c_int), ("map", C.c_int), ("nontemporal", C.c_int),
+                ("hist_copies", C.c_int), ("variant", C.c_int)]
+
+
+class PaprError(RuntimeError):
+    def __init__(self, code: int, what: str, detail: str):
+        super().__init__(f"{what} failed with code {code}: {detail}")
+        self.code = code
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libpaprhip.so (built in-tree by `make lib` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `make lib` or __graft_entry__.build(); "
+            "there is no fallback implementation")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    L.papr_hip_abi_version.restype = i32
+    L.papr_hip_device_count.restype = i32
+    L.papr_hip_open.argtypes = [C.POINTER(vp), i32]
+    L.papr_hip_close.argtypes = [vp]
+    L.papr_hip_close.restype = None
+    L.papr_hip_last_error.argtypes = [vp]
+    L.papr_hip_last_error.restype = C.c_char_p
+    L.papr_hip_device_name.argtypes = [vp, C.c_char_p, i32]
+    L.papr_hip_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
+    L.papr_hip_set_timing.argtypes = [vp, i32]
+    L.papr_hip_get_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.papr_file_samples.argtypes = [C.c_char_p, C.POINTER(u64)]
+    L.papr_hip_load_file.argtypes = [vp, C.c_char_p, u64, u64]
+    L.papr_hip_upload.argtypes = [vp, vp, u64, u64]
+    L.papr_hip_adopt.argtypes = [vp, vp, u64, u64]
+    L.papr_hip_generate.argtypes = [vp, C.POINTER(SynthSpec), u64, u64]
+    L.papr_hip_download.argtypes = [vp, vp, u64, u64]
+    L.papr_hip_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.papr_stats_init.argtypes = [C.POINTER(Stats)]
+    L.papr_stats_init.restype = None
+    L.papr_stats_merge.argtypes = [C.POINTER(Stats), C.POINTER(Stats)]
+    L.papr_stats_merge.restype = None
+    L.papr_levels.argtypes = [C.POINTER(Stats), i32, C.POINTER(C.c_double), C.POINTER(C.c_float), vp, i32]
+    L.papr_hip_ccdf.argtypes = [vp, vp, i32, vp]
+    for name in ("papr_hip_open", "papr_hip_device_name", "papr_hip_set_tuning", "papr_hip_set_timing",
+                 "papr_hip_get_timing", "papr_file_samples", "papr_hip_load_file", "papr_hip_upload",
+                 "papr_hip_adopt", "papr_hip_generate", "papr_hip_download", "papr_hip_stats",
+                 "papr_levels", "papr_hip_ccdf"):
+        getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+# ---- GPU-free helpers (host side of the ABI) ---------------------------------
+
+def stats_merge(parts: Sequence[Stats]) -> Stats:
+    """Fold shard records in file order (papr_stats_merge)."""
+    L = lib()
+    acc = Stats()
+    L.papr_stats_init(C.byref(acc))
+    for p in parts:
+        L.papr_stats_merge(C.byref(acc), C.byref(p))
+    return acc
+
+
+def levels(total: Stats, graph: bool):
+    """(mean, papr, float32 level table) exactly as the reference's host scalars."""
+    L = lib()
+    mean, papr = C.c_double(), C.c_float()
+    n = L.papr_levels(C.byref(total), int(graph), C.byref(mean), C.byref(papr), None, 0)
+    table = np.zeros(max(n, 0), dtype=np.float32)
+    if n > 0:
+        L.papr_levels(C.byref(total), int(graph), None, None, table.ctypes.data_as(C.c_void_p), n)
+    return mean.value, papr.value, table
+
+
+def file_samples(path: str) -> int:
+    n = C.c_uint64()
+    rc = lib().papr_file_samples(os.fsencode(path), C.byref(n))
+    if rc:
+        raise PaprError(rc, "papr_file_samples", path)
+    return n.value
+
+
+# ---- one GPU context ------------------------------------------------------------
+
+class PaprHip:
+    """One papr_hip_ctx: one GPU, one shard of the sample axis."""
+
+    def __init__(self, device: int = 0):
+        self._L = lib()
+        self._ctx = C.c_void_p()
+        rc = self._L.papr_hip_open(C.byref(self._ctx), device)
+        if rc:
+            detail = self._L.papr_hip_last_error(None).decode()
+            self._ctx = C.c_void_p()
+            raise PaprError(rc, "papr_hip_open", detail)
+        self.device = device
+        self._keepalive = None
+
+    def close(self):
+        if self._ctx:
+            self._L.papr_hip_close(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int, what: str):
+        if rc:
+            raise PaprError(rc, what, self._L.papr_hip_last_error(self._ctx).decode())
+
+    @property
+    def name(self) -> str:
+        buf = C.create_string_buffer(160)
+        self._chk(self._L.papr_hip_device_name(self._ctx, buf, 160), "papr_hip_device_name")
+        return buf.value.decode()
+
+    def set_tuning(self, blocks=0, map=0, nontemporal=1, hist_copies=0, variant=0):
+        t = Tuning(blocks, map, nontemporal, hist_copies, variant)
+        self._chk(self._L.papr_hip_set_tuning(self._ctx, C.byref(t)), "papr_hip_set_tuning")
+
+    def set_timing(self, enabled: bool):
+        self._chk(self._L.papr_hip_set_timing(self._ctx, int(enabled)), "papr_hip_set_timing")
+
+    def timing(self) -> Timing:
+        t = Timing()
+        self._chk(self._L.papr_hip_get_timing(self._ctx, C.byref(t)), "papr_hip_get_timing")
+        return t
+
+    # shard residency
+    def load_file(self, path: str, first_sample: int = 0, nsamples: int = NO_INDEX):
+        self._chk(self._L.papr_hip_load_file(self._ctx, os.fsencode(path), first_sample, nsamples),
+                  "papr_hip_load_file")
+
+    def upload(self, iq: np.ndarray, base_index: int = 0):
+        iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)
+        if iq.size % 2:
+            raise ValueError("upload takes whole IQ pairs")
+        self._chk(self._L.papr_hip_upload(self._ctx, iq.ctypes.data_as(C.c_void_p), iq.size // 2, base_index),
+                  "papr_hip_upload")
+
+    def adopt(self, device_ptr: int, nsamples: int, base_index: int = 0, keepalive=None):
+        self._chk(self._L.papr_hip_adopt(self._ctx, C.c_void_p(device_ptr), nsamples, base_index), "papr_hip_adopt")
+        self._keepalive = keepalive
+
+    def generate(self, spec: SynthSpec, first_index: int, nsamples: int):
+        self._chk(self._L.papr_hip_generate(self._ctx, C.byref(spec), first_index, nsamples), "papr_hip_generate")
+
+    def download(self, first: int, nsamples: int) -> np.ndarray:
+        out = np.empty(2 * nsamples, dtype=np.float32)
+        self._chk(self._L.papr_hip_download(self._ctx, out.ctypes.data_as(C.c_void_p), first, nsamples),
+                  "papr_hip_download")
+        return out
+
+    # the two passes
+    def stats(self) -> Stats:
+        s = Stats()
+        self._chk(self._L.papr_hip_stats(self._ctx, C.byref(s)), "papr_hip_stats")
+        return s
+
+    def ccdf(self, level_table: np.ndarray) -> np.ndarray:
+        lv = np.ascontiguousarray(level_table, dtype=np.float32)
+        out = np.zeros(lv.size, dtype=np.uint64)
+        self._chk(self._L.papr_hip_ccdf(self._ctx, lv.ctypes.data_as(C.c_void_p), lv.size,
+                                        out.ctypes.data_as(C.c_void_p)), "papr_hip_ccdf")
+        return out
+
+
+def format_report(total: Stats, mean: float, papr: float, counts: np.ndarray, graph: bool) -> str:
+    """The reference's stdout (papr.c:132-135,154-161 / 186-190) from ABI results.
+
+    Only used by tests to compare ABI-level results with golden stdout; the
+    shipped formatter is host/papr_main.c.  Uses C printf via ctypes so the
+    digits come from the same libc.
+    """
+    libc = C.CDLL(None)
+    buf = C.create_string_buffer(256)
+
+    def fmt(f: bytes, *args):
+        libc.snprintf(buf, 256, f, *args)
+        return buf.value.decode()
+
+    n32 = np.float32(np.int64(total.n))
+    with np.errstate(all="ignore"):
+        pct = [float(np.float32(np.float32(np.int64(c)) / n32)) * 100.0 for c in counts]
+    d = C.c_double
+    out = []
+    if graph:
+        for p in pct:
+            out.append(fmt(b"%0.8f\n", d(p)))
+        return "".join(out)
+    out.append(fmt(b"Peak magnitude = %f\n", d(float(np.sqrt(np.float64(total.peak))))))
+    out.append(fmt(b"average power = %lf, peak power = %f @ %lld\n\n", d(mean), d(total.peak),
+                   C.c_longlong(total.peak_idx * 8)))
+    out.append(fmt(b"Maximum PAPR = %f\n", d(papr)))
+    for j, p in enumerate(pct):
+        out.append(fmt(b"percentage above %d dB = %0.8f\n", C.c_int(j), d(p)))
+    out.append("\n")
+    out.append(fmt(b"peak real positive = %f, peak imaginary positive = %f\n", d(total.re_pos), d(total.im_pos)))
+    out.append(fmt(b"peak real negative = %f, peak imaginary negative = %f\n\n", d(total.re_neg), d(total.im_neg)))
+    out.append(fmt(b"peak real positive @ %lld, peak imaginary positive @ %lld\n",
+                   C.c_longlong(total.re_pos_idx * 8), C.c_longlong(total.im_pos_idx * 8 + 1)))
+    out.append(fmt(b"peak real negative @ %lld, peak imaginary negative @ %lld\n",
+                   C.c_longlong(total.re_neg_idx * 8), C.c_longlong(total.im_neg_idx * 8 + 1)))
+    return "".join(out)

@@ -1,0 +1,518 @@
+// papr_kernels.hip — gfx950 (MI355X / CDNA4) kernels for the papr hot path.
+//
+// Both passes are pure HBM streaming reductions (8 B per IQ sample per pass,
+// ~20 VALU ops per sample, no data reuse): no MFMA, no tiling through LDS for
+// the samples themselves.  What matters is 16-byte-per-lane coalesced loads
+// with many in flight, enough resident wave64s per CU, and keeping the
+// reduction state (trackers, LDS histograms) off the global-memory path.
+//
+//   papr_stats_kernel     pass 1  (reference papr.c:102-128)
+//   papr_stats_finalize   tail samples + fixed-order merge of workgroup partials
+//   papr_first_nan_kernel only launched when the sum came out NaN
+//   papr_ccdf_lut_kernel  pass 2  (reference papr.c:145-152 / 177-184) via an
+//                         exact bit-pattern LUT + LDS-privatised histograms
+//   papr_ccdf_search_kernel  same result for level tables the LUT cannot hold
+//   papr_generate_kernel  synthetic IQ (include/papr_synth.h) straight into HBM
+//
+// Arithmetic contract (SURVEY.md appendix A rule 3): power = fl(fl(I*I) +
+// fl(Q*Q)) in float with NO fused multiply-add; this file is compiled with
+// -ffp-contract=off and also spells the roundings out with __fmul_rn/__fadd_rn.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "papr_kernels.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWaves = PAPR_BLOCK / kWave;
+
+__device__ __forceinline__ float power_of(float re, float im)
+{
+    return __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// one global_load_dwordx4 per lane (optionally with the nontemporal hint: the
+// shard is streamed exactly once per pass, nothing is worth keeping in L2/MALL)
+template <bool NT>
+__device__ __forceinline__ float4 load16(const float4 *p)
+{
+    const f32x4 *q = reinterpret_cast<const f32x4 *>(p);
+    const f32x4 v = NT ? __builtin_nontemporal_load(q) : *q;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// Which tiles a workgroup walks, and in what order.  Every mapping visits a
+// lane's samples in increasing index order, which is what makes the per-lane
+// strict-compare trackers keep the FIRST occurrence.
+struct TileWalk {
+    uint64_t first;   // first tile
+    uint64_t stride;  // tiles between consecutive iterations
+    uint32_t count;   // iterations
+};
+
+__device__ __forceinline__ TileWalk tile_walk(uint32_t b, uint32_t nblocks, uint64_t ntiles, int map)
+{
+    TileWalk w;
+    if (map == PAPR_MAP_BLOCK_SPAN) {
+        // one contiguous span of tiles per workgroup
+        uint64_t per = (ntiles + nblocks - 1) / nblocks;
+        w.first = (uint64_t)b * per;
+        w.stride = 1;
+        uint64_t left = w.first < ntiles ? ntiles - w.first : 0;
+        w.count = (uint32_t)(left < per ? left : per);
+    } else if (map == PAPR_MAP_XCD_SPAN && (nblocks % 8u) == 0) {
+        // workgroup b is observed to run on XCD b % 8: give each XCD one
+        // contiguous eighth of the shard and stride its workgroups inside it
+        uint32_t xcd = b & 7u, slot = b >> 3, per_x = nblocks >> 3;
+        uint64_t span = (ntiles + 7) / 8;
+        uint64_t x0 = (uint64_t)xcd * span;
+        uint64_t xn = x0 < ntiles ? ntiles - x0 : 0;
+        if (xn > span) xn = span;
+        w.first = x0 + slot;
+        w.stride = per_x;
+        w.count = xn > slot ? (uint32_t)((xn - slot + per_x - 1) / per_x) : 0;
+    } else {
+        // grid-stride over tiles: concurrently running workgroups read
+        // neighbouring tiles
+        w.first = b;
+        w.stride = nblocks;
+        w.count = ntiles > b ? (uint32_t)((ntiles - b + nblocks - 1) / nblocks) : 0;
+    }
+    return w;
+}
+
+// ---- (value, index) trackers ------------------------------------------------
+
+template <bool IS_MIN>
+__device__ __forceinline__ void track(float x, uint32_t code, float &best, uint32_t &best_code)
+{
+    const bool win = IS_MIN ? (x < best) : (x > best);  // strict; NaN never wins
+    best = win ? x : best;
+    best_code = win ? code : best_code;
+}
+
+template <bool IS_MIN>
+__device__ __forceinline__ bool beats(float av, uint64_t ai, float bv, uint64_t bi)
+{
+    // "more extreme value, else smaller index" — order-independent merge rule
+    const bool more = IS_MIN ? (av < bv) : (av > bv);
+    return more || (av == bv && ai < bi);
+}
+
+template <bool IS_MIN>
+__device__ __forceinline__ void wave_reduce_pair(float &v, uint64_t &i)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const float ov = __shfl_down(v, off, kWave);
+        const uint64_t oi = __shfl_down((unsigned long long)i, off, kWave);
+        if (beats<IS_MIN>(ov, oi, v, i)) {
+            v = ov;
+            i = oi;
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_reduce_sum(double s)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1)
+        s += __shfl_down(s, off, kWave);
+    return s;
+}
+
+struct LaneStats {
+    double sum;
+    float val[5];      // peak, re_pos, re_neg, im_pos, im_neg
+    uint64_t idx[5];
+};
+
+__device__ __forceinline__ void lane_stats_sample(LaneStats &s, float re, float im, uint64_t index)
+{
+    const float pw = power_of(re, im);
+    s.sum += (double)pw;
+    if (pw > s.val[0]) { s.val[0] = pw; s.idx[0] = index; }
+    if (re > s.val[1]) { s.val[1] = re; s.idx[1] = index; }
+    if (re < s.val[2]) { s.val[2] = re; s.idx[2] = index; }
+    if (im > s.val[3]) { s.val[3] = im; s.idx[3] = index; }
+    if (im < s.val[4]) { s.val[4] = im; s.idx[4] = index; }
+}
+
+// Workgroup-wide merge of LaneStats; the result is valid in thread 0.
+__device__ __forceinline__ void block_reduce_stats(LaneStats &s)
+{
+    __shared__ double sh_sum[kWaves];
+    __shared__ float sh_val[kWaves][5];
+    __shared__ uint64_t sh_idx[kWaves][5];
+
+    s.sum = wave_reduce_sum(s.sum);
+    wave_reduce_pair<false>(s.val[0], s.idx[0]);
+    wave_reduce_pair<false>(s.val[1], s.idx[1]);
+    wave_reduce_pair<true>(s.val[2], s.idx[2]);
+    wave_reduce_pair<false>(s.val[3], s.idx[3]);
+    wave_reduce_pair<true>(s.val[4], s.idx[4]);
+
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) {
+        sh_sum[wave] = s.sum;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            sh_val[wave][k] = s.val[k];
+            sh_idx[wave][k] = s.idx[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWaves; w++) {  // fixed order => deterministic sum
+            s.sum += sh_sum[w];
+            if (beats<false>(sh_val[w][0], sh_idx[w][0], s.val[0], s.idx[0])) { s.val[0] = sh_val[w][0]; s.idx[0] = sh_idx[w][0]; }
+            if (beats<false>(sh_val[w][1], sh_idx[w][1], s.val[1], s.idx[1])) { s.val[1] = sh_val[w][1]; s.idx[1] = sh_idx[w][1]; }
+            if (beats<true>(sh_val[w][2], sh_idx[w][2], s.val[2], s.idx[2])) { s.val[2] = sh_val[w][2]; s.idx[2] = sh_idx[w][2]; }
+            if (beats<false>(sh_val[w][3], sh_idx[w][3], s.val[3], s.idx[3])) { s.val[3] = sh_val[w][3]; s.idx[3] = sh_idx[w][3]; }
+            if (beats<true>(sh_val[w][4], sh_idx[w][4], s.val[4], s.idx[4])) { s.val[4] = sh_val[w][4]; s.idx[4] = sh_idx[w][4]; }
+        }
+    }
+}
+
+}  // namespace
+
+// =============================================================================
+// pass 1 — power, double sum, first-index peak and component extrema
+// =============================================================================
+// One launch covers `ntiles` full tiles (PAPR_TILE_SAMPLES samples each) of
+// `data`; the < 1 tile remainder of the shard is folded in by
+// papr_stats_finalize.  Per lane: U independent 16-byte loads are issued
+// before any arithmetic (U KiB in flight per wave), then 2U samples are folded
+// into a double partial sum and five (value, 32-bit sample code) trackers.  The
+// 32-bit code (iteration * 2U + slot) is expanded to a 64-bit global sample
+// index once, after the loop.
+template <bool NT>
+__global__ __launch_bounds__(PAPR_BLOCK) void papr_stats_kernel(const float4 *__restrict__ data, uint64_t ntiles,
+                                                                 uint64_t base_index, int map,
+                                                                 papr_partial *__restrict__ out)
+{
+    constexpr int U = PAPR_UNROLL;
+    const uint32_t t = threadIdx.x;
+    const TileWalk w = tile_walk(blockIdx.x, gridDim.x, ntiles, map);
+
+    double sum = 0.0;
+    float v_pk = 0.f, v_rp = 0.f, v_rn = 0.f, v_ip = 0.f, v_in = 0.f;
+    uint32_t c_pk = 0, c_rp = 0, c_rn = 0, c_ip = 0, c_in = 0;
+
+    const float4 *p = data + w.first * PAPR_TILE_F4 + t;
+    const uint64_t step = w.stride * PAPR_TILE_F4;
+    uint32_t code = 0;
+    for (uint32_t it = 0; it < w.count; it++, p += step, code += 2 * U) {
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            x[u] = load16<NT>(p + u * PAPR_BLOCK);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float p0 = power_of(x[u].x, x[u].y);
+            const float p1 = power_of(x[u].z, x[u].w);
+            sum += (double)p0;
+            sum += (double)p1;
+            const uint32_t c0 = code + 2 * u, c1 = c0 + 1;
+            track<false>(p0, c0, v_pk, c_pk);
+            track<false>(p1, c1, v_pk, c_pk);
+            track<false>(x[u].x, c0, v_rp, c_rp);
+            track<false>(x[u].z, c1, v_rp, c_rp);
+            track<true>(x[u].x, c0, v_rn, c_rn);
+            track<true>(x[u].z, c1, v_rn, c_rn);
+            track<false>(x[u].y, c0, v_ip, c_ip);
+            track<false>(x[u].w, c1, v_ip, c_ip);
+            track<true>(x[u].y, c0, v_in, c_in);
+            track<true>(x[u].w, c1, v_in, c_in);
+        }
+    }
+
+    // expand codes to global sample indices; a tracker that never fired keeps
+    // value 0 and reports index 0 like the reference's initialisers
+    LaneStats s;
+    s.sum = sum;
+    const float vals[5] = {v_pk, v_rp, v_rn, v_ip, v_in};
+    const uint32_t codes[5] = {c_pk, c_rp, c_rn, c_ip, c_in};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint32_t c = codes[k];
+        const uint64_t tile = w.first + (uint64_t)(c / (2 * U)) * w.stride;
+        const uint32_t slot = (c % (2 * U)) >> 1, half = c & 1u;
+        const uint64_t idx = base_index + 2 * (tile * PAPR_TILE_F4 + (uint64_t)slot * PAPR_BLOCK + t) + half;
+        s.val[k] = vals[k];
+        s.idx[k] = vals[k] != 0.f ? idx : 0;
+    }
+    block_reduce_stats(s);
+    if (t == 0) {
+        papr_partial r;
+        r.sum = s.sum;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            r.idx[k] = s.idx[k];
+            r.val[k] = s.val[k];
+        }
+        r.pad = 0;
+        out[blockIdx.x] = r;
+    }
+}
+
+// Tail samples + merge of all workgroup partials, one workgroup, fixed order.
+// `tail` points at the first sample not covered by full tiles (may hold an odd
+// count; samples are read as scalar float pairs).
+__global__ __launch_bounds__(PAPR_BLOCK) void papr_stats_finalize(const float2 *__restrict__ tail, uint32_t tail_samples,
+                                                                   uint64_t tail_base_index,
+                                                                   const papr_partial *__restrict__ partials,
+                                                                   uint32_t npartials, papr_partial *__restrict__ result)
+{
+    LaneStats s;
+    s.sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        s.val[k] = 0.f;
+        s.idx[k] = 0;
+    }
+    // partials first (they precede the tail in file order), each thread a fixed subset
+    for (uint32_t r = threadIdx.x; r < npartials; r += PAPR_BLOCK) {
+        const papr_partial q = partials[r];
+        s.sum += q.sum;
+        if (beats<false>(q.val[0], q.idx[0], s.val[0], s.idx[0])) { s.val[0] = q.val[0]; s.idx[0] = q.idx[0]; }
+        if (beats<false>(q.val[1], q.idx[1], s.val[1], s.idx[1])) { s.val[1] = q.val[1]; s.idx[1] = q.idx[1]; }
+        if (beats<true>(q.val[2], q.idx[2], s.val[2], s.idx[2])) { s.val[2] = q.val[2]; s.idx[2] = q.idx[2]; }
+        if (beats<false>(q.val[3], q.idx[3], s.val[3], s.idx[3])) { s.val[3] = q.val[3]; s.idx[3] = q.idx[3]; }
+        if (beats<true>(q.val[4], q.idx[4], s.val[4], s.idx[4])) { s.val[4] = q.val[4]; s.idx[4] = q.idx[4]; }
+    }
+    for (uint32_t k = threadIdx.x; k < tail_samples; k += PAPR_BLOCK) {
+        const float2 x = tail[k];
+        lane_stats_sample(s, x.x, x.y, tail_base_index + k);
+    }
+    block_reduce_stats(s);
+    if (threadIdx.x == 0) {
+        papr_partial r;
+        r.sum = s.sum;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            r.idx[k] = s.idx[k];
+            r.val[k] = s.val[k];
+        }
+        r.pad = 0;
+        *result = r;
+    }
+}
+
+// Rare path: the double sum came out NaN, so some power value is NaN.  Find the
+// first such sample and the sign x86 gives its NaN (sign of I if I is NaN,
+// else sign of Q): key = index << 1 | sign, minimised.
+__global__ __launch_bounds__(PAPR_BLOCK) void papr_first_nan_kernel(const float2 *__restrict__ data, uint64_t nsamples,
+                                                                     uint64_t base_index,
+                                                                     unsigned long long *__restrict__ key)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * PAPR_BLOCK;
+    for (uint64_t k = (uint64_t)blockIdx.x * PAPR_BLOCK + threadIdx.x; k < nsamples; k += stride) {
+        const float2 x = data[k];
+        const float pw = power_of(x.x, x.y);
+        if (pw != pw) {
+            const uint32_t sign = (x.x != x.x ? __float_as_uint(x.x) : __float_as_uint(x.y)) >> 31;
+            atomicMin(key, (unsigned long long)(((base_index + k) << 1) | sign));
+        }
+    }
+}
+
+// =============================================================================
+// pass 2 — CCDF counting
+// =============================================================================
+// counts_above[j] = #{v > level[j]} is the suffix sum of a histogram over the
+// intervals between sorted thresholds, so each sample needs ONE bin index
+// k(v) = #{j : level[j] < v} instead of L compares.  For v >= 0 the IEEE bit
+// pattern is monotone in v, so with key_j = "smallest bit pattern whose float
+// is > level[j]", k(v) = #{j : key_j <= bits(v)} exactly, in integers.
+//
+// LUT form: cut the bit-pattern axis into cells of 2^shift patterns; the host
+// guarantees at most one key per cell.  lut[cell] = {keys in lower cells, the
+// key in this cell or 0xFFFFFFFF}, so k = lut.x + (bits >= lut.y): one 8-byte
+// LDS read and one compare per sample.  Bin 0 (below the lowest level, ~63 %
+// of Gaussian-like IQ) is never counted.  Counters are LDS-privatised per wave
+// (ds_add_u32) and flushed once per workgroup with 64-bit global atomics.
+
+namespace {
+
+struct CcdfShared {
+    uint2 *lut;       // ncells entries (LUT kernel) — or —
+    uint32_t *keys;   // nkeys entries (search kernel)
+    uint32_t *hist;   // copies * nbins
+};
+
+__device__ __forceinline__ void hist_flush(const uint32_t *hist, uint32_t nbins, uint32_t copies,
+                                           unsigned long long *__restrict__ ghist)
+{
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbins; b += PAPR_BLOCK) {
+        unsigned long long s = 0;
+        for (uint32_t c = 0; c < copies; c++)
+            s += hist[c * nbins + b];
+        if (s)
+            atomicAdd(&ghist[b], s);
+    }
+}
+
+__device__ __forceinline__ uint32_t lut_bin(uint32_t bits, const uint2 *lut, const papr_ccdf_params &P)
+{
+    const uint32_t rel = (bits >> P.shift) - P.cell_lo;  // wraps to huge below the table
+    uint32_t k;
+    if (rel < P.ncells) {
+        const uint2 e = lut[rel];
+        k = e.x + (bits >= e.y ? 1u : 0u);
+    } else {
+        // above the table but not NaN => above every level; below or NaN => 0
+        k = (bits - P.above_lo) <= P.above_span ? P.nkeys : 0u;
+    }
+    return k;
+}
+
+__device__ __forceinline__ uint32_t search_bin(uint32_t bits, const uint32_t *keys, const papr_ccdf_params &P)
+{
+    if (bits > 0x7F800000u)  // NaN (either sign): above nothing
+        return 0;
+    uint32_t lo = 0;
+    for (uint32_t step = P.search_step; step; step >>= 1) {
+        const uint32_t mid = lo + step;
+        if (mid <= P.nkeys && keys[mid - 1] <= bits)
+            lo = mid;
+    }
+    return lo;
+}
+
+}  // namespace
+
+template <bool NT, bool LUT>
+__global__ __launch_bounds__(PAPR_BLOCK) void papr_ccdf_kernel(const float4 *__restrict__ data, uint64_t ntiles, int map,
+                                                                const float2 *__restrict__ tail, uint32_t tail_samples,
+                                                                const uint32_t *__restrict__ table, papr_ccdf_params P,
+                                                                unsigned long long *__restrict__ ghist)
+{
+    constexpr int U = PAPR_UNROLL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t nbins = P.nkeys + 1;
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *hist = tab + P.table_words;
+
+    for (uint32_t k = threadIdx.x; k < P.table_words; k += PAPR_BLOCK)
+        tab[k] = table[k];
+    for (uint32_t k = threadIdx.x; k < P.copies * nbins; k += PAPR_BLOCK)
+        hist[k] = 0;
+    __syncthreads();
+
+    const uint2 *lut = reinterpret_cast<const uint2 *>(tab);
+    uint32_t *my = hist + ((threadIdx.x / kWave) % P.copies) * nbins;
+
+    auto count = [&](float pw) {
+        const uint32_t bits = __float_as_uint(pw);
+        const uint32_t k = LUT ? lut_bin(bits, lut, P) : search_bin(bits, tab, P);
+        if (k)
+            atomicAdd(&my[k], 1u);
+    };
+
+    const uint32_t t = threadIdx.x;
+    const TileWalk w = tile_walk(blockIdx.x, gridDim.x, ntiles, map);
+    const float4 *p = data + w.first * PAPR_TILE_F4 + t;
+    const uint64_t step = w.stride * PAPR_TILE_F4;
+    for (uint32_t it = 0; it < w.count; it++, p += step) {
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            x[u] = load16<NT>(p + u * PAPR_BLOCK);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            count(power_of(x[u].x, x[u].y));
+            count(power_of(x[u].z, x[u].w));
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1) {
+        for (uint32_t k = t; k < tail_samples; k += PAPR_BLOCK) {
+            const float2 x = tail[k];
+            count(power_of(x.x, x.y));
+        }
+    }
+    hist_flush(hist, nbins, P.copies, ghist);
+}
+
+// =============================================================================
+// synthetic IQ generator (include/papr_synth.h), two samples per lane per store
+// =============================================================================
+__global__ __launch_bounds__(PAPR_BLOCK) void papr_generate_kernel(float2 *__restrict__ out, uint64_t nsamples,
+                                                                    uint64_t first_index, papr_synth_spec spec)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * PAPR_BLOCK;
+    for (uint64_t k = (uint64_t)blockIdx.x * PAPR_BLOCK + threadIdx.x; k < nsamples; k += stride) {
+        float i, q;
+        papr_synth_sample(&spec, first_index + k, &i, &q);
+        out[k] = make_float2(i, q);
+    }
+}
+
+// ---- launch wrappers (called from papr_runtime.cpp through plain C++) ------
+
+void papr_launch_stats(hipStream_t st, int blocks, bool nt, const void *data, uint64_t ntiles, uint64_t base_index,
+                       int map, papr_partial *out)
+{
+    if (nt)
+        hipLaunchKernelGGL(papr_stats_kernel<true>, dim3(blocks), dim3(PAPR_BLOCK), 0, st, (const float4 *)data, ntiles,
+                           base_index, map, out);
+    else
+        hipLaunchKernelGGL(papr_stats_kernel<false>, dim3(blocks), dim3(PAPR_BLOCK), 0, st, (const float4 *)data, ntiles,
+                           base_index, map, out);
+}
+
+void papr_launch_stats_finalize(hipStream_t st, const void *tail, uint32_t tail_samples, uint64_t tail_base_index,
+                                const papr_partial *partials, uint32_t npartials, papr_partial *result)
+{
+    hipLaunchKernelGGL(papr_stats_finalize, dim3(1), dim3(PAPR_BLOCK), 0, st, (const float2 *)tail, tail_samples,
+                       tail_base_index, partials, npartials, result);
+}
+
+void papr_launch_first_nan(hipStream_t st, int blocks, const void *data, uint64_t nsamples, uint64_t base_index,
+                           unsigned long long *key)
+{
+    hipLaunchKernelGGL(papr_first_nan_kernel, dim3(blocks), dim3(PAPR_BLOCK), 0, st, (const float2 *)data, nsamples,
+                       base_index, key);
+}
+
+void papr_launch_ccdf(hipStream_t st, int blocks, bool nt, bool lut, size_t lds_bytes, const void *data, uint64_t ntiles,
+                      int map, const void *tail, uint32_t tail_samples, const uint32_t *table, const papr_ccdf_params &P,
+                      unsigned long long *ghist)
+{
+#define PAPR_CCDF_LAUNCH(NT, LUT)                                                                                   \
+    hipLaunchKernelGGL((papr_ccdf_kernel<NT, LUT>), dim3(blocks), dim3(PAPR_BLOCK), lds_bytes, st,                  \
+                       (const float4 *)data, ntiles, map, (const float2 *)tail, tail_samples, table, P, ghist)
+    if (nt && lut) PAPR_CCDF_LAUNCH(true, true);
+    else if (nt) PAPR_CCDF_LAUNCH(true, false);
+    else if (lut) PAPR_CCDF_LAUNCH(false, true);
+    else PAPR_CCDF_LAUNCH(false, false);
+#undef PAPR_CCDF_LAUNCH
+}
+
+void papr_launch_generate(hipStream_t st, int blocks, void *out, uint64_t nsamples, uint64_t first_index,
+                          const papr_synth_spec &spec)
+{
+    hipLaunchKernelGGL(papr_generate_kernel, dim3(blocks), dim3(PAPR_BLOCK), 0, st, (float2 *)out, nsamples, first_index,
+                       spec);
+}
+
+int papr_ccdf_max_dynamic_lds(void)
+{
+    // let one workgroup ask for more than the 64 KiB default when a level
+    // table is very large (160 KiB LDS per CU on gfx950)
+    static int done = 0;
+    if (!done) {
+        const int want = 160 * 1024 - 2048;
+        (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        done = 1;
+    }
+    return 160 * 1024 - 2048;
+}

@@ -1,0 +1,1092 @@
+// papr_runtime.cpp — host runtime behind the C ABI of include/papr_hip.h:
+// context/shard management, the file ingest engine (replaces the fread loops
+// of reference papr.c:100-101, 143-144, 175-176), launch sequencing for the two
+// passes and the exact threshold-table construction for pass 2.
+//
+// No CPU compute path: every sample is reduced on the GPU; the host only reads
+// file bytes into pinned buffers, builds the <= 16 K-entry level tables and
+// folds a handful of scalars.
+
+#include "papr_hip.h"
+#include "papr_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+
+constexpr uint64_t kChunkAlign = PAPR_TILE_SAMPLES;  // chunk boundaries stay tile aligned
+constexpr int kNumBuf = 3;
+constexpr int kMaxTimed = 4096;
+
+char g_open_error[256] = "";
+
+// ---- a tiny pool of file-reader threads -------------------------------------
+class ReaderPool {
+  public:
+    explicit ReaderPool(int n)
+    {
+        for (int i = 0; i < n; i++)
+            threads_.emplace_back([this] { run(); });
+    }
+    ~ReaderPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_)
+            t.join();
+    }
+    void submit(std::function<void()> job)
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            jobs_.push_back(std::move(job));
+            pending_++;
+        }
+        cv_.notify_one();
+    }
+    void wait_all()
+    {
+        std::unique_lock<std::mutex> g(m_);
+        done_cv_.wait(g, [this] { return pending_ == 0; });
+    }
+
+  private:
+    void run()
+    {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this] { return stop_ || !jobs_.empty(); });
+                if (stop_ && jobs_.empty())
+                    return;
+                job = std::move(jobs_.front());
+                jobs_.pop_front();
+            }
+            job();
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0)
+                    done_cv_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::deque<std::function<void()>> jobs_;
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    int pending_ = 0;
+    bool stop_ = false;
+};
+
+struct TimedLaunch {
+    hipEvent_t a, b;
+    int kind;  // 0 stats, 1 ccdf
+    uint64_t bytes;
+};
+
+}  // namespace
+
+struct papr_hip_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;     // compute
+    hipStream_t copy_stream = nullptr;
+    char name[128] = "";
+    char err[256] = "";
+    size_t hbm_budget = 0;
+
+    // shard
+    float *d_iq = nullptr;   // resident samples (owned or adopted)
+    bool owns_iq = false;
+    uint64_t cap = 0;        // capacity in samples
+    uint64_t n = 0;          // samples in the shard
+    uint64_t base = 0;       // global index of sample 0 of the shard
+    bool loaded = false;
+    bool resident = false;
+    uint32_t shard_flags = 0;
+
+    // file source (kept for re-streaming shards that exceed the HBM budget)
+    std::string path;
+    uint64_t file_first = 0;  // first sample of the range within the file
+    bool have_file_stats = false;
+    papr_stats file_stats;
+
+    // work buffers
+    papr_partial *d_partials = nullptr;
+    size_t partials_cap = 0;
+    papr_partial *h_result = nullptr;  // pinned, written by the finalize kernel
+    papr_partial *h_result_dev = nullptr;
+    unsigned long long *d_hist = nullptr;
+    unsigned long long *h_hist = nullptr;  // pinned
+    uint32_t *d_table = nullptr;
+    uint32_t *h_table = nullptr;           // pinned
+    size_t table_cap_words = 0;
+    unsigned long long *d_nan_key = nullptr;
+    float *d_tail = nullptr;               // streaming mode: the last chunk's sub-tile tail
+
+    // ingest
+    void *h_stage[kNumBuf] = {nullptr, nullptr, nullptr};
+    void *d_stage[kNumBuf] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_copy[kNumBuf] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_kernel[kNumBuf] = {nullptr, nullptr, nullptr};
+    size_t stage_bytes = 0;
+    ReaderPool *pool = nullptr;
+    int reader_threads = 0;
+
+    papr_hip_tuning tune{};
+    bool timing = false;
+    std::vector<TimedLaunch> timed;
+    size_t timed_used = 0;
+};
+
+namespace {
+
+int fail(papr_hip_ctx *ctx, int code, const char *fmt, ...)
+{
+    char *dst = ctx ? ctx->err : g_open_error;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 256, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, PAPR_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));      \
+    } while (0)
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+void parse_tune_env(papr_hip_tuning *t)
+{
+    const char *v = getenv("PAPR_HIP_TUNE");
+    if (!v)
+        return;
+    std::string s(v);
+    size_t pos = 0;
+    while (pos < s.size()) {
+        size_t end = s.find(',', pos);
+        if (end == std::string::npos)
+            end = s.size();
+        std::string kv = s.substr(pos, end - pos);
+        size_t eq = kv.find('=');
+        if (eq != std::string::npos) {
+            std::string k = kv.substr(0, eq);
+            int val = atoi(kv.c_str() + eq + 1);
+            if (k == "blocks") t->blocks = val;
+            else if (k == "map") t->map = val;
+            else if (k == "nt") t->nontemporal = val;
+            else if (k == "copies") t->hist_copies = val;
+            else if (k == "variant") t->variant = val;
+        }
+        pos = end + 1;
+    }
+}
+
+int pick_blocks(const papr_hip_ctx *ctx, uint64_t ntiles, int map)
+{
+    int blocks = ctx->tune.blocks > 0 ? ctx->tune.blocks : 2048;  // 8 workgroups on each of 256 CUs
+    if ((uint64_t)blocks > ntiles)
+        blocks = (int)std::max<uint64_t>(ntiles, 1);
+    if (map == PAPR_MAP_XCD_SPAN && blocks >= 8)
+        blocks &= ~7;
+    return blocks;
+}
+
+int effective_map(const papr_hip_ctx *ctx, int blocks)
+{
+    int map = ctx->tune.map;
+    if (map < 0 || map > 2)
+        map = 0;
+    if (map == PAPR_MAP_XCD_SPAN && (blocks % 8) != 0)
+        map = PAPR_MAP_GRID_STRIDE;
+    return map;
+}
+
+bool use_nt(const papr_hip_ctx *ctx)
+{
+    return ctx->tune.nontemporal != 0;
+}
+
+int ensure_partials(papr_hip_ctx *ctx, size_t count)
+{
+    if (count <= ctx->partials_cap)
+        return PAPR_OK;
+    if (ctx->d_partials)
+        HIPCHK(ctx, hipFree(ctx->d_partials));
+    ctx->d_partials = nullptr;
+    ctx->partials_cap = 0;
+    size_t cap = std::max<size_t>(count, 4096);
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_partials, cap * sizeof(papr_partial)));
+    ctx->partials_cap = cap;
+    return PAPR_OK;
+}
+
+int ensure_table(papr_hip_ctx *ctx, size_t words)
+{
+    if (words <= ctx->table_cap_words)
+        return PAPR_OK;
+    if (ctx->d_table) HIPCHK(ctx, hipFree(ctx->d_table));
+    if (ctx->h_table) HIPCHK(ctx, hipHostFree(ctx->h_table));
+    ctx->d_table = nullptr;
+    ctx->h_table = nullptr;
+    ctx->table_cap_words = 0;
+    size_t cap = std::max<size_t>(words, 16384);
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_table, cap * sizeof(uint32_t)));
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_table, cap * sizeof(uint32_t), hipHostMallocDefault));
+    ctx->table_cap_words = cap;
+    return PAPR_OK;
+}
+
+void release_shard(papr_hip_ctx *ctx)
+{
+    if (ctx->owns_iq && ctx->d_iq)
+        (void)hipFree(ctx->d_iq);
+    ctx->d_iq = nullptr;
+    ctx->owns_iq = false;
+    ctx->cap = ctx->n = ctx->base = 0;
+    ctx->loaded = ctx->resident = false;
+    ctx->have_file_stats = false;
+    ctx->shard_flags = 0;
+    ctx->path.clear();
+}
+
+int ensure_owned_capacity(papr_hip_ctx *ctx, uint64_t nsamples)
+{
+    if (ctx->d_iq && ctx->cap >= nsamples)
+        return PAPR_OK;
+    release_shard(ctx);
+    // one extra tile of slack keeps every 16-byte lane load in bounds
+    size_t bytes = (size_t)(nsamples + PAPR_TILE_SAMPLES) * 8;
+    hipError_t e = hipMalloc((void **)&ctx->d_iq, bytes);
+    if (e != hipSuccess) {
+        ctx->d_iq = nullptr;
+        return fail(ctx, PAPR_E_NOMEM, "hipMalloc(%zu bytes) for the shard failed: %s", bytes, hipGetErrorString(e));
+    }
+    ctx->owns_iq = true;
+    ctx->cap = nsamples;
+    return PAPR_OK;
+}
+
+void time_begin(papr_hip_ctx *ctx, int kind, uint64_t bytes)
+{
+    if (!ctx->timing || ctx->timed_used >= (size_t)kMaxTimed)
+        return;
+    if (ctx->timed_used == ctx->timed.size()) {
+        TimedLaunch t{};
+        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess)
+            return;
+        ctx->timed.push_back(t);
+    }
+    TimedLaunch &t = ctx->timed[ctx->timed_used];
+    t.kind = kind;
+    t.bytes = bytes;
+    (void)hipEventRecord(t.a, ctx->stream);
+}
+
+void time_end(papr_hip_ctx *ctx)
+{
+    if (!ctx->timing || ctx->timed_used >= ctx->timed.size() || ctx->timed_used >= (size_t)kMaxTimed)
+        return;
+    (void)hipEventRecord(ctx->timed[ctx->timed_used].b, ctx->stream);
+    ctx->timed_used++;
+}
+
+// ---- pass 1 over device-resident samples -------------------------------------
+// Launches the streaming kernel over the full tiles of [data, data + n) and
+// returns how many partial records it appended at d_partials + slot.
+int launch_stats_range(papr_hip_ctx *ctx, const float *data, uint64_t n, uint64_t base_index, size_t slot,
+                       int *nrecords)
+{
+    const uint64_t ntiles = n / PAPR_TILE_SAMPLES;
+    *nrecords = 0;
+    if (ntiles == 0)
+        return PAPR_OK;
+    int blocks = pick_blocks(ctx, ntiles, ctx->tune.map);
+    const int map = effective_map(ctx, blocks);
+    time_begin(ctx, 0, ntiles * (uint64_t)PAPR_TILE_SAMPLES * 8);
+    papr_launch_stats(ctx->stream, blocks, use_nt(ctx), data, ntiles, base_index, map, ctx->d_partials + slot);
+    time_end(ctx);
+    HIPCHK(ctx, hipGetLastError());
+    *nrecords = blocks;
+    return PAPR_OK;
+}
+
+void partial_to_stats(const papr_partial &r, uint64_t n, papr_stats *out)
+{
+    papr_stats_init(out);
+    out->sum = r.sum;
+    out->n = n;
+    out->peak = r.val[0];    out->peak_idx = r.idx[0];
+    out->re_pos = r.val[1];  out->re_pos_idx = r.idx[1];
+    out->re_neg = r.val[2];  out->re_neg_idx = r.idx[2];
+    out->im_pos = r.val[3];  out->im_pos_idx = r.idx[3];
+    out->im_neg = r.val[4];  out->im_neg_idx = r.idx[4];
+}
+
+void apply_nan_key(papr_stats *out, unsigned long long key)
+{
+    if (key == ~0ull)
+        return;
+    out->flags |= PAPR_FLAG_NAN;
+    out->nan_first_idx = key >> 1;
+    out->nan_first_neg = (uint32_t)(key & 1u);
+    // papr.c:104 — the running double sum takes the first NaN power (with the
+    // sign x86 propagates) and keeps it
+    out->sum = out->nan_first_neg ? -(double)NAN : (double)NAN;
+}
+
+// ---- pass 2 table construction ----------------------------------------------
+constexpr uint32_t kNever = 0xFFFFFFFFu;
+
+// smallest bit pattern of a non-negative float that is > t (see papr_kernels.hip)
+uint32_t level_key(float t)
+{
+    if (t != t)
+        return kNever;
+    if (t < 0.0f)
+        return 0u;
+    if (t == 0.0f)
+        return 1u;
+    uint32_t bits;
+    memcpy(&bits, &t, 4);
+    return bits >= 0x7F800000u ? kNever : bits + 1u;
+}
+
+struct CcdfPlan {
+    std::vector<uint32_t> keys;      // unique, ascending
+    std::vector<int> pos;            // per level: index into keys, or -1
+    papr_ccdf_params P{};
+    bool lut = false;
+    size_t lds_bytes = 0;
+};
+
+int plan_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, CcdfPlan *plan)
+{
+    plan->keys.clear();
+    plan->pos.assign(nlevels, -1);
+    std::vector<uint32_t> all(nlevels);
+    for (int j = 0; j < nlevels; j++) {
+        all[j] = level_key(levels[j]);
+        if (all[j] != kNever)
+            plan->keys.push_back(all[j]);
+    }
+    std::sort(plan->keys.begin(), plan->keys.end());
+    plan->keys.erase(std::unique(plan->keys.begin(), plan->keys.end()), plan->keys.end());
+    for (int j = 0; j < nlevels; j++)
+        if (all[j] != kNever)
+            plan->pos[j] = (int)(std::lower_bound(plan->keys.begin(), plan->keys.end(), all[j]) - plan->keys.begin());
+
+    const uint32_t m = (uint32_t)plan->keys.size();
+    papr_ccdf_params &P = plan->P;
+    memset(&P, 0, sizeof(P));
+    P.nkeys = m;
+    if (m == 0)
+        return PAPR_OK;
+    const uint32_t nbins = m + 1;
+    const size_t lds_cap = (size_t)papr_ccdf_max_dynamic_lds();
+    const int want_copies = ctx->tune.hist_copies > 0 ? std::min(ctx->tune.hist_copies, PAPR_BLOCK / 64) : PAPR_BLOCK / 64;
+
+    // LUT: the coarsest cell size that still isolates every key in its own cell
+    plan->lut = false;
+    if (plan->keys.front() >= 0x00800000u && ctx->tune.variant != 1) {  // keys in the normal-float range
+        for (int shift = 23; shift >= 8; shift--) {
+            const uint32_t c0 = plan->keys.front() >> shift, c1 = plan->keys.back() >> shift;
+            const uint64_t ncells = (uint64_t)c1 - c0 + 1;
+            if (ncells * 8 > 40 * 1024)
+                break;  // finer cells only get bigger
+            bool unique_cells = true;
+            for (uint32_t k = 1; k < m && unique_cells; k++)
+                unique_cells = (plan->keys[k] >> shift) != (plan->keys[k - 1] >> shift);
+            if (!unique_cells)
+                continue;
+            P.shift = (uint32_t)shift;
+            P.cell_lo = c0;
+            P.ncells = (uint32_t)ncells;
+            P.above_lo = (uint32_t)(((uint64_t)c1 + 1) << shift);
+            P.above_span = 0x7F800000u - P.above_lo;
+            P.table_words = 2 * P.ncells;
+            plan->lut = true;
+            break;
+        }
+    }
+    if (!plan->lut) {
+        P.table_words = m;
+        uint32_t step = 1;
+        while (step * 2 <= m)
+            step *= 2;
+        P.search_step = step;
+    }
+    // histogram copies: one per wave when it is cheap, fewer for huge tables
+    int copies = want_copies;
+    const size_t soft_cap = 20 * 1024;  // keeps 8 workgroups resident per CU
+    while (copies > 1 && (size_t)P.table_words * 4 + (size_t)copies * nbins * 4 > soft_cap)
+        copies--;
+    P.copies = (uint32_t)copies;
+    plan->lds_bytes = (size_t)P.table_words * 4 + (size_t)copies * nbins * 4;
+    if (plan->lds_bytes > lds_cap)
+        return fail(ctx, PAPR_E_LIMIT, "level table needs %zu bytes of LDS (limit %zu)", plan->lds_bytes, lds_cap);
+    return PAPR_OK;
+}
+
+int upload_ccdf_table(papr_hip_ctx *ctx, const CcdfPlan &plan)
+{
+    const papr_ccdf_params &P = plan.P;
+    int rc = ensure_table(ctx, P.table_words);
+    if (rc)
+        return rc;
+    if (plan.lut) {
+        // lut[cell] = {keys strictly below this cell, key inside this cell or never}
+        uint32_t k = 0;
+        for (uint32_t c = 0; c < P.ncells; c++) {
+            uint32_t in_cell = kNever;
+            const uint32_t below = k;
+            if (k < P.nkeys && (plan.keys[k] >> P.shift) == P.cell_lo + c)
+                in_cell = plan.keys[k++];
+            ctx->h_table[2 * c] = below;
+            ctx->h_table[2 * c + 1] = in_cell;
+        }
+    } else {
+        memcpy(ctx->h_table, plan.keys.data(), (size_t)P.nkeys * 4);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_table, ctx->h_table, (size_t)P.table_words * 4, hipMemcpyHostToDevice, ctx->stream));
+    return PAPR_OK;
+}
+
+int launch_ccdf_range(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *data, uint64_t n)
+{
+    const uint64_t ntiles = n / PAPR_TILE_SAMPLES;
+    const uint32_t tail = (uint32_t)(n - ntiles * PAPR_TILE_SAMPLES);
+    int blocks = pick_blocks(ctx, ntiles, ctx->tune.map);
+    const int map = effective_map(ctx, blocks);
+    time_begin(ctx, 1, n * 8);
+    papr_launch_ccdf(ctx->stream, blocks, use_nt(ctx), plan.lut, plan.lds_bytes, data, ntiles, map,
+                     data + 2 * ntiles * PAPR_TILE_SAMPLES, tail, ctx->d_table, plan.P, ctx->d_hist);
+    time_end(ctx);
+    HIPCHK(ctx, hipGetLastError());
+    return PAPR_OK;
+}
+
+// ---- file source ---------------------------------------------------------------
+struct FileSrc {
+    int fd = -1;
+    uint64_t size = 0, nfloats = 0, nsamples = 0;
+    bool odd = false;
+    float partner = 0.0f;  // Q of the phantom sample
+};
+
+// What the reference pairs a trailing lone float with (papr.c:102-103): the
+// float left in the same slot of its static 16384-float buffer by the previous
+// chunk (zero when there was none), with its low bytes overwritten by the
+// file's 1-3 stray tail bytes (glibc fread copies a partial element).
+int open_file_src(papr_hip_ctx *ctx, const char *path, FileSrc *fs)
+{
+    fs->fd = open(path, O_RDONLY);
+    if (fs->fd < 0)
+        return fail(ctx, PAPR_E_IO, "cannot open %s", path);
+    struct stat sb;
+    if (fstat(fs->fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        close(fs->fd);
+        fs->fd = -1;
+        return fail(ctx, PAPR_E_IO, "cannot stat %s (or not a regular file)", path);
+    }
+    fs->size = (uint64_t)sb.st_size;
+    fs->nfloats = fs->size / 4;
+    fs->odd = (fs->nfloats & 1u) != 0;
+    fs->nsamples = (fs->nfloats + 1) / 2;
+    fs->partner = 0.0f;
+    if (fs->odd) {
+        const uint64_t chunk = 16384;  // papr.c:30
+        const uint64_t nfull = fs->nfloats / chunk, rem = fs->nfloats % chunk;
+        unsigned char bytes[4] = {0, 0, 0, 0};
+        if (nfull >= 1) {
+            const uint64_t fidx = (nfull - 1) * chunk + rem;
+            if (pread(fs->fd, bytes, 4, (off_t)(fidx * 4)) != 4)
+                return fail(ctx, PAPR_E_IO, "short read in %s", path);
+        }
+        const uint64_t stray = fs->size % 4;
+        if (stray && pread(fs->fd, bytes, stray, (off_t)(fs->nfloats * 4)) != (ssize_t)stray)
+            return fail(ctx, PAPR_E_IO, "short read in %s", path);
+        memcpy(&fs->partner, bytes, 4);
+    }
+    return PAPR_OK;
+}
+
+// read logical samples [s0, s0 + cnt) into dst (8 bytes each)
+int read_samples(const FileSrc &fs, uint64_t s0, uint64_t cnt, unsigned char *dst)
+{
+    const uint64_t byte0 = s0 * 8, file_bytes = fs.nfloats * 4;
+    uint64_t want = cnt * 8;
+    if (byte0 + want > file_bytes)
+        want = file_bytes > byte0 ? file_bytes - byte0 : 0;
+    uint64_t done = 0;
+    while (done < want) {
+        ssize_t got = pread(fs.fd, dst + done, want - done, (off_t)(byte0 + done));
+        if (got <= 0)
+            return PAPR_E_IO;
+        done += (uint64_t)got;
+    }
+    if (fs.odd && s0 + cnt == fs.nsamples && cnt > 0)
+        memcpy(dst + cnt * 8 - 4, &fs.partner, 4);
+    return PAPR_OK;
+}
+
+int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage)
+{
+    if (!ctx->stage_bytes) {
+        size_t mb = (size_t)std::max(1, env_int("PAPR_CHUNK_MB", 64));
+        ctx->stage_bytes = (mb << 20) / (kChunkAlign * 8) * (kChunkAlign * 8);
+        if (!ctx->stage_bytes)
+            ctx->stage_bytes = kChunkAlign * 8;
+    }
+    for (int b = 0; b < kNumBuf; b++) {
+        if (!ctx->h_stage[b])
+            HIPCHK(ctx, hipHostMalloc(&ctx->h_stage[b], ctx->stage_bytes, hipHostMallocDefault));
+        if (!ctx->ev_copy[b])
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_copy[b], hipEventDisableTiming));
+        if (!ctx->ev_kernel[b])
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_kernel[b], hipEventDisableTiming));
+        if (need_device_stage && !ctx->d_stage[b])
+            HIPCHK(ctx, hipMalloc(&ctx->d_stage[b], ctx->stage_bytes + PAPR_TILE_SAMPLES * 8));
+    }
+    if (need_device_stage && !ctx->d_tail)
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_tail, PAPR_TILE_SAMPLES * 8));
+    if (!ctx->pool) {
+        int n = env_int("PAPR_READ_THREADS", 0);
+        if (n <= 0)
+            n = (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+        ctx->reader_threads = n;
+        ctx->pool = new ReaderPool(n);
+    }
+    return PAPR_OK;
+}
+
+enum StreamPass { PASS_LOAD_STATS, PASS_STREAM_STATS, PASS_STREAM_CCDF, PASS_STREAM_NAN };
+
+// Walk file samples [first, first + n) in pinned-buffer-sized chunks: parallel
+// pread into a pinned buffer, hipMemcpyAsync on the copy stream, then the pass
+// kernel on the compute stream as soon as that chunk has landed.  Three buffers
+// keep disk/page-cache reads, PCIe copies and kernels overlapped.
+int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t *nrecords_out)
+{
+    FileSrc fs;
+    int rc = open_file_src(ctx, ctx->path.c_str(), &fs);
+    if (rc)
+        return rc;
+    const bool to_resident = (pass == PASS_LOAD_STATS);
+    rc = ensure_ingest(ctx, !to_resident);
+    if (rc) {
+        close(fs.fd);
+        return rc;
+    }
+    const uint64_t chunk_samples = ctx->stage_bytes / 8;
+    const uint64_t nchunks = (ctx->n + chunk_samples - 1) / chunk_samples;
+    size_t records = 0;
+    if (pass == PASS_LOAD_STATS || pass == PASS_STREAM_STATS) {
+        const int per_chunk = ctx->tune.blocks > 0 ? ctx->tune.blocks : 2048;
+        rc = ensure_partials(ctx, (size_t)nchunks * per_chunk + 1);
+        if (rc) {
+            close(fs.fd);
+            return rc;
+        }
+    }
+    std::vector<int> read_rc(ctx->reader_threads, 0);
+    for (uint64_t c = 0; c < nchunks && rc == PAPR_OK; c++) {
+        const int b = (int)(c % kNumBuf);
+        const uint64_t s0 = c * chunk_samples;
+        const uint64_t cnt = std::min(chunk_samples, ctx->n - s0);
+        // the pinned buffer is free once its previous H2D copy has completed
+        if (c >= (uint64_t)kNumBuf)
+            HIPCHK(ctx, hipEventSynchronize(ctx->ev_copy[b]));
+        unsigned char *hbuf = (unsigned char *)ctx->h_stage[b];
+        const int nthr = ctx->reader_threads;
+        const uint64_t per = ((cnt + nthr - 1) / nthr + 511) & ~511ull;
+        std::fill(read_rc.begin(), read_rc.end(), 0);
+        for (int t = 0; t < nthr; t++) {
+            const uint64_t a = std::min<uint64_t>((uint64_t)t * per, cnt), e = std::min<uint64_t>(a + per, cnt);
+            if (e > a)
+                ctx->pool->submit([&fs, &read_rc, t, a, e, s0, hbuf, ctx] {
+                    read_rc[t] = read_samples(fs, ctx->file_first + s0 + a, e - a, hbuf + a * 8);
+                });
+        }
+        ctx->pool->wait_all();
+        for (int t = 0; t < nthr; t++)
+            if (read_rc[t]) {
+                close(fs.fd);
+                return fail(ctx, PAPR_E_IO, "read error in %s", ctx->path.c_str());
+            }
+        float *dst = to_resident ? ctx->d_iq + 2 * s0 : (float *)ctx->d_stage[b];
+        if (!to_resident && c >= (uint64_t)kNumBuf)
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_kernel[b], 0));
+        HIPCHK(ctx, hipMemcpyAsync(dst, hbuf, cnt * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_copy[b], ctx->copy_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copy[b], 0));
+        const bool last = (c + 1 == nchunks);
+        switch (pass) {
+        case PASS_LOAD_STATS:
+        case PASS_STREAM_STATS: {
+            int nrec = 0;
+            rc = launch_stats_range(ctx, dst, cnt, ctx->base + s0, records, &nrec);
+            records += (size_t)nrec;
+            if (rc == PAPR_OK && last && pass == PASS_STREAM_STATS) {
+                const uint64_t full = cnt / PAPR_TILE_SAMPLES * PAPR_TILE_SAMPLES;
+                if (cnt > full)
+                    HIPCHK(ctx, hipMemcpyAsync(ctx->d_tail, dst + 2 * full, (cnt - full) * 8, hipMemcpyDeviceToDevice,
+                                               ctx->stream));
+            }
+            break;
+        }
+        case PASS_STREAM_CCDF:
+            rc = launch_ccdf_range(ctx, *plan, dst, cnt);
+            break;
+        case PASS_STREAM_NAN:
+            papr_launch_first_nan(ctx->stream, 1024, dst, cnt, ctx->base + s0, ctx->d_nan_key);
+            if (hipGetLastError() != hipSuccess)
+                rc = fail(ctx, PAPR_E_HIP, "first-NaN kernel launch failed");
+            break;
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->ev_kernel[b], ctx->stream));
+    }
+    close(fs.fd);
+    if (nrecords_out)
+        *nrecords_out = records;
+    return rc;
+}
+
+// finalize pass 1: tail + merge of `records` partials, NaN bookkeeping
+int finish_stats(papr_hip_ctx *ctx, size_t records, const float *tail_ptr, uint32_t tail_samples, uint64_t tail_base,
+                 papr_stats *out)
+{
+    papr_launch_stats_finalize(ctx->stream, tail_ptr, tail_samples, tail_base, ctx->d_partials, (uint32_t)records,
+                               ctx->h_result_dev);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    partial_to_stats(*ctx->h_result, ctx->n, out);
+    out->flags |= ctx->shard_flags;
+    return PAPR_OK;
+}
+
+}  // namespace
+
+// =============================================================================
+// C ABI
+// =============================================================================
+extern "C" {
+
+int papr_hip_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        fail(nullptr, PAPR_E_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+        return e == hipErrorNoDevice ? 0 : PAPR_E_NO_DEVICE;
+    }
+    return n;
+}
+
+const char *papr_hip_last_error(const papr_hip_ctx *ctx)
+{
+    return ctx ? ctx->err : g_open_error;
+}
+
+int papr_hip_open(papr_hip_ctx **out, int device)
+{
+    if (!out)
+        return PAPR_E_ARG;
+    *out = nullptr;
+    int n = papr_hip_device_count();
+    if (n <= 0)
+        return fail(nullptr, PAPR_E_NO_DEVICE, "no HIP device available (libpaprhip has no CPU fallback)");
+    if (device < 0 || device >= n)
+        return fail(nullptr, PAPR_E_NO_DEVICE, "device %d out of range (%d visible)", device, n);
+    papr_hip_ctx *ctx = new (std::nothrow) papr_hip_ctx();
+    if (!ctx)
+        return PAPR_E_NOMEM;
+    ctx->device = device;
+    auto bail = [&](int code) {
+        snprintf(g_open_error, sizeof(g_open_error), "%s", ctx->err);
+        papr_hip_close(ctx);
+        return code;
+    };
+#define OPENCHK(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            fail(ctx, PAPR_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));                  \
+            return bail(PAPR_E_HIP);                                                               \
+        }                                                                                          \
+    } while (0)
+    OPENCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    OPENCHK(hipGetDeviceProperties(&prop, device));
+    snprintf(ctx->name, sizeof(ctx->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    OPENCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    OPENCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    OPENCHK(hipHostMalloc((void **)&ctx->h_result, sizeof(papr_partial), hipHostMallocMapped));
+    OPENCHK(hipHostGetDevicePointer((void **)&ctx->h_result_dev, ctx->h_result, 0));
+    OPENCHK(hipMalloc((void **)&ctx->d_hist, (PAPR_HIP_MAX_LEVELS + 1) * sizeof(unsigned long long)));
+    OPENCHK(hipHostMalloc((void **)&ctx->h_hist, (PAPR_HIP_MAX_LEVELS + 1) * sizeof(unsigned long long),
+                          hipHostMallocDefault));
+    OPENCHK(hipMalloc((void **)&ctx->d_nan_key, sizeof(unsigned long long)));
+#undef OPENCHK
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+        free_b = (size_t)64 << 30;
+    const int budget_mb = env_int("PAPR_HBM_BUDGET_MB", 0);
+    ctx->hbm_budget = budget_mb > 0 ? (size_t)budget_mb << 20 : free_b / 10 * 9;
+    ctx->tune.nontemporal = 1;
+    parse_tune_env(&ctx->tune);
+    if (ensure_partials(ctx, 4096) != PAPR_OK)
+        return bail(PAPR_E_HIP);
+    (void)papr_ccdf_max_dynamic_lds();
+    *out = ctx;
+    return PAPR_OK;
+}
+
+void papr_hip_close(papr_hip_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    if (ctx->device >= 0)
+        (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    delete ctx->pool;
+    release_shard(ctx);
+    for (auto &t : ctx->timed) {
+        (void)hipEventDestroy(t.a);
+        (void)hipEventDestroy(t.b);
+    }
+    for (int b = 0; b < kNumBuf; b++) {
+        if (ctx->h_stage[b]) (void)hipHostFree(ctx->h_stage[b]);
+        if (ctx->d_stage[b]) (void)hipFree(ctx->d_stage[b]);
+        if (ctx->ev_copy[b]) (void)hipEventDestroy(ctx->ev_copy[b]);
+        if (ctx->ev_kernel[b]) (void)hipEventDestroy(ctx->ev_kernel[b]);
+    }
+    if (ctx->d_tail) (void)hipFree(ctx->d_tail);
+    if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->h_result) (void)hipHostFree(ctx->h_result);
+    if (ctx->d_hist) (void)hipFree(ctx->d_hist);
+    if (ctx->h_hist) (void)hipHostFree(ctx->h_hist);
+    if (ctx->d_table) (void)hipFree(ctx->d_table);
+    if (ctx->h_table) (void)hipHostFree(ctx->h_table);
+    if (ctx->d_nan_key) (void)hipFree(ctx->d_nan_key);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    delete ctx;
+}
+
+int papr_hip_device_name(const papr_hip_ctx *ctx, char *buf, int buflen)
+{
+    if (!ctx || !buf || buflen <= 0)
+        return PAPR_E_ARG;
+    snprintf(buf, (size_t)buflen, "%s", ctx->name);
+    return PAPR_OK;
+}
+
+int papr_hip_set_tuning(papr_hip_ctx *ctx, const papr_hip_tuning *t)
+{
+    if (!ctx || !t)
+        return PAPR_E_ARG;
+    if (t->blocks < 0 || t->blocks > 65536 || t->map < 0 || t->map > 2 || t->hist_copies < 0)
+        return fail(ctx, PAPR_E_ARG, "bad tuning values");
+    ctx->tune = *t;
+    return PAPR_OK;
+}
+
+int papr_hip_set_timing(papr_hip_ctx *ctx, int enabled)
+{
+    if (!ctx)
+        return PAPR_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->timing = enabled != 0;
+    ctx->timed_used = 0;
+    return PAPR_OK;
+}
+
+int papr_hip_get_timing(papr_hip_ctx *ctx, papr_hip_timing *out)
+{
+    if (!ctx || !out)
+        return PAPR_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memset(out, 0, sizeof(*out));
+    for (size_t k = 0; k < ctx->timed_used; k++) {
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->timed[k].a, ctx->timed[k].b));
+        if (ctx->timed[k].kind == 0) {
+            out->stats_ms += ms;
+            out->stats_launches++;
+            out->stats_bytes += ctx->timed[k].bytes;
+        } else {
+            out->ccdf_ms += ms;
+            out->ccdf_launches++;
+            out->ccdf_bytes += ctx->timed[k].bytes;
+        }
+    }
+    return PAPR_OK;
+}
+
+// ---- shard residency ------------------------------------------------------------
+
+int papr_hip_adopt(papr_hip_ctx *ctx, void *device_iq, uint64_t nsamples, uint64_t base_index)
+{
+    if (!ctx || (!device_iq && nsamples))
+        return PAPR_E_ARG;
+    if (((uintptr_t)device_iq & 15u) != 0)
+        return fail(ctx, PAPR_E_ARG, "adopted device memory must be 16-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    release_shard(ctx);
+    ctx->d_iq = (float *)device_iq;
+    ctx->owns_iq = false;
+    ctx->cap = ctx->n = nsamples;
+    ctx->base = base_index;
+    ctx->loaded = ctx->resident = true;
+    return PAPR_OK;
+}
+
+int papr_hip_upload(papr_hip_ctx *ctx, const float *iq, uint64_t nsamples, uint64_t base_index)
+{
+    if (!ctx || (!iq && nsamples))
+        return PAPR_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->owns_iq)
+        release_shard(ctx);
+    int rc = ensure_owned_capacity(ctx, nsamples);
+    if (rc)
+        return rc;
+    if (nsamples)
+        HIPCHK(ctx, hipMemcpy(ctx->d_iq, iq, nsamples * 8, hipMemcpyHostToDevice));
+    ctx->n = nsamples;
+    ctx->base = base_index;
+    ctx->loaded = ctx->resident = true;
+    ctx->have_file_stats = false;
+    ctx->shard_flags = 0;
+    ctx->path.clear();
+    return PAPR_OK;
+}
+
+int papr_hip_generate(papr_hip_ctx *ctx, const papr_synth_spec *spec, uint64_t first_index, uint64_t nsamples)
+{
+    if (!ctx || !spec)
+        return PAPR_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!(ctx->d_iq && ctx->cap >= nsamples)) {
+        int rc = ensure_owned_capacity(ctx, nsamples);
+        if (rc)
+            return rc;
+    }
+    if (nsamples) {
+        const int blocks = (int)std::min<uint64_t>((nsamples + PAPR_BLOCK - 1) / PAPR_BLOCK, 8192);
+        papr_launch_generate(ctx->stream, blocks, ctx->d_iq, nsamples, first_index, *spec);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->n = nsamples;
+    ctx->base = first_index;
+    ctx->loaded = ctx->resident = true;
+    ctx->have_file_stats = false;
+    ctx->shard_flags = 0;
+    ctx->path.clear();
+    return PAPR_OK;
+}
+
+int papr_hip_download(papr_hip_ctx *ctx, float *iq, uint64_t first, uint64_t nsamples)
+{
+    if (!ctx || (!iq && nsamples))
+        return PAPR_E_ARG;
+    if (!ctx->loaded || !ctx->resident)
+        return fail(ctx, PAPR_E_STATE, "no resident shard to download from");
+    if (first + nsamples > ctx->n)
+        return fail(ctx, PAPR_E_ARG, "download range past the end of the shard");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (nsamples)
+        HIPCHK(ctx, hipMemcpy(iq, ctx->d_iq + 2 * first, nsamples * 8, hipMemcpyDeviceToHost));
+    return PAPR_OK;
+}
+
+int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples)
+{
+    if (!ctx || !path)
+        return PAPR_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    FileSrc fs;
+    int rc = open_file_src(ctx, path, &fs);
+    if (rc)
+        return rc;
+    close(fs.fd);
+    if (first_sample > fs.nsamples)
+        return fail(ctx, PAPR_E_ARG, "first_sample %llu is past the end of %s (%llu samples)",
+                    (unsigned long long)first_sample, path, (unsigned long long)fs.nsamples);
+    if (nsamples == UINT64_MAX || first_sample + nsamples > fs.nsamples)
+        nsamples = fs.nsamples - first_sample;
+
+    const bool fits = (nsamples + PAPR_TILE_SAMPLES) * 8 <= ctx->hbm_budget;
+    if (!ctx->owns_iq || !fits)
+        release_shard(ctx);
+    if (fits) {
+        rc = ensure_owned_capacity(ctx, nsamples);
+        if (rc)
+            return rc;
+    }
+    ctx->path = path;
+    ctx->file_first = first_sample;
+    ctx->n = nsamples;
+    ctx->base = first_sample;
+    ctx->resident = fits;
+    ctx->loaded = true;
+    ctx->have_file_stats = false;
+    ctx->shard_flags = (fs.odd && first_sample + nsamples == fs.nsamples && nsamples > 0) ? PAPR_FLAG_ODD_TAIL : 0;
+
+    // pass 1 rides along with the ingest
+    size_t records = 0;
+    rc = stream_file(ctx, fits ? PASS_LOAD_STATS : PASS_STREAM_STATS, nullptr, &records);
+    if (rc) {
+        ctx->loaded = false;
+        return rc;
+    }
+    const uint64_t chunk_samples = ctx->stage_bytes / 8;
+    const uint64_t last_cnt = nsamples ? nsamples - (nsamples - 1) / chunk_samples * chunk_samples : 0;
+    const uint32_t tail = (uint32_t)(last_cnt % PAPR_TILE_SAMPLES);
+    const float *tail_ptr = fits ? ctx->d_iq + 2 * (nsamples - tail) : ctx->d_tail;
+    papr_stats st;
+    rc = finish_stats(ctx, records, tail_ptr, tail, ctx->base + nsamples - tail, &st);
+    if (rc) {
+        ctx->loaded = false;
+        return rc;
+    }
+    if (std::isnan(st.sum)) {
+        unsigned long long key = ~0ull;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_nan_key, &key, 8, hipMemcpyHostToDevice, ctx->stream));
+        if (fits) {
+            papr_launch_first_nan(ctx->stream, 1024, ctx->d_iq, ctx->n, ctx->base, ctx->d_nan_key);
+            HIPCHK(ctx, hipGetLastError());
+        } else {
+            rc = stream_file(ctx, PASS_STREAM_NAN, nullptr, nullptr);
+            if (rc)
+                return rc;
+        }
+        HIPCHK(ctx, hipMemcpyAsync(&key, ctx->d_nan_key, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        apply_nan_key(&st, key);
+    }
+    ctx->file_stats = st;
+    ctx->have_file_stats = true;
+    return PAPR_OK;
+}
+
+// ---- pass 1 ---------------------------------------------------------------------
+
+int papr_hip_stats(papr_hip_ctx *ctx, papr_stats *out)
+{
+    if (!ctx || !out)
+        return PAPR_E_ARG;
+    if (!ctx->loaded)
+        return fail(ctx, PAPR_E_STATE, "papr_hip_stats called before a shard was loaded");
+    if (ctx->have_file_stats) {  // computed while the file streamed in
+        *out = ctx->file_stats;
+        return PAPR_OK;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int nrec = 0;
+    int rc = ensure_partials(ctx, (size_t)(ctx->tune.blocks > 0 ? ctx->tune.blocks : 2048) + 1);
+    if (rc)
+        return rc;
+    rc = launch_stats_range(ctx, ctx->d_iq, ctx->n, ctx->base, 0, &nrec);
+    if (rc)
+        return rc;
+    const uint32_t tail = (uint32_t)(ctx->n % PAPR_TILE_SAMPLES);
+    rc = finish_stats(ctx, (size_t)nrec, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->base + ctx->n - tail, out);
+    if (rc)
+        return rc;
+    if (std::isnan(out->sum)) {
+        unsigned long long key = ~0ull;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_nan_key, &key, 8, hipMemcpyHostToDevice, ctx->stream));
+        papr_launch_first_nan(ctx->stream, 1024, ctx->d_iq, ctx->n, ctx->base, ctx->d_nan_key);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(&key, ctx->d_nan_key, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        apply_nan_key(out, key);
+    }
+    return PAPR_OK;
+}
+
+// ---- pass 2 ---------------------------------------------------------------------
+
+int papr_hip_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above)
+{
+    if (!ctx || nlevels < 0 || (nlevels && (!levels || !counts_above)))
+        return PAPR_E_ARG;
+    if (!ctx->loaded)
+        return fail(ctx, PAPR_E_STATE, "papr_hip_ccdf called before a shard was loaded");
+    if (nlevels > PAPR_HIP_MAX_LEVELS)
+        return fail(ctx, PAPR_E_LIMIT, "%d levels exceeds PAPR_HIP_MAX_LEVELS (%d)", nlevels, PAPR_HIP_MAX_LEVELS);
+    if (nlevels == 0)
+        return PAPR_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CcdfPlan plan;
+    int rc = plan_ccdf(ctx, levels, nlevels, &plan);
+    if (rc)
+        return rc;
+    const uint32_t m = plan.P.nkeys;
+    if (m == 0 || ctx->n == 0) {
+        for (int j = 0; j < nlevels; j++)
+            counts_above[j] = 0;
+        return PAPR_OK;
+    }
+    rc = upload_ccdf_table(ctx, plan);
+    if (rc)
+        return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_hist, 0, (size_t)(m + 1) * sizeof(unsigned long long), ctx->stream));
+    if (ctx->resident)
+        rc = launch_ccdf_range(ctx, plan, ctx->d_iq, ctx->n);
+    else
+        rc = stream_file(ctx, PASS_STREAM_CCDF, &plan, nullptr);
+    if (rc)
+        return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(m + 1) * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // samples above unique key i = everything binned at i + 1 or higher
+    std::vector<uint64_t> above(m);
+    uint64_t run = 0;
+    for (uint32_t i = m; i-- > 0;) {
+        run += ctx->h_hist[i + 1];
+        above[i] = run;
+    }
+    for (int j = 0; j < nlevels; j++)
+        counts_above[j] = plan.pos[j] >= 0 ? above[plan.pos[j]] : 0;
+    return PAPR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+/*
+ * papr — PAPR + CCDF calculator for gr_complex .cfile IQ captures, MI355X build.
+ *
+ * Drop-in for the `papr` tool of drmpeg/dtv-utils: same command line
+ * (`papr <infile>` / `papr -g <infile>`, reference papr.c:53-98), same stdout
+ * (papr.c:132-135,154-161 / 186-190), same stderr messages and exit codes.
+ * What differs is where the two passes over the samples run: the file is cut
+ * into one contiguous shard per GPU, each shard is streamed into HBM and
+ * reduced there by libpaprhip (include/papr_hip.h), and this program only folds
+ * the per-GPU records, evaluates the libm scalars and prints.
+ *
+ * Environment (argv grammar is left untouched on purpose):
+ *   PAPR_GPUS=N    use N GPUs (default: one per 2 GiB of input, at most all visible)
+ *   PAPR_STATS=1   one JSON line with sizes and timings on stderr
+ * There is no CPU fallback: without a usable GPU the program exits 254.
+ */
+#define _FILE_OFFSET_BITS 64
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "papr_hip.h"
+
+#define MAX_GPUS 64
+#define SHARD_ALIGN 8192ull /* samples: one reference fread chunk (papr.c:30), a multiple of the kernel tile */
+
+typedef struct shard {
+    papr_hip_ctx *ctx;
+    int device;
+    const char *path;
+    uint64_t first, count;
+    papr_stats stats;
+    const float *levels;
+    int nlevels;
+    uint64_t *counts;
+    int rc;
+} shard;
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void usage(void)
+{
+    fprintf(stderr, "usage: papr -g <infile>\n");
+    fprintf(stderr, "Options:\n");
+    fprintf(stderr, "\tg = graph suitable output\n");
+}
+
+static void *pass1_thread(void *arg)
+{
+    shard *s = (shard *)arg;
+    s->rc = papr_hip_load_file(s->ctx, s->path, s->first, s->count);
+    if (s->rc == PAPR_OK)
+        s->rc = papr_hip_stats(s->ctx, &s->stats);
+    return NULL;
+}
+
+static void *pass2_thread(void *arg)
+{
+    shard *s = (shard *)arg;
+    s->rc = papr_hip_ccdf(s->ctx, s->levels, s->nlevels, s->counts);
+    return NULL;
+}
+
+static int run_all(shard *sh, int n, void *(*fn)(void *))
+{
+    pthread_t th[MAX_GPUS];
+    for (int g = 1; g < n; g++)
+        pthread_create(&th[g], NULL, fn, &sh[g]);
+    fn(&sh[0]);
+    for (int g = 1; g < n; g++)
+        pthread_join(th[g], NULL);
+    for (int g = 0; g < n; g++)
+        if (sh[g].rc != PAPR_OK) {
+            fprintf(stderr, "papr: GPU %d: %s (code %d)\n", sh[g].device, papr_hip_last_error(sh[g].ctx), sh[g].rc);
+            return sh[g].rc;
+        }
+    return PAPR_OK;
+}
+
+int main(int argc, char **argv)
+{
+    int graph = 0;
+    const char *path;
+
+    /* ---- command line, as the reference parses it (papr.c:53-98) ---- */
+    if (argc != 2 && argc != 3) {
+        usage();
+        exit(-1);
+    }
+    if (argc == 2) {
+        path = argv[1];
+    } else {
+        if (argv[1][0] != '-') {
+            usage();
+            exit(-1);
+        }
+        for (size_t i = 1; i < strlen(argv[1]); i++) {
+            if (argv[1][i] == 'g' || argv[1][i] == 'G')
+                graph = 1;
+            else
+                fprintf(stderr, "Unsupported Option: %c\n", argv[1][i]);
+        }
+        path = argv[2];
+    }
+    FILE *probe = fopen(path, "r");
+    if (probe == NULL) {
+        fprintf(stderr, "Cannot open bitstream file <%s>\n", path);
+        exit(-1);
+    }
+    fclose(probe);
+
+    const double t0 = now_s();
+    uint64_t nsamples = 0;
+    if (papr_file_samples(path, &nsamples) != PAPR_OK) {
+        fprintf(stderr, "Cannot open bitstream file <%s>\n", path);
+        exit(-1);
+    }
+
+    /* ---- one shard per GPU ---- */
+    int visible = papr_hip_device_count();
+    if (visible <= 0) {
+        fprintf(stderr, "papr: no usable GPU (%s); this build has no CPU path\n", papr_hip_last_error(NULL));
+        return 254;
+    }
+    if (visible > MAX_GPUS)
+        visible = MAX_GPUS;
+    int ngpu;
+    const char *env = getenv("PAPR_GPUS");
+    if (env && atoi(env) > 0) {
+        ngpu = atoi(env);
+    } else {
+        const uint64_t per_gpu = (2ull << 30) / 8; /* samples in 2 GiB */
+        ngpu = (int)((nsamples + per_gpu - 1) / per_gpu);
+        if (ngpu < 1)
+            ngpu = 1;
+    }
+    if (ngpu > visible)
+        ngpu = visible;
+
+    shard sh[MAX_GPUS];
+    memset(sh, 0, sizeof(sh));
+    uint64_t per = (nsamples + (uint64_t)ngpu - 1) / (uint64_t)ngpu;
+    per = (per + SHARD_ALIGN - 1) / SHARD_ALIGN * SHARD_ALIGN;
+    int used = 0;
+    for (int g = 0; g < ngpu; g++) {
+        const uint64_t first = (uint64_t)g * per;
+        if (g > 0 && first >= nsamples)
+            break;
+        sh[g].device = g;
+        sh[g].path = path;
+        sh[g].first = first;
+        sh[g].count = first + per > nsamples ? nsamples - first : per;
+        int rc = papr_hip_open(&sh[g].ctx, g);
+        if (rc != PAPR_OK) {
+            fprintf(stderr, "papr: cannot open GPU %d: %s\n", g, papr_hip_last_error(NULL));
+            return 254;
+        }
+        used++;
+    }
+    ngpu = used;
+
+    /* ---- pass 1 on every shard, then fold in file order (papr.c:100-129) ---- */
+    if (run_all(sh, ngpu, pass1_thread) != PAPR_OK)
+        return 253;
+    const double t1 = now_s();
+    papr_stats total;
+    papr_stats_init(&total);
+    for (int g = 0; g < ngpu; g++)
+        papr_stats_merge(&total, &sh[g].stats);
+
+    /* ---- host scalars (papr.c:131-141 / 164-173) ---- */
+    double mean;
+    float papr;
+    int nlevels = papr_levels(&total, graph, &mean, &papr, NULL, 0);
+    if (nlevels > PAPR_HIP_MAX_LEVELS) {
+        fprintf(stderr, "papr: %d levels exceed the supported maximum of %d\n", nlevels, PAPR_HIP_MAX_LEVELS);
+        return 253;
+    }
+    float *level = (float *)malloc((size_t)(nlevels + 1) * sizeof(float));
+    uint64_t *count = (uint64_t *)calloc((size_t)(nlevels + 1), sizeof(uint64_t));
+    papr_levels(&total, graph, NULL, NULL, level, nlevels);
+
+    /* ---- pass 2 on every shard, counts summed (papr.c:142-153 / 174-185) ---- */
+    for (int g = 0; g < ngpu; g++) {
+        sh[g].levels = level;
+        sh[g].nlevels = nlevels;
+        sh[g].counts = (uint64_t *)calloc((size_t)(nlevels + 1), sizeof(uint64_t));
+    }
+    if (nlevels > 0 && run_all(sh, ngpu, pass2_thread) != PAPR_OK)
+        return 253;
+    for (int g = 0; g < ngpu; g++)
+        for (int j = 0; j < nlevels; j++)
+            count[j] += sh[g].counts[j];
+    const double t2 = now_s();
+
+    /* ---- output, byte for byte the reference's (papr.c:132-135,154-161 / 186-190) ---- */
+    const long long offset = (long long)total.n;
+    if (!graph) {
+        printf("Peak magnitude = %f\n", sqrt(total.peak));
+        printf("average power = %lf, peak power = %f @ %lld\n\n", mean, total.peak, (long long)total.peak_idx * 8);
+        printf("Maximum PAPR = %f\n", papr);
+        for (int j = 0; j < nlevels; j++)
+            printf("percentage above %d dB = %0.8f\n", j, ((float)(long long)count[j] / (float)offset) * 100.0);
+        printf("\n");
+        printf("peak real positive = %f, peak imaginary positive = %f\n", total.re_pos, total.im_pos);
+        printf("peak real negative = %f, peak imaginary negative = %f\n\n", total.re_neg, total.im_neg);
+        printf("peak real positive @ %lld, peak imaginary positive @ %lld\n", (long long)total.re_pos_idx * 8,
+               ((long long)total.im_pos_idx * 8) + 1);
+        printf("peak real negative @ %lld, peak imaginary negative @ %lld\n", (long long)total.re_neg_idx * 8,
+               ((long long)total.im_neg_idx * 8) + 1);
+    } else {
+        for (int j = 0; j < nlevels; j++)
+            printf("%0.8f\n", ((float)(long long)count[j] / (float)offset) * 100.0);
+    }
+    fflush(stdout);
+
+    env = getenv("PAPR_STATS");
+    if (env && atoi(env) > 0) {
+        const double t3 = now_s();
+        fprintf(stderr,
+                "{\"samples\": %llu, \"bytes\": %llu, \"gpus\": %d, \"levels\": %d, \"ingest_pass1_s\": %.6f, "
+                "\"pass2_s\": %.6f, \"total_s\": %.6f, \"msamples_per_s\": %.3f}\n",
+                (unsigned long long)nsamples, (unsigned long long)nsamples * 8, ngpu, nlevels, t1 - t0, t2 - t1, t3 - t0,
+                (double)nsamples / (t3 - t0) / 1e6);
+    }
+
+    for (int g = 0; g < ngpu; g++) {
+        free(sh[g].counts);
+        papr_hip_close(sh[g].ctx);
+    }
+    free(count);
+    free(level);
+    return 0;
+}

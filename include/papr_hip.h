@@ -1,0 +1,161 @@
+/*
+ * papr_hip.h — C ABI of libpaprhip.so, the MI355X (gfx950) implementation of
+ * the `papr` IQ power-statistics hot path.
+ *
+ * The reference (drmpeg/dtv-utils papr.c) has no library or FFI surface: the
+ * whole path is inline in main().  Each entry point below therefore names the
+ * block of reference lines it replaces; INTEGRATION.md shows the edit a
+ * maintainer of papr.c would make to call them.
+ *
+ *   reference papr.c                          this ABI
+ *   ----------------------------------------  ---------------------------------
+ *   :100-101 fread loop (pass 1 ingest)       papr_hip_load_file / _upload / _adopt
+ *   :102-128 power, sum, peak, extrema        papr_hip_stats  (+ papr_stats_merge
+ *                                             across shards / GPUs)
+ *   :131,134,136-141 / :164-173 mean, PAPR,   papr_levels      (host scalar, libm)
+ *            level table
+ *   :142-153 / :174-185 rewind + O(N*L)       papr_hip_ccdf
+ *            threshold counting
+ *   :132-135,154-161 / :186-190 printing      stays in the caller (host/papr_main.c)
+ *
+ * Conventions: plain C types only (no HIP/torch types); every int-returning
+ * call returns PAPR_OK (0) or a negative PAPR_E_* code and never throws or
+ * aborts; papr_hip_last_error() gives the detail text.  One context drives one
+ * GPU and owns one "shard": a contiguous range of the file's sample axis,
+ * resident in HBM (or re-streamed from the file when it exceeds the HBM
+ * budget).  A context is not thread-safe; different contexts may be driven
+ * from different threads or processes.  Sample indices are global 64-bit
+ * sample numbers (byte offset / 8), exactly the `offset` of papr.c:37.
+ *
+ * There is no CPU fallback: without a usable GPU papr_hip_open fails.
+ */
+#ifndef PAPR_HIP_H
+#define PAPR_HIP_H
+
+#include <stdint.h>
+
+#include "papr_synth.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAPR_HIP_ABI_VERSION 1
+
+enum {
+    PAPR_OK = 0,
+    PAPR_E_NO_DEVICE = -1, /* no usable GPU / bad device ordinal */
+    PAPR_E_HIP = -2,       /* a HIP runtime call failed (see last_error) */
+    PAPR_E_ARG = -3,       /* bad argument */
+    PAPR_E_NOMEM = -4,     /* host or device allocation failed */
+    PAPR_E_IO = -5,        /* file could not be opened / read */
+    PAPR_E_STATE = -6,     /* call made before a shard was loaded */
+    PAPR_E_LIMIT = -7      /* level table larger than PAPR_HIP_MAX_LEVELS */
+};
+
+#define PAPR_HIP_MAX_LEVELS 16384
+#define PAPR_NO_INDEX UINT64_MAX
+
+/* Result of pass 1 over one shard, or the merge of several (papr.c:37-49).
+ * Trackers follow the reference exactly: all start at 0.0f with strict
+ * compares, so the first occurrence of an extreme wins, NaN never wins, and a
+ * tracker that never fires reports value 0 at index 0. */
+typedef struct papr_stats {
+    double sum;            /* sum of float powers, accumulated in double */
+    uint64_t n;            /* samples in the shard (incl. the odd-tail phantom sample) */
+    uint64_t peak_idx;     /* global index of the first max-power sample */
+    uint64_t re_pos_idx, re_neg_idx, im_pos_idx, im_neg_idx;
+    uint64_t nan_first_idx;/* first sample whose power is NaN, or PAPR_NO_INDEX */
+    float peak;            /* max power (I*I + Q*Q in float, products rounded separately) */
+    float re_pos, re_neg, im_pos, im_neg;
+    uint32_t nan_first_neg;/* sign bit of that first NaN power as x86 would produce it */
+    uint32_t flags;        /* PAPR_FLAG_* */
+    uint32_t reserved;
+} papr_stats;
+
+#define PAPR_FLAG_NAN 1u      /* some power value was NaN */
+#define PAPR_FLAG_ODD_TAIL 2u /* the shard ends with the reference's phantom sample */
+
+/* Kernel timing accumulated since the last reset (HIP events on the context's
+ * stream, kernel launches only). */
+typedef struct papr_hip_timing {
+    double stats_ms;  uint64_t stats_launches;  uint64_t stats_bytes;
+    double ccdf_ms;   uint64_t ccdf_launches;   uint64_t ccdf_bytes;
+} papr_hip_timing;
+
+/* Launch geometry knobs (0 = built-in default); also settable with the
+ * PAPR_HIP_TUNE environment variable, e.g. "blocks=2048,map=1,nt=1". */
+typedef struct papr_hip_tuning {
+    int blocks;       /* workgroups per launch */
+    int map;          /* 0 grid-stride tiles, 1 contiguous span per workgroup, 2 contiguous span per XCD */
+    int nontemporal;  /* 1 = nontemporal loads */
+    int hist_copies;  /* LDS histogram copies per workgroup (1..waves) */
+    int variant;      /* kernel variant selector */
+} papr_hip_tuning;
+
+typedef struct papr_hip_ctx papr_hip_ctx;
+
+/* ---- context ------------------------------------------------------------ */
+int papr_hip_abi_version(void);
+int papr_hip_device_count(void);                       /* >= 0, or a PAPR_E_* code */
+int papr_hip_open(papr_hip_ctx **ctx, int device);
+void papr_hip_close(papr_hip_ctx *ctx);
+const char *papr_hip_last_error(const papr_hip_ctx *ctx); /* ctx may be NULL: last open error */
+int papr_hip_device_name(const papr_hip_ctx *ctx, char *buf, int buflen);
+int papr_hip_set_tuning(papr_hip_ctx *ctx, const papr_hip_tuning *t);
+int papr_hip_set_timing(papr_hip_ctx *ctx, int enabled); /* also resets the counters */
+int papr_hip_get_timing(papr_hip_ctx *ctx, papr_hip_timing *out);
+
+/* ---- shard residency (replaces the fread ingest, papr.c:100-101,143-144) -- */
+
+/* Number of samples the reference would count for this file (papr.c:127
+ * `offset`), including the phantom sample of an odd float count. */
+int papr_file_samples(const char *path, uint64_t *nsamples);
+
+/* Load samples [first_sample, first_sample + nsamples) of the file into this
+ * context's shard; nsamples = UINT64_MAX means "to the end".  The reference's
+ * odd-float / stray-byte tail behaviour (papr.c:102-103 with the stale static
+ * buffer) is reproduced when the range includes the file's last sample.  The
+ * copy to HBM is double-buffered and overlapped with the pass-1 kernel. */
+int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples);
+
+/* Copy nsamples IQ pairs from host memory into the shard. */
+int papr_hip_upload(papr_hip_ctx *ctx, const float *iq, uint64_t nsamples, uint64_t base_index);
+
+/* Use caller-owned device memory (16-byte aligned, on this context's GPU) as
+ * the shard, without copying.  The memory must stay valid until the next
+ * load/upload/adopt/close. */
+int papr_hip_adopt(papr_hip_ctx *ctx, void *device_iq, uint64_t nsamples, uint64_t base_index);
+
+/* Fill the shard with synthetic samples [first_index, first_index+nsamples)
+ * of the stream defined by include/papr_synth.h.  If a buffer of at least that
+ * size was adopted it is filled in place, otherwise the context allocates. */
+int papr_hip_generate(papr_hip_ctx *ctx, const papr_synth_spec *spec, uint64_t first_index, uint64_t nsamples);
+
+/* Copy shard samples [first, first+nsamples) (shard-relative) back to the host (tests). */
+int papr_hip_download(papr_hip_ctx *ctx, float *iq, uint64_t first, uint64_t nsamples);
+
+/* ---- pass 1 (papr.c:102-128) -------------------------------------------- */
+int papr_hip_stats(papr_hip_ctx *ctx, papr_stats *out);
+
+/* Host-side, GPU-free helpers. `merge` folds the stats of the NEXT shard in
+ * file order into `acc` (sum added in call order; extrema by value, then by
+ * smaller index). */
+void papr_stats_init(papr_stats *s);
+void papr_stats_merge(papr_stats *acc, const papr_stats *next);
+
+/* Mean, PAPR and the level table exactly as papr.c:131,134,136-141 (graph=0)
+ * or :164-173 (graph!=0) compute them.  Returns the number of levels L (>= 0)
+ * and writes min(L, cap) of them; a NaN PAPR gives 0 levels (papr.c:138 with
+ * (int)NaN = INT_MIN on x86-64). */
+int papr_levels(const papr_stats *total, int graph, double *mean, float *papr, float *levels, int cap);
+
+/* ---- pass 2 (papr.c:143-153 / 175-185) ---------------------------------- */
+/* counts_above[j] = number of shard samples whose power is > levels[j]
+ * (float compare, strict, NaN never counts).  Levels may be any floats. */
+int papr_hip_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAPR_HIP_H */

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/: small .cfile fixtures + the REAL reference's stdout.
+
+Run in the build container only (needs /root/reference): it compiles the
+reference papr.c where it lies into oracle/_ref/papr (oracle/Makefile `ref`),
+writes every fixture below, and records the reference's stdout/stderr/exit code
+for `papr <f>` and `papr -g <f>` in manifest.json + <name>.default.txt /
+<name>.graph.txt.  Fixtures are data only (inputs and expected outputs); no
+reference source is stored.
+
+    python tests/golden/make_golden.py            # small fixtures
+    python tests/golden/make_golden.py --big FILE # also record the 10 GiB bench
+                                                  # workload from a file made by
+                                                  # `oracle/mkcfile FILE 1342177280 --spike`
+"""
+import argparse
+import json
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+ORACLE = os.path.join(ROOT, "oracle")
+MKCFILE = os.path.join(ORACLE, "mkcfile")
+REF = os.path.join(ORACLE, "_ref", "papr")
+
+
+def mk(name, n, *extra):
+    subprocess.check_call([MKCFILE, os.path.join(HERE, name + ".cfile"), str(n), *map(str, extra)])
+
+
+def raw(name, floats=(), tail=b""):
+    with open(os.path.join(HERE, name + ".cfile"), "wb") as f:
+        f.write(np.asarray(floats, dtype=np.float32).tobytes())
+        f.write(tail)
+
+
+def build_fixtures():
+    # hand-specified vectors from SURVEY.md section 8(a)
+    raw("k8", [1, 0, 0, 1, 1, 1, 2, 0, 0, -2, -1, -1, 3, 4, 0.5, 0.5])
+    tie = [0.1] * 20
+    tie[6], tie[7], tie[14], tie[15] = 2, 1, 1, 2
+    raw("tie", tie)
+    raw("one", [3.0])
+    raw("oneb", [3.0], b"\xa5")
+    raw("empty")
+    raw("zeros", [0.0] * 2000)
+    raw("negzero", [-0.0, 0.0, 0.0, -0.0] * 100)
+    # BASELINE.json configs[0]: 1 MiB synthetic gr_complex
+    mk("g1m", 131072)
+    mk("spike20k", 20000, "--spike")
+    # tail quirks (papr.c:102-103 with the stale static buffer)
+    mk("odd", 20000, "--extra-floats", 1)
+    mk("oddb", 20000, "--extra-floats", 1, "--extra-bytes", 3)
+    mk("evenb", 5000, "--extra-bytes", 2)
+    mk("chunk3odd", 24576, "--extra-floats", 1, "--extra-bytes", 2)
+    mk("chunk1exact", 8192)
+    mk("chunk1plus", 8192, "--extra-floats", 1)
+    mk("tileplus", 4096 * 3 + 17)
+    # non-finite samples
+    mk("nan_i", 5000, "--set", 100, "nan", 1)
+    mk("nan_q_neg", 5000, "--set", 100, 1, "-nan")
+    mk("nan_both", 5000, "--set", 100, "nan", "-nan", "--set", 200, "-nan", "nan")
+    mk("nan_order", 5000, "--set", 4500, "nan", 1, "--set", 4097, 1, "-nan")
+    mk("inf", 5000, "--set", 100, "inf", 1)
+    mk("inf_nan", 5000, "--set", 100, "inf", 1, "--set", 50, "-nan", 0)
+    mk("overflow", 5000, "--scale", 1e14)
+    # amplitude scales: GNU Radio tx scaling, denormal powers
+    mk("tiny", 50000, "--scale", 3.3717e-8)
+    mk("denorm", 5000, "--scale", 4e-26)
+    # ties: equal peaks / equal extrema in different places, first must win
+    mk("ties", 30000, "--set", 29000, 5, 5, "--set", 123, 5, 5, "--set", 7000, -5, -5, "--set", 6999, -5, -5)
+    # a signalling NaN bit pattern in I and in Q
+    snan = np.frombuffer(struct.pack("<I", 0x7FA00001), dtype=np.float32)[0]
+    base = np.fromfile(os.path.join(HERE, "nan_i.cfile"), dtype=np.float32).copy()
+    base[2 * 100] = 0.25
+    raw_bits = base.view(np.uint32)
+    raw_bits[2 * 300] = 0x7FA00001
+    raw_bits[2 * 17 + 1] = 0xFFA00001
+    raw("snan", base)
+    del snan
+
+
+def record(path, graph):
+    args = [REF] + (["-g"] if graph else []) + [path]
+    p = subprocess.run(args, capture_output=True)
+    return p.returncode, p.stdout, p.stderr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", help="path of the 10 GiB spike workload file (optional)")
+    args = ap.parse_args()
+    subprocess.check_call(["make", "-C", ORACLE, "mkcfile", "ref"])
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/papr missing: this script needs /root/reference")
+    manifest_path = os.path.join(HERE, "manifest.json")
+    manifest = {}
+    if os.path.exists(manifest_path):
+        manifest = json.load(open(manifest_path))
+    build_fixtures()
+    names = sorted(f[:-6] for f in os.listdir(HERE) if f.endswith(".cfile"))
+    for name in names:
+        path = os.path.join(HERE, name + ".cfile")
+        entry = {"bytes": os.path.getsize(path)}
+        for graph, tag in ((False, "default"), (True, "graph")):
+            rc, out, err = record(path, graph)
+            with open(os.path.join(HERE, f"{name}.{tag}.txt"), "wb") as f:
+                f.write(out)
+            entry[tag] = {"rc": rc, "stderr": err.decode(), "lines": out.count(b"\n")}
+        manifest[name] = entry
+    if args.big:
+        # BASELINE.json configs[1] / configs[2]: the full-size bench workload.
+        # Only the reference's stdout is committed; the GPU test regenerates
+        # the same stream on the device from include/papr_synth.h.
+        entry = {"bytes": os.path.getsize(args.big), "synthetic": "spike", "nsamples": os.path.getsize(args.big) // 8}
+        for graph, tag in ((False, "default"), (True, "graph")):
+            rc, out, err = record(args.big, graph)
+            with open(os.path.join(HERE, f"big_spike10g.{tag}.txt"), "wb") as f:
+                f.write(out)
+            entry[tag] = {"rc": rc, "stderr": err.decode(), "lines": out.count(b"\n")}
+        manifest["big_spike10g"] = entry
+    json.dump(manifest, open(manifest_path, "w"), indent=1, sort_keys=True)
+    print(f"recorded {len(names)} fixtures")
+
+
+if __name__ == "__main__":
+    main()
