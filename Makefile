@@ -10,7 +10,7 @@ LIB     := $(PKG)/libpaprhip.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-result
 CFLAGS  := -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
 
-all: lib cli oracle
+all: lib cli oracle tools
 
 lib: $(LIB)
 
@@ -35,8 +35,14 @@ bin/papr: $(PKG)/host/papr_main.c include/papr_hip.h $(LIB)
 oracle:
 	$(MAKE) -C oracle all
 
+tools: bin/hbm_read_probe
+
+bin/hbm_read_probe: tools/hbm_read_probe.hip
+	@mkdir -p bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Wno-unused-result $< -o $@
+
 clean:
-	rm -f $(CSRC)/*.o $(LIB) bin/papr
+	rm -f $(CSRC)/*.o $(LIB) bin/papr bin/hbm_read_probe
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib cli oracle clean
+.PHONY: all lib cli oracle tools clean

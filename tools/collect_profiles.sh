@@ -1,0 +1,29 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats of the bench
+# command, the PMC passes (each on its own, with --kernel-trace only), the HBM read
+# probe and plain bench lines.  Writes gpurun_out/<tag>/; tools/summarize_profiles.py
+# then distils what is committed under profiles/.
+#   gpurun -- 'bash tools/collect_profiles.sh r01'
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py"
+$R/bin/hbm_read_probe 10 10 > $O/hbm_read_probe.txt 2>&1
+$B --steps 20 --warmup 3                > $O/bench_default.json 2> $O/bench_default.err
+$B --steps 20 --warmup 3 --mode graph   > $O/bench_graph.json   2> $O/bench_graph.err
+for MODE in default graph; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$MODE -- \
+      $B --steps 20 --warmup 3 --mode $MODE --no-cpu-baseline > $O/stats_$MODE.json 2> $O/stats_$MODE.err
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$MODE -- \
+      $B --steps 3 --warmup 1 --mode $MODE --no-cpu-baseline > $O/pmc_fetch_$MODE.json 2> $O/pmc_fetch_$MODE.err
+done
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv \
+    -d $O/pmc_tcc -- $B --steps 3 --warmup 1 --mode graph --no-cpu-baseline > $O/pmc_tcc.json 2> $O/pmc_tcc.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+    --kernel-trace --output-format csv -d $O/pmc_sq -- $B --steps 3 --warmup 1 --mode graph --no-cpu-baseline > $O/pmc_sq.json 2> $O/pmc_sq.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-trace --output-format csv \
+    -d $O/pmc_grbm -- $B --steps 3 --warmup 1 --mode graph --no-cpu-baseline > $O/pmc_grbm.json 2> $O/pmc_grbm.err
+ls $O

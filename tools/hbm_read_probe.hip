@@ -1,0 +1,97 @@
+// hbm_read_probe — empirical HBM read ceiling of this GPU for the access
+// pattern the papr kernels use (16 B per lane, PAPR_UNROLL loads in flight,
+// grid-stride tiles), with the arithmetic stripped to one xor per dword.
+// Measurement tool only; prints one JSON line per configuration.
+//
+//   hipcc --offload-arch=gfx950 -O3 tools/hbm_read_probe.hip -o bin/hbm_read_probe
+//   bin/hbm_read_probe [GiB=10] [rounds=10]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int BLOCK, int U, bool NT>
+__global__ __launch_bounds__(BLOCK) void read_kernel(const f32x4 *__restrict__ data, uint64_t ntiles, unsigned *out)
+{
+    const f32x4 *p = data + (uint64_t)blockIdx.x * (BLOCK * U) + threadIdx.x;
+    const uint64_t step = (uint64_t)gridDim.x * (BLOCK * U);
+    unsigned acc = 0;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x, p += step) {
+        f32x4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            x[u] = NT ? __builtin_nontemporal_load(p + u * BLOCK) : p[u * BLOCK];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            u32x4 b = __builtin_bit_cast(u32x4, x[u]);
+            acc ^= b.x ^ b.y ^ b.z ^ b.w;
+        }
+    }
+    if (acc == 0x12345678u)
+        out[0] = acc;  // keeps the loads alive
+}
+
+__global__ void fill_kernel(unsigned *p, uint64_t n)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x)
+        p[k] = (unsigned)(k * 2654435761u) >> 3;
+}
+
+template <int BLOCK, int U, bool NT>
+static void run(const char *tag, const void *d, size_t bytes, unsigned *out, int blocks, int rounds)
+{
+    const uint64_t ntiles = bytes / ((size_t)BLOCK * U * 16);
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    std::vector<float> ms;
+    for (int r = 0; r < rounds + 2; r++) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((read_kernel<BLOCK, U, NT>), dim3(blocks), dim3(BLOCK), 0, 0, (const f32x4 *)d, ntiles, out);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float t;
+        hipEventElapsedTime(&t, a, b);
+        if (r >= 2)
+            ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    const double used = (double)ntiles * BLOCK * U * 16;
+    printf("{\"probe\": \"%s\", \"block\": %d, \"unroll\": %d, \"nt\": %d, \"blocks\": %d, \"median_ms\": %.4f, "
+           "\"min_ms\": %.4f, \"GB/s_median\": %.1f, \"GB/s_best\": %.1f}\n",
+           tag, BLOCK, U, (int)NT, blocks, ms[ms.size() / 2], ms[0], used / ms[ms.size() / 2] / 1e6, used / ms[0] / 1e6);
+    fflush(stdout);
+}
+
+int main(int argc, char **argv)
+{
+    const double gib = argc > 1 ? atof(argv[1]) : 10.0;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 10;
+    const size_t bytes = (size_t)(gib * (1 << 30)) / 65536 * 65536;
+    void *d;
+    unsigned *out;
+    if (hipMalloc(&d, bytes) != hipSuccess || hipMalloc((void **)&out, 4) != hipSuccess) {
+        fprintf(stderr, "hipMalloc failed\n");
+        return 1;
+    }
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (unsigned *)d, bytes / 4);
+    hipDeviceSynchronize();
+    for (int blocks : {512, 1024, 2048, 4096}) {
+        run<256, 8, true>("read", d, bytes, out, blocks, rounds);
+        run<256, 8, false>("read", d, bytes, out, blocks, rounds);
+    }
+    run<256, 4, true>("read", d, bytes, out, 2048, rounds);
+    run<256, 16, true>("read", d, bytes, out, 1024, rounds);
+    run<512, 8, true>("read", d, bytes, out, 1024, rounds);
+    run<1024, 4, true>("read", d, bytes, out, 512, rounds);
+    run<1024, 8, true>("read", d, bytes, out, 256, rounds);
+    hipFree(d);
+    hipFree(out);
+    return 0;
+}
