@@ -92,8 +92,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the papr product has no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ   # under torchrun even N=1 goes through RCCL
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     pkg = ge.load_package()
@@ -118,7 +120,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -133,7 +135,7 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = gpu.timing()
     gpu.set_timing(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -170,7 +172,7 @@ def main():
                        "mode": args.mode, "samples_per_gpu": per_gpu, "samples_total": total,
                        "levels": int(result["table"].size), "papr_db": round(float(result["papr"]), 6),
                        "sharding": f"sample axis, {world} contiguous shard(s)",
-                       "exchange": "RCCL all-gather(stats) + all-reduce(counts)" if world > 1 else "none"},
+                       "exchange": "RCCL all-gather(stats) + all-reduce(counts)" if use_dist else "none"},
             "roofline": {"bound": "hbm", "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": per_gpu * 8,
@@ -193,7 +195,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     gpu.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -94,8 +94,10 @@ class Timing(C.Structure):
 
 
 class Tuning(C.Structure):
-    _fields_ = [("blocks", C.c_int), ("map", C.c_int), ("nontemporal", C.c_int),
-                ("hist_copies", C.c_int), ("variant", C.c_int)]
+    """papr_hip_tuning; *_variant fields hold (variant id + 1), 0 = built-in default."""
+    _fields_ = [("stats_blocks", C.c_int), ("stats_variant", C.c_int), ("stats_map", C.c_int),
+                ("ccdf_blocks", C.c_int), ("ccdf_variant", C.c_int), ("ccdf_map", C.c_int),
+                ("nontemporal", C.c_int), ("hist_copies", C.c_int), ("flags", C.c_int)]
 
 
 class PaprError(RuntimeError):
@@ -225,8 +227,17 @@ class PaprHip:
         self._chk(self._L.papr_hip_device_name(self._ctx, buf, 160), "papr_hip_device_name")
         return buf.value.decode()
 
-    def set_tuning(self, blocks=0, map=0, nontemporal=1, hist_copies=0, variant=0):
-        t = Tuning(blocks, map, nontemporal, hist_copies, variant)
+    def set_tuning(self, blocks=0, variant=None, map=None, nontemporal=1, hist_copies=0, flags=0,
+                   stats_blocks=None, stats_variant=None, stats_map=None,
+                   ccdf_blocks=None, ccdf_variant=None, ccdf_map=None):
+        """`blocks` / `variant` / `map` apply to both passes unless the per-pass value is given;
+        None (0 for blocks) keeps each pass's built-in default."""
+        def pick(per_pass, both):
+            v = both if per_pass is None else per_pass
+            return 0 if v is None else v + 1
+        t = Tuning(blocks if stats_blocks is None else stats_blocks, pick(stats_variant, variant),
+                   pick(stats_map, map), blocks if ccdf_blocks is None else ccdf_blocks,
+                   pick(ccdf_variant, variant), pick(ccdf_map, map), 1 if nontemporal else 2, hist_copies, flags)
         self._chk(self._L.papr_hip_set_tuning(self._ctx, C.byref(t)), "papr_hip_set_tuning")
 
     def set_timing(self, enabled: bool):

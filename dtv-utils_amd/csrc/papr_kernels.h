@@ -9,13 +9,14 @@
 
 #include "papr_synth.h"
 
-// Launch geometry.  A workgroup is 4 wave64s; one loop iteration of a
-// workgroup consumes one tile = PAPR_UNROLL coalesced 4 KiB rows
-// (256 lanes x 16 B), i.e. 32 KiB = 4096 IQ samples.
+// Launch geometry.  The default streaming variant uses 4-wave workgroups whose
+// loop iteration consumes one tile = 8 coalesced 4 KiB rows (256 lanes x 16 B),
+// i.e. 32 KiB = 4096 IQ samples; other (block, unroll) variants exist for
+// measurement (papr_variant_geometry).  PAPR_BLOCK is the workgroup size of
+// the small helper kernels; PAPR_TILE_SAMPLES_MAX bounds every variant's tile
+// (shard slack, chunk alignment).
 #define PAPR_BLOCK 256
-#define PAPR_UNROLL 8
-#define PAPR_TILE_F4 (PAPR_BLOCK * PAPR_UNROLL) /* float4 (2-sample) slots per tile */
-#define PAPR_TILE_SAMPLES (2 * PAPR_TILE_F4)
+#define PAPR_TILE_SAMPLES_MAX 8192
 
 #define PAPR_MAP_GRID_STRIDE 0
 #define PAPR_MAP_BLOCK_SPAN 1
@@ -42,15 +43,16 @@ struct papr_ccdf_params {
     uint32_t search_step; // search: largest power of two <= nkeys
 };
 
-void papr_launch_stats(hipStream_t st, int blocks, bool nt, const void *data, uint64_t ntiles, uint64_t base_index,
-                       int map, papr_partial *out);
+int papr_variant_geometry(int variant, int *block, int *unroll); /* 0, or -1 for an unknown variant */
+void papr_launch_stats(hipStream_t st, int variant, int blocks, bool nt, const void *data, uint64_t ntiles,
+                       uint64_t base_index, int map, papr_partial *out);
 void papr_launch_stats_finalize(hipStream_t st, const void *tail, uint32_t tail_samples, uint64_t tail_base_index,
                                 const papr_partial *partials, uint32_t npartials, papr_partial *result);
 void papr_launch_first_nan(hipStream_t st, int blocks, const void *data, uint64_t nsamples, uint64_t base_index,
                            unsigned long long *key);
-void papr_launch_ccdf(hipStream_t st, int blocks, bool nt, bool lut, size_t lds_bytes, const void *data, uint64_t ntiles,
-                      int map, const void *tail, uint32_t tail_samples, const uint32_t *table, const papr_ccdf_params &P,
-                      unsigned long long *ghist);
+void papr_launch_ccdf(hipStream_t st, int variant, int blocks, bool nt, bool lut, size_t lds_bytes, const void *data,
+                      uint64_t ntiles, int map, const void *tail, uint32_t tail_samples, const uint32_t *table,
+                      const papr_ccdf_params &P, unsigned long long *ghist);
 void papr_launch_generate(hipStream_t st, int blocks, void *out, uint64_t nsamples, uint64_t first_index,
                           const papr_synth_spec &spec);
 int papr_ccdf_max_dynamic_lds(void);

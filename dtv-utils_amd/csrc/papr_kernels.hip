@@ -26,7 +26,6 @@
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kWaves = PAPR_BLOCK / kWave;
 
 __device__ __forceinline__ float power_of(float re, float im)
 {
@@ -143,6 +142,7 @@ __device__ __forceinline__ void lane_stats_sample(LaneStats &s, float re, float 
 }
 
 // Workgroup-wide merge of LaneStats; the result is valid in thread 0.
+template <int kWaves>
 __device__ __forceinline__ void block_reduce_stats(LaneStats &s)
 {
     __shared__ double sh_sum[kWaves];
@@ -183,80 +183,116 @@ __device__ __forceinline__ void block_reduce_stats(LaneStats &s)
 // =============================================================================
 // pass 1 — power, double sum, first-index peak and component extrema
 // =============================================================================
-// One launch covers `ntiles` full tiles (PAPR_TILE_SAMPLES samples each) of
+// One launch covers `ntiles` full tiles (2 * BLOCK * U samples each) of
 // `data`; the < 1 tile remainder of the shard is folded in by
 // papr_stats_finalize.  Per lane: U independent 16-byte loads are issued
-// before any arithmetic (U KiB in flight per wave), then 2U samples are folded
-// into a double partial sum and five (value, 32-bit sample code) trackers.  The
-// 32-bit code (iteration * 2U + slot) is expanded to a 64-bit global sample
-// index once, after the loop.
-template <bool NT>
-__global__ __launch_bounds__(PAPR_BLOCK) void papr_stats_kernel(const float4 *__restrict__ data, uint64_t ntiles,
-                                                                 uint64_t base_index, int map,
-                                                                 papr_partial *__restrict__ out)
+// before any arithmetic (U KiB in flight per wave; with PIPE the next tile's
+// loads are issued before the current tile is reduced), then 2U samples are
+// folded into a double partial sum and five (value, 32-bit sample code)
+// trackers.  The code (iteration * 2U + slot) is expanded to a 64-bit global
+// sample index once, after the loop.
+
+namespace {
+
+struct StatsRegs {
+    double sum;
+    float v_pk, v_rp, v_rn, v_ip, v_in;
+    uint32_t c_pk, c_rp, c_rn, c_ip, c_in;
+};
+
+template <int U>
+__device__ __forceinline__ void stats_fold(StatsRegs &r, const float4 (&x)[U], uint32_t code)
 {
-    constexpr int U = PAPR_UNROLL;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const float p0 = power_of(x[u].x, x[u].y);
+        const float p1 = power_of(x[u].z, x[u].w);
+        r.sum += (double)p0;
+        r.sum += (double)p1;
+        const uint32_t c0 = code + 2 * u, c1 = c0 + 1;
+        track<false>(p0, c0, r.v_pk, r.c_pk);
+        track<false>(p1, c1, r.v_pk, r.c_pk);
+        track<false>(x[u].x, c0, r.v_rp, r.c_rp);
+        track<false>(x[u].z, c1, r.v_rp, r.c_rp);
+        track<true>(x[u].x, c0, r.v_rn, r.c_rn);
+        track<true>(x[u].z, c1, r.v_rn, r.c_rn);
+        track<false>(x[u].y, c0, r.v_ip, r.c_ip);
+        track<false>(x[u].w, c1, r.v_ip, r.c_ip);
+        track<true>(x[u].y, c0, r.v_in, r.c_in);
+        track<true>(x[u].w, c1, r.v_in, r.c_in);
+    }
+}
+
+template <int BLOCK, int U, bool NT>
+__device__ __forceinline__ void load_tile(float4 (&x)[U], const float4 *p)
+{
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        x[u] = load16<NT>(p + u * BLOCK);
+}
+
+}  // namespace
+
+template <int BLOCK, int U, bool NT, bool PIPE>
+__global__ __launch_bounds__(BLOCK) void papr_stats_kernel(const float4 *__restrict__ data, uint64_t ntiles,
+                                                            uint64_t base_index, int map,
+                                                            papr_partial *__restrict__ out)
+{
+    constexpr uint64_t TILE_F4 = (uint64_t)BLOCK * U;
     const uint32_t t = threadIdx.x;
     const TileWalk w = tile_walk(blockIdx.x, gridDim.x, ntiles, map);
 
-    double sum = 0.0;
-    float v_pk = 0.f, v_rp = 0.f, v_rn = 0.f, v_ip = 0.f, v_in = 0.f;
-    uint32_t c_pk = 0, c_rp = 0, c_rn = 0, c_ip = 0, c_in = 0;
-
-    const float4 *p = data + w.first * PAPR_TILE_F4 + t;
-    const uint64_t step = w.stride * PAPR_TILE_F4;
+    StatsRegs r = {0.0, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0, 0};
+    const float4 *p = data + w.first * TILE_F4 + t;
+    const uint64_t step = w.stride * TILE_F4;
     uint32_t code = 0;
-    for (uint32_t it = 0; it < w.count; it++, p += step, code += 2 * U) {
-        float4 x[U];
+    if constexpr (PIPE) {
+        float4 cur[U], nxt[U];
+        if (w.count)
+            load_tile<BLOCK, U, NT>(cur, p);
+        for (uint32_t it = 0; it < w.count; it++, code += 2 * U) {
+            p += step;
+            if (it + 1 < w.count)
+                load_tile<BLOCK, U, NT>(nxt, p);
+            stats_fold<U>(r, cur, code);
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            x[u] = load16<NT>(p + u * PAPR_BLOCK);
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const float p0 = power_of(x[u].x, x[u].y);
-            const float p1 = power_of(x[u].z, x[u].w);
-            sum += (double)p0;
-            sum += (double)p1;
-            const uint32_t c0 = code + 2 * u, c1 = c0 + 1;
-            track<false>(p0, c0, v_pk, c_pk);
-            track<false>(p1, c1, v_pk, c_pk);
-            track<false>(x[u].x, c0, v_rp, c_rp);
-            track<false>(x[u].z, c1, v_rp, c_rp);
-            track<true>(x[u].x, c0, v_rn, c_rn);
-            track<true>(x[u].z, c1, v_rn, c_rn);
-            track<false>(x[u].y, c0, v_ip, c_ip);
-            track<false>(x[u].w, c1, v_ip, c_ip);
-            track<true>(x[u].y, c0, v_in, c_in);
-            track<true>(x[u].w, c1, v_in, c_in);
+            for (int u = 0; u < U; u++)
+                cur[u] = nxt[u];
+        }
+    } else {
+        for (uint32_t it = 0; it < w.count; it++, p += step, code += 2 * U) {
+            float4 x[U];
+            load_tile<BLOCK, U, NT>(x, p);
+            stats_fold<U>(r, x, code);
         }
     }
 
     // expand codes to global sample indices; a tracker that never fired keeps
     // value 0 and reports index 0 like the reference's initialisers
     LaneStats s;
-    s.sum = sum;
-    const float vals[5] = {v_pk, v_rp, v_rn, v_ip, v_in};
-    const uint32_t codes[5] = {c_pk, c_rp, c_rn, c_ip, c_in};
+    s.sum = r.sum;
+    const float vals[5] = {r.v_pk, r.v_rp, r.v_rn, r.v_ip, r.v_in};
+    const uint32_t codes[5] = {r.c_pk, r.c_rp, r.c_rn, r.c_ip, r.c_in};
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const uint32_t c = codes[k];
         const uint64_t tile = w.first + (uint64_t)(c / (2 * U)) * w.stride;
         const uint32_t slot = (c % (2 * U)) >> 1, half = c & 1u;
-        const uint64_t idx = base_index + 2 * (tile * PAPR_TILE_F4 + (uint64_t)slot * PAPR_BLOCK + t) + half;
+        const uint64_t idx = base_index + 2 * (tile * TILE_F4 + (uint64_t)slot * BLOCK + t) + half;
         s.val[k] = vals[k];
         s.idx[k] = vals[k] != 0.f ? idx : 0;
     }
-    block_reduce_stats(s);
+    block_reduce_stats<BLOCK / kWave>(s);
     if (t == 0) {
-        papr_partial r;
-        r.sum = s.sum;
+        papr_partial q;
+        q.sum = s.sum;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            r.idx[k] = s.idx[k];
-            r.val[k] = s.val[k];
+            q.idx[k] = s.idx[k];
+            q.val[k] = s.val[k];
         }
-        r.pad = 0;
-        out[blockIdx.x] = r;
+        q.pad = 0;
+        out[blockIdx.x] = q;
     }
 }
 
@@ -289,7 +325,7 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_stats_finalize(const float2 *
         const float2 x = tail[k];
         lane_stats_sample(s, x.x, x.y, tail_base_index + k);
     }
-    block_reduce_stats(s);
+    block_reduce_stats<PAPR_BLOCK / kWave>(s);
     if (threadIdx.x == 0) {
         papr_partial r;
         r.sum = s.sum;
@@ -345,11 +381,12 @@ struct CcdfShared {
     uint32_t *hist;   // copies * nbins
 };
 
+template <int BLOCK>
 __device__ __forceinline__ void hist_flush(const uint32_t *hist, uint32_t nbins, uint32_t copies,
                                            unsigned long long *__restrict__ ghist)
 {
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nbins; b += PAPR_BLOCK) {
+    for (uint32_t b = threadIdx.x; b < nbins; b += BLOCK) {
         unsigned long long s = 0;
         for (uint32_t c = 0; c < copies; c++)
             s += hist[c * nbins + b];
@@ -387,21 +424,21 @@ __device__ __forceinline__ uint32_t search_bin(uint32_t bits, const uint32_t *ke
 
 }  // namespace
 
-template <bool NT, bool LUT>
-__global__ __launch_bounds__(PAPR_BLOCK) void papr_ccdf_kernel(const float4 *__restrict__ data, uint64_t ntiles, int map,
-                                                                const float2 *__restrict__ tail, uint32_t tail_samples,
-                                                                const uint32_t *__restrict__ table, papr_ccdf_params P,
-                                                                unsigned long long *__restrict__ ghist)
+template <int BLOCK, int U, bool NT, bool PIPE, bool LUT>
+__global__ __launch_bounds__(BLOCK) void papr_ccdf_kernel(const float4 *__restrict__ data, uint64_t ntiles, int map,
+                                                           const float2 *__restrict__ tail, uint32_t tail_samples,
+                                                           const uint32_t *__restrict__ table, papr_ccdf_params P,
+                                                           unsigned long long *__restrict__ ghist)
 {
-    constexpr int U = PAPR_UNROLL;
+    constexpr uint64_t TILE_F4 = (uint64_t)BLOCK * U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t nbins = P.nkeys + 1;
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
     uint32_t *hist = tab + P.table_words;
 
-    for (uint32_t k = threadIdx.x; k < P.table_words; k += PAPR_BLOCK)
+    for (uint32_t k = threadIdx.x; k < P.table_words; k += BLOCK)
         tab[k] = table[k];
-    for (uint32_t k = threadIdx.x; k < P.copies * nbins; k += PAPR_BLOCK)
+    for (uint32_t k = threadIdx.x; k < P.copies * nbins; k += BLOCK)
         hist[k] = 0;
     __syncthreads();
 
@@ -414,29 +451,45 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_ccdf_kernel(const float4 *__r
         if (k)
             atomicAdd(&my[k], 1u);
     };
-
-    const uint32_t t = threadIdx.x;
-    const TileWalk w = tile_walk(blockIdx.x, gridDim.x, ntiles, map);
-    const float4 *p = data + w.first * PAPR_TILE_F4 + t;
-    const uint64_t step = w.stride * PAPR_TILE_F4;
-    for (uint32_t it = 0; it < w.count; it++, p += step) {
-        float4 x[U];
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            x[u] = load16<NT>(p + u * PAPR_BLOCK);
+    auto fold = [&](const float4(&x)[U]) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             count(power_of(x[u].x, x[u].y));
             count(power_of(x[u].z, x[u].w));
         }
+    };
+
+    const uint32_t t = threadIdx.x;
+    const TileWalk w = tile_walk(blockIdx.x, gridDim.x, ntiles, map);
+    const float4 *p = data + w.first * TILE_F4 + t;
+    const uint64_t step = w.stride * TILE_F4;
+    if constexpr (PIPE) {
+        float4 cur[U], nxt[U];
+        if (w.count)
+            load_tile<BLOCK, U, NT>(cur, p);
+        for (uint32_t it = 0; it < w.count; it++) {
+            p += step;
+            if (it + 1 < w.count)
+                load_tile<BLOCK, U, NT>(nxt, p);
+            fold(cur);
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                cur[u] = nxt[u];
+        }
+    } else {
+        for (uint32_t it = 0; it < w.count; it++, p += step) {
+            float4 x[U];
+            load_tile<BLOCK, U, NT>(x, p);
+            fold(x);
+        }
     }
     if (blockIdx.x == gridDim.x - 1) {
-        for (uint32_t k = t; k < tail_samples; k += PAPR_BLOCK) {
+        for (uint32_t k = t; k < tail_samples; k += BLOCK) {
             const float2 x = tail[k];
             count(power_of(x.x, x.y));
         }
     }
-    hist_flush(hist, nbins, P.copies, ghist);
+    hist_flush<BLOCK>(hist, nbins, P.copies, ghist);
 }
 
 // =============================================================================
@@ -454,16 +507,47 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_generate_kernel(float2 *__res
 }
 
 // ---- launch wrappers (called from papr_runtime.cpp through plain C++) ------
+//
+// Kernel geometry variants; tile = 2 * block * unroll samples (<= 8192).
+//   id: block x loads-per-lane, P = software-pipelined (next tile's loads issued
+//   before the current tile is reduced)
+//    0: 256x8      1: 256x4 P    2: 256x8 P    3: 512x8      4: 1024x4
+//    5: 256x16     6: 512x4 P    7: 256x4      8: 1024x4 P   9: 1024x2 P
+//   10: 512x2 P   11: 256x2 P   12: 1024x2    13: 512x4
+// Plain (non-"nt") loads exist for variant 0 only (A/B of the nontemporal hint).
 
-void papr_launch_stats(hipStream_t st, int blocks, bool nt, const void *data, uint64_t ntiles, uint64_t base_index,
-                       int map, papr_partial *out)
+#define PAPR_FOR_EACH_VARIANT(X) \
+    X(0, 256, 8, false) X(1, 256, 4, true) X(2, 256, 8, true) X(3, 512, 8, false) X(4, 1024, 4, false) \
+    X(5, 256, 16, false) X(6, 512, 4, true) X(7, 256, 4, false) X(8, 1024, 4, true) X(9, 1024, 2, true) \
+    X(10, 512, 2, true) X(11, 256, 2, true) X(12, 1024, 2, false) X(13, 512, 4, false)
+
+int papr_variant_geometry(int variant, int *block, int *unroll)
 {
-    if (nt)
-        hipLaunchKernelGGL(papr_stats_kernel<true>, dim3(blocks), dim3(PAPR_BLOCK), 0, st, (const float4 *)data, ntiles,
-                           base_index, map, out);
-    else
-        hipLaunchKernelGGL(papr_stats_kernel<false>, dim3(blocks), dim3(PAPR_BLOCK), 0, st, (const float4 *)data, ntiles,
-                           base_index, map, out);
+    switch (variant) {
+#define X(V, B, U, P) case V: *block = B; *unroll = U; return 0;
+        PAPR_FOR_EACH_VARIANT(X)
+#undef X
+    default: return -1;
+    }
+}
+
+void papr_launch_stats(hipStream_t st, int variant, int blocks, bool nt, const void *data, uint64_t ntiles,
+                       uint64_t base_index, int map, papr_partial *out)
+{
+    if (variant == 0 && !nt) {
+        hipLaunchKernelGGL((papr_stats_kernel<256, 8, false, false>), dim3(blocks), dim3(256), 0, st,
+                           (const float4 *)data, ntiles, base_index, map, out);
+        return;
+    }
+    switch (variant) {
+#define X(V, B, U, P)                                                                                               \
+    case V:                                                                                                          \
+        hipLaunchKernelGGL((papr_stats_kernel<B, U, true, P>), dim3(blocks), dim3(B), 0, st, (const float4 *)data,   \
+                           ntiles, base_index, map, out);                                                            \
+        break;
+        PAPR_FOR_EACH_VARIANT(X)
+#undef X
+    }
 }
 
 void papr_launch_stats_finalize(hipStream_t st, const void *tail, uint32_t tail_samples, uint64_t tail_base_index,
@@ -480,18 +564,37 @@ void papr_launch_first_nan(hipStream_t st, int blocks, const void *data, uint64_
                        base_index, key);
 }
 
-void papr_launch_ccdf(hipStream_t st, int blocks, bool nt, bool lut, size_t lds_bytes, const void *data, uint64_t ntiles,
-                      int map, const void *tail, uint32_t tail_samples, const uint32_t *table, const papr_ccdf_params &P,
-                      unsigned long long *ghist)
+template <int B, int U, bool NT, bool P>
+static void launch_ccdf_variant(hipStream_t st, int blocks, bool lut, size_t lds_bytes, const void *data,
+                                uint64_t ntiles, int map, const void *tail, uint32_t tail_samples,
+                                const uint32_t *table, const papr_ccdf_params &Pm, unsigned long long *ghist)
 {
-#define PAPR_CCDF_LAUNCH(NT, LUT)                                                                                   \
-    hipLaunchKernelGGL((papr_ccdf_kernel<NT, LUT>), dim3(blocks), dim3(PAPR_BLOCK), lds_bytes, st,                  \
-                       (const float4 *)data, ntiles, map, (const float2 *)tail, tail_samples, table, P, ghist)
-    if (nt && lut) PAPR_CCDF_LAUNCH(true, true);
-    else if (nt) PAPR_CCDF_LAUNCH(true, false);
-    else if (lut) PAPR_CCDF_LAUNCH(false, true);
-    else PAPR_CCDF_LAUNCH(false, false);
-#undef PAPR_CCDF_LAUNCH
+    if (lut)
+        hipLaunchKernelGGL((papr_ccdf_kernel<B, U, NT, P, true>), dim3(blocks), dim3(B), lds_bytes, st,
+                           (const float4 *)data, ntiles, map, (const float2 *)tail, tail_samples, table, Pm, ghist);
+    else
+        hipLaunchKernelGGL((papr_ccdf_kernel<B, U, NT, P, false>), dim3(blocks), dim3(B), lds_bytes, st,
+                           (const float4 *)data, ntiles, map, (const float2 *)tail, tail_samples, table, Pm, ghist);
+}
+
+void papr_launch_ccdf(hipStream_t st, int variant, int blocks, bool nt, bool lut, size_t lds_bytes, const void *data,
+                      uint64_t ntiles, int map, const void *tail, uint32_t tail_samples, const uint32_t *table,
+                      const papr_ccdf_params &P, unsigned long long *ghist)
+{
+    if (variant == 0 && !nt) {
+        launch_ccdf_variant<256, 8, false, false>(st, blocks, lut, lds_bytes, data, ntiles, map, tail, tail_samples,
+                                                  table, P, ghist);
+        return;
+    }
+    switch (variant) {
+#define X(V, B, U, PP)                                                                                              \
+    case V:                                                                                                          \
+        launch_ccdf_variant<B, U, true, PP>(st, blocks, lut, lds_bytes, data, ntiles, map, tail, tail_samples,       \
+                                            table, P, ghist);                                                        \
+        break;
+        PAPR_FOR_EACH_VARIANT(X)
+#undef X
+    }
 }
 
 void papr_launch_generate(hipStream_t st, int blocks, void *out, uint64_t nsamples, uint64_t first_index,
@@ -506,13 +609,20 @@ int papr_ccdf_max_dynamic_lds(void)
     // let one workgroup ask for more than the 64 KiB default when a level
     // table is very large (160 KiB LDS per CU on gfx950)
     static int done = 0;
+    const int want = 160 * 1024 - 2048;
     if (!done) {
-        const int want = 160 * 1024 - 2048;
-        (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
-        (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
-        (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
-        (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+#define X(V, B, U, P)                                                                                               \
+    (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<B, U, true, P, true>,                                   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, want);                                     \
+    (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<B, U, true, P, false>,                                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        PAPR_FOR_EACH_VARIANT(X)
+#undef X
+        (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<256, 8, false, false, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, want);
+        (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<256, 8, false, false, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, want);
         done = 1;
     }
-    return 160 * 1024 - 2048;
+    return want;
 }

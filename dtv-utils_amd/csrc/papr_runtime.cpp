@@ -33,7 +33,7 @@
 
 namespace {
 
-constexpr uint64_t kChunkAlign = PAPR_TILE_SAMPLES;  // chunk boundaries stay tile aligned
+constexpr uint64_t kChunkAlign = PAPR_TILE_SAMPLES_MAX;  // chunk boundaries stay tile aligned for every variant
 constexpr int kNumBuf = 3;
 constexpr int kMaxTimed = 4096;
 
@@ -115,6 +115,7 @@ struct papr_hip_ctx {
     hipStream_t copy_stream = nullptr;
     char name[128] = "";
     char err[256] = "";
+    int num_cus = 256;
     size_t hbm_budget = 0;
 
     // shard
@@ -202,31 +203,75 @@ void parse_tune_env(papr_hip_tuning *t)
         if (eq != std::string::npos) {
             std::string k = kv.substr(0, eq);
             int val = atoi(kv.c_str() + eq + 1);
-            if (k == "blocks") t->blocks = val;
-            else if (k == "map") t->map = val;
-            else if (k == "nt") t->nontemporal = val;
+            if (k == "blocks") t->stats_blocks = t->ccdf_blocks = val;
+            else if (k == "variant") t->stats_variant = t->ccdf_variant = val + 1;
+            else if (k == "sblocks") t->stats_blocks = val;
+            else if (k == "svariant") t->stats_variant = val + 1;
+            else if (k == "cblocks") t->ccdf_blocks = val;
+            else if (k == "cvariant") t->ccdf_variant = val + 1;
+            else if (k == "map") t->stats_map = t->ccdf_map = val + 1;
+            else if (k == "smap") t->stats_map = val + 1;
+            else if (k == "cmap") t->ccdf_map = val + 1;
+            else if (k == "nt") t->nontemporal = val ? 1 : 2;
             else if (k == "copies") t->hist_copies = val;
-            else if (k == "variant") t->variant = val;
+            else if (k == "search") t->flags = val ? (t->flags | 1) : (t->flags & ~1);
         }
         pos = end + 1;
     }
 }
 
-int pick_blocks(const papr_hip_ctx *ctx, uint64_t ntiles, int map)
+// Built-in launch geometry, from the 10 GiB sweeps on MI355X:
+//   pass 1: 256-thread workgroups, 4 loads per lane, software-pipelined, 2 workgroups per CU (8 waves/CU),
+//           one contiguous eighth of the shard per XCD                       -> 7.31 TB/s
+//   pass 2: 512-thread workgroups, 4 loads per lane, 2 workgroups per CU (16 waves/CU), grid-stride tiles
+//                                                                            -> 7.20 TB/s
+constexpr int kStatsVariant = 1, kStatsPerCU = 2, kStatsMap = PAPR_MAP_XCD_SPAN;
+constexpr int kCcdfVariant = 13, kCcdfPerCU = 2, kCcdfMap = PAPR_MAP_GRID_STRIDE;
+
+enum Pass { PASS1 = 0, PASS2 = 1 };
+
+int variant_of(const papr_hip_ctx *ctx, Pass p)
 {
-    int blocks = ctx->tune.blocks > 0 ? ctx->tune.blocks : 2048;  // 8 workgroups on each of 256 CUs
+    const int v = (p == PASS1 ? ctx->tune.stats_variant : ctx->tune.ccdf_variant) - 1;
+    int b, u;
+    if (v >= 0 && papr_variant_geometry(v, &b, &u) == 0)
+        return v;
+    return p == PASS1 ? kStatsVariant : kCcdfVariant;
+}
+
+int blocks_of(const papr_hip_ctx *ctx, Pass p)
+{
+    const int b = p == PASS1 ? ctx->tune.stats_blocks : ctx->tune.ccdf_blocks;
+    return b > 0 ? b : ctx->num_cus * (p == PASS1 ? kStatsPerCU : kCcdfPerCU);
+}
+
+// samples one workgroup consumes per loop iteration under the pass's kernel variant
+uint64_t tile_samples(const papr_hip_ctx *ctx, Pass p)
+{
+    int block = 256, unroll = 8;
+    (void)papr_variant_geometry(variant_of(ctx, p), &block, &unroll);
+    return 2ull * (uint64_t)block * (uint64_t)unroll;
+}
+
+int map_of(const papr_hip_ctx *ctx, Pass p)
+{
+    const int m = (p == PASS1 ? ctx->tune.stats_map : ctx->tune.ccdf_map) - 1;
+    return (m >= 0 && m <= 2) ? m : (p == PASS1 ? kStatsMap : kCcdfMap);
+}
+
+int pick_blocks(const papr_hip_ctx *ctx, Pass p, uint64_t ntiles)
+{
+    int blocks = blocks_of(ctx, p);
     if ((uint64_t)blocks > ntiles)
         blocks = (int)std::max<uint64_t>(ntiles, 1);
-    if (map == PAPR_MAP_XCD_SPAN && blocks >= 8)
+    if (map_of(ctx, p) == PAPR_MAP_XCD_SPAN && blocks >= 8)
         blocks &= ~7;
     return blocks;
 }
 
-int effective_map(const papr_hip_ctx *ctx, int blocks)
+int effective_map(const papr_hip_ctx *ctx, Pass p, int blocks)
 {
-    int map = ctx->tune.map;
-    if (map < 0 || map > 2)
-        map = 0;
+    int map = map_of(ctx, p);
     if (map == PAPR_MAP_XCD_SPAN && (blocks % 8) != 0)
         map = PAPR_MAP_GRID_STRIDE;
     return map;
@@ -234,7 +279,7 @@ int effective_map(const papr_hip_ctx *ctx, int blocks)
 
 bool use_nt(const papr_hip_ctx *ctx)
 {
-    return ctx->tune.nontemporal != 0;
+    return ctx->tune.nontemporal != 2;
 }
 
 int ensure_partials(papr_hip_ctx *ctx, size_t count)
@@ -286,7 +331,7 @@ int ensure_owned_capacity(papr_hip_ctx *ctx, uint64_t nsamples)
         return PAPR_OK;
     release_shard(ctx);
     // one extra tile of slack keeps every 16-byte lane load in bounds
-    size_t bytes = (size_t)(nsamples + PAPR_TILE_SAMPLES) * 8;
+    size_t bytes = (size_t)(nsamples + PAPR_TILE_SAMPLES_MAX) * 8;
     hipError_t e = hipMalloc((void **)&ctx->d_iq, bytes);
     if (e != hipSuccess) {
         ctx->d_iq = nullptr;
@@ -327,14 +372,16 @@ void time_end(papr_hip_ctx *ctx)
 int launch_stats_range(papr_hip_ctx *ctx, const float *data, uint64_t n, uint64_t base_index, size_t slot,
                        int *nrecords)
 {
-    const uint64_t ntiles = n / PAPR_TILE_SAMPLES;
+    const uint64_t tile = tile_samples(ctx, PASS1);
+    const uint64_t ntiles = n / tile;
     *nrecords = 0;
     if (ntiles == 0)
         return PAPR_OK;
-    int blocks = pick_blocks(ctx, ntiles, ctx->tune.map);
-    const int map = effective_map(ctx, blocks);
-    time_begin(ctx, 0, ntiles * (uint64_t)PAPR_TILE_SAMPLES * 8);
-    papr_launch_stats(ctx->stream, blocks, use_nt(ctx), data, ntiles, base_index, map, ctx->d_partials + slot);
+    int blocks = pick_blocks(ctx, PASS1, ntiles);
+    const int map = effective_map(ctx, PASS1, blocks);
+    time_begin(ctx, 0, ntiles * tile * 8);
+    papr_launch_stats(ctx->stream, variant_of(ctx, PASS1), blocks, use_nt(ctx), data, ntiles, base_index, map,
+                      ctx->d_partials + slot);
     time_end(ctx);
     HIPCHK(ctx, hipGetLastError());
     *nrecords = blocks;
@@ -414,11 +461,14 @@ int plan_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, CcdfPlan *pla
         return PAPR_OK;
     const uint32_t nbins = m + 1;
     const size_t lds_cap = (size_t)papr_ccdf_max_dynamic_lds();
-    const int want_copies = ctx->tune.hist_copies > 0 ? std::min(ctx->tune.hist_copies, PAPR_BLOCK / 64) : PAPR_BLOCK / 64;
+    int vblock = 256, vunroll = 8;
+    (void)papr_variant_geometry(variant_of(ctx, PASS2), &vblock, &vunroll);
+    const int waves = vblock / 64;
+    const int want_copies = ctx->tune.hist_copies > 0 ? std::min(ctx->tune.hist_copies, waves) : std::min(waves, 4);
 
     // LUT: the coarsest cell size that still isolates every key in its own cell
     plan->lut = false;
-    if (plan->keys.front() >= 0x00800000u && ctx->tune.variant != 1) {  // keys in the normal-float range
+    if (plan->keys.front() >= 0x00800000u && !(ctx->tune.flags & 1)) {  // keys in the normal-float range
         for (int shift = 23; shift >= 8; shift--) {
             const uint32_t c0 = plan->keys.front() >> shift, c1 = plan->keys.back() >> shift;
             const uint64_t ncells = (uint64_t)c1 - c0 + 1;
@@ -448,7 +498,7 @@ int plan_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, CcdfPlan *pla
     }
     // histogram copies: one per wave when it is cheap, fewer for huge tables
     int copies = want_copies;
-    const size_t soft_cap = 20 * 1024;  // keeps 8 workgroups resident per CU
+    const size_t soft_cap = (size_t)vblock * 80;  // the workgroup's share of 160 KiB when the CU is full of threads
     while (copies > 1 && (size_t)P.table_words * 4 + (size_t)copies * nbins * 4 > soft_cap)
         copies--;
     P.copies = (uint32_t)copies;
@@ -484,13 +534,14 @@ int upload_ccdf_table(papr_hip_ctx *ctx, const CcdfPlan &plan)
 
 int launch_ccdf_range(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *data, uint64_t n)
 {
-    const uint64_t ntiles = n / PAPR_TILE_SAMPLES;
-    const uint32_t tail = (uint32_t)(n - ntiles * PAPR_TILE_SAMPLES);
-    int blocks = pick_blocks(ctx, ntiles, ctx->tune.map);
-    const int map = effective_map(ctx, blocks);
+    const uint64_t tile = tile_samples(ctx, PASS2);
+    const uint64_t ntiles = n / tile;
+    const uint32_t tail = (uint32_t)(n - ntiles * tile);
+    int blocks = pick_blocks(ctx, PASS2, ntiles);
+    const int map = effective_map(ctx, PASS2, blocks);
     time_begin(ctx, 1, n * 8);
-    papr_launch_ccdf(ctx->stream, blocks, use_nt(ctx), plan.lut, plan.lds_bytes, data, ntiles, map,
-                     data + 2 * ntiles * PAPR_TILE_SAMPLES, tail, ctx->d_table, plan.P, ctx->d_hist);
+    papr_launch_ccdf(ctx->stream, variant_of(ctx, PASS2), blocks, use_nt(ctx), plan.lut, plan.lds_bytes, data, ntiles, map,
+                     data + 2 * ntiles * tile, tail, ctx->d_table, plan.P, ctx->d_hist);
     time_end(ctx);
     HIPCHK(ctx, hipGetLastError());
     return PAPR_OK;
@@ -576,10 +627,10 @@ int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage)
         if (!ctx->ev_kernel[b])
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_kernel[b], hipEventDisableTiming));
         if (need_device_stage && !ctx->d_stage[b])
-            HIPCHK(ctx, hipMalloc(&ctx->d_stage[b], ctx->stage_bytes + PAPR_TILE_SAMPLES * 8));
+            HIPCHK(ctx, hipMalloc(&ctx->d_stage[b], ctx->stage_bytes + PAPR_TILE_SAMPLES_MAX * 8));
     }
     if (need_device_stage && !ctx->d_tail)
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_tail, PAPR_TILE_SAMPLES * 8));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_tail, PAPR_TILE_SAMPLES_MAX * 8));
     if (!ctx->pool) {
         int n = env_int("PAPR_READ_THREADS", 0);
         if (n <= 0)
@@ -612,7 +663,7 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
     const uint64_t nchunks = (ctx->n + chunk_samples - 1) / chunk_samples;
     size_t records = 0;
     if (pass == PASS_LOAD_STATS || pass == PASS_STREAM_STATS) {
-        const int per_chunk = ctx->tune.blocks > 0 ? ctx->tune.blocks : 2048;
+        const int per_chunk = blocks_of(ctx, PASS1);
         rc = ensure_partials(ctx, (size_t)nchunks * per_chunk + 1);
         if (rc) {
             close(fs.fd);
@@ -658,7 +709,7 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
             rc = launch_stats_range(ctx, dst, cnt, ctx->base + s0, records, &nrec);
             records += (size_t)nrec;
             if (rc == PAPR_OK && last && pass == PASS_STREAM_STATS) {
-                const uint64_t full = cnt / PAPR_TILE_SAMPLES * PAPR_TILE_SAMPLES;
+                const uint64_t full = cnt / tile_samples(ctx, PASS1) * tile_samples(ctx, PASS1);
                 if (cnt > full)
                     HIPCHK(ctx, hipMemcpyAsync(ctx->d_tail, dst + 2 * full, (cnt - full) * 8, hipMemcpyDeviceToDevice,
                                                ctx->stream));
@@ -763,8 +814,9 @@ int papr_hip_open(papr_hip_ctx **out, int device)
         free_b = (size_t)64 << 30;
     const int budget_mb = env_int("PAPR_HBM_BUDGET_MB", 0);
     ctx->hbm_budget = budget_mb > 0 ? (size_t)budget_mb << 20 : free_b / 10 * 9;
-    ctx->tune.nontemporal = 1;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     parse_tune_env(&ctx->tune);
+
     if (ensure_partials(ctx, 4096) != PAPR_OK)
         return bail(PAPR_E_HIP);
     (void)papr_ccdf_max_dynamic_lds();
@@ -817,7 +869,11 @@ int papr_hip_set_tuning(papr_hip_ctx *ctx, const papr_hip_tuning *t)
 {
     if (!ctx || !t)
         return PAPR_E_ARG;
-    if (t->blocks < 0 || t->blocks > 65536 || t->map < 0 || t->map > 2 || t->hist_copies < 0)
+    int vb, vu;
+    if (t->stats_blocks < 0 || t->stats_blocks > 65536 || t->ccdf_blocks < 0 || t->ccdf_blocks > 65536 ||
+        t->stats_map < 0 || t->stats_map > 3 || t->ccdf_map < 0 || t->ccdf_map > 3 || t->hist_copies < 0 ||
+        (t->stats_variant != 0 && papr_variant_geometry(t->stats_variant - 1, &vb, &vu) != 0) ||
+        (t->ccdf_variant != 0 && papr_variant_geometry(t->ccdf_variant - 1, &vb, &vu) != 0))
         return fail(ctx, PAPR_E_ARG, "bad tuning values");
     ctx->tune = *t;
     return PAPR_OK;
@@ -951,7 +1007,7 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
     if (nsamples == UINT64_MAX || first_sample + nsamples > fs.nsamples)
         nsamples = fs.nsamples - first_sample;
 
-    const bool fits = (nsamples + PAPR_TILE_SAMPLES) * 8 <= ctx->hbm_budget;
+    const bool fits = (nsamples + PAPR_TILE_SAMPLES_MAX) * 8 <= ctx->hbm_budget;
     if (!ctx->owns_iq || !fits)
         release_shard(ctx);
     if (fits) {
@@ -977,7 +1033,7 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
     }
     const uint64_t chunk_samples = ctx->stage_bytes / 8;
     const uint64_t last_cnt = nsamples ? nsamples - (nsamples - 1) / chunk_samples * chunk_samples : 0;
-    const uint32_t tail = (uint32_t)(last_cnt % PAPR_TILE_SAMPLES);
+    const uint32_t tail = (uint32_t)(last_cnt % tile_samples(ctx, PASS1));
     const float *tail_ptr = fits ? ctx->d_iq + 2 * (nsamples - tail) : ctx->d_tail;
     papr_stats st;
     rc = finish_stats(ctx, records, tail_ptr, tail, ctx->base + nsamples - tail, &st);
@@ -1019,13 +1075,13 @@ int papr_hip_stats(papr_hip_ctx *ctx, papr_stats *out)
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int nrec = 0;
-    int rc = ensure_partials(ctx, (size_t)(ctx->tune.blocks > 0 ? ctx->tune.blocks : 2048) + 1);
+    int rc = ensure_partials(ctx, (size_t)blocks_of(ctx, PASS1) + 1);
     if (rc)
         return rc;
     rc = launch_stats_range(ctx, ctx->d_iq, ctx->n, ctx->base, 0, &nrec);
     if (rc)
         return rc;
-    const uint32_t tail = (uint32_t)(ctx->n % PAPR_TILE_SAMPLES);
+    const uint32_t tail = (uint32_t)(ctx->n % tile_samples(ctx, PASS1));
     rc = finish_stats(ctx, (size_t)nrec, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->base + ctx->n - tail, out);
     if (rc)
         return rc;

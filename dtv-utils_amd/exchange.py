@@ -26,9 +26,9 @@ from . import Stats, stats_merge
 
 def allgather_stats(local: Stats, device: torch.device, group=None) -> List[Stats]:
     """Every rank's pass-1 record, in rank order."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return [local]
+    world = dist.get_world_size(group)
     raw = np.frombuffer(local.to_bytes(), dtype=np.uint8).copy()
     mine = torch.from_numpy(raw).to(device)
     gathered = torch.empty(world * raw.size, dtype=torch.uint8, device=device)
@@ -45,8 +45,7 @@ def merged_stats(local: Stats, device: torch.device, group=None) -> Stats:
 
 def allreduce_counts(counts: np.ndarray, device: torch.device, group=None) -> np.ndarray:
     """Exchange 2: per-level counts summed over all shards."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1 or counts.size == 0:
+    if not dist.is_initialized() or counts.size == 0:
         return counts.astype(np.uint64, copy=True)
     t = torch.from_numpy(counts.astype(np.int64)).to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)

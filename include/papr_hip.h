@@ -83,14 +83,21 @@ typedef struct papr_hip_timing {
     double ccdf_ms;   uint64_t ccdf_launches;   uint64_t ccdf_bytes;
 } papr_hip_timing;
 
-/* Launch geometry knobs (0 = built-in default); also settable with the
- * PAPR_HIP_TUNE environment variable, e.g. "blocks=2048,map=1,nt=1". */
+/* Launch geometry knobs.  0 always means "built-in default" (chosen from the
+ * 10 GiB sweeps in DESIGN.md section 6); variant and map fields therefore hold
+ * id + 1.  Also settable with the PAPR_HIP_TUNE environment variable, e.g.
+ * "sblocks=512,svariant=1,smap=2,cblocks=512,cvariant=13,cmap=0,nt=1"
+ * ("blocks=" / "variant=" / "map=" set both passes). */
 typedef struct papr_hip_tuning {
-    int blocks;       /* workgroups per launch */
-    int map;          /* 0 grid-stride tiles, 1 contiguous span per workgroup, 2 contiguous span per XCD */
-    int nontemporal;  /* 1 = nontemporal loads */
-    int hist_copies;  /* LDS histogram copies per workgroup (1..waves) */
-    int variant;      /* kernel variant selector */
+    int stats_blocks;   /* pass 1: workgroups per launch */
+    int stats_variant;  /* pass 1: kernel geometry variant id + 1 (block x unroll x pipelining, papr_kernels.hip) */
+    int stats_map;      /* pass 1: tile mapping id + 1 (0 grid-stride, 1 span per workgroup, 2 span per XCD) */
+    int ccdf_blocks;    /* pass 2: workgroups per launch */
+    int ccdf_variant;   /* pass 2: kernel geometry variant id + 1 */
+    int ccdf_map;       /* pass 2: tile mapping id + 1 */
+    int nontemporal;    /* 0/1 = default (nontemporal loads), 2 = plain loads */
+    int hist_copies;    /* LDS histogram copies per workgroup (1..waves) */
+    int flags;          /* bit 0: force the binary-search form of pass 2 (tests) */
 } papr_hip_tuning;
 
 typedef struct papr_hip_ctx papr_hip_ctx;

@@ -18,10 +18,13 @@ import __graft_entry__ as ge  # noqa: E402
 
 
 def parse(spec):
-    d = dict(blocks=0, map=0, nontemporal=1, hist_copies=0, variant=0)
+    d = dict(blocks=0, variant=None, map=None, nontemporal=1, hist_copies=0, flags=0)
+    alias = {"nt": "nontemporal", "copies": "hist_copies", "search": "flags", "sblocks": "stats_blocks",
+             "svariant": "stats_variant", "smap": "stats_map", "cblocks": "ccdf_blocks", "cvariant": "ccdf_variant",
+             "cmap": "ccdf_map"}
     for kv in filter(None, spec.split(",")):
         k, v = kv.split("=")
-        d[{"nt": "nontemporal", "copies": "hist_copies"}.get(k, k)] = int(v)
+        d[alias.get(k, k)] = int(v)
     return d
 
 
@@ -30,7 +33,7 @@ def main():
     ap.add_argument("--gib", type=float, default=10.0)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--mode", default="both")
-    ap.add_argument("specs", nargs="*", default=["blocks=2048,map=0,nt=1"])
+    ap.add_argument("specs", nargs="*", default=[""])
     a = ap.parse_args()
     pkg = ge.load_package()
     n = int(a.gib * (1 << 30)) // 8 // 8192 * 8192
