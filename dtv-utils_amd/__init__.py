@@ -31,7 +31,7 @@ MAX_LEVELS = 16384
 ABI_SYMBOLS = (
     "papr_hip_abi_version", "papr_hip_device_count", "papr_hip_open", "papr_hip_close",
     "papr_hip_last_error", "papr_hip_device_name", "papr_hip_set_tuning", "papr_hip_set_timing",
-    "papr_hip_get_timing", "papr_file_samples", "papr_hip_load_file", "papr_hip_upload",
+    "papr_hip_get_timing", "papr_file_samples", "papr_hip_load_file", "papr_hip_get_ingest_timing", "papr_hip_upload",
     "papr_hip_adopt", "papr_hip_generate", "papr_hip_download", "papr_hip_stats",
     "papr_stats_init", "papr_stats_merge", "papr_levels", "papr_hip_ccdf",
 )
@@ -93,6 +93,15 @@ class Timing(C.Structure):
                 ("ccdf_ms", C.c_double), ("ccdf_launches", C.c_uint64), ("ccdf_bytes", C.c_uint64)]
 
 
+class IngestTiming(C.Structure):
+    _fields_ = [("total_s", C.c_double), ("setup_s", C.c_double), ("read_s", C.c_double),
+                ("buffer_wait_s", C.c_double), ("issue_s", C.c_double), ("drain_s", C.c_double),
+                ("bytes", C.c_uint64), ("chunks", C.c_uint64), ("reader_threads", C.c_int), ("resident", C.c_int)]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
 class Tuning(C.Structure):
     """papr_hip_tuning; *_variant fields hold (variant id + 1), 0 = built-in default."""
     _fields_ = [("stats_blocks", C.c_int), ("stats_variant", C.c_int), ("stats_map", C.c_int),
@@ -133,6 +142,8 @@ def lib() -> C.CDLL:
     L.papr_hip_get_timing.argtypes = [vp, C.POINTER(Timing)]
     L.papr_file_samples.argtypes = [C.c_char_p, C.POINTER(u64)]
     L.papr_hip_load_file.argtypes = [vp, C.c_char_p, u64, u64]
+    L.papr_hip_get_ingest_timing.argtypes = [vp, C.POINTER(IngestTiming)]
+    L.papr_hip_get_ingest_timing.restype = i32
     L.papr_hip_upload.argtypes = [vp, vp, u64, u64]
     L.papr_hip_adopt.argtypes = [vp, vp, u64, u64]
     L.papr_hip_generate.argtypes = [vp, C.POINTER(SynthSpec), u64, u64]
@@ -145,7 +156,7 @@ def lib() -> C.CDLL:
     L.papr_levels.argtypes = [C.POINTER(Stats), i32, C.POINTER(C.c_double), C.POINTER(C.c_float), vp, i32]
     L.papr_hip_ccdf.argtypes = [vp, vp, i32, vp]
     for name in ("papr_hip_open", "papr_hip_device_name", "papr_hip_set_tuning", "papr_hip_set_timing",
-                 "papr_hip_get_timing", "papr_file_samples", "papr_hip_load_file", "papr_hip_upload",
+                 "papr_hip_get_timing", "papr_file_samples", "papr_hip_load_file", "papr_hip_get_ingest_timing", "papr_hip_upload",
                  "papr_hip_adopt", "papr_hip_generate", "papr_hip_download", "papr_hip_stats",
                  "papr_levels", "papr_hip_ccdf"):
         getattr(L, name).restype = i32
@@ -252,6 +263,11 @@ class PaprHip:
     def load_file(self, path: str, first_sample: int = 0, nsamples: int = NO_INDEX):
         self._chk(self._L.papr_hip_load_file(self._ctx, os.fsencode(path), first_sample, nsamples),
                   "papr_hip_load_file")
+
+    def ingest_timing(self) -> IngestTiming:
+        t = IngestTiming()
+        self._chk(self._L.papr_hip_get_ingest_timing(self._ctx, C.byref(t)), "papr_hip_get_ingest_timing")
+        return t
 
     def upload(self, iq: np.ndarray, base_index: int = 0):
         iq = np.ascontiguousarray(iq, dtype=np.float32).reshape(-1)

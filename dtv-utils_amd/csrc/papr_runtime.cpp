@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdarg>
@@ -34,12 +35,26 @@
 namespace {
 
 constexpr uint64_t kChunkAlign = PAPR_TILE_SAMPLES_MAX;  // chunk boundaries stay tile aligned for every variant
-constexpr int kNumBuf = 3;
+constexpr int kNumBuf = 4;      // pinned staging buffers
+constexpr int kReadAhead = 2;   // chunks being read ahead of the one being copied
 constexpr int kMaxTimed = 4096;
 
 char g_open_error[256] = "";
 
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 // ---- a tiny pool of file-reader threads -------------------------------------
+// Jobs are grouped in batches (one batch = the slices of one chunk); the
+// submitter can queue the next chunk's batch before waiting for the current
+// one, so the readers never go idle between chunks.
+struct ReadBatch {
+    int pending = 0;
+    int error = 0;
+};
+
 class ReaderPool {
   public:
     explicit ReaderPool(int n)
@@ -57,26 +72,32 @@ class ReaderPool {
         for (auto &t : threads_)
             t.join();
     }
-    void submit(std::function<void()> job)
+    // job returns 0 or an error code, recorded in the batch
+    void submit(ReadBatch *batch, std::function<int()> job)
     {
         {
             std::lock_guard<std::mutex> g(m_);
-            jobs_.push_back(std::move(job));
-            pending_++;
+            batch->pending++;
+            jobs_.push_back({batch, std::move(job)});
         }
         cv_.notify_one();
     }
-    void wait_all()
+    int wait(ReadBatch *batch)
     {
         std::unique_lock<std::mutex> g(m_);
-        done_cv_.wait(g, [this] { return pending_ == 0; });
+        done_cv_.wait(g, [batch] { return batch->pending == 0; });
+        return batch->error;
     }
 
   private:
+    struct Job {
+        ReadBatch *batch;
+        std::function<int()> fn;
+    };
     void run()
     {
         for (;;) {
-            std::function<void()> job;
+            Job job;
             {
                 std::unique_lock<std::mutex> g(m_);
                 cv_.wait(g, [this] { return stop_ || !jobs_.empty(); });
@@ -85,19 +106,20 @@ class ReaderPool {
                 job = std::move(jobs_.front());
                 jobs_.pop_front();
             }
-            job();
+            const int rc = job.fn();
             {
                 std::lock_guard<std::mutex> g(m_);
-                if (--pending_ == 0)
+                if (rc)
+                    job.batch->error = rc;
+                if (--job.batch->pending == 0)
                     done_cv_.notify_all();
             }
         }
     }
     std::vector<std::thread> threads_;
-    std::deque<std::function<void()>> jobs_;
+    std::deque<Job> jobs_;
     std::mutex m_;
     std::condition_variable cv_, done_cv_;
-    int pending_ = 0;
     bool stop_ = false;
 };
 
@@ -148,14 +170,15 @@ struct papr_hip_ctx {
     float *d_tail = nullptr;               // streaming mode: the last chunk's sub-tile tail
 
     // ingest
-    void *h_stage[kNumBuf] = {nullptr, nullptr, nullptr};
-    void *d_stage[kNumBuf] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_copy[kNumBuf] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_kernel[kNumBuf] = {nullptr, nullptr, nullptr};
+    void *h_stage[kNumBuf] = {};
+    void *d_stage[kNumBuf] = {};
+    hipEvent_t ev_copy[kNumBuf] = {};
+    hipEvent_t ev_kernel[kNumBuf] = {};
     size_t stage_bytes = 0;
     ReaderPool *pool = nullptr;
     int reader_threads = 0;
 
+    papr_hip_ingest_timing ingest{};
     papr_hip_tuning tune{};
     bool timing = false;
     std::vector<TimedLaunch> timed;
@@ -614,7 +637,7 @@ int read_samples(const FileSrc &fs, uint64_t s0, uint64_t cnt, unsigned char *ds
 int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage)
 {
     if (!ctx->stage_bytes) {
-        size_t mb = (size_t)std::max(1, env_int("PAPR_CHUNK_MB", 64));
+        size_t mb = (size_t)std::max(1, env_int("PAPR_CHUNK_MB", 32));
         ctx->stage_bytes = (mb << 20) / (kChunkAlign * 8) * (kChunkAlign * 8);
         if (!ctx->stage_bytes)
             ctx->stage_bytes = kChunkAlign * 8;
@@ -634,7 +657,7 @@ int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage)
     if (!ctx->pool) {
         int n = env_int("PAPR_READ_THREADS", 0);
         if (n <= 0)
-            n = (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+            n = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
         ctx->reader_threads = n;
         ctx->pool = new ReaderPool(n);
     }
@@ -654,6 +677,8 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
     if (rc)
         return rc;
     const bool to_resident = (pass == PASS_LOAD_STATS);
+    const bool timed = (pass == PASS_LOAD_STATS || pass == PASS_STREAM_STATS);
+    double t_mark = now_s();
     rc = ensure_ingest(ctx, !to_resident);
     if (rc) {
         close(fs.fd);
@@ -670,31 +695,36 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
             return rc;
         }
     }
-    std::vector<int> read_rc(ctx->reader_threads, 0);
-    for (uint64_t c = 0; c < nchunks && rc == PAPR_OK; c++) {
+    if (timed) {
+        ctx->ingest.setup_s += now_s() - t_mark;
+        ctx->ingest.chunks = nchunks;
+        ctx->ingest.reader_threads = ctx->reader_threads;
+    }
+    // queue the slices of chunk c for the reader threads (buffer c % kNumBuf must be free)
+    std::vector<ReadBatch> batches(nchunks);
+    const FileSrc *fsp = &fs;
+    const uint64_t file_first = ctx->file_first, shard_n = ctx->n;
+    auto submit_chunk = [&](uint64_t c) {
         const int b = (int)(c % kNumBuf);
         const uint64_t s0 = c * chunk_samples;
-        const uint64_t cnt = std::min(chunk_samples, ctx->n - s0);
-        // the pinned buffer is free once its previous H2D copy has completed
-        if (c >= (uint64_t)kNumBuf)
-            HIPCHK(ctx, hipEventSynchronize(ctx->ev_copy[b]));
+        const uint64_t cnt = std::min(chunk_samples, shard_n - s0);
         unsigned char *hbuf = (unsigned char *)ctx->h_stage[b];
         const int nthr = ctx->reader_threads;
         const uint64_t per = ((cnt + nthr - 1) / nthr + 511) & ~511ull;
-        std::fill(read_rc.begin(), read_rc.end(), 0);
         for (int t = 0; t < nthr; t++) {
             const uint64_t a = std::min<uint64_t>((uint64_t)t * per, cnt), e = std::min<uint64_t>(a + per, cnt);
             if (e > a)
-                ctx->pool->submit([&fs, &read_rc, t, a, e, s0, hbuf, ctx] {
-                    read_rc[t] = read_samples(fs, ctx->file_first + s0 + a, e - a, hbuf + a * 8);
+                ctx->pool->submit(&batches[c], [fsp, file_first, s0, a, e, hbuf] {
+                    return read_samples(*fsp, file_first + s0 + a, e - a, hbuf + a * 8);
                 });
         }
-        ctx->pool->wait_all();
-        for (int t = 0; t < nthr; t++)
-            if (read_rc[t]) {
-                close(fs.fd);
-                return fail(ctx, PAPR_E_IO, "read error in %s", ctx->path.c_str());
-            }
+    };
+    // copy chunk c (already read into its pinned buffer) to the device and run the pass kernel on it
+    auto process_chunk = [&](uint64_t c) -> int {
+        const int b = (int)(c % kNumBuf);
+        const uint64_t s0 = c * chunk_samples;
+        const uint64_t cnt = std::min(chunk_samples, ctx->n - s0);
+        unsigned char *hbuf = (unsigned char *)ctx->h_stage[b];
         float *dst = to_resident ? ctx->d_iq + 2 * s0 : (float *)ctx->d_stage[b];
         if (!to_resident && c >= (uint64_t)kNumBuf)
             HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_kernel[b], 0));
@@ -702,13 +732,14 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
         HIPCHK(ctx, hipEventRecord(ctx->ev_copy[b], ctx->copy_stream));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copy[b], 0));
         const bool last = (c + 1 == nchunks);
+        int prc = PAPR_OK;
         switch (pass) {
         case PASS_LOAD_STATS:
         case PASS_STREAM_STATS: {
             int nrec = 0;
-            rc = launch_stats_range(ctx, dst, cnt, ctx->base + s0, records, &nrec);
+            prc = launch_stats_range(ctx, dst, cnt, ctx->base + s0, records, &nrec);
             records += (size_t)nrec;
-            if (rc == PAPR_OK && last && pass == PASS_STREAM_STATS) {
+            if (prc == PAPR_OK && last && pass == PASS_STREAM_STATS) {
                 const uint64_t full = cnt / tile_samples(ctx, PASS1) * tile_samples(ctx, PASS1);
                 if (cnt > full)
                     HIPCHK(ctx, hipMemcpyAsync(ctx->d_tail, dst + 2 * full, (cnt - full) * 8, hipMemcpyDeviceToDevice,
@@ -717,16 +748,50 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
             break;
         }
         case PASS_STREAM_CCDF:
-            rc = launch_ccdf_range(ctx, *plan, dst, cnt);
+            prc = launch_ccdf_range(ctx, *plan, dst, cnt);
             break;
         case PASS_STREAM_NAN:
             papr_launch_first_nan(ctx->stream, 1024, dst, cnt, ctx->base + s0, ctx->d_nan_key);
-            if (hipGetLastError() != hipSuccess)
-                rc = fail(ctx, PAPR_E_HIP, "first-NaN kernel launch failed");
+            HIPCHK(ctx, hipGetLastError());
             break;
         }
+        if (prc)
+            return prc;
         HIPCHK(ctx, hipEventRecord(ctx->ev_kernel[b], ctx->stream));
+        return PAPR_OK;
+    };
+
+    uint64_t submitted = 0;
+    for (; submitted < std::min<uint64_t>(kReadAhead, nchunks); submitted++)
+        submit_chunk(submitted);
+    for (uint64_t c = 0; c < nchunks && rc == PAPR_OK; c++) {
+        t_mark = now_s();
+        if (ctx->pool->wait(&batches[c]))
+            rc = fail(ctx, PAPR_E_IO, "read error in %s", ctx->path.c_str());
+        if (timed)
+            ctx->ingest.read_s += now_s() - t_mark;
+        if (rc)
+            break;
+        t_mark = now_s();
+        rc = process_chunk(c);
+        if (timed)
+            ctx->ingest.issue_s += now_s() - t_mark;
+        // read ahead: the next unread chunk goes into the buffer used kNumBuf chunks earlier, which is
+        // free once that chunk's H2D copy has completed
+        if (rc == PAPR_OK && submitted < nchunks) {
+            t_mark = now_s();
+            if (submitted >= (uint64_t)kNumBuf &&
+                hipEventSynchronize(ctx->ev_copy[submitted % kNumBuf]) != hipSuccess)
+                rc = fail(ctx, PAPR_E_HIP, "hipEventSynchronize failed while recycling a staging buffer");
+            if (timed)
+                ctx->ingest.buffer_wait_s += now_s() - t_mark;
+            if (rc == PAPR_OK)
+                submit_chunk(submitted++);
+        }
     }
+    // on any failure let the reads already queued finish before `fs` and the batches go away
+    for (uint64_t k = 0; k < submitted; k++)
+        (void)ctx->pool->wait(&batches[k]);
     close(fs.fd);
     if (nrecords_out)
         *nrecords_out = records;
@@ -996,6 +1061,8 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
     if (!ctx || !path)
         return PAPR_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    const double t_begin = now_s();
+    memset(&ctx->ingest, 0, sizeof(ctx->ingest));
     FileSrc fs;
     int rc = open_file_src(ctx, path, &fs);
     if (rc)
@@ -1024,6 +1091,9 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
     ctx->have_file_stats = false;
     ctx->shard_flags = (fs.odd && first_sample + nsamples == fs.nsamples && nsamples > 0) ? PAPR_FLAG_ODD_TAIL : 0;
 
+    ctx->ingest.setup_s = now_s() - t_begin;
+    ctx->ingest.bytes = nsamples * 8;
+    ctx->ingest.resident = fits ? 1 : 0;
     // pass 1 rides along with the ingest
     size_t records = 0;
     rc = stream_file(ctx, fits ? PASS_LOAD_STATS : PASS_STREAM_STATS, nullptr, &records);
@@ -1036,11 +1106,13 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
     const uint32_t tail = (uint32_t)(last_cnt % tile_samples(ctx, PASS1));
     const float *tail_ptr = fits ? ctx->d_iq + 2 * (nsamples - tail) : ctx->d_tail;
     papr_stats st;
+    const double t_drain = now_s();
     rc = finish_stats(ctx, records, tail_ptr, tail, ctx->base + nsamples - tail, &st);
     if (rc) {
         ctx->loaded = false;
         return rc;
     }
+    ctx->ingest.drain_s = now_s() - t_drain;
     if (std::isnan(st.sum)) {
         unsigned long long key = ~0ull;
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_nan_key, &key, 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1058,6 +1130,15 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
     }
     ctx->file_stats = st;
     ctx->have_file_stats = true;
+    ctx->ingest.total_s = now_s() - t_begin;
+    return PAPR_OK;
+}
+
+int papr_hip_get_ingest_timing(const papr_hip_ctx *ctx, papr_hip_ingest_timing *out)
+{
+    if (!ctx || !out)
+        return PAPR_E_ARG;
+    *out = ctx->ingest;
     return PAPR_OK;
 }
 

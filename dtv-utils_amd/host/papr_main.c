@@ -118,6 +118,7 @@ int main(int argc, char **argv)
     fclose(probe);
 
     const double t0 = now_s();
+    double t_open = t0;
     uint64_t nsamples = 0;
     if (papr_file_samples(path, &nsamples) != PAPR_OK) {
         fprintf(stderr, "Cannot open bitstream file <%s>\n", path);
@@ -166,6 +167,7 @@ int main(int argc, char **argv)
         used++;
     }
     ngpu = used;
+    t_open = now_s();
 
     /* ---- pass 1 on every shard, then fold in file order (papr.c:100-129) ---- */
     if (run_all(sh, ngpu, pass1_thread) != PAPR_OK)
@@ -225,11 +227,18 @@ int main(int argc, char **argv)
     env = getenv("PAPR_STATS");
     if (env && atoi(env) > 0) {
         const double t3 = now_s();
+        papr_hip_ingest_timing it;
+        memset(&it, 0, sizeof(it));
+        papr_hip_get_ingest_timing(sh[0].ctx, &it);
         fprintf(stderr,
-                "{\"samples\": %llu, \"bytes\": %llu, \"gpus\": %d, \"levels\": %d, \"ingest_pass1_s\": %.6f, "
-                "\"pass2_s\": %.6f, \"total_s\": %.6f, \"msamples_per_s\": %.3f}\n",
-                (unsigned long long)nsamples, (unsigned long long)nsamples * 8, ngpu, nlevels, t1 - t0, t2 - t1, t3 - t0,
-                (double)nsamples / (t3 - t0) / 1e6);
+                "{\"samples\": %llu, \"bytes\": %llu, \"gpus\": %d, \"levels\": %d, \"open_s\": %.6f, "
+                "\"ingest_pass1_s\": %.6f, \"pass2_s\": %.6f, \"total_s\": %.6f, \"msamples_per_s\": %.3f, "
+                "\"ingest_GBps\": %.2f, \"gpu0_ingest\": {\"setup_s\": %.4f, \"read_s\": %.4f, \"buffer_wait_s\": %.4f, "
+                "\"issue_s\": %.4f, \"drain_s\": %.4f, \"chunks\": %llu, \"reader_threads\": %d, \"resident\": %d}}\n",
+                (unsigned long long)nsamples, (unsigned long long)nsamples * 8, ngpu, nlevels, t_open - t0, t1 - t_open,
+                t2 - t1, t3 - t0, (double)nsamples / (t3 - t0) / 1e6, (double)nsamples * 8 / (t1 - t_open) / 1e9,
+                it.setup_s, it.read_s, it.buffer_wait_s, it.issue_s, it.drain_s, (unsigned long long)it.chunks,
+                it.reader_threads, it.resident);
     }
 
     for (int g = 0; g < ngpu; g++) {

@@ -83,6 +83,19 @@ typedef struct papr_hip_timing {
     double ccdf_ms;   uint64_t ccdf_launches;   uint64_t ccdf_bytes;
 } papr_hip_timing;
 
+/* Where the wall time of the last papr_hip_load_file went (seconds). */
+typedef struct papr_hip_ingest_timing {
+    double total_s;       /* whole call */
+    double setup_s;       /* staging buffers, shard allocation, reader threads */
+    double read_s;        /* main thread blocked on the file readers */
+    double buffer_wait_s; /* main thread blocked on a pinned buffer still being copied */
+    double issue_s;       /* hipMemcpyAsync / kernel launch calls */
+    double drain_s;       /* final wait for copies + pass-1 kernels + finalize */
+    uint64_t bytes, chunks;
+    int reader_threads;
+    int resident;         /* 1 = shard kept in HBM, 0 = will be re-streamed for pass 2 */
+} papr_hip_ingest_timing;
+
 /* Launch geometry knobs.  0 always means "built-in default" (chosen from the
  * 10 GiB sweeps in DESIGN.md section 6); variant and map fields therefore hold
  * id + 1.  Also settable with the PAPR_HIP_TUNE environment variable, e.g.
@@ -125,6 +138,7 @@ int papr_file_samples(const char *path, uint64_t *nsamples);
  * buffer) is reproduced when the range includes the file's last sample.  The
  * copy to HBM is double-buffered and overlapped with the pass-1 kernel. */
 int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples);
+int papr_hip_get_ingest_timing(const papr_hip_ctx *ctx, papr_hip_ingest_timing *out);
 
 /* Copy nsamples IQ pairs from host memory into the shard. */
 int papr_hip_upload(papr_hip_ctx *ctx, const float *iq, uint64_t nsamples, uint64_t base_index);
