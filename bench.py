@@ -110,12 +110,13 @@ def main():
     gpu.generate(pkg.SynthSpec.spike(total), rank * per_gpu, per_gpu)
 
     result = {}
+    xch = exchange.Exchange(device)
 
     def step():
-        local = gpu.stats()                                         # pass 1 on this shard
-        tot = exchange.merged_stats(local, device)                  # exchange 1 (RCCL all-gather)
-        mean, papr, table = pkg.levels(tot, graph)                  # host scalars
-        counts = exchange.allreduce_counts(gpu.ccdf(table), device) # pass 2 + exchange 2 (RCCL all-reduce)
+        local = gpu.stats()                                  # pass 1 on this shard
+        tot = xch.merged_stats(local)                        # exchange 1 (RCCL all-gather + ordered merge)
+        mean, papr, table = pkg.levels(tot, graph)           # host scalars
+        counts = xch.allreduce_counts(gpu.ccdf(table))       # pass 2 + exchange 2 (RCCL all-reduce)
         result.update(total=tot, mean=mean, papr=papr, table=table, counts=counts)
 
     def fence():

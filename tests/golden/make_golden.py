@@ -83,6 +83,30 @@ def build_fixtures():
     raw_bits[2 * 17 + 1] = 0xFFA00001
     raw("snan", base)
     del snan
+    # producer-side formats: what the GNU Radio flowgraphs that feed papr write —
+    # blocks.file_sink(gr.sizeof_gr_complex) after a constant scale (dvbt-blade.py:189,214 / dvbt2-blade.py:132,159 /
+    # qam-blade.py:59,83).  Seeded numpy stand-ins with the same statistics and amplitude scales.
+    rng = np.random.default_rng(20260928)
+    n = 40000
+    ofdm = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2.0)
+    raw("ofdm_dvbt", np.column_stack([ofdm.real, ofdm.imag]).ravel() * 0.0022097087)
+    # DVB-T2 with PAPR reduction: the envelope is clipped ~8.6 dB above the mean, scale 0.2
+    clip = np.sqrt(10 ** 0.86)
+    mag = np.abs(ofdm)
+    t2 = ofdm * np.minimum(1.0, clip / np.maximum(mag, 1e-30))
+    raw("ofdm_dvbt2_clipped", np.column_stack([t2.real, t2.imag]).ravel() * 0.2)
+    # J.83B 64-QAM through a root-raised-cosine interpolator (x2), roll-off 0.18
+    sym = (rng.integers(0, 8, n // 2) * 2 - 7) + 1j * (rng.integers(0, 8, n // 2) * 2 - 7)
+    up = np.zeros(n, dtype=np.complex128)
+    up[::2] = sym
+    k = np.arange(-44, 45) / 2.0
+    beta = 0.18
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rrc = (np.sin(np.pi * k * (1 - beta)) + 4 * beta * k * np.cos(np.pi * k * (1 + beta))) / \
+              (np.pi * k * (1 - (4 * beta * k) ** 2))
+    rrc[np.isnan(rrc) | np.isinf(rrc)] = 1.0 - beta + 4 * beta / np.pi
+    qam = np.convolve(up, rrc / np.sqrt(np.sum(rrc ** 2)), mode="same") * 0.1
+    raw("qam64_rrc", np.column_stack([qam.real, qam.imag]).ravel())
 
 
 def record(path, graph):
