@@ -8,22 +8,25 @@ PKG     := dtv-utils_amd
 CSRC    := $(PKG)/csrc
 LIB     := $(PKG)/libpaprhip.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-result
-CFLAGS  := -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude
+CFLAGS  := -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude -I$(CSRC)
 
 all: lib cli oracle tools
 
 lib: $(LIB)
 
-$(CSRC)/papr_host.o: $(CSRC)/papr_host.c include/papr_hip.h include/papr_synth.h
+$(CSRC)/papr_host.o: $(CSRC)/papr_host.c $(CSRC)/papr_exact_format.h include/papr_hip.h include/papr_synth.h
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(CSRC)/papr_kernels.o: $(CSRC)/papr_kernels.hip $(CSRC)/papr_kernels.h include/papr_synth.h
+$(CSRC)/papr_kernels.o: $(CSRC)/papr_kernels.hip $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h include/papr_synth.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/papr_runtime.o: $(CSRC)/papr_runtime.cpp $(CSRC)/papr_kernels.h include/papr_hip.h include/papr_synth.h
+$(CSRC)/papr_exact.o: $(CSRC)/papr_exact.hip $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIB): $(CSRC)/papr_kernels.o $(CSRC)/papr_runtime.o $(CSRC)/papr_host.o
+$(CSRC)/papr_runtime.o: $(CSRC)/papr_runtime.cpp $(CSRC)/papr_kernels.h $(CSRC)/papr_exact_format.h include/papr_hip.h include/papr_synth.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(CSRC)/papr_kernels.o $(CSRC)/papr_exact.o $(CSRC)/papr_runtime.o $(CSRC)/papr_host.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -lm -lpthread
 
 cli: bin/papr

@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["default", "graph"], default="default")
     ap.add_argument("--gib", type=float, default=10.0, help="GiB of IQ per GPU")
+    ap.add_argument("--exact", action="store_true",
+                    help="also reproduce the reference's sequential double sum bit for bit every step "
+                         "(one more 8 B/sample pass + a short host chain); off by default")
     ap.add_argument("--cpu-sample-gib", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -112,9 +115,17 @@ def main():
     result = {}
     xch = exchange.Exchange(device)
 
+    if args.exact:
+        gpu.set_exact(True)
+
     def step():
         local = gpu.stats()                                  # pass 1 on this shard
-        tot = xch.merged_stats(local)                        # exchange 1 (RCCL all-gather + ordered merge)
+        parts = xch.allgather_stats(local)                   # exchange 1 (RCCL all-gather)
+        tot = pkg.stats_merge(parts)                         #   + ordered merge, identical on every rank
+        if args.exact and np.isfinite(tot.sum):
+            before = float(sum(p.sum for p in parts[:rank]))
+            progs = xch.allgather_bytes(gpu.exact_program(before, total))
+            tot.sum = pkg.exact_chain(progs)                 # papr.c:104's rounding sequence, bit for bit
         mean, papr, table = pkg.levels(tot, graph)           # host scalars
         counts = xch.allreduce_counts(gpu.ccdf(table))       # pass 2 + exchange 2 (RCCL all-reduce)
         result.update(total=tot, mean=mean, papr=papr, table=table, counts=counts)
@@ -172,6 +183,7 @@ def main():
                                    f"{world}xMI355X",
                        "mode": args.mode, "samples_per_gpu": per_gpu, "samples_total": total,
                        "levels": int(result["table"].size), "papr_db": round(float(result["papr"]), 6),
+                       "exact_sequential_sum": bool(args.exact), "sum_hex": float(result["total"].sum).hex(),
                        "sharding": f"sample axis, {world} contiguous shard(s)",
                        "exchange": "RCCL all-gather(stats) + all-reduce(counts)" if use_dist else "none"},
             "roofline": {"bound": "hbm", "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -182,7 +194,10 @@ def main():
                         "papr_ccdf_kernel": {"avg_ms": k_ccdf, "GB/s": gbs_ccdf, "launches": int(tm.ccdf_launches)},
                         "both_passes_frac_of_peak": (b_stats + b_ccdf) / ((k_stats + k_ccdf) * 1e-3) / 1e9 / HBM_PEAK_GBS
                         if (k_stats + k_ccdf) else 0.0,
-                        "host_and_exchange_ms_per_step": ms_per_step - k_stats - k_ccdf},
+                        "papr_exact_kernels": {"avg_ms": tm.exact_ms / max(tm.exact_launches, 1),
+                                               "launches": int(tm.exact_launches)},
+                        "host_and_exchange_ms_per_step": ms_per_step - k_stats - k_ccdf
+                        - tm.exact_ms / max(tm.exact_launches, 1)},
             "device": gpu.name,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -34,6 +34,7 @@ ABI_SYMBOLS = (
     "papr_hip_get_timing", "papr_file_samples", "papr_hip_load_file", "papr_hip_get_ingest_timing", "papr_hip_upload",
     "papr_hip_adopt", "papr_hip_generate", "papr_hip_download", "papr_hip_stats",
     "papr_stats_init", "papr_stats_merge", "papr_levels", "papr_hip_ccdf",
+    "papr_hip_set_exact", "papr_hip_exact_program", "papr_exact_chain",
 )
 
 
@@ -90,7 +91,8 @@ class Stats(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("stats_ms", C.c_double), ("stats_launches", C.c_uint64), ("stats_bytes", C.c_uint64),
-                ("ccdf_ms", C.c_double), ("ccdf_launches", C.c_uint64), ("ccdf_bytes", C.c_uint64)]
+                ("ccdf_ms", C.c_double), ("ccdf_launches", C.c_uint64), ("ccdf_bytes", C.c_uint64),
+                ("exact_ms", C.c_double), ("exact_launches", C.c_uint64), ("exact_bytes", C.c_uint64)]
 
 
 class IngestTiming(C.Structure):
@@ -155,6 +157,11 @@ def lib() -> C.CDLL:
     L.papr_stats_merge.restype = None
     L.papr_levels.argtypes = [C.POINTER(Stats), i32, C.POINTER(C.c_double), C.POINTER(C.c_float), vp, i32]
     L.papr_hip_ccdf.argtypes = [vp, vp, i32, vp]
+    L.papr_hip_set_exact.argtypes = [vp, i32]
+    L.papr_hip_exact_program.argtypes = [vp, C.c_double, u64, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.papr_exact_chain.argtypes = [C.POINTER(vp), C.POINTER(C.c_size_t), i32, C.POINTER(C.c_double)]
+    for name in ("papr_hip_set_exact", "papr_hip_exact_program", "papr_exact_chain"):
+        getattr(L, name).restype = i32
     for name in ("papr_hip_open", "papr_hip_device_name", "papr_hip_set_tuning", "papr_hip_set_timing",
                  "papr_hip_get_timing", "papr_file_samples", "papr_hip_load_file", "papr_hip_get_ingest_timing", "papr_hip_upload",
                  "papr_hip_adopt", "papr_hip_generate", "papr_hip_download", "papr_hip_stats",
@@ -185,6 +192,21 @@ def levels(total: Stats, graph: bool):
     if n > 0:
         L.papr_levels(C.byref(total), int(graph), None, None, table.ctypes.data_as(C.c_void_p), n)
     return mean.value, papr.value, table
+
+
+def exact_chain(programs: Sequence[bytes]) -> float:
+    """papr_exact_chain: replay the shards' sum programs (file order) into the
+    reference's sequential double sum."""
+    L = lib()
+    n = len(programs)
+    bufs = [C.create_string_buffer(p, len(p)) for p in programs]
+    ptrs = (C.c_void_p * max(n, 1))(*[C.cast(b, C.c_void_p) for b in bufs])
+    sizes = (C.c_size_t * max(n, 1))(*[len(p) for p in programs])
+    out = C.c_double()
+    rc = L.papr_exact_chain(ptrs, sizes, n, C.byref(out))
+    if rc:
+        raise PaprError(rc, "papr_exact_chain", "malformed program" if rc == -3 else "exact-sum invariant violated")
+    return out.value
 
 
 def file_samples(path: str) -> int:
@@ -288,6 +310,17 @@ class PaprHip:
         self._chk(self._L.papr_hip_download(self._ctx, out.ctypes.data_as(C.c_void_p), first, nsamples),
                   "papr_hip_download")
         return out
+
+    # bit-exact mean
+    def set_exact(self, enabled: bool = True):
+        self._chk(self._L.papr_hip_set_exact(self._ctx, int(enabled)), "papr_hip_set_exact")
+
+    def exact_program(self, before: float = 0.0, n_total: int = 0) -> bytes:
+        """This shard's serialised sum program (needs set_exact(True) + stats() first)."""
+        ptr, size = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.papr_hip_exact_program(self._ctx, before, n_total, C.byref(ptr), C.byref(size)),
+                  "papr_hip_exact_program")
+        return C.string_at(ptr, size.value)
 
     # the two passes
     def stats(self) -> Stats:

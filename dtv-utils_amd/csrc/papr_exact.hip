@@ -1,0 +1,310 @@
+// papr_exact.hip — bit-exact emulation of the reference's SEQUENTIAL double
+// accumulator (`sum += value`, papr.c:104) on the GPU.
+//
+// Why it is parallelisable.  All terms are >= 0, so the running sum S only
+// grows.  While S stays inside one binade [2^E, 2^(E+1)) its ulp is the fixed
+// u = 2^(E-52), and fl(S + v) = S + u * round_half_even(v / u) where the
+// half-way case is resolved by the parity of S/u ALONE.  So "add v" acts on S as
+// a function that depends on S only through one bit, and a whole run of
+// additions inside a binade collapses to a pair (D0, D1): the total increment
+// for even / odd entry parity.  Pairs compose associatively
+//     (f then g)(p) = f.D[p] + g.D[p ^ lsb(f.D[p] / u)],
+// so they can be built per lane and merged in file order by an ordered tree.
+//
+// How a lane gets its pair without any integer rounding logic: it runs the
+// additions themselves, in double, from the two canonical entry states
+// M0 = 2^E (even) and M1 = 2^E + u (odd).  The hardware's round-to-nearest-even
+// then does exactly what it would do to the real S, as long as the lane's own
+// total stays far below 2^E — which the tile classification guarantees.
+//
+// What cannot be collapsed: the additions during which S changes binade.  Pass 1
+// (papr_stats_kernel<..., TSUM>) leaves a sum per 2048-sample tile; a scan gives
+// each tile an accurate prefix P, and a tile is "safe" for binade E only if
+// [P(1-d), (P+s)(1+d)] lies inside [2^E, 2^(E+1)) with margin d >= the worst-case
+// drift of a sequential sum (and s <= 2^(E-2)).  The few tiles that are not
+// provably safe (one or two per binade crossing, plus the very first tiles) are
+// shipped raw and added one by one on the host, which also chains everything
+// (papr_exact_chain in papr_host.c) — a few thousand dependent operations.
+//
+// Kernels:  papr_exact_block_sums -> papr_exact_scan_blocks -> papr_exact_classify
+//           papr_exact_seg_kernel   (8 B/sample HBM read; LDS transpose so that each
+//                                    lane owns 16 CONSECUTIVE samples)
+//           papr_exact_group_kernel (pre-composes 128-tile groups)
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "papr_kernels.h"
+#include "papr_device.h"
+
+namespace {
+
+constexpr int kTilesPerBlock = 1024;  // classification workgroup: 256 threads x 4 tiles
+constexpr int kSegF4 = PAPR_EXACT_SEG_SAMPLES / 2;  // float4 slots per segment (512)
+constexpr int kRows = kSegF4 / kWave;               // 16-byte loads per lane per segment (8)
+constexpr int kRunStride = kRows + 1;               // LDS run stride in float4: 8 data + 1 pad
+
+__device__ __forceinline__ double two_pow(int e)  // 2^e for normal results
+{
+    return __longlong_as_double((long long)(e + 1023) << 52);
+}
+
+__device__ __forceinline__ double tile_sum_of(const double *tws, uint64_t tile)
+{
+    const double *p = tws + tile * PAPR_EXACT_TILE_WAVES;
+    return ((p[0] + p[1]) + p[2]) + p[3];
+}
+
+// (f then g) for entry parity 0 / 1; m0 = 2^E
+struct Pair {
+    double d0, d1;
+};
+
+__device__ __forceinline__ Pair compose(Pair f, Pair g, double m0)
+{
+    const int q0 = __double2loint(m0 + f.d0) & 1;        // parity after f from an even entry
+    const int q1 = (__double2loint(m0 + f.d1) & 1) ^ 1;  // ... from an odd entry
+    Pair h;
+    h.d0 = f.d0 + (q0 ? g.d1 : g.d0);
+    h.d1 = f.d1 + (q1 ? g.d1 : g.d0);
+    return h;
+}
+
+// ordered merge of the 64 lanes' pairs (lane order = file order); result in lane 0
+__device__ __forceinline__ Pair wave_compose(Pair f, double m0)
+{
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        Pair g;
+        g.d0 = __shfl_down(f.d0, off, kWave);
+        g.d1 = __shfl_down(f.d1, off, kWave);
+        f = compose(f, g, m0);  // only lanes that are multiples of 2*off stay meaningful
+    }
+    return f;
+}
+
+}  // namespace
+
+// ---- tile prefix sums and classification ------------------------------------------
+
+__global__ __launch_bounds__(256) void papr_exact_block_sums(const double *__restrict__ tws, uint64_t ntiles,
+                                                              double *__restrict__ block_sums)
+{
+    __shared__ double sh[256];
+    const uint64_t t0 = (uint64_t)blockIdx.x * kTilesPerBlock + (uint64_t)threadIdx.x * 4;
+    double s = 0.0;
+    for (int k = 0; k < 4; k++)
+        if (t0 + k < ntiles)
+            s += tile_sum_of(tws, t0 + k);
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int k = 0; k < 256; k++)
+            tot += sh[k];
+        block_sums[blockIdx.x] = tot;
+    }
+}
+
+// in-place exclusive scan of the block sums, starting from `before` (the accurate
+// sum of everything that precedes this shard in the file)
+__global__ __launch_bounds__(256) void papr_exact_scan_blocks(double *__restrict__ block_sums, uint32_t nblocks,
+                                                               double before)
+{
+    __shared__ double sh[256];
+    const uint32_t per = (nblocks + 255) / 256;
+    const uint32_t a = threadIdx.x * per, e = min(a + per, nblocks);
+    double s = 0.0;
+    for (uint32_t k = a; k < e; k++)
+        s += block_sums[k];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = before;
+        for (int k = 0; k < 256; k++) {
+            const double v = sh[k];
+            sh[k] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    double run = sh[threadIdx.x];
+    for (uint32_t k = a; k < e; k++) {
+        const double v = block_sums[k];
+        block_sums[k] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(256) void papr_exact_classify(const double *__restrict__ tws, uint64_t ntiles,
+                                                            const double *__restrict__ block_prefix, double delta,
+                                                            int32_t *__restrict__ tile_E)
+{
+    __shared__ double sh[256];
+    const uint64_t t0 = (uint64_t)blockIdx.x * kTilesPerBlock + (uint64_t)threadIdx.x * 4;
+    double s[4], tot = 0.0;
+    for (int k = 0; k < 4; k++) {
+        s[k] = t0 + k < ntiles ? tile_sum_of(tws, t0 + k) : 0.0;
+        tot += s[k];
+    }
+    sh[threadIdx.x] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = block_prefix[blockIdx.x];
+        for (int k = 0; k < 256; k++) {
+            const double v = sh[k];
+            sh[k] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    double P = sh[threadIdx.x];
+    for (int k = 0; k < 4; k++) {
+        if (t0 + k >= ntiles)
+            break;
+        int32_t cls = PAPR_EXACT_AMBIG;
+        const double sk = s[k];
+        if (sk == 0.0) {
+            cls = PAPR_EXACT_ZERO;  // sum of non-negative terms is +0 only if every term is +0
+        } else if (sk > 0.0 && sk < 1.0e300 && P > 0.0 && P < 1.0e300) {
+            const int biased = (int)((__double_as_longlong(P) >> 52) & 0x7ff);
+            const int E = biased - 1023;
+            if (biased != 0 && E >= -960) {
+                const double m0 = two_pow(E);
+                const double lo = P * (1.0 - delta), hi = (P + sk) * (1.0 + delta);
+                if (lo >= m0 && hi < 2.0 * m0 && sk <= 0.25 * m0)
+                    cls = E;
+            }
+        }
+        tile_E[t0 + k] = cls;
+        P += sk;
+    }
+}
+
+// ---- per-segment rounding functions --------------------------------------------------
+// One wave per 1024-sample segment.  Coalesced 16-byte loads, then a padded LDS
+// transpose so that lane l holds samples 16 l .. 16 l + 15 of the segment, in order.
+__global__ __launch_bounds__(256) void papr_exact_seg_kernel(const float4 *__restrict__ data, uint64_t nsegs,
+                                                              const int32_t *__restrict__ tile_E,
+                                                              double2 *__restrict__ seg_D)
+{
+    __shared__ float4 lds[256 / kWave][kWave * kRunStride];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint64_t nwaves = (uint64_t)gridDim.x * (256 / kWave);
+    for (uint64_t seg = (uint64_t)blockIdx.x * (256 / kWave) + wave; seg < nsegs; seg += nwaves) {
+        const int E = __builtin_amdgcn_readfirstlane(tile_E[seg >> 1]);
+        if (E == PAPR_EXACT_AMBIG || E == PAPR_EXACT_ZERO)
+            continue;  // handled raw on the host / cannot change the sum
+        const float4 *p = data + seg * kSegF4 + lane;
+        float4 x[kRows];
+#pragma unroll
+        for (int r = 0; r < kRows; r++)
+            x[r] = load16<true>(p + r * kWave);
+#pragma unroll
+        for (int r = 0; r < kRows; r++) {
+            const int f = r * kWave + lane;  // float4 slot within the segment, file order
+            lds[wave][(f >> 3) * kRunStride + (f & 7)] = x[r];
+        }
+        // same wave wrote and reads: LDS operations of one wave complete in order
+        const double m0 = two_pow(E), m1 = m0 + two_pow(E - 52);
+        double x0 = m0, x1 = m1;
+#pragma unroll
+        for (int k = 0; k < kRows; k++) {
+            const float4 y = lds[wave][lane * kRunStride + k];
+            const double v0 = (double)power_of(y.x, y.y);
+            const double v1 = (double)power_of(y.z, y.w);
+            x0 += v0;
+            x1 += v0;
+            x0 += v1;
+            x1 += v1;
+        }
+        Pair f;
+        f.d0 = x0 - m0;  // exact: multiples of u inside the binade
+        f.d1 = x1 - m1;
+        f = wave_compose(f, m0);
+        if (lane == 0)
+            seg_D[seg] = make_double2(f.d0, f.d1);
+    }
+}
+
+// ---- pre-composition of 128-tile groups -------------------------------------------------
+// One wave per group: if every non-zero tile of the group is safe in the SAME binade the
+// group collapses to one pair, otherwise it is flagged for tile-by-tile handling on the host.
+__global__ __launch_bounds__(256) void papr_exact_group_kernel(const int32_t *__restrict__ tile_E, uint64_t ntiles,
+                                                                const double2 *__restrict__ seg_D, uint64_t ngroups,
+                                                                papr_exact_group *__restrict__ out)
+{
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint64_t g = (uint64_t)blockIdx.x * (256 / kWave) + wave;
+    if (g >= ngroups)
+        return;
+    const uint64_t tile0 = g * PAPR_EXACT_GROUP_TILES + 2 * (uint64_t)lane;
+    int32_t e[2];
+    e[0] = tile0 < ntiles ? tile_E[tile0] : PAPR_EXACT_ZERO;
+    e[1] = tile0 + 1 < ntiles ? tile_E[tile0 + 1] : PAPR_EXACT_ZERO;
+    const bool bad = e[0] == PAPR_EXACT_AMBIG || e[1] == PAPR_EXACT_AMBIG ||
+                     (e[0] != PAPR_EXACT_ZERO && e[1] != PAPR_EXACT_ZERO && e[0] != e[1]);
+    const int32_t mine = e[0] != PAPR_EXACT_ZERO ? e[0] : e[1];
+    const unsigned long long has = __ballot(mine != PAPR_EXACT_ZERO);
+    papr_exact_group rec;
+    rec.E = PAPR_EXACT_ZERO;
+    rec.pad = 0;
+    rec.D0 = rec.D1 = 0.0;
+    if (has != 0) {
+        const int first = __ffsll((long long)has) - 1;
+        const int32_t Eg = __shfl(mine, first, kWave);
+        const bool mixed = __any(bad || (mine != PAPR_EXACT_ZERO && mine != Eg));
+        if (mixed) {
+            rec.E = PAPR_EXACT_AMBIG;
+        } else {
+            const double m0 = two_pow(Eg);
+            Pair f = {0.0, 0.0};
+            for (int k = 0; k < 4; k++) {
+                if (e[k >> 1] == PAPR_EXACT_ZERO)
+                    continue;
+                const double2 d = seg_D[2 * tile0 + k];
+                Pair gk = {d.x, d.y};
+                f = compose(f, gk, m0);
+            }
+            f = wave_compose(f, m0);
+            rec.E = Eg;
+            rec.D0 = f.d0;
+            rec.D1 = f.d1;
+        }
+    }
+    if (lane == 0)
+        out[g] = rec;
+}
+
+// ---- launch wrappers -------------------------------------------------------------------------
+
+void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, uint64_t ntiles, double *block_sums,
+                                double before, double delta, int32_t *tile_E)
+{
+    const uint32_t nb = (uint32_t)((ntiles + kTilesPerBlock - 1) / kTilesPerBlock);
+    if (nb == 0)
+        return;
+    hipLaunchKernelGGL(papr_exact_block_sums, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums);
+    hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before);
+    hipLaunchKernelGGL(papr_exact_classify, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums, delta,
+                       tile_E);
+}
+
+void papr_launch_exact_segments(hipStream_t st, int blocks, const void *data, uint64_t nsegs, const int32_t *tile_E,
+                                void *seg_D)
+{
+    if (nsegs == 0)
+        return;
+    hipLaunchKernelGGL(papr_exact_seg_kernel, dim3(blocks), dim3(256), 0, st, (const float4 *)data, nsegs, tile_E,
+                       (double2 *)seg_D);
+}
+
+void papr_launch_exact_groups(hipStream_t st, const int32_t *tile_E, uint64_t ntiles, const void *seg_D,
+                              uint64_t ngroups, papr_exact_group *out)
+{
+    if (ngroups == 0)
+        return;
+    const uint32_t nb = (uint32_t)((ngroups + 3) / 4);
+    hipLaunchKernelGGL(papr_exact_group_kernel, dim3(nb), dim3(256), 0, st, tile_E, ntiles, (const double2 *)seg_D,
+                       ngroups, out);
+}

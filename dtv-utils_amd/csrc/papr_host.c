@@ -13,6 +13,7 @@
 #include <string.h>
 #include <sys/stat.h>
 
+#include "papr_exact_format.h"
 #include "papr_hip.h"
 
 int papr_hip_abi_version(void)
@@ -108,5 +109,103 @@ int papr_file_samples(const char *path, uint64_t *nsamples)
         return PAPR_E_IO;
     const uint64_t nfloats = (uint64_t)sb.st_size / 4;
     *nsamples = (nfloats + 1) / 2; /* an odd float count still yields a (phantom) sample, papr.c:102 */
+    return PAPR_OK;
+}
+
+/* ---- exact sequential sum: the host end of papr_exact.hip -------------------
+ * Replays papr.c:104 (`sum += value`, double, file order) from the per-shard sum
+ * programs: whole groups / segments of additions that provably stay inside one
+ * binade are applied as one exact increment chosen by the parity of the running
+ * sum's last mantissa bit; everything else is added sample by sample, exactly as
+ * the reference does it. */
+
+static int binade_of(double s)
+{
+    uint64_t b;
+    memcpy(&b, &s, 8);
+    const int biased = (int)((b >> 52) & 0x7ff);
+    return (biased == 0 || biased == 0x7ff) ? INT_MIN : biased - 1023;
+}
+
+/* S += D[parity of S's last mantissa bit]; both S and the result must lie in binade E */
+static int apply_pair(double *S, int E, double D0, double D1)
+{
+    uint64_t b;
+    if (binade_of(*S) != E)
+        return -1;
+    memcpy(&b, S, 8);
+    *S += (b & 1u) ? D1 : D0;
+    return binade_of(*S) == E ? 0 : -1;
+}
+
+static void add_raw(double *S, const float *iq, uint64_t nsamples)
+{
+    double acc = *S;
+    for (uint64_t k = 0; k < nsamples; k++) {
+        const float re = iq[2 * k], im = iq[2 * k + 1];
+        const float re2 = re * re, im2 = im * im; /* separate roundings, no FMA (papr.c:103) */
+        const float pw = re2 + im2;
+        acc += pw;
+    }
+    *S = acc;
+}
+
+int papr_exact_chain(const void *const *programs, const size_t *bytes, int nprograms, double *sum_out)
+{
+    if (!programs || !bytes || !sum_out || nprograms < 0)
+        return PAPR_E_ARG;
+    double S = 0.0;
+    for (int k = 0; k < nprograms; k++) {
+        const unsigned char *p = (const unsigned char *)programs[k], *end = p + bytes[k];
+        papr_exact_header h;
+        if (!p || bytes[k] < sizeof(h))
+            return PAPR_E_ARG;
+        memcpy(&h, p, sizeof(h));
+        p += sizeof(h);
+        if (h.magic != PAPR_EXACT_MAGIC || h.version != PAPR_EXACT_VERSION)
+            return PAPR_E_ARG;
+        const uint64_t need = h.ngroups * sizeof(papr_exact_group_rec) + (uint64_t)h.nmixed * sizeof(papr_exact_mixed_rec) +
+                              (uint64_t)h.nraw * sizeof(papr_exact_raw_rec) + (uint64_t)h.tail_samples * 8;
+        if ((uint64_t)(end - p) < need)
+            return PAPR_E_ARG;
+        const papr_exact_group_rec *groups = (const papr_exact_group_rec *)p;
+        const papr_exact_mixed_rec *mixed = (const papr_exact_mixed_rec *)(groups + h.ngroups);
+        const papr_exact_raw_rec *raw = (const papr_exact_raw_rec *)(mixed + h.nmixed);
+        const float *tail = (const float *)(raw + h.nraw);
+        uint32_t mi = 0, ri = 0;
+        for (uint64_t g = 0; g < h.ngroups; g++) {
+            const papr_exact_group_rec *gr = &groups[g];
+            if (gr->E == PAPR_XF_ZERO)
+                continue;
+            if (gr->E != PAPR_XF_AMBIG) {
+                if (apply_pair(&S, gr->E, gr->D0, gr->D1))
+                    return PAPR_E_INTERNAL;
+                continue;
+            }
+            if (mi >= h.nmixed || mixed[mi].group != g)
+                return PAPR_E_ARG;
+            const papr_exact_mixed_rec *m = &mixed[mi++];
+            for (uint64_t j = 0; j < PAPR_XF_GROUP_TILES; j++) {
+                const uint64_t tile = g * PAPR_XF_GROUP_TILES + j;
+                if (tile >= h.ntiles)
+                    break;
+                const int32_t e = m->tile_E[j];
+                if (e == PAPR_XF_ZERO)
+                    continue;
+                if (e == PAPR_XF_AMBIG) {
+                    if (ri >= h.nraw || raw[ri].tile != tile)
+                        return PAPR_E_ARG;
+                    add_raw(&S, raw[ri++].iq, PAPR_XF_TILE_SAMPLES);
+                } else if (apply_pair(&S, e, m->seg_D[2 * j][0], m->seg_D[2 * j][1]) ||
+                           apply_pair(&S, e, m->seg_D[2 * j + 1][0], m->seg_D[2 * j + 1][1])) {
+                    return PAPR_E_INTERNAL;
+                }
+            }
+        }
+        if (mi != h.nmixed || ri != h.nraw)
+            return PAPR_E_ARG;
+        add_raw(&S, tail, h.tail_samples);
+    }
+    *sum_out = S;
     return PAPR_OK;
 }

@@ -18,6 +18,17 @@
 #define PAPR_BLOCK 256
 #define PAPR_TILE_SAMPLES_MAX 8192
 
+// Exact-sum mode geometry (papr_exact.hip): pass 1 runs as 256 threads x 4
+// loads, i.e. tiles of 2048 samples (16 KiB) with 4 per-wave sums each; the
+// rounding-function kernel works on segments of half a tile (one wave, 16
+// samples per lane); segment functions are pre-composed in groups of 128 tiles.
+#define PAPR_EXACT_TILE_SAMPLES 2048
+#define PAPR_EXACT_TILE_WAVES 4
+#define PAPR_EXACT_SEG_SAMPLES 1024
+#define PAPR_EXACT_GROUP_TILES 128
+#define PAPR_EXACT_AMBIG (-2147483647 - 1) /* tile_E: entry binade not provable, or the tile crosses a binade */
+#define PAPR_EXACT_ZERO (-2147483647)      /* tile_E: every power in the tile is +0: the running sum cannot change */
+
 #define PAPR_MAP_GRID_STRIDE 0
 #define PAPR_MAP_BLOCK_SPAN 1
 #define PAPR_MAP_XCD_SPAN 2
@@ -43,9 +54,25 @@ struct papr_ccdf_params {
     uint32_t search_step; // search: largest power of two <= nkeys
 };
 
+// exact-sum mode: one pre-composed group of PAPR_EXACT_GROUP_TILES tiles
+struct papr_exact_group {
+    int32_t E;     // binade of the running sum throughout the group, PAPR_EXACT_ZERO, or PAPR_EXACT_AMBIG (= mixed)
+    int32_t pad;
+    double D0, D1; // total increment for even / odd entry parity
+};
+
+void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, uint64_t ntiles, double *block_sums,
+                                double before, double delta, int32_t *tile_E);
+void papr_launch_exact_segments(hipStream_t st, int blocks, const void *data, uint64_t nsegs, const int32_t *tile_E,
+                                void *seg_D);
+void papr_launch_exact_groups(hipStream_t st, const int32_t *tile_E, uint64_t ntiles, const void *seg_D,
+                              uint64_t ngroups, papr_exact_group *out);
+
 int papr_variant_geometry(int variant, int *block, int *unroll); /* 0, or -1 for an unknown variant */
 void papr_launch_stats(hipStream_t st, int variant, int blocks, bool nt, const void *data, uint64_t ntiles,
                        uint64_t base_index, int map, papr_partial *out);
+void papr_launch_stats_tilesums(hipStream_t st, int blocks, const void *data, uint64_t ntiles, uint64_t base_index,
+                                int map, papr_partial *out, double *tile_sums, uint64_t tile_offset);
 void papr_launch_stats_finalize(hipStream_t st, const void *tail, uint32_t tail_samples, uint64_t tail_base_index,
                                 const papr_partial *partials, uint32_t npartials, papr_partial *result);
 void papr_launch_first_nan(hipStream_t st, int blocks, const void *data, uint64_t nsamples, uint64_t base_index,

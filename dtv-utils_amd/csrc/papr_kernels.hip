@@ -22,27 +22,9 @@
 #include <stdint.h>
 
 #include "papr_kernels.h"
+#include "papr_device.h"
 
 namespace {
-
-constexpr int kWave = 64;
-
-__device__ __forceinline__ float power_of(float re, float im)
-{
-    return __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
-}
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// one global_load_dwordx4 per lane (optionally with the nontemporal hint: the
-// shard is streamed exactly once per pass, nothing is worth keeping in L2/MALL)
-template <bool NT>
-__device__ __forceinline__ float4 load16(const float4 *p)
-{
-    const f32x4 *q = reinterpret_cast<const f32x4 *>(p);
-    const f32x4 v = NT ? __builtin_nontemporal_load(q) : *q;
-    return make_float4(v.x, v.y, v.z, v.w);
-}
 
 // Which tiles a workgroup walks, and in what order.  Every mapping visits a
 // lane's samples in increasing index order, which is what makes the per-lane
@@ -200,15 +182,22 @@ struct StatsRegs {
     uint32_t c_pk, c_rp, c_rn, c_ip, c_in;
 };
 
-template <int U>
-__device__ __forceinline__ void stats_fold(StatsRegs &r, const float4 (&x)[U], uint32_t code)
+// TSUM: also return this iteration's per-lane sum (the exact-sum path needs a sum per tile)
+template <int U, bool TSUM>
+__device__ __forceinline__ double stats_fold(StatsRegs &r, const float4 (&x)[U], uint32_t code)
 {
+    double it_sum = 0.0;
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const float p0 = power_of(x[u].x, x[u].y);
         const float p1 = power_of(x[u].z, x[u].w);
-        r.sum += (double)p0;
-        r.sum += (double)p1;
+        if constexpr (TSUM) {
+            it_sum += (double)p0;
+            it_sum += (double)p1;
+        } else {
+            r.sum += (double)p0;
+            r.sum += (double)p1;
+        }
         const uint32_t c0 = code + 2 * u, c1 = c0 + 1;
         track<false>(p0, c0, r.v_pk, r.c_pk);
         track<false>(p1, c1, r.v_pk, r.c_pk);
@@ -221,6 +210,9 @@ __device__ __forceinline__ void stats_fold(StatsRegs &r, const float4 (&x)[U], u
         track<true>(x[u].y, c0, r.v_in, r.c_in);
         track<true>(x[u].w, c1, r.v_in, r.c_in);
     }
+    if constexpr (TSUM)
+        r.sum += it_sum;
+    return it_sum;
 }
 
 template <int BLOCK, int U, bool NT>
@@ -233,14 +225,26 @@ __device__ __forceinline__ void load_tile(float4 (&x)[U], const float4 *p)
 
 }  // namespace
 
-template <int BLOCK, int U, bool NT, bool PIPE>
+// TSUM (exact-sum mode): every wave also stores the sum of its lanes' samples of
+// each tile, tile_sums[(tile_offset + tile) * (BLOCK/64) + wave]; the waves of a
+// workgroup together cover the tile, so those BLOCK/64 numbers add up to the
+// tile's sum (papr_exact.hip turns them into per-tile prefix sums).
+template <int BLOCK, int U, bool NT, bool PIPE, bool TSUM = false>
 __global__ __launch_bounds__(BLOCK) void papr_stats_kernel(const float4 *__restrict__ data, uint64_t ntiles,
                                                             uint64_t base_index, int map,
-                                                            papr_partial *__restrict__ out)
+                                                            papr_partial *__restrict__ out,
+                                                            double *__restrict__ tile_sums, uint64_t tile_offset)
 {
     constexpr uint64_t TILE_F4 = (uint64_t)BLOCK * U;
     const uint32_t t = threadIdx.x;
     const TileWalk w = tile_walk(blockIdx.x, gridDim.x, ntiles, map);
+    auto emit_tile_sum = [&](uint32_t it, double lane_sum) {
+        if constexpr (TSUM) {
+            const double ws = wave_reduce_sum(lane_sum);
+            if ((t & (kWave - 1)) == 0)
+                tile_sums[(tile_offset + w.first + (uint64_t)it * w.stride) * (BLOCK / kWave) + t / kWave] = ws;
+        }
+    };
 
     StatsRegs r = {0.0, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0, 0, 0, 0};
     const float4 *p = data + w.first * TILE_F4 + t;
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(BLOCK) void papr_stats_kernel(const float4 *__restr
             p += step;
             if (it + 1 < w.count)
                 load_tile<BLOCK, U, NT>(nxt, p);
-            stats_fold<U>(r, cur, code);
+            emit_tile_sum(it, stats_fold<U, TSUM>(r, cur, code));
 #pragma unroll
             for (int u = 0; u < U; u++)
                 cur[u] = nxt[u];
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(BLOCK) void papr_stats_kernel(const float4 *__restr
         for (uint32_t it = 0; it < w.count; it++, p += step, code += 2 * U) {
             float4 x[U];
             load_tile<BLOCK, U, NT>(x, p);
-            stats_fold<U>(r, x, code);
+            emit_tile_sum(it, stats_fold<U, TSUM>(r, x, code));
         }
     }
 
@@ -536,18 +540,27 @@ void papr_launch_stats(hipStream_t st, int variant, int blocks, bool nt, const v
 {
     if (variant == 0 && !nt) {
         hipLaunchKernelGGL((papr_stats_kernel<256, 8, false, false>), dim3(blocks), dim3(256), 0, st,
-                           (const float4 *)data, ntiles, base_index, map, out);
+                           (const float4 *)data, ntiles, base_index, map, out, (double *)nullptr, (uint64_t)0);
         return;
     }
     switch (variant) {
 #define X(V, B, U, P)                                                                                               \
     case V:                                                                                                          \
         hipLaunchKernelGGL((papr_stats_kernel<B, U, true, P>), dim3(blocks), dim3(B), 0, st, (const float4 *)data,   \
-                           ntiles, base_index, map, out);                                                            \
+                           ntiles, base_index, map, out, (double *)nullptr, (uint64_t)0);                            \
         break;
         PAPR_FOR_EACH_VARIANT(X)
 #undef X
     }
+}
+
+// exact-sum mode: fixed geometry (PAPR_EXACT_TILE_SAMPLES per tile, 4 waves), per-wave tile sums stored
+void papr_launch_stats_tilesums(hipStream_t st, int blocks, const void *data, uint64_t ntiles, uint64_t base_index,
+                                int map, papr_partial *out, double *tile_sums, uint64_t tile_offset)
+{
+    static_assert(2 * 256 * 4 == PAPR_EXACT_TILE_SAMPLES, "exact-sum tile geometry");
+    hipLaunchKernelGGL((papr_stats_kernel<256, 4, true, true, true>), dim3(blocks), dim3(256), 0, st,
+                       (const float4 *)data, ntiles, base_index, map, out, tile_sums, tile_offset);
 }
 
 void papr_launch_stats_finalize(hipStream_t st, const void *tail, uint32_t tail_samples, uint64_t tail_base_index,

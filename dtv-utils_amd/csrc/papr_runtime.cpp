@@ -8,6 +8,7 @@
 // folds a handful of scalars.
 
 #include "papr_hip.h"
+#include "papr_exact_format.h"
 #include "papr_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -178,6 +179,18 @@ struct papr_hip_ctx {
     ReaderPool *pool = nullptr;
     int reader_threads = 0;
 
+    // exact-sum mode (papr_exact.hip)
+    bool exact = false;
+    bool exact_valid = false;        // tile sums of the current shard are on the device
+    uint64_t exact_tiles_cap = 0;
+    double *d_tile_sums = nullptr;   // ntiles x 4 per-wave sums
+    double *d_block_sums = nullptr;
+    int32_t *d_tile_E = nullptr;
+    double *d_seg_D = nullptr;       // 2 x ntiles pairs
+    papr_exact_group *d_groups = nullptr;
+    unsigned char *h_program = nullptr;  // pinned
+    size_t h_program_cap = 0;
+
     papr_hip_ingest_timing ingest{};
     papr_hip_tuning tune{};
     bool timing = false;
@@ -255,6 +268,8 @@ enum Pass { PASS1 = 0, PASS2 = 1 };
 
 int variant_of(const papr_hip_ctx *ctx, Pass p)
 {
+    if (p == PASS1 && ctx->exact)
+        return 1;  // 256 x 4 pipelined: the geometry papr_launch_stats_tilesums is built for
     const int v = (p == PASS1 ? ctx->tune.stats_variant : ctx->tune.ccdf_variant) - 1;
     int b, u;
     if (v >= 0 && papr_variant_geometry(v, &b, &u) == 0)
@@ -344,6 +359,8 @@ void release_shard(papr_hip_ctx *ctx)
     ctx->cap = ctx->n = ctx->base = 0;
     ctx->loaded = ctx->resident = false;
     ctx->have_file_stats = false;
+    ctx->exact_valid = false;
+    ctx->exact_valid = false;
     ctx->shard_flags = 0;
     ctx->path.clear();
 }
@@ -389,6 +406,31 @@ void time_end(papr_hip_ctx *ctx)
     ctx->timed_used++;
 }
 
+// exact-sum mode: device buffers sized for the current shard
+int ensure_exact_buffers(papr_hip_ctx *ctx)
+{
+    const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
+    if (ntiles <= ctx->exact_tiles_cap && ctx->d_tile_sums)
+        return PAPR_OK;
+    if (ctx->d_tile_sums) (void)hipFree(ctx->d_tile_sums);
+    if (ctx->d_block_sums) (void)hipFree(ctx->d_block_sums);
+    if (ctx->d_tile_E) (void)hipFree(ctx->d_tile_E);
+    if (ctx->d_seg_D) (void)hipFree(ctx->d_seg_D);
+    if (ctx->d_groups) (void)hipFree(ctx->d_groups);
+    ctx->d_tile_sums = ctx->d_block_sums = ctx->d_seg_D = nullptr;
+    ctx->d_tile_E = nullptr;
+    ctx->d_groups = nullptr;
+    ctx->exact_tiles_cap = 0;
+    const uint64_t cap = std::max<uint64_t>(ntiles, 1024);
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_tile_sums, cap * PAPR_EXACT_TILE_WAVES * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_block_sums, (cap / 1024 + 2) * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_tile_E, cap * sizeof(int32_t)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_seg_D, cap * 2 * 2 * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_groups, (cap / PAPR_EXACT_GROUP_TILES + 2) * sizeof(papr_exact_group)));
+    ctx->exact_tiles_cap = cap;
+    return PAPR_OK;
+}
+
 // ---- pass 1 over device-resident samples -------------------------------------
 // Launches the streaming kernel over the full tiles of [data, data + n) and
 // returns how many partial records it appended at d_partials + slot.
@@ -403,8 +445,16 @@ int launch_stats_range(papr_hip_ctx *ctx, const float *data, uint64_t n, uint64_
     int blocks = pick_blocks(ctx, PASS1, ntiles);
     const int map = effective_map(ctx, PASS1, blocks);
     time_begin(ctx, 0, ntiles * tile * 8);
-    papr_launch_stats(ctx->stream, variant_of(ctx, PASS1), blocks, use_nt(ctx), data, ntiles, base_index, map,
-                      ctx->d_partials + slot);
+    if (ctx->exact) {
+        int rc = ensure_exact_buffers(ctx);
+        if (rc)
+            return rc;
+        papr_launch_stats_tilesums(ctx->stream, blocks, data, ntiles, base_index, map, ctx->d_partials + slot,
+                                   ctx->d_tile_sums, (base_index - ctx->base) / PAPR_EXACT_TILE_SAMPLES);
+    } else {
+        papr_launch_stats(ctx->stream, variant_of(ctx, PASS1), blocks, use_nt(ctx), data, ntiles, base_index, map,
+                          ctx->d_partials + slot);
+    }
     time_end(ctx);
     HIPCHK(ctx, hipGetLastError());
     *nrecords = blocks;
@@ -910,6 +960,12 @@ void papr_hip_close(papr_hip_ctx *ctx)
         if (ctx->ev_kernel[b]) (void)hipEventDestroy(ctx->ev_kernel[b]);
     }
     if (ctx->d_tail) (void)hipFree(ctx->d_tail);
+    if (ctx->d_tile_sums) (void)hipFree(ctx->d_tile_sums);
+    if (ctx->d_block_sums) (void)hipFree(ctx->d_block_sums);
+    if (ctx->d_tile_E) (void)hipFree(ctx->d_tile_E);
+    if (ctx->d_seg_D) (void)hipFree(ctx->d_seg_D);
+    if (ctx->d_groups) (void)hipFree(ctx->d_groups);
+    if (ctx->h_program) (void)hipHostFree(ctx->h_program);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->d_hist) (void)hipFree(ctx->d_hist);
@@ -965,7 +1021,11 @@ int papr_hip_get_timing(papr_hip_ctx *ctx, papr_hip_timing *out)
     for (size_t k = 0; k < ctx->timed_used; k++) {
         float ms = 0.f;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->timed[k].a, ctx->timed[k].b));
-        if (ctx->timed[k].kind == 0) {
+        if (ctx->timed[k].kind == 2) {
+            out->exact_ms += ms;
+            out->exact_launches++;
+            out->exact_bytes += ctx->timed[k].bytes;
+        } else if (ctx->timed[k].kind == 0) {
             out->stats_ms += ms;
             out->stats_launches++;
             out->stats_bytes += ctx->timed[k].bytes;
@@ -1012,6 +1072,7 @@ int papr_hip_upload(papr_hip_ctx *ctx, const float *iq, uint64_t nsamples, uint6
     ctx->base = base_index;
     ctx->loaded = ctx->resident = true;
     ctx->have_file_stats = false;
+    ctx->exact_valid = false;
     ctx->shard_flags = 0;
     ctx->path.clear();
     return PAPR_OK;
@@ -1037,6 +1098,7 @@ int papr_hip_generate(papr_hip_ctx *ctx, const papr_synth_spec *spec, uint64_t f
     ctx->base = first_index;
     ctx->loaded = ctx->resident = true;
     ctx->have_file_stats = false;
+    ctx->exact_valid = false;
     ctx->shard_flags = 0;
     ctx->path.clear();
     return PAPR_OK;
@@ -1089,6 +1151,7 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
     ctx->resident = fits;
     ctx->loaded = true;
     ctx->have_file_stats = false;
+    ctx->exact_valid = false;
     ctx->shard_flags = (fs.odd && first_sample + nsamples == fs.nsamples && nsamples > 0) ? PAPR_FLAG_ODD_TAIL : 0;
 
     ctx->ingest.setup_s = now_s() - t_begin;
@@ -1130,6 +1193,7 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
     }
     ctx->file_stats = st;
     ctx->have_file_stats = true;
+    ctx->exact_valid = ctx->exact && ctx->resident;
     ctx->ingest.total_s = now_s() - t_begin;
     return PAPR_OK;
 }
@@ -1175,6 +1239,125 @@ int papr_hip_stats(papr_hip_ctx *ctx, papr_stats *out)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         apply_nan_key(out, key);
     }
+    ctx->exact_valid = ctx->exact;
+    return PAPR_OK;
+}
+
+// ---- bit-exact mean ---------------------------------------------------------------
+
+int papr_hip_set_exact(papr_hip_ctx *ctx, int enabled)
+{
+    if (!ctx)
+        return PAPR_E_ARG;
+    if ((enabled != 0) != ctx->exact) {
+        ctx->exact = enabled != 0;
+        ctx->exact_valid = false;
+        ctx->have_file_stats = false;  // pass 1 must be re-run in the other mode
+    }
+    return PAPR_OK;
+}
+
+int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, const void **program, size_t *bytes)
+{
+    if (!ctx || !program || !bytes)
+        return PAPR_E_ARG;
+    if (!ctx->exact || !ctx->exact_valid || !ctx->loaded)
+        return fail(ctx, PAPR_E_STATE, "exact program needs papr_hip_set_exact(1) and papr_hip_stats on the current shard first");
+    if (!ctx->resident)
+        return fail(ctx, PAPR_E_STATE, "exact sum needs a shard that is resident in HBM");
+    if (!(before >= 0.0) || !std::isfinite(before))
+        return fail(ctx, PAPR_E_ARG, "`before` must be a finite, non-negative sum");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
+    const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
+    const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
+    // margin >= the worst-case relative drift of a sequential double sum of n_total non-negative terms
+    const double delta = std::max(1.0e-6, 8.0 * (double)std::max<uint64_t>(n_total, ctx->n) * 1.1102230246251565e-16);
+
+    std::vector<papr_exact_group> groups(ngroups);
+    std::vector<int32_t> tile_E(ntiles);
+    if (ntiles) {
+        int rc = ensure_exact_buffers(ctx);
+        if (rc)
+            return rc;
+        const uint64_t nsegs = 2 * ntiles;
+        const int blocks = (int)std::min<uint64_t>((nsegs + 3) / 4, (uint64_t)ctx->num_cus * 4);
+        time_begin(ctx, 2, ntiles * PAPR_EXACT_TILE_SAMPLES * 8);
+        papr_launch_exact_classify(ctx->stream, ctx->d_tile_sums, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E);
+        papr_launch_exact_segments(ctx->stream, blocks, ctx->d_iq, nsegs, ctx->d_tile_E, ctx->d_seg_D);
+        papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
+        time_end(ctx);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(groups.data(), ctx->d_groups, ngroups * sizeof(papr_exact_group), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(tile_E.data(), ctx->d_tile_E, ntiles * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // what has to travel in detail: mixed groups (per-segment pairs) and their unprovable tiles (raw samples)
+    std::vector<uint64_t> mixed, raw;
+    for (uint64_t g = 0; g < ngroups; g++) {
+        if (groups[g].E != PAPR_EXACT_AMBIG)
+            continue;
+        mixed.push_back(g);
+        const uint64_t t0 = g * PAPR_EXACT_GROUP_TILES, t1 = std::min<uint64_t>(t0 + PAPR_EXACT_GROUP_TILES, ntiles);
+        for (uint64_t t = t0; t < t1; t++)
+            if (tile_E[t] == PAPR_EXACT_AMBIG)
+                raw.push_back(t);
+    }
+    const size_t total = sizeof(papr_exact_header) + ngroups * sizeof(papr_exact_group_rec) +
+                         mixed.size() * sizeof(papr_exact_mixed_rec) + raw.size() * sizeof(papr_exact_raw_rec) +
+                         (size_t)tail * 8;
+    if (total > ctx->h_program_cap) {
+        if (ctx->h_program)
+            HIPCHK(ctx, hipHostFree(ctx->h_program));
+        ctx->h_program = nullptr;
+        ctx->h_program_cap = 0;
+        const size_t cap = std::max<size_t>(total + total / 4, (size_t)1 << 20);
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_program, cap, hipHostMallocDefault));
+        ctx->h_program_cap = cap;
+    }
+    static_assert(sizeof(papr_exact_group) == sizeof(papr_exact_group_rec), "group record layout");
+    unsigned char *p = ctx->h_program;
+    papr_exact_header h;
+    memset(&h, 0, sizeof(h));
+    h.magic = PAPR_EXACT_MAGIC;
+    h.version = PAPR_EXACT_VERSION;
+    h.nsamples = ctx->n;
+    h.ntiles = ntiles;
+    h.ngroups = ngroups;
+    h.tail_samples = tail;
+    h.nmixed = (uint32_t)mixed.size();
+    h.nraw = (uint32_t)raw.size();
+    memcpy(p, &h, sizeof(h));
+    p += sizeof(h);
+    if (ngroups)
+        memcpy(p, groups.data(), ngroups * sizeof(papr_exact_group_rec));
+    p += ngroups * sizeof(papr_exact_group_rec);
+    for (uint64_t g : mixed) {
+        papr_exact_mixed_rec *m = (papr_exact_mixed_rec *)p;
+        m->group = g;
+        const uint64_t t0 = g * PAPR_EXACT_GROUP_TILES, t1 = std::min<uint64_t>(t0 + PAPR_EXACT_GROUP_TILES, ntiles);
+        for (uint64_t j = 0; j < PAPR_EXACT_GROUP_TILES; j++)
+            m->tile_E[j] = t0 + j < t1 ? tile_E[t0 + j] : PAPR_EXACT_ZERO;
+        memset(m->seg_D, 0, sizeof(m->seg_D));
+        HIPCHK(ctx, hipMemcpyAsync(m->seg_D, ctx->d_seg_D + 4 * t0, (t1 - t0) * 2 * 2 * sizeof(double),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        p += sizeof(papr_exact_mixed_rec);
+    }
+    for (uint64_t t : raw) {
+        papr_exact_raw_rec *r = (papr_exact_raw_rec *)p;
+        r->tile = t;
+        HIPCHK(ctx, hipMemcpyAsync(r->iq, ctx->d_iq + 2 * t * PAPR_EXACT_TILE_SAMPLES, PAPR_EXACT_TILE_SAMPLES * 8,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        p += sizeof(papr_exact_raw_rec);
+    }
+    if (tail)
+        HIPCHK(ctx, hipMemcpyAsync(p, ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, (size_t)tail * 8,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *program = ctx->h_program;
+    *bytes = total;
     return PAPR_OK;
 }
 

@@ -72,6 +72,24 @@ class Exchange:
         """Exchange 1: the whole file's pass-1 result, identical on every rank."""
         return stats_merge(self.allgather_stats(local))
 
+    def allgather_bytes(self, blob: bytes) -> List[bytes]:
+        """Variable-size byte strings from every rank, in rank order (exact-sum programs:
+        ~0.1-2 MB each).  Two collectives: sizes, then the padded payload."""
+        if not self.active:
+            return [blob]
+        size = torch.tensor([len(blob)], dtype=torch.int64, device=self.device)
+        sizes = torch.empty(self.world, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(sizes, size, group=self.group)
+        sizes = sizes.cpu().tolist()
+        cap = max(max(sizes), 1)
+        mine = torch.zeros(cap, dtype=torch.uint8)
+        mine[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        mine = mine.to(self.device)
+        allb = torch.empty(self.world * cap, dtype=torch.uint8, device=self.device)
+        dist.all_gather_into_tensor(allb, mine, group=self.group)
+        flat = allb.cpu().numpy()
+        return [flat[r * cap:r * cap + sizes[r]].tobytes() for r in range(self.world)]
+
     def allreduce_counts(self, counts: np.ndarray) -> np.ndarray:
         """Exchange 2: per-level counts summed over all shards."""
         n = int(counts.size)

@@ -32,6 +32,7 @@
 #ifndef PAPR_HIP_H
 #define PAPR_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "papr_synth.h"
@@ -50,7 +51,8 @@ enum {
     PAPR_E_NOMEM = -4,     /* host or device allocation failed */
     PAPR_E_IO = -5,        /* file could not be opened / read */
     PAPR_E_STATE = -6,     /* call made before a shard was loaded */
-    PAPR_E_LIMIT = -7      /* level table larger than PAPR_HIP_MAX_LEVELS */
+    PAPR_E_LIMIT = -7,     /* level table larger than PAPR_HIP_MAX_LEVELS */
+    PAPR_E_INTERNAL = -8   /* an exact-sum invariant did not hold (never expected; results are not used) */
 };
 
 #define PAPR_HIP_MAX_LEVELS 16384
@@ -81,6 +83,7 @@ typedef struct papr_stats {
 typedef struct papr_hip_timing {
     double stats_ms;  uint64_t stats_launches;  uint64_t stats_bytes;
     double ccdf_ms;   uint64_t ccdf_launches;   uint64_t ccdf_bytes;
+    double exact_ms;  uint64_t exact_launches;  uint64_t exact_bytes; /* exact-sum kernels (classify + segments + groups) */
 } papr_hip_timing;
 
 /* Where the wall time of the last papr_hip_load_file went (seconds). */
@@ -170,6 +173,25 @@ void papr_stats_merge(papr_stats *acc, const papr_stats *next);
  * and writes min(L, cap) of them; a NaN PAPR gives 0 levels (papr.c:138 with
  * (int)NaN = INT_MIN on x86-64). */
 int papr_levels(const papr_stats *total, int graph, double *mean, float *papr, float *levels, int cap);
+
+/* ---- bit-exact mean (papr.c:104: `sum += value`, double, strictly in file order) --
+ * papr_hip_stats sums in a parallel tree, accurate to ~1e-15 but not the
+ * reference's rounding sequence (which is itself ~1e-13 off the exact sum).
+ * Exact mode reproduces the reference's value bit for bit (see papr_exact.hip):
+ *
+ *   papr_hip_set_exact(ctx, 1)               before load/upload/adopt/generate + stats
+ *   papr_hip_stats(ctx, &st)                 as usual (also leaves per-tile sums on the GPU)
+ *   papr_hip_exact_program(ctx, before, n_total, &prog, &bytes)
+ *        `before` = accurate sum of all samples of EARLIER shards (0 for the first),
+ *        `n_total` = samples in the whole file; prog points at context-owned memory
+ *        (valid until the next call) holding this shard's serialisable "sum program"
+ *   papr_exact_chain(programs, sizes, nshards, &sum)   host, shards in file order
+ *
+ * then use `sum` as papr_stats.sum of the merged record.  Needs a resident shard
+ * and a finite sum (with NaN/Inf present papr_hip_stats is already exact). */
+int papr_hip_set_exact(papr_hip_ctx *ctx, int enabled);
+int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, const void **program, size_t *bytes);
+int papr_exact_chain(const void *const *programs, const size_t *bytes, int nprograms, double *sum_out);
 
 /* ---- pass 2 (papr.c:143-153 / 175-185) ---------------------------------- */
 /* counts_above[j] = number of shard samples whose power is > levels[j]

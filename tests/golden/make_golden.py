@@ -147,6 +147,11 @@ def main():
             with open(os.path.join(HERE, f"big_spike10g.{tag}.txt"), "wb") as f:
                 f.write(out)
             entry[tag] = {"rc": rc, "stderr": err.decode(), "lines": out.count(b"\n")}
+        # the reference never prints its double accumulator in full; the oracle (pinned to the reference by
+        # tests/test_oracle.py) restates papr.c:100-129, so its pass-1 sum is the sequential sum to reproduce
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as ge
+        entry["oracle_sequential_sum_hex"] = ge.load_oracle().run_file(args.big, False)["sum"].hex()
         manifest["big_spike10g"] = entry
     json.dump(manifest, open(manifest_path, "w"), indent=1, sort_keys=True)
     print(f"recorded {len(names)} fixtures")

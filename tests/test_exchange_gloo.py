@@ -46,6 +46,8 @@ def _worker(rank, world, port, name, graph, out_dir):
         total = exchange.merged_stats(local, dev)
         mean, papr, table = pkg.levels(total, graph)
         counts = exchange.allreduce_counts(orc.count_mem(shard, table).astype(np.uint64), dev)
+        blobs = exchange.Exchange(dev).allgather_bytes(bytes([rank + 1]) * (1000 * rank + 3))
+        assert blobs == [bytes([r + 1]) * (1000 * r + 3) for r in range(world)]
         text = pkg.format_report(total, mean, papr, counts, graph)
         with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
             f.write(text)

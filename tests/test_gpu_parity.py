@@ -373,3 +373,138 @@ def test_full_size_properties(pkg, orc, big):
         assert np.array_equal(sub.ccdf(tab).astype(np.int64), orc.count_mem(iq, tab))
     finally:
         sub.close()
+
+
+# ---- bit-exact mean: the reference's sequential double sum, reproduced on the GPU ------
+
+def exact_sum_one_shard(pkg, g, n_total=None):
+    st = g.stats()
+    prog = g.exact_program(0.0, n_total or st.n)
+    return st, pkg.exact_chain([prog]), prog
+
+
+@pytest.fixture(scope="module")
+def xgpu(pkg):
+    g = pkg.PaprHip(0)
+    g.set_exact(True)
+    yield g
+    g.close()
+
+
+@pytest.mark.parametrize("n", [1, 5, 2047, 2048, 2049, 6000, 300007, 128 * 2048 + 17, 4 * 128 * 2048, 5000011])
+def test_exact_sum_equals_sequential_sum_sizes(pkg, orc, xgpu, n):
+    rng = np.random.default_rng(1000 + n)
+    iq = rng.standard_normal(2 * n).astype(np.float32)
+    xgpu.upload(iq)
+    st, exact, _ = exact_sum_one_shard(pkg, xgpu)
+    ref = orc.run_mem(iq, False)
+    assert exact == ref["sum"], (exact.hex(), ref["sum"].hex(), st.sum.hex())
+    check_stats(st, ref)   # exact mode leaves pass 1's other results unchanged
+
+
+@pytest.mark.parametrize("case", ["spike", "tiny", "huge", "zeros_first", "zeros_mixed", "growing", "shrinking",
+                                  "constant", "denormal", "sparse"])
+def test_exact_sum_hard_inputs(pkg, orc, xgpu, case):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(case.encode()))
+    n = 1_500_000
+    iq = rng.standard_normal(2 * n).astype(np.float32)
+    if case == "spike":
+        iq[2 * 777777] = 3.0e4
+    elif case == "tiny":
+        iq *= np.float32(3.3717e-8)
+    elif case == "huge":
+        iq *= np.float32(1e15)
+    elif case == "zeros_first":
+        iq[: 2 * 700000] = 0
+    elif case == "zeros_mixed":
+        iq[2 * 100000: 2 * 900000] = 0
+        iq[2 * 1200000: 2 * 1200100] = 0
+    elif case == "growing":      # amplitude x 2^40 over the file: the sum changes binade constantly
+        iq *= np.exp2(np.repeat(np.linspace(-20, 20, n), 2)).astype(np.float32)
+    elif case == "shrinking":
+        iq *= np.exp2(np.repeat(np.linspace(20, -20, n), 2)).astype(np.float32)
+    elif case == "constant":     # every addition is a potential tie
+        iq[0::2], iq[1::2] = 0.75, 0.25
+    elif case == "denormal":
+        iq *= np.float32(4e-21)
+    elif case == "sparse":
+        mask = rng.random(n) < 0.999
+        iq[0::2][mask] = 0
+        iq[1::2][mask] = 0
+    xgpu.upload(iq)
+    st, exact, prog = exact_sum_one_shard(pkg, xgpu)
+    ref = orc.run_mem(iq, False)
+    assert exact == ref["sum"], (case, exact.hex(), ref["sum"].hex(), st.sum.hex())
+    assert len(prog) < 8 * n // 2, "the program must stay a small fraction of the data"
+
+
+def test_exact_sum_golden_fixtures(pkg, orc):
+    """Exact mode through the file ingest on every fixture with a finite sum."""
+    with pkg.PaprHip(0) as g:
+        g.set_exact(True)
+        for name in golden_names():
+            ref = orc.run_file(golden_path(name), False)
+            if not np.isfinite(ref["sum"]):
+                continue
+            g.load_file(golden_path(name))
+            st = g.stats()
+            assert pkg.exact_chain([g.exact_program(0.0, st.n)]) == ref["sum"], name
+
+
+def test_exact_sum_across_shards(pkg, orc, xgpu):
+    """Multi-GPU form: every shard builds its program knowing only the ACCURATE sum of the
+    shards before it; the chained result is the sequential sum of the whole stream."""
+    from dtv_utils_amd import exchange
+    n = 3_000_017
+    xgpu.generate(pkg.SynthSpec.spike(n, seed=31), 0, n)
+    iq = xgpu.download(0, n)
+    ref = orc.run_mem(iq, False)
+    for world in (1, 2, 5):
+        progs, before = [], 0.0
+        for r in range(world):
+            first, cnt = exchange.shard_range(n, r, world)
+            xgpu.upload(iq[2 * first:2 * (first + cnt)], base_index=first)
+            st = xgpu.stats()
+            progs.append(xgpu.exact_program(before, n))
+            before += st.sum
+        assert pkg.exact_chain(progs) == ref["sum"], world
+
+
+def test_exact_program_states(pkg):
+    with pkg.PaprHip(0) as g:
+        g.upload(np.ones(20000, np.float32))
+        g.stats()
+        with pytest.raises(pkg.PaprError) as e:
+            g.exact_program()          # exact mode was not enabled
+        assert e.value.code == -6
+        g.set_exact(True)
+        with pytest.raises(pkg.PaprError):
+            g.exact_program()          # stats not re-run in exact mode
+        g.stats()
+        assert pkg.exact_chain([g.exact_program()]) == 20000.0
+    with pytest.raises(pkg.PaprError):
+        pkg.exact_chain([b"garbage" * 10])
+
+
+def test_exact_sum_full_size(pkg, manifest, big):
+    """10 GiB: the GPU-reproduced sequential sum equals the oracle's, bit for bit."""
+    want = manifest.get("big_spike10g", {}).get("oracle_sequential_sum_hex")
+    if not want:
+        pytest.skip("full-size sequential sum not recorded")
+    g, n = big
+    g.set_exact(True)
+    try:
+        st = g.stats()
+        g.set_timing(True)
+        prog = g.exact_program(0.0, n)
+        tm = g.timing()
+        g.set_timing(False)
+        exact = pkg.exact_chain([prog])
+        assert exact == float.fromhex(want), (exact.hex(), want, st.sum.hex())
+        # the tree sum is the accurate one: at 1.3e9 terms the reference's serial accumulator has drifted
+        # ~1e-11 relative from it, which is why the exact emulation exists
+        assert abs(st.sum - exact) <= 1e-10 * exact
+        print(f"exact program: {len(prog)} bytes, device {tm.exact_ms:.3f} ms")
+    finally:
+        g.set_exact(False)
