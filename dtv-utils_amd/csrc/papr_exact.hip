@@ -70,15 +70,40 @@ __device__ __forceinline__ Pair compose(Pair f, Pair g, double m0)
     return h;
 }
 
-// ordered merge of the 64 lanes' pairs (lane order = file order); result in lane 0
+// value of lane (l + SHIFT) of the same 16-lane row (garbage-free: 0 where there is none), via DPP
+template <int SHIFT>
+__device__ __forceinline__ double row_shl_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + SHIFT, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + SHIFT, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int SHIFT>
+__device__ __forceinline__ Pair compose_row_step(Pair f, double m0)
+{
+    Pair g;
+    g.d0 = row_shl_f64<SHIFT>(f.d0);
+    g.d1 = row_shl_f64<SHIFT>(f.d1);
+    return compose(f, g, m0);
+}
+
+// ordered merge of the 64 lanes' pairs (lane order = file order); result in lane 0.
+// Levels 1,2,4,8 stay inside 16-lane rows (DPP row_shl: VALU latency only); the two
+// cross-row levels go through ds_bpermute.  Only lanes that are multiples of twice
+// the step stay meaningful at each level.
 __device__ __forceinline__ Pair wave_compose(Pair f, double m0)
 {
+    f = compose_row_step<1>(f, m0);
+    f = compose_row_step<2>(f, m0);
+    f = compose_row_step<4>(f, m0);
+    f = compose_row_step<8>(f, m0);
 #pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
+    for (int off = 16; off < kWave; off <<= 1) {
         Pair g;
         g.d0 = __shfl_down(f.d0, off, kWave);
         g.d1 = __shfl_down(f.d1, off, kWave);
-        f = compose(f, g, m0);  // only lanes that are multiples of 2*off stay meaningful
+        f = compose(f, g, m0);
     }
     return f;
 }
@@ -191,39 +216,57 @@ __global__ __launch_bounds__(256) void papr_exact_seg_kernel(const float4 *__res
     __shared__ float4 lds[256 / kWave][kWave * kRunStride];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const uint64_t nwaves = (uint64_t)gridDim.x * (256 / kWave);
-    for (uint64_t seg = (uint64_t)blockIdx.x * (256 / kWave) + wave; seg < nsegs; seg += nwaves) {
-        const int E = __builtin_amdgcn_readfirstlane(tile_E[seg >> 1]);
-        if (E == PAPR_EXACT_AMBIG || E == PAPR_EXACT_ZERO)
-            continue;  // handled raw on the host / cannot change the sum
+    // software pipeline: the next segment's loads are in flight while this one is reduced
+    uint64_t seg = (uint64_t)blockIdx.x * (256 / kWave) + wave;
+    float4 x[kRows], nx[kRows];
+    int curE = PAPR_EXACT_ZERO, nextE = PAPR_EXACT_ZERO;
+    if (seg < nsegs) {
+        curE = tile_E[seg >> 1];
         const float4 *p = data + seg * kSegF4 + lane;
-        float4 x[kRows];
 #pragma unroll
         for (int r = 0; r < kRows; r++)
             x[r] = load16<true>(p + r * kWave);
+    }
+    for (; seg < nsegs; seg += nwaves) {
+        const uint64_t nseg = seg + nwaves;
+        if (nseg < nsegs) {
+            nextE = tile_E[nseg >> 1];  // fetched a whole iteration before it is needed
+            const float4 *p = data + nseg * kSegF4 + lane;
 #pragma unroll
-        for (int r = 0; r < kRows; r++) {
-            const int f = r * kWave + lane;  // float4 slot within the segment, file order
-            lds[wave][(f >> 3) * kRunStride + (f & 7)] = x[r];
+            for (int r = 0; r < kRows; r++)
+                nx[r] = load16<true>(p + r * kWave);
         }
-        // same wave wrote and reads: LDS operations of one wave complete in order
-        const double m0 = two_pow(E), m1 = m0 + two_pow(E - 52);
-        double x0 = m0, x1 = m1;
+        const int E = __builtin_amdgcn_readfirstlane(curE);
+        if (E != PAPR_EXACT_AMBIG && E != PAPR_EXACT_ZERO) {  // else: handled raw on the host / cannot change the sum
 #pragma unroll
-        for (int k = 0; k < kRows; k++) {
-            const float4 y = lds[wave][lane * kRunStride + k];
-            const double v0 = (double)power_of(y.x, y.y);
-            const double v1 = (double)power_of(y.z, y.w);
-            x0 += v0;
-            x1 += v0;
-            x0 += v1;
-            x1 += v1;
+            for (int r = 0; r < kRows; r++) {
+                const int f = r * kWave + lane;  // float4 slot within the segment, file order
+                lds[wave][(f >> 3) * kRunStride + (f & 7)] = x[r];
+            }
+            // same wave wrote and reads: LDS operations of one wave complete in order
+            const double m0 = two_pow(E), m1 = m0 + two_pow(E - 52);
+            double x0 = m0, x1 = m1;
+#pragma unroll
+            for (int k = 0; k < kRows; k++) {
+                const float4 y = lds[wave][lane * kRunStride + k];
+                const double v0 = (double)power_of(y.x, y.y);
+                const double v1 = (double)power_of(y.z, y.w);
+                x0 += v0;
+                x1 += v0;
+                x0 += v1;
+                x1 += v1;
+            }
+            Pair f;
+            f.d0 = x0 - m0;  // exact: multiples of u inside the binade
+            f.d1 = x1 - m1;
+            f = wave_compose(f, m0);
+            if (lane == 0)
+                seg_D[seg] = make_double2(f.d0, f.d1);
         }
-        Pair f;
-        f.d0 = x0 - m0;  // exact: multiples of u inside the binade
-        f.d1 = x1 - m1;
-        f = wave_compose(f, m0);
-        if (lane == 0)
-            seg_D[seg] = make_double2(f.d0, f.d1);
+#pragma unroll
+        for (int r = 0; r < kRows; r++)
+            x[r] = nx[r];
+        curE = nextE;
     }
 }
 

@@ -240,8 +240,8 @@ __global__ __launch_bounds__(BLOCK) void papr_stats_kernel(const float4 *__restr
     const TileWalk w = tile_walk(blockIdx.x, gridDim.x, ntiles, map);
     auto emit_tile_sum = [&](uint32_t it, double lane_sum) {
         if constexpr (TSUM) {
-            const double ws = wave_reduce_sum(lane_sum);
-            if ((t & (kWave - 1)) == 0)
+            const double ws = wave_sum_to_lane63(lane_sum);
+            if ((t & (kWave - 1)) == kWave - 1)
                 tile_sums[(tile_offset + w.first + (uint64_t)it * w.stride) * (BLOCK / kWave) + t / kWave] = ws;
         }
     };

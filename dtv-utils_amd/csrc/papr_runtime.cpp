@@ -1275,13 +1275,13 @@ int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, c
     const double delta = std::max(1.0e-6, 8.0 * (double)std::max<uint64_t>(n_total, ctx->n) * 1.1102230246251565e-16);
 
     std::vector<papr_exact_group> groups(ngroups);
-    std::vector<int32_t> tile_E(ntiles);
     if (ntiles) {
         int rc = ensure_exact_buffers(ctx);
         if (rc)
             return rc;
         const uint64_t nsegs = 2 * ntiles;
-        const int blocks = (int)std::min<uint64_t>((nsegs + 3) / 4, (uint64_t)ctx->num_cus * 4);
+        const int per_cu = std::max(1, env_int("PAPR_EXACT_WG_PER_CU", 4));
+        const int blocks = (int)std::min<uint64_t>((nsegs + 3) / 4, (uint64_t)ctx->num_cus * per_cu);
         time_begin(ctx, 2, ntiles * PAPR_EXACT_TILE_SAMPLES * 8);
         papr_launch_exact_classify(ctx->stream, ctx->d_tile_sums, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E);
         papr_launch_exact_segments(ctx->stream, blocks, ctx->d_iq, nsegs, ctx->d_tile_E, ctx->d_seg_D);
@@ -1290,35 +1290,76 @@ int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, c
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(groups.data(), ctx->d_groups, ngroups * sizeof(papr_exact_group), hipMemcpyDeviceToHost,
                                    ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(tile_E.data(), ctx->d_tile_E, ntiles * sizeof(int32_t), hipMemcpyDeviceToHost,
-                                   ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    // what has to travel in detail: mixed groups (per-segment pairs) and their unprovable tiles (raw samples)
-    std::vector<uint64_t> mixed, raw;
-    for (uint64_t g = 0; g < ngroups; g++) {
-        if (groups[g].E != PAPR_EXACT_AMBIG)
-            continue;
-        mixed.push_back(g);
-        const uint64_t t0 = g * PAPR_EXACT_GROUP_TILES, t1 = std::min<uint64_t>(t0 + PAPR_EXACT_GROUP_TILES, ntiles);
-        for (uint64_t t = t0; t < t1; t++)
-            if (tile_E[t] == PAPR_EXACT_AMBIG)
-                raw.push_back(t);
-    }
-    const size_t total = sizeof(papr_exact_header) + ngroups * sizeof(papr_exact_group_rec) +
-                         mixed.size() * sizeof(papr_exact_mixed_rec) + raw.size() * sizeof(papr_exact_raw_rec) +
-                         (size_t)tail * 8;
-    if (total > ctx->h_program_cap) {
-        if (ctx->h_program)
-            HIPCHK(ctx, hipHostFree(ctx->h_program));
-        ctx->h_program = nullptr;
-        ctx->h_program_cap = 0;
-        const size_t cap = std::max<size_t>(total + total / 4, (size_t)1 << 20);
-        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_program, cap, hipHostMallocDefault));
+    // what has to travel in detail: mixed groups (per-tile classes + per-segment pairs) ...
+    std::vector<uint64_t> mixed;
+    for (uint64_t g = 0; g < ngroups; g++)
+        if (groups[g].E == PAPR_EXACT_AMBIG)
+            mixed.push_back(g);
+    auto reserve = [&](size_t want) -> int {  // grow the pinned program buffer, keeping its contents
+        if (want <= ctx->h_program_cap)
+            return PAPR_OK;
+        unsigned char *fresh = nullptr;
+        const size_t cap = std::max<size_t>(want + want / 4, (size_t)1 << 20);
+        HIPCHK(ctx, hipHostMalloc((void **)&fresh, cap, hipHostMallocDefault));
+        if (ctx->h_program) {
+            memcpy(fresh, ctx->h_program, ctx->h_program_cap);
+            (void)hipHostFree(ctx->h_program);
+        }
+        ctx->h_program = fresh;
         ctx->h_program_cap = cap;
-    }
+        return PAPR_OK;
+    };
     static_assert(sizeof(papr_exact_group) == sizeof(papr_exact_group_rec), "group record layout");
-    unsigned char *p = ctx->h_program;
+    const size_t off_groups = sizeof(papr_exact_header);
+    const size_t off_mixed = off_groups + ngroups * sizeof(papr_exact_group_rec);
+    const size_t off_raw = off_mixed + mixed.size() * sizeof(papr_exact_mixed_rec);
+    int rc = reserve(off_raw + (size_t)tail * 8);
+    if (rc)
+        return rc;
+    if (ngroups)
+        memcpy(ctx->h_program + off_groups, groups.data(), ngroups * sizeof(papr_exact_group_rec));
+    for (size_t k = 0; k < mixed.size(); k++) {
+        const uint64_t g = mixed[k];
+        papr_exact_mixed_rec *m = (papr_exact_mixed_rec *)(ctx->h_program + off_mixed + k * sizeof(papr_exact_mixed_rec));
+        const uint64_t t0 = g * PAPR_EXACT_GROUP_TILES, t1 = std::min<uint64_t>(t0 + PAPR_EXACT_GROUP_TILES, ntiles);
+        m->group = g;
+        for (uint64_t j = t1 - t0; j < PAPR_EXACT_GROUP_TILES; j++)
+            m->tile_E[j] = PAPR_EXACT_ZERO;
+        memset(m->seg_D, 0, sizeof(m->seg_D));
+        HIPCHK(ctx, hipMemcpyAsync(m->tile_E, ctx->d_tile_E + t0, (t1 - t0) * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(m->seg_D, ctx->d_seg_D + 4 * t0, (t1 - t0) * 2 * 2 * sizeof(double),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (!mixed.empty())
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // ... and their tiles that are not provably inside one binade (raw samples)
+    std::vector<uint64_t> raw;
+    for (size_t k = 0; k < mixed.size(); k++) {
+        const papr_exact_mixed_rec *m =
+            (const papr_exact_mixed_rec *)(ctx->h_program + off_mixed + k * sizeof(papr_exact_mixed_rec));
+        for (uint64_t j = 0; j < PAPR_EXACT_GROUP_TILES; j++)
+            if (m->tile_E[j] == PAPR_EXACT_AMBIG)
+                raw.push_back(mixed[k] * PAPR_EXACT_GROUP_TILES + j);
+    }
+    const size_t off_tail = off_raw + raw.size() * sizeof(papr_exact_raw_rec);
+    const size_t total = off_tail + (size_t)tail * 8;
+    rc = reserve(total);
+    if (rc)
+        return rc;
+    for (size_t k = 0; k < raw.size(); k++) {
+        papr_exact_raw_rec *r = (papr_exact_raw_rec *)(ctx->h_program + off_raw + k * sizeof(papr_exact_raw_rec));
+        r->tile = raw[k];
+        HIPCHK(ctx, hipMemcpyAsync(r->iq, ctx->d_iq + 2 * raw[k] * PAPR_EXACT_TILE_SAMPLES, PAPR_EXACT_TILE_SAMPLES * 8,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (tail)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_program + off_tail, ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES,
+                                   (size_t)tail * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (!raw.empty() || tail)
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     papr_exact_header h;
     memset(&h, 0, sizeof(h));
     h.magic = PAPR_EXACT_MAGIC;
@@ -1329,33 +1370,7 @@ int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, c
     h.tail_samples = tail;
     h.nmixed = (uint32_t)mixed.size();
     h.nraw = (uint32_t)raw.size();
-    memcpy(p, &h, sizeof(h));
-    p += sizeof(h);
-    if (ngroups)
-        memcpy(p, groups.data(), ngroups * sizeof(papr_exact_group_rec));
-    p += ngroups * sizeof(papr_exact_group_rec);
-    for (uint64_t g : mixed) {
-        papr_exact_mixed_rec *m = (papr_exact_mixed_rec *)p;
-        m->group = g;
-        const uint64_t t0 = g * PAPR_EXACT_GROUP_TILES, t1 = std::min<uint64_t>(t0 + PAPR_EXACT_GROUP_TILES, ntiles);
-        for (uint64_t j = 0; j < PAPR_EXACT_GROUP_TILES; j++)
-            m->tile_E[j] = t0 + j < t1 ? tile_E[t0 + j] : PAPR_EXACT_ZERO;
-        memset(m->seg_D, 0, sizeof(m->seg_D));
-        HIPCHK(ctx, hipMemcpyAsync(m->seg_D, ctx->d_seg_D + 4 * t0, (t1 - t0) * 2 * 2 * sizeof(double),
-                                   hipMemcpyDeviceToHost, ctx->stream));
-        p += sizeof(papr_exact_mixed_rec);
-    }
-    for (uint64_t t : raw) {
-        papr_exact_raw_rec *r = (papr_exact_raw_rec *)p;
-        r->tile = t;
-        HIPCHK(ctx, hipMemcpyAsync(r->iq, ctx->d_iq + 2 * t * PAPR_EXACT_TILE_SAMPLES, PAPR_EXACT_TILE_SAMPLES * 8,
-                                   hipMemcpyDeviceToHost, ctx->stream));
-        p += sizeof(papr_exact_raw_rec);
-    }
-    if (tail)
-        HIPCHK(ctx, hipMemcpyAsync(p, ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, (size_t)tail * 8,
-                                   hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(ctx->h_program, &h, sizeof(h));
     *program = ctx->h_program;
     *bytes = total;
     return PAPR_OK;
