@@ -73,8 +73,8 @@ def cpu_baseline(pkg, mode: str, sample_gib: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["default", "graph"], default="default")
     ap.add_argument("--gib", type=float, default=10.0, help="GiB of IQ per GPU")
     ap.add_argument("--exact", action="store_true",
@@ -83,6 +83,12 @@ def main():
     ap.add_argument("--cpu-sample-gib", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line (the JSON): library chatter during set-up (e.g. the RCCL
+    # version banner printed at communicator creation) is routed to stderr until then
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -208,7 +214,10 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 cb = {"error": repr(e)}
             line["cpu_baseline"] = cb
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
 
     gpu.close()
     if use_dist:

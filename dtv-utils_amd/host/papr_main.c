@@ -11,6 +11,8 @@
  *
  * Environment (argv grammar is left untouched on purpose):
  *   PAPR_GPUS=N        use N GPUs (default: one per 2 GiB of input, at most all visible)
+ *   PAPR_OVERSUBSCRIBE=1  let PAPR_GPUS exceed the visible GPUs (shard g runs on GPU g mod visible);
+ *                      for exercising the multi-shard path on a small machine
  *   PAPR_STATS=1       one JSON line with sizes and timings on stderr
  *   PAPR_EXACT_SUM=0   skip the bit-exact emulation of the reference's sequential double
  *                      sum (papr.c:104) and print the mean from the parallel tree sum, which
@@ -172,8 +174,12 @@ int main(int argc, char **argv)
         if (ngpu < 1)
             ngpu = 1;
     }
-    if (ngpu > visible)
+    env = getenv("PAPR_OVERSUBSCRIBE");
+    const int oversubscribe = env && atoi(env) > 0;
+    if (ngpu > visible && !oversubscribe)
         ngpu = visible;
+    if (ngpu > MAX_GPUS)
+        ngpu = MAX_GPUS;
 
     env = getenv("PAPR_EXACT_SUM");
     int exact = !(env && atoi(env) == 0 && env[0] != '\0');
@@ -186,13 +192,13 @@ int main(int argc, char **argv)
         const uint64_t first = (uint64_t)g * per;
         if (g > 0 && first >= nsamples)
             break;
-        sh[g].device = g;
+        sh[g].device = g % visible;
         sh[g].path = path;
         sh[g].first = first;
         sh[g].count = first + per > nsamples ? nsamples - first : per;
-        int rc = papr_hip_open(&sh[g].ctx, g);
+        int rc = papr_hip_open(&sh[g].ctx, sh[g].device);
         if (rc != PAPR_OK) {
-            fprintf(stderr, "papr: cannot open GPU %d: %s\n", g, papr_hip_last_error(NULL));
+            fprintf(stderr, "papr: cannot open GPU %d: %s\n", sh[g].device, papr_hip_last_error(NULL));
             return 254;
         }
         papr_hip_set_exact(sh[g].ctx, exact);

@@ -1,0 +1,55 @@
+"""bench.py's driver contract: ONE JSON line on stdout with the agreed keys, also under
+torch.distributed.run (RCCL initialised, both exchanges executed)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def check(line, steps, warmup):
+    d = json.loads(line)
+    assert KEYS <= set(d)
+    assert d["steps"] == steps and d["warmup"] == warmup and d["n_gpus"] == 1
+    assert d["unit"] == "Msamples/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    return d
+
+
+def test_single_process_line_with_cpu_baseline():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gib", "0.5", "--steps", "4", "--warmup", "1",
+                        "--cpu-sample-gib", "0.125"], capture_output=True, text=True, cwd=ROOT)
+    assert p.returncode == 0, p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    d = check(lines[0], 4, 1)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
+    assert cb["gpu_stdout_identical"] is True
+
+
+@pytest.mark.parametrize("extra", [[], ["--mode", "graph", "--exact"]])
+def test_torchrun_single_rank_uses_rccl(extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--gib", "0.5",
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *extra]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    d = check(lines[0], 3, 1)
+    assert d["config"]["exchange"].startswith("RCCL")
+    assert d["config"]["exact_sequential_sum"] == ("--exact" in extra)

@@ -74,6 +74,18 @@ def test_cli_reproduces_reference_stdout(pkg, manifest, name, graph):
     assert p.stdout == golden_text(name, graph)
 
 
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_cli_multi_shard_path(pkg, manifest, shards):
+    """The multi-GPU code path of bin/papr (one context + thread per shard, ordered merge, chained
+    exact-sum programs, summed counts), exercised by oversubscribing the one GPU of the test box."""
+    env = dict(os.environ, PAPR_GPUS=str(shards), PAPR_OVERSUBSCRIBE="1")
+    for name in ("g1m", "ties", "spike20k", "chunk3odd", "tiny", "nan_order", "ofdm_dvbt2_clipped", "one", "empty"):
+        for graph in (False, True):
+            args = [pkg.CLI_PATH] + (["-g"] if graph else []) + [golden_path(name)]
+            p = subprocess.run(args, capture_output=True, env=env)
+            assert p.returncode == 0 and p.stdout == golden_text(name, graph), (name, graph, shards, p.stderr)
+
+
 def test_cli_option_grammar_on_gpu(pkg):
     p = subprocess.run([pkg.CLI_PATH, "-xGy", golden_path("k8")], capture_output=True)
     assert p.returncode == 0 and p.stderr == b"Unsupported Option: x\nUnsupported Option: y\n"

@@ -14,6 +14,21 @@ B="python $R/bench.py"
 $R/bin/hbm_read_probe 10 10 > $O/hbm_read_probe.txt 2>&1
 $B --steps 20 --warmup 3                > $O/bench_default.json 2> $O/bench_default.err
 $B --steps 20 --warmup 3 --mode graph   > $O/bench_graph.json   2> $O/bench_graph.err
+$B --steps 20 --warmup 3 --exact --no-cpu-baseline > $O/bench_exact.json 2> $O/bench_exact.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_exact -- \
+    $B --steps 20 --warmup 3 --exact --no-cpu-baseline > $O/stats_exact.json 2> $O/stats_exact.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
+    $R/bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
+# end-to-end CLI (file -> pinned host -> HBM), PCIe-inclusive
+$R/oracle/mkcfile /dev/shm/papr_prof_10g.cfile 1342177280 --spike
+for i in 1 2 3; do
+  PAPR_STATS=1 $R/bin/papr /dev/shm/papr_prof_10g.cfile 2>> $O/cli_e2e.txt > $O/cli_default.txt
+  PAPR_STATS=1 $R/bin/papr -g /dev/shm/papr_prof_10g.cfile 2>> $O/cli_e2e.txt > $O/cli_graph.txt
+done
+PAPR_EXACT_SUM=0 PAPR_STATS=1 $R/bin/papr /dev/shm/papr_prof_10g.cfile 2>> $O/cli_e2e.txt > /dev/null
+cmp $O/cli_default.txt $R/tests/golden/big_spike10g.default.txt && cmp $O/cli_graph.txt $R/tests/golden/big_spike10g.graph.txt \
+  && echo "CLI stdout identical to the reference on the 10 GiB workload (both modes)" >> $O/cli_e2e.txt
+rm -f /dev/shm/papr_prof_10g.cfile
 for MODE in default graph; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$MODE -- \
       $B --steps 20 --warmup 3 --mode $MODE --no-cpu-baseline > $O/stats_$MODE.json 2> $O/stats_$MODE.err

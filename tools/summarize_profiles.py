@@ -28,9 +28,15 @@ def short(name):
     return name.split("(")[0]
 
 
+def newest(pattern):
+    """gpurun merges every call's files into the same local directory: keep the latest run only."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 def counters(d):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(d, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             out[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"dispatches": len(next(iter(cs.values())))}
@@ -42,8 +48,14 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
+    for name in ("bench_exact.json", "bench_torchrun1.json", "cli_e2e.txt"):
+        p = os.path.join(src, name)
+        if os.path.exists(p) and os.path.getsize(p):
+            shutil.copy(p, os.path.join(dst, f"{tag}_{name}"))
+    for f in newest(os.path.join(src, "stats_exact", "*", "*_kernel_stats.csv")):
+        shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats_exact.csv"))
     for mode in ("default", "graph"):
-        for f in glob.glob(os.path.join(src, f"stats_{mode}", "*", "*_kernel_stats.csv")):
+        for f in newest(os.path.join(src, f"stats_{mode}", "*", "*_kernel_stats.csv")):
             shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats_{mode}.csv"))
         for name in (f"bench_{mode}.json", f"stats_{mode}.json"):
             p = os.path.join(src, name)
