@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "papr_hip_get_timing", "papr_file_samples", "papr_hip_load_file", "papr_hip_get_ingest_timing", "papr_hip_upload",
     "papr_hip_adopt", "papr_hip_generate", "papr_hip_download", "papr_hip_stats",
     "papr_stats_init", "papr_stats_merge", "papr_levels", "papr_hip_ccdf",
-    "papr_hip_set_exact", "papr_hip_exact_program", "papr_exact_chain",
+    "papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
 )
 
 
@@ -159,8 +159,9 @@ def lib() -> C.CDLL:
     L.papr_hip_ccdf.argtypes = [vp, vp, i32, vp]
     L.papr_hip_set_exact.argtypes = [vp, i32]
     L.papr_hip_exact_program.argtypes = [vp, C.c_double, u64, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.papr_hip_ccdf_exact.argtypes = [vp, vp, i32, vp, C.c_double, u64, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.papr_exact_chain.argtypes = [C.POINTER(vp), C.POINTER(C.c_size_t), i32, C.POINTER(C.c_double)]
-    for name in ("papr_hip_set_exact", "papr_hip_exact_program", "papr_exact_chain"):
+    for name in ("papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain"):
         getattr(L, name).restype = i32
     for name in ("papr_hip_open", "papr_hip_device_name", "papr_hip_set_tuning", "papr_hip_set_timing",
                  "papr_hip_get_timing", "papr_file_samples", "papr_hip_load_file", "papr_hip_get_ingest_timing", "papr_hip_upload",
@@ -321,6 +322,16 @@ class PaprHip:
         self._chk(self._L.papr_hip_exact_program(self._ctx, before, n_total, C.byref(ptr), C.byref(size)),
                   "papr_hip_exact_program")
         return C.string_at(ptr, size.value)
+
+    def ccdf_exact(self, level_table: np.ndarray, before: float = 0.0, n_total: int = 0):
+        """Pass 2 and the sum program from ONE sweep over the samples: (counts, program)."""
+        lv = np.ascontiguousarray(level_table, dtype=np.float32)
+        out = np.zeros(lv.size, dtype=np.uint64)
+        ptr, size = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.papr_hip_ccdf_exact(self._ctx, lv.ctypes.data_as(C.c_void_p), lv.size,
+                                              out.ctypes.data_as(C.c_void_p), before, n_total, C.byref(ptr),
+                                              C.byref(size)), "papr_hip_ccdf_exact")
+        return out, C.string_at(ptr, size.value)
 
     # the two passes
     def stats(self) -> Stats:

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "papr_kernels.h"
+
 namespace {
 
 constexpr int kWave = 64;
@@ -46,6 +48,49 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v)
     v = dpp_add_f64<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1 and 3
     v = dpp_add_f64<0x143, 0xc, 0xf>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
     return v;
+}
+
+// ---- pass-2 binning helpers (see the comment block above papr_ccdf_kernel) -----------
+
+template <int BLOCK>
+__device__ __forceinline__ void hist_flush(const uint32_t *hist, uint32_t nbins, uint32_t copies,
+                                           unsigned long long *__restrict__ ghist)
+{
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbins; b += BLOCK) {
+        unsigned long long s = 0;
+        for (uint32_t c = 0; c < copies; c++)
+            s += hist[c * nbins + b];
+        if (s)
+            atomicAdd(&ghist[b], s);
+    }
+}
+
+__device__ __forceinline__ uint32_t lut_bin(uint32_t bits, const uint2 *lut, const papr_ccdf_params &P)
+{
+    const uint32_t rel = (bits >> P.shift) - P.cell_lo;  // wraps to huge below the table
+    uint32_t k;
+    if (rel < P.ncells) {
+        const uint2 e = lut[rel];
+        k = e.x + (bits >= e.y ? 1u : 0u);
+    } else {
+        // above the table but not NaN => above every level; below or NaN => 0
+        k = (bits - P.above_lo) <= P.above_span ? P.nkeys : 0u;
+    }
+    return k;
+}
+
+__device__ __forceinline__ uint32_t search_bin(uint32_t bits, const uint32_t *keys, const papr_ccdf_params &P)
+{
+    if (bits > 0x7F800000u)  // NaN (either sign): above nothing
+        return 0;
+    uint32_t lo = 0;
+    for (uint32_t step = P.search_step; step; step >>= 1) {
+        const uint32_t mid = lo + step;
+        if (mid <= P.nkeys && keys[mid - 1] <= bits)
+            lo = mid;
+    }
+    return lo;
 }
 
 }  // namespace

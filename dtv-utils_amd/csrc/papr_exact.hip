@@ -33,6 +33,9 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
 
 #include "papr_kernels.h"
 #include "papr_device.h"
@@ -42,7 +45,15 @@ namespace {
 constexpr int kTilesPerBlock = 1024;  // classification workgroup: 256 threads x 4 tiles
 constexpr int kSegF4 = PAPR_EXACT_SEG_SAMPLES / 2;  // float4 slots per segment (512)
 constexpr int kRows = kSegF4 / kWave;               // 16-byte loads per lane per segment (8)
-constexpr int kRunStride = kRows + 1;               // LDS run stride in float4: 8 data + 1 pad
+
+// LDS transpose without padding: the lane that owns run r (8 consecutive float4 = 16 samples)
+// finds its w-th float4 at slot r*8 + (w ^ ((r >> 1) & 7)).  Writers (8 consecutive lanes fill one
+// run) still cover one contiguous 128 bytes; readers (lane l reads run l, same w) land on 16
+// different 16-byte bank groups per 16-lane group: conflict-free both ways, 8 KiB per wave.
+__device__ __forceinline__ int transpose_slot(int run, int w)
+{
+    return run * kRows + (w ^ ((run >> 1) & 7));
+}
 
 __device__ __forceinline__ double two_pow(int e)  // 2^e for normal results
 {
@@ -209,15 +220,49 @@ __global__ __launch_bounds__(256) void papr_exact_classify(const double *__restr
 // ---- per-segment rounding functions --------------------------------------------------
 // One wave per 1024-sample segment.  Coalesced 16-byte loads, then a padded LDS
 // transpose so that lane l holds samples 16 l .. 16 l + 15 of the segment, in order.
-__global__ __launch_bounds__(256) void papr_exact_seg_kernel(const float4 *__restrict__ data, uint64_t nsegs,
+//
+// CCDF = true fuses pass 2 into the same sweep (one 8 B/sample read for both): every
+// power is also binned against the level table staged in LDS, exactly as
+// papr_ccdf_kernel does it.  The caller runs this with the thresholds derived from the
+// tree sum and re-runs plain pass 2 only in the rare case the exact sum moves a
+// threshold (papr_hip_ccdf_exact).
+template <bool CCDF, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void papr_exact_seg_kernel(const float4 *__restrict__ data, uint64_t nsegs,
                                                               const int32_t *__restrict__ tile_E,
-                                                              double2 *__restrict__ seg_D)
+                                                              double2 *__restrict__ seg_D,
+                                                              const float2 *__restrict__ tail, uint32_t tail_samples,
+                                                              const uint32_t *__restrict__ table, papr_ccdf_params P,
+                                                              unsigned long long *__restrict__ ghist)
 {
-    __shared__ float4 lds[256 / kWave][kWave * kRunStride];
+    constexpr int kWaves = BLOCK / kWave;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *lds = reinterpret_cast<float4 *>(smem);                    // kWaves x (64 runs x 8 float4)
+    uint32_t *tab = reinterpret_cast<uint32_t *>(lds + kWaves * kSegF4);
+    uint32_t *hist = tab + P.table_words;
+    const uint32_t nbins = P.nkeys + 1;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const uint64_t nwaves = (uint64_t)gridDim.x * (256 / kWave);
+    float4 *mine = lds + wave * kSegF4;
+    uint32_t *my_hist = hist;
+    if constexpr (CCDF) {
+        for (uint32_t k = threadIdx.x; k < P.table_words; k += BLOCK)
+            tab[k] = table[k];
+        for (uint32_t k = threadIdx.x; k < P.copies * nbins; k += BLOCK)
+            hist[k] = 0;
+        __syncthreads();
+        my_hist = hist + (wave % P.copies) * nbins;
+    }
+    const uint2 *lut = reinterpret_cast<const uint2 *>(tab);
+    auto count = [&](float pw) {
+        if constexpr (CCDF) {
+            const uint32_t k = lut_bin(__float_as_uint(pw), lut, P);
+            if (k)
+                atomicAdd(&my_hist[k], 1u);
+        }
+    };
+
+    const uint64_t nwaves = (uint64_t)gridDim.x * kWaves;
     // software pipeline: the next segment's loads are in flight while this one is reduced
-    uint64_t seg = (uint64_t)blockIdx.x * (256 / kWave) + wave;
+    uint64_t seg = (uint64_t)blockIdx.x * kWaves + wave;
     float4 x[kRows], nx[kRows];
     int curE = PAPR_EXACT_ZERO, nextE = PAPR_EXACT_ZERO;
     if (seg < nsegs) {
@@ -237,24 +282,26 @@ __global__ __launch_bounds__(256) void papr_exact_seg_kernel(const float4 *__res
                 nx[r] = load16<true>(p + r * kWave);
         }
         const int E = __builtin_amdgcn_readfirstlane(curE);
-        if (E != PAPR_EXACT_AMBIG && E != PAPR_EXACT_ZERO) {  // else: handled raw on the host / cannot change the sum
+        if (E != PAPR_EXACT_AMBIG && E != PAPR_EXACT_ZERO) {
 #pragma unroll
             for (int r = 0; r < kRows; r++) {
                 const int f = r * kWave + lane;  // float4 slot within the segment, file order
-                lds[wave][(f >> 3) * kRunStride + (f & 7)] = x[r];
+                mine[transpose_slot(f >> 3, f & 7)] = x[r];
             }
             // same wave wrote and reads: LDS operations of one wave complete in order
             const double m0 = two_pow(E), m1 = m0 + two_pow(E - 52);
             double x0 = m0, x1 = m1;
 #pragma unroll
             for (int k = 0; k < kRows; k++) {
-                const float4 y = lds[wave][lane * kRunStride + k];
-                const double v0 = (double)power_of(y.x, y.y);
-                const double v1 = (double)power_of(y.z, y.w);
+                const float4 y = mine[transpose_slot(lane, k)];
+                const float p0 = power_of(y.x, y.y), p1 = power_of(y.z, y.w);
+                const double v0 = (double)p0, v1 = (double)p1;
                 x0 += v0;
                 x1 += v0;
                 x0 += v1;
                 x1 += v1;
+                count(p0);
+                count(p1);
             }
             Pair f;
             f.d0 = x0 - m0;  // exact: multiples of u inside the binade
@@ -262,11 +309,26 @@ __global__ __launch_bounds__(256) void papr_exact_seg_kernel(const float4 *__res
             f = wave_compose(f, m0);
             if (lane == 0)
                 seg_D[seg] = make_double2(f.d0, f.d1);
+        } else if constexpr (CCDF) {
+            // no rounding function for this tile (added raw on the host, or all zeros): binning only
+#pragma unroll
+            for (int r = 0; r < kRows; r++) {
+                count(power_of(x[r].x, x[r].y));
+                count(power_of(x[r].z, x[r].w));
+            }
         }
 #pragma unroll
         for (int r = 0; r < kRows; r++)
             x[r] = nx[r];
         curE = nextE;
+    }
+    if constexpr (CCDF) {
+        if (blockIdx.x == gridDim.x - 1)
+            for (uint32_t k = threadIdx.x; k < tail_samples; k += BLOCK) {
+                const float2 t = tail[k];
+                count(power_of(t.x, t.y));
+            }
+        hist_flush<BLOCK>(hist, nbins, P.copies, ghist);
     }
 }
 
@@ -319,6 +381,157 @@ __global__ __launch_bounds__(256) void papr_exact_group_kernel(const int32_t *__
         out[g] = rec;
 }
 
+// ---- program assembly on the device ---------------------------------------------------------
+// The sum program (papr_exact_format.h) is gathered by two small kernels straight into mapped
+// pinned host memory, so the host does one stream synchronisation instead of ~50 small copies.
+
+// ordered lists of the mixed groups and of their unprovable tiles
+__global__ __launch_bounds__(256) void papr_exact_plan_kernel(const papr_exact_group *__restrict__ groups, uint64_t ngroups,
+                                                               const int32_t *__restrict__ tile_E, uint64_t ntiles,
+                                                               uint32_t *__restrict__ mixed_list, uint32_t cap_mixed,
+                                                               uint32_t *__restrict__ raw_list, uint32_t cap_raw,
+                                                               papr_exact_plan *__restrict__ out)
+{
+    __shared__ uint32_t sh[256];
+    __shared__ uint32_t sh_total;
+    auto ordered_offsets = [&](uint32_t mine) -> uint32_t {  // exclusive scan over the 256 threads, in order
+        __syncthreads();
+        sh[threadIdx.x] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int k = 0; k < 256; k++) {
+                const uint32_t v = sh[k];
+                sh[k] = run;
+                run += v;
+            }
+            sh_total = run;
+        }
+        __syncthreads();
+        return sh[threadIdx.x];
+    };
+    // mixed groups
+    const uint64_t per_g = (ngroups + 255) / 256;
+    const uint64_t g0 = threadIdx.x * per_g, g1 = min(g0 + per_g, ngroups);
+    uint32_t cnt = 0;
+    for (uint64_t g = g0; g < g1; g++)
+        cnt += groups[g].E == PAPR_EXACT_AMBIG;
+    uint32_t pos = ordered_offsets(cnt);
+    const uint32_t nmixed_all = sh_total;
+    for (uint64_t g = g0; g < g1; g++)
+        if (groups[g].E == PAPR_EXACT_AMBIG) {
+            if (pos < cap_mixed)
+                mixed_list[pos] = (uint32_t)g;
+            pos++;
+        }
+    const uint32_t nmixed = min(nmixed_all, cap_mixed);
+    __syncthreads();
+    // their tiles that have to travel raw
+    const uint64_t items = (uint64_t)nmixed * PAPR_EXACT_GROUP_TILES;
+    const uint64_t per_t = (items + 255) / 256;
+    const uint64_t i0 = threadIdx.x * per_t, i1 = min(i0 + per_t, items);
+    auto tile_of = [&](uint64_t item) -> uint64_t {
+        return (uint64_t)mixed_list[item / PAPR_EXACT_GROUP_TILES] * PAPR_EXACT_GROUP_TILES + item % PAPR_EXACT_GROUP_TILES;
+    };
+    cnt = 0;
+    for (uint64_t it = i0; it < i1; it++) {
+        const uint64_t t = tile_of(it);
+        cnt += t < ntiles && tile_E[t] == PAPR_EXACT_AMBIG;
+    }
+    pos = ordered_offsets(cnt);
+    const uint32_t nraw_all = sh_total;
+    for (uint64_t it = i0; it < i1; it++) {
+        const uint64_t t = tile_of(it);
+        if (t < ntiles && tile_E[t] == PAPR_EXACT_AMBIG) {
+            if (pos < cap_raw)
+                raw_list[pos] = (uint32_t)t;
+            pos++;
+        }
+    }
+    if (threadIdx.x == 0) {
+        out->nmixed = nmixed;
+        out->nraw = min(nraw_all, cap_raw);
+        out->overflow = (nmixed_all > cap_mixed || nraw_all > cap_raw) ? 1u : 0u;
+        out->pad = 0;
+    }
+}
+
+// one workgroup per piece of the program: group-table chunks, mixed records, raw tiles, header + tail
+__global__ __launch_bounds__(256) void papr_exact_pack_kernel(const papr_exact_plan *__restrict__ plan,
+                                                               const uint32_t *__restrict__ mixed_list,
+                                                               const uint32_t *__restrict__ raw_list,
+                                                               const papr_exact_group *__restrict__ groups,
+                                                               uint64_t ngroups, const int32_t *__restrict__ tile_E,
+                                                               uint64_t ntiles, const double *__restrict__ seg_D,
+                                                               const float *__restrict__ data, uint64_t nsamples,
+                                                               uint32_t tail_samples, uint32_t group_blocks,
+                                                               uint32_t cap_mixed, uint32_t cap_raw,
+                                                               unsigned char *__restrict__ out)
+{
+    const uint32_t nmixed = plan->nmixed, nraw = plan->nraw;
+    const size_t off_groups = 48;  // sizeof(papr_exact_header)
+    const size_t off_mixed = off_groups + ngroups * 24;
+    const size_t off_raw = off_mixed + (size_t)nmixed * 4616;
+    const size_t off_tail = off_raw + (size_t)nraw * 16392;
+    uint32_t b = blockIdx.x;
+    if (b < group_blocks) {  // group table, 8 bytes per thread per step
+        const uint64_t words = ngroups * 3;
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(groups);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(out + off_groups);
+        for (uint64_t k = (uint64_t)b * 256 + threadIdx.x; k < words; k += (uint64_t)group_blocks * 256)
+            dst[k] = src[k];
+        return;
+    }
+    b -= group_blocks;
+    if (b < cap_mixed) {
+        if (b >= nmixed)
+            return;
+        const uint64_t g = mixed_list[b], t0 = g * PAPR_EXACT_GROUP_TILES;
+        unsigned char *rec = out + off_mixed + (size_t)b * 4616;
+        if (threadIdx.x == 0)
+            *reinterpret_cast<unsigned long long *>(rec) = g;
+        int32_t *te = reinterpret_cast<int32_t *>(rec + 8);
+        for (uint32_t j = threadIdx.x; j < PAPR_EXACT_GROUP_TILES; j += 256)
+            te[j] = t0 + j < ntiles ? tile_E[t0 + j] : PAPR_EXACT_ZERO;
+        double *sd = reinterpret_cast<double *>(rec + 8 + 4 * PAPR_EXACT_GROUP_TILES);
+        for (uint32_t j = threadIdx.x; j < 4 * PAPR_EXACT_GROUP_TILES; j += 256)
+            sd[j] = t0 + j / 4 < ntiles ? seg_D[4 * t0 + j] : 0.0;
+        return;
+    }
+    b -= cap_mixed;
+    if (b < cap_raw) {
+        if (b >= nraw)
+            return;
+        const uint64_t t = raw_list[b];
+        unsigned char *rec = out + off_raw + (size_t)b * 16392;
+        if (threadIdx.x == 0)
+            *reinterpret_cast<unsigned long long *>(rec) = t;
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(data + 2 * t * PAPR_EXACT_TILE_SAMPLES);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(rec + 8);
+        for (uint32_t k = threadIdx.x; k < PAPR_EXACT_TILE_SAMPLES; k += 256)
+            dst[k] = src[k];  // one IQ pair per 8-byte word
+        return;
+    }
+    // last workgroup: the tail samples and the header (layout of papr_exact_header)
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(data + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(out + off_tail);
+    for (uint32_t k = threadIdx.x; k < tail_samples; k += 256)
+        dst[k] = src[k];
+    if (threadIdx.x == 0) {
+        uint32_t *h32 = reinterpret_cast<uint32_t *>(out);
+        unsigned long long *h64 = reinterpret_cast<unsigned long long *>(out);
+        h32[0] = 0x31535850u;  // PAPR_EXACT_MAGIC
+        h32[1] = 1u;           // PAPR_EXACT_VERSION
+        h64[1] = nsamples;
+        h64[2] = ntiles;
+        h64[3] = ngroups;
+        h32[8] = tail_samples;
+        h32[9] = nmixed;
+        h32[10] = nraw;
+        h32[11] = plan->overflow;  // reserved word: non-zero = lists were truncated, do not use this program
+    }
+}
+
 // ---- launch wrappers -------------------------------------------------------------------------
 
 void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, uint64_t ntiles, double *block_sums,
@@ -333,13 +546,49 @@ void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, ui
                        tile_E);
 }
 
+// workgroup sizes: 4 waves for the plain sweep; 8 waves for the fused one so that the level table is
+// shared by more waves and two workgroups (16 waves) fit a CU's 160 KiB of LDS
+constexpr int kSegBlock = 256, kFusedBlock = 512;
+
+size_t papr_exact_transpose_lds_bytes(void)
+{
+    return (size_t)(kFusedBlock / kWave) * kSegF4 * sizeof(float4);
+}
+
+int papr_exact_fused_waves(void)
+{
+    return kFusedBlock / kWave;
+}
+
 void papr_launch_exact_segments(hipStream_t st, int blocks, const void *data, uint64_t nsegs, const int32_t *tile_E,
                                 void *seg_D)
 {
     if (nsegs == 0)
         return;
-    hipLaunchKernelGGL(papr_exact_seg_kernel, dim3(blocks), dim3(256), 0, st, (const float4 *)data, nsegs, tile_E,
-                       (double2 *)seg_D);
+    papr_ccdf_params none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL((papr_exact_seg_kernel<false, kSegBlock>), dim3(blocks), dim3(kSegBlock),
+                       (size_t)(kSegBlock / kWave) * kSegF4 * sizeof(float4), st, (const float4 *)data, nsegs, tile_E,
+                       (double2 *)seg_D, (const float2 *)nullptr, 0u, (const uint32_t *)nullptr, none,
+                       (unsigned long long *)nullptr);
+}
+
+// the same sweep with pass 2 fused in (LUT form of the level table only); lds_table_bytes = table + histograms;
+// `blocks` counts kFusedBlock-thread workgroups
+void papr_launch_exact_segments_ccdf(hipStream_t st, int blocks, const void *data, uint64_t nsegs,
+                                     const int32_t *tile_E, void *seg_D, const void *tail, uint32_t tail_samples,
+                                     const uint32_t *table, const papr_ccdf_params &P, size_t lds_table_bytes,
+                                     unsigned long long *ghist)
+{
+    static int attr_done = 0;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)papr_exact_seg_kernel<true, kFusedBlock>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        attr_done = 1;
+    }
+    hipLaunchKernelGGL((papr_exact_seg_kernel<true, kFusedBlock>), dim3(blocks), dim3(kFusedBlock),
+                       papr_exact_transpose_lds_bytes() + lds_table_bytes, st, (const float4 *)data, nsegs, tile_E,
+                       (double2 *)seg_D, (const float2 *)tail, tail_samples, table, P, ghist);
 }
 
 void papr_launch_exact_groups(hipStream_t st, const int32_t *tile_E, uint64_t ntiles, const void *seg_D,
@@ -350,4 +599,17 @@ void papr_launch_exact_groups(hipStream_t st, const int32_t *tile_E, uint64_t nt
     const uint32_t nb = (uint32_t)((ngroups + 3) / 4);
     hipLaunchKernelGGL(papr_exact_group_kernel, dim3(nb), dim3(256), 0, st, tile_E, ntiles, (const double2 *)seg_D,
                        ngroups, out);
+}
+
+void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint64_t ngroups, const int32_t *tile_E,
+                            uint64_t ntiles, const void *seg_D, const void *data, uint64_t nsamples,
+                            uint32_t tail_samples, uint32_t *mixed_list, uint32_t cap_mixed, uint32_t *raw_list,
+                            uint32_t cap_raw, papr_exact_plan *plan, unsigned char *out_mapped)
+{
+    hipLaunchKernelGGL(papr_exact_plan_kernel, dim3(1), dim3(256), 0, st, groups, ngroups, tile_E, ntiles, mixed_list,
+                       cap_mixed, raw_list, cap_raw, plan);
+    const uint32_t group_blocks = (uint32_t)std::min<uint64_t>(64, (ngroups * 3 + 255) / 256 + 1);
+    hipLaunchKernelGGL(papr_exact_pack_kernel, dim3(group_blocks + cap_mixed + cap_raw + 1), dim3(256), 0, st, plan,
+                       mixed_list, raw_list, groups, ngroups, tile_E, ntiles, (const double *)seg_D, (const float *)data,
+                       nsamples, tail_samples, group_blocks, cap_mixed, cap_raw, out_mapped);
 }

@@ -61,10 +61,24 @@ struct papr_exact_group {
     double D0, D1; // total increment for even / odd entry parity
 };
 
+struct papr_exact_plan {
+    uint32_t nmixed, nraw, overflow, pad;
+};
+
+void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint64_t ngroups, const int32_t *tile_E,
+                            uint64_t ntiles, const void *seg_D, const void *data, uint64_t nsamples,
+                            uint32_t tail_samples, uint32_t *mixed_list, uint32_t cap_mixed, uint32_t *raw_list,
+                            uint32_t cap_raw, papr_exact_plan *plan, unsigned char *out_mapped);
 void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, uint64_t ntiles, double *block_sums,
                                 double before, double delta, int32_t *tile_E);
 void papr_launch_exact_segments(hipStream_t st, int blocks, const void *data, uint64_t nsegs, const int32_t *tile_E,
                                 void *seg_D);
+size_t papr_exact_transpose_lds_bytes(void); /* of the fused sweep's workgroup */
+int papr_exact_fused_waves(void);
+void papr_launch_exact_segments_ccdf(hipStream_t st, int blocks, const void *data, uint64_t nsegs,
+                                     const int32_t *tile_E, void *seg_D, const void *tail, uint32_t tail_samples,
+                                     const uint32_t *table, const papr_ccdf_params &P, size_t lds_table_bytes,
+                                     unsigned long long *ghist);
 void papr_launch_exact_groups(hipStream_t st, const int32_t *tile_E, uint64_t ntiles, const void *seg_D,
                               uint64_t ngroups, papr_exact_group *out);
 

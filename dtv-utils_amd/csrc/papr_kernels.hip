@@ -377,57 +377,6 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_first_nan_kernel(const float2
 // of Gaussian-like IQ) is never counted.  Counters are LDS-privatised per wave
 // (ds_add_u32) and flushed once per workgroup with 64-bit global atomics.
 
-namespace {
-
-struct CcdfShared {
-    uint2 *lut;       // ncells entries (LUT kernel) — or —
-    uint32_t *keys;   // nkeys entries (search kernel)
-    uint32_t *hist;   // copies * nbins
-};
-
-template <int BLOCK>
-__device__ __forceinline__ void hist_flush(const uint32_t *hist, uint32_t nbins, uint32_t copies,
-                                           unsigned long long *__restrict__ ghist)
-{
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < nbins; b += BLOCK) {
-        unsigned long long s = 0;
-        for (uint32_t c = 0; c < copies; c++)
-            s += hist[c * nbins + b];
-        if (s)
-            atomicAdd(&ghist[b], s);
-    }
-}
-
-__device__ __forceinline__ uint32_t lut_bin(uint32_t bits, const uint2 *lut, const papr_ccdf_params &P)
-{
-    const uint32_t rel = (bits >> P.shift) - P.cell_lo;  // wraps to huge below the table
-    uint32_t k;
-    if (rel < P.ncells) {
-        const uint2 e = lut[rel];
-        k = e.x + (bits >= e.y ? 1u : 0u);
-    } else {
-        // above the table but not NaN => above every level; below or NaN => 0
-        k = (bits - P.above_lo) <= P.above_span ? P.nkeys : 0u;
-    }
-    return k;
-}
-
-__device__ __forceinline__ uint32_t search_bin(uint32_t bits, const uint32_t *keys, const papr_ccdf_params &P)
-{
-    if (bits > 0x7F800000u)  // NaN (either sign): above nothing
-        return 0;
-    uint32_t lo = 0;
-    for (uint32_t step = P.search_step; step; step >>= 1) {
-        const uint32_t mid = lo + step;
-        if (mid <= P.nkeys && keys[mid - 1] <= bits)
-            lo = mid;
-    }
-    return lo;
-}
-
-}  // namespace
-
 template <int BLOCK, int U, bool NT, bool PIPE, bool LUT>
 __global__ __launch_bounds__(BLOCK) void papr_ccdf_kernel(const float4 *__restrict__ data, uint64_t ntiles, int map,
                                                            const float2 *__restrict__ tail, uint32_t tail_samples,

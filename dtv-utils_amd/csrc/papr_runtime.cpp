@@ -188,8 +188,10 @@ struct papr_hip_ctx {
     int32_t *d_tile_E = nullptr;
     double *d_seg_D = nullptr;       // 2 x ntiles pairs
     papr_exact_group *d_groups = nullptr;
-    unsigned char *h_program = nullptr;  // pinned
+    unsigned char *h_program = nullptr;  // pinned + mapped: the pack kernel writes the program straight into it
     size_t h_program_cap = 0;
+    uint32_t *d_mixed_list = nullptr, *d_raw_list = nullptr;
+    papr_exact_plan *d_plan = nullptr;
 
     papr_hip_ingest_timing ingest{};
     papr_hip_tuning tune{};
@@ -966,6 +968,9 @@ void papr_hip_close(papr_hip_ctx *ctx)
     if (ctx->d_seg_D) (void)hipFree(ctx->d_seg_D);
     if (ctx->d_groups) (void)hipFree(ctx->d_groups);
     if (ctx->h_program) (void)hipHostFree(ctx->h_program);
+    if (ctx->d_mixed_list) (void)hipFree(ctx->d_mixed_list);
+    if (ctx->d_raw_list) (void)hipFree(ctx->d_raw_list);
+    if (ctx->d_plan) (void)hipFree(ctx->d_plan);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->d_hist) (void)hipFree(ctx->d_hist);
@@ -1257,39 +1262,111 @@ int papr_hip_set_exact(papr_hip_ctx *ctx, int enabled)
     return PAPR_OK;
 }
 
-int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, const void **program, size_t *bytes)
+}  // extern "C"
+
+namespace {
+
+int exact_preconditions(papr_hip_ctx *ctx, double before)
 {
-    if (!ctx || !program || !bytes)
-        return PAPR_E_ARG;
     if (!ctx->exact || !ctx->exact_valid || !ctx->loaded)
-        return fail(ctx, PAPR_E_STATE, "exact program needs papr_hip_set_exact(1) and papr_hip_stats on the current shard first");
+        return fail(ctx, PAPR_E_STATE, "exact sum needs papr_hip_set_exact(1) and papr_hip_stats on the current shard first");
     if (!ctx->resident)
         return fail(ctx, PAPR_E_STATE, "exact sum needs a shard that is resident in HBM");
     if (!(before >= 0.0) || !std::isfinite(before))
         return fail(ctx, PAPR_E_ARG, "`before` must be a finite, non-negative sum");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return PAPR_OK;
+}
+
+constexpr uint32_t kCapMixed = 256, kCapRaw = 512;  // beyond this the program is assembled by the host path
+
+int reserve_program(papr_hip_ctx *ctx, size_t want)  // grow the pinned program buffer, keeping its contents
+{
+    if (want <= ctx->h_program_cap)
+        return PAPR_OK;
+    unsigned char *fresh = nullptr;
+    const size_t cap = std::max<size_t>(want + want / 4, (size_t)1 << 20);
+    HIPCHK(ctx, hipHostMalloc((void **)&fresh, cap, hipHostMallocMapped));
+    if (ctx->h_program) {
+        memcpy(fresh, ctx->h_program, ctx->h_program_cap);
+        (void)hipHostFree(ctx->h_program);
+    }
+    ctx->h_program = fresh;
+    ctx->h_program_cap = cap;
+    return PAPR_OK;
+}
+
+// Device side of the exact sum: classify tiles, one sweep over the samples for the per-segment
+// rounding functions (with pass 2 fused in when `fused` is given), pre-compose the groups and gather
+// the sum program into mapped host memory — one stream synchronisation in total.  *bytes = 0 means
+// the device-side gather overflowed its lists and the caller has to assemble the program itself.
+int run_exact_device(papr_hip_ctx *ctx, double before, uint64_t n_total, const CcdfPlan *fused, size_t *bytes)
+{
     const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
     const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
     const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
     // margin >= the worst-case relative drift of a sequential double sum of n_total non-negative terms
     const double delta = std::max(1.0e-6, 8.0 * (double)std::max<uint64_t>(n_total, ctx->n) * 1.1102230246251565e-16);
-
-    std::vector<papr_exact_group> groups(ngroups);
-    if (ntiles) {
-        int rc = ensure_exact_buffers(ctx);
-        if (rc)
-            return rc;
-        const uint64_t nsegs = 2 * ntiles;
-        const int per_cu = std::max(1, env_int("PAPR_EXACT_WG_PER_CU", 4));
-        const int blocks = (int)std::min<uint64_t>((nsegs + 3) / 4, (uint64_t)ctx->num_cus * per_cu);
-        time_begin(ctx, 2, ntiles * PAPR_EXACT_TILE_SAMPLES * 8);
-        papr_launch_exact_classify(ctx->stream, ctx->d_tile_sums, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E);
+    *bytes = 0;
+    int rc = ensure_exact_buffers(ctx);
+    if (rc)
+        return rc;
+    if (!ctx->d_plan) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_mixed_list, kCapMixed * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_raw_list, kCapRaw * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_plan, sizeof(papr_exact_plan)));
+    }
+    rc = reserve_program(ctx, sizeof(papr_exact_header) + ngroups * sizeof(papr_exact_group_rec) +
+                                  (size_t)kCapMixed * sizeof(papr_exact_mixed_rec) +
+                                  (size_t)kCapRaw * sizeof(papr_exact_raw_rec) + (size_t)tail * 8);
+    if (rc)
+        return rc;
+    unsigned char *program_dev = nullptr;
+    HIPCHK(ctx, hipHostGetDevicePointer((void **)&program_dev, ctx->h_program, 0));
+    const uint64_t nsegs = 2 * ntiles;
+    // plain sweep: 4-wave workgroups, 2 per CU; fused sweep: 8-wave workgroups, 2 per CU (16 waves share the LDS tables)
+    const int per_cu = std::max(1, env_int("PAPR_EXACT_WG_PER_CU", 2));
+    const uint64_t wg_waves = fused ? (uint64_t)papr_exact_fused_waves() : 4;
+    const int blocks =
+        (int)std::max<uint64_t>(1, std::min<uint64_t>((nsegs + wg_waves - 1) / wg_waves, (uint64_t)ctx->num_cus * per_cu));
+    time_begin(ctx, 2, ctx->n * 8);
+    papr_launch_exact_classify(ctx->stream, ctx->d_tile_sums, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E);
+    if (fused)
+        papr_launch_exact_segments_ccdf(ctx->stream, blocks, ctx->d_iq, nsegs, ctx->d_tile_E, ctx->d_seg_D,
+                                        ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, tail, ctx->d_table, fused->P,
+                                        fused->lds_bytes, ctx->d_hist);
+    else
         papr_launch_exact_segments(ctx->stream, blocks, ctx->d_iq, nsegs, ctx->d_tile_E, ctx->d_seg_D);
-        papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
-        time_end(ctx);
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(groups.data(), ctx->d_groups, ngroups * sizeof(papr_exact_group), hipMemcpyDeviceToHost,
-                                   ctx->stream));
+    papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
+    time_end(ctx);
+    papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, ctx->d_iq, ctx->n,
+                           tail, ctx->d_mixed_list, kCapMixed, ctx->d_raw_list, kCapRaw, ctx->d_plan, program_dev);
+    HIPCHK(ctx, hipGetLastError());
+    if (fused)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(fused->P.nkeys + 1) * sizeof(unsigned long long),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    papr_exact_header h;
+    memcpy(&h, ctx->h_program, sizeof(h));
+    if (h.magic == PAPR_EXACT_MAGIC && h.reserved == 0 && h.ngroups == ngroups && h.nsamples == ctx->n &&
+        !env_int("PAPR_EXACT_HOST_ASSEMBLY", 0))  // (the env switch lets the tests exercise the fallback)
+        *bytes = sizeof(h) + ngroups * sizeof(papr_exact_group_rec) + (size_t)h.nmixed * sizeof(papr_exact_mixed_rec) +
+                 (size_t)h.nraw * sizeof(papr_exact_raw_rec) + (size_t)tail * 8;
+    return PAPR_OK;
+}
+
+// Host-driven assembly, for the (never yet seen) case that a shard has more mixed groups / raw tiles
+// than the device-side lists hold.
+int assemble_program_on_host(papr_hip_ctx *ctx, const void **program, size_t *bytes);
+
+int assemble_program_on_host(papr_hip_ctx *ctx, const void **program, size_t *bytes)
+{
+    const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
+    const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
+    const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
+    std::vector<papr_exact_group> groups(ngroups);
+    if (ngroups) {
+        HIPCHK(ctx, hipMemcpyAsync(groups.data(), ctx->d_groups, ngroups * sizeof(papr_exact_group),
+                                   hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     // what has to travel in detail: mixed groups (per-tile classes + per-segment pairs) ...
@@ -1297,20 +1374,7 @@ int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, c
     for (uint64_t g = 0; g < ngroups; g++)
         if (groups[g].E == PAPR_EXACT_AMBIG)
             mixed.push_back(g);
-    auto reserve = [&](size_t want) -> int {  // grow the pinned program buffer, keeping its contents
-        if (want <= ctx->h_program_cap)
-            return PAPR_OK;
-        unsigned char *fresh = nullptr;
-        const size_t cap = std::max<size_t>(want + want / 4, (size_t)1 << 20);
-        HIPCHK(ctx, hipHostMalloc((void **)&fresh, cap, hipHostMallocDefault));
-        if (ctx->h_program) {
-            memcpy(fresh, ctx->h_program, ctx->h_program_cap);
-            (void)hipHostFree(ctx->h_program);
-        }
-        ctx->h_program = fresh;
-        ctx->h_program_cap = cap;
-        return PAPR_OK;
-    };
+    auto reserve = [&](size_t want) -> int { return reserve_program(ctx, want); };
     static_assert(sizeof(papr_exact_group) == sizeof(papr_exact_group_rec), "group record layout");
     const size_t off_groups = sizeof(papr_exact_header);
     const size_t off_mixed = off_groups + ngroups * sizeof(papr_exact_group_rec);
@@ -1376,6 +1440,86 @@ int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, c
     return PAPR_OK;
 }
 
+void counts_from_histogram(const papr_hip_ctx *ctx, const CcdfPlan &plan, int nlevels, uint64_t *counts_above)
+{
+    // samples above unique key i = everything binned at i + 1 or higher
+    const uint32_t m = plan.P.nkeys;
+    std::vector<uint64_t> above(m);
+    uint64_t run = 0;
+    for (uint32_t i = m; i-- > 0;) {
+        run += ctx->h_hist[i + 1];
+        above[i] = run;
+    }
+    for (int j = 0; j < nlevels; j++)
+        counts_above[j] = plan.pos[j] >= 0 ? above[plan.pos[j]] : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, const void **program, size_t *bytes)
+{
+    if (!ctx || !program || !bytes)
+        return PAPR_E_ARG;
+    int rc = exact_preconditions(ctx, before);
+    if (rc)
+        return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    rc = run_exact_device(ctx, before, n_total, nullptr, bytes);
+    if (rc)
+        return rc;
+    *program = ctx->h_program;
+    return *bytes ? PAPR_OK : assemble_program_on_host(ctx, program, bytes);
+}
+
+int papr_hip_ccdf_exact(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above, double before,
+                        uint64_t n_total, const void **program, size_t *bytes)
+{
+    if (!ctx || !program || !bytes || nlevels < 0 || (nlevels && (!levels || !counts_above)))
+        return PAPR_E_ARG;
+    if (nlevels > PAPR_HIP_MAX_LEVELS)
+        return fail(ctx, PAPR_E_LIMIT, "%d levels exceeds PAPR_HIP_MAX_LEVELS (%d)", nlevels, PAPR_HIP_MAX_LEVELS);
+    int rc = exact_preconditions(ctx, before);
+    if (rc)
+        return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CcdfPlan plan;
+    if (nlevels) {
+        rc = plan_ccdf(ctx, levels, nlevels, &plan);
+        if (rc)
+            return rc;
+    }
+    // the fused sweep holds the LUT form of the table plus the 36 KiB transpose buffer in LDS
+    size_t fused_lds = 0;
+    if (nlevels && plan.lut && plan.P.nkeys) {
+        plan.P.copies = std::min<uint32_t>(plan.P.copies, 4);
+        fused_lds = (size_t)plan.P.table_words * 4 + (size_t)plan.P.copies * (plan.P.nkeys + 1) * 4;
+        while (plan.P.copies > 1 && fused_lds > 12 * 1024) {  // two workgroups per CU: 2 x (64 KiB + this) <= 160 KiB
+            plan.P.copies--;
+            fused_lds = (size_t)plan.P.table_words * 4 + (size_t)plan.P.copies * (plan.P.nkeys + 1) * 4;
+        }
+        plan.lds_bytes = fused_lds;
+    }
+    const bool fuse = fused_lds != 0 && fused_lds + papr_exact_transpose_lds_bytes() <= 150 * 1024 && ctx->n > 0;
+    if (!fuse) {  // unusual level table: the two sweeps run one after the other
+        rc = papr_hip_ccdf(ctx, levels, nlevels, counts_above);
+        if (rc)
+            return rc;
+        return papr_hip_exact_program(ctx, before, n_total, program, bytes);
+    }
+    rc = upload_ccdf_table(ctx, plan);
+    if (rc)
+        return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_hist, 0, (size_t)(plan.P.nkeys + 1) * sizeof(unsigned long long), ctx->stream));
+    rc = run_exact_device(ctx, before, n_total, &plan, bytes);
+    if (rc)
+        return rc;
+    counts_from_histogram(ctx, plan, nlevels, counts_above);
+    *program = ctx->h_program;
+    return *bytes ? PAPR_OK : assemble_program_on_host(ctx, program, bytes);
+}
+
 // ---- pass 2 ---------------------------------------------------------------------
 
 int papr_hip_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above)
@@ -1412,15 +1556,7 @@ int papr_hip_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t 
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(m + 1) * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    // samples above unique key i = everything binned at i + 1 or higher
-    std::vector<uint64_t> above(m);
-    uint64_t run = 0;
-    for (uint32_t i = m; i-- > 0;) {
-        run += ctx->h_hist[i + 1];
-        above[i] = run;
-    }
-    for (int j = 0; j < nlevels; j++)
-        counts_above[j] = plan.pos[j] >= 0 ? above[plan.pos[j]] : 0;
+    counts_from_histogram(ctx, plan, nlevels, counts_above);
     return PAPR_OK;
 }
 

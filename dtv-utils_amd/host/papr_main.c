@@ -74,7 +74,8 @@ static void *pass1_thread(void *arg)
 static void *exact_thread(void *arg)
 {
     shard *s = (shard *)arg;
-    s->rc = papr_hip_exact_program(s->ctx, s->before, s->n_total, &s->program, &s->program_bytes);
+    s->rc = papr_hip_ccdf_exact(s->ctx, s->levels, s->nlevels, s->counts, s->before, s->n_total, &s->program,
+                                &s->program_bytes);
     return NULL;
 }
 
@@ -218,9 +219,28 @@ int main(int argc, char **argv)
         sh[g].n_total = nsamples;
         papr_stats_merge(&total, &sh[g].stats);
     }
-    /* papr.c:104 adds in file order in double; reproduce that rounding sequence exactly.  With
-     * NaN/Inf present the merged record already carries the reference's value. */
-    int exact_done = 0;
+    /* ---- host scalars (papr.c:131-141 / 164-173), here from the tree sum ---- */
+    double mean;
+    float papr;
+    int nlevels = papr_levels(&total, graph, &mean, &papr, NULL, 0);
+    if (nlevels > PAPR_HIP_MAX_LEVELS) {
+        fprintf(stderr, "papr: %d levels exceed the supported maximum of %d\n", nlevels, PAPR_HIP_MAX_LEVELS);
+        return 253;
+    }
+    float *level = (float *)malloc((size_t)(nlevels + 1) * sizeof(float));
+    uint64_t *count = (uint64_t *)calloc((size_t)(nlevels + 1), sizeof(uint64_t));
+    papr_levels(&total, graph, NULL, NULL, level, nlevels);
+    for (int g = 0; g < ngpu; g++) {
+        sh[g].levels = level;
+        sh[g].nlevels = nlevels;
+        sh[g].counts = (uint64_t *)calloc((size_t)(nlevels + 1), sizeof(uint64_t));
+    }
+
+    /* ---- pass 2 on every shard (papr.c:142-153 / 174-185).  papr.c:104 adds in file order in double; by
+     * default that rounding sequence is reproduced exactly from the same sweep (papr_hip_ccdf_exact); with
+     * NaN/Inf present the merged record already carries the reference's value. ---- */
+    int exact_done = 0, need_pass2 = nlevels > 0;
+    double t1x = now_s();
     if (exact && isfinite(total.sum) && run_all_quiet(sh, ngpu, exact_thread) == PAPR_OK) {
         const void *progs[MAX_GPUS];
         size_t sizes[MAX_GPUS];
@@ -232,30 +252,33 @@ int main(int argc, char **argv)
         if (papr_exact_chain(progs, sizes, ngpu, &seq) == PAPR_OK) {
             total.sum = seq;
             exact_done = 1;
+            need_pass2 = 0;
+            /* the exact sum almost never moves a float threshold; when it does, pass 2 runs again */
+            float *level2 = (float *)malloc((size_t)(nlevels + 1) * sizeof(float));
+            const int nlevels2 = papr_levels(&total, graph, &mean, &papr, level2, nlevels);
+            if (nlevels2 != nlevels || memcmp(level, level2, (size_t)nlevels * sizeof(float)) != 0) {
+                free(level2);
+                if (nlevels2 > PAPR_HIP_MAX_LEVELS)
+                    return 253;
+                nlevels = nlevels2;
+                level = (float *)realloc(level, (size_t)(nlevels + 1) * sizeof(float));
+                count = (uint64_t *)realloc(count, (size_t)(nlevels + 1) * sizeof(uint64_t));
+                papr_levels(&total, graph, NULL, NULL, level, nlevels);
+                for (int g = 0; g < ngpu; g++) {
+                    sh[g].levels = level;
+                    sh[g].nlevels = nlevels;
+                    sh[g].counts = (uint64_t *)realloc(sh[g].counts, (size_t)(nlevels + 1) * sizeof(uint64_t));
+                }
+                need_pass2 = nlevels > 0;
+            } else {
+                free(level2);
+            }
         }
+        t1x = now_s();
     }
-    const double t1x = now_s();
-
-    /* ---- host scalars (papr.c:131-141 / 164-173) ---- */
-    double mean;
-    float papr;
-    int nlevels = papr_levels(&total, graph, &mean, &papr, NULL, 0);
-    if (nlevels > PAPR_HIP_MAX_LEVELS) {
-        fprintf(stderr, "papr: %d levels exceed the supported maximum of %d\n", nlevels, PAPR_HIP_MAX_LEVELS);
+    if (need_pass2 && run_all(sh, ngpu, pass2_thread) != PAPR_OK)
         return 253;
-    }
-    float *level = (float *)malloc((size_t)(nlevels + 1) * sizeof(float));
-    uint64_t *count = (uint64_t *)calloc((size_t)(nlevels + 1), sizeof(uint64_t));
-    papr_levels(&total, graph, NULL, NULL, level, nlevels);
-
-    /* ---- pass 2 on every shard, counts summed (papr.c:142-153 / 174-185) ---- */
-    for (int g = 0; g < ngpu; g++) {
-        sh[g].levels = level;
-        sh[g].nlevels = nlevels;
-        sh[g].counts = (uint64_t *)calloc((size_t)(nlevels + 1), sizeof(uint64_t));
-    }
-    if (nlevels > 0 && run_all(sh, ngpu, pass2_thread) != PAPR_OK)
-        return 253;
+    memset(count, 0, (size_t)(nlevels + 1) * sizeof(uint64_t));
     for (int g = 0; g < ngpu; g++)
         for (int j = 0; j < nlevels; j++)
             count[j] += sh[g].counts[j];

@@ -191,6 +191,11 @@ int papr_levels(const papr_stats *total, int graph, double *mean, float *papr, f
  * and a finite sum (with NaN/Inf present papr_hip_stats is already exact). */
 int papr_hip_set_exact(papr_hip_ctx *ctx, int enabled);
 int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, const void **program, size_t *bytes);
+/* The same with pass 2 fused into the one sweep over the samples (no extra HBM pass): counts against
+ * `levels` — normally the table derived from the tree sum — AND the sum program.  If the exact sum then
+ * yields a different table (rare: the two sums differ by ~1e-11), call papr_hip_ccdf with the new one. */
+int papr_hip_ccdf_exact(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above, double before,
+                        uint64_t n_total, const void **program, size_t *bytes);
 int papr_exact_chain(const void *const *programs, const size_t *bytes, int nprograms, double *sum_out);
 
 /* ---- pass 2 (papr.c:143-153 / 175-185) ---------------------------------- */

@@ -520,3 +520,48 @@ def test_exact_sum_full_size(pkg, manifest, big):
         print(f"exact program: {len(prog)} bytes, device {tm.exact_ms:.3f} ms")
     finally:
         g.set_exact(False)
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["default", "graph"])
+@pytest.mark.parametrize("n", [1000, 2048 * 3 + 5, 700001, 3 * 1048576 + 123])
+def test_fused_pass2_and_sum_program(pkg, orc, xgpu, n, graph):
+    """papr_hip_ccdf_exact: ONE sweep yields pass 2's counts and the sum program."""
+    xgpu.generate(pkg.SynthSpec.spike(n, seed=900 + n % 97), 0, n)
+    iq = xgpu.download(0, n)
+    st = xgpu.stats()
+    mean, papr, table = pkg.levels(st, graph)
+    counts, prog = xgpu.ccdf_exact(table, 0.0, n)
+    ref = orc.run_mem(iq, graph)
+    assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
+    assert pkg.exact_chain([prog]) == ref["sum"]
+    st.sum = ref["sum"]
+    assert np.array_equal(pkg.levels(st, graph)[2], ref["level"])
+
+
+def test_fused_pass2_falls_back_for_unusual_tables(pkg, orc, xgpu):
+    n = 200003
+    rng = np.random.default_rng(77)
+    iq = rng.standard_normal(2 * n).astype(np.float32)
+    xgpu.upload(iq)
+    xgpu.stats()
+    ref_sum = orc.run_mem(iq, False)["sum"]
+    for tab in (np.linspace(0.9, 1.1, 700).astype(np.float32),              # search form
+                np.array([-1.0, 0.0, np.nan, 1.0], np.float32), np.zeros(0, np.float32),
+                (10 ** np.linspace(-6, 3, 5000)).astype(np.float32)):
+        counts, prog = xgpu.ccdf_exact(tab, 0.0, n)
+        assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, tab))
+        assert pkg.exact_chain([prog]) == ref_sum
+
+
+def test_exact_program_host_assembly_fallback(pkg, orc, xgpu, monkeypatch):
+    """The host-driven program assembly (used when a shard has more mixed groups / raw tiles than the
+    device-side lists hold) produces the same program as the device-side gather."""
+    n = 2_000_003
+    xgpu.generate(pkg.SynthSpec.spike(n, seed=4), 0, n)
+    iq = xgpu.download(0, n)
+    xgpu.stats()
+    dev = xgpu.exact_program(0.0, n)
+    monkeypatch.setenv("PAPR_EXACT_HOST_ASSEMBLY", "1")
+    host = xgpu.exact_program(0.0, n)
+    assert host == dev
+    assert pkg.exact_chain([host]) == orc.run_mem(iq, False)["sum"]
