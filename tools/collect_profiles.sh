@@ -8,17 +8,19 @@ set -u
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
+rm -rf "$O"
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
 $R/bin/hbm_read_probe 10 10 > $O/hbm_read_probe.txt 2>&1
-$B --steps 20 --warmup 3                > $O/bench_default.json 2> $O/bench_default.err
-$B --steps 20 --warmup 3 --mode graph   > $O/bench_graph.json   2> $O/bench_graph.err
-$B --steps 20 --warmup 3 --exact --no-cpu-baseline > $O/bench_exact.json 2> $O/bench_exact.err
+$B                > $O/bench_default.json 2> $O/bench_default.err
+$B --mode graph   > $O/bench_graph.json   2> $O/bench_graph.err
+$B --exact --no-cpu-baseline > $O/bench_exact.json 2> $O/bench_exact.err
+$B --exact --mode graph --no-cpu-baseline > $O/bench_exact_graph.json 2> $O/bench_exact_graph.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_exact -- \
     $B --steps 20 --warmup 3 --exact --no-cpu-baseline > $O/stats_exact.json 2> $O/stats_exact.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
-    $R/bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
+    $R/bench.py --gpus 1 --no-cpu-baseline > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
 # end-to-end CLI (file -> pinned host -> HBM), PCIe-inclusive
 $R/oracle/mkcfile /dev/shm/papr_prof_10g.cfile 1342177280 --spike
 for i in 1 2 3; do

@@ -48,7 +48,7 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for name in ("bench_exact.json", "bench_torchrun1.json", "cli_e2e.txt"):
+    for name in ("bench_exact.json", "bench_exact_graph.json", "bench_torchrun1.json", "cli_e2e.txt"):
         p = os.path.join(src, name)
         if os.path.exists(p) and os.path.getsize(p):
             shutil.copy(p, os.path.join(dst, f"{tag}_{name}"))
