@@ -104,7 +104,7 @@ def test_chain_replays_the_sequential_sum(pkg, orc, case):
 
 def test_chain_rejects_malformed_programs(pkg):
     rng = np.random.default_rng(1)
-    iq = rng.standard_normal(2 * 5000).astype(np.float32)
+    iq = rng.standard_normal(2 * 100000).astype(np.float32)   # 48 tiles: one group, the later tiles safe
     prog, _ = build_program(iq)
     assert pkg.exact_chain([]) == 0.0
     for bad in (prog[:40], b"\x00" * 64, prog[:-8], prog[:4] + b"\x09" + prog[5:]):
