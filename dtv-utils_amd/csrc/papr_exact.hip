@@ -550,6 +550,12 @@ void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, ui
 // shared by more waves and two workgroups (16 waves) fit a CU's 160 KiB of LDS
 constexpr int kSegBlock = 256, kFusedBlock = 512;
 
+void papr_exact_prepare_device(void)  // per device: the fused sweep asks for > 64 KiB of dynamic LDS
+{
+    (void)hipFuncSetAttribute((const void *)papr_exact_seg_kernel<true, kFusedBlock>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+}
+
 size_t papr_exact_transpose_lds_bytes(void)
 {
     return (size_t)(kFusedBlock / kWave) * kSegF4 * sizeof(float4);
@@ -580,12 +586,6 @@ void papr_launch_exact_segments_ccdf(hipStream_t st, int blocks, const void *dat
                                      const uint32_t *table, const papr_ccdf_params &P, size_t lds_table_bytes,
                                      unsigned long long *ghist)
 {
-    static int attr_done = 0;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)papr_exact_seg_kernel<true, kFusedBlock>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-        attr_done = 1;
-    }
     hipLaunchKernelGGL((papr_exact_seg_kernel<true, kFusedBlock>), dim3(blocks), dim3(kFusedBlock),
                        papr_exact_transpose_lds_bytes() + lds_table_bytes, st, (const float4 *)data, nsegs, tile_E,
                        (double2 *)seg_D, (const float2 *)tail, tail_samples, table, P, ghist);

@@ -97,5 +97,7 @@ void papr_launch_ccdf(hipStream_t st, int variant, int blocks, bool nt, bool lut
 void papr_launch_generate(hipStream_t st, int blocks, void *out, uint64_t nsamples, uint64_t first_index,
                           const papr_synth_spec &spec);
 int papr_ccdf_max_dynamic_lds(void);
+void papr_kernels_prepare_device(void); /* call once per device after hipSetDevice */
+void papr_exact_prepare_device(void);
 
 #endif

@@ -566,25 +566,27 @@ void papr_launch_generate(hipStream_t st, int blocks, void *out, uint64_t nsampl
                        spec);
 }
 
+// Largest dynamic-LDS request a pass-2 workgroup may make (160 KiB LDS per CU on gfx950, default
+// limit 64 KiB).  Function attributes belong to the CURRENT device, so every context calls
+// papr_kernels_prepare_device() once after hipSetDevice (a multi-GPU process has several).
 int papr_ccdf_max_dynamic_lds(void)
 {
-    // let one workgroup ask for more than the 64 KiB default when a level
-    // table is very large (160 KiB LDS per CU on gfx950)
-    static int done = 0;
-    const int want = 160 * 1024 - 2048;
-    if (!done) {
+    return 160 * 1024 - 2048;
+}
+
+void papr_kernels_prepare_device(void)
+{
+    const int want = papr_ccdf_max_dynamic_lds();
 #define X(V, B, U, P)                                                                                               \
     (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<B, U, true, P, true>,                                   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);                                     \
     (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<B, U, true, P, false>,                                  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
-        PAPR_FOR_EACH_VARIANT(X)
+    PAPR_FOR_EACH_VARIANT(X)
 #undef X
-        (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<256, 8, false, false, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, want);
-        (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<256, 8, false, false, false>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, want);
-        done = 1;
-    }
-    return want;
+    (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<256, 8, false, false, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<256, 8, false, false, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    papr_exact_prepare_device();
 }

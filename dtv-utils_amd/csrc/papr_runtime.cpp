@@ -936,7 +936,7 @@ int papr_hip_open(papr_hip_ctx **out, int device)
 
     if (ensure_partials(ctx, 4096) != PAPR_OK)
         return bail(PAPR_E_HIP);
-    (void)papr_ccdf_max_dynamic_lds();
+    papr_kernels_prepare_device();  // function attributes are per device
     *out = ctx;
     return PAPR_OK;
 }
