@@ -1223,6 +1223,8 @@ int papr_hip_stats(papr_hip_ctx *ctx, papr_stats *out)
         *out = ctx->file_stats;
         return PAPR_OK;
     }
+    if (!ctx->resident)
+        return fail(ctx, PAPR_E_STATE, "the shard is not resident and has no pass-1 result: reload it");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int nrec = 0;
     int rc = ensure_partials(ctx, (size_t)blocks_of(ctx, PASS1) + 1);
@@ -1257,7 +1259,8 @@ int papr_hip_set_exact(papr_hip_ctx *ctx, int enabled)
     if ((enabled != 0) != ctx->exact) {
         ctx->exact = enabled != 0;
         ctx->exact_valid = false;
-        ctx->have_file_stats = false;  // pass 1 must be re-run in the other mode
+        if (ctx->resident)
+            ctx->have_file_stats = false;  // pass 1 is re-run over the resident shard in the other mode
     }
     return PAPR_OK;
 }
