@@ -1,18 +1,20 @@
 // papr_kernels.hip — gfx950 (MI355X / CDNA4) kernels for the papr hot path.
 //
 // Both passes are pure HBM streaming reductions (8 B per IQ sample per pass,
-// ~20 VALU ops per sample, no data reuse): no MFMA, no tiling through LDS for
-// the samples themselves.  What matters is 16-byte-per-lane coalesced loads
-// with many in flight, enough resident wave64s per CU, and keeping the
-// reduction state (trackers, LDS histograms) off the global-memory path.
+// 15-23 VALU ops per sample, no data reuse): no MFMA, no tiling through LDS for
+// the samples themselves.  What matters is 16-byte-per-lane coalesced
+// nontemporal loads with the next ones already in flight, the right number of
+// resident wave64s per CU (measured: 8 for pass 1, 16 for pass 2), and keeping
+// the reduction state (trackers, LDS histograms) off the global-memory path.
 //
-//   papr_stats_kernel     pass 1  (reference papr.c:102-128)
-//   papr_stats_finalize   tail samples + fixed-order merge of workgroup partials
-//   papr_first_nan_kernel only launched when the sum came out NaN
-//   papr_ccdf_lut_kernel  pass 2  (reference papr.c:145-152 / 177-184) via an
-//                         exact bit-pattern LUT + LDS-privatised histograms
-//   papr_ccdf_search_kernel  same result for level tables the LUT cannot hold
-//   papr_generate_kernel  synthetic IQ (include/papr_synth.h) straight into HBM
+//   papr_stats_kernel<B,U,NT,PIPE,TSUM>  pass 1  (reference papr.c:102-128)
+//   papr_stats_finalize    tail samples + fixed-order merge of workgroup partials
+//   papr_first_nan_kernel  only launched when the sum came out NaN
+//   papr_ccdf_kernel<B,U,NT,PIPE,LUT>    pass 2  (reference papr.c:145-152 / 177-184):
+//                          LUT = exact bit-pattern lookup table, else a binary search for
+//                          level tables the LUT cannot hold; LDS-privatised histograms
+//   papr_generate_kernel   synthetic IQ (include/papr_synth.h) straight into HBM
+// (the bit-exact sequential-sum kernels live in papr_exact.hip)
 //
 // Arithmetic contract (SURVEY.md appendix A rule 3): power = fl(fl(I*I) +
 // fl(Q*Q)) in float with NO fused multiply-add; this file is compiled with
@@ -229,7 +231,7 @@ __device__ __forceinline__ void load_tile(float4 (&x)[U], const float4 *p)
 // each tile, tile_sums[(tile_offset + tile) * (BLOCK/64) + wave]; the waves of a
 // workgroup together cover the tile, so those BLOCK/64 numbers add up to the
 // tile's sum (papr_exact.hip turns them into per-tile prefix sums).
-template <int BLOCK, int U, bool NT, bool PIPE, bool TSUM = false>
+template <int BLOCK, int U, bool NT, int PIPE, bool TSUM = false>
 __global__ __launch_bounds__(BLOCK) void papr_stats_kernel(const float4 *__restrict__ data, uint64_t ntiles,
                                                             uint64_t base_index, int map,
                                                             papr_partial *__restrict__ out,
@@ -250,7 +252,25 @@ __global__ __launch_bounds__(BLOCK) void papr_stats_kernel(const float4 *__restr
     const float4 *p = data + w.first * TILE_F4 + t;
     const uint64_t step = w.stride * TILE_F4;
     uint32_t code = 0;
-    if constexpr (PIPE) {
+    if constexpr (PIPE == 2) {
+        // true double buffering: two register sets and a loop unrolled by two, so that the compiler's
+        // wait counts are exact ("the other set may still be in flight") instead of the conservative
+        // vmcnt(0) it derives for the copy-based form below
+        float4 a[U], b[U];
+        const float4 *plast = data + (w.first + (uint64_t)(w.count ? w.count - 1 : 0) * w.stride) * TILE_F4 + t;
+        if (w.count)
+            load_tile<BLOCK, U, NT>(a, p);
+        uint32_t it = 0;
+        for (; it + 1 < w.count; it += 2, code += 4 * U) {
+            load_tile<BLOCK, U, NT>(b, p + step);
+            emit_tile_sum(it, stats_fold<U, TSUM>(r, a, code));
+            p += 2 * step;
+            load_tile<BLOCK, U, NT>(a, it + 2 < w.count ? p : plast);  // past the end: harmless re-read
+            emit_tile_sum(it + 1, stats_fold<U, TSUM>(r, b, code + 2 * U));
+        }
+        if (it < w.count)
+            emit_tile_sum(it, stats_fold<U, TSUM>(r, a, code));
+    } else if constexpr (PIPE == 1) {
         float4 cur[U], nxt[U];
         if (w.count)
             load_tile<BLOCK, U, NT>(cur, p);
@@ -377,7 +397,7 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_first_nan_kernel(const float2
 // of Gaussian-like IQ) is never counted.  Counters are LDS-privatised per wave
 // (ds_add_u32) and flushed once per workgroup with 64-bit global atomics.
 
-template <int BLOCK, int U, bool NT, bool PIPE, bool LUT>
+template <int BLOCK, int U, bool NT, int PIPE, bool LUT>
 __global__ __launch_bounds__(BLOCK) void papr_ccdf_kernel(const float4 *__restrict__ data, uint64_t ntiles, int map,
                                                            const float2 *__restrict__ tail, uint32_t tail_samples,
                                                            const uint32_t *__restrict__ table, papr_ccdf_params P,
@@ -416,7 +436,22 @@ __global__ __launch_bounds__(BLOCK) void papr_ccdf_kernel(const float4 *__restri
     const TileWalk w = tile_walk(blockIdx.x, gridDim.x, ntiles, map);
     const float4 *p = data + w.first * TILE_F4 + t;
     const uint64_t step = w.stride * TILE_F4;
-    if constexpr (PIPE) {
+    if constexpr (PIPE == 2) {  // true double buffering, see papr_stats_kernel
+        float4 a[U], b[U];
+        const float4 *plast = data + (w.first + (uint64_t)(w.count ? w.count - 1 : 0) * w.stride) * TILE_F4 + t;
+        if (w.count)
+            load_tile<BLOCK, U, NT>(a, p);
+        uint32_t it = 0;
+        for (; it + 1 < w.count; it += 2) {
+            load_tile<BLOCK, U, NT>(b, p + step);
+            fold(a);
+            p += 2 * step;
+            load_tile<BLOCK, U, NT>(a, it + 2 < w.count ? p : plast);
+            fold(b);
+        }
+        if (it < w.count)
+            fold(a);
+    } else if constexpr (PIPE == 1) {
         float4 cur[U], nxt[U];
         if (w.count)
             load_tile<BLOCK, U, NT>(cur, p);
@@ -467,12 +502,14 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_generate_kernel(float2 *__res
 //    0: 256x8      1: 256x4 P    2: 256x8 P    3: 512x8      4: 1024x4
 //    5: 256x16     6: 512x4 P    7: 256x4      8: 1024x4 P   9: 1024x2 P
 //   10: 512x2 P   11: 256x2 P   12: 1024x2    13: 512x4
+//   14: 256x4 D   15: 512x4 D   16: 256x8 D   17: 1024x4 D      (D = true double buffering, unrolled by two)
 // Plain (non-"nt") loads exist for variant 0 only (A/B of the nontemporal hint).
 
 #define PAPR_FOR_EACH_VARIANT(X) \
-    X(0, 256, 8, false) X(1, 256, 4, true) X(2, 256, 8, true) X(3, 512, 8, false) X(4, 1024, 4, false) \
-    X(5, 256, 16, false) X(6, 512, 4, true) X(7, 256, 4, false) X(8, 1024, 4, true) X(9, 1024, 2, true) \
-    X(10, 512, 2, true) X(11, 256, 2, true) X(12, 1024, 2, false) X(13, 512, 4, false)
+    X(0, 256, 8, 0) X(1, 256, 4, 1) X(2, 256, 8, 1) X(3, 512, 8, 0) X(4, 1024, 4, 0) \
+    X(5, 256, 16, 0) X(6, 512, 4, 1) X(7, 256, 4, 0) X(8, 1024, 4, 1) X(9, 1024, 2, 1) \
+    X(10, 512, 2, 1) X(11, 256, 2, 1) X(12, 1024, 2, 0) X(13, 512, 4, 0) \
+    X(14, 256, 4, 2) X(15, 512, 4, 2) X(16, 256, 8, 2) X(17, 1024, 4, 2)
 
 int papr_variant_geometry(int variant, int *block, int *unroll)
 {
@@ -488,7 +525,7 @@ void papr_launch_stats(hipStream_t st, int variant, int blocks, bool nt, const v
                        uint64_t base_index, int map, papr_partial *out)
 {
     if (variant == 0 && !nt) {
-        hipLaunchKernelGGL((papr_stats_kernel<256, 8, false, false>), dim3(blocks), dim3(256), 0, st,
+        hipLaunchKernelGGL((papr_stats_kernel<256, 8, false, 0>), dim3(blocks), dim3(256), 0, st,
                            (const float4 *)data, ntiles, base_index, map, out, (double *)nullptr, (uint64_t)0);
         return;
     }
@@ -508,7 +545,7 @@ void papr_launch_stats_tilesums(hipStream_t st, int blocks, const void *data, ui
                                 int map, papr_partial *out, double *tile_sums, uint64_t tile_offset)
 {
     static_assert(2 * 256 * 4 == PAPR_EXACT_TILE_SAMPLES, "exact-sum tile geometry");
-    hipLaunchKernelGGL((papr_stats_kernel<256, 4, true, true, true>), dim3(blocks), dim3(256), 0, st,
+    hipLaunchKernelGGL((papr_stats_kernel<256, 4, true, 1, true>), dim3(blocks), dim3(256), 0, st,
                        (const float4 *)data, ntiles, base_index, map, out, tile_sums, tile_offset);
 }
 
@@ -526,7 +563,7 @@ void papr_launch_first_nan(hipStream_t st, int blocks, const void *data, uint64_
                        base_index, key);
 }
 
-template <int B, int U, bool NT, bool P>
+template <int B, int U, bool NT, int P>
 static void launch_ccdf_variant(hipStream_t st, int blocks, bool lut, size_t lds_bytes, const void *data,
                                 uint64_t ntiles, int map, const void *tail, uint32_t tail_samples,
                                 const uint32_t *table, const papr_ccdf_params &Pm, unsigned long long *ghist)
@@ -544,7 +581,7 @@ void papr_launch_ccdf(hipStream_t st, int variant, int blocks, bool nt, bool lut
                       const papr_ccdf_params &P, unsigned long long *ghist)
 {
     if (variant == 0 && !nt) {
-        launch_ccdf_variant<256, 8, false, false>(st, blocks, lut, lds_bytes, data, ntiles, map, tail, tail_samples,
+        launch_ccdf_variant<256, 8, false, 0>(st, blocks, lut, lds_bytes, data, ntiles, map, tail, tail_samples,
                                                   table, P, ghist);
         return;
     }
@@ -584,9 +621,9 @@ void papr_kernels_prepare_device(void)
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
     PAPR_FOR_EACH_VARIANT(X)
 #undef X
-    (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<256, 8, false, false, true>,
+    (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<256, 8, false, 0, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
-    (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<256, 8, false, false, false>,
+    (void)hipFuncSetAttribute((const void *)papr_ccdf_kernel<256, 8, false, 0, false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
     papr_exact_prepare_device();
 }
