@@ -41,10 +41,17 @@ def test_single_process_line_with_cpu_baseline():
     assert cb["gpu_stdout_identical"] is True
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 @pytest.mark.parametrize("extra", [[], ["--mode", "graph", "--exact"]])
 def test_torchrun_single_rank_uses_rccl(extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--gib", "0.5",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--gib", "0.5",
            "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *extra]
     p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
