@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libpapr_oracle.so")
 CLI_PATH = os.path.join(_HERE, "papr_oracle")
 MKCFILE = os.path.join(_HERE, "mkcfile")
 REF_CLI = os.path.join(_HERE, "_ref", "papr")  # the real reference, when it was built
+REF_CLI_VECTORISED = os.path.join(_HERE, "_ref", "papr_o3avx2")  # same source, gcc -O3 -mavx2 -ffp-contract=off
 
 
 class Result(C.Structure):
