@@ -22,6 +22,7 @@ import os
 import subprocess
 import sys
 import time
+import zlib
 
 import numpy as np
 import torch
@@ -88,6 +89,9 @@ def main():
     ap.add_argument("--exact", action="store_true",
                     help="also reproduce the reference's sequential double sum bit for bit every step "
                          "(rounding functions computed in the pass-2 sweep + a short host chain); off by default")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend; gloo (+ ranks sharing GPUs round-robin) exists so the N>1 "
+                         "code path can be exercised on a box with fewer GPUs than ranks")
     ap.add_argument("--cpu-sample-gib", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -107,13 +111,18 @@ def main():
         raise SystemExit("for --gpus > 1 launch with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the papr product has no CPU path")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ   # under torchrun even N=1 goes through RCCL
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = ge.load_package()
     from dtv_utils_amd import exchange
@@ -127,7 +136,7 @@ def main():
     gpu.generate(pkg.SynthSpec.spike(total), rank * per_gpu, per_gpu)
 
     result = {}
-    xch = exchange.Exchange(device)
+    xch = exchange.Exchange(device if args.backend == "nccl" else torch.device("cpu"))
 
     if args.exact:
         gpu.set_exact(True)
@@ -170,7 +179,7 @@ def main():
     tm = gpu.timing()
     gpu.set_timing(False)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -207,8 +216,10 @@ def main():
                        "levels": int(result["table"].size), "papr_db": round(float(result["papr"]), 6),
                        "exact_sequential_sum": bool(args.exact), "sum_hex": float(result["total"].sum).hex(),
                        "exact_pass2_reruns": int(result.get("reruns", 0)),
+                       "counts_crc32": zlib.crc32(np.ascontiguousarray(result["counts"], dtype=np.uint64).tobytes()),
                        "sharding": f"sample axis, {world} contiguous shard(s)",
-                       "exchange": "RCCL all-gather(stats) + all-reduce(counts)" if use_dist else "none"},
+                       "exchange": ("RCCL" if args.backend == "nccl" else "gloo") +
+                                   " all-gather(stats) + all-reduce(counts)" if use_dist else "none"},
             "roofline": {"bound": "hbm", "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": per_gpu * 8,

@@ -60,3 +60,32 @@ def test_torchrun_single_rank_uses_rccl(extra):
     d = check(lines[0], 3, 1)
     assert d["config"]["exchange"].startswith("RCCL")
     assert d["config"]["exact_sequential_sum"] == ("--exact" in extra)
+
+
+def _run_bench(nproc, gib, extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+               "--backend", "gloo"]
+    cmd += ["--gpus", str(nproc), "--gib", str(gib), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *extra]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode", ["default", "graph"])
+def test_sharded_run_equals_single_shard_run(mode):
+    """The N>1 code path of bench.py (rank-dependent shard of ONE global stream, stats all-gather + ordered
+    merge, chained exact-sum programs, count all-reduce) on a box with one GPU: 2 and 4 ranks share it over
+    gloo, and must reproduce the 1-rank result over the same stream bit for bit."""
+    extra = ["--mode", mode, "--exact"]
+    one = _run_bench(1, 0.5, extra)
+    for ranks in (2, 4):
+        many = _run_bench(ranks, 0.5 / ranks, extra)
+        assert many["n_gpus"] == ranks and many["config"]["samples_total"] == one["config"]["samples_total"]
+        for key in ("sum_hex", "papr_db", "levels", "counts_crc32"):
+            assert many["config"][key] == one["config"][key], (ranks, key)
+        assert many["config"]["exchange"].startswith("gloo")
