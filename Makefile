@@ -38,14 +38,18 @@ bin/papr: $(PKG)/host/papr_main.c include/papr_hip.h $(LIB)
 oracle:
 	$(MAKE) -C oracle all
 
-tools: bin/hbm_read_probe
+tools: bin/hbm_read_probe bin/ingest_probe
+
+bin/ingest_probe: tools/ingest_probe.cpp
+	@mkdir -p bin
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Wno-unused-result $< -o $@ -lpthread
 
 bin/hbm_read_probe: tools/hbm_read_probe.hip
 	@mkdir -p bin
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Wno-unused-result $< -o $@
 
 clean:
-	rm -f $(CSRC)/*.o $(LIB) bin/papr bin/hbm_read_probe
+	rm -f $(CSRC)/*.o $(LIB) bin/papr bin/hbm_read_probe bin/ingest_probe
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib cli oracle tools clean

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -85,6 +86,40 @@ int main(int argc, char **argv)
         }
         t1 = now();
         printf(", \"pread_%dthr_GBs\": %.1f", nthr, total / (t1 - t0) / 1e9);
+    }
+    // mmap + hipHostRegister: DMA straight out of the page cache, no staging copy
+    {
+        const size_t total = std::min(bytes, (size_t)4 << 30);
+        void *m = mmap(nullptr, total, PROT_READ, MAP_SHARED, fd, 0);
+        if (m != MAP_FAILED) {
+            const size_t piece = 256u << 20;
+            double treg = 0, tcopy = 0, tunreg = 0;
+            bool ok = true;
+            for (size_t off = 0; off < total && ok; off += piece) {
+                const size_t len = std::min(piece, total - off);
+                t0 = now();
+                hipError_t e = hipHostRegister((char *)m + off, len, hipHostRegisterDefault);
+                t1 = now();
+                if (e != hipSuccess) {
+                    printf(", \"mmap_register_error\": \"%s\"", hipGetErrorString(e));
+                    ok = false;
+                    break;
+                }
+                treg += t1 - t0;
+                t0 = now();
+                hipMemcpyAsync((char *)d + off, (char *)m + off, len, hipMemcpyHostToDevice, s);
+                hipStreamSynchronize(s);
+                t1 = now();
+                tcopy += t1 - t0;
+                t0 = now();
+                hipHostUnregister((char *)m + off);
+                tunreg += now() - t0;
+            }
+            if (ok)
+                printf(", \"mmap_register_GBs\": %.1f, \"mmap_h2d_GBs\": %.1f, \"mmap_unregister_GBs\": %.1f, \"mmap_total_GBs\": %.1f",
+                       total / treg / 1e9, total / tcopy / 1e9, total / tunreg / 1e9, total / (treg + tcopy + tunreg) / 1e9);
+            munmap(m, total);
+        }
     }
     printf("}\n");
     return 0;
