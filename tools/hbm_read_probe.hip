@@ -37,6 +37,54 @@ __global__ __launch_bounds__(BLOCK) void read_kernel(const f32x4 *__restrict__ d
         out[0] = acc;  // keeps the loads alive
 }
 
+// the same sweep through a buffer descriptor with an explicit cache-policy field (aux: 1 = sc0,
+// 2 = nt, 16 = sc1 and their sums), to see whether any policy beats the plain nontemporal hint
+template <int BLOCK, int U, int AUX>
+__global__ __launch_bounds__(BLOCK) void read_kernel_buf(const f32x4 *__restrict__ data, uint64_t ntiles, unsigned *out)
+{
+    unsigned acc = 0;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const f32x4 *tile = data + t * (BLOCK * U);
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(tile), 0, BLOCK * U * 16, 0x00027000);
+        u32x4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            x[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (u * BLOCK + threadIdx.x) * 16, 0, AUX));
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            acc ^= x[u].x ^ x[u].y ^ x[u].z ^ x[u].w;
+    }
+    if (acc == 0x12345678u)
+        out[0] = acc;
+}
+
+template <int BLOCK, int U, int AUX>
+static void run_buf(const void *d, size_t bytes, unsigned *out, int blocks, int rounds)
+{
+    const uint64_t ntiles = bytes / ((size_t)BLOCK * U * 16);
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    std::vector<float> ms;
+    for (int r = 0; r < rounds + 2; r++) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((read_kernel_buf<BLOCK, U, AUX>), dim3(blocks), dim3(BLOCK), 0, 0, (const f32x4 *)d, ntiles, out);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float t;
+        hipEventElapsedTime(&t, a, b);
+        if (r >= 2)
+            ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    const double used = (double)ntiles * BLOCK * U * 16;
+    printf("{\"probe\": \"buffer_load\", \"block\": %d, \"unroll\": %d, \"aux\": %d, \"blocks\": %d, \"median_ms\": %.4f, "
+           "\"GB/s_median\": %.1f, \"GB/s_best\": %.1f}\n",
+           BLOCK, U, AUX, blocks, ms[ms.size() / 2], used / ms[ms.size() / 2] / 1e6, used / ms[0] / 1e6);
+    fflush(stdout);
+}
+
 __global__ void fill_kernel(unsigned *p, uint64_t n)
 {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x)
@@ -91,6 +139,18 @@ int main(int argc, char **argv)
     run<512, 8, true>("read", d, bytes, out, 1024, rounds);
     run<1024, 4, true>("read", d, bytes, out, 512, rounds);
     run<1024, 8, true>("read", d, bytes, out, 256, rounds);
+    if (argc > 3) {  // cache-policy sweep (optional third argument)
+        run_buf<256, 4, 0>(d, bytes, out, 512, rounds);
+        run_buf<256, 4, 1>(d, bytes, out, 512, rounds);
+        run_buf<256, 4, 2>(d, bytes, out, 512, rounds);
+        run_buf<256, 4, 3>(d, bytes, out, 512, rounds);
+        run_buf<256, 4, 16>(d, bytes, out, 512, rounds);
+        run_buf<256, 4, 17>(d, bytes, out, 512, rounds);
+        run_buf<256, 4, 18>(d, bytes, out, 512, rounds);
+        run_buf<256, 4, 19>(d, bytes, out, 512, rounds);
+        run_buf<256, 8, 2>(d, bytes, out, 512, rounds);
+        run_buf<256, 8, 18>(d, bytes, out, 512, rounds);
+    }
     hipFree(d);
     hipFree(out);
     return 0;
