@@ -174,7 +174,9 @@ __global__ __launch_bounds__(256) void papr_exact_scan_blocks(double *__restrict
 
 __global__ __launch_bounds__(256) void papr_exact_classify(const double *__restrict__ tws, uint64_t ntiles,
                                                             const double *__restrict__ block_prefix, double delta,
-                                                            int32_t *__restrict__ tile_E)
+                                                            int32_t *__restrict__ tile_E,
+                                                            uint32_t *__restrict__ ambig_list, uint32_t ambig_cap,
+                                                            uint32_t *__restrict__ ambig_count)
 {
     __shared__ double sh[256];
     const uint64_t t0 = (uint64_t)blockIdx.x * kTilesPerBlock + (uint64_t)threadIdx.x * 4;
@@ -213,6 +215,11 @@ __global__ __launch_bounds__(256) void papr_exact_classify(const double *__restr
             }
         }
         tile_E[t0 + k] = cls;
+        if (cls == PAPR_EXACT_AMBIG && ambig_list) {  // re-streamed shards: remember which tiles to capture raw
+            const uint32_t pos = atomicAdd(ambig_count, 1u);
+            if (pos < ambig_cap)
+                ambig_list[pos] = (uint32_t)(t0 + k);
+        }
         P += sk;
     }
 }
@@ -381,6 +388,43 @@ __global__ __launch_bounds__(256) void papr_exact_group_kernel(const int32_t *__
         out[g] = rec;
 }
 
+// ---- re-streamed shards: keep the unprovable tiles while their chunk is on the device ------------
+
+// ascending order of the (few) tile numbers collected by papr_exact_classify: rank sort, one workgroup
+__global__ __launch_bounds__(512) void papr_exact_sort_list_kernel(const uint32_t *__restrict__ list,
+                                                                    const uint32_t *__restrict__ count, uint32_t cap,
+                                                                    uint32_t *__restrict__ sorted)
+{
+    const uint32_t n = min(*count, cap);
+    for (uint32_t i = threadIdx.x; i < n; i += 512) {
+        const uint32_t v = list[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; j++)
+            rank += list[j] < v;
+        sorted[rank] = v;  // tile numbers are distinct
+    }
+}
+
+// copy the listed tiles that lie in the chunk now staged on the device into raw_store[k]
+__global__ __launch_bounds__(256) void papr_exact_capture_kernel(const float *__restrict__ chunk, uint64_t chunk_tile0,
+                                                                  uint64_t chunk_ntiles,
+                                                                  const uint32_t *__restrict__ sorted,
+                                                                  const uint32_t *__restrict__ count, uint32_t cap,
+                                                                  float *__restrict__ raw_store)
+{
+    const uint32_t k = blockIdx.x;
+    if (k >= min(*count, cap))
+        return;
+    const uint64_t t = sorted[k];
+    if (t < chunk_tile0 || t >= chunk_tile0 + chunk_ntiles)
+        return;
+    const unsigned long long *src =
+        reinterpret_cast<const unsigned long long *>(chunk + 2 * (t - chunk_tile0) * PAPR_EXACT_TILE_SAMPLES);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(raw_store + 2 * (uint64_t)k * PAPR_EXACT_TILE_SAMPLES);
+    for (uint32_t i = threadIdx.x; i < PAPR_EXACT_TILE_SAMPLES; i += 256)
+        dst[i] = src[i];
+}
+
 // ---- program assembly on the device ---------------------------------------------------------
 // The sum program (papr_exact_format.h) is gathered by two small kernels straight into mapped
 // pinned host memory, so the host does one stream synchronisation instead of ~50 small copies.
@@ -463,7 +507,9 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(const papr_exact_p
                                                                const papr_exact_group *__restrict__ groups,
                                                                uint64_t ngroups, const int32_t *__restrict__ tile_E,
                                                                uint64_t ntiles, const double *__restrict__ seg_D,
-                                                               const float *__restrict__ data, uint64_t nsamples,
+                                                               const float *__restrict__ data,
+                                                               const float *__restrict__ raw_store,
+                                                               const float *__restrict__ tail_src, uint64_t nsamples,
                                                                uint32_t tail_samples, uint32_t group_blocks,
                                                                uint32_t cap_mixed, uint32_t cap_raw,
                                                                unsigned char *__restrict__ out)
@@ -506,14 +552,16 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(const papr_exact_p
         unsigned char *rec = out + off_raw + (size_t)b * 16392;
         if (threadIdx.x == 0)
             *reinterpret_cast<unsigned long long *>(rec) = t;
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(data + 2 * t * PAPR_EXACT_TILE_SAMPLES);
+        // resident shard: the tile itself; re-streamed shard: the copy captured while its chunk was staged
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(
+            raw_store ? raw_store + 2 * (uint64_t)b * PAPR_EXACT_TILE_SAMPLES : data + 2 * t * PAPR_EXACT_TILE_SAMPLES);
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(rec + 8);
         for (uint32_t k = threadIdx.x; k < PAPR_EXACT_TILE_SAMPLES; k += 256)
             dst[k] = src[k];  // one IQ pair per 8-byte word
         return;
     }
     // last workgroup: the tail samples and the header (layout of papr_exact_header)
-    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(data + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES);
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(tail_src);
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(out + off_tail);
     for (uint32_t k = threadIdx.x; k < tail_samples; k += 256)
         dst[k] = src[k];
@@ -535,7 +583,8 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(const papr_exact_p
 // ---- launch wrappers -------------------------------------------------------------------------
 
 void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, uint64_t ntiles, double *block_sums,
-                                double before, double delta, int32_t *tile_E)
+                                double before, double delta, int32_t *tile_E, uint32_t *ambig_list, uint32_t ambig_cap,
+                                uint32_t *ambig_count, uint32_t *ambig_sorted)
 {
     const uint32_t nb = (uint32_t)((ntiles + kTilesPerBlock - 1) / kTilesPerBlock);
     if (nb == 0)
@@ -543,7 +592,17 @@ void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, ui
     hipLaunchKernelGGL(papr_exact_block_sums, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums);
     hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before);
     hipLaunchKernelGGL(papr_exact_classify, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums, delta,
-                       tile_E);
+                       tile_E, ambig_list, ambig_cap, ambig_count);
+    if (ambig_list)
+        hipLaunchKernelGGL(papr_exact_sort_list_kernel, dim3(1), dim3(512), 0, st, ambig_list, ambig_count, ambig_cap,
+                           ambig_sorted);
+}
+
+void papr_launch_exact_capture(hipStream_t st, const void *chunk, uint64_t chunk_tile0, uint64_t chunk_ntiles,
+                               const uint32_t *sorted, const uint32_t *count, uint32_t cap, void *raw_store)
+{
+    hipLaunchKernelGGL(papr_exact_capture_kernel, dim3(cap), dim3(256), 0, st, (const float *)chunk, chunk_tile0,
+                       chunk_ntiles, sorted, count, cap, (float *)raw_store);
 }
 
 // workgroup sizes: 4 waves for the plain sweep; 8 waves for the fused one so that the level table is
@@ -602,14 +661,16 @@ void papr_launch_exact_groups(hipStream_t st, const int32_t *tile_E, uint64_t nt
 }
 
 void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint64_t ngroups, const int32_t *tile_E,
-                            uint64_t ntiles, const void *seg_D, const void *data, uint64_t nsamples,
-                            uint32_t tail_samples, uint32_t *mixed_list, uint32_t cap_mixed, uint32_t *raw_list,
-                            uint32_t cap_raw, papr_exact_plan *plan, unsigned char *out_mapped)
+                            uint64_t ntiles, const void *seg_D, const void *data, const void *raw_store,
+                            const void *tail_src, uint64_t nsamples, uint32_t tail_samples, uint32_t *mixed_list,
+                            uint32_t cap_mixed, uint32_t *raw_list, uint32_t cap_raw, papr_exact_plan *plan,
+                            unsigned char *out_mapped)
 {
     hipLaunchKernelGGL(papr_exact_plan_kernel, dim3(1), dim3(256), 0, st, groups, ngroups, tile_E, ntiles, mixed_list,
                        cap_mixed, raw_list, cap_raw, plan);
     const uint32_t group_blocks = (uint32_t)std::min<uint64_t>(64, (ngroups * 3 + 255) / 256 + 1);
     hipLaunchKernelGGL(papr_exact_pack_kernel, dim3(group_blocks + cap_mixed + cap_raw + 1), dim3(256), 0, st, plan,
                        mixed_list, raw_list, groups, ngroups, tile_E, ntiles, (const double *)seg_D, (const float *)data,
-                       nsamples, tail_samples, group_blocks, cap_mixed, cap_raw, out_mapped);
+                       (const float *)raw_store, (const float *)tail_src, nsamples, tail_samples, group_blocks, cap_mixed,
+                       cap_raw, out_mapped);
 }

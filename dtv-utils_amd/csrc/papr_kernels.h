@@ -66,11 +66,16 @@ struct papr_exact_plan {
 };
 
 void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint64_t ngroups, const int32_t *tile_E,
-                            uint64_t ntiles, const void *seg_D, const void *data, uint64_t nsamples,
-                            uint32_t tail_samples, uint32_t *mixed_list, uint32_t cap_mixed, uint32_t *raw_list,
-                            uint32_t cap_raw, papr_exact_plan *plan, unsigned char *out_mapped);
+                            uint64_t ntiles, const void *seg_D, const void *data, const void *raw_store,
+                            const void *tail_src, uint64_t nsamples, uint32_t tail_samples, uint32_t *mixed_list,
+                            uint32_t cap_mixed, uint32_t *raw_list, uint32_t cap_raw, papr_exact_plan *plan,
+                            unsigned char *out_mapped);
+/* ambig_* may be null (resident shards); otherwise the unprovable tiles are also listed, ascending, in ambig_sorted */
 void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, uint64_t ntiles, double *block_sums,
-                                double before, double delta, int32_t *tile_E);
+                                double before, double delta, int32_t *tile_E, uint32_t *ambig_list, uint32_t ambig_cap,
+                                uint32_t *ambig_count, uint32_t *ambig_sorted);
+void papr_launch_exact_capture(hipStream_t st, const void *chunk, uint64_t chunk_tile0, uint64_t chunk_ntiles,
+                               const uint32_t *sorted, const uint32_t *count, uint32_t cap, void *raw_store);
 void papr_launch_exact_segments(hipStream_t st, int blocks, const void *data, uint64_t nsegs, const int32_t *tile_E,
                                 void *seg_D);
 size_t papr_exact_transpose_lds_bytes(void); /* of the fused sweep's workgroup */

@@ -192,6 +192,8 @@ struct papr_hip_ctx {
     size_t h_program_cap = 0;
     uint32_t *d_mixed_list = nullptr, *d_raw_list = nullptr;
     papr_exact_plan *d_plan = nullptr;
+    uint32_t *d_ambig = nullptr;   // re-streamed shards: [0, cap) unordered list, [cap, 2 cap) sorted list, [2 cap] count
+    float *d_raw_store = nullptr;  // ... and the captured raw tiles
 
     papr_hip_ingest_timing ingest{};
     papr_hip_tuning tune{};
@@ -716,7 +718,34 @@ int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage)
     return PAPR_OK;
 }
 
-enum StreamPass { PASS_LOAD_STATS, PASS_STREAM_STATS, PASS_STREAM_CCDF, PASS_STREAM_NAN };
+constexpr uint32_t kCapMixed = 256, kCapRaw = 512;  // beyond this the program is assembled by the host path
+
+// exact-sum mode on a re-streamed shard: the fused sweep (rounding functions + pass 2) over one staged chunk,
+// and the unprovable tiles of that chunk kept for the sum program
+int launch_fused_chunk(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *chunk, uint64_t s0, uint64_t cnt, bool last)
+{
+    const uint64_t tile0 = s0 / PAPR_EXACT_TILE_SAMPLES, ntiles = cnt / PAPR_EXACT_TILE_SAMPLES;
+    const uint32_t tail = (uint32_t)(cnt - ntiles * PAPR_EXACT_TILE_SAMPLES);  // only the last chunk has one
+    const uint64_t nsegs = 2 * ntiles;
+    const uint64_t wg_waves = (uint64_t)papr_exact_fused_waves();
+    const int per_cu = std::max(1, env_int("PAPR_EXACT_WG_PER_CU", 2));
+    const int blocks =
+        (int)std::max<uint64_t>(1, std::min<uint64_t>((nsegs + wg_waves - 1) / wg_waves, (uint64_t)ctx->num_cus * per_cu));
+    time_begin(ctx, 2, cnt * 8);
+    papr_launch_exact_segments_ccdf(ctx->stream, blocks, chunk, nsegs, ctx->d_tile_E + tile0, ctx->d_seg_D + 4 * tile0,
+                                    chunk + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, tail, ctx->d_table, plan.P,
+                                    plan.lds_bytes, ctx->d_hist);
+    time_end(ctx);
+    papr_launch_exact_capture(ctx->stream, chunk, tile0, ntiles, ctx->d_ambig + kCapRaw, ctx->d_ambig + 2 * kCapRaw,
+                              kCapRaw, ctx->d_raw_store);
+    HIPCHK(ctx, hipGetLastError());
+    if (last && tail)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_tail, chunk + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, (size_t)tail * 8,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+    return PAPR_OK;
+}
+
+enum StreamPass { PASS_LOAD_STATS, PASS_STREAM_STATS, PASS_STREAM_CCDF, PASS_STREAM_CCDF_EXACT, PASS_STREAM_NAN };
 
 // Walk file samples [first, first + n) in pinned-buffer-sized chunks: parallel
 // pread into a pinned buffer, hipMemcpyAsync on the copy stream, then the pass
@@ -801,6 +830,9 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
         }
         case PASS_STREAM_CCDF:
             prc = launch_ccdf_range(ctx, *plan, dst, cnt);
+            break;
+        case PASS_STREAM_CCDF_EXACT:
+            prc = launch_fused_chunk(ctx, *plan, dst, s0, cnt, last);
             break;
         case PASS_STREAM_NAN:
             papr_launch_first_nan(ctx->stream, 1024, dst, cnt, ctx->base + s0, ctx->d_nan_key);
@@ -971,6 +1003,8 @@ void papr_hip_close(papr_hip_ctx *ctx)
     if (ctx->d_mixed_list) (void)hipFree(ctx->d_mixed_list);
     if (ctx->d_raw_list) (void)hipFree(ctx->d_raw_list);
     if (ctx->d_plan) (void)hipFree(ctx->d_plan);
+    if (ctx->d_ambig) (void)hipFree(ctx->d_ambig);
+    if (ctx->d_raw_store) (void)hipFree(ctx->d_raw_store);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->d_hist) (void)hipFree(ctx->d_hist);
@@ -1198,7 +1232,7 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
     }
     ctx->file_stats = st;
     ctx->have_file_stats = true;
-    ctx->exact_valid = ctx->exact && ctx->resident;
+    ctx->exact_valid = ctx->exact;  // the per-tile sums are on the device, resident shard or not
     ctx->ingest.total_s = now_s() - t_begin;
     return PAPR_OK;
 }
@@ -1269,18 +1303,17 @@ int papr_hip_set_exact(papr_hip_ctx *ctx, int enabled)
 
 namespace {
 
-int exact_preconditions(papr_hip_ctx *ctx, double before)
+int exact_preconditions(papr_hip_ctx *ctx, double before, bool allow_restreamed)
 {
     if (!ctx->exact || !ctx->exact_valid || !ctx->loaded)
         return fail(ctx, PAPR_E_STATE, "exact sum needs papr_hip_set_exact(1) and papr_hip_stats on the current shard first");
-    if (!ctx->resident)
-        return fail(ctx, PAPR_E_STATE, "exact sum needs a shard that is resident in HBM");
+    if (!ctx->resident && !allow_restreamed)
+        return fail(ctx, PAPR_E_STATE, "papr_hip_exact_program needs a shard that is resident in HBM "
+                                       "(re-streamed shards: papr_hip_ccdf_exact)");
     if (!(before >= 0.0) || !std::isfinite(before))
         return fail(ctx, PAPR_E_ARG, "`before` must be a finite, non-negative sum");
     return PAPR_OK;
 }
-
-constexpr uint32_t kCapMixed = 256, kCapRaw = 512;  // beyond this the program is assembled by the host path
 
 int reserve_program(papr_hip_ctx *ctx, size_t want)  // grow the pinned program buffer, keeping its contents
 {
@@ -1326,23 +1359,47 @@ int run_exact_device(papr_hip_ctx *ctx, double before, uint64_t n_total, const C
     unsigned char *program_dev = nullptr;
     HIPCHK(ctx, hipHostGetDevicePointer((void **)&program_dev, ctx->h_program, 0));
     const uint64_t nsegs = 2 * ntiles;
-    // plain sweep: 4-wave workgroups, 2 per CU; fused sweep: 8-wave workgroups, 2 per CU (16 waves share the LDS tables)
-    const int per_cu = std::max(1, env_int("PAPR_EXACT_WG_PER_CU", 2));
-    const uint64_t wg_waves = fused ? (uint64_t)papr_exact_fused_waves() : 4;
-    const int blocks =
-        (int)std::max<uint64_t>(1, std::min<uint64_t>((nsegs + wg_waves - 1) / wg_waves, (uint64_t)ctx->num_cus * per_cu));
-    time_begin(ctx, 2, ctx->n * 8);
-    papr_launch_exact_classify(ctx->stream, ctx->d_tile_sums, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E);
-    if (fused)
-        papr_launch_exact_segments_ccdf(ctx->stream, blocks, ctx->d_iq, nsegs, ctx->d_tile_E, ctx->d_seg_D,
-                                        ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, tail, ctx->d_table, fused->P,
-                                        fused->lds_bytes, ctx->d_hist);
-    else
-        papr_launch_exact_segments(ctx->stream, blocks, ctx->d_iq, nsegs, ctx->d_tile_E, ctx->d_seg_D);
-    papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
-    time_end(ctx);
-    papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, ctx->d_iq, ctx->n,
-                           tail, ctx->d_mixed_list, kCapMixed, ctx->d_raw_list, kCapRaw, ctx->d_plan, program_dev);
+    if (ctx->resident) {
+        // plain sweep: 4-wave workgroups, 2 per CU; fused sweep: 8-wave workgroups, 2 per CU (16 waves share the LDS tables)
+        const int per_cu = std::max(1, env_int("PAPR_EXACT_WG_PER_CU", 2));
+        const uint64_t wg_waves = fused ? (uint64_t)papr_exact_fused_waves() : 4;
+        const int blocks = (int)std::max<uint64_t>(
+            1, std::min<uint64_t>((nsegs + wg_waves - 1) / wg_waves, (uint64_t)ctx->num_cus * per_cu));
+        time_begin(ctx, 2, ctx->n * 8);
+        papr_launch_exact_classify(ctx->stream, ctx->d_tile_sums, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E,
+                                   nullptr, 0, nullptr, nullptr);
+        if (fused)
+            papr_launch_exact_segments_ccdf(ctx->stream, blocks, ctx->d_iq, nsegs, ctx->d_tile_E, ctx->d_seg_D,
+                                            ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, tail, ctx->d_table,
+                                            fused->P, fused->lds_bytes, ctx->d_hist);
+        else
+            papr_launch_exact_segments(ctx->stream, blocks, ctx->d_iq, nsegs, ctx->d_tile_E, ctx->d_seg_D);
+        papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
+        time_end(ctx);
+        papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, ctx->d_iq, nullptr,
+                               ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, ctx->n, tail, ctx->d_mixed_list,
+                               kCapMixed, ctx->d_raw_list, kCapRaw, ctx->d_plan, program_dev);
+    } else {
+        // re-streamed shard: classify (also listing the unprovable tiles), then the file goes through the
+        // staging buffers once more with the fused sweep on every chunk
+        if (!fused)
+            return fail(ctx, PAPR_E_STATE, "a re-streamed shard builds its sum program in the pass-2 sweep only");
+        if (!ctx->d_ambig) {
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_ambig, (2 * kCapRaw + 1) * sizeof(uint32_t)));
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_raw_store, (size_t)kCapRaw * PAPR_EXACT_TILE_SAMPLES * 8));
+        }
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_ambig + 2 * kCapRaw, 0, sizeof(uint32_t), ctx->stream));
+        papr_launch_exact_classify(ctx->stream, ctx->d_tile_sums, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E,
+                                   ctx->d_ambig, kCapRaw, ctx->d_ambig + 2 * kCapRaw, ctx->d_ambig + kCapRaw);
+        HIPCHK(ctx, hipGetLastError());
+        rc = stream_file(ctx, PASS_STREAM_CCDF_EXACT, fused, nullptr);
+        if (rc)
+            return rc;
+        papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
+        papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, nullptr,
+                               ctx->d_raw_store, ctx->d_tail, ctx->n, tail, ctx->d_mixed_list, kCapMixed, ctx->d_raw_list,
+                               kCapRaw, ctx->d_plan, program_dev);
+    }
     HIPCHK(ctx, hipGetLastError());
     if (fused)
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(fused->P.nkeys + 1) * sizeof(unsigned long long),
@@ -1465,7 +1522,7 @@ int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, c
 {
     if (!ctx || !program || !bytes)
         return PAPR_E_ARG;
-    int rc = exact_preconditions(ctx, before);
+    int rc = exact_preconditions(ctx, before, false);
     if (rc)
         return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1483,7 +1540,7 @@ int papr_hip_ccdf_exact(papr_hip_ctx *ctx, const float *levels, int nlevels, uin
         return PAPR_E_ARG;
     if (nlevels > PAPR_HIP_MAX_LEVELS)
         return fail(ctx, PAPR_E_LIMIT, "%d levels exceeds PAPR_HIP_MAX_LEVELS (%d)", nlevels, PAPR_HIP_MAX_LEVELS);
-    int rc = exact_preconditions(ctx, before);
+    int rc = exact_preconditions(ctx, before, true);
     if (rc)
         return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1520,7 +1577,11 @@ int papr_hip_ccdf_exact(papr_hip_ctx *ctx, const float *levels, int nlevels, uin
         return rc;
     counts_from_histogram(ctx, plan, nlevels, counts_above);
     *program = ctx->h_program;
-    return *bytes ? PAPR_OK : assemble_program_on_host(ctx, program, bytes);
+    if (*bytes)
+        return PAPR_OK;
+    if (!ctx->resident)  // the raw tiles of a re-streamed shard are gone once their chunk has left the device
+        return fail(ctx, PAPR_E_LIMIT, "too many binade crossings for the device-side program lists");
+    return assemble_program_on_host(ctx, program, bytes);
 }
 
 // ---- pass 2 ---------------------------------------------------------------------

@@ -565,3 +565,35 @@ def test_exact_program_host_assembly_fallback(pkg, orc, xgpu, monkeypatch):
     host = xgpu.exact_program(0.0, n)
     assert host == dev
     assert pkg.exact_chain([host]) == orc.run_mem(iq, False)["sum"]
+
+
+def test_exact_sum_on_restreamed_shard(pkg, orc, tmp_path, monkeypatch):
+    """Shard larger than the HBM budget (BASELINE configs[4]): pass 1 streams the file leaving per-tile sums,
+    pass 2 streams it again with the fused sweep; counts and the sequential sum must still be exact."""
+    n = 5 * 1048576 + 4321
+    path = str(tmp_path / "big.cfile")
+    subprocess.check_call([orc.MKCFILE, path, str(n), "--spike", "--extra-floats", "1", "--extra-bytes", "1"])
+    ref = orc.run_file(path, True)
+    monkeypatch.setenv("PAPR_CHUNK_MB", "2")
+    monkeypatch.setenv("PAPR_HBM_BUDGET_MB", "8")
+    with pkg.PaprHip(0) as g:
+        g.set_exact(True)
+        g.load_file(path)
+        assert not g.ingest_timing().resident
+        st = g.stats()
+        check_stats(st, ref)
+        mean, papr, table = pkg.levels(st, True)
+        counts, prog = g.ccdf_exact(table, 0.0, st.n)
+        assert pkg.exact_chain([prog]) == ref["sum"]
+        st.sum = ref["sum"]
+        assert np.array_equal(pkg.levels(st, True)[2], ref["level"])
+        if np.array_equal(table, ref["level"]):
+            assert np.array_equal(counts.astype(np.int64), ref["count"])
+    # and the CLI end to end under the same budget
+    for graph in (False, True):
+        want = subprocess.run([orc.REF_CLI if os.path.exists(orc.REF_CLI) else orc.CLI_PATH] + (["-g"] if graph else []) + [path],
+                              capture_output=True)
+        got = subprocess.run([pkg.CLI_PATH] + (["-g"] if graph else []) + [path], capture_output=True,
+                             env=dict(os.environ, PAPR_STATS="1"))
+        assert got.stdout == want.stdout and got.returncode == 0
+        assert b'"exact_sum": 1' in got.stderr and b'"resident": 0' in got.stderr
