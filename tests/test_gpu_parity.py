@@ -597,3 +597,41 @@ def test_exact_sum_on_restreamed_shard(pkg, orc, tmp_path, monkeypatch):
                              env=dict(os.environ, PAPR_STATS="1"))
         assert got.stdout == want.stdout and got.returncode == 0
         assert b'"exact_sum": 1' in got.stderr and b'"resident": 0' in got.stderr
+
+
+def test_shard_beyond_2_to_32_samples(pkg):
+    """A 34 GiB shard (4.56e9 samples > 2^32) on one GPU: in-shard sample numbers need all 64 bits.
+    No CPU oracle at this size; checked through planted extremes, shard-split invariance and the
+    agreement of the exact-sum chain with and without a cut."""
+    n = 34 * (1 << 30) // 8
+    first, second = (1 << 32) + 5, (1 << 32) + 123456789
+    sp = pkg.SynthSpec.make(seed=2026, overrides=[(second, 50.0, -50.0), (first, 50.0, -50.0), (n - 1, -60.0, 1.0),
+                                                  (7, 0.0, 55.0)])
+    with pkg.PaprHip(0) as g:
+        g.set_exact(True)
+        g.generate(sp, 0, n)
+        st = g.stats()
+        assert st.n == n and st.peak == np.float32(5000.0) and st.peak_idx == first      # first of the two equal peaks
+        assert (st.re_pos, st.re_pos_idx) == (50.0, first) and (st.im_neg, st.im_neg_idx) == (-50.0, first)
+        assert (st.re_neg, st.re_neg_idx) == (-60.0, n - 1) and (st.im_pos, st.im_pos_idx) == (55.0, 7)
+        mean, papr, table = pkg.levels(st, True)
+        counts, prog = g.ccdf_exact(table, 0.0, n)
+        whole = pkg.exact_chain([prog])
+        assert abs(whole - st.sum) <= 1e-9 * st.sum and np.all(np.diff(counts.astype(np.int64)) <= 0)
+        assert counts[0] < n and counts[-1] <= 4
+        # the same stream as two shards cut beyond 2^32: merged record, summed counts and chained exact sum agree
+        cut = ((1 << 32) + 99999) // 8192 * 8192
+        parts, progs, total_counts, before = [], [], np.zeros(table.size, np.uint64), 0.0
+        for a, b in ((0, cut), (cut, n)):
+            g.generate(sp, a, b - a)
+            s = g.stats()
+            c, p = g.ccdf_exact(table, before, n)
+            parts.append(s)
+            progs.append(p)
+            total_counts += c
+            before += s.sum
+        m = pkg.stats_merge(parts)
+        for k in TRACKERS:
+            assert getattr(m, k) == getattr(st, k) and getattr(m, k + "_idx") == getattr(st, k + "_idx"), k
+        assert np.array_equal(total_counts, counts)
+        assert pkg.exact_chain(progs) == whole
