@@ -176,8 +176,9 @@ int papr_levels(const papr_stats *total, int graph, double *mean, float *papr, f
 
 /* ---- bit-exact mean (papr.c:104: `sum += value`, double, strictly in file order) --
  * papr_hip_stats sums in a parallel tree, accurate to ~1e-15 but not the
- * reference's rounding sequence (which is itself ~1e-13 off the exact sum).
- * Exact mode reproduces the reference's value bit for bit (see papr_exact.hip):
+ * reference's rounding sequence (which itself drifts 1e-13 .. 1e-11 from the
+ * true sum as the file grows to 1e9 samples).  Exact mode reproduces the
+ * reference's value bit for bit (see papr_exact.hip):
  *
  *   papr_hip_set_exact(ctx, 1)               before load/upload/adopt/generate + stats
  *   papr_hip_stats(ctx, &st)                 as usual (also leaves per-tile sums on the GPU)
@@ -187,8 +188,10 @@ int papr_levels(const papr_stats *total, int graph, double *mean, float *papr, f
  *        (valid until the next call) holding this shard's serialisable "sum program"
  *   papr_exact_chain(programs, sizes, nshards, &sum)   host, shards in file order
  *
- * then use `sum` as papr_stats.sum of the merged record.  Needs a resident shard
- * and a finite sum (with NaN/Inf present papr_hip_stats is already exact). */
+ * then use `sum` as papr_stats.sum of the merged record.  Needs a finite sum (with
+ * NaN/Inf present papr_hip_stats is already exact); papr_hip_exact_program needs a
+ * shard that is resident in HBM, papr_hip_ccdf_exact below also serves shards
+ * that are re-streamed from their file. */
 int papr_hip_set_exact(papr_hip_ctx *ctx, int enabled);
 int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, const void **program, size_t *bytes);
 /* The same with pass 2 fused into the one sweep over the samples (no extra HBM pass): counts against
