@@ -192,8 +192,12 @@ def main():
         b_ccdf = tm.ccdf_bytes / max(tm.ccdf_launches, 1)
         gbs_stats = b_stats / (k_stats * 1e-3) / 1e9 if k_stats else 0.0
         gbs_ccdf = b_ccdf / (k_ccdf * 1e-3) / 1e9 if k_ccdf else 0.0
-        dom, dom_gbs, dom_ms = ("papr_ccdf_kernel", gbs_ccdf, k_ccdf) if k_ccdf >= k_stats else \
-            ("papr_stats_kernel", gbs_stats, k_stats)
+        # exact mode: pass 2 runs inside the fused sweep (timed with its five small helper kernels)
+        k_exact = tm.exact_ms / max(tm.exact_launches, 1)
+        b_exact = tm.exact_bytes / max(tm.exact_launches, 1)
+        gbs_exact = b_exact / (k_exact * 1e-3) / 1e9 if k_exact else 0.0
+        dom, dom_gbs, dom_ms = max([("papr_stats_kernel", gbs_stats, k_stats), ("papr_ccdf_kernel", gbs_ccdf, k_ccdf),
+                                    ("papr_exact_seg_kernel<CCDF>", gbs_exact, k_exact)], key=lambda e: e[2])
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
@@ -226,12 +230,10 @@ def main():
                          "traffic_source": traffic_src},
             "kernels": {"papr_stats_kernel": {"avg_ms": k_stats, "GB/s": gbs_stats, "launches": int(tm.stats_launches)},
                         "papr_ccdf_kernel": {"avg_ms": k_ccdf, "GB/s": gbs_ccdf, "launches": int(tm.ccdf_launches)},
-                        "both_passes_frac_of_peak": (b_stats + b_ccdf) / ((k_stats + k_ccdf) * 1e-3) / 1e9 / HBM_PEAK_GBS
-                        if (k_stats + k_ccdf) else 0.0,
-                        "papr_exact_kernels": {"avg_ms": tm.exact_ms / max(tm.exact_launches, 1),
-                                               "launches": int(tm.exact_launches)},
-                        "host_and_exchange_ms_per_step": ms_per_step - k_stats - k_ccdf
-                        - tm.exact_ms / max(tm.exact_launches, 1)},
+                        "both_passes_frac_of_peak": (b_stats + b_ccdf + b_exact) /
+                        ((k_stats + k_ccdf + k_exact) * 1e-3) / 1e9 / HBM_PEAK_GBS if (k_stats + k_ccdf + k_exact) else 0.0,
+                        "papr_exact_kernels": {"avg_ms": k_exact, "GB/s": gbs_exact, "launches": int(tm.exact_launches)},
+                        "host_and_exchange_ms_per_step": ms_per_step - k_stats - k_ccdf - k_exact},
             "device": gpu.name,
         }
         if world == 1 and not args.no_cpu_baseline:
