@@ -635,3 +635,39 @@ def test_shard_beyond_2_to_32_samples(pkg):
             assert getattr(m, k) == getattr(st, k) and getattr(m, k + "_idx") == getattr(st, k + "_idx"), k
         assert np.array_equal(total_counts, counts)
         assert pkg.exact_chain(progs) == whole
+
+
+def test_ccdf_randomised_level_tables(pkg, orc, gpu):
+    """300 random level tables (log-uniform, clustered, adjacent bit patterns, duplicates, huge spans,
+    sample powers themselves as thresholds) against the oracle's float `>` loop: exercises the LUT cell
+    choice, the LUT/search switch and the key construction at their edges."""
+    rng = np.random.default_rng(20260929)
+    n = 60011
+    iq = (rng.standard_normal(2 * n) * rng.choice([1e-3, 0.7, 40.0], size=2 * n, p=[0.2, 0.7, 0.1])).astype(np.float32)
+    iq[2 * 11:2 * 13] = 0.0
+    gpu.upload(iq)
+    pw = (iq[0::2] * iq[0::2]) + (iq[1::2] * iq[1::2])
+    for trial in range(300):
+        kind = trial % 6
+        m = int(rng.integers(1, 400))
+        if kind == 0:      # log-uniform over a random span
+            lo, hi = sorted(rng.uniform(-12, 6, 2))
+            tab = 10.0 ** rng.uniform(lo, hi + 1e-3, m)
+        elif kind == 1:    # geometric ladder like the reference's, random ratio
+            tab = rng.uniform(1e-4, 2.0) * rng.uniform(1.001, 1.6) ** np.arange(m)
+        elif kind == 2:    # clusters of adjacent float bit patterns
+            base = np.float32(10.0 ** rng.uniform(-3, 2))
+            bits = np.frombuffer(base.tobytes(), np.uint32)[0] + rng.integers(0, 40, m).astype(np.uint32)
+            tab = bits.view(np.float32)
+        elif kind == 3:    # thresholds that ARE sample powers (strictness of `>`), plus duplicates
+            tab = np.concatenate([pw[rng.integers(0, n, m)], pw[rng.integers(0, n, 3)].repeat(2)])
+        elif kind == 4:    # two far-apart clusters: a coarse LUT would be huge
+            tab = np.concatenate([10.0 ** rng.uniform(-9, -8.9, m // 2 + 1), 10.0 ** rng.uniform(3, 3.1, m // 2 + 1)])
+        else:              # mixed signs, zeros and specials sprinkled in
+            tab = np.concatenate([10.0 ** rng.uniform(-4, 3, m), [0.0, -0.0, -1.0, np.inf, np.nan][: int(rng.integers(0, 6))]])
+        with np.errstate(over="ignore"):          # ladders may run past FLT_MAX: +inf thresholds are part of the test
+            tab = np.asarray(tab, dtype=np.float32)
+        rng.shuffle(tab)
+        got = gpu.ccdf(tab)
+        want = orc.count_mem(iq, tab)
+        assert np.array_equal(got.astype(np.int64), want), (trial, kind, tab[:8])
