@@ -671,3 +671,35 @@ def test_ccdf_randomised_level_tables(pkg, orc, gpu):
         got = gpu.ccdf(tab)
         want = orc.count_mem(iq, tab)
         assert np.array_equal(got.astype(np.int64), want), (trial, kind, tab[:8])
+
+
+def test_pass1_randomised_inputs(pkg, orc, xgpu):
+    """150 random streams (random length, amplitude law, planted ties / zeros / NaN / Inf at random
+    places, random launch geometry): pass-1 record, NaN bookkeeping and — when finite — the exact
+    sequential sum against the oracle."""
+    rng = np.random.default_rng(77001)
+    for trial in range(150):
+        n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000), rng.integers(9000, 120000)]))
+        iq = (rng.standard_normal(2 * n) * 10.0 ** rng.uniform(-6, 3)).astype(np.float32)
+        if rng.random() < 0.5 and n > 8:               # equal extremes in several places
+            spots = rng.integers(0, n, int(rng.integers(2, 6)))
+            iq[2 * spots], iq[2 * spots + 1] = np.float32(77.0), np.float32(-77.0)
+        if rng.random() < 0.3:
+            a = int(rng.integers(0, n))
+            iq[2 * a:2 * min(n, a + int(rng.integers(1, 5000)))] = 0.0
+        special = rng.random()
+        if special < 0.15:
+            iq[int(rng.integers(0, 2 * n))] = rng.choice([np.nan, -np.nan])
+        if 0.1 < special < 0.25:
+            iq[int(rng.integers(0, 2 * n))] = rng.choice([np.inf, -np.inf])
+        xgpu.set_tuning(blocks=int(rng.choice([0, 1, 3, 64])), map=int(rng.integers(0, 3)))
+        base = int(rng.integers(0, 1 << 40)) // 8192 * 8192
+        xgpu.upload(iq, base_index=base)
+        st = xgpu.stats()
+        ref = orc.run_mem(iq, False)
+        check_stats(st, ref, base=base)
+        if np.isfinite(ref["sum"]):
+            assert pkg.exact_chain([xgpu.exact_program(0.0, n)]) == ref["sum"], trial
+        else:
+            assert bool(st.flags & pkg.FLAG_NAN) == bool(np.isnan(ref["sum"]))
+    xgpu.set_tuning()
