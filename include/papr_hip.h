@@ -97,6 +97,8 @@ typedef struct papr_hip_ingest_timing {
     uint64_t bytes, chunks;
     int reader_threads;
     int resident;         /* 1 = shard kept in HBM, 0 = will be re-streamed for pass 2 */
+    int o_direct;         /* 1 = the file was read with O_DIRECT (not in the page cache, or PAPR_O_DIRECT=1) */
+    int reserved;
 } papr_hip_ingest_timing;
 
 /* Launch geometry knobs.  0 always means "built-in default" (chosen from the
