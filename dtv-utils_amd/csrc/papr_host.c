@@ -164,9 +164,20 @@ int papr_exact_chain(const void *const *programs, const size_t *bytes, int nprog
         p += sizeof(h);
         if (h.magic != PAPR_EXACT_MAGIC || h.version != PAPR_EXACT_VERSION)
             return PAPR_E_ARG;
-        const uint64_t need = h.ngroups * sizeof(papr_exact_group_rec) + (uint64_t)h.nmixed * sizeof(papr_exact_mixed_rec) +
-                              (uint64_t)h.nraw * sizeof(papr_exact_raw_rec) + (uint64_t)h.tail_samples * 8;
-        if ((uint64_t)(end - p) < need)
+        /* sizes come from another process: every count is checked against what is left before it is used */
+        uint64_t left = (uint64_t)(end - p);
+        if (h.ngroups > left / sizeof(papr_exact_group_rec))
+            return PAPR_E_ARG;
+        left -= h.ngroups * sizeof(papr_exact_group_rec);
+        if (h.nmixed > left / sizeof(papr_exact_mixed_rec))
+            return PAPR_E_ARG;
+        left -= (uint64_t)h.nmixed * sizeof(papr_exact_mixed_rec);
+        if (h.nraw > left / sizeof(papr_exact_raw_rec))
+            return PAPR_E_ARG;
+        left -= (uint64_t)h.nraw * sizeof(papr_exact_raw_rec);
+        if (h.tail_samples >= PAPR_XF_TILE_SAMPLES || (uint64_t)h.tail_samples * 8 > left)
+            return PAPR_E_ARG;
+        if (h.ngroups != (h.ntiles + PAPR_XF_GROUP_TILES - 1) / PAPR_XF_GROUP_TILES || h.reserved != 0)
             return PAPR_E_ARG;
         const papr_exact_group_rec *groups = (const papr_exact_group_rec *)p;
         const papr_exact_mixed_rec *mixed = (const papr_exact_mixed_rec *)(groups + h.ngroups);

@@ -1,0 +1,71 @@
+"""Host-side C under AddressSanitizer + UndefinedBehaviorSanitizer (the reference has
+no sanitizer story; the build gets one for the code that parses bytes).  papr_exact_chain replays sum
+programs that, in a multi-GPU run, arrive from other processes — it must reject damaged ones without ever
+reading outside them — and the oracle's chunk feeder is run over every fixture the same way."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_names, golden_path, golden_text
+from test_exact_chain_cpu import build_program
+
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-g", "-O1"]
+
+
+@pytest.fixture(scope="module")
+def san_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("san")
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "dtv-utils_amd", "csrc")]
+    subprocess.check_call(["gcc", *SAN, "-ffp-contract=off", *inc, os.path.join(ROOT, "tests", "c", "chain_harness.c"),
+                           os.path.join(ROOT, "dtv-utils_amd", "csrc", "papr_host.c"), "-o", str(d / "chain"), "-lm"])
+    subprocess.check_call(["gcc", *SAN, "-ffp-contract=off", "-DPAPR_ORACLE_MAIN", *inc,
+                           os.path.join(ROOT, "oracle", "papr_oracle.c"), "-o", str(d / "oracle"), "-lm"])
+    return d
+
+
+def run(binary, *args):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([str(binary), *map(str, args)], capture_output=True, env=env)
+    assert b"ERROR: AddressSanitizer" not in p.stderr and b"runtime error" not in p.stderr, p.stderr.decode()[-3000:]
+    return p
+
+
+def test_chain_under_sanitizers_valid_and_damaged_programs(orc, san_dir):
+    rng = np.random.default_rng(99)
+    iq = rng.standard_normal(2 * 300001).astype(np.float32)
+    prog, _ = build_program(iq)
+    good = san_dir / "good.bin"
+    good.write_bytes(prog)
+    p = run(san_dir / "chain", good)
+    rc, hexsum = p.stdout.split()
+    assert int(rc) == 0 and float.fromhex(hexsum.decode()) == orc.run_mem(iq, False)["sum"]
+    # truncations, random byte flips, inflated counts: any return code is fine, a sanitizer report is not
+    bad = san_dir / "bad.bin"
+    for trial in range(300):
+        b = bytearray(prog)
+        kind = trial % 4
+        if kind == 0:
+            b = b[: int(rng.integers(0, len(b)))]
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 20))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        elif kind == 2:      # header fields only (counts, sizes)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(8, 48))] = int(rng.integers(0, 256))
+        else:                # huge counts
+            off = int(rng.choice([16, 24, 32, 36, 40]))
+            b[off:off + 4] = (0xFFFFFFF0 + int(rng.integers(0, 15))).to_bytes(4, "little")
+        bad.write_bytes(bytes(b))
+        p = run(san_dir / "chain", bad)
+        assert p.returncode == 0 and p.stdout.split()[0] in (b"0", b"-3", b"-8"), (trial, p.stdout)
+
+
+def test_oracle_under_sanitizers(san_dir):
+    for name in golden_names():
+        for graph in (False, True):
+            p = run(san_dir / "oracle", *(["-g"] if graph else []), golden_path(name))
+            want = golden_text(name, graph)
+            if b"nan" not in want:   # which NaN sign a compiler's operand order produces differs between -O1 and
+                assert p.stdout == want, name   # the reference's -O2 build; the sanitizer run is about memory safety
