@@ -449,11 +449,13 @@ int launch_stats_range(papr_hip_ctx *ctx, const float *data, uint64_t n, uint64_
         return PAPR_OK;
     int blocks = pick_blocks(ctx, PASS1, ntiles);
     const int map = effective_map(ctx, PASS1, blocks);
-    time_begin(ctx, 0, ntiles * tile * 8);
     if (ctx->exact) {
         int rc = ensure_exact_buffers(ctx);
         if (rc)
             return rc;
+    }
+    time_begin(ctx, 0, ntiles * tile * 8);
+    if (ctx->exact) {
         papr_launch_stats_tilesums(ctx->stream, blocks, data, ntiles, base_index, map, ctx->d_partials + slot,
                                    ctx->d_tile_sums, (base_index - ctx->base) / PAPR_EXACT_TILE_SAMPLES);
     } else {
