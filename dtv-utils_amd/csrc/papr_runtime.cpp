@@ -262,11 +262,13 @@ void parse_tune_env(papr_hip_tuning *t)
 }
 
 // Built-in launch geometry, from the 10 GiB sweeps on MI355X:
-//   pass 1: 256-thread workgroups, 4 loads per lane, software-pipelined, 2 workgroups per CU (8 waves/CU),
-//           one contiguous eighth of the shard per XCD                       -> 7.31 TB/s
+//   pass 1: 256-thread workgroups, 4 loads per lane, next-tile prefetch, 2 workgroups per CU (8 waves/CU),
+//           grid-stride tiles                                                -> 7.2-7.3 TB/s
 //   pass 2: 512-thread workgroups, 4 loads per lane, 2 workgroups per CU (16 waves/CU), grid-stride tiles
 //                                                                            -> 7.20 TB/s
-constexpr int kStatsVariant = 1, kStatsPerCU = 2, kStatsMap = PAPR_MAP_XCD_SPAN;
+// (one contiguous eighth of the shard per XCD is 1 % faster for pass 1 in most processes and 8 % slower in about
+// one process in four — it depends on where the allocation landed — so it is not the default)
+constexpr int kStatsVariant = 1, kStatsPerCU = 2, kStatsMap = PAPR_MAP_GRID_STRIDE;
 constexpr int kCcdfVariant = 13, kCcdfPerCU = 2, kCcdfMap = PAPR_MAP_GRID_STRIDE;
 
 enum Pass { PASS1 = 0, PASS2 = 1 };
