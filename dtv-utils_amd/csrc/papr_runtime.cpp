@@ -301,7 +301,13 @@ uint64_t tile_samples(const papr_hip_ctx *ctx, Pass p)
 int map_of(const papr_hip_ctx *ctx, Pass p)
 {
     const int m = (p == PASS1 ? ctx->tune.stats_map : ctx->tune.ccdf_map) - 1;
-    return (m >= 0 && m <= 2) ? m : (p == PASS1 ? kStatsMap : kCcdfMap);
+    if (m >= 0 && m <= 2)
+        return m;
+    // exact-sum mode: the per-tile sums of neighbouring tiles are then written by workgroups of the same
+    // XCD (1.70 ms vs 1.83 ms per 10 GiB with grid-stride; its slow mode costs no more than that)
+    if (p == PASS1 && ctx->exact)
+        return PAPR_MAP_XCD_SPAN;
+    return p == PASS1 ? kStatsMap : kCcdfMap;
 }
 
 int pick_blocks(const papr_hip_ctx *ctx, Pass p, uint64_t ntiles)
