@@ -104,12 +104,12 @@ typedef struct papr_hip_ingest_timing {
 /* Launch geometry knobs.  0 always means "built-in default" (chosen from the
  * 10 GiB sweeps in DESIGN.md section 6); variant and map fields therefore hold
  * id + 1.  Also settable with the PAPR_HIP_TUNE environment variable, e.g.
- * "sblocks=512,svariant=1,smap=2,cblocks=512,cvariant=13,cmap=0,nt=1"
+ * "sblocks=512,svariant=1,smap=0,cblocks=512,cvariant=13,cmap=0,nt=1" (= the defaults on a 256-CU device)
  * ("blocks=" / "variant=" / "map=" set both passes). */
 typedef struct papr_hip_tuning {
     int stats_blocks;   /* pass 1: workgroups per launch */
-    int stats_variant;  /* pass 1: kernel geometry variant id + 1 (block x unroll x pipelining, papr_kernels.hip) */
-    int stats_map;      /* pass 1: tile mapping id + 1 (0 grid-stride, 1 span per workgroup, 2 span per XCD) */
+    int stats_variant;  /* pass 1: kernel geometry variant id + 1 (block x unroll x prefetch form, papr_kernels.hip) */
+    int stats_map;      /* pass 1: tile mapping id + 1 (ids: 0 grid-stride, 1 span per workgroup, 2 span per XCD) */
     int ccdf_blocks;    /* pass 2: workgroups per launch */
     int ccdf_variant;   /* pass 2: kernel geometry variant id + 1 */
     int ccdf_map;       /* pass 2: tile mapping id + 1 */
