@@ -80,10 +80,10 @@ def _run_bench(nproc, gib, extra):
 def test_sharded_run_equals_single_shard_run(mode):
     """The N>1 code path of bench.py (rank-dependent shard of ONE global stream, stats all-gather + ordered
     merge, chained exact-sum programs, count all-reduce) on a box with one GPU: 2 and 4 ranks share it over
-    gloo, and must reproduce the 1-rank result over the same stream bit for bit."""
+    gloo, and must reproduce the 1-rank result over the same stream bit for bit (2, 4 and 8 ranks)."""
     extra = ["--mode", mode, "--exact"]
     one = _run_bench(1, 0.5, extra)
-    for ranks in (2, 4):
+    for ranks in (2, 4, 8):   # 8 = the rank count of BASELINE.json configs[3]
         many = _run_bench(ranks, 0.5 / ranks, extra)
         assert many["n_gpus"] == ranks and many["config"]["samples_total"] == one["config"]["samples_total"]
         for key in ("sum_hex", "papr_db", "levels", "counts_crc32"):
