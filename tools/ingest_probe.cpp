@@ -121,6 +121,36 @@ int main(int argc, char **argv)
             munmap(m, total);
         }
     }
+    // does page pinning scale across threads?  N threads register disjoint 256 MiB pieces of a FRESH 2 GiB
+    // window each time (unregistering is lazy, a window registered before would be free the second time)
+    {
+        void *m = mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0);
+        if (m != MAP_FAILED) {
+            const size_t piece = 256u << 20, window = (size_t)2 << 30;
+            size_t off = (size_t)4 << 30;  // [0, 4 GiB) was used above
+            for (int nthr : {2, 4, 8}) {
+                if (off + window > bytes)
+                    break;
+                const int npieces = (int)(window / piece);
+                char *base = (char *)m + off;
+                std::vector<std::thread> th;
+                t0 = now();
+                for (int t = 0; t < nthr; t++)
+                    th.emplace_back([=] {
+                        hipSetDevice(0);
+                        for (int k = t; k < npieces; k += nthr)
+                            hipHostRegister(base + (size_t)k * piece, piece, hipHostRegisterDefault);
+                    });
+                for (auto &x : th) x.join();
+                t1 = now();
+                printf(", \"register_%dthr_GBs\": %.1f", nthr, (double)window / (t1 - t0) / 1e9);
+                for (int k = 0; k < npieces; k++)
+                    hipHostUnregister(base + (size_t)k * piece);
+                off += window;
+            }
+            munmap(m, bytes);
+        }
+    }
     printf("}\n");
     return 0;
 }
