@@ -48,6 +48,7 @@ def build_fixtures():
     raw("one", [3.0])
     raw("oneb", [3.0], b"\xa5")
     raw("empty")
+    raw("stray3", [], b"\x01\x02\x03")              # not even one whole float
     raw("zeros", [0.0] * 2000)
     raw("negzero", [-0.0, 0.0, 0.0, -0.0] * 100)
     # BASELINE.json configs[0]: 1 MiB synthetic gr_complex
