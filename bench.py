@@ -237,7 +237,7 @@ def main():
             "device": gpu.name,
         }
         if world == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample_gib if args.cpu_sample_gib else (1.0 if graph else 2.0)
+            sample = args.cpu_sample_gib if args.cpu_sample_gib else (1.0 if graph else 4.0)   # ~10-15 s of reference CPU time
             sample = min(sample, args.gib)
             try:
                 cb = cpu_baseline(pkg, args.mode, sample)
