@@ -17,7 +17,10 @@ lib: $(LIB)
 $(CSRC)/papr_host.o: $(CSRC)/papr_host.c $(CSRC)/papr_exact_format.h include/papr_hip.h include/papr_synth.h
 	$(CC) $(CFLAGS) -c $< -o $@
 
-$(CSRC)/papr_kernels.o: $(CSRC)/papr_kernels.hip $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h include/papr_synth.h
+$(CSRC)/papr_kernels.o: $(CSRC)/papr_kernels.hip $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h $(CSRC)/papr_stream.h include/papr_synth.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/papr_sweep.o: $(CSRC)/papr_sweep.hip $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h $(CSRC)/papr_stream.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/papr_exact.o: $(CSRC)/papr_exact.hip $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h
@@ -26,7 +29,7 @@ $(CSRC)/papr_exact.o: $(CSRC)/papr_exact.hip $(CSRC)/papr_kernels.h $(CSRC)/papr
 $(CSRC)/papr_runtime.o: $(CSRC)/papr_runtime.cpp $(CSRC)/papr_kernels.h $(CSRC)/papr_exact_format.h include/papr_hip.h include/papr_synth.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIB): $(CSRC)/papr_kernels.o $(CSRC)/papr_exact.o $(CSRC)/papr_runtime.o $(CSRC)/papr_host.o
+$(LIB): $(CSRC)/papr_kernels.o $(CSRC)/papr_sweep.o $(CSRC)/papr_exact.o $(CSRC)/papr_runtime.o $(CSRC)/papr_host.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -lm -lpthread
 
 cli: bin/papr

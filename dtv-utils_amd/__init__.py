@@ -35,6 +35,7 @@ ABI_SYMBOLS = (
     "papr_hip_adopt", "papr_hip_generate", "papr_hip_download", "papr_hip_stats",
     "papr_stats_init", "papr_stats_merge", "papr_levels", "papr_hip_ccdf",
     "papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
+    "papr_hip_estimate", "papr_hip_stats_sweep", "papr_hip_get_sweep_info", "papr_guess_levels",
 )
 
 
@@ -92,7 +93,23 @@ class Stats(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("stats_ms", C.c_double), ("stats_launches", C.c_uint64), ("stats_bytes", C.c_uint64),
                 ("ccdf_ms", C.c_double), ("ccdf_launches", C.c_uint64), ("ccdf_bytes", C.c_uint64),
-                ("exact_ms", C.c_double), ("exact_launches", C.c_uint64), ("exact_bytes", C.c_uint64)]
+                ("exact_ms", C.c_double), ("exact_launches", C.c_uint64), ("exact_bytes", C.c_uint64),
+                ("sweep_ms", C.c_double), ("sweep_launches", C.c_uint64), ("sweep_bytes", C.c_uint64),
+                ("aux_ms", C.c_double), ("aux_launches", C.c_uint64), ("aux_bytes", C.c_uint64)]
+
+
+SWEEP_REASONS = ("ok", "no sweep", "exact mode / not resident", "no band form", "out of band", "stash full")
+
+
+class SweepInfo(C.Structure):
+    """papr_hip_sweep_info: what the last one-sweep pass / papr_hip_ccdf did."""
+    _fields_ = [("stash_samples", C.c_uint64), ("stash_capacity", C.c_uint64), ("estimate_samples", C.c_uint64),
+                ("swept", C.c_int), ("resolved", C.c_int), ("reason", C.c_int), ("band_log2", C.c_int)]
+
+    def as_dict(self) -> dict:
+        d = {name: getattr(self, name) for name, _ in self._fields_}
+        d["reason"] = SWEEP_REASONS[self.reason] if 0 <= self.reason < len(SWEEP_REASONS) else self.reason
+        return d
 
 
 class IngestTiming(C.Structure):
@@ -109,7 +126,9 @@ class Tuning(C.Structure):
     """papr_hip_tuning; *_variant fields hold (variant id + 1), 0 = built-in default."""
     _fields_ = [("stats_blocks", C.c_int), ("stats_variant", C.c_int), ("stats_map", C.c_int),
                 ("ccdf_blocks", C.c_int), ("ccdf_variant", C.c_int), ("ccdf_map", C.c_int),
-                ("nontemporal", C.c_int), ("hist_copies", C.c_int), ("flags", C.c_int)]
+                ("nontemporal", C.c_int), ("hist_copies", C.c_int), ("flags", C.c_int),
+                ("sweep_blocks", C.c_int), ("sweep_variant", C.c_int), ("sweep_map", C.c_int),
+                ("sweep_band_log2", C.c_int), ("estimate_ratio", C.c_int), ("reserved", C.c_int)]
 
 
 class PaprError(RuntimeError):
@@ -162,7 +181,13 @@ def lib() -> C.CDLL:
     L.papr_hip_exact_program.argtypes = [vp, C.c_double, u64, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.papr_hip_ccdf_exact.argtypes = [vp, vp, i32, vp, C.c_double, u64, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.papr_exact_chain.argtypes = [C.POINTER(vp), C.POINTER(C.c_size_t), i32, C.POINTER(C.c_double)]
-    for name in ("papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain"):
+    L.papr_hip_estimate.argtypes = [vp, C.POINTER(Stats)]
+    L.papr_guess_levels.argtypes = [C.POINTER(Stats), i32, C.c_double, vp, i32]
+    L.papr_guess_levels.restype = i32
+    L.papr_hip_stats_sweep.argtypes = [vp, vp, i32, C.POINTER(Stats)]
+    L.papr_hip_get_sweep_info.argtypes = [vp, C.POINTER(SweepInfo)]
+    for name in ("papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
+                 "papr_hip_estimate", "papr_hip_stats_sweep", "papr_hip_get_sweep_info"):
         getattr(L, name).restype = i32
     for name in ("papr_hip_open", "papr_hip_device_name", "papr_hip_set_tuning", "papr_hip_set_timing",
                  "papr_hip_get_timing", "papr_file_samples", "papr_hip_load_file", "papr_hip_get_ingest_timing", "papr_hip_upload",
@@ -194,6 +219,17 @@ def levels(total: Stats, graph: bool):
     if n > 0:
         L.papr_levels(C.byref(total), int(graph), None, None, table.ctypes.data_as(C.c_void_p), n)
     return mean.value, papr.value, table
+
+
+def guess_levels(est_total: Stats, graph: bool, max_db: float = None) -> np.ndarray:
+    """Speculative level table for the one-sweep mode (papr_guess_levels); default reach: 60 dB
+    above the estimated mean (48 dB for the 0.1 dB table, whose band LUT is four times denser)."""
+    if max_db is None:
+        max_db = 48.0 if graph else 60.0
+    buf = np.zeros(MAX_LEVELS, dtype=np.float32)
+    n = lib().papr_guess_levels(C.byref(est_total), int(bool(graph)), float(max_db), buf.ctypes.data_as(C.c_void_p),
+                                MAX_LEVELS)
+    return buf[:n].copy()
 
 
 def exact_chain(programs: Sequence[bytes]) -> float:
@@ -264,15 +300,18 @@ class PaprHip:
 
     def set_tuning(self, blocks=0, variant=None, map=None, nontemporal=1, hist_copies=0, flags=0,
                    stats_blocks=None, stats_variant=None, stats_map=None,
-                   ccdf_blocks=None, ccdf_variant=None, ccdf_map=None):
+                   ccdf_blocks=None, ccdf_variant=None, ccdf_map=None,
+                   sweep_blocks=0, sweep_variant=None, sweep_map=None, sweep_band_log2=0, estimate_ratio=0):
         """`blocks` / `variant` / `map` apply to both passes unless the per-pass value is given;
-        None (0 for blocks) keeps each pass's built-in default."""
+        None (0 for blocks) keeps each pass's built-in default.  The sweep_* / estimate_ratio knobs
+        belong to the one-sweep mode."""
         def pick(per_pass, both):
             v = both if per_pass is None else per_pass
             return 0 if v is None else v + 1
         t = Tuning(blocks if stats_blocks is None else stats_blocks, pick(stats_variant, variant),
                    pick(stats_map, map), blocks if ccdf_blocks is None else ccdf_blocks,
-                   pick(ccdf_variant, variant), pick(ccdf_map, map), 1 if nontemporal else 2, hist_copies, flags)
+                   pick(ccdf_variant, variant), pick(ccdf_map, map), 1 if nontemporal else 2, hist_copies, flags,
+                   sweep_blocks, pick(sweep_variant, None), pick(sweep_map, None), sweep_band_log2, estimate_ratio, 0)
         self._chk(self._L.papr_hip_set_tuning(self._ctx, C.byref(t)), "papr_hip_set_tuning")
 
     def set_timing(self, enabled: bool):
@@ -339,6 +378,27 @@ class PaprHip:
         s = Stats()
         self._chk(self._L.papr_hip_stats(self._ctx, C.byref(s)), "papr_hip_stats")
         return s
+
+    # one-sweep mode: both passes in one read (papr_sweep.hip)
+    def estimate(self) -> Stats:
+        """sum / n over a pseudo-random 1/64 sample of the shard (only those two fields are set)."""
+        s = Stats()
+        self._chk(self._L.papr_hip_estimate(self._ctx, C.byref(s)), "papr_hip_estimate")
+        return s
+
+    def stats_sweep(self, guess_table: np.ndarray) -> Stats:
+        """papr_hip_stats + banded pass 2 around the guessed thresholds; a following ccdf() is then
+        answered from the sweep whenever the true thresholds fall inside the bands."""
+        lv = np.ascontiguousarray(guess_table, dtype=np.float32)
+        s = Stats()
+        self._chk(self._L.papr_hip_stats_sweep(self._ctx, lv.ctypes.data_as(C.c_void_p), lv.size, C.byref(s)),
+                  "papr_hip_stats_sweep")
+        return s
+
+    def sweep_info(self) -> SweepInfo:
+        i = SweepInfo()
+        self._chk(self._L.papr_hip_get_sweep_info(self._ctx, C.byref(i)), "papr_hip_get_sweep_info")
+        return i
 
     def ccdf(self, level_table: np.ndarray) -> np.ndarray:
         lv = np.ascontiguousarray(level_table, dtype=np.float32)

@@ -100,6 +100,31 @@ int papr_levels(const papr_stats *total, int graph, double *mean_out, float *pap
     return nl;
 }
 
+/* one-sweep mode: the speculative table — papr_levels' thresholds for the estimated mean, carried on
+ * to max_db above it (the true table stops at the true peak, which is not known yet) */
+int papr_guess_levels(const papr_stats *est_total, int graph, double max_db, float *levels, int cap)
+{
+    if (!est_total || !levels || cap <= 0 || est_total->n == 0 || !(max_db >= 0))
+        return 0;
+    const double mean = est_total->sum / (double)(long long)est_total->n;
+    if (!(mean > 0) || mean > 3e38)
+        return 0;
+    int nl = 0;
+    if (graph) {
+        float tenth_db = 0.0f;
+        while (nl < cap && (double)tenth_db <= max_db) {
+            levels[nl++] = (float)(pow(10, (double)(tenth_db / 10)) * mean);
+            tenth_db = (float)(tenth_db + 0.1);
+        }
+    } else {
+        while (nl < cap && (double)nl <= max_db) {
+            levels[nl] = (float)(pow(10, (double)((float)nl / 10)) * mean);
+            nl++;
+        }
+    }
+    return nl;
+}
+
 int papr_file_samples(const char *path, uint64_t *nsamples)
 {
     struct stat sb;

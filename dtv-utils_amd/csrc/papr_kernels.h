@@ -29,6 +29,16 @@
 #define PAPR_EXACT_AMBIG (-2147483647 - 1) /* tile_E: entry binade not provable, or the tile crosses a binade */
 #define PAPR_EXACT_ZERO (-2147483647)      /* tile_E: every power in the tile is +0: the running sum cannot change */
 
+// One-sweep mode (papr_sweep.hip): the mean estimate reads one 2048-sample tile out of every
+// `ratio`; every wave of the sweep kernel compacts in-band powers into an LDS slice of
+// papr_sweep_slice_floats(unroll) floats (1.5 x what one tile can add: it spills once a third is
+// used; LDS per workgroup decides how many waves a CU holds) before spilling to HBM.
+#define PAPR_ESTIMATE_TILE_SAMPLES 2048
+constexpr uint32_t papr_sweep_slice_floats(int unroll)
+{
+    return 3u * (uint32_t)unroll * 64u;
+}
+
 #define PAPR_MAP_GRID_STRIDE 0
 #define PAPR_MAP_BLOCK_SPAN 1
 #define PAPR_MAP_XCD_SPAN 2
@@ -101,6 +111,19 @@ void papr_launch_ccdf(hipStream_t st, int variant, int blocks, bool nt, bool lut
                       const papr_ccdf_params &P, unsigned long long *ghist);
 void papr_launch_generate(hipStream_t st, int blocks, void *out, uint64_t nsamples, uint64_t first_index,
                           const papr_synth_spec &spec);
+/* one-sweep mode (papr_sweep.hip) */
+void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t ngroups, uint32_t ratio,
+                          papr_partial *out);
+int papr_sweep_variant(int variant); /* the sweep geometry used for a variant id, or -1 */
+size_t papr_sweep_stash_lds_bytes(int variant);
+void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
+                       uint64_t base_index, int map, papr_partial *out, const void *tail, uint32_t tail_samples,
+                       const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist, float *stash,
+                       unsigned long long *seg_counts, uint64_t seg_cap);
+void papr_launch_ccdf_power(hipStream_t st, int blocks, bool lut, size_t lds_bytes, const float *stash,
+                            const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs, uint32_t split,
+                            const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist);
+void papr_sweep_prepare_device(void);
 int papr_ccdf_max_dynamic_lds(void);
 void papr_kernels_prepare_device(void); /* call once per device after hipSetDevice */
 void papr_exact_prepare_device(void);

@@ -127,7 +127,7 @@ class ReaderPool {
 
 struct TimedLaunch {
     hipEvent_t a, b;
-    int kind;  // 0 stats, 1 ccdf
+    int kind;  // 0 stats, 1 ccdf, 2 exact-sum kernels, 3 one-sweep kernel, 4 estimate / stash recount
     uint64_t bytes;
 };
 
@@ -196,6 +196,21 @@ struct papr_hip_ctx {
     uint32_t *d_ambig = nullptr;   // re-streamed shards: [0, cap) unordered list, [cap, 2 cap) sorted list, [2 cap] count
     float *d_raw_store = nullptr;  // ... and the captured raw tiles
 
+    // one-sweep mode (papr_sweep.hip)
+    unsigned long long *d_sweep_hist = nullptr;  // 2 L + 2 bins, then one stash-segment length per workgroup
+    unsigned long long *h_sweep_hist = nullptr;  // pinned
+    float *d_stash = nullptr;                    // in-band powers of the last sweep
+    uint64_t stash_cap = 0;
+    bool sweep_valid = false;                    // the fields below describe the CURRENT shard
+    uint32_t sweep_half = 0;                     // half-width of a band, in bit patterns
+    std::vector<uint32_t> sweep_keys;            // unique guessed keys (band centres), ascending
+    std::vector<uint64_t> sweep_even_above;      // per guessed key j: samples in even bins >= 2 j + 2
+    uint64_t sweep_stash_count = 0;
+    uint64_t sweep_seg_cap = 0;                  // floats per stash segment
+    uint32_t sweep_nsegs = 0, sweep_nbins = 0;
+    bool sweep_overflow = false;
+    papr_hip_sweep_info sweep_info{};
+
     papr_hip_ingest_timing ingest{};
     papr_hip_tuning tune{};
     bool timing = false;
@@ -256,6 +271,11 @@ void parse_tune_env(papr_hip_tuning *t)
             else if (k == "nt") t->nontemporal = val ? 1 : 2;
             else if (k == "copies") t->hist_copies = val;
             else if (k == "search") t->flags = val ? (t->flags | 1) : (t->flags & ~1);
+            else if (k == "wblocks") t->sweep_blocks = val;
+            else if (k == "wvariant") t->sweep_variant = val + 1;
+            else if (k == "wmap") t->sweep_map = val + 1;
+            else if (k == "band") t->sweep_band_log2 = val;
+            else if (k == "ratio") t->estimate_ratio = val;
         }
         pos = end + 1;
     }
@@ -271,12 +291,21 @@ void parse_tune_env(papr_hip_tuning *t)
 constexpr int kStatsVariant = 1, kStatsPerCU = 2, kStatsMap = PAPR_MAP_GRID_STRIDE;
 constexpr int kCcdfVariant = 13, kCcdfPerCU = 2, kCcdfMap = PAPR_MAP_GRID_STRIDE;
 
-enum Pass { PASS1 = 0, PASS2 = 1 };
+// one-sweep kernel (pass 1 + banded pass 2 in one read)
+constexpr int kSweepVariant = 13, kSweepPerCU = 2, kSweepMap = PAPR_MAP_GRID_STRIDE;
+constexpr int kSweepBandLog2 = 14, kEstimateRatio = 64;
+constexpr uint64_t kEstimateMinTiles = 8192;  // sample at least 16 Mi samples (or everything)
+
+enum Pass { PASS1 = 0, PASS2 = 1, SWEEP = 2 };
 
 int variant_of(const papr_hip_ctx *ctx, Pass p)
 {
     if (p == PASS1 && ctx->exact)
         return 1;  // 256 x 4 pipelined: the geometry papr_launch_stats_tilesums is built for
+    if (p == SWEEP) {
+        const int v = papr_sweep_variant(ctx->tune.sweep_variant - 1);
+        return v >= 0 ? v : kSweepVariant;
+    }
     const int v = (p == PASS1 ? ctx->tune.stats_variant : ctx->tune.ccdf_variant) - 1;
     int b, u;
     if (v >= 0 && papr_variant_geometry(v, &b, &u) == 0)
@@ -286,8 +315,8 @@ int variant_of(const papr_hip_ctx *ctx, Pass p)
 
 int blocks_of(const papr_hip_ctx *ctx, Pass p)
 {
-    const int b = p == PASS1 ? ctx->tune.stats_blocks : ctx->tune.ccdf_blocks;
-    return b > 0 ? b : ctx->num_cus * (p == PASS1 ? kStatsPerCU : kCcdfPerCU);
+    const int b = p == PASS1 ? ctx->tune.stats_blocks : p == PASS2 ? ctx->tune.ccdf_blocks : ctx->tune.sweep_blocks;
+    return b > 0 ? b : ctx->num_cus * (p == PASS1 ? kStatsPerCU : p == PASS2 ? kCcdfPerCU : kSweepPerCU);
 }
 
 // samples one workgroup consumes per loop iteration under the pass's kernel variant
@@ -300,9 +329,11 @@ uint64_t tile_samples(const papr_hip_ctx *ctx, Pass p)
 
 int map_of(const papr_hip_ctx *ctx, Pass p)
 {
-    const int m = (p == PASS1 ? ctx->tune.stats_map : ctx->tune.ccdf_map) - 1;
+    const int m = (p == PASS1 ? ctx->tune.stats_map : p == PASS2 ? ctx->tune.ccdf_map : ctx->tune.sweep_map) - 1;
     if (m >= 0 && m <= 2)
         return m;
+    if (p == SWEEP)
+        return kSweepMap;
     // exact-sum mode: the per-tile sums of neighbouring tiles are then written by workgroups of the same
     // XCD (1.70 ms vs 1.83 ms per 10 GiB with grid-stride; its slow mode costs no more than that)
     if (p == PASS1 && ctx->exact)
@@ -373,7 +404,7 @@ void release_shard(papr_hip_ctx *ctx)
     ctx->loaded = ctx->resident = false;
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
-    ctx->exact_valid = false;
+    ctx->sweep_valid = false;
     ctx->shard_flags = 0;
     ctx->path.clear();
 }
@@ -525,37 +556,24 @@ struct CcdfPlan {
     size_t lds_bytes = 0;
 };
 
-int plan_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, CcdfPlan *plan)
+// LUT / search form and LDS layout for plan->keys (unique, ascending); `vblock` = threads of the workgroup that
+// will use it, `extra_lds` = what else that workgroup keeps in LDS
+int finish_plan(papr_hip_ctx *ctx, CcdfPlan *plan, int vblock, size_t extra_lds)
 {
-    plan->keys.clear();
-    plan->pos.assign(nlevels, -1);
-    std::vector<uint32_t> all(nlevels);
-    for (int j = 0; j < nlevels; j++) {
-        all[j] = level_key(levels[j]);
-        if (all[j] != kNever)
-            plan->keys.push_back(all[j]);
-    }
-    std::sort(plan->keys.begin(), plan->keys.end());
-    plan->keys.erase(std::unique(plan->keys.begin(), plan->keys.end()), plan->keys.end());
-    for (int j = 0; j < nlevels; j++)
-        if (all[j] != kNever)
-            plan->pos[j] = (int)(std::lower_bound(plan->keys.begin(), plan->keys.end(), all[j]) - plan->keys.begin());
-
     const uint32_t m = (uint32_t)plan->keys.size();
     papr_ccdf_params &P = plan->P;
     memset(&P, 0, sizeof(P));
     P.nkeys = m;
+    plan->lut = false;
+    plan->lds_bytes = 0;
     if (m == 0)
         return PAPR_OK;
     const uint32_t nbins = m + 1;
     const size_t lds_cap = (size_t)papr_ccdf_max_dynamic_lds();
-    int vblock = 256, vunroll = 8;
-    (void)papr_variant_geometry(variant_of(ctx, PASS2), &vblock, &vunroll);
     const int waves = vblock / 64;
     const int want_copies = ctx->tune.hist_copies > 0 ? std::min(ctx->tune.hist_copies, waves) : std::min(waves, 4);
 
     // LUT: the coarsest cell size that still isolates every key in its own cell
-    plan->lut = false;
     if (plan->keys.front() >= 0x00800000u && !(ctx->tune.flags & 1)) {  // keys in the normal-float range
         for (int shift = 23; shift >= 8; shift--) {
             const uint32_t c0 = plan->keys.front() >> shift, c1 = plan->keys.back() >> shift;
@@ -587,13 +605,34 @@ int plan_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, CcdfPlan *pla
     // histogram copies: one per wave when it is cheap, fewer for huge tables
     int copies = want_copies;
     const size_t soft_cap = (size_t)vblock * 80;  // the workgroup's share of 160 KiB when the CU is full of threads
-    while (copies > 1 && (size_t)P.table_words * 4 + (size_t)copies * nbins * 4 > soft_cap)
+    while (copies > 1 && (size_t)P.table_words * 4 + (size_t)copies * nbins * 4 + extra_lds > soft_cap)
         copies--;
     P.copies = (uint32_t)copies;
     plan->lds_bytes = (size_t)P.table_words * 4 + (size_t)copies * nbins * 4;
-    if (plan->lds_bytes > lds_cap)
-        return fail(ctx, PAPR_E_LIMIT, "level table needs %zu bytes of LDS (limit %zu)", plan->lds_bytes, lds_cap);
+    if (plan->lds_bytes + extra_lds > lds_cap)
+        return fail(ctx, PAPR_E_LIMIT, "level table needs %zu bytes of LDS (limit %zu)", plan->lds_bytes + extra_lds,
+                    lds_cap);
     return PAPR_OK;
+}
+
+int plan_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, CcdfPlan *plan)
+{
+    plan->keys.clear();
+    plan->pos.assign(nlevels, -1);
+    std::vector<uint32_t> all(nlevels);
+    for (int j = 0; j < nlevels; j++) {
+        all[j] = level_key(levels[j]);
+        if (all[j] != kNever)
+            plan->keys.push_back(all[j]);
+    }
+    std::sort(plan->keys.begin(), plan->keys.end());
+    plan->keys.erase(std::unique(plan->keys.begin(), plan->keys.end()), plan->keys.end());
+    for (int j = 0; j < nlevels; j++)
+        if (all[j] != kNever)
+            plan->pos[j] = (int)(std::lower_bound(plan->keys.begin(), plan->keys.end(), all[j]) - plan->keys.begin());
+    int vblock = 256, vunroll = 8;
+    (void)papr_variant_geometry(variant_of(ctx, PASS2), &vblock, &vunroll);
+    return finish_plan(ctx, plan, vblock, 0);
 }
 
 int upload_ccdf_table(papr_hip_ctx *ctx, const CcdfPlan &plan)
@@ -967,6 +1006,21 @@ int finish_stats(papr_hip_ctx *ctx, size_t records, const float *tail_ptr, uint3
     return PAPR_OK;
 }
 
+// the double sum of a resident shard came out NaN: find the first NaN power and the sign x86 gives it
+int resolve_resident_nan(papr_hip_ctx *ctx, papr_stats *out)
+{
+    if (!std::isnan(out->sum))
+        return PAPR_OK;
+    unsigned long long key = ~0ull;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_nan_key, &key, 8, hipMemcpyHostToDevice, ctx->stream));
+    papr_launch_first_nan(ctx->stream, 1024, ctx->d_iq, ctx->n, ctx->base, ctx->d_nan_key);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(&key, ctx->d_nan_key, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    apply_nan_key(out, key);
+    return PAPR_OK;
+}
+
 }  // namespace
 
 // =============================================================================
@@ -1066,6 +1120,9 @@ void papr_hip_close(papr_hip_ctx *ctx)
         if (ctx->ev_kernel[b]) (void)hipEventDestroy(ctx->ev_kernel[b]);
     }
     if (ctx->d_tail) (void)hipFree(ctx->d_tail);
+    if (ctx->d_sweep_hist) (void)hipFree(ctx->d_sweep_hist);
+    if (ctx->h_sweep_hist) (void)hipHostFree(ctx->h_sweep_hist);
+    if (ctx->d_stash) (void)hipFree(ctx->d_stash);
     if (ctx->d_tile_sums) (void)hipFree(ctx->d_tile_sums);
     if (ctx->d_block_sums) (void)hipFree(ctx->d_block_sums);
     if (ctx->d_tile_E) (void)hipFree(ctx->d_tile_E);
@@ -1105,7 +1162,11 @@ int papr_hip_set_tuning(papr_hip_ctx *ctx, const papr_hip_tuning *t)
     if (t->stats_blocks < 0 || t->stats_blocks > 65536 || t->ccdf_blocks < 0 || t->ccdf_blocks > 65536 ||
         t->stats_map < 0 || t->stats_map > 3 || t->ccdf_map < 0 || t->ccdf_map > 3 || t->hist_copies < 0 ||
         (t->stats_variant != 0 && papr_variant_geometry(t->stats_variant - 1, &vb, &vu) != 0) ||
-        (t->ccdf_variant != 0 && papr_variant_geometry(t->ccdf_variant - 1, &vb, &vu) != 0))
+        (t->ccdf_variant != 0 && papr_variant_geometry(t->ccdf_variant - 1, &vb, &vu) != 0) ||
+        t->sweep_blocks < 0 || t->sweep_blocks > 65536 || t->sweep_map < 0 || t->sweep_map > 3 ||
+        (t->sweep_variant != 0 && papr_sweep_variant(t->sweep_variant - 1) < 0) ||
+        (t->sweep_band_log2 != 0 && (t->sweep_band_log2 < 8 || t->sweep_band_log2 > 20)) || t->estimate_ratio < 0 ||
+        t->estimate_ratio > 65536)
         return fail(ctx, PAPR_E_ARG, "bad tuning values");
     ctx->tune = *t;
     return PAPR_OK;
@@ -1132,7 +1193,15 @@ int papr_hip_get_timing(papr_hip_ctx *ctx, papr_hip_timing *out)
     for (size_t k = 0; k < ctx->timed_used; k++) {
         float ms = 0.f;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->timed[k].a, ctx->timed[k].b));
-        if (ctx->timed[k].kind == 2) {
+        if (ctx->timed[k].kind == 3) {
+            out->sweep_ms += ms;
+            out->sweep_launches++;
+            out->sweep_bytes += ctx->timed[k].bytes;
+        } else if (ctx->timed[k].kind == 4) {
+            out->aux_ms += ms;
+            out->aux_launches++;
+            out->aux_bytes += ctx->timed[k].bytes;
+        } else if (ctx->timed[k].kind == 2) {
             out->exact_ms += ms;
             out->exact_launches++;
             out->exact_bytes += ctx->timed[k].bytes;
@@ -1184,6 +1253,7 @@ int papr_hip_upload(papr_hip_ctx *ctx, const float *iq, uint64_t nsamples, uint6
     ctx->loaded = ctx->resident = true;
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
+    ctx->sweep_valid = false;
     ctx->shard_flags = 0;
     ctx->path.clear();
     return PAPR_OK;
@@ -1210,6 +1280,7 @@ int papr_hip_generate(papr_hip_ctx *ctx, const papr_synth_spec *spec, uint64_t f
     ctx->loaded = ctx->resident = true;
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
+    ctx->sweep_valid = false;
     ctx->shard_flags = 0;
     ctx->path.clear();
     return PAPR_OK;
@@ -1263,6 +1334,7 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
     ctx->loaded = true;
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
+    ctx->sweep_valid = false;
     ctx->shard_flags = (fs.odd && first_sample + nsamples == fs.nsamples && nsamples > 0) ? PAPR_FLAG_ODD_TAIL : 0;
 
     ctx->ingest.setup_s = now_s() - t_begin;
@@ -1325,6 +1397,7 @@ int papr_hip_stats(papr_hip_ctx *ctx, papr_stats *out)
         return PAPR_E_ARG;
     if (!ctx->loaded)
         return fail(ctx, PAPR_E_STATE, "papr_hip_stats called before a shard was loaded");
+    ctx->sweep_valid = false;  // a sweep only serves the papr_hip_ccdf calls that directly follow it
     if (ctx->have_file_stats) {  // computed while the file streamed in
         *out = ctx->file_stats;
         return PAPR_OK;
@@ -1343,16 +1416,234 @@ int papr_hip_stats(papr_hip_ctx *ctx, papr_stats *out)
     rc = finish_stats(ctx, (size_t)nrec, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->base + ctx->n - tail, out);
     if (rc)
         return rc;
-    if (std::isnan(out->sum)) {
-        unsigned long long key = ~0ull;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_nan_key, &key, 8, hipMemcpyHostToDevice, ctx->stream));
-        papr_launch_first_nan(ctx->stream, 1024, ctx->d_iq, ctx->n, ctx->base, ctx->d_nan_key);
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(&key, ctx->d_nan_key, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        apply_nan_key(out, key);
-    }
+    rc = resolve_resident_nan(ctx, out);
+    if (rc)
+        return rc;
     ctx->exact_valid = ctx->exact;
+    return PAPR_OK;
+}
+
+// ---- one-sweep mode (papr_sweep.hip) -----------------------------------------------
+
+int papr_hip_estimate(papr_hip_ctx *ctx, papr_stats *est)
+{
+    if (!ctx || !est)
+        return PAPR_E_ARG;
+    if (!ctx->loaded)
+        return fail(ctx, PAPR_E_STATE, "papr_hip_estimate called before a shard was loaded");
+    papr_stats_init(est);
+    ctx->sweep_info.estimate_samples = 0;
+    if (ctx->have_file_stats) {  // pass 1 already ran while the file streamed in: the "estimate" is the real thing
+        est->sum = ctx->file_stats.sum;
+        est->n = ctx->file_stats.n;
+        return PAPR_OK;
+    }
+    if (!ctx->resident)
+        return fail(ctx, PAPR_E_STATE, "the shard is not resident and has no pass-1 result: reload it");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t ntiles = ctx->n / PAPR_ESTIMATE_TILE_SAMPLES;
+    if (ntiles == 0)
+        return PAPR_OK;  // nothing to sample: n = 0 tells the caller there is no estimate
+    uint64_t ratio = ctx->tune.estimate_ratio > 0 ? (uint64_t)ctx->tune.estimate_ratio : (uint64_t)kEstimateRatio;
+    ratio = std::max<uint64_t>(1, std::min<uint64_t>(ratio, ntiles / kEstimateMinTiles));
+    const uint64_t ngroups = ntiles / ratio;
+    const int blocks = (int)std::min<uint64_t>(ngroups, (uint64_t)ctx->num_cus * 8);
+    int rc = ensure_partials(ctx, (size_t)blocks + 1);
+    if (rc)
+        return rc;
+    time_begin(ctx, 4, ngroups * PAPR_ESTIMATE_TILE_SAMPLES * 8);
+    papr_launch_estimate(ctx->stream, blocks, ctx->d_iq, ngroups, (uint32_t)ratio, ctx->d_partials);
+    time_end(ctx);
+    HIPCHK(ctx, hipGetLastError());
+    papr_launch_stats_finalize(ctx->stream, nullptr, 0, 0, ctx->d_partials, (uint32_t)blocks, ctx->h_result_dev);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    est->sum = ctx->h_result->sum;
+    est->n = ngroups * PAPR_ESTIMATE_TILE_SAMPLES;
+    ctx->sweep_info.estimate_samples = est->n;
+    return PAPR_OK;
+}
+
+int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, papr_stats *out)
+{
+    if (!ctx || !out || nlevels < 0 || (nlevels && !guess_levels))
+        return PAPR_E_ARG;
+    if (!ctx->loaded)
+        return fail(ctx, PAPR_E_STATE, "papr_hip_stats_sweep called before a shard was loaded");
+    papr_hip_sweep_info &info = ctx->sweep_info;
+    info.swept = info.resolved = 0;
+    info.stash_samples = 0;
+    info.band_log2 = ctx->tune.sweep_band_log2 > 0 ? ctx->tune.sweep_band_log2 : kSweepBandLog2;
+    ctx->sweep_valid = false;
+    auto plain = [&](int reason) {
+        info.reason = reason;
+        return papr_hip_stats(ctx, out);
+    };
+    if (ctx->have_file_stats || !ctx->resident || ctx->exact)
+        return plain(PAPR_SWEEP_MODE);
+    if (nlevels == 0 || nlevels > PAPR_HIP_MAX_LEVELS)
+        return plain(PAPR_SWEEP_NO_BANDS);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+
+    // guessed keys -> band edges lo_0 < hi_0 < lo_1 < hi_1 < ...
+    std::vector<uint32_t> all(nlevels), gkeys;
+    for (int j = 0; j < nlevels; j++) {
+        all[j] = level_key(guess_levels[j]);
+        if (all[j] != kNever)
+            gkeys.push_back(all[j]);
+    }
+    std::sort(gkeys.begin(), gkeys.end());
+    gkeys.erase(std::unique(gkeys.begin(), gkeys.end()), gkeys.end());
+    if (gkeys.empty())
+        return plain(PAPR_SWEEP_NO_BANDS);
+    // widest band (<= the configured width) whose edges stay apart and still have a LUT form
+    const int variant = variant_of(ctx, SWEEP);
+    int vblock = 256, vunroll = 4;
+    (void)papr_variant_geometry(variant, &vblock, &vunroll);
+    const size_t stash_lds = papr_sweep_stash_lds_bytes(variant);
+    CcdfPlan bands;
+    uint32_t half = 0;
+    for (int log2w = info.band_log2; log2w >= std::max(info.band_log2 - 3, 8) && !half; log2w--) {
+        const uint32_t h = 1u << log2w;
+        bands.keys.clear();
+        bool ok = true;
+        for (size_t j = 0; j < gkeys.size() && ok; j++) {
+            const uint32_t g = gkeys[j];
+            ok = g >= 0x00800000u + h && g < 0x7F800000u - h && !(j && g - h <= gkeys[j - 1] + h);  // bands must not touch
+            bands.keys.push_back(g - h);
+            bands.keys.push_back(g + h);
+        }
+        if (!ok)
+            continue;
+        char keep[sizeof(ctx->err)];
+        memcpy(keep, ctx->err, sizeof(keep));
+        const bool fits = finish_plan(ctx, &bands, vblock, stash_lds) == PAPR_OK && bands.lut;
+        memcpy(ctx->err, keep, sizeof(keep));  // not an error of this call: a narrower band or the plain pass follows
+        if (fits) {
+            half = h;
+            info.band_log2 = log2w;
+        }
+    }
+    if (!half)
+        return plain(PAPR_SWEEP_NO_BANDS);
+    // the sweep kernel's LUT has a sentinel cell at either end and its histogram one more (NaN) bin
+    bands.P.table_words = 2 * (bands.P.ncells + 2);
+    const uint32_t nbins = bands.P.nkeys + 2;
+    bands.lds_bytes = (size_t)bands.P.table_words * 4 + (size_t)bands.P.copies * nbins * 4;
+    if (bands.lds_bytes + stash_lds > (size_t)papr_ccdf_max_dynamic_lds())
+        return plain(PAPR_SWEEP_NO_BANDS);
+
+    const uint64_t tile = tile_samples(ctx, SWEEP);
+    const uint64_t ntiles = ctx->n / tile;
+    const uint32_t tail = (uint32_t)(ctx->n - ntiles * tile);
+    const int blocks = pick_blocks(ctx, SWEEP, ntiles);
+    const int map = effective_map(ctx, SWEEP, blocks);
+
+    // buffers: band histogram with the stash-segment lengths right behind it; stash = 1/4 of the shard's samples
+    // (as floats: 1/8 of its bytes), one equal segment per workgroup
+    constexpr size_t kMaxSweepBlocks = 65536;
+    if (!ctx->d_sweep_hist) {
+        const size_t bytes = (2 * (size_t)PAPR_HIP_MAX_LEVELS + 2 + kMaxSweepBlocks) * sizeof(unsigned long long);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_sweep_hist, bytes));
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_sweep_hist, bytes, hipHostMallocDefault));
+    }
+    const uint64_t seg_cap = std::max<uint64_t>((ctx->n / 4 / (uint64_t)blocks + 3) & ~3ull, 4096);
+    const uint64_t want_stash = seg_cap * (uint64_t)blocks;
+    if (ctx->stash_cap < want_stash) {
+        if (ctx->d_stash) HIPCHK(ctx, hipFree(ctx->d_stash));
+        ctx->d_stash = nullptr;
+        ctx->stash_cap = 0;
+        if (hipMalloc((void **)&ctx->d_stash, want_stash * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->d_stash = nullptr;
+            return plain(PAPR_SWEEP_STASH_FULL);
+        }
+        ctx->stash_cap = want_stash;
+    }
+    int rc = ensure_table(ctx, bands.P.table_words);
+    if (rc)
+        return rc;
+    {
+        // lut[0] = below everything, lut[1 + c] = {edges below cell c, the edge inside it or never},
+        // lut[ncells + 1] = above every edge; a NaN pattern compares >= 0x7F800001 and lands in the trash bin
+        const papr_ccdf_params &P = bands.P;
+        uint32_t *tab = ctx->h_table;
+        tab[0] = 0;
+        tab[1] = kNever;
+        uint32_t k = 0;
+        for (uint32_t c = 0; c < P.ncells; c++) {
+            uint32_t in_cell = kNever;
+            const uint32_t below = k;
+            if (k < P.nkeys && (bands.keys[k] >> P.shift) == P.cell_lo + c)
+                in_cell = bands.keys[k++];
+            tab[2 * (c + 1)] = below;
+            tab[2 * (c + 1) + 1] = in_cell;
+        }
+        tab[2 * (P.ncells + 1)] = P.nkeys;
+        tab[2 * (P.ncells + 1) + 1] = 0x7F800001u;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_table, ctx->h_table, (size_t)P.table_words * 4, hipMemcpyHostToDevice,
+                                   ctx->stream));
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_sweep_hist, 0, (size_t)nbins * sizeof(unsigned long long), ctx->stream));
+    rc = ensure_partials(ctx, (size_t)blocks + 1);
+    if (rc)
+        return rc;
+    const float *tail_ptr = ctx->d_iq + 2 * (ctx->n - tail);
+    time_begin(ctx, 3, ctx->n * 8);
+    papr_launch_sweep(ctx->stream, variant, blocks, bands.lds_bytes + stash_lds, ctx->d_iq, ntiles, ctx->base, map,
+                      ctx->d_partials, tail_ptr, tail, ctx->d_table, bands.P, ctx->d_sweep_hist, ctx->d_stash,
+                      ctx->d_sweep_hist + nbins, seg_cap);
+    time_end(ctx);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_sweep_hist, ctx->d_sweep_hist,
+                               ((size_t)nbins + (size_t)blocks) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    rc = finish_stats(ctx, (size_t)blocks, tail_ptr, tail, ctx->base + ctx->n - tail, out);  // synchronises
+    if (rc)
+        return rc;
+    if (std::isnan(out->sum))  // NaN in the data: the sweep's integer-max trackers do not apply (papr_sweep.hip)
+        return plain(PAPR_SWEEP_NO_BANDS);
+
+    // what the sweep decided: samples in even bins above each band; odd bins are exactly the stash
+    const unsigned long long *H = ctx->h_sweep_hist;
+    uint64_t stash_count = 0, in_bands = 0;
+    bool overflow = false;
+    for (int b = 0; b < blocks; b++) {
+        stash_count += H[nbins + b];
+        overflow = overflow || H[nbins + b] > seg_cap;
+    }
+    for (uint32_t b = 1; b < nbins; b += 2)
+        in_bands += H[b];
+    if (in_bands != stash_count)
+        return fail(ctx, PAPR_E_INTERNAL, "one-sweep invariant broken: %llu samples binned inside bands, %llu stashed",
+                    (unsigned long long)in_bands, (unsigned long long)stash_count);
+    const size_t m = gkeys.size();
+    ctx->sweep_even_above.assign(m, 0);
+    uint64_t run = 0;
+    for (size_t j = m; j-- > 0;) {
+        run += H[2 * j + 2];
+        ctx->sweep_even_above[j] = run;
+    }
+    ctx->sweep_keys = gkeys;
+    ctx->sweep_half = half;
+    ctx->sweep_stash_count = stash_count;
+    ctx->sweep_seg_cap = seg_cap;
+    ctx->sweep_nsegs = (uint32_t)blocks;
+    ctx->sweep_nbins = nbins;
+    ctx->sweep_overflow = overflow;
+    ctx->sweep_valid = true;
+    info.swept = 1;
+    info.reason = PAPR_SWEEP_OK;
+    info.stash_samples = stash_count;
+    info.stash_capacity = seg_cap * (uint64_t)blocks;  // what this sweep could use (one segment per workgroup)
+    return PAPR_OK;
+}
+
+int papr_hip_get_sweep_info(const papr_hip_ctx *ctx, papr_hip_sweep_info *out)
+{
+    if (!ctx || !out)
+        return PAPR_E_ARG;
+    *out = ctx->sweep_info;
     return PAPR_OK;
 }
 
@@ -1586,6 +1877,64 @@ void counts_from_histogram(const papr_hip_ctx *ctx, const CcdfPlan &plan, int nl
         counts_above[j] = plan.pos[j] >= 0 ? above[plan.pos[j]] : 0;
 }
 
+// Answer papr_hip_ccdf from the last one-sweep pass if every true threshold lies inside the band of its guess:
+// samples outside the bands were decided by the sweep, the stash holds the rest.
+int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, int nlevels, uint64_t *counts_above, bool *done)
+{
+    papr_hip_sweep_info &info = ctx->sweep_info;
+    *done = false;
+    info.resolved = 0;
+    // every true threshold must lie inside one of the bands (matched by value: the true table may be
+    // longer or shorter than the guess, e.g. when the sampled peak missed the real one)
+    std::vector<int> band_of(plan.P.nkeys, -1);
+    for (uint32_t i = 0; i < plan.P.nkeys; i++) {
+        const uint32_t t = plan.keys[i];
+        const auto it = std::lower_bound(ctx->sweep_keys.begin(), ctx->sweep_keys.end(), t);
+        int j = -1;
+        if (it != ctx->sweep_keys.end() && *it - t <= ctx->sweep_half)
+            j = (int)(it - ctx->sweep_keys.begin());
+        else if (it != ctx->sweep_keys.begin() && t - *(it - 1) <= ctx->sweep_half)
+            j = (int)(it - ctx->sweep_keys.begin()) - 1;
+        if (j < 0) {
+            info.reason = PAPR_SWEEP_OUT_OF_BAND;
+            return PAPR_OK;
+        }
+        band_of[i] = j;
+    }
+    if (ctx->sweep_overflow) {
+        info.reason = PAPR_SWEEP_STASH_FULL;
+        return PAPR_OK;
+    }
+    const uint32_t m = plan.P.nkeys;
+    if (ctx->sweep_stash_count) {
+        int rc = upload_ccdf_table(ctx, plan);
+        if (rc)
+            return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_hist, 0, (size_t)(m + 1) * sizeof(unsigned long long), ctx->stream));
+        time_begin(ctx, 4, ctx->sweep_stash_count * 4);
+        // enough workgroups to fill the chip: every segment is split over `split` of them
+        const uint32_t split = std::max<uint32_t>(1, (uint32_t)(ctx->num_cus * 8) / ctx->sweep_nsegs);
+        papr_launch_ccdf_power(ctx->stream, (int)(ctx->sweep_nsegs * split), plan.lut, plan.lds_bytes, ctx->d_stash,
+                               ctx->d_sweep_hist + ctx->sweep_nbins, ctx->sweep_seg_cap, ctx->sweep_nsegs, split,
+                               ctx->d_table, plan.P, ctx->d_hist);
+        time_end(ctx);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(m + 1) * sizeof(unsigned long long),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        memset(ctx->h_hist, 0, (size_t)(m + 1) * sizeof(unsigned long long));
+    }
+    counts_from_histogram(ctx, plan, nlevels, counts_above);  // stash powers above each level ...
+    for (int j = 0; j < nlevels; j++)
+        if (plan.pos[j] >= 0)
+            counts_above[j] += ctx->sweep_even_above[band_of[plan.pos[j]]];  // ... + everything above its band
+    info.resolved = 1;
+    info.reason = PAPR_SWEEP_OK;
+    *done = true;
+    return PAPR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1666,6 +2015,7 @@ int papr_hip_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t 
         return fail(ctx, PAPR_E_STATE, "papr_hip_ccdf called before a shard was loaded");
     if (nlevels > PAPR_HIP_MAX_LEVELS)
         return fail(ctx, PAPR_E_LIMIT, "%d levels exceeds PAPR_HIP_MAX_LEVELS (%d)", nlevels, PAPR_HIP_MAX_LEVELS);
+    ctx->sweep_info.resolved = 0;
     if (nlevels == 0)
         return PAPR_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1678,6 +2028,12 @@ int papr_hip_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t 
         for (int j = 0; j < nlevels; j++)
             counts_above[j] = 0;
         return PAPR_OK;
+    }
+    if (ctx->sweep_valid) {  // the one-sweep pass already decided everything outside the bands
+        bool done = false;
+        rc = resolve_from_sweep(ctx, plan, nlevels, counts_above, &done);
+        if (rc || done)
+            return rc;
     }
     rc = upload_ccdf_table(ctx, plan);
     if (rc)

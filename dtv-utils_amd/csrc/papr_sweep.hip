@@ -1,0 +1,477 @@
+// papr_sweep.hip — ONE read of the shard for both passes of papr (gfx950 / MI355X).
+//
+// The reference reads the file twice because pass 2's thresholds are mean * 10^(dB/10) and the mean
+// is only known after pass 1 (papr.c:131-141 -> :145-152).  Both passes are HBM-bound here, so the
+// second read is half of the job.  The one-sweep scheme keeps the result exact and drops it:
+//
+//   1. papr_estimate_kernel      sums one pseudo-randomly chosen 16 KiB tile out of every `ratio`
+//                                (1/64 of the shard by default): a mean good to ~1e-4 relative
+//   2. the host turns that guess into the level table the reference would build from it and widens
+//      every threshold into a BAND of +-2^w float bit patterns (default w = 15, i.e. +-0.2 .. 0.4 %)
+//   3. papr_sweep_kernel         pass 1 exactly as papr_stats_kernel (same geometry => same sum,
+//                                same trackers), and in the same read every power is binned against
+//                                the band edges: even bins lie BETWEEN bands, so whichever way the
+//                                true threshold falls inside its band those samples are already
+//                                decided; the few per cent that land INSIDE a band (odd bins) are
+//                                appended to a stash of float powers in HBM
+//   4. once the true mean — hence the true table — is known, papr_ccdf_power_kernel bins just the
+//      stash against it.  counts_above[j] = (even bins above band j) + (stash powers > level j).
+//
+// If a true threshold falls outside its band, the stash overflows or the table has no LUT form, the
+// runtime simply runs the classic pass 2 (papr_ccdf_kernel): speculation never changes a result, it
+// only decides how many bytes are read.  Typical extra traffic: 1-3 % of a pass (default table),
+// ~6 % (-g), instead of 100 %.
+//
+// The stash is filled without workgroup barriers and without global atomics: every workgroup owns one
+// segment of the HBM stash, every wave owns a slice of LDS and compacts its in-band powers into it
+// with ballot/mbcnt; when the slice is half full the wave reserves a range of the workgroup's segment
+// with one LDS atomic and writes it out coalesced.  (A single global counter serialises at ~11 ns per
+// reservation across the 8 XCDs — measured: it doubled the kernel time of the 0.1 dB table.)
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "papr_kernels.h"
+#include "papr_device.h"
+#include "papr_stream.h"
+
+namespace {
+
+
+// min(max(cell, first), last) in one instruction (the compiler will not form med3 from min/max when it
+// cannot prove last >= 0)
+__device__ __forceinline__ int32_t clamp_cell(int32_t cell, int32_t first, int32_t last)
+{
+    int32_t r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(cell), "v"(first), "s"(last));  // one SGPR operand at most on gfx9
+    return r;
+}
+
+// which tile of group g the estimate reads
+__device__ __forceinline__ uint32_t papr_estimate_pick(uint64_t g, uint32_t ratio)
+{
+    return (uint32_t)(((g + 1) * 0x9E3779B97F4A7C15ull) >> 40) % ratio;
+}
+
+// Per-wave append buffer in LDS + its spill to the workgroup's segment of the HBM stash.  Lanes that
+// hold an in-band power reserve a slot with a returning LDS atomic on the wave's own counter (three
+// VALU instructions per sample; a ballot/mbcnt compaction costs seven).
+struct WaveStash {
+    float *buf;                         // this wave's slice of LDS
+    uint32_t *fill;                     // LDS: entries in buf (this wave's counter)
+    float *__restrict__ seg;            // this workgroup's stash segment
+    unsigned long long *seg_fill;       // LDS: floats reserved in the segment so far (may run past seg_cap)
+    uint64_t seg_cap;
+
+    __device__ __forceinline__ void put(float pw, bool take)
+    {
+        if (take)
+            buf[atomicAdd(fill, 1u)] = pw;
+    }
+    // spill if more than `limit` entries are waiting (wave-uniform decision)
+    __device__ __forceinline__ void spill_if_above(uint32_t limit)
+    {
+        __builtin_amdgcn_wave_barrier();  // LDS is in-order per wave; this pins the compiler's order too
+        const uint32_t n = __builtin_amdgcn_readfirstlane(*fill);
+        if (n <= limit)
+            return;
+        const uint32_t lane = threadIdx.x & (kWave - 1);
+        unsigned long long pos = 0;
+        if (lane == 0) {
+            pos = atomicAdd(seg_fill, (unsigned long long)n);  // counts even what no longer fits: the host sees the overflow
+            *fill = 0;
+        }
+        pos = __shfl((unsigned long long)pos, 0, kWave);
+        for (uint32_t i = lane; i < n; i += kWave)
+            if (pos + i < seg_cap)
+                seg[pos + i] = buf[i];
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+}  // namespace
+
+// =============================================================================
+// 1. mean estimate from a 1/ratio sample of the tiles
+// =============================================================================
+// Group g = tiles [g*ratio, (g+1)*ratio); one tile of it (a hash of g picks which, so that no
+// periodic structure in the capture can alias with the sampling) is read by one workgroup:
+// 256 lanes x 4 x 16 B = 16 KiB = 2048 samples.  Output: one papr_partial per workgroup with only
+// `sum` set (merged by papr_stats_finalize like pass-1 partials).
+__global__ __launch_bounds__(PAPR_BLOCK) void papr_estimate_kernel(const float4 *__restrict__ data, uint64_t ngroups,
+                                                                    uint32_t ratio, papr_partial *__restrict__ out)
+{
+    constexpr int U = PAPR_ESTIMATE_TILE_SAMPLES / (2 * PAPR_BLOCK);
+    constexpr uint64_t TILE_F4 = (uint64_t)PAPR_BLOCK * U;
+    double sum = 0.0;
+    for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const uint64_t tile = g * ratio + papr_estimate_pick(g, ratio);
+        float4 x[U];
+        load_tile<PAPR_BLOCK, U, false>(x, data + tile * TILE_F4 + threadIdx.x);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            sum += (double)power_of(x[u].x, x[u].y);
+            sum += (double)power_of(x[u].z, x[u].w);
+        }
+    }
+    LaneStats s;
+    s.sum = sum;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        s.val[k] = 0.f;
+        s.idx[k] = 0;
+    }
+    block_reduce_stats<PAPR_BLOCK / kWave>(s);
+    if (threadIdx.x == 0) {
+        papr_partial q;
+        q.sum = s.sum;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            q.idx[k] = 0;
+            q.val[k] = 0.f;
+        }
+        q.pad = 0;
+        out[blockIdx.x] = q;
+    }
+}
+
+// =============================================================================
+// 3. the sweep: pass 1 + band binning + stash, one read
+// =============================================================================
+// Doing both passes' arithmetic per sample costs more VALU work than either pass alone (a CU has 64
+// lane-ops per clock, i.e. ~44 per sample at full HBM speed), so this kernel trims both halves:
+//
+//  * trackers per TILE, not per sample: the lane folds the 2U values of a tile with integer max3 on
+//    the float bit patterns (signed max finds the largest positive float, unsigned max the most
+//    negative one; powers are >= +0), then does ONE strict float compare per tracker per tile and
+//    remembers the iteration.  After the loop the lane re-reads that one tile and takes the first
+//    slot that holds the value: the same first-occurrence answer as papr_stats_kernel.  NaN bit
+//    patterns would win an integer max, but any NaN in I or Q also makes the sum NaN, and then the
+//    runtime discards this launch's pass-1 record and runs papr_stats_kernel instead.
+//  * the double sum adds the same powers in the same order as papr_stats_kernel (bit-identical sum)
+//  * branch-free binning: the LUT carries a "below" sentinel cell in front and an "above" one behind,
+//    the cell index is clamped with one med3.  The above sentinel sends NaN powers to a trash bin
+//    (index nkeys + 1, odd: they also go to the stash, where the recount ignores them).
+//
+// LDS: [LUT of the band edges | histogram copies | one stash slice per wave].
+// `table`/P describe the 2m band edges lo_0 < hi_0 < lo_1 < ... so bin k = #{edges <= bits(power)}:
+// k odd <=> inside band (k-1)/2.
+
+namespace {
+
+struct TileTrack {
+    float best[5];     // peak power, re_pos, re_neg, im_pos, im_neg
+    uint32_t iter[5];  // loop iteration in which `best` first appeared
+};
+
+__device__ __forceinline__ int32_t imax3(int32_t a, int32_t b, int32_t c) { return max(max(a, b), c); }
+__device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
+
+template <int U>
+__device__ __forceinline__ void track_tile(TileTrack &tr, const float4 (&x)[U], const float (&pw)[2 * U], uint32_t it)
+{
+    uint32_t m_pk = 0, m_rn = 0, m_in = 0;             // unsigned max: most negative float, or largest power
+    int32_t m_rp = INT32_MIN, m_ip = INT32_MIN;        // signed max: largest positive float
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        m_pk = umax3(m_pk, __float_as_uint(pw[2 * u]), __float_as_uint(pw[2 * u + 1]));
+        m_rp = imax3(m_rp, __float_as_int(x[u].x), __float_as_int(x[u].z));
+        m_rn = umax3(m_rn, __float_as_uint(x[u].x), __float_as_uint(x[u].z));
+        m_ip = imax3(m_ip, __float_as_int(x[u].y), __float_as_int(x[u].w));
+        m_in = umax3(m_in, __float_as_uint(x[u].y), __float_as_uint(x[u].w));
+    }
+    const float c[5] = {__uint_as_float(m_pk), __int_as_float(m_rp), __uint_as_float(m_rn), __int_as_float(m_ip),
+                        __uint_as_float(m_in)};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const bool win = (k == 2 || k == 4) ? (c[k] < tr.best[k]) : (c[k] > tr.best[k]);  // strict: first tile wins
+        tr.best[k] = win ? c[k] : tr.best[k];
+        tr.iter[k] = win ? it : tr.iter[k];
+    }
+}
+
+}  // namespace
+
+template <int BLOCK, int U, bool NT, int PIPE>
+__global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restrict__ data, uint64_t ntiles,
+                                                            uint64_t base_index, int map,
+                                                            papr_partial *__restrict__ out,
+                                                            const float2 *__restrict__ tail, uint32_t tail_samples,
+                                                            const uint32_t *__restrict__ table, papr_ccdf_params P,
+                                                            unsigned long long *__restrict__ ghist,
+                                                            float *__restrict__ stash,
+                                                            unsigned long long *__restrict__ seg_counts,
+                                                            uint64_t seg_cap)
+{
+    constexpr uint64_t TILE_F4 = (uint64_t)BLOCK * U;
+    constexpr uint32_t SLICE = papr_sweep_slice_floats(U);
+    __shared__ unsigned long long seg_fill;
+    __shared__ uint32_t wave_fill[BLOCK / kWave];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t nbins = P.nkeys + 2;  // + the NaN trash bin
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *hist = tab + P.table_words;
+    float *slices = reinterpret_cast<float *>(hist + P.copies * nbins);
+
+    const uint32_t t = threadIdx.x;
+    for (uint32_t k = t; k < P.table_words; k += BLOCK)
+        tab[k] = table[k];
+    for (uint32_t k = t; k < P.copies * nbins; k += BLOCK)
+        hist[k] = 0;
+    if (t == 0)
+        seg_fill = 0;
+    if (t < BLOCK / kWave)
+        wave_fill[t] = 0;
+    __syncthreads();
+
+    const uint2 *lut_biased = reinterpret_cast<const uint2 *>(tab) - ((int32_t)P.cell_lo - 1);
+    uint32_t *my = hist + ((t / kWave) % P.copies) * nbins;
+    WaveStash ws{slices + (t / kWave) * SLICE, &wave_fill[t / kWave], stash + (uint64_t)blockIdx.x * seg_cap, &seg_fill,
+                 seg_cap};
+    // cell index straight from the bit pattern: lut_biased[cell] with cell clamped to [cell_lo - 1, cell_lo + ncells]
+    const int32_t cell_last = (int32_t)(P.cell_lo + P.ncells);
+    int32_t cell_first;  // pinned in a VGPR for the whole kernel (v_med3 takes one scalar operand)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(cell_first) : "s"((int32_t)P.cell_lo - 1));
+    const uint32_t shift = P.shift;
+
+    auto bin_of = [&](float pw) -> uint32_t {
+        const int32_t cell = __float_as_int(pw) >> shift;   // arithmetic shift: sign-bit patterns go below
+        const uint2 e = lut_biased[clamp_cell(cell, cell_first, cell_last)];
+        return e.x + (__float_as_uint(pw) >= e.y ? 1u : 0u);
+    };
+    auto count_and_stash = [&](float pw, uint32_t k) {
+        if (k)
+            atomicAdd(&my[k], 1u);
+        ws.put(pw, (k & 1u) != 0u);
+    };
+
+    double sum = 0.0;
+    TileTrack tr = {{0.f, 0.f, 0.f, 0.f, 0.f}, {0, 0, 0, 0, 0}};
+    const TileWalk w = tile_walk(blockIdx.x, gridDim.x, ntiles, map);
+    auto fold = [&](const float4(&x)[U], uint32_t it) {
+        float pw[2 * U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            pw[2 * u] = power_of(x[u].x, x[u].y);
+            pw[2 * u + 1] = power_of(x[u].z, x[u].w);
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * U; u++)
+            sum += (double)pw[u];  // same order as papr_stats_kernel
+        track_tile<U>(tr, x, pw, it);
+        uint32_t k[2 * U];
+#pragma unroll
+        for (int u = 0; u < 2 * U; u++)
+            k[u] = bin_of(pw[u]);  // all LUT reads of the tile in flight together
+#pragma unroll
+        for (int u = 0; u < 2 * U; u++)
+            count_and_stash(pw[u], k[u]);
+        ws.spill_if_above(SLICE - 2 * U * kWave);  // the next tile might not fit
+    };
+
+    const float4 *p = data + w.first * TILE_F4 + t;
+    const uint64_t step = w.stride * TILE_F4;
+    if constexpr (PIPE == 2) {
+        // true double buffering (two register sets, loop unrolled by two): no cur = nxt copies
+        float4 a[U], b[U];
+        const float4 *plast = data + (w.first + (uint64_t)(w.count ? w.count - 1 : 0) * w.stride) * TILE_F4 + t;
+        if (w.count)
+            load_tile<BLOCK, U, NT>(a, p);
+        uint32_t it = 0;
+        for (; it + 1 < w.count; it += 2) {
+            load_tile<BLOCK, U, NT>(b, p + step);
+            fold(a, it);
+            p += 2 * step;
+            load_tile<BLOCK, U, NT>(a, it + 2 < w.count ? p : plast);  // past the end: harmless re-read
+            fold(b, it + 1);
+        }
+        if (it < w.count)
+            fold(a, it);
+    } else if constexpr (PIPE == 1) {
+        float4 cur[U], nxt[U];
+        if (w.count)
+            load_tile<BLOCK, U, NT>(cur, p);
+        for (uint32_t it = 0; it < w.count; it++) {
+            p += step;
+            if (it + 1 < w.count)
+                load_tile<BLOCK, U, NT>(nxt, p);
+            fold(cur, it);
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                cur[u] = nxt[u];
+        }
+    } else {
+        for (uint32_t it = 0; it < w.count; it++, p += step) {
+            float4 x[U];
+            load_tile<BLOCK, U, NT>(x, p);
+            fold(x, it);
+        }
+    }
+    // sub-tile remainder of the shard: binned here (its pass-1 part is folded in by papr_stats_finalize)
+    if (blockIdx.x == gridDim.x - 1) {
+        for (uint32_t k0 = 0; k0 < tail_samples; k0 += BLOCK) {  // wave-uniform trip count
+            const bool valid = k0 + t < tail_samples;
+            const float2 x = valid ? tail[k0 + t] : make_float2(0.f, 0.f);
+            const float pw = power_of(x.x, x.y);
+            count_and_stash(pw, valid ? bin_of(pw) : 0u);
+            ws.spill_if_above(SLICE - kWave);
+        }
+    }
+    ws.spill_if_above(0);
+
+    // which slot of the remembered tile held each extreme first: re-read that one tile
+    StatsRegs r = {sum, tr.best[0], tr.best[1], tr.best[2], tr.best[3], tr.best[4], 0, 0, 0, 0, 0};
+    uint32_t codes[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        uint32_t slot = 0;
+        if (tr.best[k] != 0.f) {
+            const float4 *q = data + (w.first + (uint64_t)tr.iter[k] * w.stride) * TILE_F4 + t;
+            bool found = false;
+            for (int u = 0; u < U; u++) {
+                const float4 x = q[(uint64_t)u * BLOCK];
+                const float a = k == 0 ? power_of(x.x, x.y) : (k <= 2 ? x.x : x.y);
+                const float b = k == 0 ? power_of(x.z, x.w) : (k <= 2 ? x.z : x.w);
+                if (!found && a == tr.best[k]) {
+                    slot = 2 * u;
+                    found = true;
+                }
+                if (!found && b == tr.best[k]) {
+                    slot = 2 * u + 1;
+                    found = true;
+                }
+            }
+        }
+        codes[k] = tr.iter[k] * (2 * U) + slot;
+    }
+    r.c_pk = codes[0];
+    r.c_rp = codes[1];
+    r.c_rn = codes[2];
+    r.c_ip = codes[3];
+    r.c_in = codes[4];
+    stats_finish<BLOCK, U>(r, w, base_index, out);
+    hist_flush<BLOCK>(hist, nbins, P.copies, ghist);  // (starts with a barrier: every wave has spilled)
+    if (t == 0)
+        seg_counts[blockIdx.x] = seg_fill;
+}
+
+// =============================================================================
+// 4. pass 2 over the stash (float powers, not IQ)
+// =============================================================================
+// `split` workgroups per stash segment (= per workgroup of the sweep), segment lengths read from the device.
+template <bool LUT>
+__global__ __launch_bounds__(PAPR_BLOCK) void papr_ccdf_power_kernel(const float *__restrict__ stash,
+                                                                      const unsigned long long *__restrict__ seg_counts,
+                                                                      uint64_t seg_cap, uint32_t nsegs, uint32_t split,
+                                                                      const uint32_t *__restrict__ table,
+                                                                      papr_ccdf_params P,
+                                                                      unsigned long long *__restrict__ ghist)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t nbins = P.nkeys + 1;
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *hist = tab + P.table_words;
+    for (uint32_t k = threadIdx.x; k < P.table_words; k += PAPR_BLOCK)
+        tab[k] = table[k];
+    for (uint32_t k = threadIdx.x; k < P.copies * nbins; k += PAPR_BLOCK)
+        hist[k] = 0;
+    __syncthreads();
+    const uint2 *lut = reinterpret_cast<const uint2 *>(tab);
+    uint32_t *my = hist + ((threadIdx.x / kWave) % P.copies) * nbins;
+    auto count = [&](float v) {
+        const uint32_t bits = __float_as_uint(v);
+        const uint32_t k = LUT ? lut_bin(bits, lut, P) : search_bin(bits, tab, P);
+        if (k)
+            atomicAdd(&my[k], 1u);
+    };
+    for (uint32_t job = blockIdx.x; job < nsegs * split; job += gridDim.x) {
+        const uint32_t seg = job / split, part = job % split;
+        const float *pw = stash + (uint64_t)seg * seg_cap;  // seg_cap is a multiple of 4: 16-byte aligned
+        const uint64_t n = min((uint64_t)seg_counts[seg], seg_cap);
+        const uint64_t nquads = n / 4;
+        const float4 *q = reinterpret_cast<const float4 *>(pw);
+        for (uint64_t i = (uint64_t)part * PAPR_BLOCK + threadIdx.x; i < nquads; i += (uint64_t)split * PAPR_BLOCK) {
+            const float4 x = load16<true>(q + i);
+            count(x.x);
+            count(x.y);
+            count(x.z);
+            count(x.w);
+        }
+        if (part == 0 && threadIdx.x < (uint32_t)(n - 4 * nquads))
+            count(pw[4 * nquads + threadIdx.x]);
+    }
+    hist_flush<PAPR_BLOCK>(hist, nbins, P.copies, ghist);
+}
+
+// ---- launch wrappers -------------------------------------------------------------------
+
+void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t ngroups, uint32_t ratio,
+                          papr_partial *out)
+{
+    hipLaunchKernelGGL(papr_estimate_kernel, dim3(blocks), dim3(PAPR_BLOCK), 0, st, (const float4 *)data, ngroups, ratio,
+                       out);
+}
+
+// Geometry variants of the sweep (ids as in papr_kernels.hip's table).
+#define PAPR_FOR_EACH_SWEEP_VARIANT(X) \
+    X(0, 256, 8, 0) X(1, 256, 4, 1) X(2, 256, 8, 1) X(3, 512, 8, 0) X(4, 1024, 4, 0) X(6, 512, 4, 1) X(7, 256, 4, 0) \
+    X(8, 1024, 4, 1) X(9, 1024, 2, 1) X(10, 512, 2, 1) X(11, 256, 2, 1) X(12, 1024, 2, 0) X(13, 512, 4, 0)              \
+    X(14, 256, 4, 2) X(15, 512, 4, 2) X(16, 256, 8, 2) X(17, 1024, 4, 2)
+
+int papr_sweep_variant(int variant)
+{
+    switch (variant) {
+#define X(V, B, U, P) case V: return V;
+        PAPR_FOR_EACH_SWEEP_VARIANT(X)
+#undef X
+    default: return -1;
+    }
+}
+
+size_t papr_sweep_stash_lds_bytes(int variant)
+{
+    int block = 256, unroll = 4;
+    (void)papr_variant_geometry(variant, &block, &unroll);
+    return (size_t)(block / kWave) * papr_sweep_slice_floats(unroll) * sizeof(float);
+}
+
+void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
+                       uint64_t base_index, int map, papr_partial *out, const void *tail, uint32_t tail_samples,
+                       const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist, float *stash,
+                       unsigned long long *seg_counts, uint64_t seg_cap)
+{
+    switch (variant) {
+#define X(V, B, U, PP)                                                                                               \
+    case V:                                                                                                           \
+        hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP>), dim3(blocks), dim3(B), lds_bytes, st,                 \
+                           (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
+                           table, P, ghist, stash, seg_counts, seg_cap);                                              \
+        break;
+        PAPR_FOR_EACH_SWEEP_VARIANT(X)
+#undef X
+    }
+}
+
+void papr_launch_ccdf_power(hipStream_t st, int blocks, bool lut, size_t lds_bytes, const float *stash,
+                            const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs, uint32_t split,
+                            const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist)
+{
+    if (lut)
+        hipLaunchKernelGGL((papr_ccdf_power_kernel<true>), dim3(blocks), dim3(PAPR_BLOCK), lds_bytes, st, stash,
+                           seg_counts, seg_cap, nsegs, split, table, P, ghist);
+    else
+        hipLaunchKernelGGL((papr_ccdf_power_kernel<false>), dim3(blocks), dim3(PAPR_BLOCK), lds_bytes, st, stash,
+                           seg_counts, seg_cap, nsegs, split, table, P, ghist);
+}
+
+void papr_sweep_prepare_device(void)
+{
+    const int want = papr_ccdf_max_dynamic_lds();
+#define X(V, B, U, PP)                                                                                               \
+    (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<B, U, true, PP>,                                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    PAPR_FOR_EACH_SWEEP_VARIANT(X)
+#undef X
+    (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+}

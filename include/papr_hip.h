@@ -16,6 +16,8 @@
  *            level table
  *   :142-153 / :174-185 rewind + O(N*L)       papr_hip_ccdf
  *            threshold counting
+ *   (the second read of the file itself)      papr_hip_estimate + papr_hip_stats_sweep:
+ *                                             both passes in ONE read of the shard
  *   :132-135,154-161 / :186-190 printing      stays in the caller (host/papr_main.c)
  *
  * Conventions: plain C types only (no HIP/torch types); every int-returning
@@ -41,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PAPR_HIP_ABI_VERSION 1
+#define PAPR_HIP_ABI_VERSION 2
 
 enum {
     PAPR_OK = 0,
@@ -84,6 +86,8 @@ typedef struct papr_hip_timing {
     double stats_ms;  uint64_t stats_launches;  uint64_t stats_bytes;
     double ccdf_ms;   uint64_t ccdf_launches;   uint64_t ccdf_bytes;
     double exact_ms;  uint64_t exact_launches;  uint64_t exact_bytes; /* exact-sum kernels (classify + segments + groups) */
+    double sweep_ms;  uint64_t sweep_launches;  uint64_t sweep_bytes; /* one-sweep kernel (pass 1 + banded pass 2) */
+    double aux_ms;    uint64_t aux_launches;    uint64_t aux_bytes;   /* mean-estimate and stash-recount kernels */
 } papr_hip_timing;
 
 /* Where the wall time of the last papr_hip_load_file went (seconds). */
@@ -105,7 +109,8 @@ typedef struct papr_hip_ingest_timing {
  * 10 GiB sweeps in DESIGN.md section 6); variant and map fields therefore hold
  * id + 1.  Also settable with the PAPR_HIP_TUNE environment variable, e.g.
  * "sblocks=512,svariant=1,smap=0,cblocks=512,cvariant=13,cmap=0,nt=1" (= the defaults on a 256-CU device)
- * ("blocks=" / "variant=" / "map=" set both passes). */
+ * ("blocks=" / "variant=" / "map=" set both passes; "wblocks=" / "wvariant=" / "wmap=" / "band=" / "ratio="
+ * the one-sweep kernel). */
 typedef struct papr_hip_tuning {
     int stats_blocks;   /* pass 1: workgroups per launch */
     int stats_variant;  /* pass 1: kernel geometry variant id + 1 (block x unroll x prefetch form, papr_kernels.hip) */
@@ -116,6 +121,12 @@ typedef struct papr_hip_tuning {
     int nontemporal;    /* 0/1 = default (nontemporal loads), 2 = plain loads */
     int hist_copies;    /* LDS histogram copies per workgroup (1..waves) */
     int flags;          /* bit 0: force the binary-search form of pass 2 (tests) */
+    int sweep_blocks;   /* one-sweep kernel: workgroups per launch */
+    int sweep_variant;  /* one-sweep kernel: geometry variant id + 1 */
+    int sweep_map;      /* one-sweep kernel: tile mapping id + 1 */
+    int sweep_band_log2;/* half-width of a threshold band in float bit patterns, log2 (default 14; 8..20) */
+    int estimate_ratio; /* papr_hip_estimate reads one 2048-sample tile out of this many (default 64) */
+    int reserved;
 } papr_hip_tuning;
 
 typedef struct papr_hip_ctx papr_hip_ctx;
@@ -202,6 +213,53 @@ int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, c
 int papr_hip_ccdf_exact(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above, double before,
                         uint64_t n_total, const void **program, size_t *bytes);
 int papr_exact_chain(const void *const *programs, const size_t *bytes, int nprograms, double *sum_out);
+
+/* ---- one-sweep mode: pass 1 and pass 2 in ONE read of the shard ----------------------
+ * papr.c reads the file twice because its thresholds are mean * 10^(dB/10) (papr.c:131-141)
+ * and the mean needs a full pass.  Here both passes are HBM-bound, so the second read is half
+ * of the job; speculation removes it without changing one count (papr_sweep.hip):
+ *
+ *   papr_hip_estimate(ctx, &est)      est.sum / est.n over a pseudo-random 1/64 sample of the
+ *                                     shard's 16 KiB tiles (1/64 of a pass)
+ *   (merge the shards' estimates with papr_stats_merge; guess table = papr_guess_levels(&est_total, ...))
+ *   papr_hip_stats_sweep(ctx, guess, L, &st)
+ *                                     st is exactly what papr_hip_stats returns; in the same read
+ *                                     every power is binned against BANDS of +-2^14 bit patterns
+ *                                     (+-0.1..0.2 %) around the guessed thresholds, and the few
+ *                                     per cent that fall inside a band are stashed in HBM
+ *   (true table from the merged stats, as always)
+ *   papr_hip_ccdf(ctx, levels, L, counts)
+ *                                     if every true threshold lies inside one of the bands,
+ *                                     only the stash is re-examined (exact counts, ~1-6 % of a
+ *                                     pass); otherwise — bad guess, stash overflow, unusual table —
+ *                                     the shard is read again as before.  Same counts either way.
+ *
+ * papr_hip_stats_sweep falls back to plain papr_hip_stats by itself (exact-sum mode, shards that are
+ * not resident, guess tables without a band form); papr_hip_get_sweep_info tells what happened. */
+enum {
+    PAPR_SWEEP_OK = 0,
+    PAPR_SWEEP_NONE = 1,        /* no sweep was made for the current shard */
+    PAPR_SWEEP_MODE = 2,        /* exact-sum mode or a shard that is not resident: plain pass 1 */
+    PAPR_SWEEP_NO_BANDS = 3,    /* the guess table has no band form (NaN/zero/denormal/crowded thresholds) */
+    PAPR_SWEEP_OUT_OF_BAND = 4, /* a true threshold fell outside every band of the guess */
+    PAPR_SWEEP_STASH_FULL = 5   /* more in-band samples than the stash holds (1/8 of the shard) */
+};
+typedef struct papr_hip_sweep_info {
+    uint64_t stash_samples;  /* in-band samples the last sweep produced */
+    uint64_t stash_capacity;
+    uint64_t estimate_samples; /* samples the last papr_hip_estimate read */
+    int swept;               /* last papr_hip_stats_sweep: 1 = banded + stashed, 0 = plain pass 1 */
+    int resolved;            /* last papr_hip_ccdf: 1 = answered from the sweep, 0 = read the shard again */
+    int reason;              /* PAPR_SWEEP_*: why not */
+    int band_log2;
+} papr_hip_sweep_info;
+int papr_hip_estimate(papr_hip_ctx *ctx, papr_stats *est);
+/* Host helper: the table papr_levels would build for the (merged) estimate's mean, carried on to max_db
+ * dB above the mean whatever the peak turns out to be (the real table's length depends on the true
+ * peak; bands above it cost nothing).  Returns the number of levels written (<= cap). */
+int papr_guess_levels(const papr_stats *est_total, int graph, double max_db, float *levels, int cap);
+int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, papr_stats *out);
+int papr_hip_get_sweep_info(const papr_hip_ctx *ctx, papr_hip_sweep_info *out);
 
 /* ---- pass 2 (papr.c:143-153 / 175-185) ---------------------------------- */
 /* counts_above[j] = number of shard samples whose power is > levels[j]

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(pkg):
     L = pkg.lib()
     for name in declared_functions():
         assert hasattr(L, name), f"libpaprhip.so does not export {name}"
-    assert L.papr_hip_abi_version() == 1
+    assert L.papr_hip_abi_version() == 2
     # struct layouts the binding assumes
     assert C.sizeof(pkg.Stats) == 96
     assert C.sizeof(pkg.SynthSpec) == 16 + 16 * 8
@@ -168,3 +168,16 @@ def test_product_fails_loudly_without_gpu(pkg):
     assert e.value.code == -1
     p = subprocess.run([pkg.CLI_PATH, golden_path("k8")], capture_output=True)
     assert p.returncode == 254 and p.stdout == b"" and b"no usable GPU" in p.stderr
+
+
+def test_guess_levels_matches_levels_where_they_overlap(pkg):
+    """host helper: the guess table is papr_levels' table for the same mean, carried on past the peak"""
+    st = pkg.Stats()
+    st.sum, st.n, st.peak = 123456.789, 100000, 50.0
+    for graph in (False, True):
+        mean, papr, table = pkg.levels(st, graph)
+        guess = pkg.guess_levels(st, graph)
+        assert guess.size > table.size and np.array_equal(guess[:table.size], table)
+        assert np.all(np.diff(guess) > 0)
+    st.n = 0
+    assert pkg.guess_levels(st, False).size == 0

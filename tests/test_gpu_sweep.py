@@ -1,0 +1,280 @@
+"""One-sweep mode (papr_sweep.hip): pass 1 and pass 2 in ONE read of the shard.
+
+The sweep speculates on the level table (mean estimated from a 1/64 sample, thresholds widened into
+bands, in-band powers stashed) — so the tests pin down that speculation can never change a result:
+every count equals the oracle's `power > level` count, whether the sweep resolved the table from its
+stash or fell back to reading the shard again, and its pass-1 record equals papr_hip_stats'."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import TRACKERS, check_stats
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(pkg):
+    g = pkg.PaprHip(0)
+    yield g
+    g.set_tuning()
+    g.close()
+
+
+def one_sweep(pkg, g, graph, guess=None):
+    """estimate -> guess table -> sweep -> true table -> counts; returns (stats, table, counts, info)"""
+    if guess is None:
+        guess = pkg.guess_levels(g.estimate(), graph)
+    st = g.stats_sweep(guess)
+    swept = g.sweep_info().swept
+    mean, papr, table = pkg.levels(st, graph)
+    counts = g.ccdf(table)
+    info = g.sweep_info()
+    assert info.swept == swept
+    return st, table, counts, info
+
+
+def same_record(a, b):
+    assert a.n == b.n and a.flags == b.flags
+    for k in TRACKERS:
+        assert getattr(a, k) == getattr(b, k), k
+        assert getattr(a, k + "_idx") == getattr(b, k + "_idx"), k
+    if a.sum != a.sum:
+        assert b.sum != b.sum and np.signbit(a.sum) == np.signbit(b.sum)
+        assert a.nan_first_idx == b.nan_first_idx and a.nan_first_neg == b.nan_first_neg
+    elif np.isinf(b.sum):
+        assert a.sum == b.sum
+    else:
+        assert abs(a.sum - b.sum) <= 1e-12 * abs(b.sum)
+
+
+SIZES = [1, 2, 63, 64, 255, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 12289, 100003, 1048576 + 5, 5 * 1048576 + 4099]
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["default", "graph"])
+@pytest.mark.parametrize("n", SIZES)
+def test_sweep_equals_oracle_sizes(pkg, orc, gpu, n, graph):
+    rng = np.random.default_rng(1000 + n)
+    iq = rng.standard_normal(2 * n).astype(np.float32)
+    gpu.upload(iq)
+    st, table, counts, info = one_sweep(pkg, gpu, graph)
+    check_stats(st, orc.run_mem(iq, graph))
+    assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
+    same_record(st, gpu.stats())
+    if n >= 2048 and table.size:   # enough samples for an estimate: the sweep must have run ...
+        assert info.swept == 1, info.as_dict()
+        assert 0 < info.stash_samples <= n
+    if n >= 100003:                # ... and with a decent estimate the speculation must have paid off
+        assert info.resolved == 1 and info.stash_samples <= n // 4, info.as_dict()
+
+
+@pytest.mark.parametrize("tune", [dict(sweep_variant=v, sweep_blocks=b, sweep_map=m)
+                                  for v, b, m in [(0, 0, 0), (1, 96, 1), (2, 1000, 2), (3, 1, 0), (4, 7, 0), (6, 0, 2),
+                                                  (7, 300, 1), (8, 0, 0), (9, 64, 2), (10, 0, 1), (11, 2048, 0),
+                                                  (12, 0, 0), (13, 0, 0), (13, 1536, 2), (14, 0, 0), (15, 8, 2),
+                                                  (16, 0, 1), (17, 0, 0)]] +
+                         [dict(sweep_band_log2=b) for b in (13, 15, 16, 17)] +
+                         [dict(estimate_ratio=r) for r in (1, 7, 1000)] + [dict(hist_copies=1), dict(hist_copies=8)],
+                         ids=str)
+def test_sweep_geometries_agree(pkg, orc, gpu, tune):
+    n = 3 * 1048576 + 4099
+    gpu.generate(pkg.SynthSpec.spike(n, seed=78), 0, n)
+    iq = gpu.download(0, n)
+    ref = orc.run_mem(iq, True)
+    try:
+        gpu.set_tuning(**tune)
+        for graph in (False, True):
+            st, table, counts, info = one_sweep(pkg, gpu, graph)
+            check_stats(st, ref)
+            assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
+            if tune.get("sweep_band_log2", 14) >= 14:   # (narrower bands need a finer LUT than fits: plain pass 1)
+                assert info.swept == 1 and info.resolved == 1, info.as_dict()
+    finally:
+        gpu.set_tuning()
+
+
+def test_sweep_first_index_wins(pkg, orc, gpu):
+    """equal extremes planted in different lanes, waves, workgroups and loop iterations, plus the
+    sub-tile remainder: the sweep's per-tile trackers must still report the FIRST occurrence"""
+    n = 6 * 1048576 + 777
+    rng = np.random.default_rng(5)
+    iq = (rng.standard_normal(2 * n) * 0.25).astype(np.float32)
+    spots = [n - 3, 5 * 1048576 + 11, 4096 * 300 + 2049, 4096 * 300 + 1, 777777, 4097, 64, 63]
+    for s in spots:
+        iq[2 * s] = 9.5
+        iq[2 * s + 1] = -9.5
+    gpu.upload(iq)
+    for tune in (dict(), dict(sweep_variant=1, sweep_blocks=3), dict(sweep_variant=8, sweep_map=2), dict(sweep_variant=2)):
+        gpu.set_tuning(**tune)
+        st, table, counts, info = one_sweep(pkg, gpu, False)
+        gpu.set_tuning()
+        assert st.peak_idx == 63 and st.re_pos_idx == 63 and st.im_neg_idx == 63
+        check_stats(st, orc.run_mem(iq, False))
+        assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
+
+
+def test_sweep_bad_guess_falls_back(pkg, orc, gpu):
+    """a guess that is off by 3 % puts the true thresholds outside the bands: the counts are still the oracle's"""
+    n = 2 * 1048576 + 33
+    rng = np.random.default_rng(11)
+    iq = rng.standard_normal(2 * n).astype(np.float32)
+    gpu.upload(iq)
+    est = gpu.estimate()
+    for factor, want_resolved in ((1.03, 0), (0.5, 0), (1.0002, 1)):
+        bad = pkg.Stats.from_bytes(est.to_bytes())
+        bad.sum = est.sum * factor
+        for graph in (False, True):
+            st, table, counts, info = one_sweep(pkg, gpu, graph, pkg.guess_levels(bad, graph))
+            assert info.swept == 1 and info.resolved == want_resolved, info.as_dict()
+            if not want_resolved:
+                assert info.as_dict()["reason"] == "out of band"
+            assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
+
+
+def test_sweep_guess_tables_without_band_form(pkg, orc, gpu):
+    n = 300007
+    rng = np.random.default_rng(12)
+    iq = rng.standard_normal(2 * n).astype(np.float32)
+    gpu.upload(iq)
+    ref = orc.run_mem(iq, False)
+    for guess in (np.zeros(0, np.float32), np.array([np.nan], np.float32), np.array([0.0, 1.0], np.float32),
+                  np.array([1e-42, 2.0], np.float32), np.array([2.0, 2.0001], np.float32),
+                  np.array([np.inf], np.float32), np.array([-1.0, 3e38], np.float32)):
+        st = gpu.stats_sweep(guess)
+        info = gpu.sweep_info()
+        assert info.swept == 0 and info.as_dict()["reason"] == "no band form", (guess, info.as_dict())
+        check_stats(st, ref)
+        mean, papr, table = pkg.levels(st, False)
+        assert np.array_equal(gpu.ccdf(table).astype(np.int64), orc.count_mem(iq, table))
+    # duplicated and unsorted guesses are fine
+    st = gpu.stats_sweep(np.array([8.0, 2.0, 2.0, 4.0], np.float32))
+    assert gpu.sweep_info().swept == 1
+    tab = np.array([4.0001, 1.9999, 8.0, 2.0], np.float32)
+    assert np.array_equal(gpu.ccdf(tab).astype(np.int64), orc.count_mem(iq, tab))
+    assert gpu.sweep_info().resolved == 1
+    # a table that reaches outside the bands is answered by reading the shard
+    tab = np.array([2.0, 3.0], np.float32)
+    assert np.array_equal(gpu.ccdf(tab).astype(np.int64), orc.count_mem(iq, tab))
+    assert gpu.sweep_info().resolved == 0
+
+
+def test_sweep_constant_envelope_overflows_the_stash(pkg, orc, gpu):
+    """every sample has the mean power: all of them land in the 0 dB band, far more than the stash holds"""
+    n = 1048576 + 9
+    ph = np.random.default_rng(13).uniform(0, 2 * np.pi, n)
+    iq = np.empty(2 * n, np.float32)
+    iq[0::2] = np.cos(ph) * 3
+    iq[1::2] = np.sin(ph) * 3
+    gpu.upload(iq)
+    for graph in (False, True):
+        st, table, counts, info = one_sweep(pkg, gpu, graph)
+        assert info.swept == 1 and info.resolved == 0 and info.as_dict()["reason"] == "stash full", info.as_dict()
+        assert info.stash_samples == n > info.stash_capacity
+        check_stats(st, orc.run_mem(iq, graph))
+        assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
+
+
+def test_sweep_nan_and_inf_inputs(pkg, orc, gpu):
+    n = 400000
+    rng = np.random.default_rng(14)
+    base = rng.standard_normal(2 * n).astype(np.float32)
+    for kind in ("nan_i", "nan_q_neg", "inf", "both"):
+        iq = base.copy()
+        if kind in ("nan_i", "both"):
+            iq[2 * 123457] = np.nan
+        if kind == "nan_q_neg":
+            iq[2 * 99 + 1] = -np.nan
+        if kind in ("inf", "both"):
+            iq[2 * 200001 + 1] = np.inf
+        gpu.upload(iq)
+        guess = pkg.guess_levels(gpu.estimate(), False)
+        st = gpu.stats_sweep(guess if guess.size else np.array([2.0], np.float32))
+        check_stats(st, orc.run_mem(iq, False))
+        same_record(st, gpu.stats())
+        tab = np.array([0.5, 2.0, 8.0, np.inf, 1e30], np.float32)
+        assert np.array_equal(gpu.ccdf(tab).astype(np.int64), orc.count_mem(iq, tab))
+
+
+def test_sweep_state_is_tied_to_the_shard(pkg, orc, gpu):
+    rng = np.random.default_rng(15)
+    a = rng.standard_normal(2 * 500000).astype(np.float32)
+    b = (rng.standard_normal(2 * 500000) * 1.0005).astype(np.float32)
+    gpu.upload(a)
+    guess = pkg.guess_levels(gpu.estimate(), False)
+    st = gpu.stats_sweep(guess)
+    mean, papr, table = pkg.levels(st, False)
+    assert np.array_equal(gpu.ccdf(table).astype(np.int64), orc.count_mem(a, table)) and gpu.sweep_info().resolved == 1
+    # a second table against the same sweep
+    assert np.array_equal(gpu.ccdf(table[:3]).astype(np.int64), orc.count_mem(a, table[:3]))
+    assert gpu.sweep_info().resolved == 1
+    # new samples: the old sweep must not be used
+    gpu.upload(b)
+    assert np.array_equal(gpu.ccdf(table).astype(np.int64), orc.count_mem(b, table)) and gpu.sweep_info().resolved == 0
+    # plain stats() after a sweep drops it as well
+    gpu.stats_sweep(guess)
+    gpu.stats()
+    assert np.array_equal(gpu.ccdf(table).astype(np.int64), orc.count_mem(b, table)) and gpu.sweep_info().resolved == 0
+    # exact-sum mode: the sweep call is just pass 1
+    gpu.set_exact(True)
+    try:
+        st = gpu.stats_sweep(guess)
+        assert gpu.sweep_info().swept == 0 and gpu.sweep_info().as_dict()["reason"].startswith("exact mode")
+        check_stats(st, orc.run_mem(b, False))
+    finally:
+        gpu.set_exact(False)
+
+
+def test_sweep_shards_merge_like_the_two_pass_path(pkg, orc, gpu):
+    """three shards of one stream, estimates merged before guessing, stats merged before the true table"""
+    n = 3 * 700001
+    rng = np.random.default_rng(16)
+    iq = rng.standard_normal(2 * n).astype(np.float32)
+    cuts = [0, 700001, 1500000, n]
+    ests = []
+    for s0, s1 in zip(cuts, cuts[1:]):
+        gpu.upload(iq[2 * s0:2 * s1], base_index=s0)
+        ests.append(gpu.estimate())
+    for graph in (False, True):
+        guess = pkg.guess_levels(pkg.stats_merge(ests), graph)
+        ctxs = []
+        try:
+            parts = []
+            for s0, s1 in zip(cuts, cuts[1:]):
+                g = pkg.PaprHip(0)
+                ctxs.append(g)
+                g.upload(iq[2 * s0:2 * s1], base_index=s0)
+                parts.append(g.stats_sweep(guess))
+            tot = pkg.stats_merge(parts)
+            check_stats(tot, orc.run_mem(iq, graph))
+            mean, papr, table = pkg.levels(tot, graph)
+            counts = sum(g.ccdf(table).astype(np.int64) for g in ctxs)
+            assert all(g.sweep_info().resolved == 1 for g in ctxs)
+            assert np.array_equal(counts, orc.count_mem(iq, table))
+        finally:
+            for g in ctxs:
+                g.close()
+
+
+def test_sweep_randomised(pkg, orc, gpu):
+    """random sizes, scales, offsets and heavy tails; the sweep may or may not resolve — counts must not care"""
+    rng = np.random.default_rng(2024)
+    resolved = 0
+    for case in range(60):
+        n = int(rng.integers(1, 600000))
+        kind = case % 4
+        if kind == 0:
+            iq = rng.standard_normal(2 * n) * 10.0 ** rng.uniform(-3, 3)
+        elif kind == 1:
+            iq = rng.standard_t(3, 2 * n) * 0.1
+        elif kind == 2:
+            iq = rng.standard_normal(2 * n) * np.repeat(rng.uniform(0.0, 2.0, n // 4096 + 1), 8192)[:2 * n]   # bursty
+        else:
+            iq = rng.uniform(-1, 1, 2 * n) + rng.uniform(-0.5, 0.5)
+        iq = iq.astype(np.float32)
+        base = int(rng.integers(0, 1 << 40))
+        gpu.upload(iq, base_index=base)
+        graph = bool(case & 4)
+        st, table, counts, info = one_sweep(pkg, gpu, graph)
+        check_stats(st, orc.run_mem(iq, graph), base=base)
+        assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table)), (case, info.as_dict())
+        resolved += info.resolved
+    assert resolved >= 30
