@@ -1,10 +1,17 @@
 #!/usr/bin/env python3
 """bench.py — the papr hot path on N MI355X GPUs of one node.
 
-One "step" = one complete papr run over the HBM-resident shard(s): pass 1
-(power, double sum, first-index peak + I/Q extrema), the stats exchange, the
-host scalar stage (mean, PAPR, level table), pass 2 (CCDF counting) and the
-count exchange.  Workload at N=1 is BASELINE.json configs[1]: 10 GiB of
+One "step" = one complete papr run over the HBM-resident shard(s).  By default
+it takes ONE read of the samples (papr_sweep.hip): a 1/64-sample mean estimate
+(+ exchange), the guessed level table, the sweep kernel — pass 1 (power, double
+sum, first-index peak + I/Q extrema) plus pass-2 counting against bands around
+the guessed thresholds — the stats exchange, the host scalar stage (mean, PAPR,
+the true level table), the recount of the few in-band samples and the count
+exchange.  `--two-pass` runs the classic pass 1 / pass 2 kernels instead (two
+reads; also what a step falls back to if the speculation misses), `--exact`
+the two-read path that reproduces the reference's sequential double sum.
+Every step recomputes everything from the samples; nothing carries over
+between steps.  Workload at N=1 is BASELINE.json configs[1]: 10 GiB of
 synthetic gr_complex IQ, default mode ("peak+mean+1 dB histogram"); `--mode
 graph` gives configs[2] (0.1 dB CCDF, ~301 bins).  With N ranks every rank owns
 its own 10 GiB shard of an N x 10 GiB stream (weak scaling; N=8 is configs[3]).
@@ -89,6 +96,8 @@ def main():
     ap.add_argument("--exact", action="store_true",
                     help="also reproduce the reference's sequential double sum bit for bit every step "
                          "(rounding functions computed in the pass-2 sweep + a short host chain); off by default")
+    ap.add_argument("--two-pass", action="store_true",
+                    help="read the shard twice (papr_stats_kernel + papr_ccdf_kernel) instead of the one-sweep path")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend; gloo (+ ranks sharing GPUs round-robin) exists so the N>1 "
                          "code path can be exercised on a box with fewer GPUs than ranks")
@@ -140,9 +149,14 @@ def main():
 
     if args.exact:
         gpu.set_exact(True)
+    one_sweep = not (args.two_pass or args.exact)
 
     def step():
-        local = gpu.stats()                                  # pass 1 on this shard
+        if one_sweep:
+            est = pkg.stats_merge(xch.allgather_stats(gpu.estimate()))   # 1/64-sample mean of the whole stream
+            local = gpu.stats_sweep(pkg.guess_levels(est, graph))        # pass 1 + banded pass 2, one read
+        else:
+            local = gpu.stats()                              # pass 1 on this shard
         parts = xch.allgather_stats(local)                   # exchange 1 (RCCL all-gather)
         tot = pkg.stats_merge(parts)                         #   + ordered merge, identical on every rank
         mean, papr, table = pkg.levels(tot, graph)           # host scalars
@@ -157,7 +171,11 @@ def main():
                 local_counts = gpu.ccdf(table)
                 result["reruns"] = result.get("reruns", 0) + 1
         else:
-            local_counts = gpu.ccdf(table)                   # pass 2
+            local_counts = gpu.ccdf(table)                   # pass 2 (one-sweep: recount of the stash only)
+            if one_sweep:
+                info = gpu.sweep_info()
+                result["resolved"] = result.get("resolved", 0) + int(info.resolved)
+                result["sweep_info"] = info.as_dict()
         counts = xch.allreduce_counts(local_counts)          # exchange 2 (RCCL all-reduce)
         result.update(total=tot, mean=mean, papr=papr, table=table, counts=counts)
 
@@ -169,6 +187,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    result.pop("resolved", None)
     gpu.set_timing(True)
     fence()
     t0 = time.perf_counter()
@@ -196,14 +215,21 @@ def main():
         k_exact = tm.exact_ms / max(tm.exact_launches, 1)
         b_exact = tm.exact_bytes / max(tm.exact_launches, 1)
         gbs_exact = b_exact / (k_exact * 1e-3) / 1e9 if k_exact else 0.0
+        k_sweep = tm.sweep_ms / max(tm.sweep_launches, 1)
+        b_sweep = tm.sweep_bytes / max(tm.sweep_launches, 1)
+        gbs_sweep = b_sweep / (k_sweep * 1e-3) / 1e9 if k_sweep else 0.0
+        aux_ms = tm.aux_ms / args.steps       # estimate + stash recount kernels, per step
         dom, dom_gbs, dom_ms = max([("papr_stats_kernel", gbs_stats, k_stats), ("papr_ccdf_kernel", gbs_ccdf, k_ccdf),
-                                    ("papr_exact_seg_kernel<CCDF>", gbs_exact, k_exact)], key=lambda e: e[2])
+                                    ("papr_exact_seg_kernel<CCDF>", gbs_exact, k_exact),
+                                    ("papr_sweep_kernel", gbs_sweep, k_sweep)], key=lambda e: e[2])
+        kernel_ms_per_step = (tm.stats_ms + tm.ccdf_ms + tm.exact_ms + tm.sweep_ms + tm.aux_ms) / args.steps
+        bytes_per_step = (tm.stats_bytes + tm.ccdf_bytes + tm.exact_bytes + tm.sweep_bytes + tm.aux_bytes) / args.steps
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                ent = tj.get(dom, {}).get(args.mode if dom == "papr_ccdf_kernel" else "any")
+                ent = tj.get(dom, {}).get(args.mode if dom in ("papr_ccdf_kernel", "papr_sweep_kernel") else "any")
                 if ent and abs(ent.get("gib_per_gpu", 0) - args.gib) < 1e-9:
                     traffic, traffic_src = ent["hbm_bytes_per_launch"], tj.get("source")
             except Exception:
@@ -218,22 +244,35 @@ def main():
                                    f"{world}xMI355X",
                        "mode": args.mode, "samples_per_gpu": per_gpu, "samples_total": total,
                        "levels": int(result["table"].size), "papr_db": round(float(result["papr"]), 6),
+                       "reads_of_the_shard_per_step": 1 if one_sweep and result.get("resolved", 0) == args.steps else 2,
+                       "one_sweep": ({"steps_resolved_from_the_sweep": int(result.get("resolved", 0)),
+                                      **{k: result.get("sweep_info", {}).get(k) for k in
+                                         ("stash_samples", "stash_capacity", "estimate_samples", "band_log2", "reason")}}
+                                     if one_sweep else None),
                        "exact_sequential_sum": bool(args.exact), "sum_hex": float(result["total"].sum).hex(),
                        "exact_pass2_reruns": int(result.get("reruns", 0)),
                        "counts_crc32": zlib.crc32(np.ascontiguousarray(result["counts"], dtype=np.uint64).tobytes()),
                        "sharding": f"sample axis, {world} contiguous shard(s)",
                        "exchange": ("RCCL" if args.backend == "nccl" else "gloo") +
+                                   (" all-gather(estimate) +" if one_sweep else "") +
                                    " all-gather(stats) + all-reduce(counts)" if use_dist else "none"},
             "roofline": {"bound": "hbm", "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": per_gpu * 8,
-                         "traffic_source": traffic_src},
+                         "traffic_source": traffic_src,
+                         # the reference's algorithm reads every sample twice (16 B/sample); the rate
+                         # at which THOSE bytes are retired by the whole step, for comparison with two-pass numbers
+                         "two_read_equivalent_GBs": 2 * per_gpu * 8 / (kernel_ms_per_step * 1e-3) / 1e9
+                         if kernel_ms_per_step else None},
             "kernels": {"papr_stats_kernel": {"avg_ms": k_stats, "GB/s": gbs_stats, "launches": int(tm.stats_launches)},
                         "papr_ccdf_kernel": {"avg_ms": k_ccdf, "GB/s": gbs_ccdf, "launches": int(tm.ccdf_launches)},
-                        "both_passes_frac_of_peak": (b_stats + b_ccdf + b_exact) /
-                        ((k_stats + k_ccdf + k_exact) * 1e-3) / 1e9 / HBM_PEAK_GBS if (k_stats + k_ccdf + k_exact) else 0.0,
+                        "papr_sweep_kernel": {"avg_ms": k_sweep, "GB/s": gbs_sweep, "launches": int(tm.sweep_launches)},
+                        "estimate_and_recount_kernels": {"ms_per_step": aux_ms, "launches": int(tm.aux_launches),
+                                                         "bytes_per_step": tm.aux_bytes / args.steps},
+                        "all_kernels_frac_of_peak": bytes_per_step / (kernel_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+                        if kernel_ms_per_step else 0.0,
                         "papr_exact_kernels": {"avg_ms": k_exact, "GB/s": gbs_exact, "launches": int(tm.exact_launches)},
-                        "host_and_exchange_ms_per_step": ms_per_step - k_stats - k_ccdf - k_exact},
+                        "host_and_exchange_ms_per_step": ms_per_step - kernel_ms_per_step},
             "device": gpu.name,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -48,7 +48,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("extra", [[], ["--mode", "graph", "--exact"]])
+@pytest.mark.parametrize("extra", [[], ["--mode", "graph"], ["--two-pass"], ["--mode", "graph", "--exact"]], ids=str)
 def test_torchrun_single_rank_uses_rccl(extra):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--gib", "0.5",
@@ -60,6 +60,13 @@ def test_torchrun_single_rank_uses_rccl(extra):
     d = check(lines[0], 3, 1)
     assert d["config"]["exchange"].startswith("RCCL")
     assert d["config"]["exact_sequential_sum"] == ("--exact" in extra)
+    if "--exact" in extra or "--two-pass" in extra:
+        assert d["config"]["one_sweep"] is None and d["config"]["reads_of_the_shard_per_step"] == 2
+        assert d["roofline"]["kernel"] != "papr_sweep_kernel"
+    else:   # the default: one read of the shard per step, every step answered from the sweep
+        assert d["config"]["one_sweep"]["steps_resolved_from_the_sweep"] == 3
+        assert d["config"]["reads_of_the_shard_per_step"] == 1 and d["roofline"]["kernel"] == "papr_sweep_kernel"
+        assert 0 < d["config"]["one_sweep"]["stash_samples"] < d["config"]["samples_per_gpu"] // 8
 
 
 def _run_bench(nproc, gib, extra):
@@ -89,3 +96,18 @@ def test_sharded_run_equals_single_shard_run(mode):
         for key in ("sum_hex", "papr_db", "levels", "counts_crc32"):
             assert many["config"][key] == one["config"][key], (ranks, key)
         assert many["config"]["exchange"].startswith("gloo")
+
+
+@pytest.mark.parametrize("mode", ["default", "graph"])
+def test_one_sweep_equals_two_pass_at_every_rank_count(mode):
+    """bench.py's default one-read step (estimate exchange + sweep + stash recount) against --two-pass on the
+    same stream, 1, 2 and 4 ranks: same table, same counts."""
+    ref = _run_bench(1, 0.5, ["--mode", mode, "--two-pass"])
+    assert ref["config"]["one_sweep"] is None
+    for ranks in (1, 2, 4):
+        got = _run_bench(ranks, 0.5 / ranks, ["--mode", mode])
+        assert got["config"]["one_sweep"]["steps_resolved_from_the_sweep"] == 2, got["config"]["one_sweep"]
+        for key in ("papr_db", "levels", "counts_crc32", "samples_total"):
+            assert got["config"][key] == ref["config"][key], (ranks, key)
+        assert abs(float.fromhex(got["config"]["sum_hex"]) - float.fromhex(ref["config"]["sum_hex"])) <= \
+            1e-12 * float.fromhex(ref["config"]["sum_hex"])
