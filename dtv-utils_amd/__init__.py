@@ -36,6 +36,7 @@ ABI_SYMBOLS = (
     "papr_stats_init", "papr_stats_merge", "papr_levels", "papr_hip_ccdf",
     "papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
     "papr_hip_estimate", "papr_hip_stats_sweep", "papr_hip_get_sweep_info", "papr_guess_levels",
+    "papr_hip_estimate_file", "papr_hip_load_file_sweep",
 )
 
 
@@ -185,9 +186,12 @@ def lib() -> C.CDLL:
     L.papr_guess_levels.argtypes = [C.POINTER(Stats), i32, C.c_double, vp, i32]
     L.papr_guess_levels.restype = i32
     L.papr_hip_stats_sweep.argtypes = [vp, vp, i32, C.POINTER(Stats)]
+    L.papr_hip_estimate_file.argtypes = [vp, C.c_char_p, u64, u64, C.POINTER(Stats)]
+    L.papr_hip_load_file_sweep.argtypes = [vp, C.c_char_p, u64, u64, vp, i32]
     L.papr_hip_get_sweep_info.argtypes = [vp, C.POINTER(SweepInfo)]
     for name in ("papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
-                 "papr_hip_estimate", "papr_hip_stats_sweep", "papr_hip_get_sweep_info"):
+                 "papr_hip_estimate", "papr_hip_stats_sweep", "papr_hip_get_sweep_info", "papr_hip_estimate_file",
+                 "papr_hip_load_file_sweep"):
         getattr(L, name).restype = i32
     for name in ("papr_hip_open", "papr_hip_device_name", "papr_hip_set_tuning", "papr_hip_set_timing",
                  "papr_hip_get_timing", "papr_file_samples", "papr_hip_load_file", "papr_hip_get_ingest_timing", "papr_hip_upload",
@@ -326,6 +330,19 @@ class PaprHip:
     def load_file(self, path: str, first_sample: int = 0, nsamples: int = NO_INDEX):
         self._chk(self._L.papr_hip_load_file(self._ctx, os.fsencode(path), first_sample, nsamples),
                   "papr_hip_load_file")
+
+    def estimate_file(self, path: str, first_sample: int = 0, nsamples: int = NO_INDEX) -> Stats:
+        """papr_hip_estimate for a file range that is not loaded (yet)."""
+        s = Stats()
+        self._chk(self._L.papr_hip_estimate_file(self._ctx, os.fsencode(path), first_sample, nsamples, C.byref(s)),
+                  "papr_hip_estimate_file")
+        return s
+
+    def load_file_sweep(self, path: str, guess_table: np.ndarray, first_sample: int = 0, nsamples: int = NO_INDEX):
+        """load_file with pass 1 AND the banded pass 2 riding along with the ingest (one read of the file)."""
+        lv = np.ascontiguousarray(guess_table, dtype=np.float32)
+        self._chk(self._L.papr_hip_load_file_sweep(self._ctx, os.fsencode(path), first_sample, nsamples,
+                                                   lv.ctypes.data_as(C.c_void_p), lv.size), "papr_hip_load_file_sweep")
 
     def ingest_timing(self) -> IngestTiming:
         t = IngestTiming()

@@ -133,6 +133,10 @@ struct TimedLaunch {
 
 }  // namespace
 
+namespace {
+struct SweepRun;
+}
+
 struct papr_hip_ctx {
     int device = -1;
     hipStream_t stream = nullptr;     // compute
@@ -210,6 +214,7 @@ struct papr_hip_ctx {
     uint32_t sweep_nsegs = 0, sweep_nbins = 0;
     bool sweep_overflow = false;
     papr_hip_sweep_info sweep_info{};
+    const SweepRun *ingest_run = nullptr;        // set while papr_hip_load_file_sweep streams the file in
 
     papr_hip_ingest_timing ingest{};
     papr_hip_tuning tune{};
@@ -855,6 +860,202 @@ int launch_fused_chunk(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *chu
     return PAPR_OK;
 }
 
+// ---- one-sweep mode: set-up, launch and bookkeeping shared by resident shards and file ingest -------------------
+struct SweepRun {
+    CcdfPlan bands;               // band edges lo_0 < hi_0 < lo_1 < ... in LUT form
+    std::vector<uint32_t> gkeys;  // guessed keys (band centres), unique, ascending
+    uint32_t half = 0;            // half-width of a band in bit patterns
+    int variant = 0;
+    int blocks = 0;               // workgroups of the largest launch (= stash segments)
+    uint64_t tile = 0;            // samples per workgroup iteration
+    size_t stash_lds = 0;
+    uint32_t nbins = 0;           // 2 * bands + 1 + the NaN trash bin
+    uint64_t seg_cap = 0;         // floats per stash segment
+};
+
+// Plan the bands for `guess_levels`, size and clear the buffers, upload the LUT.  *reason != PAPR_SWEEP_OK: the guess
+// has no band form (or memory is short) and the caller runs the plain pass instead.  `n_shard` sizes the stash,
+// `n_launch` (a whole resident shard, or one ingest chunk) the grid.
+int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uint64_t n_shard, uint64_t n_launch,
+                  SweepRun *run, int *reason)
+{
+    papr_hip_sweep_info &info = ctx->sweep_info;
+    info.band_log2 = ctx->tune.sweep_band_log2 > 0 ? ctx->tune.sweep_band_log2 : kSweepBandLog2;
+    *reason = PAPR_SWEEP_NO_BANDS;
+    if (nlevels <= 0 || nlevels > PAPR_HIP_MAX_LEVELS)
+        return PAPR_OK;
+    // guessed keys -> band edges lo_0 < hi_0 < lo_1 < hi_1 < ...
+    std::vector<uint32_t> &gkeys = run->gkeys;
+    gkeys.clear();
+    for (int j = 0; j < nlevels; j++) {
+        const uint32_t key = level_key(guess_levels[j]);
+        if (key != kNever)
+            gkeys.push_back(key);
+    }
+    std::sort(gkeys.begin(), gkeys.end());
+    gkeys.erase(std::unique(gkeys.begin(), gkeys.end()), gkeys.end());
+    if (gkeys.empty())
+        return PAPR_OK;
+    // widest band (<= the configured width) whose edges stay apart and still have a LUT form
+    run->variant = variant_of(ctx, SWEEP);
+    int vblock = 256, vunroll = 4;
+    (void)papr_variant_geometry(run->variant, &vblock, &vunroll);
+    run->tile = 2ull * (uint64_t)vblock * (uint64_t)vunroll;
+    run->stash_lds = papr_sweep_stash_lds_bytes(run->variant);
+    CcdfPlan &bands = run->bands;
+    run->half = 0;
+    for (int log2w = info.band_log2; log2w >= std::max(info.band_log2 - 3, 8) && !run->half; log2w--) {
+        const uint32_t h = 1u << log2w;
+        bands.keys.clear();
+        bool ok = true;
+        for (size_t j = 0; j < gkeys.size() && ok; j++) {
+            const uint32_t g = gkeys[j];
+            ok = g >= 0x00800000u + h && g < 0x7F800000u - h && !(j && g - h <= gkeys[j - 1] + h);  // bands must not touch
+            bands.keys.push_back(g - h);
+            bands.keys.push_back(g + h);
+        }
+        if (!ok)
+            continue;
+        char keep[sizeof(ctx->err)];
+        memcpy(keep, ctx->err, sizeof(keep));
+        const bool fits = finish_plan(ctx, &bands, vblock, run->stash_lds) == PAPR_OK && bands.lut;
+        memcpy(ctx->err, keep, sizeof(keep));  // not an error of this call: a narrower band or the plain pass follows
+        if (fits) {
+            run->half = h;
+            info.band_log2 = log2w;
+        }
+    }
+    if (!run->half)
+        return PAPR_OK;
+    // the sweep kernel's LUT has a sentinel cell at either end and its histogram one more (NaN) bin
+    bands.P.table_words = 2 * (bands.P.ncells + 2);
+    run->nbins = bands.P.nkeys + 2;
+    bands.lds_bytes = (size_t)bands.P.table_words * 4 + (size_t)bands.P.copies * run->nbins * 4;
+    if (bands.lds_bytes + run->stash_lds > (size_t)papr_ccdf_max_dynamic_lds())
+        return PAPR_OK;
+
+    run->blocks = pick_blocks(ctx, SWEEP, n_launch / run->tile);
+    // buffers: band histogram with the stash-segment lengths right behind it; stash = 1/4 of the shard's samples
+    // (as floats: 1/8 of its bytes), one equal segment per workgroup
+    constexpr size_t kMaxSweepBlocks = 65536;
+    if (!ctx->d_sweep_hist) {
+        const size_t bytes = (2 * (size_t)PAPR_HIP_MAX_LEVELS + 2 + kMaxSweepBlocks) * sizeof(unsigned long long);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_sweep_hist, bytes));
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_sweep_hist, bytes, hipHostMallocDefault));
+    }
+    run->seg_cap = std::max<uint64_t>((n_shard / 4 / (uint64_t)run->blocks + 3) & ~3ull, 4096);
+    const uint64_t want_stash = run->seg_cap * (uint64_t)run->blocks;
+    if (ctx->stash_cap < want_stash) {
+        if (ctx->d_stash) HIPCHK(ctx, hipFree(ctx->d_stash));
+        ctx->d_stash = nullptr;
+        ctx->stash_cap = 0;
+        if (hipMalloc((void **)&ctx->d_stash, want_stash * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->d_stash = nullptr;
+            *reason = PAPR_SWEEP_STASH_FULL;
+            return PAPR_OK;
+        }
+        ctx->stash_cap = want_stash;
+    }
+    int rc = ensure_table(ctx, bands.P.table_words);
+    if (rc)
+        return rc;
+    {
+        // lut[0] = below everything, lut[1 + c] = {edges below cell c, the edge inside it or never},
+        // lut[ncells + 1] = above every edge; a NaN pattern compares >= 0x7F800001 and lands in the trash bin
+        const papr_ccdf_params &P = bands.P;
+        uint32_t *tab = ctx->h_table;
+        tab[0] = 0;
+        tab[1] = kNever;
+        uint32_t k = 0;
+        for (uint32_t c = 0; c < P.ncells; c++) {
+            uint32_t in_cell = kNever;
+            const uint32_t below = k;
+            if (k < P.nkeys && (bands.keys[k] >> P.shift) == P.cell_lo + c)
+                in_cell = bands.keys[k++];
+            tab[2 * (c + 1)] = below;
+            tab[2 * (c + 1) + 1] = in_cell;
+        }
+        tab[2 * (P.ncells + 1)] = P.nkeys;
+        tab[2 * (P.ncells + 1) + 1] = 0x7F800001u;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_table, ctx->h_table, (size_t)P.table_words * 4, hipMemcpyHostToDevice,
+                                   ctx->stream));
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_sweep_hist, 0, ((size_t)run->nbins + (size_t)run->blocks) * sizeof(unsigned long long),
+                               ctx->stream));
+    *reason = PAPR_SWEEP_OK;
+    return PAPR_OK;
+}
+
+// One launch of the sweep kernel over [data, data + n): full tiles by the grid, the sub-tile remainder binned by the
+// last workgroup (its pass-1 half belongs to papr_stats_finalize).  Histogram and stash segments accumulate over launches.
+int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint64_t n, uint64_t base_index, size_t slot,
+                 int *nrecords)
+{
+    const uint64_t ntiles = n / run.tile;
+    const uint32_t tail = (uint32_t)(n - ntiles * run.tile);
+    const int blocks = (int)std::min<uint64_t>((uint64_t)run.blocks, std::max<uint64_t>(ntiles, 1));
+    const int map = effective_map(ctx, SWEEP, blocks);
+    int rc = ensure_partials(ctx, slot + (size_t)blocks + 1);
+    if (rc)
+        return rc;
+    time_begin(ctx, 3, n * 8);
+    papr_launch_sweep(ctx->stream, run.variant, blocks, run.bands.lds_bytes + run.stash_lds, data, ntiles, base_index, map,
+                      ctx->d_partials + slot, data + 2 * (n - tail), tail, ctx->d_table, run.bands.P, ctx->d_sweep_hist,
+                      ctx->d_stash, ctx->d_sweep_hist + run.nbins, run.seg_cap);
+    time_end(ctx);
+    HIPCHK(ctx, hipGetLastError());
+    *nrecords = blocks;
+    return PAPR_OK;
+}
+
+// queue the copy of the band histogram + segment lengths to the host (valid after the next stream synchronisation)
+int sweep_fetch(papr_hip_ctx *ctx, const SweepRun &run)
+{
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_sweep_hist, ctx->d_sweep_hist,
+                               ((size_t)run.nbins + (size_t)run.blocks) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    return PAPR_OK;
+}
+
+// what the sweep decided: samples in even bins above each band; odd bins are exactly the stash
+int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
+{
+    papr_hip_sweep_info &info = ctx->sweep_info;
+    const unsigned long long *H = ctx->h_sweep_hist;
+    uint64_t stash_count = 0, in_bands = 0;
+    bool overflow = false;
+    for (int b = 0; b < run.blocks; b++) {
+        stash_count += H[run.nbins + b];
+        overflow = overflow || H[run.nbins + b] > run.seg_cap;
+    }
+    for (uint32_t b = 1; b < run.nbins; b += 2)
+        in_bands += H[b];
+    if (in_bands != stash_count)
+        return fail(ctx, PAPR_E_INTERNAL, "one-sweep invariant broken: %llu samples binned inside bands, %llu stashed",
+                    (unsigned long long)in_bands, (unsigned long long)stash_count);
+    const size_t m = run.gkeys.size();
+    ctx->sweep_even_above.assign(m, 0);
+    uint64_t above = 0;
+    for (size_t j = m; j-- > 0;) {
+        above += H[2 * j + 2];
+        ctx->sweep_even_above[j] = above;
+    }
+    ctx->sweep_keys = run.gkeys;
+    ctx->sweep_half = run.half;
+    ctx->sweep_stash_count = stash_count;
+    ctx->sweep_seg_cap = run.seg_cap;
+    ctx->sweep_nsegs = (uint32_t)run.blocks;
+    ctx->sweep_nbins = run.nbins;
+    ctx->sweep_overflow = overflow;
+    ctx->sweep_valid = true;
+    info.swept = 1;
+    info.reason = PAPR_SWEEP_OK;
+    info.stash_samples = stash_count;
+    info.stash_capacity = run.seg_cap * (uint64_t)run.blocks;  // what this sweep could use (one segment per workgroup)
+    return PAPR_OK;
+}
+
 enum StreamPass { PASS_LOAD_STATS, PASS_STREAM_STATS, PASS_STREAM_CCDF, PASS_STREAM_CCDF_EXACT, PASS_STREAM_NAN };
 
 // Walk file samples [first, first + n) in pinned-buffer-sized chunks: parallel
@@ -879,7 +1080,7 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
     const uint64_t nchunks = (ctx->n + chunk_samples - 1) / chunk_samples;
     size_t records = 0;
     if (pass == PASS_LOAD_STATS || pass == PASS_STREAM_STATS) {
-        const int per_chunk = blocks_of(ctx, PASS1);
+        const int per_chunk = ctx->ingest_run ? ctx->ingest_run->blocks : blocks_of(ctx, PASS1);
         rc = ensure_partials(ctx, (size_t)nchunks * per_chunk + 1);
         if (rc) {
             close_file_src(&fs);
@@ -929,10 +1130,14 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
         case PASS_LOAD_STATS:
         case PASS_STREAM_STATS: {
             int nrec = 0;
-            prc = launch_stats_range(ctx, dst, cnt, ctx->base + s0, records, &nrec);
+            if (ctx->ingest_run)  // one-sweep ingest: pass 1 + banded pass 2 on the chunk
+                prc = sweep_launch(ctx, *ctx->ingest_run, dst, cnt, ctx->base + s0, records, &nrec);
+            else
+                prc = launch_stats_range(ctx, dst, cnt, ctx->base + s0, records, &nrec);
             records += (size_t)nrec;
             if (prc == PAPR_OK && last && pass == PASS_STREAM_STATS) {
-                const uint64_t full = cnt / tile_samples(ctx, PASS1) * tile_samples(ctx, PASS1);
+                const uint64_t tile = ctx->ingest_run ? ctx->ingest_run->tile : tile_samples(ctx, PASS1);
+                const uint64_t full = cnt / tile * tile;
                 if (cnt > full)
                     HIPCHK(ctx, hipMemcpyAsync(ctx->d_tail, dst + 2 * full, (cnt - full) * 8, hipMemcpyDeviceToDevice,
                                                ctx->stream));
@@ -1300,13 +1505,25 @@ int papr_hip_download(papr_hip_ctx *ctx, float *iq, uint64_t first, uint64_t nsa
     return PAPR_OK;
 }
 
-int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples)
+}  // extern "C"
+
+namespace {
+
+// papr_hip_load_file, optionally as a one-sweep ingest (guess != nullptr): the per-chunk kernel then also bins
+// against the guessed bands and stashes, so that papr_hip_ccdf needs no second read of the shard — or of the file
+int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples, const float *guess,
+                   int nguess)
 {
     if (!ctx || !path)
         return PAPR_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const double t_begin = now_s();
     memset(&ctx->ingest, 0, sizeof(ctx->ingest));
+    papr_hip_sweep_info &info = ctx->sweep_info;
+    info.swept = info.resolved = 0;
+    info.stash_samples = 0;
+    info.reason = PAPR_SWEEP_NONE;
+    ctx->ingest_run = nullptr;
     FileSrc fs;
     int rc = open_file_src(ctx, path, &fs);
     if (rc)
@@ -1337,19 +1554,44 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
     ctx->sweep_valid = false;
     ctx->shard_flags = (fs.odd && first_sample + nsamples == fs.nsamples && nsamples > 0) ? PAPR_FLAG_ODD_TAIL : 0;
 
+    SweepRun run;
+    if (guess) {
+        int reason = PAPR_SWEEP_MODE;
+        if (!ctx->exact && nsamples) {
+            rc = ensure_ingest(ctx, !fits);  // fixes the chunk size
+            if (rc == PAPR_OK)
+                rc = sweep_prepare(ctx, guess, nguess, nsamples, ctx->stage_bytes / 8, &run, &reason);
+            if (rc) {
+                ctx->loaded = false;
+                return rc;
+            }
+        }
+        info.reason = reason;
+        if (reason == PAPR_SWEEP_OK)
+            ctx->ingest_run = &run;
+    }
     ctx->ingest.setup_s = now_s() - t_begin;
     ctx->ingest.bytes = nsamples * 8;
     ctx->ingest.resident = fits ? 1 : 0;
-    // pass 1 rides along with the ingest
+    // pass 1 (or the whole sweep) rides along with the ingest
     size_t records = 0;
     rc = stream_file(ctx, fits ? PASS_LOAD_STATS : PASS_STREAM_STATS, nullptr, &records);
+    const bool swept = ctx->ingest_run != nullptr;
+    ctx->ingest_run = nullptr;
     if (rc) {
         ctx->loaded = false;
         return rc;
     }
     const uint64_t chunk_samples = ctx->stage_bytes / 8;
     const uint64_t last_cnt = nsamples ? nsamples - (nsamples - 1) / chunk_samples * chunk_samples : 0;
-    const uint32_t tail = (uint32_t)(last_cnt % tile_samples(ctx, PASS1));
+    const uint32_t tail = (uint32_t)(last_cnt % (swept ? run.tile : tile_samples(ctx, PASS1)));
+    if (swept) {
+        rc = sweep_fetch(ctx, run);
+        if (rc) {
+            ctx->loaded = false;
+            return rc;
+        }
+    }
     const float *tail_ptr = fits ? ctx->d_iq + 2 * (nsamples - tail) : ctx->d_tail;
     papr_stats st;
     const double t_drain = now_s();
@@ -1359,6 +1601,19 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
         return rc;
     }
     ctx->ingest.drain_s = now_s() - t_drain;
+    if (swept && std::isnan(st.sum)) {
+        // NaN in the data: the sweep's integer-max trackers do not apply — take the file in again the plain way
+        rc = load_file_impl(ctx, path, first_sample, nsamples, nullptr, 0);
+        info.reason = PAPR_SWEEP_NO_BANDS;
+        return rc;
+    }
+    if (swept) {
+        rc = sweep_collect(ctx, run);
+        if (rc) {
+            ctx->loaded = false;
+            return rc;
+        }
+    }
     if (std::isnan(st.sum)) {
         unsigned long long key = ~0ull;
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_nan_key, &key, 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1381,6 +1636,129 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
     return PAPR_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples)
+{
+    return load_file_impl(ctx, path, first_sample, nsamples, nullptr, 0);
+}
+
+int papr_hip_load_file_sweep(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples,
+                             const float *guess_levels, int nlevels)
+{
+    if (nlevels < 0 || (nlevels && !guess_levels))
+        return PAPR_E_ARG;
+    static const float none = 0.0f;
+    return load_file_impl(ctx, path, first_sample, nsamples, guess_levels ? guess_levels : &none, nlevels);
+}
+
+// Mean estimate of a file range without loading it: the same 1-in-`ratio` tile sample as papr_hip_estimate, read
+// by the ingest's reader threads into the staging buffers and summed on the device.
+int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples, papr_stats *est)
+{
+    if (!ctx || !path || !est)
+        return PAPR_E_ARG;
+    papr_stats_init(est);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    FileSrc fs;
+    int rc = open_file_src(ctx, path, &fs);
+    if (rc)
+        return rc;
+    if (first_sample > fs.nsamples) {
+        close_file_src(&fs);
+        return fail(ctx, PAPR_E_ARG, "first_sample %llu is past the end of %s (%llu samples)",
+                    (unsigned long long)first_sample, path, (unsigned long long)fs.nsamples);
+    }
+    if (nsamples == UINT64_MAX || first_sample + nsamples > fs.nsamples)
+        nsamples = fs.nsamples - first_sample;
+    ctx->sweep_info.estimate_samples = 0;
+    const uint64_t ntiles = nsamples / PAPR_ESTIMATE_TILE_SAMPLES;
+    if (ntiles == 0) {
+        close_file_src(&fs);
+        return PAPR_OK;  // n = 0: no estimate
+    }
+    rc = ensure_ingest(ctx, true);
+    if (rc) {
+        close_file_src(&fs);
+        return rc;
+    }
+    uint64_t ratio = ctx->tune.estimate_ratio > 0 ? (uint64_t)ctx->tune.estimate_ratio : (uint64_t)kEstimateRatio;
+    ratio = std::max<uint64_t>(1, std::min<uint64_t>(ratio, ntiles / kEstimateMinTiles));
+    const uint64_t ngroups = ntiles / ratio;
+    constexpr uint64_t kTileBytes = (uint64_t)PAPR_ESTIMATE_TILE_SAMPLES * 8;
+    const uint64_t per_batch = ctx->stage_bytes / kTileBytes;
+    const uint64_t nbatches = (ngroups + per_batch - 1) / per_batch;
+    const int blocks_max = (int)std::min<uint64_t>(per_batch, (uint64_t)ctx->num_cus * 8);
+    rc = ensure_partials(ctx, (size_t)nbatches * blocks_max + 1);
+    std::vector<ReadBatch> batches(nbatches);
+    const FileSrc *fsp = &fs;
+    auto submit = [&](uint64_t bi) {
+        const uint64_t g0 = bi * per_batch, g1 = std::min(ngroups, g0 + per_batch);
+        unsigned char *hbuf = (unsigned char *)ctx->h_stage[bi % kNumBuf];
+        const int nthr = ctx->reader_threads;
+        const uint64_t per = (g1 - g0 + nthr - 1) / nthr;
+        for (int t = 0; t < nthr; t++) {
+            const uint64_t a = std::min(g1, g0 + (uint64_t)t * per), e = std::min(g1, a + per);
+            if (e > a)
+                ctx->pool->submit(&batches[bi], [fsp, first_sample, ratio, g0, a, e, hbuf] {
+                    for (uint64_t g = a; g < e; g++) {
+                        // one tile of group g, picked by a hash of g (no aliasing with periodic structure in the capture)
+                        const uint64_t tile = g * ratio + ((g + 1) * 0x9E3779B97F4A7C15ull >> 40) % ratio;
+                        const int r = read_samples(*fsp, first_sample + tile * PAPR_ESTIMATE_TILE_SAMPLES,
+                                                   PAPR_ESTIMATE_TILE_SAMPLES, hbuf + (g - g0) * kTileBytes);
+                        if (r)
+                            return r;
+                    }
+                    return (int)PAPR_OK;
+                });
+        }
+    };
+    size_t records = 0;
+    uint64_t submitted = 0;
+    for (; rc == PAPR_OK && submitted < std::min<uint64_t>(2, nbatches); submitted++)
+        submit(submitted);
+    for (uint64_t bi = 0; bi < nbatches && rc == PAPR_OK; bi++) {
+        if (ctx->pool->wait(&batches[bi])) {
+            rc = fail(ctx, PAPR_E_IO, "read error in %s", path);
+            break;
+        }
+        const int b = (int)(bi % kNumBuf);
+        const uint64_t cnt = std::min(ngroups, (bi + 1) * per_batch) - bi * per_batch;
+        if (hipMemcpyAsync(ctx->d_stage[b], ctx->h_stage[b], cnt * kTileBytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            rc = fail(ctx, PAPR_E_HIP, "hipMemcpyAsync of the estimate sample failed");
+            break;
+        }
+        const int blocks = (int)std::min<uint64_t>(cnt, (uint64_t)blocks_max);
+        time_begin(ctx, 4, cnt * kTileBytes);
+        papr_launch_estimate(ctx->stream, blocks, ctx->d_stage[b], cnt, 1, ctx->d_partials + records);
+        time_end(ctx);
+        records += (size_t)blocks;
+        if (hipEventRecord(ctx->ev_copy[b], ctx->stream) != hipSuccess)
+            rc = fail(ctx, PAPR_E_HIP, "hipEventRecord failed");
+        if (rc == PAPR_OK && submitted < nbatches) {
+            // the buffer about to be refilled was consumed kNumBuf batches ago
+            if (submitted >= (uint64_t)kNumBuf && hipEventSynchronize(ctx->ev_copy[submitted % kNumBuf]) != hipSuccess)
+                rc = fail(ctx, PAPR_E_HIP, "hipEventSynchronize failed while recycling a staging buffer");
+            if (rc == PAPR_OK)
+                submit(submitted++);
+        }
+    }
+    for (uint64_t k = 0; k < submitted; k++)
+        (void)ctx->pool->wait(&batches[k]);
+    close_file_src(&fs);
+    if (rc)
+        return rc;
+    papr_launch_stats_finalize(ctx->stream, nullptr, 0, 0, ctx->d_partials, (uint32_t)records, ctx->h_result_dev);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    est->sum = ctx->h_result->sum;
+    est->n = ngroups * PAPR_ESTIMATE_TILE_SAMPLES;
+    ctx->sweep_info.estimate_samples = est->n;
+    return PAPR_OK;
+}
+
 int papr_hip_get_ingest_timing(const papr_hip_ctx *ctx, papr_hip_ingest_timing *out)
 {
     if (!ctx || !out)
@@ -1397,11 +1775,11 @@ int papr_hip_stats(papr_hip_ctx *ctx, papr_stats *out)
         return PAPR_E_ARG;
     if (!ctx->loaded)
         return fail(ctx, PAPR_E_STATE, "papr_hip_stats called before a shard was loaded");
-    ctx->sweep_valid = false;  // a sweep only serves the papr_hip_ccdf calls that directly follow it
-    if (ctx->have_file_stats) {  // computed while the file streamed in
+    if (ctx->have_file_stats) {  // computed while the file streamed in (a sweep made during that load stays valid)
         *out = ctx->file_stats;
         return PAPR_OK;
     }
+    ctx->sweep_valid = false;  // a sweep only serves the papr_hip_ccdf calls that directly follow it
     if (!ctx->resident)
         return fail(ctx, PAPR_E_STATE, "the shard is not resident and has no pass-1 result: reload it");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1473,7 +1851,6 @@ int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nleve
     papr_hip_sweep_info &info = ctx->sweep_info;
     info.swept = info.resolved = 0;
     info.stash_samples = 0;
-    info.band_log2 = ctx->tune.sweep_band_log2 > 0 ? ctx->tune.sweep_band_log2 : kSweepBandLog2;
     ctx->sweep_valid = false;
     auto plain = [&](int reason) {
         info.reason = reason;
@@ -1481,162 +1858,28 @@ int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nleve
     };
     if (ctx->have_file_stats || !ctx->resident || ctx->exact)
         return plain(PAPR_SWEEP_MODE);
-    if (nlevels == 0 || nlevels > PAPR_HIP_MAX_LEVELS)
-        return plain(PAPR_SWEEP_NO_BANDS);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-
-    // guessed keys -> band edges lo_0 < hi_0 < lo_1 < hi_1 < ...
-    std::vector<uint32_t> all(nlevels), gkeys;
-    for (int j = 0; j < nlevels; j++) {
-        all[j] = level_key(guess_levels[j]);
-        if (all[j] != kNever)
-            gkeys.push_back(all[j]);
-    }
-    std::sort(gkeys.begin(), gkeys.end());
-    gkeys.erase(std::unique(gkeys.begin(), gkeys.end()), gkeys.end());
-    if (gkeys.empty())
-        return plain(PAPR_SWEEP_NO_BANDS);
-    // widest band (<= the configured width) whose edges stay apart and still have a LUT form
-    const int variant = variant_of(ctx, SWEEP);
-    int vblock = 256, vunroll = 4;
-    (void)papr_variant_geometry(variant, &vblock, &vunroll);
-    const size_t stash_lds = papr_sweep_stash_lds_bytes(variant);
-    CcdfPlan bands;
-    uint32_t half = 0;
-    for (int log2w = info.band_log2; log2w >= std::max(info.band_log2 - 3, 8) && !half; log2w--) {
-        const uint32_t h = 1u << log2w;
-        bands.keys.clear();
-        bool ok = true;
-        for (size_t j = 0; j < gkeys.size() && ok; j++) {
-            const uint32_t g = gkeys[j];
-            ok = g >= 0x00800000u + h && g < 0x7F800000u - h && !(j && g - h <= gkeys[j - 1] + h);  // bands must not touch
-            bands.keys.push_back(g - h);
-            bands.keys.push_back(g + h);
-        }
-        if (!ok)
-            continue;
-        char keep[sizeof(ctx->err)];
-        memcpy(keep, ctx->err, sizeof(keep));
-        const bool fits = finish_plan(ctx, &bands, vblock, stash_lds) == PAPR_OK && bands.lut;
-        memcpy(ctx->err, keep, sizeof(keep));  // not an error of this call: a narrower band or the plain pass follows
-        if (fits) {
-            half = h;
-            info.band_log2 = log2w;
-        }
-    }
-    if (!half)
-        return plain(PAPR_SWEEP_NO_BANDS);
-    // the sweep kernel's LUT has a sentinel cell at either end and its histogram one more (NaN) bin
-    bands.P.table_words = 2 * (bands.P.ncells + 2);
-    const uint32_t nbins = bands.P.nkeys + 2;
-    bands.lds_bytes = (size_t)bands.P.table_words * 4 + (size_t)bands.P.copies * nbins * 4;
-    if (bands.lds_bytes + stash_lds > (size_t)papr_ccdf_max_dynamic_lds())
-        return plain(PAPR_SWEEP_NO_BANDS);
-
-    const uint64_t tile = tile_samples(ctx, SWEEP);
-    const uint64_t ntiles = ctx->n / tile;
-    const uint32_t tail = (uint32_t)(ctx->n - ntiles * tile);
-    const int blocks = pick_blocks(ctx, SWEEP, ntiles);
-    const int map = effective_map(ctx, SWEEP, blocks);
-
-    // buffers: band histogram with the stash-segment lengths right behind it; stash = 1/4 of the shard's samples
-    // (as floats: 1/8 of its bytes), one equal segment per workgroup
-    constexpr size_t kMaxSweepBlocks = 65536;
-    if (!ctx->d_sweep_hist) {
-        const size_t bytes = (2 * (size_t)PAPR_HIP_MAX_LEVELS + 2 + kMaxSweepBlocks) * sizeof(unsigned long long);
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_sweep_hist, bytes));
-        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_sweep_hist, bytes, hipHostMallocDefault));
-    }
-    const uint64_t seg_cap = std::max<uint64_t>((ctx->n / 4 / (uint64_t)blocks + 3) & ~3ull, 4096);
-    const uint64_t want_stash = seg_cap * (uint64_t)blocks;
-    if (ctx->stash_cap < want_stash) {
-        if (ctx->d_stash) HIPCHK(ctx, hipFree(ctx->d_stash));
-        ctx->d_stash = nullptr;
-        ctx->stash_cap = 0;
-        if (hipMalloc((void **)&ctx->d_stash, want_stash * sizeof(float)) != hipSuccess) {
-            (void)hipGetLastError();
-            ctx->d_stash = nullptr;
-            return plain(PAPR_SWEEP_STASH_FULL);
-        }
-        ctx->stash_cap = want_stash;
-    }
-    int rc = ensure_table(ctx, bands.P.table_words);
+    SweepRun run;
+    int reason = PAPR_SWEEP_OK;
+    int rc = sweep_prepare(ctx, guess_levels, nlevels, ctx->n, ctx->n, &run, &reason);
     if (rc)
         return rc;
-    {
-        // lut[0] = below everything, lut[1 + c] = {edges below cell c, the edge inside it or never},
-        // lut[ncells + 1] = above every edge; a NaN pattern compares >= 0x7F800001 and lands in the trash bin
-        const papr_ccdf_params &P = bands.P;
-        uint32_t *tab = ctx->h_table;
-        tab[0] = 0;
-        tab[1] = kNever;
-        uint32_t k = 0;
-        for (uint32_t c = 0; c < P.ncells; c++) {
-            uint32_t in_cell = kNever;
-            const uint32_t below = k;
-            if (k < P.nkeys && (bands.keys[k] >> P.shift) == P.cell_lo + c)
-                in_cell = bands.keys[k++];
-            tab[2 * (c + 1)] = below;
-            tab[2 * (c + 1) + 1] = in_cell;
-        }
-        tab[2 * (P.ncells + 1)] = P.nkeys;
-        tab[2 * (P.ncells + 1) + 1] = 0x7F800001u;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_table, ctx->h_table, (size_t)P.table_words * 4, hipMemcpyHostToDevice,
-                                   ctx->stream));
-    }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_sweep_hist, 0, (size_t)nbins * sizeof(unsigned long long), ctx->stream));
-    rc = ensure_partials(ctx, (size_t)blocks + 1);
+    if (reason != PAPR_SWEEP_OK)
+        return plain(reason);
+    int nrec = 0;
+    rc = sweep_launch(ctx, run, ctx->d_iq, ctx->n, ctx->base, 0, &nrec);
     if (rc)
         return rc;
-    const float *tail_ptr = ctx->d_iq + 2 * (ctx->n - tail);
-    time_begin(ctx, 3, ctx->n * 8);
-    papr_launch_sweep(ctx->stream, variant, blocks, bands.lds_bytes + stash_lds, ctx->d_iq, ntiles, ctx->base, map,
-                      ctx->d_partials, tail_ptr, tail, ctx->d_table, bands.P, ctx->d_sweep_hist, ctx->d_stash,
-                      ctx->d_sweep_hist + nbins, seg_cap);
-    time_end(ctx);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_sweep_hist, ctx->d_sweep_hist,
-                               ((size_t)nbins + (size_t)blocks) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                               ctx->stream));
-    rc = finish_stats(ctx, (size_t)blocks, tail_ptr, tail, ctx->base + ctx->n - tail, out);  // synchronises
+    rc = sweep_fetch(ctx, run);
+    if (rc)
+        return rc;
+    const uint32_t tail = (uint32_t)(ctx->n % run.tile);
+    rc = finish_stats(ctx, (size_t)nrec, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->base + ctx->n - tail, out);  // synchronises
     if (rc)
         return rc;
     if (std::isnan(out->sum))  // NaN in the data: the sweep's integer-max trackers do not apply (papr_sweep.hip)
         return plain(PAPR_SWEEP_NO_BANDS);
-
-    // what the sweep decided: samples in even bins above each band; odd bins are exactly the stash
-    const unsigned long long *H = ctx->h_sweep_hist;
-    uint64_t stash_count = 0, in_bands = 0;
-    bool overflow = false;
-    for (int b = 0; b < blocks; b++) {
-        stash_count += H[nbins + b];
-        overflow = overflow || H[nbins + b] > seg_cap;
-    }
-    for (uint32_t b = 1; b < nbins; b += 2)
-        in_bands += H[b];
-    if (in_bands != stash_count)
-        return fail(ctx, PAPR_E_INTERNAL, "one-sweep invariant broken: %llu samples binned inside bands, %llu stashed",
-                    (unsigned long long)in_bands, (unsigned long long)stash_count);
-    const size_t m = gkeys.size();
-    ctx->sweep_even_above.assign(m, 0);
-    uint64_t run = 0;
-    for (size_t j = m; j-- > 0;) {
-        run += H[2 * j + 2];
-        ctx->sweep_even_above[j] = run;
-    }
-    ctx->sweep_keys = gkeys;
-    ctx->sweep_half = half;
-    ctx->sweep_stash_count = stash_count;
-    ctx->sweep_seg_cap = seg_cap;
-    ctx->sweep_nsegs = (uint32_t)blocks;
-    ctx->sweep_nbins = nbins;
-    ctx->sweep_overflow = overflow;
-    ctx->sweep_valid = true;
-    info.swept = 1;
-    info.reason = PAPR_SWEEP_OK;
-    info.stash_samples = stash_count;
-    info.stash_capacity = seg_cap * (uint64_t)blocks;  // what this sweep could use (one segment per workgroup)
-    return PAPR_OK;
+    return sweep_collect(ctx, run);
 }
 
 int papr_hip_get_sweep_info(const papr_hip_ctx *ctx, papr_hip_sweep_info *out)

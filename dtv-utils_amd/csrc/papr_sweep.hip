@@ -219,7 +219,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
     for (uint32_t k = t; k < P.copies * nbins; k += BLOCK)
         hist[k] = 0;
     if (t == 0)
-        seg_fill = 0;
+        seg_fill = seg_counts[blockIdx.x];  // segments keep filling over the launches of a chunked ingest
     if (t < BLOCK / kWave)
         wave_fill[t] = 0;
     __syncthreads();
@@ -319,37 +319,90 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
     }
     ws.spill_if_above(0);
 
-    // which slot of the remembered tile held each extreme first: re-read that one tile
-    StatsRegs r = {sum, tr.best[0], tr.best[1], tr.best[2], tr.best[3], tr.best[4], 0, 0, 0, 0, 0};
-    uint32_t codes[5];
+    // Workgroup record.  The lanes only know in WHICH tile their extreme first appeared; finding the slot means
+    // re-reading that tile, which is uncoalesced (every lane another tile: 64-128 B fetched per 16 B used), so it is
+    // done by the workgroup's winners only: reduce the VALUES first, then just the lanes that hold the winning value
+    // (normally one) look up their slot, then the smallest index among them wins — the reference's first occurrence.
+    constexpr int kWaves = BLOCK / kWave;
+    __shared__ double sh_sum[kWaves];
+    __shared__ float sh_val[kWaves][5];
+    __shared__ unsigned long long sh_idx[kWaves][5];
+    const int lane = t & (kWave - 1), wave = t / kWave;
+    float wv[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-        uint32_t slot = 0;
-        if (tr.best[k] != 0.f) {
-            const float4 *q = data + (w.first + (uint64_t)tr.iter[k] * w.stride) * TILE_F4 + t;
-            bool found = false;
-            for (int u = 0; u < U; u++) {
+        float v = tr.best[k];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            const float o = __shfl_down(v, off, kWave);
+            v = (k == 2 || k == 4) ? (o < v ? o : v) : (o > v ? o : v);
+        }
+        wv[k] = v;
+    }
+    const double wsum = wave_reduce_sum(sum);
+    if (lane == 0) {
+        sh_sum[wave] = wsum;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            sh_val[wave][k] = wv[k];
+    }
+    __syncthreads();
+    float win[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        float v = sh_val[0][k];
+        for (int wq = 1; wq < kWaves; wq++) {
+            const float o = sh_val[wq][k];
+            v = (k == 2 || k == 4) ? (o < v ? o : v) : (o > v ? o : v);
+        }
+        win[k] = v;
+    }
+    unsigned long long idx[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        idx[k] = ~0ull;
+        if (win[k] != 0.f && tr.best[k] == win[k]) {  // a tracker that never fired keeps value 0 and reports index 0
+            const uint64_t tile = w.first + (uint64_t)tr.iter[k] * w.stride;
+            const float4 *q = data + tile * TILE_F4 + t;
+            for (int u = U - 1; u >= 0; u--) {  // last match written last = first slot wins
                 const float4 x = q[(uint64_t)u * BLOCK];
                 const float a = k == 0 ? power_of(x.x, x.y) : (k <= 2 ? x.x : x.y);
                 const float b = k == 0 ? power_of(x.z, x.w) : (k <= 2 ? x.z : x.w);
-                if (!found && a == tr.best[k]) {
-                    slot = 2 * u;
-                    found = true;
-                }
-                if (!found && b == tr.best[k]) {
-                    slot = 2 * u + 1;
-                    found = true;
-                }
+                const uint64_t i0 = base_index + 2 * (tile * TILE_F4 + (uint64_t)u * BLOCK + t);
+                if (b == win[k])
+                    idx[k] = i0 + 1;
+                if (a == win[k])
+                    idx[k] = i0;
             }
         }
-        codes[k] = tr.iter[k] * (2 * U) + slot;
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_down(idx[k], off, kWave);
+            idx[k] = o < idx[k] ? o : idx[k];
+        }
     }
-    r.c_pk = codes[0];
-    r.c_rp = codes[1];
-    r.c_rn = codes[2];
-    r.c_ip = codes[3];
-    r.c_in = codes[4];
-    stats_finish<BLOCK, U>(r, w, base_index, out);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            sh_idx[wave][k] = idx[k];
+    }
+    __syncthreads();
+    if (t == 0) {
+        papr_partial q;
+        q.sum = sh_sum[0];
+        for (int wq = 1; wq < kWaves; wq++)  // fixed order => deterministic sum (as block_reduce_stats)
+            q.sum += sh_sum[wq];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            unsigned long long best_idx = sh_idx[0][k];
+            for (int wq = 1; wq < kWaves; wq++)
+                best_idx = sh_idx[wq][k] < best_idx ? sh_idx[wq][k] : best_idx;
+            q.val[k] = win[k];
+            q.idx[k] = win[k] != 0.f ? best_idx : 0;
+        }
+        q.pad = 0;
+        out[blockIdx.x] = q;
+    }
     hist_flush<BLOCK>(hist, nbins, P.copies, ghist);  // (starts with a barrier: every wave has spilled)
     if (t == 0)
         seg_counts[blockIdx.x] = seg_fill;

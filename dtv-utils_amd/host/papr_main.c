@@ -16,7 +16,9 @@
  *   PAPR_STATS=1       one JSON line with sizes and timings on stderr
  *   PAPR_EXACT_SUM=0   skip the bit-exact emulation of the reference's sequential double
  *                      sum (papr.c:104) and print the mean from the parallel tree sum, which
- *                      differs from the reference's value by ~1e-13 relative (default: exact)
+ *                      differs from the reference's value by ~1e-13 relative (default: exact).
+ *                      That path reads the samples ONCE (papr_hip_load_file_sweep: both passes
+ *                      ride along with the ingest; PAPR_ONE_SWEEP=0 turns that off)
  * There is no CPU fallback: without a usable GPU the program exits 254.
  */
 #define _FILE_OFFSET_BITS 64
@@ -45,6 +47,9 @@ typedef struct shard {
     const float *levels;
     int nlevels;
     uint64_t *counts;
+    papr_stats estimate;   /* one-sweep ingest: sampled mean of this shard's file range */
+    const float *guess;    /* ... and the speculative level table (NULL: plain ingest) */
+    int nguess;
     int rc;
 } shard;
 
@@ -62,10 +67,20 @@ static void usage(void)
     fprintf(stderr, "\tg = graph suitable output\n");
 }
 
+static void *estimate_thread(void *arg)
+{
+    shard *s = (shard *)arg;
+    s->rc = papr_hip_estimate_file(s->ctx, s->path, s->first, s->count, &s->estimate);
+    return NULL;
+}
+
 static void *pass1_thread(void *arg)
 {
     shard *s = (shard *)arg;
-    s->rc = papr_hip_load_file(s->ctx, s->path, s->first, s->count);
+    if (s->guess)
+        s->rc = papr_hip_load_file_sweep(s->ctx, s->path, s->first, s->count, s->guess, s->nguess);
+    else
+        s->rc = papr_hip_load_file(s->ctx, s->path, s->first, s->count);
     if (s->rc == PAPR_OK)
         s->rc = papr_hip_stats(s->ctx, &s->stats);
     return NULL;
@@ -208,6 +223,25 @@ int main(int argc, char **argv)
     ngpu = used;
     t_open = now_s();
 
+    /* ---- one-sweep ingest (tree-sum mode only: the exact-sum sweep needs pass 1's per-tile sums first):
+     * a 1-in-64 tile sample of every shard gives the mean to ~1e-4, the level table it implies is widened
+     * into bands, and pass 2 then rides along with pass 1 on the one read of the file ---- */
+    float *guess = NULL;
+    env = getenv("PAPR_ONE_SWEEP");
+    if (!exact && !(env && env[0] != '\0' && atoi(env) == 0) && run_all_quiet(sh, ngpu, estimate_thread) == PAPR_OK) {
+        papr_stats est_total;
+        papr_stats_init(&est_total);
+        for (int g = 0; g < ngpu; g++)
+            papr_stats_merge(&est_total, &sh[g].estimate);
+        guess = (float *)malloc(PAPR_HIP_MAX_LEVELS * sizeof(float));
+        const int nguess = guess ? papr_guess_levels(&est_total, graph, graph ? 48.0 : 60.0, guess, PAPR_HIP_MAX_LEVELS) : 0;
+        for (int g = 0; g < ngpu && nguess > 0; g++) {
+            sh[g].guess = guess;
+            sh[g].nguess = nguess;
+        }
+    }
+    const double t_est = now_s();
+
     /* ---- pass 1 on every shard, then fold in file order (papr.c:100-129) ---- */
     if (run_all(sh, ngpu, pass1_thread) != PAPR_OK)
         return 253;
@@ -311,13 +345,23 @@ int main(int argc, char **argv)
         papr_hip_ingest_timing it;
         memset(&it, 0, sizeof(it));
         papr_hip_get_ingest_timing(sh[0].ctx, &it);
+        int swept = 0, resolved = 0;
+        for (int g = 0; g < ngpu; g++) {
+            papr_hip_sweep_info si;
+            memset(&si, 0, sizeof(si));
+            papr_hip_get_sweep_info(sh[g].ctx, &si);
+            swept += si.swept;
+            resolved += si.resolved;
+        }
         fprintf(stderr,
                 "{\"samples\": %llu, \"bytes\": %llu, \"gpus\": %d, \"levels\": %d, \"open_s\": %.6f, "
+                "\"estimate_s\": %.6f, \"shards_swept\": %d, \"shards_resolved_from_sweep\": %d, "
                 "\"ingest_pass1_s\": %.6f, \"exact_sum\": %d, \"exact_sum_s\": %.6f, \"pass2_s\": %.6f, \"total_s\": %.6f, \"msamples_per_s\": %.3f, "
                 "\"ingest_GBps\": %.2f, \"gpu0_ingest\": {\"setup_s\": %.4f, \"read_s\": %.4f, \"buffer_wait_s\": %.4f, "
                 "\"issue_s\": %.4f, \"drain_s\": %.4f, \"chunks\": %llu, \"reader_threads\": %d, \"resident\": %d, \"o_direct\": %d}}\n",
-                (unsigned long long)nsamples, (unsigned long long)nsamples * 8, ngpu, nlevels, t_open - t0, t1 - t_open,
-                exact_done, t1x - t1, t2 - t1x, t3 - t0, (double)nsamples / (t3 - t0) / 1e6, (double)nsamples * 8 / (t1 - t_open) / 1e9,
+                (unsigned long long)nsamples, (unsigned long long)nsamples * 8, ngpu, nlevels, t_open - t0,
+                t_est - t_open, swept, resolved, t1 - t_est,
+                exact_done, t1x - t1, t2 - t1x, t3 - t0, (double)nsamples / (t3 - t0) / 1e6, (double)nsamples * 8 / (t1 - t_est) / 1e9,
                 it.setup_s, it.read_s, it.buffer_wait_s, it.issue_s, it.drain_s, (unsigned long long)it.chunks,
                 it.reader_threads, it.resident, it.o_direct);
     }
@@ -328,5 +372,6 @@ int main(int argc, char **argv)
     }
     free(count);
     free(level);
+    free(guess);
     return 0;
 }

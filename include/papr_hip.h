@@ -254,11 +254,20 @@ typedef struct papr_hip_sweep_info {
     int band_log2;
 } papr_hip_sweep_info;
 int papr_hip_estimate(papr_hip_ctx *ctx, papr_stats *est);
+/* The same estimate for a range of a FILE that is not loaded yet (the 1-in-64 tiles are read by the
+ * ingest's reader threads and summed on the GPU): what a one-sweep ingest needs before it starts. */
+int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples, papr_stats *est);
 /* Host helper: the table papr_levels would build for the (merged) estimate's mean, carried on to max_db
  * dB above the mean whatever the peak turns out to be (the real table's length depends on the true
  * peak; bands above it cost nothing).  Returns the number of levels written (<= cap). */
 int papr_guess_levels(const papr_stats *est_total, int graph, double max_db, float *levels, int cap);
 int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, papr_stats *out);
+/* papr_hip_load_file as a one-sweep ingest: the kernel that runs on every chunk as it lands also bins against the
+ * guessed bands and stashes, so papr_hip_stats returns the file's pass-1 record as usual and papr_hip_ccdf needs
+ * no second pass — neither over a resident shard nor, for a shard larger than the HBM budget, over the FILE
+ * (which papr.c:142-144 and the plain path read twice).  Same fall-backs as papr_hip_stats_sweep. */
+int papr_hip_load_file_sweep(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples,
+                             const float *guess_levels, int nlevels);
 int papr_hip_get_sweep_info(const papr_hip_ctx *ctx, papr_hip_sweep_info *out);
 
 /* ---- pass 2 (papr.c:143-153 / 175-185) ---------------------------------- */

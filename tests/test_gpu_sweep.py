@@ -278,3 +278,121 @@ def test_sweep_randomised(pkg, orc, gpu):
         assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table)), (case, info.as_dict())
         resolved += info.resolved
     assert resolved >= 30
+
+
+# ---- one-sweep INGEST: both passes ride along with the file on its way into HBM (or through it) ----------------
+
+def test_file_ingest_sweep_resident_and_streamed(pkg, orc, tmp_path, monkeypatch):
+    """papr_hip_estimate_file + papr_hip_load_file_sweep: odd float count + stray bytes, many chunks, resident and
+    re-streamed (HBM budget too small) shards, one and two shards — counts without a second read of the file"""
+    import subprocess
+    from dtv_utils_amd import exchange
+    n = 3 * 1048576 + 12345
+    path = str(tmp_path / "sweep.cfile")
+    subprocess.check_call([orc.MKCFILE, path, str(n), "--spike", "--extra-floats", "1", "--extra-bytes", "2"])
+    monkeypatch.setenv("PAPR_CHUNK_MB", "1")           # many chunks => many sweep launches into the same stash segments
+    for graph in (False, True):
+        ref = orc.run_file(path, graph)
+        for budget in (None, "4"):                    # resident, then streamed (4 MiB HBM budget)
+            if budget:
+                monkeypatch.setenv("PAPR_HBM_BUDGET_MB", budget)
+            else:
+                monkeypatch.delenv("PAPR_HBM_BUDGET_MB", raising=False)
+            with pkg.PaprHip(0) as g:
+                est = g.estimate_file(path)
+                assert est.n > 0 and abs(est.sum / est.n - ref["sum"] / ref["n"]) < 2e-3 * ref["sum"] / ref["n"]
+                g.load_file_sweep(path, pkg.guess_levels(est, graph))
+                assert g.ingest_timing().resident == (0 if budget else 1)
+                st = g.stats()
+                check_stats(st, ref)
+                assert st.flags & pkg.FLAG_ODD_TAIL and g.sweep_info().swept == 1
+                mean, papr, table = pkg.levels(st, graph)
+                assert np.array_equal(table, ref["level"])
+                assert np.array_equal(g.ccdf(table).astype(np.int64), ref["count"])
+                assert g.sweep_info().resolved == 1, g.sweep_info().as_dict()
+                # a table outside the bands still gets the right answer, by reading again
+                odd = (table[:4] * np.float32(1.05)).astype(np.float32)
+                got = g.ccdf(odd)
+                assert g.sweep_info().resolved == 0
+                with pkg.PaprHip(0) as plain:           # (the two-pass path, itself checked against the oracle elsewhere)
+                    plain.load_file(path)
+                    assert np.array_equal(got, plain.ccdf(odd))
+                # two shards of the same file, estimates merged, then merged stats
+                total_n = pkg.file_samples(path)
+                ranges = [exchange.shard_range(total_n, r, 2) for r in range(2)]
+                guess = pkg.guess_levels(pkg.stats_merge([g.estimate_file(path, f, c) for f, c in ranges]), graph)
+                parts, counts = [], np.zeros(table.size, np.uint64)
+                ctxs = [pkg.PaprHip(0) for _ in ranges]
+                try:
+                    for c, (first, cnt) in zip(ctxs, ranges):
+                        c.load_file_sweep(path, guess, first, cnt)
+                        parts.append(c.stats())
+                    check_stats(pkg.stats_merge(parts), ref)
+                    for c in ctxs:
+                        counts += c.ccdf(table)
+                        assert c.sweep_info().resolved == 1
+                finally:
+                    for c in ctxs:
+                        c.close()
+                assert np.array_equal(counts.astype(np.int64), ref["count"])
+
+
+def test_file_ingest_sweep_fallbacks(pkg, orc, tmp_path, monkeypatch):
+    import subprocess
+    monkeypatch.setenv("PAPR_CHUNK_MB", "1")
+    # NaN in the file: the ingest is redone the plain way, first-NaN index and sign as the reference has them
+    path = str(tmp_path / "nan.cfile")
+    subprocess.check_call([orc.MKCFILE, path, "600000", "--set", "500000", "nan", "1", "--set", "300001", "1", "-nan"])
+    ref = orc.run_file(path, False)
+    for budget in (None, "2"):
+        if budget:
+            monkeypatch.setenv("PAPR_HBM_BUDGET_MB", budget)
+        with pkg.PaprHip(0) as g:
+            g.load_file_sweep(path, np.array([1.0, 2.0, 4.0], np.float32))
+            st = g.stats()
+            check_stats(st, ref)
+            assert st.nan_first_idx == 300001 and st.nan_first_neg == 1 and g.sweep_info().swept == 0
+    monkeypatch.delenv("PAPR_HBM_BUDGET_MB", raising=False)
+    # exact-sum mode, empty guess, tiny and empty files: plain ingest, same results
+    small = str(tmp_path / "small.cfile")
+    subprocess.check_call([orc.MKCFILE, small, "1000"])
+    empty = str(tmp_path / "empty.cfile")
+    open(empty, "wb").close()
+    with pkg.PaprHip(0) as g:
+        assert g.estimate_file(small).n == 0 and g.estimate_file(empty).n == 0
+        for p in (small, empty):
+            ref = orc.run_file(p, False)
+            g.load_file_sweep(p, np.array([2.0], np.float32))
+            st = g.stats()
+            check_stats(st, ref)
+            mean, papr, table = pkg.levels(st, False)
+            assert np.array_equal(g.ccdf(table).astype(np.int64), ref["count"])
+        g.set_exact(True)
+        g.load_file_sweep(small, np.array([2.0], np.float32))
+        assert g.sweep_info().swept == 0 and g.sweep_info().as_dict()["reason"].startswith("exact mode")
+        check_stats(g.stats(), orc.run_file(small, False))
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_cli_tree_sum_mode_reads_the_file_once(pkg, orc, tmp_path, shards):
+    """bin/papr with PAPR_EXACT_SUM=0: estimate + one-sweep ingest.  Same stdout as with PAPR_ONE_SWEEP=0 (two
+    passes), resident or streamed; PAPR_STATS tells that every shard was answered from its sweep."""
+    import json
+    import os
+    import subprocess
+    n = 2 * 1048576 + 777
+    path = str(tmp_path / "cli.cfile")
+    subprocess.check_call([orc.MKCFILE, path, str(n), "--spike"])
+    base = dict(os.environ, PAPR_EXACT_SUM="0", PAPR_STATS="1", PAPR_GPUS=str(shards), PAPR_OVERSUBSCRIBE="1",
+                PAPR_CHUNK_MB="1")
+    for graph in (False, True):
+        args = [pkg.CLI_PATH] + (["-g"] if graph else []) + [path]
+        two = subprocess.run(args, capture_output=True, env=dict(base, PAPR_ONE_SWEEP="0"))
+        assert two.returncode == 0 and json.loads(two.stderr.decode().splitlines()[-1])["shards_swept"] == 0
+        for budget in (None, "2"):
+            env = dict(base, **({"PAPR_HBM_BUDGET_MB": budget} if budget else {}))
+            one = subprocess.run(args, capture_output=True, env=env)
+            info = json.loads(one.stderr.decode().splitlines()[-1])
+            assert one.returncode == 0 and one.stdout == two.stdout, (graph, budget)
+            assert info["shards_swept"] == shards and info["shards_resolved_from_sweep"] == shards, info
+            assert info["gpu0_ingest"]["resident"] == (0 if budget else 1)

@@ -15,6 +15,8 @@ B="python $R/bench.py"
 $R/bin/hbm_read_probe 10 10 > $O/hbm_read_probe.txt 2>&1
 $B                > $O/bench_default.json 2> $O/bench_default.err
 $B --mode graph   > $O/bench_graph.json   2> $O/bench_graph.err
+$B --two-pass              --no-cpu-baseline > $O/bench_twopass_default.json 2> $O/bench_twopass_default.err
+$B --two-pass --mode graph --no-cpu-baseline > $O/bench_twopass_graph.json   2> $O/bench_twopass_graph.err
 $B --exact --no-cpu-baseline > $O/bench_exact.json 2> $O/bench_exact.err
 $B --exact --mode graph --no-cpu-baseline > $O/bench_exact_graph.json 2> $O/bench_exact_graph.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_exact -- \
@@ -31,16 +33,27 @@ PAPR_EXACT_SUM=0 PAPR_STATS=1 $R/bin/papr /dev/shm/papr_prof_10g.cfile 2>> $O/cl
 cmp $O/cli_default.txt $R/tests/golden/big_spike10g.default.txt && cmp $O/cli_graph.txt $R/tests/golden/big_spike10g.graph.txt \
   && echo "CLI stdout identical to the reference on the 10 GiB workload (both modes)" >> $O/cli_e2e.txt
 rm -f /dev/shm/papr_prof_10g.cfile
+# one-sweep (the default) and two-pass, both level tables: kernel-trace stats, then each PMC set in a pass of its own
 for MODE in default graph; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$MODE -- \
-      $B --steps 20 --warmup 3 --mode $MODE --no-cpu-baseline > $O/stats_$MODE.json 2> $O/stats_$MODE.err
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$MODE -- \
-      $B --steps 3 --warmup 1 --mode $MODE --no-cpu-baseline > $O/pmc_fetch_$MODE.json 2> $O/pmc_fetch_$MODE.err
+  for WAY in "" twopass_; do
+    FLAG=""; [ -n "$WAY" ] && FLAG="--two-pass"
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$WAY$MODE -- \
+        $B --steps 20 --warmup 3 --mode $MODE $FLAG --no-cpu-baseline > $O/stats_$WAY$MODE.json 2> $O/stats_$WAY$MODE.err
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$WAY$MODE -- \
+        $B --steps 3 --warmup 1 --mode $MODE $FLAG --no-cpu-baseline > $O/pmc_fetch_$WAY$MODE.json 2> $O/pmc_fetch_$WAY$MODE.err
+  done
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$MODE -- \
+      $B --steps 3 --warmup 1 --mode $MODE --no-cpu-baseline > $O/pmc_write_$MODE.json 2> $O/pmc_write_$MODE.err
 done
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv \
-    -d $O/pmc_tcc -- $B --steps 3 --warmup 1 --mode graph --no-cpu-baseline > $O/pmc_tcc.json 2> $O/pmc_tcc.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
-    --kernel-trace --output-format csv -d $O/pmc_sq -- $B --steps 3 --warmup 1 --mode graph --no-cpu-baseline > $O/pmc_sq.json 2> $O/pmc_sq.err
+for WAY in "" twopass_; do
+  FLAG=""; [ -n "$WAY" ] && FLAG="--two-pass"
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv \
+      -d $O/pmc_tcc_$WAY -- $B --steps 3 --warmup 1 --mode graph $FLAG --no-cpu-baseline > $O/pmc_tcc_$WAY.json 2> $O/pmc_tcc_$WAY.err
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS \
+      --kernel-trace --output-format csv -d $O/pmc_sq_$WAY -- $B --steps 3 --warmup 1 --mode graph $FLAG --no-cpu-baseline > $O/pmc_sq_$WAY.json 2> $O/pmc_sq_$WAY.err
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA \
+      --kernel-trace --output-format csv -d $O/pmc_lds_$WAY -- $B --steps 3 --warmup 1 --mode graph $FLAG --no-cpu-baseline > $O/pmc_lds_$WAY.json 2> $O/pmc_lds_$WAY.err
+done
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --kernel-trace --output-format csv \
     -d $O/pmc_grbm -- $B --steps 3 --warmup 1 --mode graph --no-cpu-baseline > $O/pmc_grbm.json 2> $O/pmc_grbm.err
 ls $O
