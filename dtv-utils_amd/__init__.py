@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "papr_stats_init", "papr_stats_merge", "papr_levels", "papr_hip_ccdf",
     "papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
     "papr_hip_estimate", "papr_hip_stats_sweep", "papr_hip_get_sweep_info", "papr_guess_levels",
-    "papr_hip_estimate_file", "papr_hip_load_file_sweep",
+    "papr_hip_estimate_file", "papr_hip_load_file_sweep", "papr_hip_shard_fits",
 )
 
 
@@ -187,6 +187,8 @@ def lib() -> C.CDLL:
     L.papr_guess_levels.restype = i32
     L.papr_hip_stats_sweep.argtypes = [vp, vp, i32, C.POINTER(Stats)]
     L.papr_hip_estimate_file.argtypes = [vp, C.c_char_p, u64, u64, C.POINTER(Stats)]
+    L.papr_hip_shard_fits.argtypes = [vp, u64]
+    L.papr_hip_shard_fits.restype = i32
     L.papr_hip_load_file_sweep.argtypes = [vp, C.c_char_p, u64, u64, vp, i32]
     L.papr_hip_get_sweep_info.argtypes = [vp, C.POINTER(SweepInfo)]
     for name in ("papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
@@ -292,6 +294,11 @@ class PaprHip:
         except Exception:
             pass
 
+    def _chk_pos(self, rc: int, what: str) -> int:
+        if rc < 0:
+            self._chk(rc, what)
+        return rc
+
     def _chk(self, rc: int, what: str):
         if rc:
             raise PaprError(rc, what, self._L.papr_hip_last_error(self._ctx).decode())
@@ -343,6 +350,9 @@ class PaprHip:
         lv = np.ascontiguousarray(guess_table, dtype=np.float32)
         self._chk(self._L.papr_hip_load_file_sweep(self._ctx, os.fsencode(path), first_sample, nsamples,
                                                    lv.ctypes.data_as(C.c_void_p), lv.size), "papr_hip_load_file_sweep")
+
+    def shard_fits(self, nsamples: int) -> bool:
+        return bool(self._chk_pos(self._L.papr_hip_shard_fits(self._ctx, nsamples), "papr_hip_shard_fits"))
 
     def ingest_timing(self) -> IngestTiming:
         t = IngestTiming()

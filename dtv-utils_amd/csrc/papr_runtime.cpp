@@ -1645,6 +1645,13 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
     return load_file_impl(ctx, path, first_sample, nsamples, nullptr, 0);
 }
 
+int papr_hip_shard_fits(const papr_hip_ctx *ctx, uint64_t nsamples)
+{
+    if (!ctx)
+        return PAPR_E_ARG;
+    return (nsamples + PAPR_TILE_SAMPLES_MAX) * 8 <= ctx->hbm_budget ? 1 : 0;
+}
+
 int papr_hip_load_file_sweep(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples,
                              const float *guess_levels, int nlevels)
 {

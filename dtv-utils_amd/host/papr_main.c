@@ -17,8 +17,10 @@
  *   PAPR_EXACT_SUM=0   skip the bit-exact emulation of the reference's sequential double
  *                      sum (papr.c:104) and print the mean from the parallel tree sum, which
  *                      differs from the reference's value by ~1e-13 relative (default: exact).
- *                      That path reads the samples ONCE (papr_hip_load_file_sweep: both passes
- *                      ride along with the ingest; PAPR_ONE_SWEEP=0 turns that off)
+ *                      In that mode a file too large to stay in HBM is read ONCE instead of twice
+ *                      (papr_hip_load_file_sweep: both passes ride along with the ingest);
+ *                      PAPR_ONE_SWEEP=0 turns that off, =1 also uses it for shards that fit
+ *                      (no gain there: pass 2 over a resident shard is 1.5 ms, the sample costs 40)
  * There is no CPU fallback: without a usable GPU the program exits 254.
  */
 #define _FILE_OFFSET_BITS 64
@@ -228,7 +230,14 @@ int main(int argc, char **argv)
      * into bands, and pass 2 then rides along with pass 1 on the one read of the file ---- */
     float *guess = NULL;
     env = getenv("PAPR_ONE_SWEEP");
-    if (!exact && !(env && env[0] != '\0' && atoi(env) == 0) && run_all_quiet(sh, ngpu, estimate_thread) == PAPR_OK) {
+    int one_sweep = env && env[0] != '\0' ? (atoi(env) > 0 ? 2 : 0) : 1; /* 2 = forced, 1 = when the file is streamed */
+    if (one_sweep == 1) {
+        one_sweep = 0;
+        for (int g = 0; g < ngpu; g++)
+            if (papr_hip_shard_fits(sh[g].ctx, sh[g].count) == 0)
+                one_sweep = 1;
+    }
+    if (!exact && one_sweep && run_all_quiet(sh, ngpu, estimate_thread) == PAPR_OK) {
         papr_stats est_total;
         papr_stats_init(&est_total);
         for (int g = 0; g < ngpu; g++)

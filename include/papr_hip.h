@@ -154,6 +154,10 @@ int papr_file_samples(const char *path, uint64_t *nsamples);
  * buffer) is reproduced when the range includes the file's last sample.  The
  * copy to HBM is double-buffered and overlapped with the pass-1 kernel. */
 int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples);
+/* 1 if a shard of nsamples would be kept resident in HBM by papr_hip_load_file (it fits the context's HBM
+ * budget: 90 % of the free memory at open, or PAPR_HBM_BUDGET_MB), 0 if it would be re-streamed from the file
+ * for every further pass. */
+int papr_hip_shard_fits(const papr_hip_ctx *ctx, uint64_t nsamples);
 int papr_hip_get_ingest_timing(const papr_hip_ctx *ctx, papr_hip_ingest_timing *out);
 
 /* Copy nsamples IQ pairs from host memory into the shard. */

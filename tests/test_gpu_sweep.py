@@ -389,10 +389,11 @@ def test_cli_tree_sum_mode_reads_the_file_once(pkg, orc, tmp_path, shards):
         args = [pkg.CLI_PATH] + (["-g"] if graph else []) + [path]
         two = subprocess.run(args, capture_output=True, env=dict(base, PAPR_ONE_SWEEP="0"))
         assert two.returncode == 0 and json.loads(two.stderr.decode().splitlines()[-1])["shards_swept"] == 0
-        for budget in (None, "2"):
-            env = dict(base, **({"PAPR_HBM_BUDGET_MB": budget} if budget else {}))
+        for budget, force in ((None, None), (None, "1"), ("2", None)):
+            env = dict(base, **({"PAPR_HBM_BUDGET_MB": budget} if budget else {}), **({"PAPR_ONE_SWEEP": force} if force else {}))
             one = subprocess.run(args, capture_output=True, env=env)
             info = json.loads(one.stderr.decode().splitlines()[-1])
             assert one.returncode == 0 and one.stdout == two.stdout, (graph, budget)
-            assert info["shards_swept"] == shards and info["shards_resolved_from_sweep"] == shards, info
+            want = shards if (budget or force) else 0      # by default only shards that do not fit in HBM are swept
+            assert info["shards_swept"] == want and info["shards_resolved_from_sweep"] == want, info
             assert info["gpu0_ingest"]["resident"] == (0 if budget else 1)

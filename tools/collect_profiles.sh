@@ -32,6 +32,19 @@ done
 PAPR_EXACT_SUM=0 PAPR_STATS=1 $R/bin/papr /dev/shm/papr_prof_10g.cfile 2>> $O/cli_e2e.txt > /dev/null
 cmp $O/cli_default.txt $R/tests/golden/big_spike10g.default.txt && cmp $O/cli_graph.txt $R/tests/golden/big_spike10g.graph.txt \
   && echo "CLI stdout identical to the reference on the 10 GiB workload (both modes)" >> $O/cli_e2e.txt
+# the file does not fit the HBM budget (configs[4] situation): streamed through device staging
+echo "--- PAPR_HBM_BUDGET_MB=1024: exact sum (two reads of the file) / tree sum, one-sweep ingest (one read) / tree sum, two passes" >> $O/cli_e2e.txt
+for i in 1 2 3; do
+  for M in "" "-g"; do
+    PAPR_HBM_BUDGET_MB=1024 PAPR_STATS=1 $R/bin/papr $M /dev/shm/papr_prof_10g.cfile 2>> $O/cli_e2e.txt > $O/cli_streamed_exact$M.txt
+    PAPR_HBM_BUDGET_MB=1024 PAPR_EXACT_SUM=0 PAPR_STATS=1 $R/bin/papr $M /dev/shm/papr_prof_10g.cfile 2>> $O/cli_e2e.txt > $O/cli_streamed_sweep$M.txt
+    PAPR_HBM_BUDGET_MB=1024 PAPR_EXACT_SUM=0 PAPR_ONE_SWEEP=0 PAPR_STATS=1 $R/bin/papr $M /dev/shm/papr_prof_10g.cfile 2>> $O/cli_e2e.txt > $O/cli_streamed_twopass$M.txt
+  done
+done
+cmp $O/cli_streamed_exact.txt $R/tests/golden/big_spike10g.default.txt && cmp $O/cli_streamed_exact-g.txt $R/tests/golden/big_spike10g.graph.txt \
+  && cmp $O/cli_streamed_sweep.txt $R/tests/golden/big_spike10g.default.txt && cmp $O/cli_streamed_sweep-g.txt $R/tests/golden/big_spike10g.graph.txt \
+  && cmp $O/cli_streamed_twopass.txt $R/tests/golden/big_spike10g.default.txt \
+  && echo "streamed: stdout identical to the reference in all three forms (both modes)" >> $O/cli_e2e.txt
 rm -f /dev/shm/papr_prof_10g.cfile
 # one-sweep (the default) and two-pass, both level tables: kernel-trace stats, then each PMC set in a pass of its own
 for MODE in default graph; do

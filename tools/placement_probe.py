@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Does the pass-1 kernel time depend on WHERE the 10 GiB shard was allocated?  Allocates several shards
 (all kept alive, so they land in different places), fills each with the same stream and times pass 1 with
-the XCD-contiguous (map=2) and grid-stride (map=0) tile mappings, and pass 2, on each of them."""
+the XCD-contiguous (map=2) and grid-stride (map=0) tile mappings, pass 2, and the one-sweep kernel with
+each mapping, on each of them."""
 import json
 import os
 import statistics
@@ -44,6 +45,17 @@ def main():
             g.ccdf(table)
             ms.append(g.timing().ccdf_ms)
         row["ccdf_map0"] = round(statistics.median(ms), 4)
+        guess = pkg.guess_levels(g.estimate(), False)
+        for m in (0, 1, 2):
+            g.set_tuning(sweep_map=m)
+            g.stats_sweep(guess)
+            ms = []
+            for _ in range(6):
+                g.set_timing(True)
+                g.stats_sweep(guess)
+                ms.append(g.timing().sweep_ms)
+            row[f"sweep_map{m}"] = round(statistics.median(ms), 4)
+        g.set_tuning()
         print(json.dumps(row), flush=True)
     g.close()
 
