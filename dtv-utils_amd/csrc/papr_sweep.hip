@@ -8,8 +8,8 @@
 //                                (1/64 of the shard by default): a mean good to ~1e-4 relative
 //   2. the host turns that guess into the level table the reference would build from it and widens
 //      every threshold into a BAND of +-2^w float bit patterns (default w = 15, i.e. +-0.2 .. 0.4 %)
-//   3. papr_sweep_kernel         pass 1 exactly as papr_stats_kernel (same geometry => same sum,
-//                                same trackers), and in the same read every power is binned against
+//   3. papr_sweep_kernel         pass 1 as papr_stats_kernel does it (same trackers; same geometry =>
+//                                same sum), and in the same read every power is binned against
 //                                the band edges: even bins lie BETWEEN bands, so whichever way the
 //                                true threshold falls inside its band those samples are already
 //                                decided; the few per cent that land INSIDE a band (odd bins) are
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_estimate_kernel(const float4 
 //    slot that holds the value: the same first-occurrence answer as papr_stats_kernel.  NaN bit
 //    patterns would win an integer max, but any NaN in I or Q also makes the sum NaN, and then the
 //    runtime discards this launch's pass-1 record and runs papr_stats_kernel instead.
-//  * the double sum adds the same powers in the same order as papr_stats_kernel (bit-identical sum)
+//  * the double sum is accumulated exactly as papr_stats_kernel does it (per lane in tile order, then a fixed
+//    wave / workgroup / grid tree): the same value whenever the two kernels run the same geometry
 //  * branch-free binning: the LUT carries a "below" sentinel cell in front and an "above" one behind,
 //    the cell index is clamped with one med3.  The above sentinel sends NaN powers to a trash bin
 //    (index nkeys + 1, odd: they also go to the stash, where the recount ignores them).

@@ -227,7 +227,8 @@ int papr_exact_chain(const void *const *programs, const size_t *bytes, int nprog
  *                                     shard's 16 KiB tiles (1/64 of a pass)
  *   (merge the shards' estimates with papr_stats_merge; guess table = papr_guess_levels(&est_total, ...))
  *   papr_hip_stats_sweep(ctx, guess, L, &st)
- *                                     st is exactly what papr_hip_stats returns; in the same read
+ *                                     st is what papr_hip_stats returns (same trackers; the double sum
+ *                                     from another, equally accurate summation tree); in the same read
  *                                     every power is binned against BANDS of +-2^14 bit patterns
  *                                     (+-0.1..0.2 %) around the guessed thresholds, and the few
  *                                     per cent that fall inside a band are stashed in HBM

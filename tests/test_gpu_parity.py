@@ -619,6 +619,20 @@ def test_shard_beyond_2_to_32_samples(pkg):
         whole = pkg.exact_chain([prog])
         assert abs(whole - st.sum) <= 1e-9 * st.sum and np.all(np.diff(counts.astype(np.int64)) <= 0)
         assert counts[0] < n and counts[-1] <= 4
+        # the one-sweep path on the same 34 GiB shard: same record (indices beyond 2^32), same counts
+        g.set_exact(False)
+        two = g.stats()
+        sw = g.stats_sweep(pkg.guess_levels(g.estimate(), True))
+        assert g.sweep_info().swept == 1 and sw.n == two.n and abs(sw.sum - two.sum) <= SUM_RTOL * two.sum
+        for k in TRACKERS:
+            assert getattr(sw, k) == getattr(two, k) and getattr(sw, k + "_idx") == getattr(two, k + "_idx"), k
+        assert sw.peak_idx == first and sw.re_neg_idx == n - 1 and sw.im_pos_idx == 7
+        mean_t, papr_t, table_t = pkg.levels(sw, True)
+        swept_counts = g.ccdf(table_t)
+        assert g.sweep_info().resolved == 1, g.sweep_info().as_dict()
+        g.stats()                                   # drops the sweep: the next ccdf reads the shard
+        assert np.array_equal(swept_counts, g.ccdf(table_t)) and g.sweep_info().resolved == 0
+        g.set_exact(True)
         # the same stream as two shards cut beyond 2^32: merged record, summed counts and chained exact sum agree
         cut = ((1 << 32) + 99999) // 8192 * 8192
         parts, progs, total_counts, before = [], [], np.zeros(table.size, np.uint64), 0.0
