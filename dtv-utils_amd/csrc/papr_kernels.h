@@ -115,7 +115,7 @@ void papr_launch_generate(hipStream_t st, int blocks, void *out, uint64_t nsampl
 void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t ngroups, uint32_t ratio,
                           papr_partial *out);
 int papr_sweep_variant(int variant); /* the sweep geometry used for a variant id, or -1 */
-size_t papr_sweep_stash_lds_bytes(int variant);
+int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_t *stash_lds); /* 0, or -1 */
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
                        uint64_t base_index, int map, papr_partial *out, const void *tail, uint32_t tail_samples,
                        const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist, float *stash,

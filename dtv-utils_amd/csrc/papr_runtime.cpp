@@ -898,10 +898,8 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
         return PAPR_OK;
     // widest band (<= the configured width) whose edges stay apart and still have a LUT form
     run->variant = variant_of(ctx, SWEEP);
-    int vblock = 256, vunroll = 4;
-    (void)papr_variant_geometry(run->variant, &vblock, &vunroll);
-    run->tile = 2ull * (uint64_t)vblock * (uint64_t)vunroll;
-    run->stash_lds = papr_sweep_stash_lds_bytes(run->variant);
+    int vblock = 512;
+    (void)papr_sweep_geometry(run->variant, &vblock, &run->tile, &run->stash_lds);
     CcdfPlan &bands = run->bands;
     run->half = 0;
     for (int log2w = info.band_log2; log2w >= std::max(info.band_log2 - 3, 8) && !run->half; log2w--) {

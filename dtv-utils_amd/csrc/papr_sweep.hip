@@ -191,6 +191,100 @@ __device__ __forceinline__ void track_tile(TileTrack &tr, const float4 (&x)[U], 
     }
 }
 
+// Workgroup record of the sweep kernel.  THREADS = workgroup size, ROW = lanes that share a tile row, tl = this
+// lane's position in the row.
+template <int THREADS, int ROW, int U>
+__device__ __forceinline__ void sweep_record(double sum, const TileTrack &tr, const TileWalk &w, const float4 *__restrict__ data,
+                                             uint64_t base_index, uint32_t tl, papr_partial *__restrict__ out)
+{
+    // Workgroup record.  The lanes only know in WHICH tile their extreme first appeared; finding the slot means
+    // re-reading that tile, which is uncoalesced (every lane another tile: 64-128 B fetched per 16 B used), so it is
+    // done by the workgroup's winners only: reduce the VALUES first, then just the lanes that hold the winning value
+    // (normally one) look up their slot, then the smallest index among them wins — the reference's first occurrence.
+    constexpr int kWaves = THREADS / kWave;
+    constexpr uint64_t TILE_F4 = (uint64_t)ROW * U;
+    const uint32_t t = threadIdx.x;
+    __shared__ double sh_sum[kWaves];
+    __shared__ float sh_val[kWaves][5];
+    __shared__ unsigned long long sh_idx[kWaves][5];
+    const int lane = t & (kWave - 1), wave = t / kWave;
+    float wv[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        float v = tr.best[k];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            const float o = __shfl_down(v, off, kWave);
+            v = (k == 2 || k == 4) ? (o < v ? o : v) : (o > v ? o : v);
+        }
+        wv[k] = v;
+    }
+    const double wsum = wave_reduce_sum(sum);
+    if (lane == 0) {
+        sh_sum[wave] = wsum;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            sh_val[wave][k] = wv[k];
+    }
+    __syncthreads();
+    float win[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        float v = sh_val[0][k];
+        for (int wq = 1; wq < kWaves; wq++) {
+            const float o = sh_val[wq][k];
+            v = (k == 2 || k == 4) ? (o < v ? o : v) : (o > v ? o : v);
+        }
+        win[k] = v;
+    }
+    unsigned long long idx[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        idx[k] = ~0ull;
+        if (win[k] != 0.f && tr.best[k] == win[k]) {  // a tracker that never fired keeps value 0 and reports index 0
+            const uint64_t tile = w.first + (uint64_t)tr.iter[k] * w.stride;
+            const float4 *q = data + tile * TILE_F4 + tl;
+            for (int u = U - 1; u >= 0; u--) {  // last match written last = first slot wins
+                const float4 x = q[(uint64_t)u * ROW];
+                const float a = k == 0 ? power_of(x.x, x.y) : (k <= 2 ? x.x : x.y);
+                const float b = k == 0 ? power_of(x.z, x.w) : (k <= 2 ? x.z : x.w);
+                const uint64_t i0 = base_index + 2 * (tile * TILE_F4 + (uint64_t)u * ROW + tl);
+                if (b == win[k])
+                    idx[k] = i0 + 1;
+                if (a == win[k])
+                    idx[k] = i0;
+            }
+        }
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_down(idx[k], off, kWave);
+            idx[k] = o < idx[k] ? o : idx[k];
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            sh_idx[wave][k] = idx[k];
+    }
+    __syncthreads();
+    if (t == 0) {
+        papr_partial q;
+        q.sum = sh_sum[0];
+        for (int wq = 1; wq < kWaves; wq++)  // fixed order => deterministic sum (as block_reduce_stats)
+            q.sum += sh_sum[wq];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            unsigned long long best_idx = sh_idx[0][k];
+            for (int wq = 1; wq < kWaves; wq++)
+                best_idx = sh_idx[wq][k] < best_idx ? sh_idx[wq][k] : best_idx;
+            q.val[k] = win[k];
+            q.idx[k] = win[k] != 0.f ? best_idx : 0;
+        }
+        q.pad = 0;
+        out[blockIdx.x] = q;
+    }
+}
+
 }  // namespace
 
 template <int BLOCK, int U, bool NT, int PIPE>
@@ -320,90 +414,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
     }
     ws.spill_if_above(0);
 
-    // Workgroup record.  The lanes only know in WHICH tile their extreme first appeared; finding the slot means
-    // re-reading that tile, which is uncoalesced (every lane another tile: 64-128 B fetched per 16 B used), so it is
-    // done by the workgroup's winners only: reduce the VALUES first, then just the lanes that hold the winning value
-    // (normally one) look up their slot, then the smallest index among them wins — the reference's first occurrence.
-    constexpr int kWaves = BLOCK / kWave;
-    __shared__ double sh_sum[kWaves];
-    __shared__ float sh_val[kWaves][5];
-    __shared__ unsigned long long sh_idx[kWaves][5];
-    const int lane = t & (kWave - 1), wave = t / kWave;
-    float wv[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        float v = tr.best[k];
-#pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) {
-            const float o = __shfl_down(v, off, kWave);
-            v = (k == 2 || k == 4) ? (o < v ? o : v) : (o > v ? o : v);
-        }
-        wv[k] = v;
-    }
-    const double wsum = wave_reduce_sum(sum);
-    if (lane == 0) {
-        sh_sum[wave] = wsum;
-#pragma unroll
-        for (int k = 0; k < 5; k++)
-            sh_val[wave][k] = wv[k];
-    }
-    __syncthreads();
-    float win[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        float v = sh_val[0][k];
-        for (int wq = 1; wq < kWaves; wq++) {
-            const float o = sh_val[wq][k];
-            v = (k == 2 || k == 4) ? (o < v ? o : v) : (o > v ? o : v);
-        }
-        win[k] = v;
-    }
-    unsigned long long idx[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        idx[k] = ~0ull;
-        if (win[k] != 0.f && tr.best[k] == win[k]) {  // a tracker that never fired keeps value 0 and reports index 0
-            const uint64_t tile = w.first + (uint64_t)tr.iter[k] * w.stride;
-            const float4 *q = data + tile * TILE_F4 + t;
-            for (int u = U - 1; u >= 0; u--) {  // last match written last = first slot wins
-                const float4 x = q[(uint64_t)u * BLOCK];
-                const float a = k == 0 ? power_of(x.x, x.y) : (k <= 2 ? x.x : x.y);
-                const float b = k == 0 ? power_of(x.z, x.w) : (k <= 2 ? x.z : x.w);
-                const uint64_t i0 = base_index + 2 * (tile * TILE_F4 + (uint64_t)u * BLOCK + t);
-                if (b == win[k])
-                    idx[k] = i0 + 1;
-                if (a == win[k])
-                    idx[k] = i0;
-            }
-        }
-#pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_down(idx[k], off, kWave);
-            idx[k] = o < idx[k] ? o : idx[k];
-        }
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 5; k++)
-            sh_idx[wave][k] = idx[k];
-    }
-    __syncthreads();
-    if (t == 0) {
-        papr_partial q;
-        q.sum = sh_sum[0];
-        for (int wq = 1; wq < kWaves; wq++)  // fixed order => deterministic sum (as block_reduce_stats)
-            q.sum += sh_sum[wq];
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            unsigned long long best_idx = sh_idx[0][k];
-            for (int wq = 1; wq < kWaves; wq++)
-                best_idx = sh_idx[wq][k] < best_idx ? sh_idx[wq][k] : best_idx;
-            q.val[k] = win[k];
-            q.idx[k] = win[k] != 0.f ? best_idx : 0;
-        }
-        q.pad = 0;
-        out[blockIdx.x] = q;
-    }
+    sweep_record<BLOCK, BLOCK, U>(sum, tr, w, data, base_index, t, out);
     hist_flush<BLOCK>(hist, nbins, P.copies, ghist);  // (starts with a barrier: every wave has spilled)
     if (t == 0)
         seg_counts[blockIdx.x] = seg_fill;
@@ -482,11 +493,19 @@ int papr_sweep_variant(int variant)
     }
 }
 
-size_t papr_sweep_stash_lds_bytes(int variant)
+int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_t *stash_lds)
 {
-    int block = 256, unroll = 4;
-    (void)papr_variant_geometry(variant, &block, &unroll);
-    return (size_t)(block / kWave) * papr_sweep_slice_floats(unroll) * sizeof(float);
+    switch (variant) {
+#define X(V, B, U, P)                                                                     \
+    case V:                                                                                \
+        *threads = B;                                                                      \
+        *tile_samples = 2ull * B * U;                                                      \
+        *stash_lds = (size_t)(B / kWave) * papr_sweep_slice_floats(U) * sizeof(float);     \
+        return 0;
+        PAPR_FOR_EACH_SWEEP_VARIANT(X)
+#undef X
+    default: return -1;
+    }
 }
 
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
