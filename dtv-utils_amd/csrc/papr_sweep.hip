@@ -4,10 +4,10 @@
 // is only known after pass 1 (papr.c:131-141 -> :145-152).  Both passes are HBM-bound here, so the
 // second read is half of the job.  The one-sweep scheme keeps the result exact and drops it:
 //
-//   1. papr_estimate_kernel      sums one pseudo-randomly chosen 16 KiB tile out of every `ratio`
-//                                (1/64 of the shard by default): a mean good to ~1e-4 relative
+//   1. papr_estimate_kernel      sums a pseudo-random 1/ratio of the shard's 1 KiB rows (1/64 by
+//                                default): a mean good to ~1e-4 relative
 //   2. the host turns that guess into the level table the reference would build from it and widens
-//      every threshold into a BAND of +-2^w float bit patterns (default w = 15, i.e. +-0.2 .. 0.4 %)
+//      every threshold into a BAND of +-2^w float bit patterns (default w = 14, i.e. +-0.1 .. 0.2 %)
 //   3. papr_sweep_kernel         pass 1 as papr_stats_kernel does it (same trackers; same geometry =>
 //                                same sum), and in the same read every power is binned against
 //                                the band edges: even bins lie BETWEEN bands, so whichever way the
@@ -19,13 +19,13 @@
 //
 // If a true threshold falls outside its band, the stash overflows or the table has no LUT form, the
 // runtime simply runs the classic pass 2 (papr_ccdf_kernel): speculation never changes a result, it
-// only decides how many bytes are read.  Typical extra traffic: 1-3 % of a pass (default table),
-// ~6 % (-g), instead of 100 %.
+// only decides how many bytes are read.  Typical extra traffic: 0.5 % of a pass (default table),
+// 4.6 % (-g), instead of 100 %.
 //
 // The stash is filled without workgroup barriers and without global atomics: every workgroup owns one
-// segment of the HBM stash, every wave owns a slice of LDS and compacts its in-band powers into it
-// with ballot/mbcnt; when the slice is half full the wave reserves a range of the workgroup's segment
-// with one LDS atomic and writes it out coalesced.  (A single global counter serialises at ~11 ns per
+// segment of the HBM stash, every wave owns a slice of LDS in which its lanes reserve slots for their
+// in-band powers with a returning LDS atomic; when a third of the slice is used the wave reserves a
+// range of the workgroup's segment with one more LDS atomic and writes it out coalesced.  (A single global counter serialises at ~11 ns per
 // reservation across the 8 XCDs — measured: it doubled the kernel time of the 0.1 dB table.)
 
 #include <hip/hip_runtime.h>
@@ -47,7 +47,7 @@ __device__ __forceinline__ int32_t clamp_cell(int32_t cell, int32_t first, int32
     return r;
 }
 
-// which tile of group g the estimate reads
+// which tile of its group an estimate row is read from
 __device__ __forceinline__ uint32_t papr_estimate_pick(uint64_t g, uint32_t ratio)
 {
     return (uint32_t)(((g + 1) * 0x9E3779B97F4A7C15ull) >> 40) % ratio;
@@ -94,20 +94,27 @@ struct WaveStash {
 // =============================================================================
 // 1. mean estimate from a 1/ratio sample of the tiles
 // =============================================================================
-// Group g = tiles [g*ratio, (g+1)*ratio); one tile of it (a hash of g picks which, so that no
-// periodic structure in the capture can alias with the sampling) is read by one workgroup:
-// 256 lanes x 4 x 16 B = 16 KiB = 2048 samples.  Output: one papr_partial per workgroup with only
-// `sum` set (merged by papr_stats_finalize like pass-1 partials).
+// Group g = tiles [g*ratio, (g+1)*ratio) of 16 KiB.  A workgroup reads one tile's worth of it, but every 1 KiB
+// row (one wave-wide 16-byte load) from a tile of the group chosen by a hash of (g, row): no periodic structure
+// in the capture can alias with the sampling, and a bursty capture is sampled in 16 x more independent places
+// than whole tiles would give (the error of the mean is sigma(piece means) / sqrt(pieces)).
+// Output: one papr_partial per workgroup with only `sum` set (merged by papr_stats_finalize like pass-1 partials).
 __global__ __launch_bounds__(PAPR_BLOCK) void papr_estimate_kernel(const float4 *__restrict__ data, uint64_t ngroups,
                                                                     uint32_t ratio, papr_partial *__restrict__ out)
 {
     constexpr int U = PAPR_ESTIMATE_TILE_SAMPLES / (2 * PAPR_BLOCK);
+    constexpr int kRows = U * (PAPR_BLOCK / kWave);
     constexpr uint64_t TILE_F4 = (uint64_t)PAPR_BLOCK * U;
+    const uint32_t wave = threadIdx.x / kWave;
     double sum = 0.0;
     for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const uint64_t tile = g * ratio + papr_estimate_pick(g, ratio);
         float4 x[U];
-        load_tile<PAPR_BLOCK, U, false>(x, data + tile * TILE_F4 + threadIdx.x);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t row = g * kRows + (uint64_t)u * (PAPR_BLOCK / kWave) + wave;
+            const uint64_t tile = g * ratio + papr_estimate_pick(row, ratio);
+            x[u] = load16<false>(data + tile * TILE_F4 + (uint64_t)u * PAPR_BLOCK + threadIdx.x);
+        }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             sum += (double)power_of(x[u].x, x[u].y);
