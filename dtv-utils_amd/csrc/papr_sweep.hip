@@ -72,14 +72,14 @@ struct WaveStash {
     __device__ __forceinline__ void spill_if_above(uint32_t limit)
     {
         __builtin_amdgcn_wave_barrier();  // LDS is in-order per wave; this pins the compiler's order too
-        const uint32_t n = __builtin_amdgcn_readfirstlane(*fill);
+        const uint32_t n = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)fill);  // other lanes' atomics: never cached
         if (n <= limit)
             return;
         const uint32_t lane = threadIdx.x & (kWave - 1);
         unsigned long long pos = 0;
         if (lane == 0) {
             pos = atomicAdd(seg_fill, (unsigned long long)n);  // counts even what no longer fits: the host sees the overflow
-            *fill = 0;
+            *(volatile uint32_t *)fill = 0;
         }
         pos = __shfl((unsigned long long)pos, 0, kWave);
         for (uint32_t i = lane; i < n; i += kWave)
