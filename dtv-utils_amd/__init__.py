@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
     "papr_hip_estimate", "papr_hip_stats_sweep", "papr_hip_get_sweep_info", "papr_guess_levels",
     "papr_hip_estimate_file", "papr_hip_load_file_sweep", "papr_hip_shard_fits",
+    "papr_level_key", "papr_sweep_bands", "papr_sweep_resolve",
 )
 
 
@@ -187,6 +188,12 @@ def lib() -> C.CDLL:
     L.papr_guess_levels.restype = i32
     L.papr_hip_stats_sweep.argtypes = [vp, vp, i32, C.POINTER(Stats)]
     L.papr_hip_estimate_file.argtypes = [vp, C.c_char_p, u64, u64, C.POINTER(Stats)]
+    L.papr_level_key.argtypes = [C.c_float]
+    L.papr_level_key.restype = C.c_uint32
+    L.papr_sweep_bands.argtypes = [vp, i32, i32, vp, vp]
+    L.papr_sweep_bands.restype = i32
+    L.papr_sweep_resolve.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp]
+    L.papr_sweep_resolve.restype = i32
     L.papr_hip_shard_fits.argtypes = [vp, u64]
     L.papr_hip_shard_fits.restype = i32
     L.papr_hip_load_file_sweep.argtypes = [vp, C.c_char_p, u64, u64, vp, i32]
@@ -236,6 +243,30 @@ def guess_levels(est_total: Stats, graph: bool, max_db: float = None) -> np.ndar
     n = lib().papr_guess_levels(C.byref(est_total), int(bool(graph)), float(max_db), buf.ctypes.data_as(C.c_void_p),
                                 MAX_LEVELS)
     return buf[:n].copy()
+
+
+def sweep_bands(guess_table: np.ndarray, band_log2: int = 14):
+    """(keys, edges) of the bands around the guessed thresholds (papr_sweep_bands), or None without a band form."""
+    lv = np.ascontiguousarray(guess_table, dtype=np.float32)
+    keys = np.zeros(max(lv.size, 1), dtype=np.uint32)
+    edges = np.zeros(2 * max(lv.size, 1), dtype=np.uint32)
+    m = lib().papr_sweep_bands(lv.ctypes.data_as(C.c_void_p), lv.size, band_log2, keys.ctypes.data_as(C.c_void_p),
+                               edges.ctypes.data_as(C.c_void_p))
+    return (keys[:m].copy(), edges[:2 * m].copy()) if m > 0 else None
+
+
+def sweep_resolve(guess_keys: np.ndarray, band_log2: int, above_band: np.ndarray, level_table: np.ndarray,
+                  stash_above: np.ndarray):
+    """counts_above for the true table from a sweep's leftovers (papr_sweep_resolve), or None if out of band."""
+    gk = np.ascontiguousarray(guess_keys, dtype=np.uint32)
+    ab = np.ascontiguousarray(above_band, dtype=np.uint64)
+    lv = np.ascontiguousarray(level_table, dtype=np.float32)
+    sa = np.ascontiguousarray(stash_above, dtype=np.uint64)
+    out = np.zeros(lv.size, dtype=np.uint64)
+    ok = lib().papr_sweep_resolve(gk.ctypes.data_as(C.c_void_p), gk.size, band_log2, ab.ctypes.data_as(C.c_void_p),
+                                  lv.ctypes.data_as(C.c_void_p), lv.size, sa.ctypes.data_as(C.c_void_p),
+                                  out.ctypes.data_as(C.c_void_p))
+    return out if ok else None
 
 
 def exact_chain(programs: Sequence[bytes]) -> float:

@@ -10,6 +10,7 @@
 #define _FILE_OFFSET_BITS 64
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 
@@ -123,6 +124,95 @@ int papr_guess_levels(const papr_stats *est_total, int graph, double max_db, flo
         }
     }
     return nl;
+}
+
+/* ---- one-sweep mode: the host halves of the speculation (papr_sweep.hip) -------------------------- */
+
+uint32_t papr_level_key(float t)
+{
+    uint32_t bits;
+    if (t != t)
+        return UINT32_MAX;
+    if (t < 0.0f)
+        return 0u;
+    if (t == 0.0f)
+        return 1u;
+    memcpy(&bits, &t, 4);
+    return bits >= 0x7F800000u ? UINT32_MAX : bits + 1u;
+}
+
+static int cmp_u32(const void *a, const void *b)
+{
+    const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return (x > y) - (x < y);
+}
+
+int papr_sweep_bands(const float *guess_levels, int nlevels, int band_log2, uint32_t *keys, uint32_t *edges)
+{
+    if (!guess_levels || !keys || !edges || nlevels <= 0 || band_log2 < 1 || band_log2 > 24)
+        return 0;
+    const uint32_t half = 1u << band_log2;
+    int m = 0;
+    for (int j = 0; j < nlevels; j++) {
+        const uint32_t key = papr_level_key(guess_levels[j]);
+        if (key != UINT32_MAX)
+            keys[m++] = key;
+    }
+    if (m == 0)
+        return 0;
+    qsort(keys, (size_t)m, sizeof(uint32_t), cmp_u32);
+    int u = 1;
+    for (int j = 1; j < m; j++)
+        if (keys[j] != keys[u - 1])
+            keys[u++] = keys[j];
+    m = u;
+    for (int j = 0; j < m; j++) {
+        const uint32_t g = keys[j];
+        /* normal floats only, and neighbouring bands must not touch */
+        if (g < 0x00800000u + half || g >= 0x7F800000u - half || (j && g - half <= keys[j - 1] + half))
+            return 0;
+        edges[2 * j] = g - half;
+        edges[2 * j + 1] = g + half;
+    }
+    return m;
+}
+
+int papr_sweep_resolve(const uint32_t *guess_keys, int nguess, int band_log2, const uint64_t *above_band,
+                       const float *levels, int nlevels, const uint64_t *stash_above, uint64_t *counts_above)
+{
+    if (nlevels < 0 || nguess <= 0 || !guess_keys || !above_band || (nlevels && (!levels || !stash_above || !counts_above)))
+        return 0;
+    const uint32_t half = 1u << band_log2;
+    /* pass 1: every true threshold must lie inside a band (matched by value: the true table may be longer or
+     * shorter than the guess); levels nothing can exceed need no band */
+    for (int pass = 0; pass < 2; pass++) {
+        for (int l = 0; l < nlevels; l++) {
+            const uint32_t t = papr_level_key(levels[l]);
+            if (t == UINT32_MAX) {
+                if (pass)
+                    counts_above[l] = 0;
+                continue;
+            }
+            int lo = 0, hi = nguess; /* first guess key >= t */
+            while (lo < hi) {
+                const int mid = (lo + hi) / 2;
+                if (guess_keys[mid] < t)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            int band = -1;
+            if (lo < nguess && guess_keys[lo] - t <= half)
+                band = lo;
+            else if (lo > 0 && t - guess_keys[lo - 1] <= half)
+                band = lo - 1;
+            if (band < 0)
+                return 0;
+            if (pass)
+                counts_above[l] = above_band[band] + stash_above[l];
+        }
+    }
+    return 1;
 }
 
 int papr_file_samples(const char *path, uint64_t *nsamples)

@@ -539,18 +539,10 @@ void apply_nan_key(papr_stats *out, unsigned long long key)
 // ---- pass 2 table construction ----------------------------------------------
 constexpr uint32_t kNever = 0xFFFFFFFFu;
 
-// smallest bit pattern of a non-negative float that is > t (see papr_kernels.hip)
-uint32_t level_key(float t)
+// smallest bit pattern of a non-negative float that is > t: papr_level_key (papr_host.c)
+inline uint32_t level_key(float t)
 {
-    if (t != t)
-        return kNever;
-    if (t < 0.0f)
-        return 0u;
-    if (t == 0.0f)
-        return 1u;
-    uint32_t bits;
-    memcpy(&bits, &t, 4);
-    return bits >= 0x7F800000u ? kNever : bits + 1u;
+    return papr_level_key(t);
 }
 
 struct CcdfPlan {
@@ -884,42 +876,27 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
     *reason = PAPR_SWEEP_NO_BANDS;
     if (nlevels <= 0 || nlevels > PAPR_HIP_MAX_LEVELS)
         return PAPR_OK;
-    // guessed keys -> band edges lo_0 < hi_0 < lo_1 < hi_1 < ...
-    std::vector<uint32_t> &gkeys = run->gkeys;
-    gkeys.clear();
-    for (int j = 0; j < nlevels; j++) {
-        const uint32_t key = level_key(guess_levels[j]);
-        if (key != kNever)
-            gkeys.push_back(key);
-    }
-    std::sort(gkeys.begin(), gkeys.end());
-    gkeys.erase(std::unique(gkeys.begin(), gkeys.end()), gkeys.end());
-    if (gkeys.empty())
-        return PAPR_OK;
-    // widest band (<= the configured width) whose edges stay apart and still have a LUT form
-    run->variant = variant_of(ctx, SWEEP);
+    // widest band (<= the configured width) that has a band form (papr_sweep_bands) and whose edges have a LUT form
     int vblock = 512;
+    run->variant = variant_of(ctx, SWEEP);
     (void)papr_sweep_geometry(run->variant, &vblock, &run->tile, &run->stash_lds);
+    std::vector<uint32_t> &gkeys = run->gkeys;
     CcdfPlan &bands = run->bands;
     run->half = 0;
     for (int log2w = info.band_log2; log2w >= std::max(info.band_log2 - 3, 8) && !run->half; log2w--) {
-        const uint32_t h = 1u << log2w;
-        bands.keys.clear();
-        bool ok = true;
-        for (size_t j = 0; j < gkeys.size() && ok; j++) {
-            const uint32_t g = gkeys[j];
-            ok = g >= 0x00800000u + h && g < 0x7F800000u - h && !(j && g - h <= gkeys[j - 1] + h);  // bands must not touch
-            bands.keys.push_back(g - h);
-            bands.keys.push_back(g + h);
-        }
-        if (!ok)
-            continue;
+        gkeys.assign((size_t)nlevels, 0);
+        bands.keys.assign(2 * (size_t)nlevels, 0);
+        const int m = papr_sweep_bands(guess_levels, nlevels, log2w, gkeys.data(), bands.keys.data());
+        if (m <= 0)
+            continue;  // (a narrower band may still fit between crowded thresholds)
+        gkeys.resize((size_t)m);
+        bands.keys.resize(2 * (size_t)m);
         char keep[sizeof(ctx->err)];
         memcpy(keep, ctx->err, sizeof(keep));
         const bool fits = finish_plan(ctx, &bands, vblock, run->stash_lds) == PAPR_OK && bands.lut;
         memcpy(ctx->err, keep, sizeof(keep));  // not an error of this call: a narrower band or the plain pass follows
         if (fits) {
-            run->half = h;
+            run->half = 1u << log2w;
             info.band_log2 = log2w;
         }
     }
@@ -2127,27 +2104,19 @@ void counts_from_histogram(const papr_hip_ctx *ctx, const CcdfPlan &plan, int nl
 
 // Answer papr_hip_ccdf from the last one-sweep pass if every true threshold lies inside the band of its guess:
 // samples outside the bands were decided by the sweep, the stash holds the rest.
-int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, int nlevels, uint64_t *counts_above, bool *done)
+int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *levels, int nlevels, uint64_t *counts_above,
+                       bool *done)
 {
     papr_hip_sweep_info &info = ctx->sweep_info;
     *done = false;
     info.resolved = 0;
-    // every true threshold must lie inside one of the bands (matched by value: the true table may be
-    // longer or shorter than the guess, e.g. when the sampled peak missed the real one)
-    std::vector<int> band_of(plan.P.nkeys, -1);
-    for (uint32_t i = 0; i < plan.P.nkeys; i++) {
-        const uint32_t t = plan.keys[i];
-        const auto it = std::lower_bound(ctx->sweep_keys.begin(), ctx->sweep_keys.end(), t);
-        int j = -1;
-        if (it != ctx->sweep_keys.end() && *it - t <= ctx->sweep_half)
-            j = (int)(it - ctx->sweep_keys.begin());
-        else if (it != ctx->sweep_keys.begin() && t - *(it - 1) <= ctx->sweep_half)
-            j = (int)(it - ctx->sweep_keys.begin()) - 1;
-        if (j < 0) {
-            info.reason = PAPR_SWEEP_OUT_OF_BAND;
-            return PAPR_OK;
-        }
-        band_of[i] = j;
+    // every true threshold must lie inside one of the bands (papr_sweep_resolve, first without stash counts: a dry run)
+    const int band_log2 = __builtin_ctz(ctx->sweep_half);  // of the sweep that left this state behind
+    std::vector<uint64_t> stash_above((size_t)nlevels, 0);
+    if (!papr_sweep_resolve(ctx->sweep_keys.data(), (int)ctx->sweep_keys.size(), band_log2, ctx->sweep_even_above.data(),
+                            levels, nlevels, stash_above.data(), counts_above)) {
+        info.reason = PAPR_SWEEP_OUT_OF_BAND;
+        return PAPR_OK;
     }
     if (ctx->sweep_overflow) {
         info.reason = PAPR_SWEEP_STASH_FULL;
@@ -2173,10 +2142,9 @@ int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, int nlevels, uin
     } else {
         memset(ctx->h_hist, 0, (size_t)(m + 1) * sizeof(unsigned long long));
     }
-    counts_from_histogram(ctx, plan, nlevels, counts_above);  // stash powers above each level ...
-    for (int j = 0; j < nlevels; j++)
-        if (plan.pos[j] >= 0)
-            counts_above[j] += ctx->sweep_even_above[band_of[plan.pos[j]]];  // ... + everything above its band
+    counts_from_histogram(ctx, plan, nlevels, stash_above.data());  // stash powers above each level ...
+    (void)papr_sweep_resolve(ctx->sweep_keys.data(), (int)ctx->sweep_keys.size(), band_log2, ctx->sweep_even_above.data(),
+                             levels, nlevels, stash_above.data(), counts_above);  // ... + everything above its band
     info.resolved = 1;
     info.reason = PAPR_SWEEP_OK;
     *done = true;
@@ -2279,7 +2247,7 @@ int papr_hip_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t 
     }
     if (ctx->sweep_valid) {  // the one-sweep pass already decided everything outside the bands
         bool done = false;
-        rc = resolve_from_sweep(ctx, plan, nlevels, counts_above, &done);
+        rc = resolve_from_sweep(ctx, plan, levels, nlevels, counts_above, &done);
         if (rc || done)
             return rc;
     }

@@ -275,6 +275,22 @@ int papr_hip_load_file_sweep(papr_hip_ctx *ctx, const char *path, uint64_t first
                              const float *guess_levels, int nlevels);
 int papr_hip_get_sweep_info(const papr_hip_ctx *ctx, papr_hip_sweep_info *out);
 
+/* The GPU-free halves of the one-sweep bookkeeping — what the runtime itself calls, exported so that the
+ * speculation's logic can be checked without a GPU (tests/test_sweep_host.py):
+ *   papr_level_key      smallest bit pattern of a non-negative float that is > level (the integer compare
+ *                       `bits(v) >= key` is the reference's float compare `v > level`); 0 for negative levels,
+ *                       UINT32_MAX when nothing can exceed the level (NaN, +Inf)
+ *   papr_sweep_bands    guessed levels -> unique ascending keys and the band edges key -+ 2^band_log2
+ *                       (edges[2j], edges[2j+1]); returns the number of keys, or 0 when the guess has no band
+ *                       form (no usable level, denormal/huge thresholds, bands that touch)
+ *   papr_sweep_resolve  counts_above[l] for the true levels from what a sweep left behind: above_band[j] =
+ *                       samples at or above band j's upper edge, stash_above[l] = stash powers > levels[l].
+ *                       Returns 1, or 0 if some true level lies in no band (then nothing is written). */
+uint32_t papr_level_key(float level);
+int papr_sweep_bands(const float *guess_levels, int nlevels, int band_log2, uint32_t *keys, uint32_t *edges);
+int papr_sweep_resolve(const uint32_t *guess_keys, int nguess, int band_log2, const uint64_t *above_band,
+                       const float *levels, int nlevels, const uint64_t *stash_above, uint64_t *counts_above);
+
 /* ---- pass 2 (papr.c:143-153 / 175-185) ---------------------------------- */
 /* counts_above[j] = number of shard samples whose power is > levels[j]
  * (float compare, strict, NaN never counts).  Levels may be any floats. */
