@@ -20,6 +20,8 @@ def san_dir(tmp_path_factory):
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "dtv-utils_amd", "csrc")]
     subprocess.check_call(["gcc", *SAN, "-ffp-contract=off", *inc, os.path.join(ROOT, "tests", "c", "chain_harness.c"),
                            os.path.join(ROOT, "dtv-utils_amd", "csrc", "papr_host.c"), "-o", str(d / "chain"), "-lm"])
+    subprocess.check_call(["gcc", *SAN, "-ffp-contract=off", *inc, os.path.join(ROOT, "tests", "c", "sweep_harness.c"),
+                           os.path.join(ROOT, "dtv-utils_amd", "csrc", "papr_host.c"), "-o", str(d / "sweep"), "-lm"])
     subprocess.check_call(["gcc", *SAN, "-ffp-contract=off", "-DPAPR_ORACLE_MAIN", *inc,
                            os.path.join(ROOT, "oracle", "papr_oracle.c"), "-o", str(d / "oracle"), "-lm"])
     return d
@@ -60,6 +62,18 @@ def test_chain_under_sanitizers_valid_and_damaged_programs(orc, san_dir):
         bad.write_bytes(bytes(b))
         p = run(san_dir / "chain", bad)
         assert p.returncode == 0 and p.stdout.split()[0] in (b"0", b"-3", b"-8"), (trial, p.stdout)
+
+
+def test_sweep_host_logic_under_sanitizers(san_dir):
+    """papr_guess_levels / papr_sweep_bands / papr_sweep_resolve (the host half of the one-sweep mode) on random and
+    hostile tables — NaN, +-0, denormal, huge, duplicated, unsorted levels, every band width — in exact-size heap
+    blocks: no sanitizer report, and all three outcomes (resolved, refused, no band form) occur."""
+    totals = np.zeros(3, dtype=np.int64)
+    for seed in (1, 2, 3, 20260929):
+        p = run(san_dir / "sweep", seed, 400)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        totals += np.array(p.stdout.split(), dtype=np.int64)
+    assert np.all(totals > 0), totals
 
 
 def test_oracle_under_sanitizers(san_dir):
