@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -30,6 +31,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -57,12 +59,78 @@ struct ReadBatch {
     int error = 0;
 };
 
+// CPUs of the NUMA node the GPU hangs off (its PCIe root): the ingest's reader threads run there and the pinned
+// staging buffers are first touched there, so that the H2D DMA never crosses the socket interconnect.
+// Empty set = unknown / single node / PAPR_NUMA=0.
+struct CpuSet {
+    cpu_set_t set;
+    bool valid = false;
+};
+
+CpuSet numa_cpus_of_device(int device)
+{
+    CpuSet out;
+    CPU_ZERO(&out.set);
+    const char *env = getenv("PAPR_NUMA");
+    if (env && env[0] == '0')
+        return out;
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return out;
+    }
+    for (char *c = bus; *c; c++)
+        *c = (char)tolower(*c);
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *fp = fopen(path, "r");
+    int node = -1;
+    if (!fp || fscanf(fp, "%d", &node) != 1)
+        node = -1;
+    if (fp)
+        fclose(fp);
+    if (node < 0)
+        return out;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    fp = fopen(path, "r");
+    if (!fp)
+        return out;
+    char list[4096] = "";
+    if (!fgets(list, sizeof(list), fp))
+        list[0] = 0;
+    fclose(fp);
+    // "0-63,128-191" -> set, intersected with what this process may use
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
+        return out;
+    int count = 0;
+    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k == 1)
+            b = a;
+        if (k < 1)
+            continue;
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &allowed)) {
+                CPU_SET(c, &out.set);
+                count++;
+            }
+    }
+    out.valid = count > 0 && count < CPU_COUNT(&allowed);  // nothing to gain when the node is all we have
+    return out;
+}
+
 class ReaderPool {
   public:
-    explicit ReaderPool(int n)
+    explicit ReaderPool(int n, const CpuSet &cpus = CpuSet())
     {
         for (int i = 0; i < n; i++)
-            threads_.emplace_back([this] { run(); });
+            threads_.emplace_back([this, cpus] {
+                if (cpus.valid)
+                    (void)sched_setaffinity(0, sizeof(cpus.set), &cpus.set);
+                run();
+            });
     }
     ~ReaderPool()
     {
@@ -183,6 +251,7 @@ struct papr_hip_ctx {
     size_t stage_bytes = 0;
     ReaderPool *pool = nullptr;
     int reader_threads = 0;
+    bool ingest_numa = false;   // reader threads and staging buffers are bound to the GPU's NUMA node
 
     // exact-sum mode (papr_exact.hip)
     bool exact = false;
@@ -798,14 +867,25 @@ int read_samples(const FileSrc &fs, uint64_t s0, uint64_t cnt, unsigned char *ds
 int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage)
 {
     if (!ctx->stage_bytes) {
-        size_t mb = (size_t)std::max(1, env_int("PAPR_CHUNK_MB", 32));
+        size_t mb = (size_t)std::max(1, env_int("PAPR_CHUNK_MB", 16));
         ctx->stage_bytes = (mb << 20) / (kChunkAlign * 8) * (kChunkAlign * 8);
         if (!ctx->stage_bytes)
             ctx->stage_bytes = kChunkAlign * 8;
     }
+    const CpuSet near_gpu = numa_cpus_of_device(ctx->device);
     for (int b = 0; b < kNumBuf; b++) {
-        if (!ctx->h_stage[b])
-            HIPCHK(ctx, hipHostMalloc(&ctx->h_stage[b], ctx->stage_bytes, hipHostMallocDefault));
+        if (!ctx->h_stage[b]) {
+            // pinned pages are placed where they are first touched: do that on the GPU's NUMA node
+            cpu_set_t before;
+            const bool moved = near_gpu.valid && sched_getaffinity(0, sizeof(before), &before) == 0 &&
+                               sched_setaffinity(0, sizeof(near_gpu.set), &near_gpu.set) == 0;
+            const hipError_t e = hipHostMalloc(&ctx->h_stage[b], ctx->stage_bytes, hipHostMallocDefault);
+            if (e == hipSuccess && moved)
+                memset(ctx->h_stage[b], 0, ctx->stage_bytes);
+            if (moved)
+                (void)sched_setaffinity(0, sizeof(before), &before);
+            HIPCHK(ctx, e);
+        }
         if (!ctx->ev_copy[b])
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_copy[b], hipEventDisableTiming));
         if (!ctx->ev_kernel[b])
@@ -820,7 +900,8 @@ int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage)
         if (n <= 0)
             n = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
         ctx->reader_threads = n;
-        ctx->pool = new ReaderPool(n);
+        ctx->pool = new ReaderPool(n, near_gpu);
+        ctx->ingest_numa = near_gpu.valid;
     }
     return PAPR_OK;
 }
@@ -1067,6 +1148,7 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
         ctx->ingest.chunks = nchunks;
         ctx->ingest.reader_threads = ctx->reader_threads;
         ctx->ingest.o_direct = fs.fd_direct >= 0;
+        ctx->ingest.numa_bound = ctx->ingest_numa ? 1 : 0;
     }
     // queue the slices of chunk c for the reader threads (buffer c % kNumBuf must be free)
     std::vector<ReadBatch> batches(nchunks);

@@ -367,12 +367,12 @@ int main(int argc, char **argv)
                 "\"estimate_s\": %.6f, \"shards_swept\": %d, \"shards_resolved_from_sweep\": %d, "
                 "\"ingest_pass1_s\": %.6f, \"exact_sum\": %d, \"exact_sum_s\": %.6f, \"pass2_s\": %.6f, \"total_s\": %.6f, \"msamples_per_s\": %.3f, "
                 "\"ingest_GBps\": %.2f, \"gpu0_ingest\": {\"setup_s\": %.4f, \"read_s\": %.4f, \"buffer_wait_s\": %.4f, "
-                "\"issue_s\": %.4f, \"drain_s\": %.4f, \"chunks\": %llu, \"reader_threads\": %d, \"resident\": %d, \"o_direct\": %d}}\n",
+                "\"issue_s\": %.4f, \"drain_s\": %.4f, \"chunks\": %llu, \"reader_threads\": %d, \"resident\": %d, \"o_direct\": %d, \"numa_bound\": %d}}\n",
                 (unsigned long long)nsamples, (unsigned long long)nsamples * 8, ngpu, nlevels, t_open - t0,
                 t_est - t_open, swept, resolved, t1 - t_est,
                 exact_done, t1x - t1, t2 - t1x, t3 - t0, (double)nsamples / (t3 - t0) / 1e6, (double)nsamples * 8 / (t1 - t_est) / 1e9,
                 it.setup_s, it.read_s, it.buffer_wait_s, it.issue_s, it.drain_s, (unsigned long long)it.chunks,
-                it.reader_threads, it.resident, it.o_direct);
+                it.reader_threads, it.resident, it.o_direct, it.numa_bound);
     }
 
     for (int g = 0; g < ngpu; g++) {
