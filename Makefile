@@ -26,10 +26,21 @@ $(CSRC)/papr_sweep.o: $(CSRC)/papr_sweep.hip $(CSRC)/papr_kernels.h $(CSRC)/papr
 $(CSRC)/papr_exact.o: $(CSRC)/papr_exact.hip $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/papr_runtime.o: $(CSRC)/papr_runtime.cpp $(CSRC)/papr_kernels.h $(CSRC)/papr_exact_format.h include/papr_hip.h include/papr_synth.h
+RT_HDRS := $(CSRC)/papr_runtime_internal.h $(CSRC)/papr_kernels.h $(CSRC)/papr_exact_format.h include/papr_hip.h include/papr_synth.h
+$(CSRC)/papr_runtime.o: $(CSRC)/papr_runtime.cpp $(RT_HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIB): $(CSRC)/papr_kernels.o $(CSRC)/papr_sweep.o $(CSRC)/papr_exact.o $(CSRC)/papr_runtime.o $(CSRC)/papr_host.o
+$(CSRC)/papr_ingest.o: $(CSRC)/papr_ingest.cpp $(RT_HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/papr_sweep_rt.o: $(CSRC)/papr_sweep_rt.cpp $(RT_HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/papr_exact_rt.o: $(CSRC)/papr_exact_rt.cpp $(RT_HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(CSRC)/papr_kernels.o $(CSRC)/papr_sweep.o $(CSRC)/papr_exact.o $(CSRC)/papr_runtime.o $(CSRC)/papr_ingest.o \
+        $(CSRC)/papr_sweep_rt.o $(CSRC)/papr_exact_rt.o $(CSRC)/papr_host.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -lm -lpthread
 
 cli: bin/papr

@@ -1,0 +1,350 @@
+// papr_exact_rt.cpp — host side of the bit-exact sequential sum (papr_exact.hip): buffers, the classify / segment /
+// group / pack launch sequence, the sum program and its host-assembled fallback.
+
+#include "papr_runtime_internal.h"
+
+using namespace papr_rt;
+
+namespace papr_rt {
+
+// exact-sum mode: device buffers sized for the current shard
+int ensure_exact_buffers(papr_hip_ctx *ctx)
+{
+    const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
+    if (ntiles <= ctx->exact_tiles_cap && ctx->d_tile_sums)
+        return PAPR_OK;
+    if (ctx->d_tile_sums) (void)hipFree(ctx->d_tile_sums);
+    if (ctx->d_block_sums) (void)hipFree(ctx->d_block_sums);
+    if (ctx->d_tile_E) (void)hipFree(ctx->d_tile_E);
+    if (ctx->d_seg_D) (void)hipFree(ctx->d_seg_D);
+    if (ctx->d_groups) (void)hipFree(ctx->d_groups);
+    ctx->d_tile_sums = ctx->d_block_sums = ctx->d_seg_D = nullptr;
+    ctx->d_tile_E = nullptr;
+    ctx->d_groups = nullptr;
+    ctx->exact_tiles_cap = 0;
+    const uint64_t cap = std::max<uint64_t>(ntiles, 1024);
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_tile_sums, cap * PAPR_EXACT_TILE_WAVES * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_block_sums, (cap / 1024 + 2) * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_tile_E, cap * sizeof(int32_t)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_seg_D, cap * 2 * 2 * sizeof(double)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_groups, (cap / PAPR_EXACT_GROUP_TILES + 2) * sizeof(papr_exact_group)));
+    ctx->exact_tiles_cap = cap;
+    return PAPR_OK;
+}
+
+// exact-sum mode on a re-streamed shard: the fused sweep (rounding functions + pass 2) over one staged chunk,
+// and the unprovable tiles of that chunk kept for the sum program
+int launch_fused_chunk(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *chunk, uint64_t s0, uint64_t cnt, bool last)
+{
+    const uint64_t tile0 = s0 / PAPR_EXACT_TILE_SAMPLES, ntiles = cnt / PAPR_EXACT_TILE_SAMPLES;
+    const uint32_t tail = (uint32_t)(cnt - ntiles * PAPR_EXACT_TILE_SAMPLES);  // only the last chunk has one
+    const uint64_t nsegs = 2 * ntiles;
+    const uint64_t wg_waves = (uint64_t)papr_exact_fused_waves();
+    const int per_cu = std::max(1, env_int("PAPR_EXACT_WG_PER_CU", 2));
+    const int blocks =
+        (int)std::max<uint64_t>(1, std::min<uint64_t>((nsegs + wg_waves - 1) / wg_waves, (uint64_t)ctx->num_cus * per_cu));
+    time_begin(ctx, 2, cnt * 8);
+    papr_launch_exact_segments_ccdf(ctx->stream, blocks, chunk, nsegs, ctx->d_tile_E + tile0, ctx->d_seg_D + 4 * tile0,
+                                    chunk + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, tail, ctx->d_table, plan.P,
+                                    plan.lds_bytes, ctx->d_hist);
+    time_end(ctx);
+    papr_launch_exact_capture(ctx->stream, chunk, tile0, ntiles, ctx->d_ambig + kCapRaw, ctx->d_ambig + 2 * kCapRaw,
+                              kCapRaw, ctx->d_raw_store);
+    HIPCHK(ctx, hipGetLastError());
+    if (last && tail)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_tail, chunk + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, (size_t)tail * 8,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+    return PAPR_OK;
+}
+
+}  // namespace papr_rt
+
+extern "C" {
+
+// ---- bit-exact mean ---------------------------------------------------------------
+
+int papr_hip_set_exact(papr_hip_ctx *ctx, int enabled)
+{
+    if (!ctx)
+        return PAPR_E_ARG;
+    if ((enabled != 0) != ctx->exact) {
+        ctx->exact = enabled != 0;
+        ctx->exact_valid = false;
+        if (ctx->resident)
+            ctx->have_file_stats = false;  // pass 1 is re-run over the resident shard in the other mode
+    }
+    return PAPR_OK;
+}
+
+}  // extern "C"
+
+namespace papr_rt {
+
+int exact_preconditions(papr_hip_ctx *ctx, double before, bool allow_restreamed)
+{
+    if (!ctx->exact || !ctx->exact_valid || !ctx->loaded)
+        return fail(ctx, PAPR_E_STATE, "exact sum needs papr_hip_set_exact(1) and papr_hip_stats on the current shard first");
+    if (!ctx->resident && !allow_restreamed)
+        return fail(ctx, PAPR_E_STATE, "papr_hip_exact_program needs a shard that is resident in HBM "
+                                       "(re-streamed shards: papr_hip_ccdf_exact)");
+    if (!(before >= 0.0) || !std::isfinite(before))
+        return fail(ctx, PAPR_E_ARG, "`before` must be a finite, non-negative sum");
+    return PAPR_OK;
+}
+
+int reserve_program(papr_hip_ctx *ctx, size_t want)  // grow the pinned program buffer, keeping its contents
+{
+    if (want <= ctx->h_program_cap)
+        return PAPR_OK;
+    unsigned char *fresh = nullptr;
+    const size_t cap = std::max<size_t>(want + want / 4, (size_t)1 << 20);
+    HIPCHK(ctx, hipHostMalloc((void **)&fresh, cap, hipHostMallocMapped));
+    if (ctx->h_program) {
+        memcpy(fresh, ctx->h_program, ctx->h_program_cap);
+        (void)hipHostFree(ctx->h_program);
+    }
+    ctx->h_program = fresh;
+    ctx->h_program_cap = cap;
+    return PAPR_OK;
+}
+
+// Device side of the exact sum: classify tiles, one sweep over the samples for the per-segment
+// rounding functions (with pass 2 fused in when `fused` is given), pre-compose the groups and gather
+// the sum program into mapped host memory — one stream synchronisation in total.  *bytes = 0 means
+// the device-side gather overflowed its lists and the caller has to assemble the program itself.
+int run_exact_device(papr_hip_ctx *ctx, double before, uint64_t n_total, const CcdfPlan *fused, size_t *bytes)
+{
+    const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
+    const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
+    const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
+    // margin >= the worst-case relative drift of a sequential double sum of n_total non-negative terms
+    const double delta = std::max(1.0e-6, 8.0 * (double)std::max<uint64_t>(n_total, ctx->n) * 1.1102230246251565e-16);
+    *bytes = 0;
+    int rc = ensure_exact_buffers(ctx);
+    if (rc)
+        return rc;
+    if (!ctx->d_plan) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_mixed_list, kCapMixed * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_raw_list, kCapRaw * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_plan, sizeof(papr_exact_plan)));
+    }
+    rc = reserve_program(ctx, sizeof(papr_exact_header) + ngroups * sizeof(papr_exact_group_rec) +
+                                  (size_t)kCapMixed * sizeof(papr_exact_mixed_rec) +
+                                  (size_t)kCapRaw * sizeof(papr_exact_raw_rec) + (size_t)tail * 8);
+    if (rc)
+        return rc;
+    unsigned char *program_dev = nullptr;
+    HIPCHK(ctx, hipHostGetDevicePointer((void **)&program_dev, ctx->h_program, 0));
+    const uint64_t nsegs = 2 * ntiles;
+    if (ctx->resident) {
+        // plain sweep: 4-wave workgroups, 2 per CU; fused sweep: 8-wave workgroups, 2 per CU (16 waves share the LDS tables)
+        const int per_cu = std::max(1, env_int("PAPR_EXACT_WG_PER_CU", 2));
+        const uint64_t wg_waves = fused ? (uint64_t)papr_exact_fused_waves() : 4;
+        const int blocks = (int)std::max<uint64_t>(
+            1, std::min<uint64_t>((nsegs + wg_waves - 1) / wg_waves, (uint64_t)ctx->num_cus * per_cu));
+        time_begin(ctx, 2, ctx->n * 8);
+        papr_launch_exact_classify(ctx->stream, ctx->d_tile_sums, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E,
+                                   nullptr, 0, nullptr, nullptr);
+        if (fused)
+            papr_launch_exact_segments_ccdf(ctx->stream, blocks, ctx->d_iq, nsegs, ctx->d_tile_E, ctx->d_seg_D,
+                                            ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, tail, ctx->d_table,
+                                            fused->P, fused->lds_bytes, ctx->d_hist);
+        else
+            papr_launch_exact_segments(ctx->stream, blocks, ctx->d_iq, nsegs, ctx->d_tile_E, ctx->d_seg_D);
+        papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
+        time_end(ctx);
+        papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, ctx->d_iq, nullptr,
+                               ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, ctx->n, tail, ctx->d_mixed_list,
+                               kCapMixed, ctx->d_raw_list, kCapRaw, ctx->d_plan, program_dev);
+    } else {
+        // re-streamed shard: classify (also listing the unprovable tiles), then the file goes through the
+        // staging buffers once more with the fused sweep on every chunk
+        if (!fused)
+            return fail(ctx, PAPR_E_STATE, "a re-streamed shard builds its sum program in the pass-2 sweep only");
+        if (!ctx->d_ambig) {
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_ambig, (2 * kCapRaw + 1) * sizeof(uint32_t)));
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_raw_store, (size_t)kCapRaw * PAPR_EXACT_TILE_SAMPLES * 8));
+        }
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_ambig + 2 * kCapRaw, 0, sizeof(uint32_t), ctx->stream));
+        papr_launch_exact_classify(ctx->stream, ctx->d_tile_sums, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E,
+                                   ctx->d_ambig, kCapRaw, ctx->d_ambig + 2 * kCapRaw, ctx->d_ambig + kCapRaw);
+        HIPCHK(ctx, hipGetLastError());
+        rc = stream_file(ctx, PASS_STREAM_CCDF_EXACT, fused, nullptr);
+        if (rc)
+            return rc;
+        papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
+        papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, nullptr,
+                               ctx->d_raw_store, ctx->d_tail, ctx->n, tail, ctx->d_mixed_list, kCapMixed, ctx->d_raw_list,
+                               kCapRaw, ctx->d_plan, program_dev);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (fused)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(fused->P.nkeys + 1) * sizeof(unsigned long long),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    papr_exact_header h;
+    memcpy(&h, ctx->h_program, sizeof(h));
+    if (h.magic == PAPR_EXACT_MAGIC && h.reserved == 0 && h.ngroups == ngroups && h.nsamples == ctx->n &&
+        !env_int("PAPR_EXACT_HOST_ASSEMBLY", 0))  // (the env switch lets the tests exercise the fallback)
+        *bytes = sizeof(h) + ngroups * sizeof(papr_exact_group_rec) + (size_t)h.nmixed * sizeof(papr_exact_mixed_rec) +
+                 (size_t)h.nraw * sizeof(papr_exact_raw_rec) + (size_t)tail * 8;
+    return PAPR_OK;
+}
+
+// Host-driven assembly, for the (never yet seen) case that a shard has more mixed groups / raw tiles
+// than the device-side lists hold.
+int assemble_program_on_host(papr_hip_ctx *ctx, const void **program, size_t *bytes);
+
+int assemble_program_on_host(papr_hip_ctx *ctx, const void **program, size_t *bytes)
+{
+    const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
+    const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
+    const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
+    std::vector<papr_exact_group> groups(ngroups);
+    if (ngroups) {
+        HIPCHK(ctx, hipMemcpyAsync(groups.data(), ctx->d_groups, ngroups * sizeof(papr_exact_group),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // what has to travel in detail: mixed groups (per-tile classes + per-segment pairs) ...
+    std::vector<uint64_t> mixed;
+    for (uint64_t g = 0; g < ngroups; g++)
+        if (groups[g].E == PAPR_EXACT_AMBIG)
+            mixed.push_back(g);
+    auto reserve = [&](size_t want) -> int { return reserve_program(ctx, want); };
+    static_assert(sizeof(papr_exact_group) == sizeof(papr_exact_group_rec), "group record layout");
+    const size_t off_groups = sizeof(papr_exact_header);
+    const size_t off_mixed = off_groups + ngroups * sizeof(papr_exact_group_rec);
+    const size_t off_raw = off_mixed + mixed.size() * sizeof(papr_exact_mixed_rec);
+    int rc = reserve(off_raw + (size_t)tail * 8);
+    if (rc)
+        return rc;
+    if (ngroups)
+        memcpy(ctx->h_program + off_groups, groups.data(), ngroups * sizeof(papr_exact_group_rec));
+    for (size_t k = 0; k < mixed.size(); k++) {
+        const uint64_t g = mixed[k];
+        papr_exact_mixed_rec *m = (papr_exact_mixed_rec *)(ctx->h_program + off_mixed + k * sizeof(papr_exact_mixed_rec));
+        const uint64_t t0 = g * PAPR_EXACT_GROUP_TILES, t1 = std::min<uint64_t>(t0 + PAPR_EXACT_GROUP_TILES, ntiles);
+        m->group = g;
+        for (uint64_t j = t1 - t0; j < PAPR_EXACT_GROUP_TILES; j++)
+            m->tile_E[j] = PAPR_EXACT_ZERO;
+        memset(m->seg_D, 0, sizeof(m->seg_D));
+        HIPCHK(ctx, hipMemcpyAsync(m->tile_E, ctx->d_tile_E + t0, (t1 - t0) * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(m->seg_D, ctx->d_seg_D + 4 * t0, (t1 - t0) * 2 * 2 * sizeof(double),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (!mixed.empty())
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // ... and their tiles that are not provably inside one binade (raw samples)
+    std::vector<uint64_t> raw;
+    for (size_t k = 0; k < mixed.size(); k++) {
+        const papr_exact_mixed_rec *m =
+            (const papr_exact_mixed_rec *)(ctx->h_program + off_mixed + k * sizeof(papr_exact_mixed_rec));
+        for (uint64_t j = 0; j < PAPR_EXACT_GROUP_TILES; j++)
+            if (m->tile_E[j] == PAPR_EXACT_AMBIG)
+                raw.push_back(mixed[k] * PAPR_EXACT_GROUP_TILES + j);
+    }
+    const size_t off_tail = off_raw + raw.size() * sizeof(papr_exact_raw_rec);
+    const size_t total = off_tail + (size_t)tail * 8;
+    rc = reserve(total);
+    if (rc)
+        return rc;
+    for (size_t k = 0; k < raw.size(); k++) {
+        papr_exact_raw_rec *r = (papr_exact_raw_rec *)(ctx->h_program + off_raw + k * sizeof(papr_exact_raw_rec));
+        r->tile = raw[k];
+        HIPCHK(ctx, hipMemcpyAsync(r->iq, ctx->d_iq + 2 * raw[k] * PAPR_EXACT_TILE_SAMPLES, PAPR_EXACT_TILE_SAMPLES * 8,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (tail)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_program + off_tail, ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES,
+                                   (size_t)tail * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (!raw.empty() || tail)
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    papr_exact_header h;
+    memset(&h, 0, sizeof(h));
+    h.magic = PAPR_EXACT_MAGIC;
+    h.version = PAPR_EXACT_VERSION;
+    h.nsamples = ctx->n;
+    h.ntiles = ntiles;
+    h.ngroups = ngroups;
+    h.tail_samples = tail;
+    h.nmixed = (uint32_t)mixed.size();
+    h.nraw = (uint32_t)raw.size();
+    memcpy(ctx->h_program, &h, sizeof(h));
+    *program = ctx->h_program;
+    *bytes = total;
+    return PAPR_OK;
+}
+
+}  // namespace papr_rt
+
+extern "C" {
+
+int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, const void **program, size_t *bytes)
+{
+    if (!ctx || !program || !bytes)
+        return PAPR_E_ARG;
+    int rc = exact_preconditions(ctx, before, false);
+    if (rc)
+        return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    rc = run_exact_device(ctx, before, n_total, nullptr, bytes);
+    if (rc)
+        return rc;
+    *program = ctx->h_program;
+    return *bytes ? PAPR_OK : assemble_program_on_host(ctx, program, bytes);
+}
+
+int papr_hip_ccdf_exact(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above, double before,
+                        uint64_t n_total, const void **program, size_t *bytes)
+{
+    if (!ctx || !program || !bytes || nlevels < 0 || (nlevels && (!levels || !counts_above)))
+        return PAPR_E_ARG;
+    if (nlevels > PAPR_HIP_MAX_LEVELS)
+        return fail(ctx, PAPR_E_LIMIT, "%d levels exceeds PAPR_HIP_MAX_LEVELS (%d)", nlevels, PAPR_HIP_MAX_LEVELS);
+    int rc = exact_preconditions(ctx, before, true);
+    if (rc)
+        return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CcdfPlan plan;
+    if (nlevels) {
+        rc = plan_ccdf(ctx, levels, nlevels, &plan);
+        if (rc)
+            return rc;
+    }
+    // the fused sweep holds the LUT form of the table plus the 36 KiB transpose buffer in LDS
+    size_t fused_lds = 0;
+    if (nlevels && plan.lut && plan.P.nkeys) {
+        plan.P.copies = std::min<uint32_t>(plan.P.copies, 4);
+        fused_lds = (size_t)plan.P.table_words * 4 + (size_t)plan.P.copies * (plan.P.nkeys + 1) * 4;
+        while (plan.P.copies > 1 && fused_lds > 12 * 1024) {  // two workgroups per CU: 2 x (64 KiB + this) <= 160 KiB
+            plan.P.copies--;
+            fused_lds = (size_t)plan.P.table_words * 4 + (size_t)plan.P.copies * (plan.P.nkeys + 1) * 4;
+        }
+        plan.lds_bytes = fused_lds;
+    }
+    const bool fuse = fused_lds != 0 && fused_lds + papr_exact_transpose_lds_bytes() <= 150 * 1024 && ctx->n > 0;
+    if (!fuse) {  // unusual level table: the two sweeps run one after the other
+        rc = papr_hip_ccdf(ctx, levels, nlevels, counts_above);
+        if (rc)
+            return rc;
+        return papr_hip_exact_program(ctx, before, n_total, program, bytes);
+    }
+    rc = upload_ccdf_table(ctx, plan);
+    if (rc)
+        return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_hist, 0, (size_t)(plan.P.nkeys + 1) * sizeof(unsigned long long), ctx->stream));
+    rc = run_exact_device(ctx, before, n_total, &plan, bytes);
+    if (rc)
+        return rc;
+    counts_from_histogram(ctx, plan, nlevels, counts_above);
+    *program = ctx->h_program;
+    if (*bytes)
+        return PAPR_OK;
+    if (!ctx->resident)  // the raw tiles of a re-streamed shard are gone once their chunk has left the device
+        return fail(ctx, PAPR_E_LIMIT, "too many binade crossings for the device-side program lists");
+    return assemble_program_on_host(ctx, program, bytes);
+}
+
+}  // extern "C"

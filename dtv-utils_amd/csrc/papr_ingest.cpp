@@ -1,0 +1,628 @@
+// papr_ingest.cpp — the file ingest engine of the host runtime (replaces the fread loops of reference papr.c:100-101,
+// 143-144, 175-176): reader threads -> pinned staging buffers -> hipMemcpyAsync -> the pass kernel on every chunk as it
+// lands; resident and re-streamed shards; the one-sweep ingest and the mean estimate of a file that is not loaded yet.
+
+#include "papr_runtime_internal.h"
+
+using namespace papr_rt;
+
+namespace papr_rt {
+
+CpuSet numa_cpus_of_device(int device)
+{
+    CpuSet out;
+    CPU_ZERO(&out.set);
+    const char *env = getenv("PAPR_NUMA");
+    if (env && env[0] == '0')
+        return out;
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return out;
+    }
+    for (char *c = bus; *c; c++)
+        *c = (char)tolower(*c);
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *fp = fopen(path, "r");
+    int node = -1;
+    if (!fp || fscanf(fp, "%d", &node) != 1)
+        node = -1;
+    if (fp)
+        fclose(fp);
+    if (node < 0)
+        return out;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    fp = fopen(path, "r");
+    if (!fp)
+        return out;
+    char list[4096] = "";
+    if (!fgets(list, sizeof(list), fp))
+        list[0] = 0;
+    fclose(fp);
+    // "0-63,128-191" -> set, intersected with what this process may use
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
+        return out;
+    int count = 0;
+    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k == 1)
+            b = a;
+        if (k < 1)
+            continue;
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &allowed)) {
+                CPU_SET(c, &out.set);
+                count++;
+            }
+    }
+    out.valid = count > 0 && count < CPU_COUNT(&allowed);  // nothing to gain when the node is all we have
+    return out;
+}
+
+// Fraction of the file that is in the page cache, from mincore() on 64 windows of 1 MiB spread over it.
+double page_cache_fraction(int fd, uint64_t size)
+{
+    if (size == 0)
+        return 1.0;
+    const uint64_t win = std::min<uint64_t>(size, 1u << 20), nwin = std::min<uint64_t>(64, (size + win - 1) / win);
+    uint64_t seen = 0, resident = 0;
+    std::vector<unsigned char> vec((win + 4095) / 4096);
+    for (uint64_t k = 0; k < nwin; k++) {
+        const uint64_t off = nwin > 1 ? (size - win) / (nwin - 1) * k / 4096 * 4096 : 0;
+        const uint64_t len = std::min<uint64_t>(win, size - off);
+        void *m = mmap(nullptr, len, PROT_READ, MAP_SHARED, fd, (off_t)off);
+        if (m == MAP_FAILED)
+            return 1.0;
+        const uint64_t pages = (len + 4095) / 4096;
+        if (mincore(m, len, vec.data()) == 0) {
+            seen += pages;
+            for (uint64_t p = 0; p < pages; p++)
+                resident += vec[p] & 1;
+        }
+        munmap(m, len);
+    }
+    return seen ? (double)resident / (double)seen : 1.0;
+}
+
+void close_file_src(FileSrc *fs)
+{
+    if (fs->fd >= 0)
+        close(fs->fd);
+    if (fs->fd_direct >= 0)
+        close(fs->fd_direct);
+    fs->fd = fs->fd_direct = -1;
+}
+
+// What the reference pairs a trailing lone float with (papr.c:102-103): the
+// float left in the same slot of its static 16384-float buffer by the previous
+// chunk (zero when there was none), with its low bytes overwritten by the
+// file's 1-3 stray tail bytes (glibc fread copies a partial element).
+int open_file_src(papr_hip_ctx *ctx, const char *path, FileSrc *fs)
+{
+    fs->fd = open(path, O_RDONLY);
+    if (fs->fd < 0)
+        return fail(ctx, PAPR_E_IO, "cannot open %s", path);
+    struct stat sb;
+    if (fstat(fs->fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        close(fs->fd);
+        fs->fd = -1;
+        return fail(ctx, PAPR_E_IO, "cannot stat %s (or not a regular file)", path);
+    }
+    fs->size = (uint64_t)sb.st_size;
+    // O_DIRECT pays off for files that are NOT in the page cache (measured 1.7x on the test box's disk) and
+    // costs 2x for files that are: PAPR_O_DIRECT=0/1 forces, otherwise decide from a residency sample
+    const int direct_mode = env_int("PAPR_O_DIRECT", -1);
+    const bool want_direct =
+        direct_mode > 0 || (direct_mode < 0 && fs->size >= (64u << 20) && page_cache_fraction(fs->fd, fs->size) < 0.5);
+    fs->fd_direct = want_direct ? open(path, O_RDONLY | O_DIRECT) : -1;  // EINVAL on tmpfs: stays -1
+    fs->nfloats = fs->size / 4;
+    fs->odd = (fs->nfloats & 1u) != 0;
+    fs->nsamples = (fs->nfloats + 1) / 2;
+    fs->partner = 0.0f;
+    if (fs->odd) {
+        const uint64_t chunk = 16384;  // papr.c:30
+        const uint64_t nfull = fs->nfloats / chunk, rem = fs->nfloats % chunk;
+        unsigned char bytes[4] = {0, 0, 0, 0};
+        if (nfull >= 1) {
+            const uint64_t fidx = (nfull - 1) * chunk + rem;
+            if (pread(fs->fd, bytes, 4, (off_t)(fidx * 4)) != 4) {
+                close_file_src(fs);
+                return fail(ctx, PAPR_E_IO, "short read in %s", path);
+            }
+        }
+        const uint64_t stray = fs->size % 4;
+        if (stray && pread(fs->fd, bytes, stray, (off_t)(fs->nfloats * 4)) != (ssize_t)stray) {
+            close_file_src(fs);
+            return fail(ctx, PAPR_E_IO, "short read in %s", path);
+        }
+        memcpy(&fs->partner, bytes, 4);
+    }
+    return PAPR_OK;
+}
+
+// read logical samples [s0, s0 + cnt) into dst (8 bytes each)
+int read_samples(const FileSrc &fs, uint64_t s0, uint64_t cnt, unsigned char *dst)
+{
+    const uint64_t byte0 = s0 * 8, file_bytes = fs.nfloats * 4;
+    uint64_t want = cnt * 8;
+    if (byte0 + want > file_bytes)
+        want = file_bytes > byte0 ? file_bytes - byte0 : 0;
+    uint64_t done = 0;
+    // O_DIRECT (cold files: the device DMAs into the pinned buffer, no page-cache copy) needs 4 KiB-aligned
+    // offset, address and length; slices are cut that way, the request is rounded up and a short count
+    // at end of file is expected.  Anything that does not fit falls through to the buffered descriptor.
+    if (fs.fd_direct >= 0 && (byte0 & 4095) == 0 && ((uintptr_t)dst & 4095) == 0) {
+        while (done < want) {
+            const uint64_t ask = std::min<uint64_t>((want - done + 4095) & ~4095ull, (uint64_t)1 << 30);
+            ssize_t got = pread(fs.fd_direct, dst + done, ask, (off_t)(byte0 + done));
+            if (got <= 0 || (got & 4095) != 0) {
+                if (got > 0)
+                    done += std::min<uint64_t>((uint64_t)got, want - done);
+                break;  // error, or the unaligned end of the file: the buffered path finishes the job
+            }
+            done += std::min<uint64_t>((uint64_t)got, want - done);
+        }
+    }
+    while (done < want) {
+        ssize_t got = pread(fs.fd, dst + done, want - done, (off_t)(byte0 + done));
+        if (got <= 0)
+            return PAPR_E_IO;
+        done += (uint64_t)got;
+    }
+    if (fs.odd && s0 + cnt == fs.nsamples && cnt > 0)
+        memcpy(dst + cnt * 8 - 4, &fs.partner, 4);
+    return PAPR_OK;
+}
+
+int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage)
+{
+    if (!ctx->stage_bytes) {
+        size_t mb = (size_t)std::max(1, env_int("PAPR_CHUNK_MB", 16));
+        ctx->stage_bytes = (mb << 20) / (kChunkAlign * 8) * (kChunkAlign * 8);
+        if (!ctx->stage_bytes)
+            ctx->stage_bytes = kChunkAlign * 8;
+    }
+    const CpuSet near_gpu = numa_cpus_of_device(ctx->device);
+    for (int b = 0; b < kNumBuf; b++) {
+        if (!ctx->h_stage[b]) {
+            // pinned pages are placed where they are first touched: do that on the GPU's NUMA node
+            cpu_set_t before;
+            const bool moved = near_gpu.valid && sched_getaffinity(0, sizeof(before), &before) == 0 &&
+                               sched_setaffinity(0, sizeof(near_gpu.set), &near_gpu.set) == 0;
+            const hipError_t e = hipHostMalloc(&ctx->h_stage[b], ctx->stage_bytes, hipHostMallocDefault);
+            if (e == hipSuccess && moved)
+                memset(ctx->h_stage[b], 0, ctx->stage_bytes);
+            if (moved)
+                (void)sched_setaffinity(0, sizeof(before), &before);
+            HIPCHK(ctx, e);
+        }
+        if (!ctx->ev_copy[b])
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_copy[b], hipEventDisableTiming));
+        if (!ctx->ev_kernel[b])
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_kernel[b], hipEventDisableTiming));
+        if (need_device_stage && !ctx->d_stage[b])
+            HIPCHK(ctx, hipMalloc(&ctx->d_stage[b], ctx->stage_bytes + PAPR_TILE_SAMPLES_MAX * 8));
+    }
+    if (need_device_stage && !ctx->d_tail)
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_tail, PAPR_TILE_SAMPLES_MAX * 8));
+    if (!ctx->pool) {
+        int n = env_int("PAPR_READ_THREADS", 0);
+        if (n <= 0)
+            n = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+        ctx->reader_threads = n;
+        ctx->pool = new ReaderPool(n, near_gpu);
+        ctx->ingest_numa = near_gpu.valid;
+    }
+    return PAPR_OK;
+}
+
+// Walk file samples [first, first + n) in pinned-buffer-sized chunks: parallel
+// pread into a pinned buffer, hipMemcpyAsync on the copy stream, then the pass
+// kernel on the compute stream as soon as that chunk has landed.  Three buffers
+// keep disk/page-cache reads, PCIe copies and kernels overlapped.
+int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t *nrecords_out)
+{
+    FileSrc fs;
+    int rc = open_file_src(ctx, ctx->path.c_str(), &fs);
+    if (rc)
+        return rc;
+    const bool to_resident = (pass == PASS_LOAD_STATS);
+    const bool timed = (pass == PASS_LOAD_STATS || pass == PASS_STREAM_STATS);
+    double t_mark = now_s();
+    rc = ensure_ingest(ctx, !to_resident);
+    if (rc) {
+        close_file_src(&fs);
+        return rc;
+    }
+    const uint64_t chunk_samples = ctx->stage_bytes / 8;
+    const uint64_t nchunks = (ctx->n + chunk_samples - 1) / chunk_samples;
+    size_t records = 0;
+    if (pass == PASS_LOAD_STATS || pass == PASS_STREAM_STATS) {
+        const int per_chunk = ctx->ingest_run ? ctx->ingest_run->blocks : blocks_of(ctx, PASS1);
+        rc = ensure_partials(ctx, (size_t)nchunks * per_chunk + 1);
+        if (rc) {
+            close_file_src(&fs);
+            return rc;
+        }
+    }
+    if (timed) {
+        ctx->ingest.setup_s += now_s() - t_mark;
+        ctx->ingest.chunks = nchunks;
+        ctx->ingest.reader_threads = ctx->reader_threads;
+        ctx->ingest.o_direct = fs.fd_direct >= 0;
+        ctx->ingest.numa_bound = ctx->ingest_numa ? 1 : 0;
+    }
+    // queue the slices of chunk c for the reader threads (buffer c % kNumBuf must be free)
+    std::vector<ReadBatch> batches(nchunks);
+    const FileSrc *fsp = &fs;
+    const uint64_t file_first = ctx->file_first, shard_n = ctx->n;
+    auto submit_chunk = [&](uint64_t c) {
+        const int b = (int)(c % kNumBuf);
+        const uint64_t s0 = c * chunk_samples;
+        const uint64_t cnt = std::min(chunk_samples, shard_n - s0);
+        unsigned char *hbuf = (unsigned char *)ctx->h_stage[b];
+        const int nthr = ctx->reader_threads;
+        const uint64_t per = ((cnt + nthr - 1) / nthr + 511) & ~511ull;
+        for (int t = 0; t < nthr; t++) {
+            const uint64_t a = std::min<uint64_t>((uint64_t)t * per, cnt), e = std::min<uint64_t>(a + per, cnt);
+            if (e > a)
+                ctx->pool->submit(&batches[c], [fsp, file_first, s0, a, e, hbuf] {
+                    return read_samples(*fsp, file_first + s0 + a, e - a, hbuf + a * 8);
+                });
+        }
+    };
+    // copy chunk c (already read into its pinned buffer) to the device and run the pass kernel on it
+    auto process_chunk = [&](uint64_t c) -> int {
+        const int b = (int)(c % kNumBuf);
+        const uint64_t s0 = c * chunk_samples;
+        const uint64_t cnt = std::min(chunk_samples, ctx->n - s0);
+        unsigned char *hbuf = (unsigned char *)ctx->h_stage[b];
+        float *dst = to_resident ? ctx->d_iq + 2 * s0 : (float *)ctx->d_stage[b];
+        if (!to_resident && c >= (uint64_t)kNumBuf)
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_kernel[b], 0));
+        HIPCHK(ctx, hipMemcpyAsync(dst, hbuf, cnt * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_copy[b], ctx->copy_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copy[b], 0));
+        const bool last = (c + 1 == nchunks);
+        int prc = PAPR_OK;
+        switch (pass) {
+        case PASS_LOAD_STATS:
+        case PASS_STREAM_STATS: {
+            int nrec = 0;
+            if (ctx->ingest_run)  // one-sweep ingest: pass 1 + banded pass 2 on the chunk
+                prc = sweep_launch(ctx, *ctx->ingest_run, dst, cnt, ctx->base + s0, records, &nrec);
+            else
+                prc = launch_stats_range(ctx, dst, cnt, ctx->base + s0, records, &nrec);
+            records += (size_t)nrec;
+            if (prc == PAPR_OK && last && pass == PASS_STREAM_STATS) {
+                const uint64_t tile = ctx->ingest_run ? ctx->ingest_run->tile : tile_samples(ctx, PASS1);
+                const uint64_t full = cnt / tile * tile;
+                if (cnt > full)
+                    HIPCHK(ctx, hipMemcpyAsync(ctx->d_tail, dst + 2 * full, (cnt - full) * 8, hipMemcpyDeviceToDevice,
+                                               ctx->stream));
+            }
+            break;
+        }
+        case PASS_STREAM_CCDF:
+            prc = launch_ccdf_range(ctx, *plan, dst, cnt);
+            break;
+        case PASS_STREAM_CCDF_EXACT:
+            prc = launch_fused_chunk(ctx, *plan, dst, s0, cnt, last);
+            break;
+        case PASS_STREAM_NAN:
+            papr_launch_first_nan(ctx->stream, 1024, dst, cnt, ctx->base + s0, ctx->d_nan_key);
+            HIPCHK(ctx, hipGetLastError());
+            break;
+        }
+        if (prc)
+            return prc;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_kernel[b], ctx->stream));
+        return PAPR_OK;
+    };
+
+    uint64_t submitted = 0;
+    for (; submitted < std::min<uint64_t>(kReadAhead, nchunks); submitted++)
+        submit_chunk(submitted);
+    for (uint64_t c = 0; c < nchunks && rc == PAPR_OK; c++) {
+        t_mark = now_s();
+        if (ctx->pool->wait(&batches[c]))
+            rc = fail(ctx, PAPR_E_IO, "read error in %s", ctx->path.c_str());
+        if (timed)
+            ctx->ingest.read_s += now_s() - t_mark;
+        if (rc)
+            break;
+        t_mark = now_s();
+        rc = process_chunk(c);
+        if (timed)
+            ctx->ingest.issue_s += now_s() - t_mark;
+        // read ahead: the next unread chunk goes into the buffer used kNumBuf chunks earlier, which is
+        // free once that chunk's H2D copy has completed
+        if (rc == PAPR_OK && submitted < nchunks) {
+            t_mark = now_s();
+            if (submitted >= (uint64_t)kNumBuf &&
+                hipEventSynchronize(ctx->ev_copy[submitted % kNumBuf]) != hipSuccess)
+                rc = fail(ctx, PAPR_E_HIP, "hipEventSynchronize failed while recycling a staging buffer");
+            if (timed)
+                ctx->ingest.buffer_wait_s += now_s() - t_mark;
+            if (rc == PAPR_OK)
+                submit_chunk(submitted++);
+        }
+    }
+    // on any failure let the reads already queued finish before `fs` and the batches go away
+    for (uint64_t k = 0; k < submitted; k++)
+        (void)ctx->pool->wait(&batches[k]);
+    close_file_src(&fs);
+    if (nrecords_out)
+        *nrecords_out = records;
+    return rc;
+}
+
+// papr_hip_load_file, optionally as a one-sweep ingest (guess != nullptr): the per-chunk kernel then also bins
+// against the guessed bands and stashes, so that papr_hip_ccdf needs no second read of the shard — or of the file
+int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples, const float *guess,
+                   int nguess)
+{
+    if (!ctx || !path)
+        return PAPR_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const double t_begin = now_s();
+    memset(&ctx->ingest, 0, sizeof(ctx->ingest));
+    papr_hip_sweep_info &info = ctx->sweep_info;
+    info.swept = info.resolved = 0;
+    info.stash_samples = 0;
+    info.reason = PAPR_SWEEP_NONE;
+    ctx->ingest_run = nullptr;
+    FileSrc fs;
+    int rc = open_file_src(ctx, path, &fs);
+    if (rc)
+        return rc;
+    close_file_src(&fs);
+    if (first_sample > fs.nsamples)
+        return fail(ctx, PAPR_E_ARG, "first_sample %llu is past the end of %s (%llu samples)",
+                    (unsigned long long)first_sample, path, (unsigned long long)fs.nsamples);
+    if (nsamples == UINT64_MAX || first_sample + nsamples > fs.nsamples)
+        nsamples = fs.nsamples - first_sample;
+
+    const bool fits = (nsamples + PAPR_TILE_SAMPLES_MAX) * 8 <= ctx->hbm_budget;
+    if (!ctx->owns_iq || !fits)
+        release_shard(ctx);
+    if (fits) {
+        rc = ensure_owned_capacity(ctx, nsamples);
+        if (rc)
+            return rc;
+    }
+    ctx->path = path;
+    ctx->file_first = first_sample;
+    ctx->n = nsamples;
+    ctx->base = first_sample;
+    ctx->resident = fits;
+    ctx->loaded = true;
+    ctx->have_file_stats = false;
+    ctx->exact_valid = false;
+    ctx->sweep_valid = false;
+    ctx->shard_flags = (fs.odd && first_sample + nsamples == fs.nsamples && nsamples > 0) ? PAPR_FLAG_ODD_TAIL : 0;
+
+    SweepRun run;
+    if (guess) {
+        int reason = PAPR_SWEEP_MODE;
+        if (!ctx->exact && nsamples) {
+            rc = ensure_ingest(ctx, !fits);  // fixes the chunk size
+            if (rc == PAPR_OK)
+                rc = sweep_prepare(ctx, guess, nguess, nsamples, ctx->stage_bytes / 8, &run, &reason);
+            if (rc) {
+                ctx->loaded = false;
+                return rc;
+            }
+        }
+        info.reason = reason;
+        if (reason == PAPR_SWEEP_OK)
+            ctx->ingest_run = &run;
+    }
+    ctx->ingest.setup_s = now_s() - t_begin;
+    ctx->ingest.bytes = nsamples * 8;
+    ctx->ingest.resident = fits ? 1 : 0;
+    // pass 1 (or the whole sweep) rides along with the ingest
+    size_t records = 0;
+    rc = stream_file(ctx, fits ? PASS_LOAD_STATS : PASS_STREAM_STATS, nullptr, &records);
+    const bool swept = ctx->ingest_run != nullptr;
+    ctx->ingest_run = nullptr;
+    if (rc) {
+        ctx->loaded = false;
+        return rc;
+    }
+    const uint64_t chunk_samples = ctx->stage_bytes / 8;
+    const uint64_t last_cnt = nsamples ? nsamples - (nsamples - 1) / chunk_samples * chunk_samples : 0;
+    const uint32_t tail = (uint32_t)(last_cnt % (swept ? run.tile : tile_samples(ctx, PASS1)));
+    if (swept) {
+        rc = sweep_fetch(ctx, run);
+        if (rc) {
+            ctx->loaded = false;
+            return rc;
+        }
+    }
+    const float *tail_ptr = fits ? ctx->d_iq + 2 * (nsamples - tail) : ctx->d_tail;
+    papr_stats st;
+    const double t_drain = now_s();
+    rc = finish_stats(ctx, records, tail_ptr, tail, ctx->base + nsamples - tail, &st);
+    if (rc) {
+        ctx->loaded = false;
+        return rc;
+    }
+    ctx->ingest.drain_s = now_s() - t_drain;
+    if (swept && std::isnan(st.sum)) {
+        // NaN in the data: the sweep's integer-max trackers do not apply — take the file in again the plain way
+        rc = load_file_impl(ctx, path, first_sample, nsamples, nullptr, 0);
+        info.reason = PAPR_SWEEP_NO_BANDS;
+        return rc;
+    }
+    if (swept) {
+        rc = sweep_collect(ctx, run);
+        if (rc) {
+            ctx->loaded = false;
+            return rc;
+        }
+    }
+    if (std::isnan(st.sum)) {
+        unsigned long long key = ~0ull;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_nan_key, &key, 8, hipMemcpyHostToDevice, ctx->stream));
+        if (fits) {
+            papr_launch_first_nan(ctx->stream, 1024, ctx->d_iq, ctx->n, ctx->base, ctx->d_nan_key);
+            HIPCHK(ctx, hipGetLastError());
+        } else {
+            rc = stream_file(ctx, PASS_STREAM_NAN, nullptr, nullptr);
+            if (rc)
+                return rc;
+        }
+        HIPCHK(ctx, hipMemcpyAsync(&key, ctx->d_nan_key, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        apply_nan_key(&st, key);
+    }
+    ctx->file_stats = st;
+    ctx->have_file_stats = true;
+    ctx->exact_valid = ctx->exact;  // the per-tile sums are on the device, resident shard or not
+    ctx->ingest.total_s = now_s() - t_begin;
+    return PAPR_OK;
+}
+
+}  // namespace papr_rt
+
+extern "C" {
+
+int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples)
+{
+    return load_file_impl(ctx, path, first_sample, nsamples, nullptr, 0);
+}
+
+int papr_hip_shard_fits(const papr_hip_ctx *ctx, uint64_t nsamples)
+{
+    if (!ctx)
+        return PAPR_E_ARG;
+    return (nsamples + PAPR_TILE_SAMPLES_MAX) * 8 <= ctx->hbm_budget ? 1 : 0;
+}
+
+int papr_hip_load_file_sweep(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples,
+                             const float *guess_levels, int nlevels)
+{
+    if (nlevels < 0 || (nlevels && !guess_levels))
+        return PAPR_E_ARG;
+    static const float none = 0.0f;
+    return load_file_impl(ctx, path, first_sample, nsamples, guess_levels ? guess_levels : &none, nlevels);
+}
+
+// Mean estimate of a file range without loading it: the same 1-in-`ratio` tile sample as papr_hip_estimate, read
+// by the ingest's reader threads into the staging buffers and summed on the device.
+int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples, papr_stats *est)
+{
+    if (!ctx || !path || !est)
+        return PAPR_E_ARG;
+    papr_stats_init(est);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    FileSrc fs;
+    int rc = open_file_src(ctx, path, &fs);
+    if (rc)
+        return rc;
+    if (first_sample > fs.nsamples) {
+        close_file_src(&fs);
+        return fail(ctx, PAPR_E_ARG, "first_sample %llu is past the end of %s (%llu samples)",
+                    (unsigned long long)first_sample, path, (unsigned long long)fs.nsamples);
+    }
+    if (nsamples == UINT64_MAX || first_sample + nsamples > fs.nsamples)
+        nsamples = fs.nsamples - first_sample;
+    ctx->sweep_info.estimate_samples = 0;
+    const uint64_t ntiles = nsamples / PAPR_ESTIMATE_TILE_SAMPLES;
+    if (ntiles == 0) {
+        close_file_src(&fs);
+        return PAPR_OK;  // n = 0: no estimate
+    }
+    rc = ensure_ingest(ctx, true);
+    if (rc) {
+        close_file_src(&fs);
+        return rc;
+    }
+    uint64_t ratio = ctx->tune.estimate_ratio > 0 ? (uint64_t)ctx->tune.estimate_ratio : (uint64_t)kEstimateRatio;
+    ratio = std::max<uint64_t>(1, std::min<uint64_t>(ratio, ntiles / kEstimateMinTiles));
+    const uint64_t ngroups = ntiles / ratio;
+    constexpr uint64_t kTileBytes = (uint64_t)PAPR_ESTIMATE_TILE_SAMPLES * 8;
+    const uint64_t per_batch = ctx->stage_bytes / kTileBytes;
+    const uint64_t nbatches = (ngroups + per_batch - 1) / per_batch;
+    const int blocks_max = (int)std::min<uint64_t>(per_batch, (uint64_t)ctx->num_cus * 8);
+    rc = ensure_partials(ctx, (size_t)nbatches * blocks_max + 1);
+    std::vector<ReadBatch> batches(nbatches);
+    const FileSrc *fsp = &fs;
+    auto submit = [&](uint64_t bi) {
+        const uint64_t g0 = bi * per_batch, g1 = std::min(ngroups, g0 + per_batch);
+        unsigned char *hbuf = (unsigned char *)ctx->h_stage[bi % kNumBuf];
+        const int nthr = ctx->reader_threads;
+        const uint64_t per = (g1 - g0 + nthr - 1) / nthr;
+        for (int t = 0; t < nthr; t++) {
+            const uint64_t a = std::min(g1, g0 + (uint64_t)t * per), e = std::min(g1, a + per);
+            if (e > a)
+                ctx->pool->submit(&batches[bi], [fsp, first_sample, ratio, g0, a, e, hbuf] {
+                    for (uint64_t g = a; g < e; g++) {
+                        // one tile of group g, picked by a hash of g (no aliasing with periodic structure in the capture)
+                        const uint64_t tile = g * ratio + ((g + 1) * 0x9E3779B97F4A7C15ull >> 40) % ratio;
+                        const int r = read_samples(*fsp, first_sample + tile * PAPR_ESTIMATE_TILE_SAMPLES,
+                                                   PAPR_ESTIMATE_TILE_SAMPLES, hbuf + (g - g0) * kTileBytes);
+                        if (r)
+                            return r;
+                    }
+                    return (int)PAPR_OK;
+                });
+        }
+    };
+    size_t records = 0;
+    uint64_t submitted = 0;
+    for (; rc == PAPR_OK && submitted < std::min<uint64_t>(2, nbatches); submitted++)
+        submit(submitted);
+    for (uint64_t bi = 0; bi < nbatches && rc == PAPR_OK; bi++) {
+        if (ctx->pool->wait(&batches[bi])) {
+            rc = fail(ctx, PAPR_E_IO, "read error in %s", path);
+            break;
+        }
+        const int b = (int)(bi % kNumBuf);
+        const uint64_t cnt = std::min(ngroups, (bi + 1) * per_batch) - bi * per_batch;
+        if (hipMemcpyAsync(ctx->d_stage[b], ctx->h_stage[b], cnt * kTileBytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            rc = fail(ctx, PAPR_E_HIP, "hipMemcpyAsync of the estimate sample failed");
+            break;
+        }
+        const int blocks = (int)std::min<uint64_t>(cnt, (uint64_t)blocks_max);
+        time_begin(ctx, 4, cnt * kTileBytes);
+        papr_launch_estimate(ctx->stream, blocks, ctx->d_stage[b], cnt, 1, ctx->d_partials + records);
+        time_end(ctx);
+        records += (size_t)blocks;
+        if (hipEventRecord(ctx->ev_copy[b], ctx->stream) != hipSuccess)
+            rc = fail(ctx, PAPR_E_HIP, "hipEventRecord failed");
+        if (rc == PAPR_OK && submitted < nbatches) {
+            // the buffer about to be refilled was consumed kNumBuf batches ago
+            if (submitted >= (uint64_t)kNumBuf && hipEventSynchronize(ctx->ev_copy[submitted % kNumBuf]) != hipSuccess)
+                rc = fail(ctx, PAPR_E_HIP, "hipEventSynchronize failed while recycling a staging buffer");
+            if (rc == PAPR_OK)
+                submit(submitted++);
+        }
+    }
+    for (uint64_t k = 0; k < submitted; k++)
+        (void)ctx->pool->wait(&batches[k]);
+    close_file_src(&fs);
+    if (rc)
+        return rc;
+    papr_launch_stats_finalize(ctx->stream, nullptr, 0, 0, ctx->d_partials, (uint32_t)records, ctx->h_result_dev);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    est->sum = ctx->h_result->sum;
+    est->n = ngroups * PAPR_ESTIMATE_TILE_SAMPLES;
+    ctx->sweep_info.estimate_samples = est->n;
+    return PAPR_OK;
+}
+
+int papr_hip_get_ingest_timing(const papr_hip_ctx *ctx, papr_hip_ingest_timing *out)
+{
+    if (!ctx || !out)
+        return PAPR_E_ARG;
+    *out = ctx->ingest;
+    return PAPR_OK;
+}
+
+}  // extern "C"

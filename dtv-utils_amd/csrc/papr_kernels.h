@@ -1,5 +1,5 @@
 // papr_kernels.h — shared between the device code (papr_kernels.hip) and the
-// host runtime (papr_runtime.cpp).  Internal: not part of the C ABI.
+// host runtime (papr_runtime.cpp, papr_ingest.cpp, papr_sweep_rt.cpp, papr_exact_rt.cpp).  Internal: not part of the C ABI.
 #ifndef PAPR_KERNELS_H
 #define PAPR_KERNELS_H
 

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_generate_kernel(float2 *__res
     }
 }
 
-// ---- launch wrappers (called from papr_runtime.cpp through plain C++) ------
+// ---- launch wrappers (called from the host runtime, papr_runtime.cpp & co., through plain C++) ------
 //
 // Kernel geometry variants; tile = 2 * block * unroll samples (<= 8192).
 //   id: block x loads-per-lane, P = software-pipelined (next tile's loads issued

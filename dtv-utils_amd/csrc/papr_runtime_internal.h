@@ -1,0 +1,359 @@
+// papr_runtime_internal.h — shared by the translation units of the host runtime behind include/papr_hip.h
+// (papr_runtime.cpp: contexts, shards, the two passes; papr_ingest.cpp: file -> pinned host -> HBM;
+// papr_sweep_rt.cpp: the one-sweep mode; papr_exact_rt.cpp: the bit-exact sequential sum).  Internal: not part of the C ABI.
+#ifndef PAPR_RUNTIME_INTERNAL_H
+#define PAPR_RUNTIME_INTERNAL_H
+
+#include "papr_hip.h"
+#include "papr_exact_format.h"
+#include "papr_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cctype>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace papr_rt {
+
+constexpr uint64_t kChunkAlign = PAPR_TILE_SAMPLES_MAX;  // chunk boundaries stay tile aligned for every variant
+constexpr int kNumBuf = 4;      // pinned staging buffers
+constexpr int kReadAhead = 2;   // chunks being read ahead of the one being copied
+constexpr int kMaxTimed = 4096;
+
+// ---- a tiny pool of file-reader threads -------------------------------------
+// Jobs are grouped in batches (one batch = the slices of one chunk); the
+// submitter can queue the next chunk's batch before waiting for the current
+// one, so the readers never go idle between chunks.
+struct ReadBatch {
+    int pending = 0;
+    int error = 0;
+};
+
+// CPUs of the NUMA node the GPU hangs off (its PCIe root): the ingest's reader threads run there and the pinned
+// staging buffers are first touched there, so that the H2D DMA never crosses the socket interconnect.
+// Empty set = unknown / single node / PAPR_NUMA=0.
+struct CpuSet {
+    cpu_set_t set;
+    bool valid = false;
+};
+
+class ReaderPool {
+  public:
+    explicit ReaderPool(int n, const CpuSet &cpus = CpuSet())
+    {
+        for (int i = 0; i < n; i++)
+            threads_.emplace_back([this, cpus] {
+                if (cpus.valid)
+                    (void)sched_setaffinity(0, sizeof(cpus.set), &cpus.set);
+                run();
+            });
+    }
+    ~ReaderPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_)
+            t.join();
+    }
+    // job returns 0 or an error code, recorded in the batch
+    void submit(ReadBatch *batch, std::function<int()> job)
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            batch->pending++;
+            jobs_.push_back({batch, std::move(job)});
+        }
+        cv_.notify_one();
+    }
+    int wait(ReadBatch *batch)
+    {
+        std::unique_lock<std::mutex> g(m_);
+        done_cv_.wait(g, [batch] { return batch->pending == 0; });
+        return batch->error;
+    }
+
+  private:
+    struct Job {
+        ReadBatch *batch;
+        std::function<int()> fn;
+    };
+    void run()
+    {
+        for (;;) {
+            Job job;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this] { return stop_ || !jobs_.empty(); });
+                if (stop_ && jobs_.empty())
+                    return;
+                job = std::move(jobs_.front());
+                jobs_.pop_front();
+            }
+            const int rc = job.fn();
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (rc)
+                    job.batch->error = rc;
+                if (--job.batch->pending == 0)
+                    done_cv_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::deque<Job> jobs_;
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    bool stop_ = false;
+};
+
+struct TimedLaunch {
+    hipEvent_t a, b;
+    int kind;  // 0 stats, 1 ccdf, 2 exact-sum kernels, 3 one-sweep kernel, 4 estimate / stash recount
+    uint64_t bytes;
+};
+
+struct SweepRun;
+
+}  // namespace papr_rt
+
+struct papr_hip_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;     // compute
+    hipStream_t copy_stream = nullptr;
+    char name[128] = "";
+    char err[256] = "";
+    int num_cus = 256;
+    size_t hbm_budget = 0;
+
+    // shard
+    float *d_iq = nullptr;   // resident samples (owned or adopted)
+    bool owns_iq = false;
+    uint64_t cap = 0;        // capacity in samples
+    uint64_t n = 0;          // samples in the shard
+    uint64_t base = 0;       // global index of sample 0 of the shard
+    bool loaded = false;
+    bool resident = false;
+    uint32_t shard_flags = 0;
+
+    // file source (kept for re-streaming shards that exceed the HBM budget)
+    std::string path;
+    uint64_t file_first = 0;  // first sample of the range within the file
+    bool have_file_stats = false;
+    papr_stats file_stats;
+
+    // work buffers
+    papr_partial *d_partials = nullptr;
+    size_t partials_cap = 0;
+    papr_partial *h_result = nullptr;  // pinned, written by the finalize kernel
+    papr_partial *h_result_dev = nullptr;
+    unsigned long long *d_hist = nullptr;
+    unsigned long long *h_hist = nullptr;  // pinned
+    uint32_t *d_table = nullptr;
+    uint32_t *h_table = nullptr;           // pinned
+    size_t table_cap_words = 0;
+    unsigned long long *d_nan_key = nullptr;
+    float *d_tail = nullptr;               // streaming mode: the last chunk's sub-tile tail
+
+    // ingest
+    void *h_stage[papr_rt::kNumBuf] = {};
+    void *d_stage[papr_rt::kNumBuf] = {};
+    hipEvent_t ev_copy[papr_rt::kNumBuf] = {};
+    hipEvent_t ev_kernel[papr_rt::kNumBuf] = {};
+    size_t stage_bytes = 0;
+    papr_rt::ReaderPool *pool = nullptr;
+    int reader_threads = 0;
+    bool ingest_numa = false;   // reader threads and staging buffers are bound to the GPU's NUMA node
+
+    // exact-sum mode (papr_exact.hip)
+    bool exact = false;
+    bool exact_valid = false;        // tile sums of the current shard are on the device
+    uint64_t exact_tiles_cap = 0;
+    double *d_tile_sums = nullptr;   // ntiles x 4 per-wave sums
+    double *d_block_sums = nullptr;
+    int32_t *d_tile_E = nullptr;
+    double *d_seg_D = nullptr;       // 2 x ntiles pairs
+    papr_exact_group *d_groups = nullptr;
+    unsigned char *h_program = nullptr;  // pinned + mapped: the pack kernel writes the program straight into it
+    size_t h_program_cap = 0;
+    uint32_t *d_mixed_list = nullptr, *d_raw_list = nullptr;
+    papr_exact_plan *d_plan = nullptr;
+    uint32_t *d_ambig = nullptr;   // re-streamed shards: [0, cap) unordered list, [cap, 2 cap) sorted list, [2 cap] count
+    float *d_raw_store = nullptr;  // ... and the captured raw tiles
+
+    // one-sweep mode (papr_sweep.hip)
+    unsigned long long *d_sweep_hist = nullptr;  // 2 L + 2 bins, then one stash-segment length per workgroup
+    unsigned long long *h_sweep_hist = nullptr;  // pinned
+    float *d_stash = nullptr;                    // in-band powers of the last sweep
+    uint64_t stash_cap = 0;
+    bool sweep_valid = false;                    // the fields below describe the CURRENT shard
+    uint32_t sweep_half = 0;                     // half-width of a band, in bit patterns
+    std::vector<uint32_t> sweep_keys;            // unique guessed keys (band centres), ascending
+    std::vector<uint64_t> sweep_even_above;      // per guessed key j: samples in even bins >= 2 j + 2
+    uint64_t sweep_stash_count = 0;
+    uint64_t sweep_seg_cap = 0;                  // floats per stash segment
+    uint32_t sweep_nsegs = 0, sweep_nbins = 0;
+    bool sweep_overflow = false;
+    papr_hip_sweep_info sweep_info{};
+    const papr_rt::SweepRun *ingest_run = nullptr;        // set while papr_hip_load_file_sweep streams the file in
+
+    papr_hip_ingest_timing ingest{};
+    papr_hip_tuning tune{};
+    bool timing = false;
+    std::vector<papr_rt::TimedLaunch> timed;
+    size_t timed_used = 0;
+};
+
+namespace papr_rt {
+
+extern char g_open_error[256];
+
+#define HIPCHK(ctx, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, PAPR_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));      \
+    } while (0)
+
+// Built-in launch geometry, from the 10 GiB sweeps on MI355X:
+//   pass 1: 256-thread workgroups, 4 loads per lane, next-tile prefetch, 2 workgroups per CU (8 waves/CU),
+//           grid-stride tiles                                                -> 7.2-7.3 TB/s
+//   pass 2: 512-thread workgroups, 4 loads per lane, 2 workgroups per CU (16 waves/CU), grid-stride tiles
+//                                                                            -> 7.20 TB/s
+// (one contiguous eighth of the shard per XCD is 1 % faster for pass 1 in most processes and 8 % slower in about
+// one process in four — it depends on where the allocation landed — so it is not the default)
+constexpr int kStatsVariant = 1, kStatsPerCU = 2, kStatsMap = PAPR_MAP_GRID_STRIDE;
+
+constexpr int kCcdfVariant = 13, kCcdfPerCU = 2, kCcdfMap = PAPR_MAP_GRID_STRIDE;
+
+// one-sweep kernel (pass 1 + banded pass 2 in one read)
+constexpr int kSweepVariant = 13, kSweepPerCU = 2, kSweepMap = PAPR_MAP_GRID_STRIDE;
+
+constexpr int kSweepBandLog2 = 14, kEstimateRatio = 64;
+
+constexpr uint64_t kEstimateMinTiles = 8192;  // sample at least 16 Mi samples (or everything)
+
+enum Pass { PASS1 = 0, PASS2 = 1, SWEEP = 2 };
+
+// ---- pass 2 table construction ----------------------------------------------
+constexpr uint32_t kNever = 0xFFFFFFFFu;
+
+// smallest bit pattern of a non-negative float that is > t: papr_level_key (papr_host.c)
+inline uint32_t level_key(float t)
+{
+    return papr_level_key(t);
+}
+
+struct CcdfPlan {
+    std::vector<uint32_t> keys;      // unique, ascending
+    std::vector<int> pos;            // per level: index into keys, or -1
+    papr_ccdf_params P{};
+    bool lut = false;
+    size_t lds_bytes = 0;
+};
+
+// ---- file source ---------------------------------------------------------------
+struct FileSrc {
+    int fd = -1;
+    int fd_direct = -1;  // O_DIRECT view of the same file (PAPR_O_DIRECT=1), -1 when not usable
+    uint64_t size = 0, nfloats = 0, nsamples = 0;
+    bool odd = false;
+    float partner = 0.0f;  // Q of the phantom sample
+};
+
+constexpr uint32_t kCapMixed = 256, kCapRaw = 512;  // beyond this the program is assembled by the host path
+
+// ---- one-sweep mode: set-up, launch and bookkeeping shared by resident shards and file ingest -------------------
+struct SweepRun {
+    CcdfPlan bands;               // band edges lo_0 < hi_0 < lo_1 < ... in LUT form
+    std::vector<uint32_t> gkeys;  // guessed keys (band centres), unique, ascending
+    uint32_t half = 0;            // half-width of a band in bit patterns
+    int variant = 0;
+    int blocks = 0;               // workgroups of the largest launch (= stash segments)
+    uint64_t tile = 0;            // samples per workgroup iteration
+    size_t stash_lds = 0;
+    uint32_t nbins = 0;           // 2 * bands + 1 + the NaN trash bin
+    uint64_t seg_cap = 0;         // floats per stash segment
+};
+
+enum StreamPass { PASS_LOAD_STATS, PASS_STREAM_STATS, PASS_STREAM_CCDF, PASS_STREAM_CCDF_EXACT, PASS_STREAM_NAN };
+
+// ---- functions shared between the translation units ----
+double now_s();
+CpuSet numa_cpus_of_device(int device);
+int fail(papr_hip_ctx *ctx, int code, const char *fmt, ...);
+int env_int(const char *name, int dflt);
+void parse_tune_env(papr_hip_tuning *t);
+int variant_of(const papr_hip_ctx *ctx, Pass p);
+int blocks_of(const papr_hip_ctx *ctx, Pass p);
+uint64_t tile_samples(const papr_hip_ctx *ctx, Pass p);
+int map_of(const papr_hip_ctx *ctx, Pass p);
+int pick_blocks(const papr_hip_ctx *ctx, Pass p, uint64_t ntiles);
+int effective_map(const papr_hip_ctx *ctx, Pass p, int blocks);
+bool use_nt(const papr_hip_ctx *ctx);
+int ensure_partials(papr_hip_ctx *ctx, size_t count);
+int ensure_table(papr_hip_ctx *ctx, size_t words);
+void release_shard(papr_hip_ctx *ctx);
+int ensure_owned_capacity(papr_hip_ctx *ctx, uint64_t nsamples);
+void time_begin(papr_hip_ctx *ctx, int kind, uint64_t bytes);
+void time_end(papr_hip_ctx *ctx);
+int ensure_exact_buffers(papr_hip_ctx *ctx);
+int launch_stats_range(papr_hip_ctx *ctx, const float *data, uint64_t n, uint64_t base_index, size_t slot,
+                       int *nrecords);
+void partial_to_stats(const papr_partial &r, uint64_t n, papr_stats *out);
+void apply_nan_key(papr_stats *out, unsigned long long key);
+int finish_plan(papr_hip_ctx *ctx, CcdfPlan *plan, int vblock, size_t extra_lds);
+int plan_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, CcdfPlan *plan);
+int upload_ccdf_table(papr_hip_ctx *ctx, const CcdfPlan &plan);
+int launch_ccdf_range(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *data, uint64_t n);
+double page_cache_fraction(int fd, uint64_t size);
+void close_file_src(FileSrc *fs);
+int open_file_src(papr_hip_ctx *ctx, const char *path, FileSrc *fs);
+int read_samples(const FileSrc &fs, uint64_t s0, uint64_t cnt, unsigned char *dst);
+int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage);
+int launch_fused_chunk(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *chunk, uint64_t s0, uint64_t cnt, bool last);
+int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uint64_t n_shard, uint64_t n_launch,
+                  SweepRun *run, int *reason);
+int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint64_t n, uint64_t base_index, size_t slot,
+                 int *nrecords);
+int sweep_fetch(papr_hip_ctx *ctx, const SweepRun &run);
+int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run);
+int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t *nrecords_out);
+int finish_stats(papr_hip_ctx *ctx, size_t records, const float *tail_ptr, uint32_t tail_samples, uint64_t tail_base,
+                 papr_stats *out);
+int resolve_resident_nan(papr_hip_ctx *ctx, papr_stats *out);
+int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples, const float *guess,
+                   int nguess);
+int exact_preconditions(papr_hip_ctx *ctx, double before, bool allow_restreamed);
+int reserve_program(papr_hip_ctx *ctx, size_t want);  // grow the pinned program buffer, keeping its contents
+int run_exact_device(papr_hip_ctx *ctx, double before, uint64_t n_total, const CcdfPlan *fused, size_t *bytes);
+int assemble_program_on_host(papr_hip_ctx *ctx, const void **program, size_t *bytes);
+void counts_from_histogram(const papr_hip_ctx *ctx, const CcdfPlan &plan, int nlevels, uint64_t *counts_above);
+int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *levels, int nlevels, uint64_t *counts_above,
+                       bool *done);
+
+}  // namespace papr_rt
+
+#endif
