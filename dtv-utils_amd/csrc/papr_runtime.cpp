@@ -1,11 +1,10 @@
-// papr_runtime.cpp — host runtime behind the C ABI of include/papr_hip.h:
-// context/shard management, the file ingest engine (replaces the fread loops
-// of reference papr.c:100-101, 143-144, 175-176), launch sequencing for the two
-// passes and the exact threshold-table construction for pass 2.
+// papr_runtime.cpp — core of the host runtime behind the C ABI of include/papr_hip.h: context and shard
+// management, launch geometry, launch sequencing for the two passes (papr_hip_stats, papr_hip_ccdf) and the exact
+// threshold-table construction for pass 2.  The file ingest engine lives in papr_ingest.cpp, the one-sweep mode in
+// papr_sweep_rt.cpp, the bit-exact sequential sum in papr_exact_rt.cpp.
 //
-// No CPU compute path: every sample is reduced on the GPU; the host only reads
-// file bytes into pinned buffers, builds the <= 16 K-entry level tables and
-// folds a handful of scalars.
+// No CPU compute path: every sample is reduced on the GPU; the host only reads file bytes into pinned buffers,
+// builds the <= 16 K-entry level tables and folds a handful of scalars.
 
 #include "papr_runtime_internal.h"
 
