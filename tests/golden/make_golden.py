@@ -108,6 +108,35 @@ def build_fixtures():
     rrc[np.isnan(rrc) | np.isinf(rrc)] = 1.0 - beta + 4 * beta / np.pi
     qam = np.convolve(up, rrc / np.sqrt(np.sum(rrc ** 2)), mode="same") * 0.1
     raw("qam64_rrc", np.column_stack([qam.real, qam.imag]).ravel())
+    # (added later; drawn after everything above so that the earlier fixtures keep their bytes)
+    # DVB-S2 32-APSK (rings 4 + 12 + 16, radius ratios 2.84 / 5.27) through the same RRC, roll-off 0.2 filter shape
+    ring = rng.integers(0, 32, n // 2)
+    radius = np.where(ring < 4, 1.0, np.where(ring < 16, 2.84, 5.27)) / 5.27
+    count = np.where(ring < 4, 4, np.where(ring < 16, 12, 16))
+    index = np.where(ring < 4, ring, np.where(ring < 16, ring - 4, ring - 16))
+    apsk = radius * np.exp(2j * np.pi * (index + 0.5) / count)
+    up = np.zeros(n, dtype=np.complex128)
+    up[::2] = apsk
+    s2 = np.convolve(up, rrc / np.sqrt(np.sum(rrc ** 2)), mode="same") * 0.5
+    raw("apsk32_dvbs2_rrc", np.column_stack([s2.real, s2.imag]).ravel())
+    # ATSC 8-VSB: 8-level symbols + pilot, one sideband kept (analytic-signal approximation of the VSB filter)
+    vsb_sym = (rng.integers(0, 8, n) * 2 - 7 + 1.25).astype(np.float64)
+    spec = np.fft.fft(vsb_sym)
+    spec[n // 2 + 1:] = 0.0          # drop the lower sideband
+    spec[1:n // 2] *= 2.0
+    vsb = np.fft.ifft(spec) * 0.02
+    raw("vsb8_atsc", np.column_stack([vsb.real, vsb.imag]).ravel())
+    # TDMA-like bursts: QPSK bursts of random length and level separated by exact silence (runs of +0 power)
+    tdma = np.zeros(n, dtype=np.complex128)
+    pos = 0
+    while pos < n:
+        gap = int(rng.integers(50, 900))
+        length = int(rng.integers(200, 3000))
+        level = 10.0 ** rng.uniform(-2.0, 0.0)
+        a, b = min(n, pos + gap), min(n, pos + gap + length)
+        tdma[a:b] = level * (rng.choice([-1.0, 1.0], b - a) + 1j * rng.choice([-1.0, 1.0], b - a)) / np.sqrt(2.0)
+        pos = b
+    raw("tdma_bursts", np.column_stack([tdma.real, tdma.imag]).ravel())
 
 
 def record(path, graph):

@@ -397,3 +397,21 @@ def test_cli_tree_sum_mode_reads_the_file_once(pkg, orc, tmp_path, shards):
             want = shards if (budget or force) else 0      # by default only shards that do not fit in HBM are swept
             assert info["shards_swept"] == want and info["shards_resolved_from_sweep"] == want, info
             assert info["gpu0_ingest"]["resident"] == (0 if budget else 1)
+
+
+# ---- the committed golden fixtures through the one-sweep ingest ------------------------------------------------
+
+from conftest import golden_names, golden_path, golden_text  # noqa: E402
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["default", "graph"])
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fixtures_through_the_one_sweep_ingest(pkg, gpu, name, graph):
+    """every fixture (odd tails, NaN/Inf, denormals, ties, producer formats, bursts with exact silence) ingested
+    with papr_hip_estimate_file + papr_hip_load_file_sweep: the report is the reference's recorded stdout"""
+    path = golden_path(name)
+    gpu.load_file_sweep(path, pkg.guess_levels(gpu.estimate_file(path), graph))
+    st = gpu.stats()
+    mean, papr, table = pkg.levels(st, graph)
+    counts = gpu.ccdf(table)
+    assert pkg.format_report(st, mean, papr, counts, graph).encode() == golden_text(name, graph)
