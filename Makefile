@@ -56,11 +56,11 @@ tools: bin/hbm_read_probe bin/ingest_probe
 
 bin/ingest_probe: tools/ingest_probe.cpp
 	@mkdir -p bin
-	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Wno-unused-result $< -o $@ -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Wno-unused-result -Wno-unused-value $< -o $@ -lpthread
 
 bin/hbm_read_probe: tools/hbm_read_probe.hip
 	@mkdir -p bin
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Wno-unused-result $< -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Wno-unused-result -Wno-unused-value $< -o $@
 
 clean:
 	rm -f $(CSRC)/*.o $(LIB) bin/papr bin/hbm_read_probe bin/ingest_probe
