@@ -24,6 +24,7 @@ region starts (generated on the device by the shared counter-hash generator).
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -86,70 +87,28 @@ def cpu_baseline(pkg, mode: str, sample_gib: float):
             os.unlink(path)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", choices=["default", "graph"], default="default")
-    ap.add_argument("--gib", type=float, default=10.0, help="GiB of IQ per GPU")
-    ap.add_argument("--exact", action="store_true",
-                    help="also reproduce the reference's sequential double sum bit for bit every step "
-                         "(rounding functions computed in the pass-2 sweep + a short host chain); off by default")
-    ap.add_argument("--two-pass", action="store_true",
-                    help="read the shard twice (papr_stats_kernel + papr_ccdf_kernel) instead of the one-sweep path")
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
-                    help="torch.distributed backend; gloo (+ ranks sharing GPUs round-robin) exists so the N>1 "
-                         "code path can be exercised on a box with fewer GPUs than ranks")
-    ap.add_argument("--cpu-sample-gib", type=float, default=None)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def golden_report(world: int, gib: float, graph: bool):
+    """The reference's recorded stdout for this run's global stream (tests/golden/, produced by the reference
+    binary in the build container), or None when no golden exists for the configuration."""
+    if abs(gib - 10.0) > 1e-12:
+        return None, None
+    name = f"big_spike{10 * world}g.{'graph' if graph else 'default'}.txt"
+    path = os.path.join(ROOT, "tests", "golden", name)
+    if not os.path.exists(path):
+        return None, None
+    with open(path, "rb") as f:
+        return f.read(), name
 
-    # stdout carries exactly ONE line (the JSON): library chatter during set-up (e.g. the RCCL
-    # version banner printed at communicator creation) is routed to stderr until then
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus > 1 launch with torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the papr product has no CPU path")
-    if args.backend == "gloo":
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ   # under torchrun even N=1 goes through RCCL
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    pkg = ge.load_package()
-    from dtv_utils_amd import exchange
-    graph = args.mode == "graph"
-
-    per_gpu = int(args.gib * (1 << 30)) // 8 // 8192 * 8192   # samples per rank, chunk aligned
-    total = per_gpu * world
-    shard = torch.empty(per_gpu * 8 + 65536, dtype=torch.uint8, device=device)   # HBM-resident shard
-    gpu = pkg.PaprHip(local_rank)
-    gpu.adopt(shard.data_ptr(), per_gpu, base_index=rank * per_gpu, keepalive=shard)
-    gpu.generate(pkg.SynthSpec.spike(total), rank * per_gpu, per_gpu)
+def run_mode(args, mode, env):
+    """Warm up, time exactly --steps steps of one mode, and (rank 0) build its JSON line."""
+    pkg, gpu, xch = env["pkg"], env["gpu"], env["xch"]
+    world, rank, device, use_dist = env["world"], env["rank"], env["device"], env["use_dist"]
+    per_gpu, total, one_sweep = env["per_gpu"], env["total"], env["one_sweep"]
+    graph = mode == "graph"
+    args = argparse.Namespace(**{**vars(args), "mode": mode})
 
     result = {}
-    xch = exchange.Exchange(device if args.backend == "nccl" else torch.device("cpu"))
-
-    if args.exact:
-        gpu.set_exact(True)
-    one_sweep = not (args.two_pass or args.exact)
 
     def step():
         if one_sweep:
@@ -234,6 +193,10 @@ def main():
                     traffic, traffic_src = ent["hbm_bytes_per_launch"], tj.get("source")
             except Exception:
                 pass
+        # in-run parity: what this run would print, against what the REFERENCE printed for the same global stream
+        report = pkg.format_report(result["total"], result["mean"], result["papr"], result["counts"], graph).encode()
+        golden, golden_name = golden_report(world, args.gib, graph)
+        parity = None if golden is None else (report == golden)
         line = {
             "metric": "IQ Msamples/s + achieved HBM GB/s (% of peak), 10 GiB cfile, 1/2/4/8 GPU",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -259,11 +222,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": per_gpu * 8,
-                         "traffic_source": traffic_src,
-                         # the reference's algorithm reads every sample twice (16 B/sample); the rate
-                         # at which THOSE bytes are retired by the whole step, for comparison with two-pass numbers
-                         "two_read_equivalent_GBs": 2 * per_gpu * 8 / (kernel_ms_per_step * 1e-3) / 1e9
-                         if kernel_ms_per_step else None},
+                         "traffic_source": traffic_src},
+            # stdout of this run (last step) == the reference program's recorded stdout for the same stream
+            # (tests/golden/<name>; null: no golden for this size / rank count)
+            "parity_in_run": parity, "parity_golden": golden_name,
+            "report_sha256": hashlib.sha256(report).hexdigest(),
             "kernels": {"papr_stats_kernel": {"avg_ms": k_stats, "GB/s": gbs_stats, "launches": int(tm.stats_launches)},
                         "papr_ccdf_kernel": {"avg_ms": k_ccdf, "GB/s": gbs_ccdf, "launches": int(tm.ccdf_launches)},
                         "papr_sweep_kernel": {"avg_ms": k_sweep, "GB/s": gbs_sweep, "launches": int(tm.sweep_launches)},
@@ -275,11 +238,86 @@ def main():
                         "host_and_exchange_ms_per_step": ms_per_step - kernel_ms_per_step},
             "device": gpu.name,
         }
+        return line
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["default", "graph", "both"], default="both",
+                    help="default = configs[1] (1 dB table), graph = configs[2] (papr -g, 0.1 dB CCDF); both (the "
+                         "default) times configs[1] as the headline and adds configs[2] under \"graph\" in the same line")
+    ap.add_argument("--gib", type=float, default=10.0, help="GiB of IQ per GPU")
+    ap.add_argument("--exact", action="store_true",
+                    help="also reproduce the reference's sequential double sum bit for bit every step "
+                         "(rounding functions computed in the pass-2 sweep + a short host chain); off by default")
+    ap.add_argument("--two-pass", action="store_true",
+                    help="read the shard twice (papr_stats_kernel + papr_ccdf_kernel) instead of the one-sweep path")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend; gloo (+ ranks sharing GPUs round-robin) exists so the N>1 "
+                         "code path can be exercised on a box with fewer GPUs than ranks")
+    ap.add_argument("--cpu-sample-gib", type=float, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    # stdout carries exactly ONE line (the JSON): library chatter during set-up (e.g. the RCCL
+    # version banner printed at communicator creation) is routed to stderr until then
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus > 1 launch with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the papr product has no CPU path")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ   # under torchrun even N=1 goes through RCCL
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    pkg = ge.load_package()
+    from dtv_utils_amd import exchange
+    per_gpu = int(args.gib * (1 << 30)) // 8 // 8192 * 8192   # samples per rank, chunk aligned
+    total = per_gpu * world
+    shard = torch.empty(per_gpu * 8 + 65536, dtype=torch.uint8, device=device)   # HBM-resident shard
+    gpu = pkg.PaprHip(local_rank)
+    gpu.adopt(shard.data_ptr(), per_gpu, base_index=rank * per_gpu, keepalive=shard)
+    gpu.generate(pkg.SynthSpec.spike(total), rank * per_gpu, per_gpu)
+    xch = exchange.Exchange(device if args.backend == "nccl" else torch.device("cpu"))
+    if args.exact:
+        gpu.set_exact(True)
+    one_sweep = not (args.two_pass or args.exact)
+    env = dict(pkg=pkg, gpu=gpu, xch=xch, world=world, rank=rank, device=device, use_dist=use_dist, per_gpu=per_gpu,
+               total=total, one_sweep=one_sweep)
+    modes = ["default", "graph"] if args.mode == "both" else [args.mode]
+    lines = [run_mode(args, m, env) for m in modes]
+    if rank == 0:
+        line = lines[0]
+        if len(lines) > 1:   # configs[2] rides along: same shard, same code path, the 0.1 dB table
+            line["graph"] = {k: lines[1][k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "kernels",
+                                                       "parity_in_run")}
         if world == 1 and not args.no_cpu_baseline:
-            sample = args.cpu_sample_gib if args.cpu_sample_gib else (1.0 if graph else 4.0)   # ~10-15 s of reference CPU time
+            mode0 = modes[0]
+            sample = args.cpu_sample_gib if args.cpu_sample_gib else (1.0 if mode0 == "graph" else 4.0)   # ~10-15 s of reference CPU time
             sample = min(sample, args.gib)
             try:
-                cb = cpu_baseline(pkg, args.mode, sample)
+                cb = cpu_baseline(pkg, mode0, sample)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 cb = {"error": repr(e)}
             line["cpu_baseline"] = cb

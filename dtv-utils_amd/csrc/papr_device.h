@@ -75,7 +75,7 @@ __device__ __forceinline__ uint32_t lut_bin(uint32_t bits, const uint2 *lut, con
         k = e.x + (bits >= e.y ? 1u : 0u);
     } else {
         // above the table but not NaN => above every level; below or NaN => 0
-        k = (bits - P.above_lo) <= P.above_span ? P.nkeys : 0u;
+        k = (bits - P.above_lo) < P.above_count ? P.nkeys : 0u;
     }
     return k;
 }

@@ -8,7 +8,8 @@ using namespace papr_rt;
 
 namespace papr_rt {
 
-CpuSet numa_cpus_of_device(int device)
+// (computed once per device and cached: bin/papr drives one thread per GPU shard through here concurrently)
+static CpuSet numa_cpus_of_device_uncached(int device)
 {
     CpuSet out;
     CPU_ZERO(&out.set);
@@ -45,21 +46,41 @@ CpuSet numa_cpus_of_device(int device)
     if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
         return out;
     int count = 0;
-    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
-        int a = 0, b = 0;
-        const int k = sscanf(tok, "%d-%d", &a, &b);
-        if (k == 1)
-            b = a;
-        if (k < 1)
-            continue;
-        for (int c = a; c <= b && c < CPU_SETSIZE; c++)
+    for (const char *p = list; *p;) {
+        char *end = nullptr;
+        const long a = strtol(p, &end, 10);
+        if (end == p)
+            break;  // not a number: end of the list
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            if (end == p + 1)
+                break;
+            p = end;
+        }
+        for (long c = std::max<long>(a, 0); c <= b && c < CPU_SETSIZE; c++)
             if (CPU_ISSET(c, &allowed)) {
                 CPU_SET(c, &out.set);
                 count++;
             }
+        while (*p == ',' || *p == ' ' || *p == '\n')
+            p++;
     }
     out.valid = count > 0 && count < CPU_COUNT(&allowed);  // nothing to gain when the node is all we have
     return out;
+}
+
+CpuSet numa_cpus_of_device(int device)
+{
+    static std::mutex m;
+    static std::vector<std::pair<int, CpuSet>> cache;
+    std::lock_guard<std::mutex> g(m);
+    for (const auto &e : cache)
+        if (e.first == device)
+            return e.second;
+    cache.emplace_back(device, numa_cpus_of_device_uncached(device));
+    return cache.back().second;
 }
 
 // Fraction of the file that is in the page cache, from mincore() on 64 windows of 1 MiB spread over it.
@@ -152,18 +173,19 @@ int read_samples(const FileSrc &fs, uint64_t s0, uint64_t cnt, unsigned char *ds
         want = file_bytes > byte0 ? file_bytes - byte0 : 0;
     uint64_t done = 0;
     // O_DIRECT (cold files: the device DMAs into the pinned buffer, no page-cache copy) needs 4 KiB-aligned
-    // offset, address and length; slices are cut that way, the request is rounded up and a short count
-    // at end of file is expected.  Anything that does not fit falls through to the buffered descriptor.
+    // offset, address and length: the whole 4 KiB blocks of the request go through the direct descriptor, never a
+    // byte more than was asked for (nothing is written past dst + want); the sub-block remainder, an unaligned
+    // request, a short count at the end of the file or an error fall through to the buffered descriptor.
     if (fs.fd_direct >= 0 && (byte0 & 4095) == 0 && ((uintptr_t)dst & 4095) == 0) {
-        while (done < want) {
-            const uint64_t ask = std::min<uint64_t>((want - done + 4095) & ~4095ull, (uint64_t)1 << 30);
-            ssize_t got = pread(fs.fd_direct, dst + done, ask, (off_t)(byte0 + done));
-            if (got <= 0 || (got & 4095) != 0) {
-                if (got > 0)
-                    done += std::min<uint64_t>((uint64_t)got, want - done);
-                break;  // error, or the unaligned end of the file: the buffered path finishes the job
-            }
-            done += std::min<uint64_t>((uint64_t)got, want - done);
+        const uint64_t direct_want = want & ~4095ull;
+        while (done < direct_want) {
+            const uint64_t ask = std::min<uint64_t>(direct_want - done, (uint64_t)1 << 30);
+            const ssize_t got = pread(fs.fd_direct, dst + done, ask, (off_t)(byte0 + done));
+            if (got <= 0)
+                break;
+            done += (uint64_t)got;
+            if ((got & 4095) != 0)
+                break;  // the unaligned end of the file
         }
     }
     while (done < want) {
@@ -383,7 +405,7 @@ int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, u
     if (first_sample > fs.nsamples)
         return fail(ctx, PAPR_E_ARG, "first_sample %llu is past the end of %s (%llu samples)",
                     (unsigned long long)first_sample, path, (unsigned long long)fs.nsamples);
-    if (nsamples == UINT64_MAX || first_sample + nsamples > fs.nsamples)
+    if (nsamples > fs.nsamples - first_sample)  // (also UINT64_MAX = "to the end"; written so that it cannot wrap)
         nsamples = fs.nsamples - first_sample;
 
     const bool fits = (nsamples + PAPR_TILE_SAMPLES_MAX) * 8 <= ctx->hbm_budget;
@@ -529,7 +551,7 @@ int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_s
         return fail(ctx, PAPR_E_ARG, "first_sample %llu is past the end of %s (%llu samples)",
                     (unsigned long long)first_sample, path, (unsigned long long)fs.nsamples);
     }
-    if (nsamples == UINT64_MAX || first_sample + nsamples > fs.nsamples)
+    if (nsamples > fs.nsamples - first_sample)
         nsamples = fs.nsamples - first_sample;
     ctx->sweep_info.estimate_samples = 0;
     const uint64_t ntiles = nsamples / PAPR_ESTIMATE_TILE_SAMPLES;

@@ -58,7 +58,7 @@ struct papr_ccdf_params {
     uint32_t ncells;      // LUT: cells in the table
     uint32_t nkeys;       // unique thresholds (histogram has nkeys + 1 bins)
     uint32_t above_lo;    // LUT: first bit pattern past the table
-    uint32_t above_span;  // LUT: 0x7F800000 - above_lo
+    uint32_t above_count; // LUT: patterns in [above_lo, +Inf] (0 when the table reaches past +Inf)
     uint32_t table_words; // 32-bit words of table to stage into LDS
     uint32_t copies;      // LDS histogram copies per workgroup
     uint32_t search_step; // search: largest power of two <= nkeys

@@ -313,8 +313,11 @@ int finish_plan(papr_hip_ctx *ctx, CcdfPlan *plan, int vblock, size_t extra_lds)
             P.shift = (uint32_t)shift;
             P.cell_lo = c0;
             P.ncells = (uint32_t)ncells;
-            P.above_lo = (uint32_t)(((uint64_t)c1 + 1) << shift);
-            P.above_span = 0x7F800000u - P.above_lo;
+            // patterns past the table that are still numbers (<= +Inf) lie above every level; when the top cell
+            // reaches past +Inf (a level equal to FLT_MAX) there are none
+            const uint64_t above = ((uint64_t)c1 + 1) << shift;
+            P.above_lo = above <= 0x7F800000u ? (uint32_t)above : 0x7F800001u;
+            P.above_count = above <= 0x7F800000u ? 0x7F800001u - P.above_lo : 0u;
             P.table_words = 2 * P.ncells;
             plan->lut = true;
             break;

@@ -103,15 +103,26 @@ static void *pass2_thread(void *arg)
     return NULL;
 }
 
-/* like run_all below, but a failure is not fatal (the shard may not be resident): no message */
-static int run_all_quiet(shard *sh, int n, void *(*fn)(void *))
+/* run fn on every shard, one thread per GPU (a shard whose thread cannot be created runs inline) */
+static void run_shards(shard *sh, int n, void *(*fn)(void *))
 {
     pthread_t th[MAX_GPUS];
+    int started[MAX_GPUS];
     for (int g = 1; g < n; g++)
-        pthread_create(&th[g], NULL, fn, &sh[g]);
+        started[g] = pthread_create(&th[g], NULL, fn, &sh[g]) == 0;
     fn(&sh[0]);
-    for (int g = 1; g < n; g++)
-        pthread_join(th[g], NULL);
+    for (int g = 1; g < n; g++) {
+        if (started[g])
+            pthread_join(th[g], NULL);
+        else
+            fn(&sh[g]);
+    }
+}
+
+/* like run_all below, but a failure is not fatal (the caller has another way): no message here */
+static int run_all_quiet(shard *sh, int n, void *(*fn)(void *))
+{
+    run_shards(sh, n, fn);
     for (int g = 0; g < n; g++)
         if (sh[g].rc != PAPR_OK)
             return sh[g].rc;
@@ -120,12 +131,7 @@ static int run_all_quiet(shard *sh, int n, void *(*fn)(void *))
 
 static int run_all(shard *sh, int n, void *(*fn)(void *))
 {
-    pthread_t th[MAX_GPUS];
-    for (int g = 1; g < n; g++)
-        pthread_create(&th[g], NULL, fn, &sh[g]);
-    fn(&sh[0]);
-    for (int g = 1; g < n; g++)
-        pthread_join(th[g], NULL);
+    run_shards(sh, n, fn);
     for (int g = 0; g < n; g++)
         if (sh[g].rc != PAPR_OK) {
             fprintf(stderr, "papr: GPU %d: %s (code %d)\n", sh[g].device, papr_hip_last_error(sh[g].ctx), sh[g].rc);
@@ -284,7 +290,8 @@ int main(int argc, char **argv)
      * NaN/Inf present the merged record already carries the reference's value. ---- */
     int exact_done = 0, need_pass2 = nlevels > 0;
     double t1x = now_s();
-    if (exact && isfinite(total.sum) && run_all_quiet(sh, ngpu, exact_thread) == PAPR_OK) {
+    int exact_rc = PAPR_OK;
+    if (exact && isfinite(total.sum) && (exact_rc = run_all_quiet(sh, ngpu, exact_thread)) == PAPR_OK) {
         const void *progs[MAX_GPUS];
         size_t sizes[MAX_GPUS];
         double seq;
@@ -292,7 +299,8 @@ int main(int argc, char **argv)
             progs[g] = sh[g].program;
             sizes[g] = sh[g].program_bytes;
         }
-        if (papr_exact_chain(progs, sizes, ngpu, &seq) == PAPR_OK) {
+        exact_rc = papr_exact_chain(progs, sizes, ngpu, &seq);
+        if (exact_rc == PAPR_OK) {
             total.sum = seq;
             exact_done = 1;
             need_pass2 = 0;
@@ -318,6 +326,16 @@ int main(int argc, char **argv)
             }
         }
         t1x = now_s();
+    }
+    if (exact_rc != PAPR_OK) {
+        /* stdout stays the reference's format; the mean (and, rarely, a threshold) now comes from the parallel
+         * tree sum, which may differ from the reference's sequential sum in the last printed digit: say so */
+        const char *why = "";
+        for (int g = 0; g < ngpu; g++)
+            if (sh[g].rc != PAPR_OK)
+                why = papr_hip_last_error(sh[g].ctx);
+        fprintf(stderr, "papr: warning: bit-exact sequential sum abandoned (code %d%s%s); using the parallel sum\n",
+                exact_rc, why[0] ? ": " : "", why);
     }
     if (need_pass2 && run_all(sh, ngpu, pass2_thread) != PAPR_OK)
         return 253;

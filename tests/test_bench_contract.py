@@ -12,7 +12,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-        "vs_baseline", "dtype", "data", "config", "roofline"}
+        "vs_baseline", "dtype", "data", "config", "roofline", "parity_in_run"}
 
 
 def check(line, steps, warmup):
@@ -39,6 +39,24 @@ def test_single_process_line_with_cpu_baseline():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
     assert cb["gpu_stdout_identical"] is True
+    # no --mode: configs[1] is the headline, configs[2] (papr -g) rides along in the same line
+    assert d["config"]["mode"] == "default" and d["graph"]["config"]["mode"] == "graph"
+    assert d["graph"]["config"]["levels"] > 5 * d["config"]["levels"] and d["graph"]["value"] > 0
+    assert d["graph"]["roofline"]["kernel"] == d["roofline"]["kernel"]
+    # 0.5 GiB has no recorded reference stdout: parity_in_run must say so rather than claim anything
+    assert d["parity_in_run"] is None and d["graph"]["parity_in_run"] is None
+
+
+def test_full_size_line_checks_itself_against_the_reference_stdout():
+    """The driver's invocation (10 GiB, both tables): the line's own parity flags are computed from the recorded
+    stdout of the reference program for the same stream and must be true in both modes."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = check([l for l in p.stdout.splitlines() if l.strip()][0], 5, 1)
+    assert d["parity_in_run"] is True and d["parity_golden"] == "big_spike10g.default.txt"
+    assert d["graph"]["parity_in_run"] is True and d["graph"]["parity_golden"] == "big_spike10g.graph.txt"
+    assert d["config"]["one_sweep"]["steps_resolved_from_the_sweep"] == 5
 
 
 def _free_port():

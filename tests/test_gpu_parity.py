@@ -224,6 +224,9 @@ def test_ccdf_arbitrary_level_tables(pkg, orc, gpu):
         "one": np.array([1.0], np.float32),
         "wide": (10 ** np.linspace(-30, 30, 200)).astype(np.float32),
         "denormals": np.array([1e-44, 1e-42, 1e-40, 1e-38], np.float32),
+        # a level equal to FLT_MAX puts the top LUT cell past +Inf: nothing but +Inf itself is above it
+        "flt_max": np.array([1.0, np.finfo(np.float32).max, 2.0], np.float32),
+        "flt_max_only": np.array([np.finfo(np.float32).max, np.float32(3.0e38)], np.float32),
     }
     for tag, tab in tables.items():
         got = gpu.ccdf(tab)
@@ -311,6 +314,94 @@ def test_file_ingest_chunking_and_sharding(pkg, orc, tmp_path, monkeypatch):
             assert np.array_equal(counts.astype(np.int64), ref["count"])
 
 
+def _disk_dir():
+    """A directory on a real block-device filesystem (O_DIRECT is refused by tmpfs), or None."""
+    for cand in (os.environ.get("PAPR_TEST_DISK_DIR"), os.path.join(ROOT, "gpurun_out"), "/var/tmp", "/root"):
+        if not cand:
+            continue
+        try:
+            os.makedirs(cand, exist_ok=True)
+            probe = os.path.join(cand, f".papr_odirect_probe_{os.getpid()}")
+            with open(probe, "wb") as f:
+                f.write(b"\0" * 4096)
+            try:
+                fd = os.open(probe, os.O_RDONLY | os.O_DIRECT)
+                os.close(fd)
+                return cand
+            except OSError:
+                pass
+            finally:
+                os.unlink(probe)
+        except OSError:
+            continue
+    return None
+
+
+@pytest.mark.parametrize("budget", [None, "4"], ids=["resident", "streamed"])
+def test_file_ingest_o_direct(pkg, orc, monkeypatch, budget):
+    """PAPR_O_DIRECT=1 (what a cold file >= 64 MiB gets automatically): 4 KiB-aligned direct reads into the pinned
+    staging buffers, the unaligned end of the file finished by the buffered descriptor, odd-float tail + stray
+    bytes patched after a direct read, a shard whose start is not 4 KiB-aligned (falls through to buffered reads),
+    many chunks; resident and re-streamed.  Everything against the oracle on the same file."""
+    d = _disk_dir()
+    if d is None:
+        pytest.skip("no filesystem here accepts O_DIRECT")
+    n = 3 * 1048576 + 12345
+    path = os.path.join(d, f"papr_odirect_{os.getpid()}.cfile")
+    try:
+        subprocess.check_call([orc.MKCFILE, path, str(n), "--spike", "--extra-floats", "1", "--extra-bytes", "3"])
+        ref = orc.run_file(path, True)
+        monkeypatch.setenv("PAPR_O_DIRECT", "1")
+        monkeypatch.setenv("PAPR_CHUNK_MB", "1")
+        monkeypatch.setenv("PAPR_READ_THREADS", "5")    # slices that are not 4 KiB multiples of each other
+        if budget:
+            monkeypatch.setenv("PAPR_HBM_BUDGET_MB", budget)
+        with pkg.PaprHip(0) as g:
+            g.load_file(path)
+            t = g.ingest_timing()
+            assert t.o_direct == 1 and t.resident == (0 if budget else 1), t.as_dict()
+            st = g.stats()
+            check_stats(st, ref)
+            assert st.flags & pkg.FLAG_ODD_TAIL
+            mean, papr, table = pkg.levels(st, True)
+            assert np.array_equal(table, ref["level"])
+            assert np.array_equal(g.ccdf(table).astype(np.int64), ref["count"])
+            if not budget:
+                # the resident bytes are the file's bytes (plus the phantom partner), nothing read past `want` leaked in
+                got = g.download(0, st.n)
+                want = np.fromfile(path, dtype=np.float32, count=2 * st.n - 1)
+                assert np.array_equal(got[:-1].view(np.uint32), want.view(np.uint32))
+            # shards that start off a 4 KiB boundary (sample 8192 * k is aligned; 8192 * k + 100 is not) and a
+            # one-sweep ingest through the same descriptor
+            from dtv_utils_amd import exchange
+            parts, counts = [], np.zeros(table.size, np.uint64)
+            cuts = [0, 8192 * 37 + 100, 8192 * 200, pkg.file_samples(path)]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                g.load_file(path, a, b - a)
+                assert g.ingest_timing().o_direct == 1
+                parts.append(g.stats())
+                counts += g.ccdf(table)
+            check_stats(pkg.stats_merge(parts), ref)
+            assert np.array_equal(counts.astype(np.int64), ref["count"])
+            est = g.estimate_file(path)
+            g.load_file_sweep(path, pkg.guess_levels(est, True))
+            assert g.ingest_timing().o_direct == 1
+            st2 = g.stats()
+            check_stats(st2, ref)
+            assert np.array_equal(g.ccdf(pkg.levels(st2, True)[2]).astype(np.int64), ref["count"])
+        # the CLI on the same file, same switch
+        for graph in (False, True):
+            want = subprocess.run([orc.REF_CLI if os.path.exists(orc.REF_CLI) else orc.CLI_PATH] +
+                                  (["-g"] if graph else []) + [path], capture_output=True)
+            got = subprocess.run([pkg.CLI_PATH] + (["-g"] if graph else []) + [path], capture_output=True,
+                                 env=dict(os.environ, PAPR_STATS="1"))
+            assert got.stdout == want.stdout and got.returncode == 0
+            assert b'"o_direct": 1' in got.stderr
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+
+
 def test_nan_first_index_and_sign_when_streamed(pkg, orc, tmp_path, monkeypatch):
     path = str(tmp_path / "nan.cfile")
     subprocess.check_call([orc.MKCFILE, path, "600000", "--set", "500000", "nan", "1", "--set", "300001", "1", "-nan"])
@@ -351,6 +442,29 @@ def test_full_size_matches_reference_stdout(pkg, manifest, big, graph):
     counts = g.ccdf(table)
     got = pkg.format_report(st, mean, papr, counts, graph).encode()
     assert got == golden_text("big_spike10g", graph)
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["default", "graph"])
+def test_full_size_one_sweep_matches_reference_stdout(pkg, manifest, big, graph):
+    """The path bench.py times by default — estimate -> guessed bands -> ONE sweep -> stash recount — on the
+    10 GiB workload against the stdout the real reference printed for it, answered from the sweep (no second read)."""
+    if "big_spike10g" not in manifest:
+        pytest.skip("full-size golden not recorded")
+    g, n = big
+    est = g.estimate()
+    st = g.stats_sweep(pkg.guess_levels(est, graph))
+    info = g.sweep_info()
+    assert info.swept == 1, info.as_dict()
+    mean, papr, table = pkg.levels(st, graph)
+    counts = g.ccdf(table)
+    info = g.sweep_info()
+    assert info.resolved == 1, info.as_dict()
+    assert pkg.format_report(st, mean, papr, counts, graph).encode() == golden_text("big_spike10g", graph)
+    # and the sweep's pass-1 record equals the two-pass kernel's, indices included
+    two = g.stats()
+    for k in TRACKERS:
+        assert getattr(st, k) == getattr(two, k) and getattr(st, k + "_idx") == getattr(two, k + "_idx"), k
+    assert np.array_equal(g.ccdf(table), counts) and g.sweep_info().resolved == 0   # plain pass 2: same counts
 
 
 def test_full_size_properties(pkg, orc, big):
