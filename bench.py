@@ -112,8 +112,11 @@ def run_mode(args, mode, env):
 
     def step():
         if one_sweep:
-            est = pkg.stats_merge(xch.allgather_stats(gpu.estimate()))   # 1/64-sample mean of the whole stream
-            local = gpu.stats_sweep(pkg.guess_levels(est, graph))        # pass 1 + banded pass 2, one read
+            ests = xch.allgather_stats(gpu.estimate())                   # 1/64-sample mean of every shard
+            est = pkg.stats_merge(ests)
+            if args.exact:   # what the earlier shards add to the reference's running sum, as far as the sample tells
+                gpu.set_exact_hint(float(sum(e.sum for e in ests[:rank])))
+            local = gpu.stats_sweep(pkg.guess_levels(est, graph))        # pass 1 + banded pass 2 (+ exact-sum pairs), one read
         else:
             local = gpu.stats()                              # pass 1 on this shard
         parts = xch.allgather_stats(local)                   # exchange 1 (RCCL all-gather)
@@ -125,10 +128,16 @@ def run_mode(args, mode, env):
             local_counts, prog = gpu.ccdf_exact(table, before, total)
             tot.sum = pkg.exact_chain(xch.allgather_bytes(prog))   # papr.c:104's rounding sequence, bit for bit
             mean, papr, table2 = pkg.levels(tot, graph)
+            if one_sweep:
+                info = gpu.sweep_info()
+                result["resolved"] = result.get("resolved", 0) + int(info.resolved)
+                result["redo_tiles"] = result.get("redo_tiles", 0) + int(info.exact_redo_tiles)
             if not np.array_equal(table2, table):            # the exact sum moved a float threshold (rare)
                 table = table2
-                local_counts = gpu.ccdf(table)
+                local_counts = gpu.ccdf(table)               # (one-sweep: the stash again, not the shard)
                 result["reruns"] = result.get("reruns", 0) + 1
+            if one_sweep:
+                result["sweep_info"] = gpu.sweep_info().as_dict()
         else:
             local_counts = gpu.ccdf(table)                   # pass 2 (one-sweep: recount of the stash only)
             if one_sweep:
@@ -147,6 +156,7 @@ def run_mode(args, mode, env):
     for _ in range(args.warmup):
         step()
     result.pop("resolved", None)
+    result.pop("redo_tiles", None)
     gpu.set_timing(True)
     fence()
     t0 = time.perf_counter()
@@ -209,6 +219,8 @@ def run_mode(args, mode, env):
                        "levels": int(result["table"].size), "papr_db": round(float(result["papr"]), 6),
                        "reads_of_the_shard_per_step": 1 if one_sweep and result.get("resolved", 0) == args.steps else 2,
                        "one_sweep": ({"steps_resolved_from_the_sweep": int(result.get("resolved", 0)),
+                                      "exact_redo_tiles_per_step": (result.get("redo_tiles", 0) / args.steps
+                                                                    if args.exact else None),
                                       **{k: result.get("sweep_info", {}).get(k) for k in
                                          ("stash_samples", "stash_capacity", "estimate_samples", "band_log2", "reason")}}
                                      if one_sweep else None),
@@ -254,6 +266,9 @@ def main():
     ap.add_argument("--exact", action="store_true",
                     help="also reproduce the reference's sequential double sum bit for bit every step "
                          "(rounding functions computed in the pass-2 sweep + a short host chain); off by default")
+    ap.add_argument("--exact-two-pass", action="store_true",
+                    help="with --exact: the round-1 form (pass 1 leaving per-tile sums, then the fused rounding-function + "
+                         "pass-2 sweep: two reads) instead of the one-read form")
     ap.add_argument("--two-pass", action="store_true",
                     help="read the shard twice (papr_stats_kernel + papr_ccdf_kernel) instead of the one-sweep path")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -302,7 +317,7 @@ def main():
     xch = exchange.Exchange(device if args.backend == "nccl" else torch.device("cpu"))
     if args.exact:
         gpu.set_exact(True)
-    one_sweep = not (args.two_pass or args.exact)
+    one_sweep = not (args.two_pass or (args.exact and args.exact_two_pass))
     env = dict(pkg=pkg, gpu=gpu, xch=xch, world=world, rank=rank, device=device, use_dist=use_dist, per_gpu=per_gpu,
                total=total, one_sweep=one_sweep)
     modes = ["default", "graph"] if args.mode == "both" else [args.mode]
@@ -311,7 +326,7 @@ def main():
         line = lines[0]
         if len(lines) > 1:   # configs[2] rides along: same shard, same code path, the 0.1 dB table
             line["graph"] = {k: lines[1][k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "kernels",
-                                                       "parity_in_run")}
+                                                       "parity_in_run", "parity_golden", "report_sha256")}
         if world == 1 and not args.no_cpu_baseline:
             mode0 = modes[0]
             sample = args.cpu_sample_gib if args.cpu_sample_gib else (1.0 if mode0 == "graph" else 4.0)   # ~10-15 s of reference CPU time

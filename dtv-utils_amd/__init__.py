@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
     "papr_hip_estimate", "papr_hip_stats_sweep", "papr_hip_get_sweep_info", "papr_guess_levels",
     "papr_hip_estimate_file", "papr_hip_load_file_sweep", "papr_hip_shard_fits",
-    "papr_level_key", "papr_sweep_bands", "papr_sweep_resolve",
+    "papr_level_key", "papr_sweep_bands", "papr_sweep_resolve", "papr_hip_set_exact_hint",
 )
 
 
@@ -106,7 +106,8 @@ SWEEP_REASONS = ("ok", "no sweep", "exact mode / not resident", "no band form", 
 class SweepInfo(C.Structure):
     """papr_hip_sweep_info: what the last one-sweep pass / papr_hip_ccdf did."""
     _fields_ = [("stash_samples", C.c_uint64), ("stash_capacity", C.c_uint64), ("estimate_samples", C.c_uint64),
-                ("swept", C.c_int), ("resolved", C.c_int), ("reason", C.c_int), ("band_log2", C.c_int)]
+                ("swept", C.c_int), ("resolved", C.c_int), ("reason", C.c_int), ("band_log2", C.c_int),
+                ("exact_redo_tiles", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self) -> dict:
         d = {name: getattr(self, name) for name, _ in self._fields_}
@@ -198,6 +199,8 @@ def lib() -> C.CDLL:
     L.papr_hip_shard_fits.restype = i32
     L.papr_hip_load_file_sweep.argtypes = [vp, C.c_char_p, u64, u64, vp, i32]
     L.papr_hip_get_sweep_info.argtypes = [vp, C.POINTER(SweepInfo)]
+    L.papr_hip_set_exact_hint.argtypes = [vp, C.c_double]
+    L.papr_hip_set_exact_hint.restype = i32
     for name in ("papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
                  "papr_hip_estimate", "papr_hip_stats_sweep", "papr_hip_get_sweep_info", "papr_hip_estimate_file",
                  "papr_hip_load_file_sweep"):
@@ -413,6 +416,10 @@ class PaprHip:
     # bit-exact mean
     def set_exact(self, enabled: bool = True):
         self._chk(self._L.papr_hip_set_exact(self._ctx, int(enabled)), "papr_hip_set_exact")
+
+    def set_exact_hint(self, estimated_sum_before_shard: float):
+        """Exact one-read sweep: the estimated sum of everything before this shard (0 for the first)."""
+        self._chk(self._L.papr_hip_set_exact_hint(self._ctx, float(estimated_sum_before_shard)), "papr_hip_set_exact_hint")
 
     def exact_program(self, before: float = 0.0, n_total: int = 0) -> bytes:
         """This shard's serialised sum program (needs set_exact(True) + stats() first)."""

@@ -60,10 +60,17 @@ __device__ __forceinline__ double two_pow(int e)  // 2^e for normal results
     return __longlong_as_double((long long)(e + 1023) << 52);
 }
 
+// a tile's sum: from pass 1's four per-wave sums, or (SEGD: the one-read sweep) from D0 of its two segments' pairs
+template <bool SEGD>
 __device__ __forceinline__ double tile_sum_of(const double *tws, uint64_t tile)
 {
-    const double *p = tws + tile * PAPR_EXACT_TILE_WAVES;
-    return ((p[0] + p[1]) + p[2]) + p[3];
+    if constexpr (SEGD) {
+        const double *p = tws + tile * 4;  // two double2 per tile: (D0, D1) of either segment
+        return p[0] + p[2];
+    } else {
+        const double *p = tws + tile * PAPR_EXACT_TILE_WAVES;
+        return ((p[0] + p[1]) + p[2]) + p[3];
+    }
 }
 
 // (f then g) for entry parity 0 / 1; m0 = 2^E
@@ -123,6 +130,7 @@ __device__ __forceinline__ Pair wave_compose(Pair f, double m0)
 
 // ---- tile prefix sums and classification ------------------------------------------
 
+template <bool SEGD>
 __global__ __launch_bounds__(256) void papr_exact_block_sums(const double *__restrict__ tws, uint64_t ntiles,
                                                               double *__restrict__ block_sums)
 {
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256) void papr_exact_block_sums(const double *__res
     double s = 0.0;
     for (int k = 0; k < 4; k++)
         if (t0 + k < ntiles)
-            s += tile_sum_of(tws, t0 + k);
+            s += tile_sum_of<SEGD>(tws, t0 + k);
     sh[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -172,17 +180,23 @@ __global__ __launch_bounds__(256) void papr_exact_scan_blocks(double *__restrict
     }
 }
 
+// `spec` (one-read sweep): the binade each tile's pairs were built for; a tile that is provably inside ANOTHER binade
+// (or had none) goes on the redo list — its two segments are recomputed by papr_exact_seg_kernel's list form
+template <bool SEGD>
 __global__ __launch_bounds__(256) void papr_exact_classify(const double *__restrict__ tws, uint64_t ntiles,
                                                             const double *__restrict__ block_prefix, double delta,
                                                             int32_t *__restrict__ tile_E,
                                                             uint32_t *__restrict__ ambig_list, uint32_t ambig_cap,
-                                                            uint32_t *__restrict__ ambig_count)
+                                                            uint32_t *__restrict__ ambig_count,
+                                                            const int32_t *__restrict__ spec,
+                                                            uint32_t *__restrict__ redo_list, uint32_t redo_cap,
+                                                            uint32_t *__restrict__ redo_count)
 {
     __shared__ double sh[256];
     const uint64_t t0 = (uint64_t)blockIdx.x * kTilesPerBlock + (uint64_t)threadIdx.x * 4;
     double s[4], tot = 0.0;
     for (int k = 0; k < 4; k++) {
-        s[k] = t0 + k < ntiles ? tile_sum_of(tws, t0 + k) : 0.0;
+        s[k] = t0 + k < ntiles ? tile_sum_of<SEGD>(tws, t0 + k) : 0.0;
         tot += s[k];
     }
     sh[threadIdx.x] = tot;
@@ -215,6 +229,11 @@ __global__ __launch_bounds__(256) void papr_exact_classify(const double *__restr
             }
         }
         tile_E[t0 + k] = cls;
+        if (spec && cls != PAPR_EXACT_AMBIG && cls != PAPR_EXACT_ZERO && cls != spec[t0 + k]) {
+            const uint32_t pos = atomicAdd(redo_count, 1u);
+            if (pos < redo_cap)
+                redo_list[pos] = (uint32_t)(t0 + k);
+        }
         if (cls == PAPR_EXACT_AMBIG && ambig_list) {  // re-streamed shards: remember which tiles to capture raw
             const uint32_t pos = atomicAdd(ambig_count, 1u);
             if (pos < ambig_cap)
@@ -239,9 +258,15 @@ __global__ __launch_bounds__(BLOCK) void papr_exact_seg_kernel(const float4 *__r
                                                               double2 *__restrict__ seg_D,
                                                               const float2 *__restrict__ tail, uint32_t tail_samples,
                                                               const uint32_t *__restrict__ table, papr_ccdf_params P,
-                                                              unsigned long long *__restrict__ ghist)
+                                                              unsigned long long *__restrict__ ghist,
+                                                              const uint32_t *__restrict__ tile_list,
+                                                              const uint32_t *__restrict__ tile_count, uint32_t list_cap)
 {
     constexpr int kWaves = BLOCK / kWave;
+    // list form (the one-read sweep's redo pass): only the two segments of each listed tile
+    if (tile_list)
+        nsegs = 2ull * min(*tile_count, list_cap);
+    auto seg_of = [&](uint64_t i) -> uint64_t { return tile_list ? 2ull * tile_list[i >> 1] + (i & 1) : i; };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *lds = reinterpret_cast<float4 *>(smem);                    // kWaves x (64 runs x 8 float4)
     uint32_t *tab = reinterpret_cast<uint32_t *>(lds + kWaves * kSegF4);
@@ -269,19 +294,21 @@ __global__ __launch_bounds__(BLOCK) void papr_exact_seg_kernel(const float4 *__r
 
     const uint64_t nwaves = (uint64_t)gridDim.x * kWaves;
     // software pipeline: the next segment's loads are in flight while this one is reduced
-    uint64_t seg = (uint64_t)blockIdx.x * kWaves + wave;
+    uint64_t item = (uint64_t)blockIdx.x * kWaves + wave;
     float4 x[kRows], nx[kRows];
     int curE = PAPR_EXACT_ZERO, nextE = PAPR_EXACT_ZERO;
-    if (seg < nsegs) {
+    uint64_t seg = 0, nseg = 0;
+    if (item < nsegs) {
+        seg = seg_of(item);
         curE = tile_E[seg >> 1];
         const float4 *p = data + seg * kSegF4 + lane;
 #pragma unroll
         for (int r = 0; r < kRows; r++)
             x[r] = load16<true>(p + r * kWave);
     }
-    for (; seg < nsegs; seg += nwaves) {
-        const uint64_t nseg = seg + nwaves;
-        if (nseg < nsegs) {
+    for (; item < nsegs; item += nwaves, seg = nseg) {
+        if (item + nwaves < nsegs) {
+            nseg = seg_of(item + nwaves);
             nextE = tile_E[nseg >> 1];  // fetched a whole iteration before it is needed
             const float4 *p = data + nseg * kSegF4 + lane;
 #pragma unroll
@@ -589,13 +616,30 @@ void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, ui
     const uint32_t nb = (uint32_t)((ntiles + kTilesPerBlock - 1) / kTilesPerBlock);
     if (nb == 0)
         return;
-    hipLaunchKernelGGL(papr_exact_block_sums, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums);
+    hipLaunchKernelGGL(papr_exact_block_sums<false>, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums);
     hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before);
-    hipLaunchKernelGGL(papr_exact_classify, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums, delta,
-                       tile_E, ambig_list, ambig_cap, ambig_count);
+    hipLaunchKernelGGL(papr_exact_classify<false>, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums, delta,
+                       tile_E, ambig_list, ambig_cap, ambig_count, (const int32_t *)nullptr, (uint32_t *)nullptr, 0u,
+                       (uint32_t *)nullptr);
     if (ambig_list)
         hipLaunchKernelGGL(papr_exact_sort_list_kernel, dim3(1), dim3(512), 0, st, ambig_list, ambig_count, ambig_cap,
                            ambig_sorted);
+}
+
+// One-read sweep: the tile sums are D0 of the segments' pairs (seg_D), and every tile whose proven binade differs
+// from the speculated one (`spec`) is listed for papr_launch_exact_redo.  *redo_count must be zero on entry.
+void papr_launch_exact_classify_swept(hipStream_t st, const void *seg_D, uint64_t ntiles, double *block_sums, double before,
+                                      double delta, int32_t *tile_E, const int32_t *spec, uint32_t *redo_list,
+                                      uint32_t redo_cap, uint32_t *redo_count)
+{
+    const uint32_t nb = (uint32_t)((ntiles + kTilesPerBlock - 1) / kTilesPerBlock);
+    if (nb == 0)
+        return;
+    const double *sums = (const double *)seg_D;
+    hipLaunchKernelGGL(papr_exact_block_sums<true>, dim3(nb), dim3(256), 0, st, sums, ntiles, block_sums);
+    hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before);
+    hipLaunchKernelGGL(papr_exact_classify<true>, dim3(nb), dim3(256), 0, st, sums, ntiles, block_sums, delta, tile_E,
+                       (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, spec, redo_list, redo_cap, redo_count);
 }
 
 void papr_launch_exact_capture(hipStream_t st, const void *chunk, uint64_t chunk_tile0, uint64_t chunk_ntiles,
@@ -635,7 +679,111 @@ void papr_launch_exact_segments(hipStream_t st, int blocks, const void *data, ui
     hipLaunchKernelGGL((papr_exact_seg_kernel<false, kSegBlock>), dim3(blocks), dim3(kSegBlock),
                        (size_t)(kSegBlock / kWave) * kSegF4 * sizeof(float4), st, (const float4 *)data, nsegs, tile_E,
                        (double2 *)seg_D, (const float2 *)nullptr, 0u, (const uint32_t *)nullptr, none,
-                       (unsigned long long *)nullptr);
+                       (unsigned long long *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u);
+}
+
+// the rounding functions of the LISTED tiles only (count read on the device: no host round trip in between)
+void papr_launch_exact_redo(hipStream_t st, int blocks, const void *data, const int32_t *tile_E, void *seg_D,
+                            const uint32_t *tile_list, const uint32_t *tile_count, uint32_t list_cap)
+{
+    papr_ccdf_params none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL((papr_exact_seg_kernel<false, kSegBlock>), dim3(blocks), dim3(kSegBlock),
+                       (size_t)(kSegBlock / kWave) * kSegF4 * sizeof(float4), st, (const float4 *)data, (uint64_t)0, tile_E,
+                       (double2 *)seg_D, (const float2 *)nullptr, 0u, (const uint32_t *)nullptr, none,
+                       (unsigned long long *)nullptr, tile_list, tile_count, list_cap);
+}
+
+// ---- one-read sweep: speculated binades from the mean estimate's per-group sums ----------------------------
+// group g of the estimate = tiles [g * ratio, (g + 1) * ratio); group_sums[4 g .. 4 g + 3] (one per wave of the
+// estimate kernel) add up to the sum of ONE tile's worth of its rows, so `scale` (= ratio) times that estimates
+// the group's sum.  Exclusive scan over the groups (one workgroup) ...
+__global__ __launch_bounds__(1024) void papr_exact_spec_scan_kernel(const double *__restrict__ group_sums, uint64_t ngroups,
+                                                                    double scale, double before,
+                                                                    double *__restrict__ group_prefix)
+{
+    __shared__ double sh[1024];
+    const uint64_t per = (ngroups + 1023) / 1024;
+    const uint64_t a = threadIdx.x * per, e = min(a + per, ngroups);
+    double s = 0.0;
+    auto gsum = [&](uint64_t k) { return (((group_sums[4 * k] + group_sums[4 * k + 1]) + group_sums[4 * k + 2]) + group_sums[4 * k + 3]) * scale; };
+    for (uint64_t k = a; k < e; k++)
+        s += gsum(k);
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = before;
+        for (int k = 0; k < 1024; k++) {
+            const double v = sh[k];
+            sh[k] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    double run = sh[threadIdx.x];
+    for (uint64_t k = a; k < e; k++) {
+        group_prefix[k] = run;
+        run += gsum(k);
+    }
+}
+
+// ... then per tile: the binade of the estimated prefix if the estimated tile lies well inside it, else none.
+// A wrong guess costs a redo of that tile, never a result (papr_exact_classify<true> checks every tile against
+// the TRUE prefix afterwards).
+__global__ __launch_bounds__(256) void papr_exact_spec_tiles_kernel(const double *__restrict__ group_sums,
+                                                                    const double *__restrict__ group_prefix,
+                                                                    uint64_t ngroups, uint32_t ratio, double scale,
+                                                                    uint64_t ntiles, int32_t *__restrict__ spec)
+{
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < ntiles; t += (uint64_t)gridDim.x * 256) {
+        uint64_t g = t / ratio;
+        if (g >= ngroups)
+            g = ngroups - 1;  // the tiles behind the last whole group: carried on at its rate
+        const double per_tile = (((group_sums[4 * g] + group_sums[4 * g + 1]) + group_sums[4 * g + 2]) + group_sums[4 * g + 3]) *
+                                scale / (double)ratio;
+        const double P = group_prefix[g] + (double)(t - g * ratio) * per_tile;
+        int32_t cls = PAPR_EXACT_AMBIG;
+        if (P > 0.0 && P < 1.0e300 && per_tile >= 0.0 && per_tile < 1.0e300) {
+            const int biased = (int)((__double_as_longlong(P) >> 52) & 0x7ff);
+            const int E = biased - 1023;
+            if (biased != 0 && E >= -960) {
+                const double m0 = two_pow(E);
+                if (P + per_tile < 2.0 * m0 && per_tile <= 0.25 * m0)
+                    cls = E;
+            }
+        }
+        spec[t] = cls;
+    }
+}
+
+__global__ __launch_bounds__(256) void papr_exact_fill_spec_kernel(int32_t *__restrict__ spec, uint64_t ntiles, int32_t E)
+{
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < ntiles; t += (uint64_t)gridDim.x * 256)
+        spec[t] = E;
+}
+
+void papr_launch_exact_spec(hipStream_t st, const double *group_sums, uint64_t ngroups, uint32_t ratio, double scale,
+                            double before, double *group_prefix, uint64_t ntiles, int32_t *spec)
+{
+    if (ntiles == 0)
+        return;
+    const int blocks = (int)std::min<uint64_t>((ntiles + 255) / 256, 1024);
+    if (ngroups == 0) {
+        hipLaunchKernelGGL(papr_exact_fill_spec_kernel, dim3(blocks), dim3(256), 0, st, spec, ntiles,
+                           (int32_t)PAPR_EXACT_AMBIG);
+        return;
+    }
+    hipLaunchKernelGGL(papr_exact_spec_scan_kernel, dim3(1), dim3(1024), 0, st, group_sums, ngroups, scale, before,
+                       group_prefix);
+    hipLaunchKernelGGL(papr_exact_spec_tiles_kernel, dim3(blocks), dim3(256), 0, st, group_sums, group_prefix, ngroups,
+                       ratio, scale, ntiles, spec);
+}
+
+void papr_launch_exact_fill_spec(hipStream_t st, int32_t *spec, uint64_t ntiles, int32_t E)
+{
+    if (ntiles)
+        hipLaunchKernelGGL(papr_exact_fill_spec_kernel, dim3((int)std::min<uint64_t>((ntiles + 255) / 256, 1024)),
+                           dim3(256), 0, st, spec, ntiles, E);
 }
 
 // the same sweep with pass 2 fused in (LUT form of the level table only); lds_table_bytes = table + histograms;
@@ -647,7 +795,8 @@ void papr_launch_exact_segments_ccdf(hipStream_t st, int blocks, const void *dat
 {
     hipLaunchKernelGGL((papr_exact_seg_kernel<true, kFusedBlock>), dim3(blocks), dim3(kFusedBlock),
                        papr_exact_transpose_lds_bytes() + lds_table_bytes, st, (const float4 *)data, nsegs, tile_E,
-                       (double2 *)seg_D, (const float2 *)tail, tail_samples, table, P, ghist);
+                       (double2 *)seg_D, (const float2 *)tail, tail_samples, table, P, ghist, (const uint32_t *)nullptr,
+                       (const uint32_t *)nullptr, 0u);
 }
 
 void papr_launch_exact_groups(hipStream_t st, const int32_t *tile_E, uint64_t ntiles, const void *seg_D,

@@ -18,6 +18,8 @@ int ensure_exact_buffers(papr_hip_ctx *ctx)
     if (ctx->d_tile_E) (void)hipFree(ctx->d_tile_E);
     if (ctx->d_seg_D) (void)hipFree(ctx->d_seg_D);
     if (ctx->d_groups) (void)hipFree(ctx->d_groups);
+    if (ctx->d_tile_E_spec) (void)hipFree(ctx->d_tile_E_spec);
+    ctx->d_tile_E_spec = nullptr;
     ctx->d_tile_sums = ctx->d_block_sums = ctx->d_seg_D = nullptr;
     ctx->d_tile_E = nullptr;
     ctx->d_groups = nullptr;
@@ -26,6 +28,7 @@ int ensure_exact_buffers(papr_hip_ctx *ctx)
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_tile_sums, cap * PAPR_EXACT_TILE_WAVES * sizeof(double)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_block_sums, (cap / 1024 + 2) * sizeof(double)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_tile_E, cap * sizeof(int32_t)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_tile_E_spec, cap * sizeof(int32_t)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_seg_D, cap * 2 * 2 * sizeof(double)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_groups, (cap / PAPR_EXACT_GROUP_TILES + 2) * sizeof(papr_exact_group)));
     ctx->exact_tiles_cap = cap;
@@ -70,6 +73,7 @@ int papr_hip_set_exact(papr_hip_ctx *ctx, int enabled)
     if ((enabled != 0) != ctx->exact) {
         ctx->exact = enabled != 0;
         ctx->exact_valid = false;
+        ctx->exact_swept = ctx->est_groups_valid = false;
         if (ctx->resident)
             ctx->have_file_stats = false;  // pass 1 is re-run over the resident shard in the other mode
     }
@@ -191,6 +195,88 @@ int run_exact_device(papr_hip_ctx *ctx, double before, uint64_t n_total, const C
     return PAPR_OK;
 }
 
+// The one-read form: papr_hip_stats_sweep already left every segment's sum and its pair for a SPECULATED binade in
+// d_seg_D.  What is left to do needs no sweep over the samples: true prefix sums from the segment sums, the true
+// classification, the pairs of the tiles whose speculated binade was wrong rebuilt from the resident samples
+// (normally a fraction of a per cent of them), group composition and the program gather.  Everything is queued on
+// the stream; the caller synchronises.  *redo_overflow (valid after that synchronisation) != 0: more tiles to redo
+// than the list holds — the caller then runs the full rounding-function sweep (run_exact_full_redo).
+int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total)
+{
+    const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
+    const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
+    const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
+    const double delta = std::max(1.0e-6, 8.0 * (double)std::max<uint64_t>(n_total, ctx->n) * 1.1102230246251565e-16);
+    if (!ctx->d_plan) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_mixed_list, kCapMixed * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_raw_list, kCapRaw * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_plan, sizeof(papr_exact_plan)));
+    }
+    if (!ctx->d_redo) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_redo, (kCapRedo + 1) * sizeof(uint32_t)));
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_redo_count, sizeof(uint32_t), hipHostMallocDefault));
+    }
+    int rc = reserve_program(ctx, sizeof(papr_exact_header) + ngroups * sizeof(papr_exact_group_rec) +
+                                      (size_t)kCapMixed * sizeof(papr_exact_mixed_rec) +
+                                      (size_t)kCapRaw * sizeof(papr_exact_raw_rec) + (size_t)tail * 8);
+    if (rc)
+        return rc;
+    unsigned char *program_dev = nullptr;
+    HIPCHK(ctx, hipHostGetDevicePointer((void **)&program_dev, ctx->h_program, 0));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_redo + kCapRedo, 0, sizeof(uint32_t), ctx->stream));
+    time_begin(ctx, 2, 0);
+    papr_launch_exact_classify_swept(ctx->stream, ctx->d_seg_D, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E,
+                                     ctx->d_tile_E_spec, ctx->d_redo, kCapRedo, ctx->d_redo + kCapRedo);
+    papr_launch_exact_redo(ctx->stream, ctx->num_cus, ctx->d_iq, ctx->d_tile_E, ctx->d_seg_D, ctx->d_redo,
+                           ctx->d_redo + kCapRedo, kCapRedo);
+    papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
+    time_end(ctx);
+    papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, ctx->d_iq, nullptr,
+                           ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, ctx->n, tail, ctx->d_mixed_list, kCapMixed,
+                           ctx->d_raw_list, kCapRaw, ctx->d_plan, program_dev);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_redo_count, ctx->d_redo + kCapRedo, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    return PAPR_OK;
+}
+
+// speculation missed on more tiles than the redo list holds: every tile's pairs from its true binade (a second read)
+int run_exact_full_redo(papr_hip_ctx *ctx)
+{
+    const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
+    const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
+    const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
+    unsigned char *program_dev = nullptr;
+    HIPCHK(ctx, hipHostGetDevicePointer((void **)&program_dev, ctx->h_program, 0));
+    const uint64_t nsegs = 2 * ntiles;
+    const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((nsegs + 3) / 4, (uint64_t)ctx->num_cus * 2));
+    time_begin(ctx, 2, ctx->n * 8);
+    papr_launch_exact_segments(ctx->stream, blocks, ctx->d_iq, nsegs, ctx->d_tile_E, ctx->d_seg_D);
+    papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
+    time_end(ctx);
+    papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, ctx->d_iq, nullptr,
+                           ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, ctx->n, tail, ctx->d_mixed_list, kCapMixed,
+                           ctx->d_raw_list, kCapRaw, ctx->d_plan, program_dev);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PAPR_OK;
+}
+
+// the program the device-side gather left in h_program: its size, or 0 if the lists overflowed
+size_t swept_program_bytes(papr_hip_ctx *ctx)
+{
+    const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
+    const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
+    const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
+    papr_exact_header h;
+    memcpy(&h, ctx->h_program, sizeof(h));
+    if (h.magic == PAPR_EXACT_MAGIC && h.reserved == 0 && h.ngroups == ngroups && h.nsamples == ctx->n &&
+        !env_int("PAPR_EXACT_HOST_ASSEMBLY", 0))
+        return sizeof(h) + ngroups * sizeof(papr_exact_group_rec) + (size_t)h.nmixed * sizeof(papr_exact_mixed_rec) +
+               (size_t)h.nraw * sizeof(papr_exact_raw_rec) + (size_t)tail * 8;
+    return 0;
+}
+
 // Host-driven assembly, for the (never yet seen) case that a shard has more mixed groups / raw tiles
 // than the device-side lists hold.
 int assemble_program_on_host(papr_hip_ctx *ctx, const void **program, size_t *bytes);
@@ -289,6 +375,21 @@ int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, c
     if (rc)
         return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->exact_swept) {
+        rc = run_exact_swept(ctx, before, n_total);
+        if (rc)
+            return rc;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->sweep_info.exact_redo_tiles = *ctx->h_redo_count;
+        if (*ctx->h_redo_count > kCapRedo) {
+            rc = run_exact_full_redo(ctx);
+            if (rc)
+                return rc;
+        }
+        *bytes = swept_program_bytes(ctx);
+        *program = ctx->h_program;
+        return *bytes ? PAPR_OK : assemble_program_on_host(ctx, program, bytes);
+    }
     rc = run_exact_device(ctx, before, n_total, nullptr, bytes);
     if (rc)
         return rc;
@@ -307,6 +408,25 @@ int papr_hip_ccdf_exact(papr_hip_ctx *ctx, const float *levels, int nlevels, uin
     if (rc)
         return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->exact_swept && ctx->resident) {
+        // one-read form: the sweep already holds what both results need (papr_hip_stats_sweep in exact-sum mode)
+        rc = run_exact_swept(ctx, before, n_total);
+        if (rc)
+            return rc;
+        rc = papr_hip_ccdf(ctx, levels, nlevels, counts_above);  // the stash recount (or, speculation missed, pass 2)
+        if (rc)
+            return rc;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->sweep_info.exact_redo_tiles = *ctx->h_redo_count;
+        if (*ctx->h_redo_count > kCapRedo) {
+            rc = run_exact_full_redo(ctx);
+            if (rc)
+                return rc;
+        }
+        *bytes = swept_program_bytes(ctx);
+        *program = ctx->h_program;
+        return *bytes ? PAPR_OK : assemble_program_on_host(ctx, program, bytes);
+    }
     CcdfPlan plan;
     if (nlevels) {
         rc = plan_ccdf(ctx, levels, nlevels, &plan);

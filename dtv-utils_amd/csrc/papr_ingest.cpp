@@ -425,6 +425,7 @@ int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, u
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
     ctx->sweep_valid = false;
+    ctx->est_groups_valid = ctx->exact_swept = false;
     ctx->shard_flags = (fs.odd && first_sample + nsamples == fs.nsamples && nsamples > 0) ? PAPR_FLAG_ODD_TAIL : 0;
 
     SweepRun run;
@@ -612,7 +613,7 @@ int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_s
         }
         const int blocks = (int)std::min<uint64_t>(cnt, (uint64_t)blocks_max);
         time_begin(ctx, 4, cnt * kTileBytes);
-        papr_launch_estimate(ctx->stream, blocks, ctx->d_stage[b], cnt, 1, ctx->d_partials + records);
+        papr_launch_estimate(ctx->stream, blocks, ctx->d_stage[b], cnt, 1, ctx->d_partials + records, nullptr);
         time_end(ctx);
         records += (size_t)blocks;
         if (hipEventRecord(ctx->ev_copy[b], ctx->stream) != hipSuccess)
@@ -633,9 +634,11 @@ int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_s
     papr_launch_stats_finalize(ctx->stream, nullptr, 0, 0, ctx->d_partials, (uint32_t)records, ctx->h_result_dev);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    est->sum = ctx->h_result->sum;
-    est->n = ngroups * PAPR_ESTIMATE_TILE_SAMPLES;
-    ctx->sweep_info.estimate_samples = est->n;
+    // as papr_hip_estimate: the record describes the whole range (sampled sum scaled to all of its samples)
+    const uint64_t sampled = ngroups * PAPR_ESTIMATE_TILE_SAMPLES;
+    est->sum = ctx->h_result->sum * ((double)nsamples / (double)sampled);
+    est->n = nsamples;
+    ctx->sweep_info.estimate_samples = sampled;
     return PAPR_OK;
 }
 

@@ -84,6 +84,15 @@ void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint
 void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, uint64_t ntiles, double *block_sums,
                                 double before, double delta, int32_t *tile_E, uint32_t *ambig_list, uint32_t ambig_cap,
                                 uint32_t *ambig_count, uint32_t *ambig_sorted);
+/* one-read sweep (papr_sweep2_kernel<EXACT>): speculated binades before it, true classification + redo after it */
+void papr_launch_exact_spec(hipStream_t st, const double *group_sums, uint64_t ngroups, uint32_t ratio, double scale,
+                            double before, double *group_prefix, uint64_t ntiles, int32_t *spec);
+void papr_launch_exact_fill_spec(hipStream_t st, int32_t *spec, uint64_t ntiles, int32_t E);
+void papr_launch_exact_classify_swept(hipStream_t st, const void *seg_D, uint64_t ntiles, double *block_sums, double before,
+                                      double delta, int32_t *tile_E, const int32_t *spec, uint32_t *redo_list,
+                                      uint32_t redo_cap, uint32_t *redo_count);
+void papr_launch_exact_redo(hipStream_t st, int blocks, const void *data, const int32_t *tile_E, void *seg_D,
+                            const uint32_t *tile_list, const uint32_t *tile_count, uint32_t list_cap);
 void papr_launch_exact_capture(hipStream_t st, const void *chunk, uint64_t chunk_tile0, uint64_t chunk_ntiles,
                                const uint32_t *sorted, const uint32_t *count, uint32_t cap, void *raw_store);
 void papr_launch_exact_segments(hipStream_t st, int blocks, const void *data, uint64_t nsegs, const int32_t *tile_E,
@@ -113,7 +122,7 @@ void papr_launch_generate(hipStream_t st, int blocks, void *out, uint64_t nsampl
                           const papr_synth_spec &spec);
 /* one-sweep mode (papr_sweep.hip) */
 void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t ngroups, uint32_t ratio,
-                          papr_partial *out);
+                          papr_partial *out, double *group_sums /* may be null: one sampled sum per group */);
 int papr_sweep_variant(int variant); /* the sweep geometry used for a variant id, or -1 */
 int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_t *stash_lds); /* 0, or -1 */
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
@@ -124,6 +133,40 @@ void papr_launch_ccdf_power(hipStream_t st, int blocks, bool lut, size_t lds_byt
                             const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs, uint32_t split,
                             const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist);
 void papr_sweep_prepare_device(void);
+
+// ---- one-sweep kernel, second generation (papr_sweep.hip: papr_sweep2_kernel) -----------------------------------
+// Every WAVE owns whole segments of 64 * U float4 (U = 8: 1024 samples, 8 KiB): wave w of workgroup b takes segment
+// (it * gridDim + b) * WAVES + w.  The band-edge LUT is "compact": a cell of 2^shift bit patterns may hold up to TWO
+// edges — entry = { below << 22 | off1, off2 } with off = edge & (2^shift - 1), PAPR_LUT2_NEVER where there is none — so
+// the cell size no longer has to shrink with the band width.
+#define PAPR_LUT2_OFF_BITS 22
+#define PAPR_LUT2_NEVER 0x3FFFFFu
+#define PAPR_LUT2_MAX_SHIFT 21
+#define PAPR_LUT2_MAX_EDGES 1022       /* `below` has 10 bits */
+#define PAPR_SWEEP2_SPILL 256u         /* floats per full stash spill: one 16-byte store per lane */
+#define PAPR_STASH_PAD_BITS 0x7FC00000u /* quiet NaN: pads a partial spill to 16 bytes; the recount ignores NaN */
+
+struct papr_sweep2_params {
+    const void *data;             // first sample of the launch (16-byte aligned)
+    uint64_t nsegs;               // whole segments in the launch
+    uint64_t base_index;          // global index of sample 0 of `data`
+    papr_partial *out;            // one record per workgroup
+    const void *tail;             // the < 1 segment (exact mode: < 1 tile) remainder, binned by the last workgroup
+    uint32_t tail_samples;
+    const uint32_t *table;        // compact LUT incl. the two sentinel cells
+    papr_ccdf_params P;           // shift, cell_lo, ncells, nkeys (= edges), table_words, copies
+    unsigned long long *ghist;    // nkeys + 1 bins
+    float *stash;                 // one segment of seg_cap floats per workgroup
+    unsigned long long *seg_slots;// per workgroup: floats used in its stash segment (incl. padding; multiple of 4)
+    unsigned long long *seg_real; // per workgroup: in-band powers stashed (the invariant: == sum of the odd bins)
+    uint64_t seg_cap;
+    // exact-sum mode
+    const int32_t *tile_E_spec;   // per 2048-sample tile: speculated binade of the running sum, or PAPR_EXACT_AMBIG
+    void *seg_D;                  // per segment: double2 (D0, D1); D0 doubles as the segment's sum
+    uint64_t seg_offset;          // index of the launch's first segment within the shard (chunked launches)
+};
+int papr_sweep2_geometry(int variant, int *threads, uint64_t *seg_samples, size_t *lds_fixed, int *exact);
+void papr_launch_sweep2(hipStream_t st, int variant, int blocks, size_t lds_bytes, const papr_sweep2_params &p);
 int papr_ccdf_max_dynamic_lds(void);
 void papr_kernels_prepare_device(void); /* call once per device after hipSetDevice */
 void papr_exact_prepare_device(void);

@@ -78,7 +78,16 @@ int variant_of(const papr_hip_ctx *ctx, Pass p)
     if (p == PASS1 && ctx->exact)
         return 1;  // 256 x 4 pipelined: the geometry papr_launch_stats_tilesums is built for
     if (p == SWEEP) {
-        const int v = papr_sweep_variant(ctx->tune.sweep_variant - 1);
+        const int want = ctx->tune.sweep_variant - 1;
+        int threads, exact = 0;
+        uint64_t seg;
+        size_t lds;
+        const bool is_v2 = want >= 0 && papr_sweep2_geometry(want, &threads, &seg, &lds, &exact) == 0;
+        if (ctx->exact)  // exact-sum mode: only the variants that also build the rounding-function pairs
+            return is_v2 && exact ? want : kSweepExactVariant;
+        if (is_v2 && !exact)
+            return want;
+        const int v = papr_sweep_variant(want);
         return v >= 0 ? v : kSweepVariant;
     }
     const int v = (p == PASS1 ? ctx->tune.stats_variant : ctx->tune.ccdf_variant) - 1;
@@ -180,6 +189,7 @@ void release_shard(papr_hip_ctx *ctx)
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
     ctx->sweep_valid = false;
+    ctx->est_groups_valid = ctx->exact_swept = false;
     ctx->shard_flags = 0;
     ctx->path.clear();
 }
@@ -529,6 +539,10 @@ void papr_hip_close(papr_hip_ctx *ctx)
     if (ctx->d_sweep_hist) (void)hipFree(ctx->d_sweep_hist);
     if (ctx->h_sweep_hist) (void)hipHostFree(ctx->h_sweep_hist);
     if (ctx->d_stash) (void)hipFree(ctx->d_stash);
+    if (ctx->d_tile_E_spec) (void)hipFree(ctx->d_tile_E_spec);
+    if (ctx->d_est_groups) (void)hipFree(ctx->d_est_groups);
+    if (ctx->d_redo) (void)hipFree(ctx->d_redo);
+    if (ctx->h_redo_count) (void)hipHostFree(ctx->h_redo_count);
     if (ctx->d_tile_sums) (void)hipFree(ctx->d_tile_sums);
     if (ctx->d_block_sums) (void)hipFree(ctx->d_block_sums);
     if (ctx->d_tile_E) (void)hipFree(ctx->d_tile_E);
@@ -565,12 +579,15 @@ int papr_hip_set_tuning(papr_hip_ctx *ctx, const papr_hip_tuning *t)
     if (!ctx || !t)
         return PAPR_E_ARG;
     int vb, vu;
+    uint64_t v2seg;
+    size_t v2lds;
     if (t->stats_blocks < 0 || t->stats_blocks > 65536 || t->ccdf_blocks < 0 || t->ccdf_blocks > 65536 ||
         t->stats_map < 0 || t->stats_map > 3 || t->ccdf_map < 0 || t->ccdf_map > 3 || t->hist_copies < 0 ||
         (t->stats_variant != 0 && papr_variant_geometry(t->stats_variant - 1, &vb, &vu) != 0) ||
         (t->ccdf_variant != 0 && papr_variant_geometry(t->ccdf_variant - 1, &vb, &vu) != 0) ||
         t->sweep_blocks < 0 || t->sweep_blocks > 65536 || t->sweep_map < 0 || t->sweep_map > 3 ||
-        (t->sweep_variant != 0 && papr_sweep_variant(t->sweep_variant - 1) < 0) ||
+        (t->sweep_variant != 0 && papr_sweep_variant(t->sweep_variant - 1) < 0 &&
+         papr_sweep2_geometry(t->sweep_variant - 1, &vb, &v2seg, &v2lds, &vu) != 0) ||
         (t->sweep_band_log2 != 0 && (t->sweep_band_log2 < 8 || t->sweep_band_log2 > 20)) || t->estimate_ratio < 0 ||
         t->estimate_ratio > 65536)
         return fail(ctx, PAPR_E_ARG, "bad tuning values");
@@ -660,6 +677,7 @@ int papr_hip_upload(papr_hip_ctx *ctx, const float *iq, uint64_t nsamples, uint6
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
     ctx->sweep_valid = false;
+    ctx->est_groups_valid = ctx->exact_swept = false;
     ctx->shard_flags = 0;
     ctx->path.clear();
     return PAPR_OK;
@@ -687,6 +705,7 @@ int papr_hip_generate(papr_hip_ctx *ctx, const papr_synth_spec *spec, uint64_t f
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
     ctx->sweep_valid = false;
+    ctx->est_groups_valid = ctx->exact_swept = false;
     ctx->shard_flags = 0;
     ctx->path.clear();
     return PAPR_OK;
@@ -719,6 +738,7 @@ int papr_hip_stats(papr_hip_ctx *ctx, papr_stats *out)
         return PAPR_OK;
     }
     ctx->sweep_valid = false;  // a sweep only serves the papr_hip_ccdf calls that directly follow it
+    ctx->exact_swept = false;
     if (!ctx->resident)
         return fail(ctx, PAPR_E_STATE, "the shard is not resident and has no pass-1 result: reload it");
     HIPCHK(ctx, hipSetDevice(ctx->device));

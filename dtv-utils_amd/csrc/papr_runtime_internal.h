@@ -204,7 +204,7 @@ struct papr_hip_ctx {
     float *d_raw_store = nullptr;  // ... and the captured raw tiles
 
     // one-sweep mode (papr_sweep.hip)
-    unsigned long long *d_sweep_hist = nullptr;  // 2 L + 2 bins, then one stash-segment length per workgroup
+    unsigned long long *d_sweep_hist = nullptr;  // 2 L + 2 bins, then one stash-segment length per workgroup (v2: slots, then powers)
     unsigned long long *h_sweep_hist = nullptr;  // pinned
     float *d_stash = nullptr;                    // in-band powers of the last sweep
     uint64_t stash_cap = 0;
@@ -218,6 +218,14 @@ struct papr_hip_ctx {
     bool sweep_overflow = false;
     papr_hip_sweep_info sweep_info{};
     const papr_rt::SweepRun *ingest_run = nullptr;        // set while papr_hip_load_file_sweep streams the file in
+    int32_t *d_tile_E_spec = nullptr;            // exact one-read sweep: speculated binade per tile (same capacity as d_tile_E)
+    double *d_est_groups = nullptr;              // papr_hip_estimate: sampled sum per estimate group (exact one-read sweep)
+    uint64_t est_groups_cap = 0, est_ngroups = 0, est_ratio = 0;
+    bool est_groups_valid = false;               // ... describe the CURRENT shard
+    double exact_before_hint = 0.0;              // estimated sum of everything before this shard (papr_hip_set_exact_hint)
+    uint32_t *h_redo_count = nullptr;            // pinned
+    uint32_t *d_redo = nullptr;                  // [0, kCapRedo) tiles whose pairs must be rebuilt, [kCapRedo] their count
+    bool exact_swept = false;                    // the last sweep left speculated pairs in d_seg_D / d_tile_E_spec
 
     papr_hip_ingest_timing ingest{};
     papr_hip_tuning tune{};
@@ -250,6 +258,7 @@ constexpr int kCcdfVariant = 13, kCcdfPerCU = 2, kCcdfMap = PAPR_MAP_GRID_STRIDE
 
 // one-sweep kernel (pass 1 + banded pass 2 in one read)
 constexpr int kSweepVariant = 4, kSweepPerCU = 4, kSweepMap = PAPR_MAP_GRID_STRIDE;
+constexpr int kSweepExactVariant = 48;  // papr_sweep2_kernel<12 waves, exact-sum pairs>
 
 constexpr int kSweepBandLog2 = 14, kEstimateRatio = 64;
 
@@ -283,7 +292,8 @@ struct FileSrc {
     float partner = 0.0f;  // Q of the phantom sample
 };
 
-constexpr uint32_t kCapMixed = 256, kCapRaw = 512;  // beyond this the program is assembled by the host path
+constexpr uint32_t kCapMixed = 256, kCapRaw = 512;
+constexpr uint32_t kCapRedo = 65536;  // tiles (of 16 KiB) the one-read sweep may have to redo before a full second read is cheaper  // beyond this the program is assembled by the host path
 
 // ---- one-sweep mode: set-up, launch and bookkeeping shared by resident shards and file ingest -------------------
 struct SweepRun {
@@ -291,10 +301,13 @@ struct SweepRun {
     std::vector<uint32_t> gkeys;  // guessed keys (band centres), unique, ascending
     uint32_t half = 0;            // half-width of a band in bit patterns
     int variant = 0;
+    bool v2 = false;              // papr_sweep2_kernel (wave-private segments, compact LUT) instead of papr_sweep_kernel
+    bool exact = false;           // v2: the kernel also builds the exact-sum pairs for speculated binades
+    int threads = 0;              // v2: workgroup size
     int blocks = 0;               // workgroups of the largest launch (= stash segments)
-    uint64_t tile = 0;            // samples per workgroup iteration
-    size_t stash_lds = 0;
-    uint32_t nbins = 0;           // 2 * bands + 1 + the NaN trash bin
+    uint64_t tile = 0;            // samples per workgroup iteration (v2: per wave segment; exact: per 2048-sample tile)
+    size_t stash_lds = 0;         // LDS besides table and histogram (v2: rings + transpose buffers)
+    uint32_t nbins = 0;           // v1: 2 * bands + 1 + the NaN trash bin; v2: 2 * bands + 1
     uint64_t seg_cap = 0;         // floats per stash segment
 };
 
@@ -350,6 +363,9 @@ int exact_preconditions(papr_hip_ctx *ctx, double before, bool allow_restreamed)
 int reserve_program(papr_hip_ctx *ctx, size_t want);  // grow the pinned program buffer, keeping its contents
 int run_exact_device(papr_hip_ctx *ctx, double before, uint64_t n_total, const CcdfPlan *fused, size_t *bytes);
 int assemble_program_on_host(papr_hip_ctx *ctx, const void **program, size_t *bytes);
+int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total);
+int run_exact_full_redo(papr_hip_ctx *ctx);
+size_t swept_program_bytes(papr_hip_ctx *ctx);
 void counts_from_histogram(const papr_hip_ctx *ctx, const CcdfPlan &plan, int nlevels, uint64_t *counts_above);
 int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *levels, int nlevels, uint64_t *counts_above,
                        bool *done);

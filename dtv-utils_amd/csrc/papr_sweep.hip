@@ -99,8 +99,11 @@ struct WaveStash {
 // in the capture can alias with the sampling, and a bursty capture is sampled in 16 x more independent places
 // than whole tiles would give (the error of the mean is sigma(piece means) / sqrt(pieces)).
 // Output: one papr_partial per workgroup with only `sum` set (merged by papr_stats_finalize like pass-1 partials).
+// `group_sums` (may be null): 4 doubles per group, one per wave — their sum is the group's sampled sum (the exact
+// one-read sweep speculates each tile's running-sum binade from them, papr_exact.hip).
 __global__ __launch_bounds__(PAPR_BLOCK) void papr_estimate_kernel(const float4 *__restrict__ data, uint64_t ngroups,
-                                                                    uint32_t ratio, papr_partial *__restrict__ out)
+                                                                    uint32_t ratio, papr_partial *__restrict__ out,
+                                                                    double *__restrict__ group_sums)
 {
     constexpr int U = PAPR_ESTIMATE_TILE_SAMPLES / (2 * PAPR_BLOCK);
     constexpr int kRows = U * (PAPR_BLOCK / kWave);
@@ -115,10 +118,17 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_estimate_kernel(const float4 
             const uint64_t tile = g * ratio + papr_estimate_pick(row, ratio);
             x[u] = load16<false>(data + tile * TILE_F4 + (uint64_t)u * PAPR_BLOCK + threadIdx.x);
         }
+        double gsum = 0.0;
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            sum += (double)power_of(x[u].x, x[u].y);
-            sum += (double)power_of(x[u].z, x[u].w);
+            gsum += (double)power_of(x[u].x, x[u].y);
+            gsum += (double)power_of(x[u].z, x[u].w);
+        }
+        sum += gsum;
+        if (group_sums) {
+            const double ws = wave_reduce_sum(gsum);
+            if ((threadIdx.x & (kWave - 1)) == 0)
+                group_sums[g * (PAPR_BLOCK / kWave) + wave] = ws;
         }
     }
     LaneStats s;
@@ -428,6 +438,474 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
 }
 
 // =============================================================================
+// 3b. the sweep, second generation: wave-private segments, compact LUT, ring stash, optional exact-sum pairs
+// =============================================================================
+// What changed against papr_sweep_kernel, and why (measurements: DESIGN.md section 7):
+//  * the unit of work is a WAVE-private segment of 64 * U float4 (U = 8: 1024 samples, 8 KiB), not a workgroup-wide
+//    tile: one persistent workgroup per CU stages the LUT and zeroes / flushes its histogram ONCE, waves never meet
+//    at a barrier inside the loop, and a wave has 8 KiB in flight instead of 4
+//  * compact LUT (papr_kernels.h): up to two band edges per cell, so cells are as wide as the spacing of the
+//    THRESHOLDS allows (2^17 patterns for the 0.1 dB table: 8 KiB of LDS instead of 32-40 KiB) whatever the band
+//    width — more lanes hit the same entry (broadcast instead of bank conflict), and the band can shrink with the
+//    quality of the estimate
+//  * the stash leaves a wave through a RING in LDS in fixed spills of 256 floats written as one 16-byte store per
+//    lane at a 1 KiB-aligned position (a write-through dword store is one fabric write each: ~6x the time per byte
+//    of a 16-byte one); a partial spill (end of the launch) is padded to 16 bytes with quiet NaNs, which the
+//    recount ignores
+//  * EXACT: the same read also produces the per-segment rounding functions (D0, D1) of papr_exact.hip for a
+//    SPECULATED binade of the running sum (from the estimate's per-group sums), and D0 — exact or not — is the
+//    segment's sum, from which the true prefix sums are formed afterwards; segments whose speculated binade turns
+//    out wrong are redone by papr_exact_redo_kernel (a fraction of a per cent), so that the bit-exact sequential
+//    sum costs one read as well.  Lanes own 16 CONSECUTIVE samples there (XOR-swizzled LDS transpose), which is
+//    also the order everything else is then computed in.
+
+namespace {
+
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+// store policies for the stash: 0 plain, 1 nontemporal, 2 write-through (sc0 sc1)
+template <int WT>
+__device__ __forceinline__ void store16(float *p, f32x4s v)
+{
+    if constexpr (WT == 2) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+    } else if constexpr (WT == 1) {
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4s *>(p));
+    } else {
+        *reinterpret_cast<f32x4s *>(p) = v;
+    }
+}
+
+template <uint32_t RING, int WT>
+struct StashRing {
+    float *ring;                      // this wave's ring in LDS (RING floats, 16-byte aligned)
+    uint32_t *head;                   // LDS: slots reserved by this wave's lanes so far
+    uint32_t tail;                    // wave-uniform: slots already written out (multiple of the spill size)
+    float *__restrict__ seg;          // this workgroup's stash segment in HBM
+    unsigned long long *seg_fill;     // LDS: floats reserved in the segment (may run past seg_cap: overflow)
+    unsigned long long *seg_real;     // LDS: powers stashed (without padding)
+    uint64_t seg_cap;
+
+    __device__ __forceinline__ void put(float pw, bool take)
+    {
+        if (take)
+            ring[atomicAdd(head, 1u) & (RING - 1)] = pw;
+    }
+    // write ring[tail, tail + n) to the segment; n <= 256, tail is a multiple of 256
+    __device__ __forceinline__ void chunk(uint32_t n)
+    {
+        const uint32_t lane = threadIdx.x & (kWave - 1);
+        const uint32_t n4 = (n + 3u) & ~3u;
+        unsigned long long pos = 0;
+        if (lane == 0) {
+            pos = atomicAdd(seg_fill, (unsigned long long)n4);
+            atomicAdd(seg_real, (unsigned long long)n);
+        }
+        pos = __shfl((unsigned long long)pos, 0, kWave);
+        if (4 * lane < n4) {
+            f32x4s v = *reinterpret_cast<const f32x4s *>(ring + (tail & (RING - 1)) + 4 * lane);
+            const float pad = __uint_as_float(PAPR_STASH_PAD_BITS);
+            v.y = 4 * lane + 1 < n ? v.y : pad;
+            v.z = 4 * lane + 2 < n ? v.z : pad;
+            v.w = 4 * lane + 3 < n ? v.w : pad;
+            if (pos + 4 * lane + 4 <= seg_cap)
+                store16<WT>(seg + pos + 4 * lane, v);
+        }
+        tail += n;
+    }
+    __device__ __forceinline__ uint32_t pending()
+    {
+        __builtin_amdgcn_wave_barrier();  // LDS is in-order per wave; this pins the compiler's order too
+        return __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)head) - tail;
+    }
+    __device__ __forceinline__ void spill_full()
+    {
+        uint32_t n = pending();
+        while (n >= PAPR_SWEEP2_SPILL) {
+            chunk(PAPR_SWEEP2_SPILL);
+            n -= PAPR_SWEEP2_SPILL;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void flush()
+    {
+        spill_full();
+        const uint32_t n = pending();
+        if (n)
+            chunk(n);
+        tail = (tail + PAPR_SWEEP2_SPILL - 1) & ~(PAPR_SWEEP2_SPILL - 1);  // (keeps the ring reads 16-byte aligned)
+        __builtin_amdgcn_wave_barrier();
+        if ((threadIdx.x & (kWave - 1)) == 0)
+            *(volatile uint32_t *)head = tail;
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
+// running per-segment extremes as integer bit patterns (see track_tile)
+struct SegMax {
+    uint32_t pk, rn, in;
+    int32_t rp, ip;
+};
+
+__device__ __forceinline__ void segmax_fold(SegMax &m, const float4 &x, float p0, float p1)
+{
+    m.pk = umax3(m.pk, __float_as_uint(p0), __float_as_uint(p1));
+    m.rp = imax3(m.rp, __float_as_int(x.x), __float_as_int(x.z));
+    m.rn = umax3(m.rn, __float_as_uint(x.x), __float_as_uint(x.z));
+    m.ip = imax3(m.ip, __float_as_int(x.y), __float_as_int(x.w));
+    m.in = umax3(m.in, __float_as_uint(x.y), __float_as_uint(x.w));
+}
+
+__device__ __forceinline__ void segmax_commit(TileTrack &tr, const SegMax &m, uint32_t it)
+{
+    const float c[5] = {__uint_as_float(m.pk), __int_as_float(m.rp), __uint_as_float(m.rn), __int_as_float(m.ip),
+                        __uint_as_float(m.in)};
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const bool win = (k == 2 || k == 4) ? (c[k] < tr.best[k]) : (c[k] > tr.best[k]);  // strict: first segment wins
+        tr.best[k] = win ? c[k] : tr.best[k];
+        tr.iter[k] = win ? it : tr.iter[k];
+    }
+}
+
+// ---- exact-sum pairs (the algebra is papr_exact.hip's; restated here because both files keep their helpers
+// in anonymous namespaces) ----
+struct Pair2 {
+    double d0, d1;
+};
+__device__ __forceinline__ double pow2_f64(int e) { return __longlong_as_double((long long)(e + 1023) << 52); }
+__device__ __forceinline__ Pair2 compose2(Pair2 f, Pair2 g, double m0)
+{
+    const int q0 = __double2loint(m0 + f.d0) & 1;
+    const int q1 = (__double2loint(m0 + f.d1) & 1) ^ 1;
+    Pair2 h;
+    h.d0 = f.d0 + (q0 ? g.d1 : g.d0);
+    h.d1 = f.d1 + (q1 ? g.d1 : g.d0);
+    return h;
+}
+template <int SHIFT>
+__device__ __forceinline__ double row_shl2(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + SHIFT, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + SHIFT, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int SHIFT>
+__device__ __forceinline__ Pair2 compose2_row(Pair2 f, double m0)
+{
+    Pair2 g;
+    g.d0 = row_shl2<SHIFT>(f.d0);
+    g.d1 = row_shl2<SHIFT>(f.d1);
+    return compose2(f, g, m0);
+}
+__device__ __forceinline__ Pair2 wave_compose2(Pair2 f, double m0)  // ordered merge, lane order = file order; result in lane 0
+{
+    f = compose2_row<1>(f, m0);
+    f = compose2_row<2>(f, m0);
+    f = compose2_row<4>(f, m0);
+    f = compose2_row<8>(f, m0);
+#pragma unroll
+    for (int off = 16; off < kWave; off <<= 1) {
+        Pair2 g;
+        g.d0 = __shfl_down(f.d0, off, kWave);
+        g.d1 = __shfl_down(f.d1, off, kWave);
+        f = compose2(f, g, m0);
+    }
+    return f;
+}
+// slot of float4 w of run r in the wave's transpose buffer (conflict-free both ways; papr_exact.hip)
+__device__ __forceinline__ int xpose_slot(int run, int w) { return run * 8 + (w ^ ((run >> 1) & 7)); }
+
+// Workgroup record of the v2 kernel: as sweep_record, for wave-private segments.  LANE_MAJOR: lane l owns float4
+// l*U .. l*U+U-1 of its segment (exact mode); otherwise float4 u*64 + l.
+template <int WAVES, int U, bool LANE_MAJOR>
+__device__ __forceinline__ void sweep2_record(double sum, const TileTrack &tr, uint64_t seg0, uint64_t seg_stride,
+                                              const float4 *__restrict__ data, uint64_t base_index,
+                                              papr_partial *__restrict__ out)
+{
+    constexpr uint64_t SEG_F4 = 64ull * U;
+    const uint32_t t = threadIdx.x;
+    __shared__ double sh_sum[WAVES];
+    __shared__ float sh_val[WAVES][5];
+    __shared__ unsigned long long sh_idx[WAVES][5];
+    const int lane = t & (kWave - 1), wave = t / kWave;
+    float wv[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        float v = tr.best[k];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            const float o = __shfl_down(v, off, kWave);
+            v = (k == 2 || k == 4) ? (o < v ? o : v) : (o > v ? o : v);
+        }
+        wv[k] = v;
+    }
+    const double wsum = wave_reduce_sum(sum);
+    if (lane == 0) {
+        sh_sum[wave] = wsum;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            sh_val[wave][k] = wv[k];
+    }
+    __syncthreads();
+    float win[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        float v = sh_val[0][k];
+        for (int wq = 1; wq < WAVES; wq++) {
+            const float o = sh_val[wq][k];
+            v = (k == 2 || k == 4) ? (o < v ? o : v) : (o > v ? o : v);
+        }
+        win[k] = v;
+    }
+    unsigned long long idx[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        idx[k] = ~0ull;
+        if (win[k] != 0.f && tr.best[k] == win[k]) {  // a tracker that never fired keeps value 0 and reports index 0
+            const uint64_t f4_0 = (seg0 + (uint64_t)tr.iter[k] * seg_stride) * SEG_F4;
+            for (int u = U - 1; u >= 0; u--) {  // last match written last = first slot wins
+                const uint64_t f4 = f4_0 + (LANE_MAJOR ? (uint64_t)lane * U + u : (uint64_t)u * kWave + lane);
+                const float4 x = data[f4];
+                const float a = k == 0 ? power_of(x.x, x.y) : (k <= 2 ? x.x : x.y);
+                const float b = k == 0 ? power_of(x.z, x.w) : (k <= 2 ? x.z : x.w);
+                if (b == win[k])
+                    idx[k] = base_index + 2 * f4 + 1;
+                if (a == win[k])
+                    idx[k] = base_index + 2 * f4;
+            }
+        }
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_down(idx[k], off, kWave);
+            idx[k] = o < idx[k] ? o : idx[k];
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            sh_idx[wave][k] = idx[k];
+    }
+    __syncthreads();
+    if (t == 0) {
+        papr_partial q;
+        q.sum = sh_sum[0];
+        for (int wq = 1; wq < WAVES; wq++)  // fixed order => deterministic sum
+            q.sum += sh_sum[wq];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            unsigned long long best_idx = sh_idx[0][k];
+            for (int wq = 1; wq < WAVES; wq++)
+                best_idx = sh_idx[wq][k] < best_idx ? sh_idx[wq][k] : best_idx;
+            q.val[k] = win[k];
+            q.idx[k] = win[k] != 0.f ? best_idx : 0;
+        }
+        q.pad = 0;
+        out[blockIdx.x] = q;
+    }
+}
+
+}  // namespace
+
+template <int WAVES, int U, int PIPE, bool EXACT, int WT>
+__global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sweep2_params p)
+{
+    static_assert(!EXACT || U == 8, "exact-sum segments are 1024 samples");
+    constexpr int BLOCK = WAVES * kWave;
+    constexpr uint64_t SEG_F4 = 64ull * U;
+    constexpr uint32_t RING = EXACT ? 512u : 1024u;  // >= 255 + 64 * (samples per lane between two ring checks)
+    constexpr int BATCH = EXACT ? 2 : 4;             // float4 per lane folded between two ring checks
+    __shared__ unsigned long long seg_fill, seg_real_sh;
+    __shared__ uint32_t ring_head[WAVES];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const papr_ccdf_params &P = p.P;
+    const uint32_t nbins = P.nkeys + 1;
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *hist = tab + P.table_words;                                         // table_words is a multiple of 4
+    float *rings = reinterpret_cast<float *>(hist + ((P.copies * nbins + 3u) & ~3u));
+    float4 *xpose = reinterpret_cast<float4 *>(rings + WAVES * RING);             // EXACT: WAVES x 8 KiB
+
+    const uint32_t t = threadIdx.x;
+    const uint32_t lane = t & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(t / kWave);
+    for (uint32_t k = t; k < P.table_words; k += BLOCK)
+        tab[k] = p.table[k];
+    for (uint32_t k = t; k < P.copies * nbins; k += BLOCK)
+        hist[k] = 0;
+    if (t == 0) {
+        seg_fill = p.seg_slots[blockIdx.x];  // segments keep filling over the launches of a chunked ingest
+        seg_real_sh = p.seg_real[blockIdx.x];
+    }
+    if (t < WAVES)
+        ring_head[t] = 0;
+    __syncthreads();
+
+    const uint2 *lut_biased = reinterpret_cast<const uint2 *>(tab) - ((int32_t)P.cell_lo - 1);
+    uint32_t *my = hist + (wave % P.copies) * nbins;
+    StashRing<RING, WT> ws{rings + wave * RING,
+                           &ring_head[wave],
+                           0u,
+                           p.stash + (uint64_t)blockIdx.x * p.seg_cap,
+                           &seg_fill,
+                           &seg_real_sh,
+                           p.seg_cap};
+    const int32_t cell_last = (int32_t)(P.cell_lo + P.ncells);
+    int32_t cell_first;  // pinned in a VGPR (v_med3 takes one scalar operand)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(cell_first) : "s"((int32_t)P.cell_lo - 1));
+    const uint32_t shift = P.shift;
+    const uint32_t offmask = (1u << shift) - 1u;
+
+    auto bin_of = [&](float pw) -> uint32_t {
+        const int32_t cell = __float_as_int(pw) >> shift;  // arithmetic shift: sign-bit patterns go below the table
+        const uint2 e = lut_biased[clamp_cell(cell, cell_first, cell_last)];
+        const uint32_t off = __float_as_uint(pw) & offmask;
+        return (e.x >> PAPR_LUT2_OFF_BITS) + (off >= (e.x & PAPR_LUT2_NEVER) ? 1u : 0u) + (off >= e.y ? 1u : 0u);
+    };
+    auto count_and_stash = [&](float pw, uint32_t k) {
+        if (k)
+            atomicAdd(&my[k], 1u);
+        ws.put(pw, (k & 1u) != 0u);
+    };
+
+    const float4 *data = reinterpret_cast<const float4 *>(p.data);
+    const uint64_t seg_stride = (uint64_t)gridDim.x * WAVES;
+    const uint64_t seg0 = (uint64_t)blockIdx.x * WAVES + wave;
+    const uint32_t count = p.nsegs > seg0 ? (uint32_t)((p.nsegs - seg0 + seg_stride - 1) / seg_stride) : 0u;
+
+    double sum = 0.0;
+    TileTrack tr = {{0.f, 0.f, 0.f, 0.f, 0.f}, {0, 0, 0, 0, 0}};
+
+    // fold BATCH float4 (2 * BATCH samples) of this lane: powers, extremes, bins, stash
+    auto fold_batch = [&](const float4(&x)[BATCH], SegMax &m, double &x0, double &x1) {
+        float pw[2 * BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+            pw[2 * u] = power_of(x[u].x, x[u].y);
+            pw[2 * u + 1] = power_of(x[u].z, x[u].w);
+            segmax_fold(m, x[u], pw[2 * u], pw[2 * u + 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * BATCH; u++) {
+            const double v = (double)pw[u];
+            sum += v;  // the accurate per-lane sum (as papr_stats_kernel), also in exact mode
+            if constexpr (EXACT) {
+                x0 += v;  // the reference's additions themselves, from the two canonical entry states
+                x1 += v;
+            }
+        }
+        uint32_t k[2 * BATCH];
+#pragma unroll
+        for (int u = 0; u < 2 * BATCH; u++)
+            k[u] = bin_of(pw[u]);  // the batch's LUT reads in flight together
+#pragma unroll
+        for (int u = 0; u < 2 * BATCH; u++)
+            count_and_stash(pw[u], k[u]);
+        ws.spill_full();
+    };
+
+    auto load_seg = [&](float4(&x)[U], uint64_t seg) {
+        const float4 *q = data + seg * SEG_F4 + lane;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            x[u] = load16<true>(q + u * kWave);
+    };
+
+    if constexpr (EXACT) {
+        float4 *mine = xpose + wave * (kWave * 8);
+        const int32_t *__restrict__ tile_E = p.tile_E_spec;
+        double2 *__restrict__ seg_D = reinterpret_cast<double2 *>(p.seg_D);
+        float4 x[U];
+        if (count)
+            load_seg(x, seg0);
+        for (uint32_t it = 0; it < count; it++) {
+            const uint64_t seg = seg0 + (uint64_t)it * seg_stride;
+            const int E = tile_E[(p.seg_offset + seg) >> 1];
+#pragma unroll
+            for (int r = 0; r < U; r++) {
+                const int f = r * kWave + (int)lane;  // float4 slot within the segment, file order
+                mine[xpose_slot(f >> 3, f & 7)] = x[r];
+            }
+            // the registers are free again: the next segment's loads fly while this one is folded out of LDS
+            // (same wave wrote and reads the buffer: LDS operations of one wave complete in order)
+            if (it + 1 < count)
+                load_seg(x, seg + seg_stride);
+            const bool valid = E != PAPR_EXACT_AMBIG;
+            const double m0 = valid ? pow2_f64(E) : 0.0, m1 = valid ? m0 + pow2_f64(E - 52) : 0.0;
+            double x0 = m0, x1 = m1;
+            SegMax m = {0u, 0u, 0u, INT32_MIN, INT32_MIN};
+#pragma unroll
+            for (int b = 0; b < U / BATCH; b++) {
+                float4 y[BATCH];
+#pragma unroll
+                for (int j = 0; j < BATCH; j++)
+                    y[j] = mine[xpose_slot((int)lane, b * BATCH + j)];
+                fold_batch(y, m, x0, x1);
+            }
+            segmax_commit(tr, m, it);
+            Pair2 f;
+            f.d0 = x0 - m0;  // exact: multiples of the ulp inside the binade (a plain sum when no binade was given)
+            f.d1 = x1 - m1;
+            f = wave_compose2(f, m0);
+            if (lane == 0)
+                seg_D[p.seg_offset + seg] = make_double2(f.d0, f.d1);
+        }
+    } else {
+        double none0 = 0.0, none1 = 0.0;
+        auto fold_seg = [&](const float4(&x)[U], uint32_t it) {
+            SegMax m = {0u, 0u, 0u, INT32_MIN, INT32_MIN};
+#pragma unroll
+            for (int b = 0; b < U / BATCH; b++) {
+                float4 y[BATCH];
+#pragma unroll
+                for (int j = 0; j < BATCH; j++)
+                    y[j] = x[b * BATCH + j];
+                fold_batch(y, m, none0, none1);
+            }
+            segmax_commit(tr, m, it);
+        };
+        if constexpr (PIPE == 1) {
+            float4 cur[U], nxt[U];
+            if (count)
+                load_seg(cur, seg0);
+            for (uint32_t it = 0; it < count; it++) {
+                if (it + 1 < count)
+                    load_seg(nxt, seg0 + (uint64_t)(it + 1) * seg_stride);
+                fold_seg(cur, it);
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    cur[u] = nxt[u];
+            }
+        } else {
+            for (uint32_t it = 0; it < count; it++) {
+                float4 x[U];
+                load_seg(x, seg0 + (uint64_t)it * seg_stride);
+                fold_seg(x, it);
+            }
+        }
+    }
+    // remainder of the launch: binned here (its pass-1 part is folded in by papr_stats_finalize, its exact-sum
+    // part travels raw in the sum program)
+    if (blockIdx.x == gridDim.x - 1) {
+        const float2 *tail = reinterpret_cast<const float2 *>(p.tail);
+        for (uint32_t k0 = 0; k0 < p.tail_samples; k0 += BLOCK) {  // wave-uniform trip count
+            const bool valid = k0 + t < p.tail_samples;
+            const float2 x = valid ? tail[k0 + t] : make_float2(0.f, 0.f);
+            const float pw = power_of(x.x, x.y);
+            count_and_stash(pw, valid ? bin_of(pw) : 0u);
+            ws.spill_full();
+        }
+    }
+    ws.flush();
+
+    sweep2_record<WAVES, U, EXACT>(sum, tr, seg0, seg_stride, data, p.base_index, p.out);
+    hist_flush<BLOCK>(hist, nbins, P.copies, p.ghist);  // (starts with a barrier: every wave has flushed)
+    if (t == 0) {
+        p.seg_slots[blockIdx.x] = seg_fill;
+        p.seg_real[blockIdx.x] = seg_real_sh;
+    }
+}
+
+// =============================================================================
 // 4. pass 2 over the stash (float powers, not IQ)
 // =============================================================================
 // `split` workgroups per stash segment (= per workgroup of the sweep), segment lengths read from the device.
@@ -478,10 +956,10 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_ccdf_power_kernel(const float
 // ---- launch wrappers -------------------------------------------------------------------
 
 void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t ngroups, uint32_t ratio,
-                          papr_partial *out)
+                          papr_partial *out, double *group_sums)
 {
     hipLaunchKernelGGL(papr_estimate_kernel, dim3(blocks), dim3(PAPR_BLOCK), 0, st, (const float4 *)data, ngroups, ratio,
-                       out);
+                       out, group_sums);
 }
 
 // Geometry variants of the sweep (ids as in papr_kernels.hip's table).
@@ -532,6 +1010,42 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     }
 }
 
+// Geometry variants of the second-generation sweep: id, waves per workgroup, 16-byte loads per lane per segment,
+// next-segment prefetch, exact-sum pairs, stash store policy (0 plain, 1 nontemporal, 2 write-through).
+#define PAPR_FOR_EACH_SWEEP2_VARIANT(X)                                                                         \
+    X(32, 16, 8, 0, false, 2) X(33, 16, 8, 1, false, 2) X(34, 16, 4, 0, false, 2) X(35, 16, 4, 1, false, 2)      \
+    X(36, 8, 8, 0, false, 2) X(37, 8, 8, 1, false, 2) X(38, 16, 8, 0, false, 0) X(39, 16, 8, 0, false, 1)        \
+    X(40, 12, 8, 0, false, 2) X(41, 12, 8, 1, false, 2) X(42, 8, 4, 1, false, 2) X(43, 4, 8, 1, false, 2)        \
+    X(48, 12, 8, 0, true, 2) X(49, 10, 8, 0, true, 2) X(50, 8, 8, 0, true, 2) X(51, 12, 8, 0, true, 0)
+
+int papr_sweep2_geometry(int variant, int *threads, uint64_t *seg_samples, size_t *lds_fixed, int *exact)
+{
+    switch (variant) {
+#define X(V, W, U, PP, EX, WT)                                                                                  \
+    case V:                                                                                                      \
+        *threads = W * kWave;                                                                                    \
+        *seg_samples = 2ull * kWave * U;                                                                         \
+        *lds_fixed = (size_t)W * (EX ? 512u : 1024u) * sizeof(float) + (EX ? (size_t)W * 8192u : 0u);            \
+        *exact = EX ? 1 : 0;                                                                                     \
+        return 0;
+        PAPR_FOR_EACH_SWEEP2_VARIANT(X)
+#undef X
+    default: return -1;
+    }
+}
+
+void papr_launch_sweep2(hipStream_t st, int variant, int blocks, size_t lds_bytes, const papr_sweep2_params &p)
+{
+    switch (variant) {
+#define X(V, W, U, PP, EX, WT)                                                                                  \
+    case V:                                                                                                      \
+        hipLaunchKernelGGL((papr_sweep2_kernel<W, U, PP, EX, WT>), dim3(blocks), dim3(W * kWave), lds_bytes, st, p); \
+        break;
+        PAPR_FOR_EACH_SWEEP2_VARIANT(X)
+#undef X
+    }
+}
+
 void papr_launch_ccdf_power(hipStream_t st, int blocks, bool lut, size_t lds_bytes, const float *stash,
                             const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs, uint32_t split,
                             const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist)
@@ -551,6 +1065,11 @@ void papr_sweep_prepare_device(void)
     (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<B, U, true, PP>,                                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
     PAPR_FOR_EACH_SWEEP_VARIANT(X)
+#undef X
+#define X(V, W, U, PP, EX, WT)                                                                                  \
+    (void)hipFuncSetAttribute((const void *)papr_sweep2_kernel<W, U, PP, EX, WT>,                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    PAPR_FOR_EACH_SWEEP2_VARIANT(X)
 #undef X
     (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
     (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, want);

@@ -7,6 +7,55 @@ using namespace papr_rt;
 
 namespace papr_rt {
 
+// Compact LUT (papr_kernels.h) for ascending, distinct band edges: the coarsest cell size that leaves at most two
+// edges in any cell.  False: no such form (more than PAPR_LUT2_MAX_EDGES edges, or the table would not fit).
+static bool plan_compact_lut(const std::vector<uint32_t> &edges, papr_ccdf_params *P)
+{
+    const size_t n = edges.size();
+    if (n == 0 || n > PAPR_LUT2_MAX_EDGES || edges.front() < 0x00800000u)
+        return false;
+    for (int s = PAPR_LUT2_MAX_SHIFT; s >= 8; s--) {
+        bool ok = true;
+        for (size_t i = 0; i + 2 < n && ok; i++)
+            ok = (edges[i + 2] >> s) != (edges[i] >> s);
+        if (!ok)
+            continue;
+        const uint32_t c0 = edges.front() >> s, c1 = edges.back() >> s;
+        const uint64_t ncells = (uint64_t)c1 - c0 + 1;
+        if ((ncells + 2) * 8 > 48 * 1024)
+            return false;  // finer cells only get more
+        memset(P, 0, sizeof(*P));
+        P->shift = (uint32_t)s;
+        P->cell_lo = c0;
+        P->ncells = (uint32_t)ncells;
+        P->nkeys = (uint32_t)n;
+        P->table_words = (uint32_t)((2 * (ncells + 2) + 3) & ~3ull);
+        return true;
+    }
+    return false;
+}
+
+static void fill_compact_lut(const std::vector<uint32_t> &edges, const papr_ccdf_params &P, uint32_t *tab)
+{
+    const uint32_t mask = (1u << P.shift) - 1u;
+    memset(tab, 0, (size_t)P.table_words * 4);
+    tab[0] = PAPR_LUT2_NEVER;  // below everything: 0 edges below, none inside
+    tab[1] = kNever;
+    uint32_t k = 0;
+    for (uint32_t c = 0; c < P.ncells; c++) {
+        const uint32_t below = k;
+        uint32_t off1 = PAPR_LUT2_NEVER, off2 = kNever;
+        if (k < P.nkeys && (edges[k] >> P.shift) == P.cell_lo + c)
+            off1 = edges[k++] & mask;
+        if (k < P.nkeys && (edges[k] >> P.shift) == P.cell_lo + c)
+            off2 = edges[k++] & mask;
+        tab[2 * (c + 1)] = (below << PAPR_LUT2_OFF_BITS) | off1;
+        tab[2 * (c + 1) + 1] = off2;
+    }
+    tab[2 * (P.ncells + 1)] = (P.nkeys << PAPR_LUT2_OFF_BITS) | PAPR_LUT2_NEVER;  // above every edge (+Inf, NaN too:
+    tab[2 * (P.ncells + 1) + 1] = kNever;                                         // a NaN voids the sweep anyway)
+}
+
 // Plan the bands for `guess_levels`, size and clear the buffers, upload the LUT.  *reason != PAPR_SWEEP_OK: the guess
 // has no band form (or memory is short) and the caller runs the plain pass instead.  `n_shard` sizes the stash,
 // `n_launch` (a whole resident shard, or one ingest chunk) the grid.
@@ -18,13 +67,18 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
     *reason = PAPR_SWEEP_NO_BANDS;
     if (nlevels <= 0 || nlevels > PAPR_HIP_MAX_LEVELS)
         return PAPR_OK;
-    // widest band (<= the configured width) that has a band form (papr_sweep_bands) and whose edges have a LUT form
-    int vblock = 512;
+    int vblock = 512, v2_exact = 0;
     run->variant = variant_of(ctx, SWEEP);
-    (void)papr_sweep_geometry(run->variant, &vblock, &run->tile, &run->stash_lds);
+    run->v2 = papr_sweep2_geometry(run->variant, &vblock, &run->tile, &run->stash_lds, &v2_exact) == 0;
+    run->exact = v2_exact != 0;
+    run->threads = vblock;
+    if (!run->v2)
+        (void)papr_sweep_geometry(run->variant, &vblock, &run->tile, &run->stash_lds);
+    const size_t lds_cap = (size_t)papr_ccdf_max_dynamic_lds();
     std::vector<uint32_t> &gkeys = run->gkeys;
     CcdfPlan &bands = run->bands;
     run->half = 0;
+    // widest band (<= the configured width) that has a band form (papr_sweep_bands) and whose edges have a LUT form
     for (int log2w = info.band_log2; log2w >= std::max(info.band_log2 - 3, 8) && !run->half; log2w--) {
         gkeys.assign((size_t)nlevels, 0);
         bands.keys.assign(2 * (size_t)nlevels, 0);
@@ -33,10 +87,16 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
             continue;  // (a narrower band may still fit between crowded thresholds)
         gkeys.resize((size_t)m);
         bands.keys.resize(2 * (size_t)m);
-        char keep[sizeof(ctx->err)];
-        memcpy(keep, ctx->err, sizeof(keep));
-        const bool fits = finish_plan(ctx, &bands, vblock, run->stash_lds) == PAPR_OK && bands.lut;
-        memcpy(ctx->err, keep, sizeof(keep));  // not an error of this call: a narrower band or the plain pass follows
+        bool fits;
+        if (run->v2) {
+            fits = plan_compact_lut(bands.keys, &bands.P);
+            bands.lut = fits;
+        } else {
+            char keep[sizeof(ctx->err)];
+            memcpy(keep, ctx->err, sizeof(keep));
+            fits = finish_plan(ctx, &bands, vblock, run->stash_lds) == PAPR_OK && bands.lut;
+            memcpy(ctx->err, keep, sizeof(keep));  // not an error of this call: a narrower band or the plain pass follows
+        }
         if (fits) {
             run->half = 1u << log2w;
             info.band_log2 = log2w;
@@ -44,23 +104,48 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
     }
     if (!run->half)
         return PAPR_OK;
-    // the sweep kernel's LUT has a sentinel cell at either end and its histogram one more (NaN) bin
-    bands.P.table_words = 2 * (bands.P.ncells + 2);
-    run->nbins = bands.P.nkeys + 2;
-    bands.lds_bytes = (size_t)bands.P.table_words * 4 + (size_t)bands.P.copies * run->nbins * 4;
-    if (bands.lds_bytes + run->stash_lds > (size_t)papr_ccdf_max_dynamic_lds())
-        return PAPR_OK;
+    if (run->v2) {
+        run->nbins = bands.P.nkeys + 1;
+        const int waves = vblock / 64;
+        int copies = ctx->tune.hist_copies > 0 ? std::min(ctx->tune.hist_copies, waves) : std::min(waves, 4);
+        auto lds_of = [&](int c) {
+            return (size_t)bands.P.table_words * 4 + (((size_t)c * run->nbins + 3) & ~(size_t)3) * 4 + run->stash_lds;
+        };
+        while (copies > 1 && lds_of(copies) > lds_cap - 2048)  // (2 KiB: the kernel's static LDS)
+            copies--;
+        if (lds_of(copies) > lds_cap - 2048)
+            return PAPR_OK;
+        bands.P.copies = (uint32_t)copies;
+        bands.lds_bytes = lds_of(copies) - run->stash_lds;
+        if (run->exact) {
+            if (!ctx->exact || (!ctx->est_groups_valid && !env_int("PAPR_SWEEP2_FAKE_E", 0))) {
+                *reason = PAPR_SWEEP_MODE;  // no per-group estimate to speculate the binades from
+                return PAPR_OK;
+            }
+            run->tile = PAPR_EXACT_TILE_SAMPLES;  // the launch covers whole 2048-sample tiles (two segments each)
+        }
+        const uint64_t nsegs = n_launch / (run->exact ? (uint64_t)PAPR_EXACT_SEG_SAMPLES : run->tile);
+        const uint64_t want = ctx->tune.sweep_blocks > 0 ? (uint64_t)ctx->tune.sweep_blocks : (uint64_t)ctx->num_cus;
+        run->blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (nsegs + waves - 1) / waves));
+    } else {
+        // the sweep kernel's LUT has a sentinel cell at either end and its histogram one more (NaN) bin
+        bands.P.table_words = 2 * (bands.P.ncells + 2);
+        run->nbins = bands.P.nkeys + 2;
+        bands.lds_bytes = (size_t)bands.P.table_words * 4 + (size_t)bands.P.copies * run->nbins * 4;
+        if (bands.lds_bytes + run->stash_lds > lds_cap)
+            return PAPR_OK;
+        run->blocks = pick_blocks(ctx, SWEEP, n_launch / run->tile);
+    }
 
-    run->blocks = pick_blocks(ctx, SWEEP, n_launch / run->tile);
     // buffers: band histogram with the stash-segment lengths right behind it; stash = 1/4 of the shard's samples
     // (as floats: 1/8 of its bytes), one equal segment per workgroup
     constexpr size_t kMaxSweepBlocks = 65536;
     if (!ctx->d_sweep_hist) {
-        const size_t bytes = (2 * (size_t)PAPR_HIP_MAX_LEVELS + 2 + kMaxSweepBlocks) * sizeof(unsigned long long);
+        const size_t bytes = (2 * (size_t)PAPR_HIP_MAX_LEVELS + 2 + 2 * kMaxSweepBlocks) * sizeof(unsigned long long);
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_sweep_hist, bytes));
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_sweep_hist, bytes, hipHostMallocDefault));
     }
-    run->seg_cap = std::max<uint64_t>((n_shard / 4 / (uint64_t)run->blocks + 3) & ~3ull, 4096);
+    run->seg_cap = std::max<uint64_t>((n_shard / 4 / (uint64_t)run->blocks + 255) & ~255ull, 4096);
     const uint64_t want_stash = run->seg_cap * (uint64_t)run->blocks;
     if (ctx->stash_cap < want_stash) {
         if (ctx->d_stash) HIPCHK(ctx, hipFree(ctx->d_stash));
@@ -77,7 +162,9 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
     int rc = ensure_table(ctx, bands.P.table_words);
     if (rc)
         return rc;
-    {
+    if (run->v2) {
+        fill_compact_lut(bands.keys, bands.P, ctx->h_table);
+    } else {
         // lut[0] = below everything, lut[1 + c] = {edges below cell c, the edge inside it or never},
         // lut[ncells + 1] = above every edge; a NaN pattern compares >= 0x7F800001 and lands in the trash bin
         const papr_ccdf_params &P = bands.P;
@@ -95,10 +182,11 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
         }
         tab[2 * (P.ncells + 1)] = P.nkeys;
         tab[2 * (P.ncells + 1) + 1] = 0x7F800001u;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_table, ctx->h_table, (size_t)P.table_words * 4, hipMemcpyHostToDevice,
-                                   ctx->stream));
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_sweep_hist, 0, ((size_t)run->nbins + (size_t)run->blocks) * sizeof(unsigned long long),
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_table, ctx->h_table, (size_t)bands.P.table_words * 4, hipMemcpyHostToDevice,
+                               ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_sweep_hist, 0,
+                               ((size_t)run->nbins + (size_t)(run->v2 ? 2 : 1) * run->blocks) * sizeof(unsigned long long),
                                ctx->stream));
     *reason = PAPR_SWEEP_OK;
     return PAPR_OK;
@@ -111,6 +199,37 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
 {
     const uint64_t ntiles = n / run.tile;
     const uint32_t tail = (uint32_t)(n - ntiles * run.tile);
+    if (run.v2) {
+        const int waves = run.threads / 64;
+        const uint64_t nsegs = run.exact ? 2 * ntiles : ntiles;
+        const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)run.blocks, (nsegs + waves - 1) / waves));
+        int rc = ensure_partials(ctx, slot + (size_t)blocks + 1);
+        if (rc)
+            return rc;
+        papr_sweep2_params p{};
+        p.data = data;
+        p.nsegs = nsegs;
+        p.base_index = base_index;
+        p.out = ctx->d_partials + slot;
+        p.tail = data + 2 * (n - tail);
+        p.tail_samples = tail;
+        p.table = ctx->d_table;
+        p.P = run.bands.P;
+        p.ghist = ctx->d_sweep_hist;
+        p.stash = ctx->d_stash;
+        p.seg_slots = ctx->d_sweep_hist + run.nbins;
+        p.seg_real = ctx->d_sweep_hist + run.nbins + run.blocks;
+        p.seg_cap = run.seg_cap;
+        p.tile_E_spec = ctx->d_tile_E_spec;
+        p.seg_D = ctx->d_seg_D;
+        p.seg_offset = (base_index - ctx->base) / PAPR_EXACT_SEG_SAMPLES;
+        time_begin(ctx, 3, n * 8);
+        papr_launch_sweep2(ctx->stream, run.variant, blocks, run.bands.lds_bytes + run.stash_lds, p);
+        time_end(ctx);
+        HIPCHK(ctx, hipGetLastError());
+        *nrecords = blocks;
+        return PAPR_OK;
+    }
     const int blocks = (int)std::min<uint64_t>((uint64_t)run.blocks, std::max<uint64_t>(ntiles, 1));
     const int map = effective_map(ctx, SWEEP, blocks);
     int rc = ensure_partials(ctx, slot + (size_t)blocks + 1);
@@ -130,8 +249,8 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
 int sweep_fetch(papr_hip_ctx *ctx, const SweepRun &run)
 {
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_sweep_hist, ctx->d_sweep_hist,
-                               ((size_t)run.nbins + (size_t)run.blocks) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                               ctx->stream));
+                               ((size_t)run.nbins + (size_t)(run.v2 ? 2 : 1) * run.blocks) * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, ctx->stream));
     return PAPR_OK;
 }
 
@@ -143,7 +262,7 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
     uint64_t stash_count = 0, in_bands = 0;
     bool overflow = false;
     for (int b = 0; b < run.blocks; b++) {
-        stash_count += H[run.nbins + b];
+        stash_count += H[run.nbins + (run.v2 ? run.blocks : 0) + b];  // v2: the powers stashed, without padding
         overflow = overflow || H[run.nbins + b] > run.seg_cap;
     }
     for (uint32_t b = 1; b < run.nbins; b += 2)
@@ -205,16 +324,50 @@ int papr_hip_estimate(papr_hip_ctx *ctx, papr_stats *est)
     int rc = ensure_partials(ctx, (size_t)blocks + 1);
     if (rc)
         return rc;
+    // exact-sum mode: keep the per-group sampled sums on the device — the one-read sweep speculates every tile's
+    // running-sum binade from them (papr_exact.hip: papr_exact_spec_*)
+    ctx->est_groups_valid = false;
+    double *group_sums = nullptr;
+    if (ctx->exact) {
+        if (ctx->est_groups_cap < ngroups) {
+            if (ctx->d_est_groups) HIPCHK(ctx, hipFree(ctx->d_est_groups));
+            ctx->d_est_groups = nullptr;
+            ctx->est_groups_cap = 0;
+            const uint64_t cap = std::max<uint64_t>(ngroups, 4096);
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_est_groups, cap * 5 * sizeof(double)));  // 4 wave sums + 1 prefix per group
+            ctx->est_groups_cap = cap;
+        }
+        group_sums = ctx->d_est_groups;
+    }
     time_begin(ctx, 4, ngroups * PAPR_ESTIMATE_TILE_SAMPLES * 8);
-    papr_launch_estimate(ctx->stream, blocks, ctx->d_iq, ngroups, (uint32_t)ratio, ctx->d_partials);
+    papr_launch_estimate(ctx->stream, blocks, ctx->d_iq, ngroups, (uint32_t)ratio, ctx->d_partials, group_sums);
     time_end(ctx);
     HIPCHK(ctx, hipGetLastError());
     papr_launch_stats_finalize(ctx->stream, nullptr, 0, 0, ctx->d_partials, (uint32_t)blocks, ctx->h_result_dev);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    est->sum = ctx->h_result->sum;
-    est->n = ngroups * PAPR_ESTIMATE_TILE_SAMPLES;
-    ctx->sweep_info.estimate_samples = est->n;
+    // the record describes the SHARD: the sampled sum scaled to all of its samples, so that shards of different
+    // size (or sampling ratio) merge with the right weights and a shard's record is also the estimate of what it
+    // adds to the running sum of the shards behind it
+    const uint64_t sampled = ngroups * PAPR_ESTIMATE_TILE_SAMPLES;
+    est->sum = ctx->h_result->sum * ((double)ctx->n / (double)sampled);
+    est->n = ctx->n;
+    ctx->sweep_info.estimate_samples = sampled;
+    if (group_sums) {
+        ctx->est_ngroups = ngroups;
+        ctx->est_ratio = ratio;
+        ctx->est_groups_valid = true;
+    }
+    return PAPR_OK;
+}
+
+int papr_hip_set_exact_hint(papr_hip_ctx *ctx, double before_estimate)
+{
+    if (!ctx)
+        return PAPR_E_ARG;
+    if (!(before_estimate >= 0.0) || !std::isfinite(before_estimate))
+        return fail(ctx, PAPR_E_ARG, "the estimated sum before the shard must be finite and non-negative");
+    ctx->exact_before_hint = before_estimate;
     return PAPR_OK;
 }
 
@@ -232,8 +385,9 @@ int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nleve
         info.reason = reason;
         return papr_hip_stats(ctx, out);
     };
-    if (ctx->have_file_stats || !ctx->resident || ctx->exact)
+    if (ctx->have_file_stats || !ctx->resident)
         return plain(PAPR_SWEEP_MODE);
+    ctx->exact_swept = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     SweepRun run;
     int reason = PAPR_SWEEP_OK;
@@ -242,6 +396,20 @@ int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nleve
         return rc;
     if (reason != PAPR_SWEEP_OK)
         return plain(reason);
+    if (run.exact) {
+        // speculate every tile's running-sum binade from the estimate's per-group sums (device side, no round trip)
+        rc = ensure_exact_buffers(ctx);
+        if (rc)
+            return rc;
+        const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
+        if (ctx->est_groups_valid)
+            papr_launch_exact_spec(ctx->stream, ctx->d_est_groups, ctx->est_ngroups, (uint32_t)ctx->est_ratio,
+                                   (double)ctx->est_ratio, ctx->exact_before_hint, ctx->d_est_groups + 4 * ctx->est_groups_cap,
+                                   ntiles, ctx->d_tile_E_spec);
+        else  // PAPR_SWEEP2_FAKE_E: one binade for every tile (kernel timing without an estimate; the redo pass repairs it)
+            papr_launch_exact_fill_spec(ctx->stream, ctx->d_tile_E_spec, ntiles, env_int("PAPR_SWEEP2_FAKE_E", 0));
+        HIPCHK(ctx, hipGetLastError());
+    }
     int nrec = 0;
     rc = sweep_launch(ctx, run, ctx->d_iq, ctx->n, ctx->base, 0, &nrec);
     if (rc)
@@ -255,7 +423,12 @@ int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nleve
         return rc;
     if (std::isnan(out->sum))  // NaN in the data: the sweep's integer-max trackers do not apply (papr_sweep.hip)
         return plain(PAPR_SWEEP_NO_BANDS);
-    return sweep_collect(ctx, run);
+    rc = sweep_collect(ctx, run);
+    if (rc == PAPR_OK && run.exact) {
+        ctx->exact_swept = true;   // d_seg_D holds every segment's sum and its pair for the speculated binade
+        ctx->exact_valid = true;
+    }
+    return rc;
 }
 
 int papr_hip_get_sweep_info(const papr_hip_ctx *ctx, papr_hip_sweep_info *out)

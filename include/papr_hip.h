@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PAPR_HIP_ABI_VERSION 2
+#define PAPR_HIP_ABI_VERSION 3
 
 enum {
     PAPR_OK = 0,
@@ -223,8 +223,9 @@ int papr_exact_chain(const void *const *programs, const size_t *bytes, int nprog
  * and the mean needs a full pass.  Here both passes are HBM-bound, so the second read is half
  * of the job; speculation removes it without changing one count (papr_sweep.hip):
  *
- *   papr_hip_estimate(ctx, &est)      est.sum / est.n over a pseudo-random 1/64 sample of the
- *                                     shard's 16 KiB tiles (1/64 of a pass)
+ *   papr_hip_estimate(ctx, &est)      est.sum / est.n = mean power over a pseudo-random 1/64 sample of the
+ *                                     shard (1/64 of a pass); est.n = samples in the shard, est.sum = the
+ *                                     sampled sum scaled to them, so shards merge with the right weights
  *   (merge the shards' estimates with papr_stats_merge; guess table = papr_guess_levels(&est_total, ...))
  *   papr_hip_stats_sweep(ctx, guess, L, &st)
  *                                     st is what papr_hip_stats returns (same trackers; the double sum
@@ -257,8 +258,20 @@ typedef struct papr_hip_sweep_info {
     int resolved;            /* last papr_hip_ccdf: 1 = answered from the sweep, 0 = read the shard again */
     int reason;              /* PAPR_SWEEP_*: why not */
     int band_log2;
+    uint32_t exact_redo_tiles; /* exact-sum mode, last papr_hip_ccdf_exact / _exact_program after a sweep: 2048-sample tiles whose
+                                * speculated running-sum binade was wrong and whose rounding functions were rebuilt */
+    uint32_t reserved;
 } papr_hip_sweep_info;
 int papr_hip_estimate(papr_hip_ctx *ctx, papr_stats *est);
+/* Exact-sum mode (papr_hip_set_exact(ctx, 1)) is served by the same single read: papr_hip_estimate then also keeps
+ * one sampled sum per 1 MiB group on the device, papr_hip_stats_sweep speculates from them in which binade the
+ * reference's running double sum (papr.c:104) is while it crosses each 2048-sample tile and builds the tiles'
+ * rounding functions for THAT binade in the sweep itself, and papr_hip_ccdf_exact / papr_hip_exact_program — given
+ * the accurate sum of the earlier shards as before — only re-examine the tiles whose speculated binade turns out
+ * wrong (papr_hip_sweep_info.exact_redo_tiles: a fraction of a per cent) instead of reading the shard again.
+ * A shard that is not the first of its file passes the ESTIMATED sum of everything before it (the sum of the
+ * earlier shards' estimate records) before the sweep; a poor hint costs re-examined tiles, never a result. */
+int papr_hip_set_exact_hint(papr_hip_ctx *ctx, double estimated_sum_before_shard);
 /* The same estimate for a range of a FILE that is not loaded yet (the 1-in-64 tiles are read by the
  * ingest's reader threads and summed on the GPU): what a one-sweep ingest needs before it starts. */
 int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples, papr_stats *est);

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--bands", default="15")
     ap.add_argument("--ratios", default="64")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--configs", default="", help="variant:blocks pairs, e.g. 4:1024,32:256 (overrides --variants/--blocks)")
+    ap.add_argument("--modes", default="default,graph")
     args = ap.parse_args()
     pkg = ge.load_package()
     n = int(args.gib * (1 << 30)) // 8 // 8192 * 8192
@@ -37,7 +39,9 @@ def main():
     g.adopt(shard.data_ptr(), n, base_index=0, keepalive=shard)
     g.generate(pkg.SynthSpec.spike(n), 0, n)
 
-    for graph in (False, True):
+    pairs = ([(int(c.split(":")[0]), int(c.split(":")[1])) for c in args.configs.split(",")] if args.configs else
+             [(int(v), int(b)) for v in args.variants.split(",") for b in args.blocks.split(",")])
+    for graph in [m == "graph" for m in args.modes.split(",")]:
         st = g.stats()
         mean, papr, table = pkg.levels(st, graph)
         want = g.ccdf(table)
@@ -53,8 +57,8 @@ def main():
         print(f"mode={'graph' if graph else 'default'} levels={table.size} two-pass: stats "
               f"{tm.stats_ms / tm.stats_launches:.3f} ms + ccdf {tm.ccdf_ms / tm.ccdf_launches:.3f} ms, wall {wall:.3f} ms",
               flush=True)
-        for v in [int(x) for x in args.variants.split(",")]:
-            for b in [int(x) for x in args.blocks.split(",")]:
+        for v, b in pairs:
+            if True:
                 for m in [int(x) for x in args.maps.split(",")]:
                     for band in [int(x) for x in args.bands.split(",")]:
                         for ratio in [int(x) for x in args.ratios.split(",")]:
