@@ -309,7 +309,10 @@ int finish_plan(papr_hip_ctx *ctx, CcdfPlan *plan, int vblock, size_t extra_lds)
     const int want_copies = ctx->tune.hist_copies > 0 ? std::min(ctx->tune.hist_copies, waves) : std::min(waves, 4);
 
     // LUT: the coarsest cell size that still isolates every key in its own cell
-    if (plan->keys.front() >= 0x00800000u && !(ctx->tune.flags & 1)) {  // keys in the normal-float range
+    // keys in the normal-float range; a key of 0x7F800000 (a level of FLT_MAX: only +Inf is above it) shares its cell
+    // with NaN patterns whatever the cell size, and a LUT cell compares patterns as numbers: the search form, which
+    // screens NaNs, serves such tables
+    if (plan->keys.front() >= 0x00800000u && plan->keys.back() < 0x7F800000u && !(ctx->tune.flags & 1)) {
         for (int shift = 23; shift >= 8; shift--) {
             const uint32_t c0 = plan->keys.front() >> shift, c1 = plan->keys.back() >> shift;
             const uint64_t ncells = (uint64_t)c1 - c0 + 1;

@@ -38,6 +38,8 @@
 namespace {
 
 
+typedef __attribute__((address_space(3))) uint32_t lds_u32;  // an LDS word addressed as LDS (ds_read/ds_write, not flat)
+
 // min(max(cell, first), last) in one instruction (the compiler will not form med3 from min/max when it
 // cannot prove last >= 0)
 __device__ __forceinline__ int32_t clamp_cell(int32_t cell, int32_t first, int32_t last)
@@ -72,14 +74,16 @@ struct WaveStash {
     __device__ __forceinline__ void spill_if_above(uint32_t limit)
     {
         __builtin_amdgcn_wave_barrier();  // LDS is in-order per wave; this pins the compiler's order too
-        const uint32_t n = __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)fill);  // other lanes' atomics: never cached
+        // other lanes' atomics: never cached.  The cast matters: through a generic pointer the volatile read is a
+        // flat_load sc0 sc1 followed by s_waitcnt vmcnt(0) — it drains the prefetched tile's loads every iteration
+        const uint32_t n = __builtin_amdgcn_readfirstlane(*(volatile lds_u32 *)(lds_u32 *)fill);
         if (n <= limit)
             return;
         const uint32_t lane = threadIdx.x & (kWave - 1);
         unsigned long long pos = 0;
         if (lane == 0) {
             pos = atomicAdd(seg_fill, (unsigned long long)n);  // counts even what no longer fits: the host sees the overflow
-            *(volatile uint32_t *)fill = 0;
+            *(volatile lds_u32 *)(lds_u32 *)fill = 0;
         }
         pos = __shfl((unsigned long long)pos, 0, kWave);
         for (uint32_t i = lane; i < n; i += kWave)
@@ -486,6 +490,31 @@ struct StashRing {
     unsigned long long *seg_real;     // LDS: powers stashed (without padding)
     uint64_t seg_cap;
 
+    // One reservation per lane for ALL its in-band powers of a batch (one LDS round trip per batch; a returning
+    // atomic per sample serialises up to 2 * BATCH of them behind s_waitcnt lgkmcnt(0)), then plain LDS writes.
+    // Returns the ring's head as this lane saw it issued AFTER its own reservation (see pending_from).
+    template <int N>
+    __device__ __forceinline__ uint32_t put_batch(const float (&pw)[N], const uint32_t (&k)[N])
+    {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int u = 0; u < N; u++)
+            cnt += k[u] & 1u;
+        uint32_t slot = 0;
+        if (cnt)
+            slot = atomicAdd(head, cnt);
+        // the wave's head after every lane's reservation: LDS operations of one wave complete in issue order, so
+        // this read (issued behind the atomics, consumed only after the ring writes) sees them all
+        const uint32_t seen = *(volatile lds_u32 *)(lds_u32 *)head;
+#pragma unroll
+        for (int u = 0; u < N; u++) {
+            if (k[u] & 1u) {
+                ring[slot & (RING - 1)] = pw[u];
+                slot++;
+            }
+        }
+        return seen;
+    }
     __device__ __forceinline__ void put(float pw, bool take)
     {
         if (take)
@@ -516,7 +545,20 @@ struct StashRing {
     __device__ __forceinline__ uint32_t pending()
     {
         __builtin_amdgcn_wave_barrier();  // LDS is in-order per wave; this pins the compiler's order too
-        return __builtin_amdgcn_readfirstlane(*(volatile uint32_t *)head) - tail;
+        return __builtin_amdgcn_readfirstlane(*(volatile lds_u32 *)(lds_u32 *)head) - tail;
+    }
+    // spill whole 256-float chunks; `seen` = what put_batch returned (any lane's value is the wave's head)
+    __device__ __forceinline__ void spill_from(uint32_t seen)
+    {
+        uint32_t n = __builtin_amdgcn_readfirstlane(seen) - tail;
+        if (n >= PAPR_SWEEP2_SPILL) {
+            __builtin_amdgcn_wave_barrier();
+            do {
+                chunk(PAPR_SWEEP2_SPILL);
+                n -= PAPR_SWEEP2_SPILL;
+            } while (n >= PAPR_SWEEP2_SPILL);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     __device__ __forceinline__ void spill_full()
     {
@@ -536,7 +578,7 @@ struct StashRing {
         tail = (tail + PAPR_SWEEP2_SPILL - 1) & ~(PAPR_SWEEP2_SPILL - 1);  // (keeps the ring reads 16-byte aligned)
         __builtin_amdgcn_wave_barrier();
         if ((threadIdx.x & (kWave - 1)) == 0)
-            *(volatile uint32_t *)head = tail;
+            *(volatile lds_u32 *)(lds_u32 *)head = tail;
         __builtin_amdgcn_wave_barrier();
     }
 };
@@ -799,8 +841,9 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
             k[u] = bin_of(pw[u]);  // the batch's LUT reads in flight together
 #pragma unroll
         for (int u = 0; u < 2 * BATCH; u++)
-            count_and_stash(pw[u], k[u]);
-        ws.spill_full();
+            if (k[u])
+                atomicAdd(&my[k[u]], 1u);
+        ws.spill_from(ws.put_batch(pw, k));
     };
 
     auto load_seg = [&](float4(&x)[U], uint64_t seg) {
