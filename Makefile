@@ -17,6 +17,15 @@ lib: $(LIB)
 $(CSRC)/papr_host.o: $(CSRC)/papr_host.c $(CSRC)/papr_exact_format.h include/papr_hip.h include/papr_synth.h
 	$(CC) $(CFLAGS) -c $< -o $@
 
+$(CSRC)/ts_host.o: $(CSRC)/ts_host.c include/ts_hip.h
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(CSRC)/ts_kernels.o: $(CSRC)/ts_kernels.hip $(CSRC)/ts_kernels.h include/ts_hip.h include/ts_synth.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/ts_runtime.o: $(CSRC)/ts_runtime.cpp $(CSRC)/ts_kernels.h include/ts_hip.h include/papr_hip.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(CSRC)/papr_kernels.o: $(CSRC)/papr_kernels.hip $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h $(CSRC)/papr_stream.h include/papr_synth.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -39,9 +48,13 @@ $(CSRC)/papr_sweep_rt.o: $(CSRC)/papr_sweep_rt.cpp $(RT_HDRS)
 $(CSRC)/papr_exact_rt.o: $(CSRC)/papr_exact_rt.cpp $(RT_HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+$(CSRC)/papr_exchange.o: $(CSRC)/papr_exchange.cpp $(RT_HDRS)
+	$(HIPCC) $(HIPFLAGS) -I/opt/rocm/include -c $< -o $@
+
 $(LIB): $(CSRC)/papr_kernels.o $(CSRC)/papr_sweep.o $(CSRC)/papr_exact.o $(CSRC)/papr_runtime.o $(CSRC)/papr_ingest.o \
-        $(CSRC)/papr_sweep_rt.o $(CSRC)/papr_exact_rt.o $(CSRC)/papr_host.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -lm -lpthread
+        $(CSRC)/papr_sweep_rt.o $(CSRC)/papr_exact_rt.o $(CSRC)/papr_host.o $(CSRC)/ts_host.o \
+        $(CSRC)/ts_kernels.o $(CSRC)/ts_runtime.o $(CSRC)/papr_exchange.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -lm -lpthread -ldl
 
 cli: bin/papr
 

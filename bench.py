@@ -112,21 +112,18 @@ def run_mode(args, mode, env):
 
     def step():
         if one_sweep:
-            ests = xch.allgather_stats(gpu.estimate())                   # 1/64-sample mean of every shard
-            est = pkg.stats_merge(ests)
+            est, est_before, _ = xch.stats(gpu.estimate())   # 1/64-sample mean of the whole stream (exchange 0)
             if args.exact:   # what the earlier shards add to the reference's running sum, as far as the sample tells
-                gpu.set_exact_hint(float(sum(e.sum for e in ests[:rank])))
+                gpu.set_exact_hint(est_before)
             local = gpu.stats_sweep(pkg.guess_levels(est, graph))        # pass 1 + banded pass 2 (+ exact-sum pairs), one read
         else:
             local = gpu.stats()                              # pass 1 on this shard
-        parts = xch.allgather_stats(local)                   # exchange 1 (RCCL all-gather)
-        tot = pkg.stats_merge(parts)                         #   + ordered merge, identical on every rank
+        tot, before, _ = xch.stats(local)                    # exchange 1: all-gather + ordered merge (C ABI, RCCL)
         mean, papr, table = pkg.levels(tot, graph)           # host scalars
         if args.exact and np.isfinite(tot.sum):
-            # one sweep: pass 2 against the table from the tree sum + this shard's sum program
-            before = float(sum(p.sum for p in parts[:rank]))
+            # pass 2 against the table from the tree sum + this shard's sum program
             local_counts, prog = gpu.ccdf_exact(table, before, total)
-            tot.sum = pkg.exact_chain(xch.allgather_bytes(prog))   # papr.c:104's rounding sequence, bit for bit
+            tot.sum = xch.exact_sum(prog)                    # all-gather + chain: papr.c:104's rounding sequence, bit for bit
             mean, papr, table2 = pkg.levels(tot, graph)
             if one_sweep:
                 info = gpu.sweep_info()
@@ -144,7 +141,7 @@ def run_mode(args, mode, env):
                 info = gpu.sweep_info()
                 result["resolved"] = result.get("resolved", 0) + int(info.resolved)
                 result["sweep_info"] = info.as_dict()
-        counts = xch.allreduce_counts(local_counts)          # exchange 2 (RCCL all-reduce)
+        counts = xch.counts(local_counts)                    # exchange 2: all-reduce of the counters (C ABI, RCCL)
         result.update(total=tot, mean=mean, papr=papr, table=table, counts=counts)
 
     def fence():
@@ -157,6 +154,7 @@ def run_mode(args, mode, env):
         step()
     result.pop("resolved", None)
     result.pop("redo_tiles", None)
+    xch.timing(reset=True)
     gpu.set_timing(True)
     fence()
     t0 = time.perf_counter()
@@ -165,6 +163,7 @@ def run_mode(args, mode, env):
     fence()
     elapsed = time.perf_counter() - t0
     tm = gpu.timing()
+    xt = xch.timing().as_dict()
     gpu.set_timing(False)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
@@ -248,10 +247,102 @@ def run_mode(args, mode, env):
                         if kernel_ms_per_step else 0.0,
                         "papr_exact_kernels": {"avg_ms": k_exact, "GB/s": gbs_exact, "launches": int(tm.exact_launches)},
                         "host_and_exchange_ms_per_step": ms_per_step - kernel_ms_per_step},
+            # host wall time inside the C-ABI exchanges (H2D + collective + D2H + one stream sync each), rank 0
+            "exchange": {"transport": xch.transport, "world": world, **xt},
             "device": gpu.name,
         }
         return line
     return None
+
+
+def run_ts(args, rank, world, local_rank, use_dist, real_stdout):
+    """--workload ts: the transport-stream packet scan (include/ts_hip.h).  One step = one
+    complete scan of the HBM-resident stream: sync lock, per-PID count / first / last.  Every rank owns its own
+    10 GiB stream (independent streams: no exchange)."""
+    pkg = ge.load_package()
+    from dtv_utils_amd import ts
+    npackets = int(args.gib * (1 << 30)) // 188
+    gpu = ts.TsHip(local_rank)
+    gpu.generate(npackets, seed=0x7500001 + rank)
+    res = None
+    for _ in range(args.warmup):
+        res = gpu.scan()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for _ in range(args.steps):
+        res = gpu.scan()
+        kernel_ms += res.kernel_ms
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank) if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    nbytes = npackets * 188
+    k_ms = kernel_ms / args.steps
+    line = {
+        "metric": "TS Mpackets/s + achieved GB/s of stream (% of HBM peak), 10 GiB transport stream per GPU",
+        "value": npackets * world * args.steps / elapsed / 1e6, "unit": "Mpackets/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"xport -p packet scan (sync lock, per-PID count/first/last) on {args.gib:g} GiB synthetic "
+                               f"MPEG-2 TS per GPU, HBM-resident, {world}xMI355X", "packets_per_gpu": npackets,
+                   "bytes_per_gpu": nbytes, "launches_per_scan": int(res.launches), "walks_per_scan": int(res.walks),
+                   "pids_seen": int(np.count_nonzero(res.tables()[0])), "sharding": "independent streams, no exchange",
+                   "report_sha256": hashlib.sha256(res.report()).hexdigest()},
+        # algorithmic bytes: the reference reads every byte of the stream (1 B/B); the scan kernel itself touches only
+        # the 64-byte sector holding each packet's header (about a third of the sectors)
+        "roofline": {"bound": "hbm", "achieved": nbytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": (nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms else 0.0, "traffic": None,
+                     "kernel": "ts_scan_kernel (+ ts_merge_kernel)", "kernel_ms": k_ms,
+                     "algorithmic_bytes_per_launch": nbytes},
+        "device": None,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = ts_cpu_baseline(gpu, ts, args.cpu_sample_gib or 2.0)
+        except Exception as e:
+            line["cpu_baseline"] = {"error": repr(e)}
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(line), flush=True)
+    os.dup2(2, 1)
+    gpu.close()
+
+
+def ts_cpu_baseline(gpu, ts, sample_gib: float):
+    """The reference's xport (oracle/_ref/xport, compiled from its own source) — or the oracle port — on a bounded
+    sample of the same synthetic stream, single thread, and the GPU scan's report against it on that sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ts_oracle
+    n = int(sample_gib * (1 << 30)) // 188
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path = os.path.join(tmpdir, f"ts_bench_sample_{os.getpid()}.ts")
+    try:
+        subprocess.check_call([os.path.join(ROOT, "oracle", "mkts"), path, str(n)])
+        use_ref = os.path.exists(ts_oracle.REF_CLI)
+        cmd = [ts_oracle.REF_CLI, "-ps", path, ts_oracle.REF_PROGRAM, "1", "1"] if use_ref else [ts_oracle.CLI_PATH, path]
+        subprocess.run(cmd, capture_output=True)   # page-cache warm, untimed
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, capture_output=True)
+        cpu_s = time.perf_counter() - t0
+        want = ts_oracle.filter_lines(p.stdout)
+        gpu.load_file(path)
+        got = gpu.scan().report()
+        return {"value": n / cpu_s / 1e6, "unit": "Mpackets/s", "cores": 1, "kind": "reference" if use_ref else "port",
+                "GB/s": n * 188 / cpu_s / 1e9,
+                "sample": f"{sample_gib:g} GiB ({n} packets) of the same synthetic stream, file in {tmpdir} (page cache "
+                          f"warm), {cpu_s:.2f} s wall", "nproc": os.cpu_count(), "gpu_report_identical": got == want}
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
 
 
 def main():
@@ -263,6 +354,9 @@ def main():
                     help="default = configs[1] (1 dB table), graph = configs[2] (papr -g, 0.1 dB CCDF); both (the "
                          "default) times configs[1] as the headline and adds configs[2] under \"graph\" in the same line")
     ap.add_argument("--gib", type=float, default=10.0, help="GiB of IQ per GPU")
+    ap.add_argument("--workload", choices=["papr", "ts"], default="papr",
+                    help="papr = BASELINE.json's metric (the default); ts = the transport-stream packet scan of "
+                         "xport.c (SURVEY.md 8(f) N4), a second line of its own")
     ap.add_argument("--exact", action="store_true",
                     help="also reproduce the reference's sequential double sum bit for bit every step "
                          "(rounding functions computed in the pass-2 sweep + a short host chain); off by default")
@@ -306,6 +400,12 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    if args.workload == "ts":
+        run_ts(args, rank, world, local_rank, use_dist, real_stdout)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     pkg = ge.load_package()
     from dtv_utils_amd import exchange
     per_gpu = int(args.gib * (1 << 30)) // 8 // 8192 * 8192   # samples per rank, chunk aligned
@@ -314,7 +414,12 @@ def main():
     gpu = pkg.PaprHip(local_rank)
     gpu.adopt(shard.data_ptr(), per_gpu, base_index=rank * per_gpu, keepalive=shard)
     gpu.generate(pkg.SynthSpec.spike(total), rank * per_gpu, per_gpu)
-    xch = exchange.Exchange(device if args.backend == "nccl" else torch.device("cpu"))
+    if not use_dist:
+        xch = exchange.Exchange.single()
+    elif args.backend == "nccl":
+        xch = exchange.Exchange.rccl(gpu, rank, world)      # ncclCommInitRank inside libpaprhip; collectives on its stream
+    else:
+        xch = exchange.Exchange.over_torch()                # the same C exchange code over gloo
     if args.exact:
         gpu.set_exact(True)
     one_sweep = not (args.two_pass or (args.exact and args.exact_two_pass))

@@ -1,0 +1,370 @@
+// papr_exchange.cpp — the exchange between the shards of a sharded papr run, behind the C ABI (include/papr_hip.h):
+// all-gather of 96-byte pass-1 records + ordered merge, all-reduce of the per-level counters, all-gather of the
+// exact-sum programs + chain.  Transport: RCCL (bound at run time with dlopen, so that a process that already
+// carries an RCCL — PyTorch ships its own — uses that one instead of loading a second copy), or caller-supplied
+// collectives (the CPU tests: gloo).  SURVEY.md 7.1 C1 / C2.
+
+#include "papr_runtime_internal.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: the functions are looked up with dlsym
+
+using namespace papr_rt;
+
+namespace {
+
+char g_xch_open_error[256] = "";
+
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+RcclApi *rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // an RCCL that is already in the process first (RTLD_NOLOAD), then the ROCm installation's
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (int pass = 0; pass < 2 && !api.handle; pass++)
+            for (const char *n : names) {
+                api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (api.handle)
+                    break;
+            }
+        if (!api.handle)
+            api.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!api.handle)
+            return;
+#define SYM(name) api.name = reinterpret_cast<decltype(api.name)>(dlsym(api.handle, "nccl" #name))
+        SYM(GetUniqueId);
+        SYM(CommInitRank);
+        SYM(CommDestroy);
+        SYM(AllGather);
+        SYM(AllReduce);
+        SYM(GetErrorString);
+#undef SYM
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.AllReduce)
+            api.handle = nullptr;
+    });
+    return api.handle ? &api : nullptr;
+}
+
+double now_us()
+{
+    return now_s() * 1e6;
+}
+
+}  // namespace
+
+struct papr_exchange {
+    int rank = 0, world = 1;
+    char err[256] = "";
+    // caller-supplied transport
+    papr_exchange_ops ops{};
+    bool use_ops = false;
+    // RCCL transport
+    papr_hip_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    unsigned char *d_send = nullptr, *d_recv = nullptr;  // device staging
+    unsigned char *h_send = nullptr, *h_recv = nullptr;  // pinned mirrors
+    size_t cap_send = 0, cap_recv = 0;
+    std::vector<unsigned char> scratch;
+    papr_exchange_timing timing{};
+};
+
+namespace {
+
+int xfail(papr_exchange *x, int code, const char *fmt, ...)
+{
+    char *dst = x ? x->err : g_xch_open_error;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 256, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int ensure_staging(papr_exchange *x, size_t send_bytes, size_t recv_bytes)
+{
+    if (send_bytes > x->cap_send) {
+        if (x->d_send) (void)hipFree(x->d_send);
+        if (x->h_send) (void)hipHostFree(x->h_send);
+        x->d_send = x->h_send = nullptr;
+        x->cap_send = 0;
+        const size_t cap = std::max<size_t>(send_bytes, (size_t)PAPR_HIP_MAX_LEVELS * 8);
+        if (hipMalloc((void **)&x->d_send, cap) != hipSuccess || hipHostMalloc((void **)&x->h_send, cap, hipHostMallocDefault) != hipSuccess)
+            return xfail(x, PAPR_E_NOMEM, "cannot allocate %zu bytes of exchange staging", cap);
+        x->cap_send = cap;
+    }
+    if (recv_bytes > x->cap_recv) {
+        if (x->d_recv) (void)hipFree(x->d_recv);
+        if (x->h_recv) (void)hipHostFree(x->h_recv);
+        x->d_recv = x->h_recv = nullptr;
+        x->cap_recv = 0;
+        const size_t cap = std::max<size_t>(recv_bytes, (size_t)PAPR_HIP_MAX_LEVELS * 8);
+        if (hipMalloc((void **)&x->d_recv, cap) != hipSuccess || hipHostMalloc((void **)&x->h_recv, cap, hipHostMallocDefault) != hipSuccess)
+            return xfail(x, PAPR_E_NOMEM, "cannot allocate %zu bytes of exchange staging", cap);
+        x->cap_recv = cap;
+    }
+    return PAPR_OK;
+}
+
+#define XHIP(x, call)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return xfail(x, PAPR_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));         \
+    } while (0)
+#define XNCCL(x, call)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r_ = (call);                                                               \
+        if (r_ != ncclSuccess)                                                                  \
+            return xfail(x, PAPR_E_HIP, "%s failed: %s", #call,                                 \
+                         rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "RCCL error");   \
+    } while (0)
+
+// recv = world x bytes_per_rank, in rank order
+int allgather_bytes(papr_exchange *x, const void *send, void *recv, size_t bytes_per_rank)
+{
+    if (x->world == 1 && x->use_ops) {  // (an RCCL communicator of one rank still runs its collectives: that is
+        memcpy(recv, send, bytes_per_rank);  // what `torchrun --nproc-per-node 1` measures)
+        return PAPR_OK;
+    }
+    if (x->use_ops) {
+        if (x->ops.allgather(x->ops.user, send, recv, bytes_per_rank) != 0)
+            return xfail(x, PAPR_E_HIP, "the caller's all-gather failed");
+        return PAPR_OK;
+    }
+    const size_t total = bytes_per_rank * (size_t)x->world;
+    int rc = ensure_staging(x, bytes_per_rank, total);
+    if (rc)
+        return rc;
+    papr_hip_ctx *ctx = x->ctx;
+    XHIP(x, hipSetDevice(ctx->device));
+    memcpy(x->h_send, send, bytes_per_rank);
+    XHIP(x, hipMemcpyAsync(x->d_send, x->h_send, bytes_per_rank, hipMemcpyHostToDevice, ctx->stream));
+    XNCCL(x, rccl()->AllGather(x->d_send, x->d_recv, bytes_per_rank, ncclUint8, x->comm, ctx->stream));
+    XHIP(x, hipMemcpyAsync(x->h_recv, x->d_recv, total, hipMemcpyDeviceToHost, ctx->stream));
+    XHIP(x, hipStreamSynchronize(ctx->stream));
+    memcpy(recv, x->h_recv, total);
+    return PAPR_OK;
+}
+
+int allreduce_u64(papr_exchange *x, uint64_t *buf, size_t count)
+{
+    if ((x->world == 1 && x->use_ops) || count == 0)
+        return PAPR_OK;
+    if (x->use_ops) {
+        if (x->ops.allreduce_sum_u64(x->ops.user, buf, count) != 0)
+            return xfail(x, PAPR_E_HIP, "the caller's all-reduce failed");
+        return PAPR_OK;
+    }
+    const size_t bytes = count * sizeof(uint64_t);
+    int rc = ensure_staging(x, bytes, bytes);
+    if (rc)
+        return rc;
+    papr_hip_ctx *ctx = x->ctx;
+    XHIP(x, hipSetDevice(ctx->device));
+    memcpy(x->h_send, buf, bytes);
+    XHIP(x, hipMemcpyAsync(x->d_send, x->h_send, bytes, hipMemcpyHostToDevice, ctx->stream));
+    XNCCL(x, rccl()->AllReduce(x->d_send, x->d_recv, count, ncclUint64, ncclSum, x->comm, ctx->stream));
+    XHIP(x, hipMemcpyAsync(x->h_recv, x->d_recv, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    XHIP(x, hipStreamSynchronize(ctx->stream));
+    memcpy(buf, x->h_recv, bytes);
+    return PAPR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *papr_exchange_last_error(const papr_exchange *x)
+{
+    return x ? x->err : g_xch_open_error;
+}
+
+int papr_exchange_unique_id(void *id)
+{
+    static_assert(sizeof(ncclUniqueId) == PAPR_EXCHANGE_ID_BYTES, "ncclUniqueId size");
+    if (!id)
+        return PAPR_E_ARG;
+    if (!rccl())
+        return xfail(nullptr, PAPR_E_NO_DEVICE, "RCCL (librccl.so) could not be loaded");
+    ncclUniqueId uid;
+    if (rccl()->GetUniqueId(&uid) != ncclSuccess)
+        return xfail(nullptr, PAPR_E_HIP, "ncclGetUniqueId failed");
+    memcpy(id, &uid, sizeof(uid));
+    return PAPR_OK;
+}
+
+int papr_exchange_open_rccl(papr_exchange **out, papr_hip_ctx *ctx, const void *id, int rank, int world)
+{
+    if (!out || !ctx || !id || world < 1 || rank < 0 || rank >= world)
+        return PAPR_E_ARG;
+    *out = nullptr;
+    if (!rccl())
+        return xfail(nullptr, PAPR_E_NO_DEVICE, "RCCL (librccl.so) could not be loaded");
+    papr_exchange *x = new (std::nothrow) papr_exchange();
+    if (!x)
+        return PAPR_E_NOMEM;
+    x->rank = rank;
+    x->world = world;
+    x->ctx = ctx;
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        delete x;
+        return xfail(nullptr, PAPR_E_HIP, "hipSetDevice(%d) failed", ctx->device);
+    }
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    const ncclResult_t r = rccl()->CommInitRank(&x->comm, world, uid, rank);
+    if (r != ncclSuccess) {
+        xfail(nullptr, PAPR_E_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world,
+              rccl()->GetErrorString ? rccl()->GetErrorString(r) : "RCCL error");
+        delete x;
+        return PAPR_E_HIP;
+    }
+    *out = x;
+    return PAPR_OK;
+}
+
+int papr_exchange_open_ops(papr_exchange **out, const papr_exchange_ops *ops, int rank, int world)
+{
+    if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && (!ops || !ops->allgather || !ops->allreduce_sum_u64)))
+        return PAPR_E_ARG;
+    papr_exchange *x = new (std::nothrow) papr_exchange();
+    if (!x)
+        return PAPR_E_NOMEM;
+    x->rank = rank;
+    x->world = world;
+    x->use_ops = true;
+    if (ops)
+        x->ops = *ops;
+    *out = x;
+    return PAPR_OK;
+}
+
+void papr_exchange_close(papr_exchange *x)
+{
+    if (!x)
+        return;
+    if (x->ctx)
+        (void)hipSetDevice(x->ctx->device);
+    if (x->comm && rccl())
+        (void)rccl()->CommDestroy(x->comm);
+    if (x->d_send) (void)hipFree(x->d_send);
+    if (x->d_recv) (void)hipFree(x->d_recv);
+    if (x->h_send) (void)hipHostFree(x->h_send);
+    if (x->h_recv) (void)hipHostFree(x->h_recv);
+    delete x;
+}
+
+int papr_exchange_stats(papr_exchange *x, const papr_stats *local, papr_stats *total, double *sum_before, papr_stats *all)
+{
+    if (!x || !local || !total)
+        return PAPR_E_ARG;
+    const double t0 = now_us();
+    try {
+        x->scratch.resize((size_t)x->world * sizeof(papr_stats));
+    } catch (...) {
+        return xfail(x, PAPR_E_NOMEM, "out of host memory");
+    }
+    int rc = allgather_bytes(x, local, x->scratch.data(), sizeof(papr_stats));
+    if (rc)
+        return rc;
+    const papr_stats *recs = reinterpret_cast<const papr_stats *>(x->scratch.data());
+    papr_stats acc;
+    papr_stats_init(&acc);
+    double before = 0.0;
+    for (int r = 0; r < x->world; r++) {
+        if (r == x->rank)
+            before = acc.sum;
+        papr_stats_merge(&acc, &recs[r]);
+    }
+    *total = acc;
+    if (sum_before)
+        *sum_before = before;
+    if (all)
+        memcpy(all, recs, (size_t)x->world * sizeof(papr_stats));
+    x->timing.stats_calls++;
+    x->timing.stats_us += now_us() - t0;
+    return PAPR_OK;
+}
+
+int papr_exchange_counts(papr_exchange *x, uint64_t *counts, int n)
+{
+    if (!x || n < 0 || (n && !counts))
+        return PAPR_E_ARG;
+    const double t0 = now_us();
+    int rc = allreduce_u64(x, counts, (size_t)n);
+    if (rc)
+        return rc;
+    x->timing.counts_calls++;
+    x->timing.counts_us += now_us() - t0;
+    return PAPR_OK;
+}
+
+int papr_exchange_exact_sum(papr_exchange *x, const void *program, size_t bytes, double *sum)
+{
+    if (!x || !program || !sum)
+        return PAPR_E_ARG;
+    const double t0 = now_us();
+    int rc = PAPR_OK;
+    if (x->world == 1 && x->use_ops) {
+        const void *progs[1] = {program};
+        const size_t sizes[1] = {bytes};
+        rc = papr_exact_chain(progs, sizes, 1, sum);
+    } else {
+        // sizes first, then the programs padded to the largest
+        std::vector<uint64_t> sizes((size_t)x->world);
+        const uint64_t mine = bytes;
+        rc = allgather_bytes(x, &mine, sizes.data(), sizeof(uint64_t));
+        if (rc)
+            return rc;
+        uint64_t cap = 8;
+        for (uint64_t s : sizes)
+            cap = std::max(cap, s);
+        cap = (cap + 7) & ~7ull;
+        std::vector<unsigned char> send, recv;
+        try {
+            send.assign((size_t)cap, 0);
+            recv.resize((size_t)cap * (size_t)x->world);
+        } catch (...) {
+            return xfail(x, PAPR_E_NOMEM, "out of host memory");
+        }
+        memcpy(send.data(), program, bytes);
+        rc = allgather_bytes(x, send.data(), recv.data(), (size_t)cap);
+        if (rc)
+            return rc;
+        std::vector<const void *> progs((size_t)x->world);
+        std::vector<size_t> lens((size_t)x->world);
+        for (int r = 0; r < x->world; r++) {
+            progs[(size_t)r] = recv.data() + (size_t)r * (size_t)cap;
+            lens[(size_t)r] = (size_t)sizes[(size_t)r];
+        }
+        rc = papr_exact_chain(progs.data(), lens.data(), x->world, sum);
+    }
+    if (rc)
+        return xfail(x, rc, "papr_exact_chain failed over the gathered programs (code %d)", rc);
+    x->timing.exact_calls++;
+    x->timing.exact_us += now_us() - t0;
+    return PAPR_OK;
+}
+
+int papr_exchange_get_timing(papr_exchange *x, papr_exchange_timing *out, int reset)
+{
+    if (!x || !out)
+        return PAPR_E_ARG;
+    *out = x->timing;
+    if (reset)
+        memset(&x->timing, 0, sizeof(x->timing));
+    return PAPR_OK;
+}
+
+}  // extern "C"

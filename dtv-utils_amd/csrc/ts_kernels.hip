@@ -1,0 +1,192 @@
+// ts_kernels.hip — gfx950 kernels of the transport-stream packet scan (include/ts_hip.h; reference xport.c).
+//
+// From a clean sync position every "regular" packet sits at a fixed stride and is independent of the others, so
+// one launch takes a whole stretch of them: each lane ONE packet header (8 aligned bytes out of the unit's 188 /
+// 192: the scan touches a third of the stream's 64-byte sectors, not its payload), per-workgroup count / first /
+// last tables in LDS (3 x 32 KiB), and — because a launch cannot know in advance where the stretch ends — every
+// workgroup works on one contiguous span and stops at ITS first irregular packet; ts_merge_kernel then folds the
+// tables of the workgroups up to and including the first one that stopped and reports where the stretch ended.
+// Irregular = anything whose effect on the reference's state machine is not local to the packet (ts_host.c walks
+// those): sync byte missing, packet cut off by the end of the stream, adaptation field longer than the packet, or
+// the packet ends exactly one byte past a 16384-byte read of the reference while its payload is skipped in one
+// step (xport.c:4302).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ts_hip.h"
+#include "ts_kernels.h"
+#include "ts_synth.h"
+
+namespace {
+
+constexpr int kBlock = 1024;
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+}  // namespace
+
+__global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t ts_smem[];  // 3 x TS_PIDS words = 96 KiB (one workgroup per CU)
+    uint32_t *s_count = ts_smem, *s_first = ts_smem + TS_PIDS, *s_last = ts_smem + 2 * TS_PIDS;
+    __shared__ uint32_t s_irregular, s_entries;
+    const uint32_t t = threadIdx.x;
+    for (uint32_t k = t; k < TS_PIDS; k += kBlock) {
+        s_count[k] = 0;
+        s_first[k] = kNone;
+        s_last[k] = 0;
+    }
+    if (t == 0) {
+        s_irregular = kNone;
+        s_entries = 0;
+    }
+    __syncthreads();
+
+    // this workgroup's span of units (unit = 188 or 192 bytes; the sync byte sits p.sync_offset bytes into it)
+    const uint64_t per = (p.nunits + gridDim.x - 1) / gridDim.x;
+    const uint64_t j0 = (uint64_t)blockIdx.x * per;
+    const uint64_t j1 = j0 + per < p.nunits ? j0 + per : p.nunits;
+    for (uint64_t jb = j0; jb < j1; jb += kBlock) {  // workgroup-uniform trip count
+        const uint64_t j = jb + t;
+        bool regular = true, have = j < j1;
+        uint32_t pid = 0, tei = 0;
+        if (have) {
+            const uint64_t s = p.first_unit + j * p.stride + p.sync_offset;  // file offset of the sync byte
+            if (s + 188 > p.nbytes) {
+                regular = false;  // cut off by the end of the stream
+            } else {
+                // the five bytes that matter — sync, two PID bytes, adaptation_field_control, adaptation_field_length —
+                // out of two aligned dwords
+                const uint64_t a = s & ~3ull;
+                const uint32_t w0 = *reinterpret_cast<const uint32_t *>(p.data + a);
+                const uint32_t w1 = *reinterpret_cast<const uint32_t *>(p.data + a + 4);
+                const uint32_t sh = (uint32_t)(s & 3u);
+                const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh);  // bytes s .. s+3
+                const uint32_t b4 = (w1 >> (8 * sh)) & 0xffu;                // byte s+4 (sh <= 3: inside w1)
+                const uint32_t b0 = lo & 0xffu, b1 = (lo >> 8) & 0xffu, b2 = (lo >> 16) & 0xffu, b3 = lo >> 24;
+                tei = b1 >> 7;
+                pid = ((b1 & 0x1fu) << 8) | b2;
+                const bool has_af = (b3 & 0x20u) != 0;
+                const uint32_t af_len = has_af ? b4 : 0u;
+                regular = b0 == 0x47u && af_len <= 183u;
+                // the reference's one-step payload skip, entered before the last byte of a packet that ends one
+                // byte past a 16384-byte read, finishes the packet a byte early (xport.c:4302)
+                const bool on_boundary = ((s + 187) & (TS_READ_CHUNK - 1)) == 0;
+                if (on_boundary && pid != 0u && pid != 0x1ffbu && (!has_af || af_len <= 181u))
+                    regular = false;
+            }
+            if (!regular)
+                atomicMin(&s_irregular, (uint32_t)(j - j0));
+        }
+        __syncthreads();
+        const uint32_t stop = s_irregular;  // relative to j0
+        if (have && (uint32_t)(j - j0) < stop && tei == 0) {
+            const uint32_t rel = (uint32_t)j;  // unit number within the launch (a launch takes < 2^32 units)
+            atomicAdd(&s_count[pid], 1u);
+            atomicMin(&s_first[pid], rel);
+            atomicMax(&s_last[pid], rel);
+        }
+        if (stop != kNone)
+            break;  // (uniform: every thread read the same value after the barrier)
+    }
+    __syncthreads();
+    ts_wg_entry *mine = p.lists + (size_t)blockIdx.x * TS_PIDS;
+    for (uint32_t k = t; k < TS_PIDS; k += kBlock) {
+        if (s_count[k]) {
+            const uint32_t at = atomicAdd(&s_entries, 1u);
+            ts_wg_entry e;
+            e.pid = k;
+            e.count = s_count[k];
+            e.first = s_first[k];
+            e.last = s_last[k];
+            mine[at] = e;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        p.list_counts[blockIdx.x] = s_entries;
+        // units of this span in front of its first irregular one (all of them if there is none)
+        p.span_done[blockIdx.x] = s_irregular != kNone ? (uint64_t)s_irregular : (j1 > j0 ? j1 - j0 : 0);
+        p.span_stopped[blockIdx.x] = s_irregular != kNone ? 1u : 0u;
+    }
+}
+
+// One workgroup: fold the tables of the spans up to and including the first that stopped into the stream-wide tables
+// (absolute 1-based packet numbers = packet_base + unit number + 1) and tell the host how many units were taken.
+__global__ __launch_bounds__(kBlock) void ts_merge_kernel(const ts_scan_params p, uint32_t nspans, uint64_t packet_base,
+                                                          uint32_t *__restrict__ g_count,
+                                                          unsigned long long *__restrict__ g_first,
+                                                          unsigned long long *__restrict__ g_last,
+                                                          unsigned long long *__restrict__ taken_out)
+{
+    __shared__ uint32_t s_last_span;
+    if (threadIdx.x == 0) {
+        uint32_t b = 0;
+        unsigned long long taken = 0;
+        for (; b < nspans; b++) {
+            taken += p.span_done[b];
+            if (p.span_stopped[b])
+                break;
+        }
+        s_last_span = b < nspans ? b : nspans - 1;
+        *taken_out = taken;
+    }
+    __syncthreads();
+    const uint32_t last_span = s_last_span;
+    for (uint32_t b = 0; b <= last_span; b++) {
+        const ts_wg_entry *list = p.lists + (size_t)b * TS_PIDS;
+        const uint32_t n = p.list_counts[b];
+        for (uint32_t k = threadIdx.x; k < n; k += kBlock) {  // PIDs are distinct within a list, spans run one after the other
+            const ts_wg_entry e = list[k];
+            g_count[e.pid] += e.count;
+            const unsigned long long f = packet_base + e.first + 1, l = packet_base + e.last + 1;
+            if (g_first[e.pid] == 0 || f < g_first[e.pid])
+                g_first[e.pid] = f;
+            if (l > g_last[e.pid])
+                g_last[e.pid] = l;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void ts_generate_kernel(unsigned char *__restrict__ out, uint64_t nunits, uint32_t unit,
+                                                           uint64_t seed, int hdmv)
+{
+    // one thread per 4 bytes (units are multiples of 4 bytes)
+    const uint64_t words = nunits * (unit / 4);
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (uint64_t)gridDim.x * 256) {
+        const uint64_t k = w / (unit / 4);
+        const uint32_t i = (uint32_t)(w % (unit / 4)) * 4;
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            v |= (uint32_t)ts_synth_byte(seed, k, i + b, hdmv) << (8 * b);
+        reinterpret_cast<uint32_t *>(out)[w] = v;
+    }
+}
+
+void ts_kernels_prepare_device(void)  // function attributes belong to the current device
+{
+    (void)hipFuncSetAttribute((const void *)ts_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              3 * TS_PIDS * (int)sizeof(uint32_t));
+}
+
+void ts_launch_scan(hipStream_t st, int blocks, const ts_scan_params &p)
+{
+    hipLaunchKernelGGL(ts_scan_kernel, dim3(blocks), dim3(kBlock), 3 * TS_PIDS * sizeof(uint32_t), st, p);
+}
+
+void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t nspans, uint64_t packet_base, uint32_t *g_count,
+                     unsigned long long *g_first, unsigned long long *g_last, unsigned long long *taken_out)
+{
+    hipLaunchKernelGGL(ts_merge_kernel, dim3(1), dim3(kBlock), 0, st, p, nspans, packet_base, g_count, g_first, g_last,
+                       taken_out);
+}
+
+void ts_launch_generate(hipStream_t st, void *out, uint64_t nunits, uint32_t unit, uint64_t seed, int hdmv)
+{
+    const uint64_t words = nunits * (unit / 4);
+    const int blocks = (int)((words + 255) / 256 < 16384 ? (words + 255) / 256 : 16384);
+    if (blocks > 0)
+        hipLaunchKernelGGL(ts_generate_kernel, dim3(blocks), dim3(256), 0, st, (unsigned char *)out, nunits, unit, seed, hdmv);
+}

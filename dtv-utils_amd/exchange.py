@@ -1,129 +1,201 @@
-"""The two tiny exchange steps of a sharded papr run, over
-torch.distributed — RCCL ("nccl" backend) between GPUs on xGMI, gloo in the CPU
-tests.  One process per GPU; bulk sample data never leaves its GPU.
+"""The exchange steps of a sharded papr run — ctypes binding of the C ABI's papr_exchange_*
+(include/papr_hip.h; dtv-utils_amd/csrc/papr_exchange.cpp), one process per GPU, bulk sample data never leaves its GPU.
 
-  exchange 1 (after pass 1): all-gather one papr_stats record (96 bytes) per
-      rank, then every rank folds the records in rank (= file) order with
-      papr_stats_merge — arg-extrema with a first-index tie-break are not an
-      RCCL reduction op, and a fixed fold order keeps the double sum identical
-      on every rank.
-  exchange 2 (after pass 2): all-reduce (sum) of the L per-level counters as
-      int64.  Integer, hence exactly order-independent.
+  stats(local)        all-gather of one 96-byte papr_stats per rank + the ordered merge (rank = file order), identical
+                      on every rank; also the sum of the ranks in front of this one
+  counts(c)           all-reduce (sum) of the per-level counters, 64-bit integers
+  exact_sum(program)  all-gather of the shards' exact-sum programs + papr_exact_chain: the reference's sequential sum
 
-Messages are <= ~2.5 KB (latency-bound; link bandwidth is irrelevant), so what
-costs is host<->device hops: buffers are allocated once (pinned on the host
-side), copies are asynchronous, and each exchange ends in ONE stream
-synchronisation.
+Two transports behind the same C code: `Exchange.rccl(gpu)` — RCCL over xGMI: ncclAllGather / ncclAllReduce on the
+context's own HIP stream, device staging, one stream synchronisation per exchange (the 128-byte ncclUniqueId is
+created on rank 0 and handed round with torch.distributed, whatever its backend); `Exchange.over_torch()` — the
+collectives of an initialised torch.distributed group (gloo in the CPU tests) passed in as C callbacks.  Nothing is
+reduced in Python.
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List
+from typing import List, Optional
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
-from . import MAX_LEVELS, Stats, stats_merge
+from . import PaprError, Stats, lib
 
-_STATS_BYTES = C.sizeof(Stats)
+ID_BYTES = 128
+
+
+class ExchangeTiming(C.Structure):
+    _fields_ = [("stats_calls", C.c_uint64), ("counts_calls", C.c_uint64), ("exact_calls", C.c_uint64),
+                ("stats_us", C.c_double), ("counts_us", C.c_double), ("exact_us", C.c_double)]
+
+    def as_dict(self) -> dict:
+        d = {}
+        for kind in ("stats", "counts", "exact"):
+            calls = getattr(self, kind + "_calls")
+            d[kind] = {"calls": int(calls), "us_per_call": (getattr(self, kind + "_us") / calls) if calls else None}
+        return d
+
+
+_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t)
+
+
+class _Ops(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("allgather", _ALLGATHER), ("allreduce_sum_u64", _ALLREDUCE)]
+
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    L = lib()
+    if not _bound:
+        vp, i32 = C.c_void_p, C.c_int
+        L.papr_exchange_unique_id.argtypes = [vp]
+        L.papr_exchange_open_rccl.argtypes = [C.POINTER(vp), vp, vp, i32, i32]
+        L.papr_exchange_open_ops.argtypes = [C.POINTER(vp), C.POINTER(_Ops), i32, i32]
+        L.papr_exchange_close.argtypes = [vp]
+        L.papr_exchange_close.restype = None
+        L.papr_exchange_last_error.argtypes = [vp]
+        L.papr_exchange_last_error.restype = C.c_char_p
+        L.papr_exchange_stats.argtypes = [vp, C.POINTER(Stats), C.POINTER(Stats), C.POINTER(C.c_double), vp]
+        L.papr_exchange_counts.argtypes = [vp, vp, i32]
+        L.papr_exchange_exact_sum.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_double)]
+        L.papr_exchange_get_timing.argtypes = [vp, C.POINTER(ExchangeTiming), i32]
+        for name in ("papr_exchange_unique_id", "papr_exchange_open_rccl", "papr_exchange_open_ops", "papr_exchange_stats",
+                     "papr_exchange_counts", "papr_exchange_exact_sum", "papr_exchange_get_timing"):
+            getattr(L, name).restype = i32
+        _bound = True
+    return L
+
+
+ABI_SYMBOLS = ("papr_exchange_unique_id", "papr_exchange_open_rccl", "papr_exchange_open_ops", "papr_exchange_close",
+               "papr_exchange_last_error", "papr_exchange_stats", "papr_exchange_counts", "papr_exchange_exact_sum",
+               "papr_exchange_get_timing")
 
 
 class Exchange:
-    """Pre-allocated buffers for the two exchanges on one device / process group."""
+    """One papr_exchange: this process's end of the exchanges of a sharded run."""
 
-    def __init__(self, device: torch.device, group=None):
-        self.device = torch.device(device)
-        self.group = group
-        self.active = dist.is_initialized()
-        self.world = dist.get_world_size(group) if self.active else 1
-        self.cuda = self.device.type == "cuda"
-        if not self.active:
-            return
+    def __init__(self, handle, rank: int, world: int, transport: str, keep=None):
+        self._L = _lib()
+        self._x = handle
+        self.rank, self.world, self.transport = rank, world, transport
+        self._keep = keep   # callbacks / contexts that must outlive the handle
 
-        def host(n, dtype):
-            t = torch.empty(n, dtype=dtype)
-            return t.pin_memory() if self.cuda else t
+    # ---- constructors ----
+    @classmethod
+    def single(cls) -> "Exchange":
+        """world size 1: every exchange is the identity (no transport is touched)."""
+        L = _lib()
+        x = C.c_void_p()
+        rc = L.papr_exchange_open_ops(C.byref(x), None, 0, 1)
+        if rc:
+            raise PaprError(rc, "papr_exchange_open_ops", L.papr_exchange_last_error(None).decode())
+        return cls(x, 0, 1, "none")
 
-        self.h_rec = host(_STATS_BYTES, torch.uint8)
-        self.h_all = host(self.world * _STATS_BYTES, torch.uint8)
-        self.d_rec = torch.empty(_STATS_BYTES, dtype=torch.uint8, device=self.device)
-        self.d_all = torch.empty(self.world * _STATS_BYTES, dtype=torch.uint8, device=self.device)
-        self.h_cnt = host(MAX_LEVELS, torch.int64)
-        self.d_cnt = torch.empty(MAX_LEVELS, dtype=torch.int64, device=self.device)
+    @classmethod
+    def rccl(cls, gpu, rank: int, world: int, group=None) -> "Exchange":
+        """RCCL communicator over the ranks of an initialised torch.distributed group (used only to hand the
+        ncclUniqueId round); the collectives run on `gpu`'s own stream inside libpaprhip."""
+        import torch.distributed as dist
+        L = _lib()
+        uid = bytearray(ID_BYTES)
+        if rank == 0:
+            buf = (C.c_ubyte * ID_BYTES)()
+            rc = L.papr_exchange_unique_id(buf)
+            if rc:
+                raise PaprError(rc, "papr_exchange_unique_id", L.papr_exchange_last_error(None).decode())
+            uid = bytearray(buf)
+        if world > 1 or dist.is_initialized():
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = bytearray(box[0])
+        x = C.c_void_p()
+        raw = (C.c_ubyte * ID_BYTES).from_buffer(uid)
+        rc = L.papr_exchange_open_rccl(C.byref(x), gpu._ctx, raw, rank, world)
+        if rc:
+            raise PaprError(rc, "papr_exchange_open_rccl", L.papr_exchange_last_error(None).decode())
+        return cls(x, rank, world, "RCCL", keep=gpu)
 
-    def _sync(self):
-        if self.cuda:
-            torch.cuda.current_stream(self.device).synchronize()
+    @classmethod
+    def over_torch(cls, group=None) -> "Exchange":
+        """The same C exchange code over the collectives of a torch.distributed group (CPU tensors: gloo)."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
 
-    def allgather_stats(self, local: Stats) -> List[Stats]:
-        """Every rank's pass-1 record, in rank order."""
-        if not self.active:
-            return [local]
-        self.h_rec.numpy()[:] = np.frombuffer(local.to_bytes(), dtype=np.uint8)
-        self.d_rec.copy_(self.h_rec, non_blocking=True)
-        dist.all_gather_into_tensor(self.d_all, self.d_rec, group=self.group)
-        self.h_all.copy_(self.d_all, non_blocking=True)
-        self._sync()
-        flat = self.h_all.numpy()
-        return [Stats.from_bytes(flat[r * _STATS_BYTES:(r + 1) * _STATS_BYTES].tobytes()) for r in range(self.world)]
+        def allgather(_user, send, recv, nbytes):
+            try:
+                mine = torch.frombuffer((C.c_ubyte * nbytes).from_address(send), dtype=torch.uint8).clone()
+                out = torch.empty(world * nbytes, dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, mine, group=group)
+                C.memmove(recv, out.numpy().ctypes.data, world * nbytes)
+                return 0
+            except Exception:   # an exception must not unwind through the C frames
+                return 1
+
+        def allreduce(_user, buf, count):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(count,))
+                t = torch.from_numpy(a.astype(np.int64))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                a[:] = t.numpy().astype(np.uint64)
+                return 0
+            except Exception:
+                return 1
+
+        ops = _Ops(None, _ALLGATHER(allgather), _ALLREDUCE(allreduce))
+        L = _lib()
+        x = C.c_void_p()
+        rc = L.papr_exchange_open_ops(C.byref(x), C.byref(ops), rank, world)
+        if rc:
+            raise PaprError(rc, "papr_exchange_open_ops", L.papr_exchange_last_error(None).decode())
+        return cls(x, rank, world, "gloo", keep=ops)
+
+    def close(self):
+        if self._x:
+            self._L.papr_exchange_close(self._x)
+            self._x = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int, what: str):
+        if rc:
+            raise PaprError(rc, what, self._L.papr_exchange_last_error(self._x).decode())
+
+    # ---- the exchanges ----
+    def stats(self, local: Stats):
+        """(total, sum of the ranks in front of this one, [every rank's record])."""
+        total, before = Stats(), C.c_double()
+        every = (Stats * self.world)()
+        self._chk(self._L.papr_exchange_stats(self._x, C.byref(local), C.byref(total), C.byref(before), every),
+                  "papr_exchange_stats")
+        return total, before.value, list(every)
 
     def merged_stats(self, local: Stats) -> Stats:
-        """Exchange 1: the whole file's pass-1 result, identical on every rank."""
-        return stats_merge(self.allgather_stats(local))
+        return self.stats(local)[0]
 
-    def allgather_bytes(self, blob: bytes) -> List[bytes]:
-        """Variable-size byte strings from every rank, in rank order (exact-sum programs:
-        ~0.1-2 MB each).  Two collectives: sizes, then the padded payload."""
-        if not self.active:
-            return [blob]
-        size = torch.tensor([len(blob)], dtype=torch.int64, device=self.device)
-        sizes = torch.empty(self.world, dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(sizes, size, group=self.group)
-        sizes = sizes.cpu().tolist()
-        cap = max(max(sizes), 1)
-        mine = torch.zeros(cap, dtype=torch.uint8)
-        mine[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
-        mine = mine.to(self.device)
-        allb = torch.empty(self.world * cap, dtype=torch.uint8, device=self.device)
-        dist.all_gather_into_tensor(allb, mine, group=self.group)
-        flat = allb.cpu().numpy()
-        return [flat[r * cap:r * cap + sizes[r]].tobytes() for r in range(self.world)]
+    def counts(self, counts: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(counts, dtype=np.uint64).copy()
+        self._chk(self._L.papr_exchange_counts(self._x, a.ctypes.data_as(C.c_void_p), a.size), "papr_exchange_counts")
+        return a
 
-    def allreduce_counts(self, counts: np.ndarray) -> np.ndarray:
-        """Exchange 2: per-level counts summed over all shards."""
-        n = int(counts.size)
-        if not self.active or n == 0:
-            return counts.astype(np.uint64, copy=True)
-        self.h_cnt.numpy()[:n] = counts.astype(np.int64, copy=False)
-        d = self.d_cnt[:n]
-        d.copy_(self.h_cnt[:n], non_blocking=True)
-        dist.all_reduce(d, op=dist.ReduceOp.SUM, group=self.group)
-        self.h_cnt[:n].copy_(d, non_blocking=True)
-        self._sync()
-        return self.h_cnt.numpy()[:n].astype(np.uint64)
+    def exact_sum(self, program: bytes) -> float:
+        out = C.c_double()
+        buf = C.create_string_buffer(program, len(program))
+        self._chk(self._L.papr_exchange_exact_sum(self._x, buf, len(program), C.byref(out)), "papr_exchange_exact_sum")
+        return out.value
 
-
-_cache: Dict[tuple, Exchange] = {}
-
-
-def _get(device, group) -> Exchange:
-    key = (str(device), id(group), dist.is_initialized())
-    if key not in _cache:
-        _cache[key] = Exchange(device, group)
-    return _cache[key]
-
-
-def allgather_stats(local: Stats, device, group=None) -> List[Stats]:
-    return _get(device, group).allgather_stats(local)
-
-
-def merged_stats(local: Stats, device, group=None) -> Stats:
-    return _get(device, group).merged_stats(local)
-
-
-def allreduce_counts(counts: np.ndarray, device, group=None) -> np.ndarray:
-    return _get(device, group).allreduce_counts(counts)
+    def timing(self, reset: bool = False) -> ExchangeTiming:
+        t = ExchangeTiming()
+        self._chk(self._L.papr_exchange_get_timing(self._x, C.byref(t), int(reset)), "papr_exchange_get_timing")
+        return t
 
 
 def shard_range(nsamples: int, rank: int, world: int, align: int = 8192):

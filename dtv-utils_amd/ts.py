@@ -1,0 +1,168 @@
+"""ctypes binding of the transport-stream packet scan in libpaprhip.so (include/ts_hip.h) for tests and bench.py.
+
+Plumbing only, like the papr binding in __init__.py: nothing is computed here and there is no fallback — without the
+HIP library or a GPU the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import PaprError, lib
+
+PIDS = 0x2000
+MAX_SYNC_ERRORS = 4096
+
+ABI_SYMBOLS = ("ts_walk_init", "ts_walk_is_clean", "ts_walk", "ts_format_report", "ts_hip_open", "ts_hip_close",
+               "ts_hip_last_error", "ts_hip_upload", "ts_hip_load_file", "ts_hip_adopt", "ts_hip_generate",
+               "ts_hip_download", "ts_hip_scan")
+
+
+class SyncError(C.Structure):
+    _fields_ = [("skipped", C.c_uint64), ("at_packet", C.c_uint64)]
+
+
+class ScanResult(C.Structure):
+    """ts_scan_result (include/ts_hip.h)."""
+    _fields_ = [("packets", C.c_uint64), ("count", C.c_uint32 * PIDS), ("first", C.c_uint64 * PIDS),
+                ("last", C.c_uint64 * PIDS), ("nsync_errors", C.c_uint64), ("sync_errors", SyncError * MAX_SYNC_ERRORS),
+                ("bytes", C.c_uint64), ("gpu_packets", C.c_uint64), ("launches", C.c_uint32), ("walks", C.c_uint32),
+                ("kernel_ms", C.c_double)]
+
+    def report(self) -> bytes:
+        """The reference's report lines (ts_format_report)."""
+        buf = C.create_string_buffer(1 << 20)
+        n = _lib().ts_format_report(C.byref(self), buf, len(buf))
+        return buf.raw[:n]
+
+    def tables(self):
+        return (np.ctypeslib.as_array(self.count).copy(), np.ctypeslib.as_array(self.first).copy(),
+                np.ctypeslib.as_array(self.last).copy())
+
+    def sync_error_list(self):
+        return [(int(self.sync_errors[k].skipped), int(self.sync_errors[k].at_packet))
+                for k in range(min(int(self.nsync_errors), MAX_SYNC_ERRORS))]
+
+
+class WalkState(C.Structure):
+    _fields_ = [("pos", C.c_uint64), ("skipped", C.c_uint64), ("stale_af", C.c_uint32), ("extra_pending", C.c_uint32),
+                ("hdmv", C.c_int)]
+
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    L = lib()
+    if not _bound:
+        vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+        L.ts_walk_init.argtypes = [C.POINTER(WalkState), i32]
+        L.ts_walk_init.restype = None
+        L.ts_walk_is_clean.argtypes = [C.POINTER(WalkState)]
+        L.ts_walk_is_clean.restype = i32
+        L.ts_walk.argtypes = [C.POINTER(WalkState), vp, u64, u64, i32, u64, C.POINTER(ScanResult)]
+        L.ts_walk.restype = u64
+        L.ts_format_report.argtypes = [C.POINTER(ScanResult), C.c_char_p, C.c_size_t]
+        L.ts_format_report.restype = C.c_size_t
+        L.ts_hip_open.argtypes = [C.POINTER(vp), i32]
+        L.ts_hip_close.argtypes = [vp]
+        L.ts_hip_close.restype = None
+        L.ts_hip_last_error.argtypes = [vp]
+        L.ts_hip_last_error.restype = C.c_char_p
+        L.ts_hip_upload.argtypes = [vp, vp, u64]
+        L.ts_hip_load_file.argtypes = [vp, C.c_char_p]
+        L.ts_hip_adopt.argtypes = [vp, vp, u64]
+        L.ts_hip_generate.argtypes = [vp, u64, u64, i32]
+        L.ts_hip_download.argtypes = [vp, vp, u64, u64]
+        L.ts_hip_scan.argtypes = [vp, i32, C.POINTER(ScanResult)]
+        for name in ("ts_hip_open", "ts_hip_upload", "ts_hip_load_file", "ts_hip_adopt", "ts_hip_generate",
+                     "ts_hip_download", "ts_hip_scan"):
+            getattr(L, name).restype = i32
+        _bound = True
+    return L
+
+
+def walk(data: bytes, hdmv: bool = False, window: int = None, rng=None) -> ScanResult:
+    """The host walker alone over a whole stream (GPU-free; what ts_hip_scan uses across irregular packets).  With
+    `window` the stream is fed in windows of random size < window, as the runtime feeds it."""
+    L = _lib()
+    st, res = WalkState(), ScanResult()
+    L.ts_walk_init(C.byref(st), int(hdmv))
+    a = np.frombuffer(data, dtype=np.uint8)
+    n = a.size
+    if window is None:
+        L.ts_walk(C.byref(st), a.ctypes.data if n else None, 0, n, 1, 2 ** 64 - 1, C.byref(res))
+        return res
+    for _ in range(10 ** 7):
+        base = st.pos
+        w = min(n - base, int(rng.integers(189, window)))
+        eof = int(base + w >= n)
+        sub = a[base:base + w]
+        L.ts_walk(C.byref(st), sub.ctypes.data if w else None, base, w, eof, int(rng.integers(0, 5)), C.byref(res))
+        if eof and (st.pos >= n or st.pos == base):
+            if st.pos < n:
+                L.ts_walk(C.byref(st), a[st.pos:].ctypes.data, st.pos, n - st.pos, 1, 2 ** 64 - 1, C.byref(res))
+            return res
+    raise RuntimeError("ts_walk made no progress")
+
+
+class TsHip:
+    """One ts_hip_ctx: one GPU, one transport stream resident in HBM."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib()
+        self._ctx = C.c_void_p()
+        rc = self._L.ts_hip_open(C.byref(self._ctx), device)
+        if rc:
+            detail = self._L.ts_hip_last_error(None).decode()
+            self._ctx = C.c_void_p()
+            raise PaprError(rc, "ts_hip_open", detail)
+        self._keepalive = None
+
+    def close(self):
+        if self._ctx:
+            self._L.ts_hip_close(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int, what: str):
+        if rc:
+            raise PaprError(rc, what, self._L.ts_hip_last_error(self._ctx).decode())
+
+    def upload(self, data: bytes):
+        a = np.frombuffer(data, dtype=np.uint8)
+        self._chk(self._L.ts_hip_upload(self._ctx, a.ctypes.data if a.size else None, a.size), "ts_hip_upload")
+
+    def load_file(self, path: str):
+        self._chk(self._L.ts_hip_load_file(self._ctx, os.fsencode(path)), "ts_hip_load_file")
+
+    def adopt(self, device_ptr: int, nbytes: int, keepalive=None):
+        self._chk(self._L.ts_hip_adopt(self._ctx, C.c_void_p(device_ptr), nbytes), "ts_hip_adopt")
+        self._keepalive = keepalive
+
+    def generate(self, npackets: int, seed: int = 0x7500001, hdmv: bool = False):
+        self._chk(self._L.ts_hip_generate(self._ctx, seed, npackets, int(hdmv)), "ts_hip_generate")
+
+    def download(self, first: int, nbytes: int) -> bytes:
+        out = np.empty(nbytes, dtype=np.uint8)
+        self._chk(self._L.ts_hip_download(self._ctx, out.ctypes.data if nbytes else None, first, nbytes), "ts_hip_download")
+        return out.tobytes()
+
+    def scan(self, hdmv: bool = False) -> ScanResult:
+        res = ScanResult()
+        self._chk(self._L.ts_hip_scan(self._ctx, int(hdmv), C.byref(res)), "ts_hip_scan")
+        return res

@@ -1,0 +1,108 @@
+/*
+ * ts_hip.h — C ABI of the MI355X (gfx950) transport-stream packet scan in libpaprhip.so: sync lock, per-PID packet
+ * count and first / last packet number of an MPEG-2 transport stream (188-byte packets, or 192-byte HDMV packets).
+ *
+ * It replaces the scan inside drmpeg/dtv-utils xport.c — which, like papr.c, has no library surface: the scan is
+ * inline in main() and demux_mpeg2_transport() — for the report `xport -p` ends with:
+ *
+ *   reference xport.c                                            this ABI
+ *   -----------------------------------------------------------  ------------------------------------------
+ *   :241-244   while (!feof) fread 16384 -> demux (the read loop)  ts_hip_load_file / _upload / _adopt / _generate
+ *   :4317-4373 sync acquisition, `Transport Sync Error` events     ts_hip_scan -> ts_scan_result.sync_errors
+ *   :2844-2867 header parse, packet_counter, pid_counter[pid]++,   ts_hip_scan -> .packets, .count, .first, .last
+ *              pid_first_packet / pid_last_packet
+ *   :245-250   printf("packets for pid ...")                       stays in the caller (ts_format_report is the
+ *                                                                  reference's format, for tests and tools)
+ *
+ * Scope: the lines above as `xport -ps[h] <file> <program no PAT announces> <v> <a>` prints them — no demultiplexing,
+ * no PSI / PES parsing, no continuity-counter or PCR output.  Within that scope the result is the reference's bit for
+ * bit, including what its 16384-byte read loop does to a packet that ends exactly one byte past a read
+ * (xport.c:4302 `>=`): positions are therefore FILE offsets, and a stream must be scanned from its first byte.
+ * Streams that carry a complete ATSC Master Guide Table on PID 0x1ffb are outside the domain (the reference starts
+ * parsing further PIDs then).
+ *
+ * How: packets at a fixed stride from a known sync position are independent, so the GPU takes every stretch of
+ * "regular" packets (sync byte in place, whole, legal adaptation field, not on the read-boundary quirk) in one launch
+ * — each lane one packet header; per-workgroup LDS tables of count / first / last, committed only for the workgroups
+ * in front of the first irregular packet — and a closed-form host walker (ts_walk, plain C, exported and tested
+ * without a GPU) carries the scan across the irregular ones: sync loss, false sync bytes, malformed adaptation
+ * fields, the truncated tail, the read-boundary quirk.  Speculation decides how many launches are made, never a
+ * number in the result.
+ *
+ * Conventions as in papr_hip.h: plain C types, 0 or a negative PAPR_E_* code, no CPU fallback.
+ */
+#ifndef TS_HIP_H
+#define TS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TS_PIDS 0x2000
+#define TS_MAX_SYNC_ERRORS 4096
+#define TS_READ_CHUNK 16384u /* xport.c:70 `static unsigned char buffer[16384]` */
+
+typedef struct ts_sync_error {
+    uint64_t skipped;   /* bytes passed over before the stream locked again (xport.c prints it with %d) */
+    uint64_t at_packet; /* packet_counter at that moment */
+} ts_sync_error;
+
+typedef struct ts_scan_result {
+    uint64_t packets;          /* packet_counter (xport.c:34) */
+    uint32_t count[TS_PIDS];   /* pid_counter: unsigned int, wraps like the reference's */
+    uint64_t first[TS_PIDS];   /* pid_first_packet: 1-based packet number, 0 = PID never seen */
+    uint64_t last[TS_PIDS];    /* pid_last_packet */
+    uint64_t nsync_errors;     /* `Transport Sync Error` lines the reference prints; the first TS_MAX_SYNC_ERRORS are kept */
+    ts_sync_error sync_errors[TS_MAX_SYNC_ERRORS];
+    /* how the scan went (not part of the reference's output) */
+    uint64_t bytes;            /* stream length */
+    uint64_t gpu_packets;      /* packets counted by the GPU launches (the rest: the host walker) */
+    uint32_t launches;         /* scan-kernel launches */
+    uint32_t walks;            /* hand-overs to the host walker */
+    double kernel_ms;          /* sum of the scan kernels' durations (HIP events) */
+} ts_scan_result;
+
+/* ---- the host walker: the scan's exact state between packets, and one step of it (GPU-free) ---------------------- */
+typedef struct ts_walk_state {
+    uint64_t pos;           /* file offset of the next byte to look at; the stream is out of sync there */
+    uint64_t skipped;       /* bytes skipped so far in the current sync search (skipped_bytes) */
+    uint32_t stale_af;      /* adaptation-field bytes a malformed field still owes: taken from the next packet's payload */
+    uint32_t extra_pending; /* HDMV: tp_extra_header bytes still to swallow before a sync byte is looked for */
+    int hdmv;
+} ts_walk_state;
+
+void ts_walk_init(ts_walk_state *st, int hdmv);
+/* 1 if a GPU launch may take over at st->pos: nothing pending from earlier packets (a "clean" position) */
+int ts_walk_is_clean(const ts_walk_state *st);
+/* Walk `data` = file bytes [base, base + n) (base + n = end of what is available; `eof` says whether that is the
+ * end of the stream) from st->pos, packet by packet, adding to `res`, until st->pos is clean again AND at least
+ * `min_packets` packets were taken (or the data runs out).  Stops early — returning 0 — when the next packet might
+ * reach past the window and eof == 0: the caller then supplies a window further on.  Returns the packets taken. */
+uint64_t ts_walk(ts_walk_state *st, const unsigned char *data, uint64_t base, uint64_t n, int eof, uint64_t min_packets,
+                 ts_scan_result *res);
+/* the report lines of the reference for a result (xport.c:245-250 and :4326 / :4364); returns the bytes written
+ * (excluding the terminating NUL), at most cap - 1 */
+size_t ts_format_report(const ts_scan_result *res, char *buf, size_t cap);
+
+/* ---- GPU scan -------------------------------------------------------------------------------------------------- */
+typedef struct ts_hip_ctx ts_hip_ctx;
+
+int ts_hip_open(ts_hip_ctx **ctx, int device);
+void ts_hip_close(ts_hip_ctx *ctx);
+const char *ts_hip_last_error(const ts_hip_ctx *ctx);
+/* the stream: copied from host memory, read from a file (whole file), caller-owned device memory, or synthetic */
+int ts_hip_upload(ts_hip_ctx *ctx, const void *bytes, uint64_t nbytes);
+int ts_hip_load_file(ts_hip_ctx *ctx, const char *path);
+int ts_hip_adopt(ts_hip_ctx *ctx, void *device_bytes, uint64_t nbytes);
+/* fill the stream with `npackets` synthetic packets of include/ts_synth.h (hdmv != 0: 192-byte units) */
+int ts_hip_generate(ts_hip_ctx *ctx, uint64_t seed, uint64_t npackets, int hdmv);
+int ts_hip_download(ts_hip_ctx *ctx, void *bytes, uint64_t first, uint64_t nbytes);
+int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TS_HIP_H */

@@ -1,10 +1,12 @@
-"""The N>1 path on CPU: two processes over gloo run the same exchange code
-bench.py uses over RCCL (dtv-utils_amd/exchange.py).  Per-shard records come
-from the oracle here (no GPU in this tier); what is under test is the
-sharding rule, the all-gather + ordered merge and the count all-reduce."""
+"""The N>1 path on CPU: 2, 4 and 8 processes over gloo run the exchange code of the C ABI (papr_exchange_* in
+libpaprhip.so, include/papr_hip.h) — the very functions bench.py and a one-process-per-GPU C caller use over RCCL —
+with torch.distributed's gloo collectives plugged in as the transport.  Per-shard records come from the oracle here
+(no GPU in this tier); what is under test is the sharding rule, the all-gather + ordered merge (and the "sum of the
+ranks in front"), the count all-reduce and the all-gather + chain of exact-sum programs."""
 import ctypes as C
 import os
 import socket
+import struct
 import sys
 
 import numpy as np
@@ -22,6 +24,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _raw_program(floats: np.ndarray) -> bytes:
+    """A valid exact-sum program (papr_exact_format.h) that carries a shard as its raw tail / raw tiles only:
+    header + zero groups + the samples, added one by one by papr_exact_chain exactly as papr.c:104 adds them."""
+    n = floats.size // 2
+    assert n < 2048, "helper for small shards: everything travels as the < 1 tile tail"
+    header = struct.pack("<IIQQQIIII", 0x31535850, 1, n, 0, 0, n, 0, 0, 0)
+    return header + floats.astype(np.float32).tobytes()
+
+
 def _worker(rank, world, port, name, graph, out_dir):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -31,9 +42,11 @@ def _worker(rank, world, port, name, graph, out_dir):
     from dtv_utils_amd import exchange
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        x = exchange.Exchange.over_torch()
+        assert (x.rank, x.world, x.transport) == (rank, world, "gloo")
         floats = np.fromfile(golden_path(name), dtype=np.float32)
         n = floats.size // 2
-        first, count = exchange.shard_range(n, rank, world, align=8192)
+        first, count = exchange.shard_range(n, rank, world, align=8192 if n >= 8192 * world else 2)
         shard = floats[2 * first:2 * (first + count)]
         r = orc.run_mem(shard, graph)
         local = pkg.Stats()
@@ -42,26 +55,57 @@ def _worker(rank, world, port, name, graph, out_dir):
         for k in ("peak", "re_pos", "re_neg", "im_pos", "im_neg"):
             setattr(local, k, r[k])
             setattr(local, k + "_idx", r[k + "_idx"] + first if r[k] != 0 else 0)
-        dev = torch.device("cpu")
-        total = exchange.merged_stats(local, dev)
+        total, before, every = x.stats(local)
+        assert len(every) == world and every[rank].to_bytes() == local.to_bytes()
+        assert before == float(sum(e.sum for e in every[:rank]))          # (left-to-right, as the merge adds)
         mean, papr, table = pkg.levels(total, graph)
-        counts = exchange.allreduce_counts(orc.count_mem(shard, table).astype(np.uint64), dev)
-        blobs = exchange.Exchange(dev).allgather_bytes(bytes([rank + 1]) * (1000 * rank + 3))
-        assert blobs == [bytes([r + 1]) * (1000 * r + 3) for r in range(world)]
+        counts = x.counts(orc.count_mem(shard, table).astype(np.uint64))
         text = pkg.format_report(total, mean, papr, counts, graph)
         with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
             f.write(text)
+        # exact-sum programs of different sizes, gathered and chained in rank order: the sequential sum of the
+        # concatenation (here: the first 1500 samples of the fixture cut into `world` pieces)
+        m = min(n, 1500)
+        a, b = exchange.shard_range(m, rank, world, align=2)
+        seq = x.exact_sum(_raw_program(floats[2 * a:2 * (a + b)]))
+        assert seq == orc.run_mem(floats[:2 * m], False)["sum"], "chained sum differs from the sequential sum"
+        t = x.timing().as_dict()
+        assert t["stats"]["calls"] == 1 and t["counts"]["calls"] == 1 and t["exact"]["calls"] == 1
+        x.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,graph", [("g1m", False), ("g1m", True), ("ties", False), ("spike20k", True)])
-def test_two_rank_exchange_reproduces_reference_stdout(tmp_path, name, graph):
-    world = 2
+@pytest.mark.parametrize("world,name,graph", [(2, "g1m", False), (2, "g1m", True), (2, "ties", False), (2, "spike20k", True),
+                                              (4, "g1m", True), (8, "g1m", False), (3, "ofdm_dvbt", True)])
+def test_exchange_over_gloo_reproduces_reference_stdout(tmp_path, world, name, graph):
     mp.spawn(_worker, args=(world, _free_port(), name, graph, str(tmp_path)), nprocs=world, join=True)
     want = open(os.path.join(ROOT, "tests", "golden", f"{name}.{'graph' if graph else 'default'}.txt")).read()
     for rank in range(world):
         assert open(tmp_path / f"rank{rank}.txt").read() == want, f"rank {rank}"
+
+
+def test_single_rank_exchange_is_the_identity(pkg):
+    from dtv_utils_amd import exchange
+    x = exchange.Exchange.single()
+    local = pkg.Stats()
+    pkg.lib().papr_stats_init(C.byref(local))
+    local.sum, local.n, local.peak, local.peak_idx = 12.5, 10, 3.0, 7
+    total, before, every = x.stats(local)
+    assert total.to_bytes() == local.to_bytes() and before == 0.0 and len(every) == 1
+    c = np.array([5, 4, 3], dtype=np.uint64)
+    assert np.array_equal(x.counts(c), c)
+    assert x.exact_sum(_raw_program(np.array([1, 0, 0, 2, 3, 4], dtype=np.float32))) == 1.0 + 4.0 + 25.0
+    with pytest.raises(pkg.PaprError):
+        x.exact_sum(b"not a program")
+    x.close()
+
+
+def test_library_exports_the_exchange_abi(pkg):
+    from dtv_utils_amd import exchange
+    L = exchange._lib()
+    for name in exchange.ABI_SYMBOLS:
+        assert hasattr(L, name), name
 
 
 def test_shard_range_covers_axis_without_overlap(pkg):

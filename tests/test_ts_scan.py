@@ -1,0 +1,154 @@
+"""The transport-stream packet scan (include/ts_hip.h).
+
+CPU tier: the closed-form host walker (dtv-utils_amd/csrc/ts_host.c — product code: what ts_hip_scan runs across
+irregular packets) against the recorded lines of the real reference and against the byte-wise oracle on random
+damaged streams, whole and fed in windows; the library exports every symbol include/ts_hip.h declares.
+GPU tier: ts_hip_scan through the C ABI against the same goldens / oracle, the synthetic bench stream against the
+host generator, and the hand-over between GPU launches and the walker."""
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ts_oracle  # noqa: E402
+import ts_streams  # noqa: E402
+from test_ts_oracle import MANIFEST, golden_lines, random_stream_kwargs  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ts(pkg):
+    from dtv_utils_amd import ts as mod
+    return mod
+
+
+def test_library_exports_every_symbol_of_ts_hip_h(ts):
+    header = open(os.path.join(ROOT, "include", "ts_hip.h")).read()
+    declared = set(re.findall(r"\b(ts_(?:hip_|walk|format)\w*)\s*\(", header))
+    assert declared == set(ts.ABI_SYMBOLS), declared ^ set(ts.ABI_SYMBOLS)
+    L = ts._lib()
+    for name in ts.ABI_SYMBOLS:
+        assert hasattr(L, name), name
+
+
+@pytest.mark.parametrize("name", sorted(ts_streams.FIXTURES))
+def test_walker_reproduces_reference_lines(ts, name):
+    data = ts_streams.fixture_bytes(name)
+    assert hashlib.sha256(data).hexdigest() == MANIFEST[name]["sha256"]
+    hd = ts_streams.is_hdmv(name)
+    assert ts.walk(data, hd).report() == golden_lines(name)
+    assert ts.walk(data, hd, window=3000, rng=np.random.default_rng(3)).report() == golden_lines(name)
+
+
+def test_walker_equals_oracle_on_random_damaged_streams(ts):
+    rng = np.random.default_rng(99)
+    for t in range(150):
+        kw = random_stream_kwargs(t, rng)
+        data = ts_streams.make_stream(**kw)
+        want = ts_oracle.report_lines(ts_oracle.scan_mem(data, kw["hdmv"]))
+        assert ts.walk(data, kw["hdmv"]).report() == want, kw
+        assert ts.walk(data, kw["hdmv"], window=int(rng.integers(400, 40000)), rng=rng).report() == want, kw
+
+
+def test_synthetic_stream_is_pinned_and_regular(tmp_path):
+    """include/ts_synth.h through oracle/mkts: fixed bytes, and a stream the reference reads without a single
+    sync error or continuity complaint."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "mkts"])
+    path = str(tmp_path / "s.ts")
+    subprocess.check_call([os.path.join(ROOT, "oracle", "mkts"), path, "20000"])
+    data = open(path, "rb").read()
+    assert len(data) == 20000 * 188 and hashlib.sha256(data).hexdigest() == \
+        "5d2c099c6bcb7696b86137cddc499d84bde9d0f3134ea1395d42ad0a4681e7ac"
+    res = ts_oracle.scan_mem(data)
+    assert res["packets"] == 20000 and res["nsync_errors"] == 0
+    if os.path.exists(ts_oracle.REF_CLI):
+        p = subprocess.run([ts_oracle.REF_CLI, "-ps", path, ts_oracle.REF_PROGRAM, "1", "1"], capture_output=True)
+        assert b"Discontinuity" not in p.stdout and b"Sync Error" not in p.stdout
+        assert ts_oracle.filter_lines(p.stdout) == ts_oracle.report_lines(res)
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def gpu(ts):
+    g = ts.TsHip(0)
+    yield g
+    g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(ts_streams.FIXTURES))
+def test_scan_reproduces_reference_lines(ts, gpu, name):
+    data = ts_streams.fixture_bytes(name)
+    gpu.upload(data)
+    res = gpu.scan(ts_streams.is_hdmv(name))
+    assert res.report() == golden_lines(name)
+    assert res.bytes == len(data) and res.packets == ts_oracle.scan_mem(data, ts_streams.is_hdmv(name))["packets"]
+
+
+@pytest.mark.gpu
+def test_scan_equals_oracle_on_random_damaged_streams(ts, gpu):
+    rng = np.random.default_rng(4242)
+    for t in range(120):
+        kw = random_stream_kwargs(t, rng)
+        kw["npackets"] = int(kw["npackets"] * rng.choice([1, 1, 8, 40]))   # some streams long enough for every workgroup
+        data = ts_streams.make_stream(**kw)
+        ref = ts_oracle.scan_mem(data, kw["hdmv"])
+        gpu.upload(data)
+        res = gpu.scan(kw["hdmv"])
+        assert res.report() == ts_oracle.report_lines(ref), kw
+        cnt, first, last = res.tables()
+        assert res.packets == ref["packets"] and np.array_equal(cnt, ref["count"]) and \
+            np.array_equal(first, ref["first"]) and np.array_equal(last, ref["last"]), kw
+        assert res.sync_error_list() == ref["sync_errors"][:ts.MAX_SYNC_ERRORS]
+
+
+@pytest.mark.gpu
+def test_scan_of_the_synthetic_stream_and_handover_counts(ts, gpu, tmp_path):
+    """The bench stream generated ON the device equals the host generator's bytes; a regular stream is one launch
+    and no walk; one inserted byte costs one walk and one more launch, not a rescan."""
+    n = 300000
+    gpu.generate(n)
+    path = str(tmp_path / "s.ts")
+    subprocess.check_call([os.path.join(ROOT, "oracle", "mkts"), path, str(n)])
+    host = open(path, "rb").read()
+    assert gpu.download(0, n * 188) == host
+    res = gpu.scan()
+    ref = ts_oracle.scan_mem(host)
+    assert res.report() == ts_oracle.report_lines(ref) and res.packets == n
+    assert res.launches == 1 and res.walks == 0 and res.gpu_packets == n
+    gpu.generate(1000, hdmv=True)
+    subprocess.check_call([os.path.join(ROOT, "oracle", "mkts"), path, "1000", "--hdmv"])
+    host_h = open(path, "rb").read()
+    assert gpu.download(0, 192000) == host_h
+    assert gpu.scan(hdmv=True).report() == ts_oracle.report_lines(ts_oracle.scan_mem(host_h, True))
+    damaged = host[:188 * 1234] + b"\x00" + host[188 * 1234:]
+    gpu.upload(damaged)
+    res = gpu.scan()
+    assert res.report() == ts_oracle.report_lines(ts_oracle.scan_mem(damaged))
+    assert res.sync_error_list() == [(1, 1234)] and res.launches == 2 and res.walks == 1
+    assert res.gpu_packets >= n - 4
+    # file ingest and caller-owned device memory
+    gpu.load_file(path)
+    assert gpu.scan(hdmv=True).report() == ts_oracle.report_lines(ts_oracle.scan_mem(host_h, True))
+    with pytest.raises(Exception):
+        gpu.load_file(str(tmp_path / "missing.ts"))
+
+
+@pytest.mark.gpu
+def test_scan_error_states(ts):
+    with ts.TsHip(0) as g:
+        with pytest.raises(Exception) as e:
+            g.scan()
+        assert e.value.code == -6
+        g.upload(b"")
+        res = g.scan()
+        assert res.packets == 0 and res.report() == b"" and res.launches == 0
