@@ -48,12 +48,15 @@ $(CSRC)/papr_sweep_rt.o: $(CSRC)/papr_sweep_rt.cpp $(RT_HDRS)
 $(CSRC)/papr_exact_rt.o: $(CSRC)/papr_exact_rt.cpp $(RT_HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+$(CSRC)/papr_analyze.o: $(CSRC)/papr_analyze.cpp $(RT_HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(CSRC)/papr_exchange.o: $(CSRC)/papr_exchange.cpp $(RT_HDRS)
 	$(HIPCC) $(HIPFLAGS) -I/opt/rocm/include -c $< -o $@
 
 $(LIB): $(CSRC)/papr_kernels.o $(CSRC)/papr_sweep.o $(CSRC)/papr_exact.o $(CSRC)/papr_runtime.o $(CSRC)/papr_ingest.o \
         $(CSRC)/papr_sweep_rt.o $(CSRC)/papr_exact_rt.o $(CSRC)/papr_host.o $(CSRC)/ts_host.o \
-        $(CSRC)/ts_kernels.o $(CSRC)/ts_runtime.o $(CSRC)/papr_exchange.o
+        $(CSRC)/ts_kernels.o $(CSRC)/ts_runtime.o $(CSRC)/papr_exchange.o $(CSRC)/papr_analyze.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -lm -lpthread -ldl
 
 cli: bin/papr

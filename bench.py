@@ -111,38 +111,17 @@ def run_mode(args, mode, env):
     result = {}
 
     def step():
-        if one_sweep:
-            est, est_before, _ = xch.stats(gpu.estimate())   # 1/64-sample mean of the whole stream (exchange 0)
-            if args.exact:   # what the earlier shards add to the reference's running sum, as far as the sample tells
-                gpu.set_exact_hint(est_before)
-            local = gpu.stats_sweep(pkg.guess_levels(est, graph))        # pass 1 + banded pass 2 (+ exact-sum pairs), one read
-        else:
-            local = gpu.stats()                              # pass 1 on this shard
-        tot, before, _ = xch.stats(local)                    # exchange 1: all-gather + ordered merge (C ABI, RCCL)
-        mean, papr, table = pkg.levels(tot, graph)           # host scalars
-        if args.exact and np.isfinite(tot.sum):
-            # pass 2 against the table from the tree sum + this shard's sum program
-            local_counts, prog = gpu.ccdf_exact(table, before, total)
-            tot.sum = xch.exact_sum(prog)                    # all-gather + chain: papr.c:104's rounding sequence, bit for bit
-            mean, papr, table2 = pkg.levels(tot, graph)
-            if one_sweep:
-                info = gpu.sweep_info()
-                result["resolved"] = result.get("resolved", 0) + int(info.resolved)
-                result["redo_tiles"] = result.get("redo_tiles", 0) + int(info.exact_redo_tiles)
-            if not np.array_equal(table2, table):            # the exact sum moved a float threshold (rare)
-                table = table2
-                local_counts = gpu.ccdf(table)               # (one-sweep: the stash again, not the shard)
-                result["reruns"] = result.get("reruns", 0) + 1
-            if one_sweep:
-                result["sweep_info"] = gpu.sweep_info().as_dict()
-        else:
-            local_counts = gpu.ccdf(table)                   # pass 2 (one-sweep: recount of the stash only)
-            if one_sweep:
-                info = gpu.sweep_info()
-                result["resolved"] = result.get("resolved", 0) + int(info.resolved)
-                result["sweep_info"] = info.as_dict()
-        counts = xch.counts(local_counts)                    # exchange 2: all-reduce of the counters (C ABI, RCCL)
-        result.update(total=tot, mean=mean, papr=papr, table=table, counts=counts)
+        # ONE call into the library (papr_hip_analyze, include/papr_hip.h): mean estimate + its exchange, guessed
+        # bands, the sweep (pass 1 + banded pass 2, with --exact also the rounding functions of the sequential
+        # sum), exchange of the pass-1 records + ordered merge, mean / PAPR / level table as the reference derives
+        # them, stash recount (or pass 2 if the speculation missed), with --exact the chained sequential sum, and
+        # the all-reduce of the counters.  Nothing carries over between steps.
+        res, table, counts = gpu.analyze(xch, graph, two_pass=not one_sweep, spoil_guess=args.force_miss)
+        result["resolved"] = result.get("resolved", 0) + int(res.resolved)
+        result["redo_tiles"] = result.get("redo_tiles", 0) + int(res.exact_redo_tiles)
+        result["reruns"] = result.get("reruns", 0) + int(res.pass2_reruns)
+        result["exact_done"] = result.get("exact_done", 0) + int(res.exact_sum)
+        result.update(total=res.total, mean=res.mean, papr=res.papr, table=table, counts=counts)
 
     def fence():
         torch.cuda.synchronize()
@@ -152,8 +131,8 @@ def run_mode(args, mode, env):
 
     for _ in range(args.warmup):
         step()
-    result.pop("resolved", None)
-    result.pop("redo_tiles", None)
+    for k in ("resolved", "redo_tiles", "reruns", "exact_done"):
+        result.pop(k, None)
     xch.timing(reset=True)
     gpu.set_timing(True)
     fence()
@@ -164,6 +143,8 @@ def run_mode(args, mode, env):
     elapsed = time.perf_counter() - t0
     tm = gpu.timing()
     xt = xch.timing().as_dict()
+    if one_sweep:
+        result["sweep_info"] = gpu.sweep_info().as_dict()
     gpu.set_timing(False)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
@@ -204,7 +185,7 @@ def run_mode(args, mode, env):
                 pass
         # in-run parity: what this run would print, against what the REFERENCE printed for the same global stream
         report = pkg.format_report(result["total"], result["mean"], result["papr"], result["counts"], graph).encode()
-        golden, golden_name = golden_report(world, args.gib, graph)
+        golden, golden_name = golden_report(world, args.gib, graph) if args.signal == "gauss" else (None, None)
         parity = None if golden is None else (report == golden)
         line = {
             "metric": "IQ Msamples/s + achieved HBM GB/s (% of peak), 10 GiB cfile, 1/2/4/8 GPU",
@@ -214,7 +195,8 @@ def run_mode(args, mode, env):
             "config": {"workload": f"papr {'-g ' if graph else ''}on {args.gib:g} GiB synthetic gr_complex IQ per GPU "
                                    f"({'0.1 dB CCDF' if graph else 'peak+mean+1 dB histogram'}), HBM-resident, "
                                    f"{world}xMI355X",
-                       "mode": args.mode, "samples_per_gpu": per_gpu, "samples_total": total,
+                       "mode": args.mode, "signal": args.signal, "forced_miss": bool(args.force_miss),
+                       "samples_per_gpu": per_gpu, "samples_total": total,
                        "levels": int(result["table"].size), "papr_db": round(float(result["papr"]), 6),
                        "reads_of_the_shard_per_step": 1 if one_sweep and result.get("resolved", 0) == args.steps else 2,
                        "one_sweep": ({"steps_resolved_from_the_sweep": int(result.get("resolved", 0)),
@@ -223,7 +205,8 @@ def run_mode(args, mode, env):
                                       **{k: result.get("sweep_info", {}).get(k) for k in
                                          ("stash_samples", "stash_capacity", "estimate_samples", "band_log2", "reason")}}
                                      if one_sweep else None),
-                       "exact_sequential_sum": bool(args.exact), "sum_hex": float(result["total"].sum).hex(),
+                       "exact_sequential_sum": bool(args.exact) and result.get("exact_done", 0) == args.steps,
+                       "sum_hex": float(result["total"].sum).hex(),
                        "exact_pass2_reruns": int(result.get("reruns", 0)),
                        "counts_crc32": zlib.crc32(np.ascontiguousarray(result["counts"], dtype=np.uint64).tobytes()),
                        "sharding": f"sample axis, {world} contiguous shard(s)",
@@ -354,6 +337,12 @@ def main():
                     help="default = configs[1] (1 dB table), graph = configs[2] (papr -g, 0.1 dB CCDF); both (the "
                          "default) times configs[1] as the headline and adds configs[2] under \"graph\" in the same line")
     ap.add_argument("--gib", type=float, default=10.0, help="GiB of IQ per GPU")
+    ap.add_argument("--signal", choices=["gauss", "bursty", "constant"], default="gauss",
+                    help="envelope of the synthetic IQ (include/papr_synth.h): gauss = the BASELINE workload; bursty "
+                         "(on/off keying) and constant (constant envelope: every sample ON the 0 dB threshold) are the "
+                         "one-sweep speculation's hard cases")
+    ap.add_argument("--force-miss", action="store_true",
+                    help="feed the sweep a guess that is 3 %% off, so that every step pays the second read")
     ap.add_argument("--workload", choices=["papr", "ts"], default="papr",
                     help="papr = BASELINE.json's metric (the default); ts = the transport-stream packet scan of "
                          "xport.c (SURVEY.md 8(f) N4), a second line of its own")
@@ -413,7 +402,7 @@ def main():
     shard = torch.empty(per_gpu * 8 + 65536, dtype=torch.uint8, device=device)   # HBM-resident shard
     gpu = pkg.PaprHip(local_rank)
     gpu.adopt(shard.data_ptr(), per_gpu, base_index=rank * per_gpu, keepalive=shard)
-    gpu.generate(pkg.SynthSpec.spike(total), rank * per_gpu, per_gpu)
+    gpu.generate(pkg.SynthSpec.spike(total, envelope=args.signal), rank * per_gpu, per_gpu)
     if not use_dist:
         xch = exchange.Exchange.single()
     elif args.backend == "nccl":

@@ -38,6 +38,7 @@ ABI_SYMBOLS = (
     "papr_hip_estimate", "papr_hip_stats_sweep", "papr_hip_get_sweep_info", "papr_guess_levels",
     "papr_hip_estimate_file", "papr_hip_load_file_sweep", "papr_hip_shard_fits",
     "papr_level_key", "papr_sweep_bands", "papr_sweep_resolve", "papr_hip_set_exact_hint",
+    "papr_sweep_band_for", "papr_hip_set_band", "papr_hip_analyze",
 )
 
 
@@ -50,25 +51,27 @@ class SynthSpec(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("scale", C.c_float), ("n_overrides", C.c_uint32),
                 ("ov", SynthOverride * MAX_OVERRIDES)]
 
+    ENVELOPES = {"gauss": 0, "constant": 1, "bursty": 2}
+
     @classmethod
     def make(cls, seed: int = 0x5EED0001, scale: float = 0.0,
-             overrides: Sequence[tuple] = ()) -> "SynthSpec":
+             overrides: Sequence[tuple] = (), envelope: str = "gauss") -> "SynthSpec":
         sp = cls()
         sp.seed = seed
         sp.scale = scale
-        sp.n_overrides = len(overrides)
+        sp.n_overrides = len(overrides) | (cls.ENVELOPES[envelope] << 8)
         for k, (idx, i, q) in enumerate(overrides):
             sp.ov[k].index, sp.ov[k].i, sp.ov[k].q = idx, i, q
         return sp
 
     @classmethod
-    def spike(cls, n: int, seed: int = 0x5EED0001) -> "SynthSpec":
+    def spike(cls, n: int, seed: int = 0x5EED0001, envelope: str = "gauss") -> "SynthSpec":
         """papr_synth_spike_spec: the bench workload (two equal ~30 dB spikes)."""
         if n < 16:
-            return cls.make(seed)
+            return cls.make(seed, envelope=envelope)
         a = (n // 1000) * 731 + ((n % 1000) * 731) // 1000
         b = (n // 10) * 9 + ((n % 10) * 9) // 10
-        return cls.make(seed, 0.0, [(a, 36.9375, 0.0), (b, 36.9375, 0.0)])
+        return cls.make(seed, 0.0, [(a, 36.9375, 0.0), (b, 36.9375, 0.0)], envelope=envelope)
 
 
 class Stats(C.Structure):
@@ -113,6 +116,17 @@ class SweepInfo(C.Structure):
         d = {name: getattr(self, name) for name, _ in self._fields_}
         d["reason"] = SWEEP_REASONS[self.reason] if 0 <= self.reason < len(SWEEP_REASONS) else self.reason
         return d
+
+
+class Result(C.Structure):
+    """papr_result: what papr_hip_analyze returns (the whole file's pass-1 record, host scalars, how the step went)."""
+    _fields_ = [("total", Stats), ("mean", C.c_double), ("papr", C.c_float), ("nlevels", C.c_int),
+                ("exact_sum", C.c_int), ("swept", C.c_int), ("resolved", C.c_int), ("reason", C.c_int),
+                ("pass2_reruns", C.c_int), ("exact_redo_tiles", C.c_uint32), ("band_log2", C.c_int), ("reserved", C.c_int)]
+
+
+ANALYZE_TWO_PASS = 1
+ANALYZE_SPOIL_GUESS = 2
 
 
 class IngestTiming(C.Structure):
@@ -199,6 +213,12 @@ def lib() -> C.CDLL:
     L.papr_hip_shard_fits.restype = i32
     L.papr_hip_load_file_sweep.argtypes = [vp, C.c_char_p, u64, u64, vp, i32]
     L.papr_hip_get_sweep_info.argtypes = [vp, C.POINTER(SweepInfo)]
+    L.papr_hip_analyze.argtypes = [vp, vp, i32, C.c_uint, C.POINTER(Result), vp, vp, i32]
+    L.papr_hip_analyze.restype = i32
+    L.papr_sweep_band_for.argtypes = [C.POINTER(Stats)]
+    L.papr_sweep_band_for.restype = i32
+    L.papr_hip_set_band.argtypes = [vp, i32]
+    L.papr_hip_set_band.restype = i32
     L.papr_hip_set_exact_hint.argtypes = [vp, C.c_double]
     L.papr_hip_set_exact_hint.restype = i32
     for name in ("papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
@@ -246,6 +266,11 @@ def guess_levels(est_total: Stats, graph: bool, max_db: float = None) -> np.ndar
     n = lib().papr_guess_levels(C.byref(est_total), int(bool(graph)), float(max_db), buf.ctypes.data_as(C.c_void_p),
                                 MAX_LEVELS)
     return buf[:n].copy()
+
+
+def band_for(est_total: Stats) -> int:
+    """Band half-width (log2) the estimate's own standard error asks for (papr_sweep_band_for)."""
+    return int(lib().papr_sweep_band_for(C.byref(est_total)))
 
 
 def sweep_bands(guess_table: np.ndarray, band_log2: int = 14):
@@ -417,6 +442,10 @@ class PaprHip:
     def set_exact(self, enabled: bool = True):
         self._chk(self._L.papr_hip_set_exact(self._ctx, int(enabled)), "papr_hip_set_exact")
 
+    def set_band(self, band_log2: int = 0):
+        """Half-width (log2 of bit patterns) of the threshold bands of the next sweeps; 0 = built-in default."""
+        self._chk(self._L.papr_hip_set_band(self._ctx, int(band_log2)), "papr_hip_set_band")
+
     def set_exact_hint(self, estimated_sum_before_shard: float):
         """Exact one-read sweep: the estimated sum of everything before this shard (0 for the first)."""
         self._chk(self._L.papr_hip_set_exact_hint(self._ctx, float(estimated_sum_before_shard)), "papr_hip_set_exact_hint")
@@ -459,6 +488,21 @@ class PaprHip:
         self._chk(self._L.papr_hip_stats_sweep(self._ctx, lv.ctypes.data_as(C.c_void_p), lv.size, C.byref(s)),
                   "papr_hip_stats_sweep")
         return s
+
+    def analyze(self, xch=None, graph: bool = False, two_pass: bool = False, spoil_guess: bool = False):
+        """papr_hip_analyze: the whole result in one call — (Result, level table, counts above each level).
+        `xch`: a dtv_utils_amd.exchange.Exchange (None: single shard)."""
+        if not hasattr(self, "_an_levels"):
+            self._an_levels = np.zeros(MAX_LEVELS, dtype=np.float32)
+            self._an_counts = np.zeros(MAX_LEVELS, dtype=np.uint64)
+        res = Result()
+        self._chk(self._L.papr_hip_analyze(self._ctx, xch._x if xch is not None else None, int(bool(graph)),
+                                           (ANALYZE_TWO_PASS if two_pass else 0) | (ANALYZE_SPOIL_GUESS if spoil_guess else 0),
+                                           C.byref(res),
+                                           self._an_levels.ctypes.data_as(C.c_void_p),
+                                           self._an_counts.ctypes.data_as(C.c_void_p), MAX_LEVELS), "papr_hip_analyze")
+        n = res.nlevels
+        return res, self._an_levels[:n].copy(), self._an_counts[:n].copy()
 
     def sweep_info(self) -> SweepInfo:
         i = SweepInfo()

@@ -1,0 +1,131 @@
+// papr_analyze.cpp — papr_hip_analyze: the whole papr result for one shard among its peers in one call (the sequence
+// of include/papr_hip.h's primitives that bench.py times and bin/papr prints from), so that a step costs the host
+// one entry into the library instead of a dozen; and the in-process exchange transport of bin/papr's shard threads.
+
+#include "papr_runtime_internal.h"
+
+using namespace papr_rt;
+
+extern "C" {
+
+int papr_hip_analyze(papr_hip_ctx *ctx, papr_exchange *x, int graph, unsigned flags, papr_result *res, float *levels,
+                     uint64_t *counts_above, int cap)
+{
+    if (!ctx || !res || cap < 0 || (cap && (!levels || !counts_above)))
+        return PAPR_E_ARG;
+    if (!ctx->loaded)
+        return fail(ctx, PAPR_E_STATE, "papr_hip_analyze called before a shard was loaded");
+    memset(res, 0, sizeof(*res));
+    auto xfail = [&](int rc) {  // an exchange failed: its text is the detail
+        if (x)
+            snprintf(ctx->err, sizeof(ctx->err), "exchange: %s", papr_exchange_last_error(x));
+        return rc;
+    };
+    // ---- pass 1 (+ banded pass 2): one sweep, steered by a 1/64-sample estimate of the whole file's mean ----
+    papr_stats local;
+    int rc;
+    bool swept_path = false;
+    if (!(flags & PAPR_ANALYZE_TWO_PASS)) {
+        papr_stats est, est_total;
+        double est_before = 0.0;
+        rc = papr_hip_estimate(ctx, &est);
+        if (rc)
+            return rc;
+        est_total = est;
+        if (x && (rc = papr_exchange_stats(x, &est, &est_total, &est_before, nullptr)) != PAPR_OK)
+            return xfail(rc);
+        std::vector<float> guess;
+        int nguess = 0;
+        try {
+            guess.resize(PAPR_HIP_MAX_LEVELS);
+        } catch (...) {
+            return fail(ctx, PAPR_E_NOMEM, "out of host memory");
+        }
+        if (est_total.n)
+            nguess = papr_guess_levels(&est_total, graph, graph ? 48.0 : 60.0, guess.data(), PAPR_HIP_MAX_LEVELS);
+        if (flags & PAPR_ANALYZE_SPOIL_GUESS)
+            for (int j = 0; j < nguess; j++)
+                guess[(size_t)j] *= 1.03f;
+        (void)papr_hip_set_band(ctx, papr_sweep_band_for(&est_total));
+        if (ctx->exact)
+            (void)papr_hip_set_exact_hint(ctx, std::isfinite(est_before) && est_before >= 0.0 ? est_before : 0.0);
+        rc = papr_hip_stats_sweep(ctx, guess.data(), nguess, &local);  // falls back to plain pass 1 by itself
+        swept_path = true;
+    } else {
+        rc = papr_hip_stats(ctx, &local);
+    }
+    if (rc)
+        return rc;
+    // ---- exchange 1 + host scalars ----
+    papr_stats total = local;
+    double before = 0.0;
+    if (x && (rc = papr_exchange_stats(x, &local, &total, &before, nullptr)) != PAPR_OK)
+        return xfail(rc);
+    double mean = 0.0;
+    float papr = 0.f;
+    int L = papr_levels(&total, graph, &mean, &papr, nullptr, 0);
+    if (L > cap || L > PAPR_HIP_MAX_LEVELS)
+        return fail(ctx, PAPR_E_LIMIT, "%d levels exceed the caller's capacity (%d)", L, std::min(cap, PAPR_HIP_MAX_LEVELS));
+    (void)papr_levels(&total, graph, nullptr, nullptr, levels, L);
+    // ---- pass 2 (the stash recount when the sweep resolves) and, in exact-sum mode, the sequential sum ----
+    bool counted = false;
+    if (ctx->exact && std::isfinite(total.sum)) {
+        const void *program = nullptr;
+        size_t bytes = 0;
+        const int xrc = papr_hip_ccdf_exact(ctx, levels, L, counts_above, before, total.n, &program, &bytes);
+        counted = xrc == PAPR_OK;
+        double seq = 0.0;
+        int crc;
+        if (x) {
+            // a shard that could not build its program sends an empty one: the chain then fails on EVERY rank alike
+            static const unsigned char none[8] = {0};
+            crc = papr_exchange_exact_sum(x, xrc == PAPR_OK ? program : none, xrc == PAPR_OK ? bytes : 0, &seq);
+        } else if (xrc == PAPR_OK) {
+            const void *progs[1] = {program};
+            const size_t sizes[1] = {bytes};
+            crc = papr_exact_chain(progs, sizes, 1, &seq);
+        } else {
+            crc = xrc;
+        }
+        if (crc == PAPR_OK) {
+            total.sum = seq;
+            res->exact_sum = 1;
+            std::vector<float> again;
+            try {
+                again.resize((size_t)PAPR_HIP_MAX_LEVELS);
+            } catch (...) {
+                return fail(ctx, PAPR_E_NOMEM, "out of host memory");
+            }
+            const int L2 = papr_levels(&total, graph, &mean, &papr, again.data(), PAPR_HIP_MAX_LEVELS);
+            if (L2 > cap)
+                return fail(ctx, PAPR_E_LIMIT, "%d levels exceed the caller's capacity (%d)", L2, cap);
+            if (L2 != L || memcmp(again.data(), levels, (size_t)L * sizeof(float)) != 0) {
+                // the exact sum moved a float threshold (rare): count again — from the stash if the sweep holds
+                L = L2;
+                memcpy(levels, again.data(), (size_t)L * sizeof(float));
+                counted = false;
+                res->pass2_reruns = 1;
+            }
+        }
+    }
+    if (!counted) {
+        rc = papr_hip_ccdf(ctx, levels, L, counts_above);
+        if (rc)
+            return rc;
+    }
+    // ---- exchange 2 ----
+    if (x && (rc = papr_exchange_counts(x, counts_above, L)) != PAPR_OK)
+        return xfail(rc);
+    res->total = total;
+    res->mean = mean;
+    res->papr = papr;
+    res->nlevels = L;
+    res->swept = swept_path ? ctx->sweep_info.swept : 0;
+    res->resolved = swept_path ? ctx->sweep_info.resolved : 0;
+    res->reason = swept_path ? ctx->sweep_info.reason : PAPR_SWEEP_NONE;
+    res->exact_redo_tiles = ctx->sweep_info.exact_redo_tiles;
+    res->band_log2 = ctx->sweep_info.band_log2;
+    return PAPR_OK;
+}
+
+}  // extern "C"

@@ -63,8 +63,34 @@ double now_us()
 
 }  // namespace
 
+// in-process transport: the threads of one process meet at a barrier (bin/papr: one thread per GPU)
+struct LocalHub {
+    std::mutex m;
+    std::condition_variable cv;
+    int world = 0, arrived = 0, refs = 0;
+    uint64_t generation = 0;
+    std::vector<unsigned char> slots;  // world x bytes of the collective in flight
+    size_t slot_bytes = 0;
+    bool failed = false;  // a participant gave up (papr_exchange_abort): every collective fails from then on
+    bool barrier(std::unique_lock<std::mutex> &lk)
+    {
+        if (failed)
+            return false;
+        const uint64_t gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            generation++;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen || failed; });
+        }
+        return !failed;
+    }
+};
+
 struct papr_exchange {
     int rank = 0, world = 1;
+    LocalHub *hub = nullptr;
     char err[256] = "";
     // caller-supplied transport
     papr_exchange_ops ops{};
@@ -137,6 +163,30 @@ int allgather_bytes(papr_exchange *x, const void *send, void *recv, size_t bytes
         memcpy(recv, send, bytes_per_rank);  // what `torchrun --nproc-per-node 1` measures)
         return PAPR_OK;
     }
+    if (x->hub) {
+        LocalHub &h = *x->hub;
+        std::unique_lock<std::mutex> lk(h.m);
+        const char *gone = "another shard's thread gave up: the exchange is cancelled";
+        if (!h.barrier(lk))  // everyone has left the previous collective
+            return xfail(x, PAPR_E_STATE, "%s", gone);
+        if (h.slots.size() != bytes_per_rank * (size_t)h.world) {
+            try {
+                h.slots.assign(bytes_per_rank * (size_t)h.world, 0);
+            } catch (...) {
+                h.failed = true;
+                h.cv.notify_all();
+                return xfail(x, PAPR_E_NOMEM, "out of host memory");
+            }
+        }
+        h.slot_bytes = bytes_per_rank;
+        if (!h.barrier(lk))  // the buffer has its size
+            return xfail(x, PAPR_E_STATE, "%s", gone);
+        memcpy(h.slots.data() + (size_t)x->rank * bytes_per_rank, send, bytes_per_rank);
+        if (!h.barrier(lk))  // every slot is written
+            return xfail(x, PAPR_E_STATE, "%s", gone);
+        memcpy(recv, h.slots.data(), bytes_per_rank * (size_t)h.world);
+        return PAPR_OK;
+    }
     if (x->use_ops) {
         if (x->ops.allgather(x->ops.user, send, recv, bytes_per_rank) != 0)
             return xfail(x, PAPR_E_HIP, "the caller's all-gather failed");
@@ -161,6 +211,24 @@ int allreduce_u64(papr_exchange *x, uint64_t *buf, size_t count)
 {
     if ((x->world == 1 && x->use_ops) || count == 0)
         return PAPR_OK;
+    if (x->hub) {  // gather, then every thread adds the slots in rank order
+        std::vector<uint64_t> all;
+        try {
+            all.resize(count * (size_t)x->world);
+        } catch (...) {
+            return xfail(x, PAPR_E_NOMEM, "out of host memory");
+        }
+        int rc = allgather_bytes(x, buf, all.data(), count * sizeof(uint64_t));
+        if (rc)
+            return rc;
+        for (size_t k = 0; k < count; k++) {
+            uint64_t sum = 0;
+            for (int r = 0; r < x->world; r++)
+                sum += all[(size_t)r * count + k];
+            buf[k] = sum;
+        }
+        return PAPR_OK;
+    }
     if (x->use_ops) {
         if (x->ops.allreduce_sum_u64(x->ops.user, buf, count) != 0)
             return xfail(x, PAPR_E_HIP, "the caller's all-reduce failed");
@@ -250,10 +318,58 @@ int papr_exchange_open_ops(papr_exchange **out, const papr_exchange_ops *ops, in
     return PAPR_OK;
 }
 
+int papr_exchange_open_local(papr_exchange **xs, int n)
+{
+    if (!xs || n < 1)
+        return PAPR_E_ARG;
+    LocalHub *hub = new (std::nothrow) LocalHub();
+    if (!hub)
+        return PAPR_E_NOMEM;
+    hub->world = n;
+    hub->refs = n;
+    for (int r = 0; r < n; r++) {
+        papr_exchange *x = new (std::nothrow) papr_exchange();
+        if (!x) {
+            for (int q = 0; q < r; q++)
+                delete xs[q];
+            delete hub;
+            return PAPR_E_NOMEM;
+        }
+        x->rank = r;
+        x->world = n;
+        x->use_ops = true;  // (world == 1 short cuts apply)
+        x->hub = n > 1 ? hub : nullptr;
+        xs[r] = x;
+    }
+    if (n == 1) {
+        delete hub;
+    }
+    return PAPR_OK;
+}
+
+void papr_exchange_abort(papr_exchange *x)
+{
+    if (!x || !x->hub)
+        return;
+    std::lock_guard<std::mutex> g(x->hub->m);
+    x->hub->failed = true;
+    x->hub->cv.notify_all();
+}
+
 void papr_exchange_close(papr_exchange *x)
 {
     if (!x)
         return;
+    if (x->hub) {
+        bool last;
+        {
+            std::lock_guard<std::mutex> g(x->hub->m);
+            last = --x->hub->refs == 0;
+        }
+        if (last)
+            delete x->hub;
+        x->hub = nullptr;
+    }
     if (x->ctx)
         (void)hipSetDevice(x->ctx->device);
     if (x->comm && rccl())

@@ -126,6 +126,20 @@ int papr_guess_levels(const papr_stats *est_total, int graph, double max_db, flo
     return nl;
 }
 
+/* Band half-width for an estimate whose relative standard error is est_total->peak: a relative change d of a float
+ * moves its bit pattern by d * 2^23 * m patterns (m = its mantissa, 1 <= m < 2), so a band of h patterns covers at
+ * least h / 2^24; 4.5 standard errors, never below 2^10 (float rounding of the thresholds themselves). */
+int papr_sweep_band_for(const papr_stats *est_total)
+{
+    if (!est_total || !(est_total->peak >= 0.0f) || !(est_total->peak < 1.0f))
+        return 14;
+    const double want = 4.5 * (double)est_total->peak * 16777216.0;
+    int lg = 10;
+    while (lg < 20 && (double)(1u << lg) < want)
+        lg++;
+    return lg;
+}
+
 /* ---- one-sweep mode: the host halves of the speculation (papr_sweep.hip) -------------------------- */
 
 uint32_t papr_level_key(float t)

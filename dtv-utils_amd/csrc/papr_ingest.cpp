@@ -613,7 +613,7 @@ int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_s
         }
         const int blocks = (int)std::min<uint64_t>(cnt, (uint64_t)blocks_max);
         time_begin(ctx, 4, cnt * kTileBytes);
-        papr_launch_estimate(ctx->stream, blocks, ctx->d_stage[b], cnt, 1, ctx->d_partials + records, nullptr);
+        papr_launch_estimate(ctx->stream, blocks, ctx->d_stage[b], cnt, 1, ctx->d_partials + records, nullptr, nullptr);
         time_end(ctx);
         records += (size_t)blocks;
         if (hipEventRecord(ctx->ev_copy[b], ctx->stream) != hipSuccess)

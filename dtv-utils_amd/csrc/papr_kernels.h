@@ -122,7 +122,8 @@ void papr_launch_generate(hipStream_t st, int blocks, void *out, uint64_t nsampl
                           const papr_synth_spec &spec);
 /* one-sweep mode (papr_sweep.hip) */
 void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t ngroups, uint32_t ratio,
-                          papr_partial *out, double *group_sums /* may be null: one sampled sum per group */);
+                          papr_partial *out, double *group_sums /* may be null: 4 sampled sums per group */,
+                          double *block_sq /* may be null: per workgroup, sum of squared piece sums */);
 int papr_sweep_variant(int variant); /* the sweep geometry used for a variant id, or -1 */
 int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_t *stash_lds); /* 0, or -1 */
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,

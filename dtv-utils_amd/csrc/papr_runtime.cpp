@@ -544,6 +544,8 @@ void papr_hip_close(papr_hip_ctx *ctx)
     if (ctx->d_stash) (void)hipFree(ctx->d_stash);
     if (ctx->d_tile_E_spec) (void)hipFree(ctx->d_tile_E_spec);
     if (ctx->d_est_groups) (void)hipFree(ctx->d_est_groups);
+    if (ctx->d_est_sq) (void)hipFree(ctx->d_est_sq);
+    if (ctx->h_est_sq) (void)hipHostFree(ctx->h_est_sq);
     if (ctx->d_redo) (void)hipFree(ctx->d_redo);
     if (ctx->h_redo_count) (void)hipHostFree(ctx->h_redo_count);
     if (ctx->d_tile_sums) (void)hipFree(ctx->d_tile_sums);

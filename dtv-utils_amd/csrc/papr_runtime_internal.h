@@ -219,9 +219,11 @@ struct papr_hip_ctx {
     papr_hip_sweep_info sweep_info{};
     const papr_rt::SweepRun *ingest_run = nullptr;        // set while papr_hip_load_file_sweep streams the file in
     int32_t *d_tile_E_spec = nullptr;            // exact one-read sweep: speculated binade per tile (same capacity as d_tile_E)
+    double *d_est_sq = nullptr, *h_est_sq = nullptr; // papr_hip_estimate: per-workgroup sums of squared piece sums (-> standard error)
     double *d_est_groups = nullptr;              // papr_hip_estimate: sampled sum per estimate group (exact one-read sweep)
     uint64_t est_groups_cap = 0, est_ngroups = 0, est_ratio = 0;
     bool est_groups_valid = false;               // ... describe the CURRENT shard
+    int band_hint = 0;                           // papr_hip_set_band: half-width (log2) for the next sweeps, 0 = default
     double exact_before_hint = 0.0;              // estimated sum of everything before this shard (papr_hip_set_exact_hint)
     uint32_t *h_redo_count = nullptr;            // pinned
     uint32_t *d_redo = nullptr;                  // [0, kCapRedo) tiles whose pairs must be rebuilt, [kCapRedo] their count

@@ -105,15 +105,19 @@ struct WaveStash {
 // Output: one papr_partial per workgroup with only `sum` set (merged by papr_stats_finalize like pass-1 partials).
 // `group_sums` (may be null): 4 doubles per group, one per wave — their sum is the group's sampled sum (the exact
 // one-read sweep speculates each tile's running-sum binade from them, papr_exact.hip).
+// `block_sq` (may be null): per workgroup, the sum over its (group, wave) pieces of the piece's sum SQUARED — with
+// the total that gives the scatter of the pieces, i.e. the standard error of the estimate (the host sizes the
+// threshold bands from it: a bursty capture gets wider bands than a stationary one).
 __global__ __launch_bounds__(PAPR_BLOCK) void papr_estimate_kernel(const float4 *__restrict__ data, uint64_t ngroups,
                                                                     uint32_t ratio, papr_partial *__restrict__ out,
-                                                                    double *__restrict__ group_sums)
+                                                                    double *__restrict__ group_sums,
+                                                                    double *__restrict__ block_sq)
 {
     constexpr int U = PAPR_ESTIMATE_TILE_SAMPLES / (2 * PAPR_BLOCK);
     constexpr int kRows = U * (PAPR_BLOCK / kWave);
     constexpr uint64_t TILE_F4 = (uint64_t)PAPR_BLOCK * U;
     const uint32_t wave = threadIdx.x / kWave;
-    double sum = 0.0;
+    double sum = 0.0, sq = 0.0;
     for (uint64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         float4 x[U];
 #pragma unroll
@@ -129,10 +133,21 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_estimate_kernel(const float4 
             gsum += (double)power_of(x[u].z, x[u].w);
         }
         sum += gsum;
-        if (group_sums) {
-            const double ws = wave_reduce_sum(gsum);
-            if ((threadIdx.x & (kWave - 1)) == 0)
-                group_sums[g * (PAPR_BLOCK / kWave) + wave] = ws;
+        const double ws = wave_reduce_sum(gsum);  // this wave's piece of the group (valid in lane 0)
+        sq += ws * ws;
+        if (group_sums && (threadIdx.x & (kWave - 1)) == 0)
+            group_sums[g * (PAPR_BLOCK / kWave) + wave] = ws;
+    }
+    if (block_sq) {
+        __shared__ double sh_sq[PAPR_BLOCK / kWave];
+        if ((threadIdx.x & (kWave - 1)) == 0)
+            sh_sq[wave] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int wq = 0; wq < PAPR_BLOCK / kWave; wq++)
+                tot += sh_sq[wq];
+            block_sq[blockIdx.x] = tot;
         }
     }
     LaneStats s;
@@ -749,10 +764,12 @@ __device__ __forceinline__ void sweep2_record(double sum, const TileTrack &tr, u
 
 }  // namespace
 
-template <int WAVES, int U, int PIPE, bool EXACT, int WT>
+template <int WAVES, int U, int PIPE, bool EXACT, int WTB>
 __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sweep2_params p)
 {
     static_assert(!EXACT || U == 8, "exact-sum segments are 1024 samples");
+    constexpr bool BATCHED = (WTB & 4) != 0;  // one stash reservation per lane per batch instead of one per in-band sample
+    constexpr bool LEAN_SUM = (WTB & 8) != 0; // exact mode: the lane's sum is x0 - m0 (no separate accurate accumulation)
     constexpr int BLOCK = WAVES * kWave;
     constexpr uint64_t SEG_F4 = 64ull * U;
     constexpr uint32_t RING = EXACT ? 512u : 1024u;  // >= 255 + 64 * (samples per lane between two ring checks)
@@ -784,7 +801,7 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
 
     const uint2 *lut_biased = reinterpret_cast<const uint2 *>(tab) - ((int32_t)P.cell_lo - 1);
     uint32_t *my = hist + (wave % P.copies) * nbins;
-    StashRing<RING, WT> ws{rings + wave * RING,
+    StashRing<RING, (WTB & 3)> ws{rings + wave * RING,
                            &ring_head[wave],
                            0u,
                            p.stash + (uint64_t)blockIdx.x * p.seg_cap,
@@ -829,7 +846,8 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
 #pragma unroll
         for (int u = 0; u < 2 * BATCH; u++) {
             const double v = (double)pw[u];
-            sum += v;  // the accurate per-lane sum (as papr_stats_kernel), also in exact mode
+            if constexpr (!(EXACT && LEAN_SUM))
+                sum += v;  // the accurate per-lane sum (as papr_stats_kernel), also in exact mode
             if constexpr (EXACT) {
                 x0 += v;  // the reference's additions themselves, from the two canonical entry states
                 x1 += v;
@@ -839,11 +857,19 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
 #pragma unroll
         for (int u = 0; u < 2 * BATCH; u++)
             k[u] = bin_of(pw[u]);  // the batch's LUT reads in flight together
+        if constexpr (BATCHED) {
+            // one stash reservation per lane per batch (one LDS round trip instead of up to 2 * BATCH)
 #pragma unroll
-        for (int u = 0; u < 2 * BATCH; u++)
-            if (k[u])
-                atomicAdd(&my[k[u]], 1u);
-        ws.spill_from(ws.put_batch(pw, k));
+            for (int u = 0; u < 2 * BATCH; u++)
+                if (k[u])
+                    atomicAdd(&my[k[u]], 1u);
+            ws.spill_from(ws.put_batch(pw, k));
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2 * BATCH; u++)
+                count_and_stash(pw[u], k[u]);
+            ws.spill_full();
+        }
     };
 
     auto load_seg = [&](float4(&x)[U], uint64_t seg) {
@@ -888,6 +914,8 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
             Pair2 f;
             f.d0 = x0 - m0;  // exact: multiples of the ulp inside the binade (a plain sum when no binade was given)
             f.d1 = x1 - m1;
+            if constexpr (LEAN_SUM)
+                sum += f.d0;
             f = wave_compose2(f, m0);
             if (lane == 0)
                 seg_D[p.seg_offset + seg] = make_double2(f.d0, f.d1);
@@ -999,10 +1027,10 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_ccdf_power_kernel(const float
 // ---- launch wrappers -------------------------------------------------------------------
 
 void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t ngroups, uint32_t ratio,
-                          papr_partial *out, double *group_sums)
+                          papr_partial *out, double *group_sums, double *block_sq)
 {
     hipLaunchKernelGGL(papr_estimate_kernel, dim3(blocks), dim3(PAPR_BLOCK), 0, st, (const float4 *)data, ngroups, ratio,
-                       out, group_sums);
+                       out, group_sums, block_sq);
 }
 
 // Geometry variants of the sweep (ids as in papr_kernels.hip's table).
@@ -1056,10 +1084,10 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
 // Geometry variants of the second-generation sweep: id, waves per workgroup, 16-byte loads per lane per segment,
 // next-segment prefetch, exact-sum pairs, stash store policy (0 plain, 1 nontemporal, 2 write-through).
 #define PAPR_FOR_EACH_SWEEP2_VARIANT(X)                                                                         \
-    X(32, 16, 8, 0, false, 2) X(33, 16, 8, 1, false, 2) X(34, 16, 4, 0, false, 2) X(35, 16, 4, 1, false, 2)      \
-    X(36, 8, 8, 0, false, 2) X(37, 8, 8, 1, false, 2) X(38, 16, 8, 0, false, 0) X(39, 16, 8, 0, false, 1)        \
-    X(40, 12, 8, 0, false, 2) X(41, 12, 8, 1, false, 2) X(42, 8, 4, 1, false, 2) X(43, 4, 8, 1, false, 2)        \
-    X(48, 12, 8, 0, true, 2) X(49, 10, 8, 0, true, 2) X(50, 8, 8, 0, true, 2) X(51, 12, 8, 0, true, 0)
+    X(32, 16, 8, 0, false, 2) X(34, 16, 4, 0, false, 2) X(35, 16, 4, 1, false, 2) X(40, 12, 8, 0, false, 2)      \
+    X(41, 12, 8, 1, false, 2) X(42, 8, 4, 1, false, 2) X(44, 16, 8, 0, false, 6) X(45, 12, 8, 1, false, 6)       \
+    X(48, 12, 8, 0, true, 2) X(49, 12, 8, 0, true, 6) X(50, 12, 8, 0, true, 10) X(51, 12, 8, 0, true, 0)         \
+    X(52, 12, 8, 0, true, 14) X(54, 11, 8, 0, true, 10)
 
 int papr_sweep2_geometry(int variant, int *threads, uint64_t *seg_samples, size_t *lds_fixed, int *exact)
 {

@@ -63,7 +63,7 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
                   SweepRun *run, int *reason)
 {
     papr_hip_sweep_info &info = ctx->sweep_info;
-    info.band_log2 = ctx->tune.sweep_band_log2 > 0 ? ctx->tune.sweep_band_log2 : kSweepBandLog2;
+    info.band_log2 = ctx->tune.sweep_band_log2 > 0 ? ctx->tune.sweep_band_log2 : ctx->band_hint > 0 ? ctx->band_hint : kSweepBandLog2;
     *reason = PAPR_SWEEP_NO_BANDS;
     if (nlevels <= 0 || nlevels > PAPR_HIP_MAX_LEVELS)
         return PAPR_OK;
@@ -339,13 +339,29 @@ int papr_hip_estimate(papr_hip_ctx *ctx, papr_stats *est)
         }
         group_sums = ctx->d_est_groups;
     }
+    if (!ctx->d_est_sq) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double)));
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double), hipHostMallocDefault));
+    }
     time_begin(ctx, 4, ngroups * PAPR_ESTIMATE_TILE_SAMPLES * 8);
-    papr_launch_estimate(ctx->stream, blocks, ctx->d_iq, ngroups, (uint32_t)ratio, ctx->d_partials, group_sums);
+    papr_launch_estimate(ctx->stream, blocks, ctx->d_iq, ngroups, (uint32_t)ratio, ctx->d_partials, group_sums, ctx->d_est_sq);
     time_end(ctx);
     HIPCHK(ctx, hipGetLastError());
     papr_launch_stats_finalize(ctx->stream, nullptr, 0, 0, ctx->d_partials, (uint32_t)blocks, ctx->h_result_dev);
     HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_est_sq, ctx->d_est_sq, (size_t)blocks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        // relative standard error of the estimated mean from the scatter of its P = 4 x ngroups pieces
+        double sq = 0.0;
+        for (int b = 0; b < blocks; b++)
+            sq += ctx->h_est_sq[b];
+        const double S = ctx->h_result->sum, P = 4.0 * (double)ngroups;
+        const double var_total = P > 1.0 ? P / (P - 1.0) * std::max(0.0, sq - S * S / P) : 0.0;
+        est->peak = S > 0.0 ? (float)(std::sqrt(var_total) / S) : 0.0f;
+        if (ratio == 1)
+            est->peak = 0.0f;  // everything was read: the "estimate" is the mean itself (up to summation order)
+    }
     // the record describes the SHARD: the sampled sum scaled to all of its samples, so that shards of different
     // size (or sampling ratio) merge with the right weights and a shard's record is also the estimate of what it
     // adds to the running sum of the shards behind it
@@ -358,6 +374,14 @@ int papr_hip_estimate(papr_hip_ctx *ctx, papr_stats *est)
         ctx->est_ratio = ratio;
         ctx->est_groups_valid = true;
     }
+    return PAPR_OK;
+}
+
+int papr_hip_set_band(papr_hip_ctx *ctx, int band_log2)
+{
+    if (!ctx || (band_log2 != 0 && (band_log2 < 8 || band_log2 > 20)))
+        return PAPR_E_ARG;
+    ctx->band_hint = band_log2;
     return PAPR_OK;
 }
 
@@ -377,6 +401,10 @@ int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nleve
         return PAPR_E_ARG;
     if (!ctx->loaded)
         return fail(ctx, PAPR_E_STATE, "papr_hip_stats_sweep called before a shard was loaded");
+    if (ctx->have_file_stats) {  // pass 1 (or a whole one-sweep ingest, which stays valid) ran while the file streamed in
+        *out = ctx->file_stats;
+        return PAPR_OK;
+    }
     papr_hip_sweep_info &info = ctx->sweep_info;
     info.swept = info.resolved = 0;
     info.stash_samples = 0;
@@ -385,7 +413,7 @@ int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nleve
         info.reason = reason;
         return papr_hip_stats(ctx, out);
     };
-    if (ctx->have_file_stats || !ctx->resident)
+    if (!ctx->resident)
         return plain(PAPR_SWEEP_MODE);
     ctx->exact_swept = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -22,6 +22,11 @@ struct ts_scan_params {
     uint32_t *list_counts;      // per workgroup
     unsigned long long *span_done;  // per workgroup: units taken (in front of its first irregular one)
     uint32_t *span_stopped;     // per workgroup: 1 = it met an irregular unit
+    uint32_t *events;           // per workgroup: event_cap unit numbers whose packet hit the read-boundary quirk harmlessly
+    uint32_t *event_counts;     // per workgroup
+    uint32_t event_cap;         // 0 = treat every quirk packet as irregular
+    uint32_t *merged_events;    // the valid spans' events, compacted by ts_merge_kernel
+    uint32_t merged_event_cap;
 };
 
 void ts_kernels_prepare_device(void);

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t ts_smem[];  // 3 x TS_PIDS words = 96 KiB (one workgroup per CU)
     uint32_t *s_count = ts_smem, *s_first = ts_smem + TS_PIDS, *s_last = ts_smem + 2 * TS_PIDS;
-    __shared__ uint32_t s_irregular, s_entries;
+    __shared__ uint32_t s_irregular, s_entries, s_events;
     const uint32_t t = threadIdx.x;
     for (uint32_t k = t; k < TS_PIDS; k += kBlock) {
         s_count[k] = 0;
@@ -39,6 +39,7 @@ __global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
     if (t == 0) {
         s_irregular = kNone;
         s_entries = 0;
+        s_events = 0;
     }
     __syncthreads();
 
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
     const uint64_t j1 = j0 + per < p.nunits ? j0 + per : p.nunits;
     for (uint64_t jb = j0; jb < j1; jb += kBlock) {  // workgroup-uniform trip count
         const uint64_t j = jb + t;
-        bool regular = true, have = j < j1;
+        bool regular = true, have = j < j1, quirk = false;
         uint32_t pid = 0, tei = 0;
         if (have) {
             const uint64_t s = p.first_unit + j * p.stride + p.sync_offset;  // file offset of the sync byte
@@ -70,21 +71,36 @@ __global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
                 const uint32_t af_len = has_af ? b4 : 0u;
                 regular = b0 == 0x47u && af_len <= 183u;
                 // the reference's one-step payload skip, entered before the last byte of a packet that ends one
-                // byte past a 16384-byte read, finishes the packet a byte early (xport.c:4302)
+                // byte past a 16384-byte read, finishes the packet a byte early (xport.c:4302): its last byte goes
+                // to the sync search.  Unless that byte is 0x47 (a false sync: irregular) the search skips it,
+                // reports `skipped 1 bytes` and locks on the next packet where it would have anyway — an event for
+                // the list, nothing else changes.
                 const bool on_boundary = ((s + 187) & (TS_READ_CHUNK - 1)) == 0;
-                if (on_boundary && pid != 0u && pid != 0x1ffbu && (!has_af || af_len <= 181u))
-                    regular = false;
+                if (regular && on_boundary && pid != 0u && pid != 0x1ffbu && (!has_af || af_len <= 181u)) {
+                    if (p.data[s + 187] == 0x47u || p.event_cap == 0) {
+                        regular = false;
+                    } else {
+                        quirk = true;
+                    }
+                }
             }
             if (!regular)
                 atomicMin(&s_irregular, (uint32_t)(j - j0));
         }
         __syncthreads();
         const uint32_t stop = s_irregular;  // relative to j0
-        if (have && (uint32_t)(j - j0) < stop && tei == 0) {
+        if (have && (uint32_t)(j - j0) < stop) {
             const uint32_t rel = (uint32_t)j;  // unit number within the launch (a launch takes < 2^32 units)
-            atomicAdd(&s_count[pid], 1u);
-            atomicMin(&s_first[pid], rel);
-            atomicMax(&s_last[pid], rel);
+            if (tei == 0) {
+                atomicAdd(&s_count[pid], 1u);
+                atomicMin(&s_first[pid], rel);
+                atomicMax(&s_last[pid], rel);
+            }
+            if (quirk) {  // (about one packet in 4096 of a stream whose packets sit at odd offsets)
+                const uint32_t at = atomicAdd(&s_events, 1u);
+                if (at < p.event_cap)
+                    p.events[(size_t)blockIdx.x * p.event_cap + at] = rel;
+            }
         }
         if (stop != kNone)
             break;  // (uniform: every thread read the same value after the barrier)
@@ -107,7 +123,11 @@ __global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
         p.list_counts[blockIdx.x] = s_entries;
         // units of this span in front of its first irregular one (all of them if there is none)
         p.span_done[blockIdx.x] = s_irregular != kNone ? (uint64_t)s_irregular : (j1 > j0 ? j1 - j0 : 0);
-        p.span_stopped[blockIdx.x] = s_irregular != kNone ? 1u : 0u;
+        // more quirk events than the list holds: as good as an irregular packet (the host walker then reports them)
+        p.span_stopped[blockIdx.x] = (s_irregular != kNone || s_events > p.event_cap) ? 1u : 0u;
+        if (s_events > p.event_cap)
+            p.span_done[blockIdx.x] = 0, p.list_counts[blockIdx.x] = 0;
+        p.event_counts[blockIdx.x] = s_events <= p.event_cap ? s_events : 0u;
     }
 }
 
@@ -133,6 +153,22 @@ __global__ __launch_bounds__(kBlock) void ts_merge_kernel(const ts_scan_params p
     }
     __syncthreads();
     const uint32_t last_span = s_last_span;
+    // the valid spans' quirk events, compacted (unordered within a span: the host sorts)
+    __shared__ uint32_t s_nevents;
+    if (threadIdx.x == 0)
+        s_nevents = 0;
+    __syncthreads();
+    for (uint32_t b = 0; b <= last_span; b++) {
+        const uint32_t n = p.event_counts[b];
+        for (uint32_t k = threadIdx.x; k < n; k += kBlock) {
+            const uint32_t at = atomicAdd(&s_nevents, 1u);
+            if (at < p.merged_event_cap)
+                p.merged_events[at] = p.events[(size_t)b * p.event_cap + k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        taken_out[1] = s_nevents;
     for (uint32_t b = 0; b <= last_span; b++) {
         const ts_wg_entry *list = p.lists + (size_t)b * TS_PIDS;
         const uint32_t n = p.list_counts[b];

@@ -34,7 +34,9 @@ struct ts_hip_ctx {
     ts_wg_entry *d_lists = nullptr;
     uint32_t *d_list_counts = nullptr, *d_span_stopped = nullptr, *d_count = nullptr;
     unsigned long long *d_span_done = nullptr, *d_first = nullptr, *d_last = nullptr, *d_taken = nullptr;
-    unsigned long long *h_taken = nullptr;                  // pinned
+    uint32_t *d_events = nullptr, *d_event_counts = nullptr, *d_merged_events = nullptr;
+    uint32_t *h_events = nullptr;                           // pinned
+    unsigned long long *h_taken = nullptr;                  // pinned: [0] units taken, [1] quirk events
     unsigned char *h_window = nullptr;                      // pinned: what the walker looks at
     void *h_tables = nullptr;                               // pinned: count / first / last read back at the end
     int spans = 0;
@@ -46,6 +48,8 @@ namespace {
 char g_ts_open_error[256] = "";
 constexpr size_t kWindow = 1 << 16;       // bytes the walker gets per hand-over
 constexpr uint64_t kMaxUnitsPerLaunch = 1ull << 31;
+constexpr uint32_t kEventCap = 1024;             // per workgroup: harmless read-boundary events (one packet in 4096 at most)
+constexpr uint32_t kMergedEventCap = 1u << 20;
 
 int ts_fail(ts_hip_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -139,8 +143,12 @@ int ts_hip_open(ts_hip_ctx **out, int device)
     OPENCHK(hipMalloc((void **)&ctx->d_count, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long))));
     ctx->d_first = reinterpret_cast<unsigned long long *>(ctx->d_count + TS_PIDS);
     ctx->d_last = ctx->d_first + TS_PIDS;
-    OPENCHK(hipMalloc((void **)&ctx->d_taken, sizeof(unsigned long long)));
-    OPENCHK(hipHostMalloc((void **)&ctx->h_taken, sizeof(unsigned long long), hipHostMallocDefault));
+    OPENCHK(hipMalloc((void **)&ctx->d_taken, 2 * sizeof(unsigned long long)));
+    OPENCHK(hipHostMalloc((void **)&ctx->h_taken, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    OPENCHK(hipMalloc((void **)&ctx->d_events, (size_t)ctx->spans * kEventCap * sizeof(uint32_t)));
+    OPENCHK(hipMalloc((void **)&ctx->d_event_counts, ctx->spans * sizeof(uint32_t)));
+    OPENCHK(hipMalloc((void **)&ctx->d_merged_events, (size_t)kMergedEventCap * sizeof(uint32_t)));
+    OPENCHK(hipHostMalloc((void **)&ctx->h_events, (size_t)kMergedEventCap * sizeof(uint32_t), hipHostMallocDefault));
     OPENCHK(hipHostMalloc((void **)&ctx->h_window, kWindow, hipHostMallocDefault));
     OPENCHK(hipHostMalloc(&ctx->h_tables, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long)), hipHostMallocDefault));
     OPENCHK(hipEventCreate(&ctx->ev_a));
@@ -166,6 +174,10 @@ void ts_hip_close(ts_hip_ctx *ctx)
     if (ctx->d_span_done) (void)hipFree(ctx->d_span_done);
     if (ctx->d_count) (void)hipFree(ctx->d_count);
     if (ctx->d_taken) (void)hipFree(ctx->d_taken);
+    if (ctx->d_events) (void)hipFree(ctx->d_events);
+    if (ctx->d_event_counts) (void)hipFree(ctx->d_event_counts);
+    if (ctx->d_merged_events) (void)hipFree(ctx->d_merged_events);
+    if (ctx->h_events) (void)hipHostFree(ctx->h_events);
     if (ctx->h_taken) (void)hipHostFree(ctx->h_taken);
     if (ctx->h_window) (void)hipHostFree(ctx->h_window);
     if (ctx->h_tables) (void)hipHostFree(ctx->h_tables);
@@ -325,18 +337,42 @@ int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
             p.list_counts = ctx->d_list_counts;
             p.span_done = ctx->d_span_done;
             p.span_stopped = ctx->d_span_stopped;
+            p.events = ctx->d_events;
+            p.event_counts = ctx->d_event_counts;
+            p.event_cap = kEventCap;
+            p.merged_events = ctx->d_merged_events;
+            p.merged_event_cap = kMergedEventCap;
             const int blocks = (int)std::min<uint64_t>((uint64_t)ctx->spans, (units + 1023) / 1024);
             TSCHK(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
             ts_launch_scan(ctx->stream, blocks, p);
             ts_launch_merge(ctx->stream, p, (uint32_t)blocks, out->packets, ctx->d_count, ctx->d_first, ctx->d_last, ctx->d_taken);
             TSCHK(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
             TSCHK(ctx, hipGetLastError());
-            TSCHK(ctx, hipMemcpyAsync(ctx->h_taken, ctx->d_taken, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            TSCHK(ctx, hipMemcpyAsync(ctx->h_taken, ctx->d_taken, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
             TSCHK(ctx, hipStreamSynchronize(ctx->stream));
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b) == hipSuccess)
                 ms_total += ms;
-            const uint64_t taken = *ctx->h_taken;
+            const uint64_t taken = ctx->h_taken[0];
+            uint64_t nev = ctx->h_taken[1];
+            if (nev > kMergedEventCap)
+                return ts_fail(ctx, PAPR_E_LIMIT, "more than %u read-boundary events in one launch", kMergedEventCap);
+            if (nev) {
+                // packets that ended one byte past a 16384-byte read of the reference: each is one `skipped 1 bytes`
+                // line, reported when the stream locks again, i.e. with that packet's own number
+                TSCHK(ctx, hipMemcpyAsync(ctx->h_events, ctx->d_merged_events, nev * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                TSCHK(ctx, hipStreamSynchronize(ctx->stream));
+                std::sort(ctx->h_events, ctx->h_events + nev);
+                for (uint64_t k = 0; k < nev; k++) {
+                    if (ctx->h_events[k] >= taken)
+                        continue;  // (cannot happen: events come from the spans in front of the stop)
+                    if (out->nsync_errors < TS_MAX_SYNC_ERRORS) {
+                        out->sync_errors[out->nsync_errors].skipped = 1;
+                        out->sync_errors[out->nsync_errors].at_packet = out->packets + ctx->h_events[k] + 1;
+                    }
+                    out->nsync_errors++;
+                }
+            }
             out->launches++;
             out->packets += taken;
             out->gpu_packets += taken;

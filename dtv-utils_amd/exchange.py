@@ -55,6 +55,10 @@ def _lib():
         L.papr_exchange_unique_id.argtypes = [vp]
         L.papr_exchange_open_rccl.argtypes = [C.POINTER(vp), vp, vp, i32, i32]
         L.papr_exchange_open_ops.argtypes = [C.POINTER(vp), C.POINTER(_Ops), i32, i32]
+        L.papr_exchange_open_local.argtypes = [C.POINTER(vp), i32]
+        L.papr_exchange_open_local.restype = i32
+        L.papr_exchange_abort.argtypes = [vp]
+        L.papr_exchange_abort.restype = None
         L.papr_exchange_close.argtypes = [vp]
         L.papr_exchange_close.restype = None
         L.papr_exchange_last_error.argtypes = [vp]
@@ -72,7 +76,7 @@ def _lib():
 
 ABI_SYMBOLS = ("papr_exchange_unique_id", "papr_exchange_open_rccl", "papr_exchange_open_ops", "papr_exchange_close",
                "papr_exchange_last_error", "papr_exchange_stats", "papr_exchange_counts", "papr_exchange_exact_sum",
-               "papr_exchange_get_timing")
+               "papr_exchange_get_timing", "papr_exchange_open_local", "papr_exchange_abort")
 
 
 class Exchange:
@@ -94,6 +98,16 @@ class Exchange:
         if rc:
             raise PaprError(rc, "papr_exchange_open_ops", L.papr_exchange_last_error(None).decode())
         return cls(x, 0, 1, "none")
+
+    @classmethod
+    def local(cls, n: int) -> List["Exchange"]:
+        """n linked handles for n threads of this process (papr_exchange_open_local: what bin/papr's shard threads use)."""
+        L = _lib()
+        xs = (C.c_void_p * n)()
+        rc = L.papr_exchange_open_local(xs, n)
+        if rc:
+            raise PaprError(rc, "papr_exchange_open_local", L.papr_exchange_last_error(None).decode())
+        return [cls(C.c_void_p(xs[r]), r, n, "threads") for r in range(n)]
 
     @classmethod
     def rccl(cls, gpu, rank: int, world: int, group=None) -> "Exchange":

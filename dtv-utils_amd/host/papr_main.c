@@ -21,6 +21,9 @@
  *                      (papr_hip_load_file_sweep: both passes ride along with the ingest);
  *                      PAPR_ONE_SWEEP=0 turns that off, =1 also uses it for shards that fit
  *                      (no gain there: pass 2 over a resident shard is 1.5 ms, the sample costs 40)
+ * Structure: one thread per GPU shard opens its context, ingests its range of the file (pass 1 rides along
+ * with the copy) and calls papr_hip_analyze — the sequence bench.py times — with the in-process transport of
+ * papr_exchange between the threads; thread 0's result is printed.
  * There is no CPU fallback: without a usable GPU the program exits 254.
  */
 #define _FILE_OFFSET_BITS 64
@@ -38,21 +41,18 @@
 
 typedef struct shard {
     papr_hip_ctx *ctx;
-    int device;
-    double before;       /* accurate sum of the shards before this one */
-    uint64_t n_total;
-    const void *program; /* this shard's exact-sum program */
-    size_t program_bytes;
+    papr_exchange *xch;
+    int device, index, graph, exact, ingest_sweep;
     const char *path;
     uint64_t first, count;
-    papr_stats stats;
-    const float *levels;
-    int nlevels;
+    float *levels;        /* PAPR_HIP_MAX_LEVELS each */
     uint64_t *counts;
-    papr_stats estimate;   /* one-sweep ingest: sampled mean of this shard's file range */
-    const float *guess;    /* ... and the speculative level table (NULL: plain ingest) */
-    int nguess;
+    papr_result res;
+    papr_hip_sweep_info sweep;
+    papr_hip_ingest_timing ingest;
+    double t_open, t_loaded, t_done;
     int rc;
+    char err[300];
 } shard;
 
 static double now_s(void)
@@ -69,75 +69,71 @@ static void usage(void)
     fprintf(stderr, "\tg = graph suitable output\n");
 }
 
-static void *estimate_thread(void *arg)
+static int shard_fail(shard *s, int rc, const char *what)
 {
-    shard *s = (shard *)arg;
-    s->rc = papr_hip_estimate_file(s->ctx, s->path, s->first, s->count, &s->estimate);
-    return NULL;
+    s->rc = rc;
+    snprintf(s->err, sizeof(s->err), "%s: %s (code %d)", what, s->ctx ? papr_hip_last_error(s->ctx) : papr_hip_last_error(NULL), rc);
+    papr_exchange_abort(s->xch); /* the other shards' threads must not wait for this one */
+    return rc;
 }
 
-static void *pass1_thread(void *arg)
+/* everything one GPU does for its shard: context, ingest (papr.c:100-101), analysis (papr.c:102-153 / 164-185) */
+static void *shard_thread(void *arg)
 {
     shard *s = (shard *)arg;
-    if (s->guess)
-        s->rc = papr_hip_load_file_sweep(s->ctx, s->path, s->first, s->count, s->guess, s->nguess);
-    else
-        s->rc = papr_hip_load_file(s->ctx, s->path, s->first, s->count);
-    if (s->rc == PAPR_OK)
-        s->rc = papr_hip_stats(s->ctx, &s->stats);
-    return NULL;
-}
-
-static void *exact_thread(void *arg)
-{
-    shard *s = (shard *)arg;
-    s->rc = papr_hip_ccdf_exact(s->ctx, s->levels, s->nlevels, s->counts, s->before, s->n_total, &s->program,
-                                &s->program_bytes);
-    return NULL;
-}
-
-static void *pass2_thread(void *arg)
-{
-    shard *s = (shard *)arg;
-    s->rc = papr_hip_ccdf(s->ctx, s->levels, s->nlevels, s->counts);
-    return NULL;
-}
-
-/* run fn on every shard, one thread per GPU (a shard whose thread cannot be created runs inline) */
-static void run_shards(shard *sh, int n, void *(*fn)(void *))
-{
-    pthread_t th[MAX_GPUS];
-    int started[MAX_GPUS];
-    for (int g = 1; g < n; g++)
-        started[g] = pthread_create(&th[g], NULL, fn, &sh[g]) == 0;
-    fn(&sh[0]);
-    for (int g = 1; g < n; g++) {
-        if (started[g])
-            pthread_join(th[g], NULL);
-        else
-            fn(&sh[g]);
+    int rc = papr_hip_open(&s->ctx, s->device);
+    if (rc != PAPR_OK) {
+        shard_fail(s, rc, "cannot open the GPU");
+        return NULL;
     }
-}
-
-/* like run_all below, but a failure is not fatal (the caller has another way): no message here */
-static int run_all_quiet(shard *sh, int n, void *(*fn)(void *))
-{
-    run_shards(sh, n, fn);
-    for (int g = 0; g < n; g++)
-        if (sh[g].rc != PAPR_OK)
-            return sh[g].rc;
-    return PAPR_OK;
-}
-
-static int run_all(shard *sh, int n, void *(*fn)(void *))
-{
-    run_shards(sh, n, fn);
-    for (int g = 0; g < n; g++)
-        if (sh[g].rc != PAPR_OK) {
-            fprintf(stderr, "papr: GPU %d: %s (code %d)\n", sh[g].device, papr_hip_last_error(sh[g].ctx), sh[g].rc);
-            return sh[g].rc;
+    papr_hip_set_exact(s->ctx, s->exact);
+    s->t_open = now_s();
+    if (s->ingest_sweep == 1) {
+        /* "when the file is streamed": does any shard exceed its GPU's HBM budget?  (decided together: every thread
+         * must take the same path through the exchanges) */
+        uint64_t nofit = papr_hip_shard_fits(s->ctx, s->count) == 0 ? 1u : 0u;
+        rc = papr_exchange_counts(s->xch, &nofit, 1);
+        if (rc != PAPR_OK) {
+            shard_fail(s, rc, "exchange");
+            return NULL;
         }
-    return PAPR_OK;
+        s->ingest_sweep = nofit > 0 ? 2 : 0;
+    }
+    if (s->ingest_sweep) {
+        /* one read of the FILE for both passes: a 1-in-64 sample of every shard gives the mean to ~1e-4, the level
+         * table it implies is widened into bands, and pass 2 rides along with pass 1 on the ingest */
+        papr_stats est, est_total;
+        double before = 0.0;
+        rc = papr_hip_estimate_file(s->ctx, s->path, s->first, s->count, &est);
+        if (rc != PAPR_OK) {
+            shard_fail(s, rc, "estimate");
+            return NULL;
+        }
+        rc = papr_exchange_stats(s->xch, &est, &est_total, &before, NULL);
+        if (rc != PAPR_OK) {
+            shard_fail(s, rc, "exchange");
+            return NULL;
+        }
+        const int nguess = est_total.n ? papr_guess_levels(&est_total, s->graph, s->graph ? 48.0 : 60.0, s->levels, PAPR_HIP_MAX_LEVELS) : 0;
+        papr_hip_set_band(s->ctx, papr_sweep_band_for(&est_total));
+        rc = papr_hip_load_file_sweep(s->ctx, s->path, s->first, s->count, s->levels, nguess);
+    } else {
+        rc = papr_hip_load_file(s->ctx, s->path, s->first, s->count);
+    }
+    if (rc != PAPR_OK) {
+        shard_fail(s, rc, "ingest");
+        return NULL;
+    }
+    papr_hip_get_ingest_timing(s->ctx, &s->ingest);
+    s->t_loaded = now_s();
+    rc = papr_hip_analyze(s->ctx, s->xch, s->graph, 0, &s->res, s->levels, s->counts, PAPR_HIP_MAX_LEVELS);
+    if (rc != PAPR_OK) {
+        shard_fail(s, rc, "analysis");
+        return NULL;
+    }
+    papr_hip_get_sweep_info(s->ctx, &s->sweep);
+    s->t_done = now_s();
+    return NULL;
 }
 
 int main(int argc, char **argv)
@@ -173,7 +169,6 @@ int main(int argc, char **argv)
     fclose(probe);
 
     const double t0 = now_s();
-    double t_open = t0;
     uint64_t nsamples = 0;
     if (papr_file_samples(path, &nsamples) != PAPR_OK) {
         fprintf(stderr, "Cannot open bitstream file <%s>\n", path);
@@ -204,10 +199,10 @@ int main(int argc, char **argv)
         ngpu = visible;
     if (ngpu > MAX_GPUS)
         ngpu = MAX_GPUS;
-
     env = getenv("PAPR_EXACT_SUM");
-    int exact = !(env && atoi(env) == 0 && env[0] != '\0');
-    shard sh[MAX_GPUS];
+    const int exact = !(env && atoi(env) == 0 && env[0] != '\0');
+
+    static shard sh[MAX_GPUS];
     memset(sh, 0, sizeof(sh));
     uint64_t per = (nsamples + (uint64_t)ngpu - 1) / (uint64_t)ngpu;
     per = (per + SHARD_ALIGN - 1) / SHARD_ALIGN * SHARD_ALIGN;
@@ -216,134 +211,80 @@ int main(int argc, char **argv)
         const uint64_t first = (uint64_t)g * per;
         if (g > 0 && first >= nsamples)
             break;
+        sh[g].index = g;
         sh[g].device = g % visible;
         sh[g].path = path;
+        sh[g].graph = graph;
+        sh[g].exact = exact;
         sh[g].first = first;
         sh[g].count = first + per > nsamples ? nsamples - first : per;
-        int rc = papr_hip_open(&sh[g].ctx, sh[g].device);
-        if (rc != PAPR_OK) {
-            fprintf(stderr, "papr: cannot open GPU %d: %s\n", sh[g].device, papr_hip_last_error(NULL));
-            return 254;
-        }
-        papr_hip_set_exact(sh[g].ctx, exact);
         used++;
     }
     ngpu = used;
-    t_open = now_s();
 
-    /* ---- one-sweep ingest (tree-sum mode only: the exact-sum sweep needs pass 1's per-tile sums first):
-     * a 1-in-64 tile sample of every shard gives the mean to ~1e-4, the level table it implies is widened
-     * into bands, and pass 2 then rides along with pass 1 on the one read of the file ---- */
-    float *guess = NULL;
+    /* one-sweep ingest (tree-sum mode): by default for shards that will not stay in HBM, where it saves a whole
+     * second read of the file (the shard threads settle that between them once their contexts know the budget) */
     env = getenv("PAPR_ONE_SWEEP");
-    int one_sweep = env && env[0] != '\0' ? (atoi(env) > 0 ? 2 : 0) : 1; /* 2 = forced, 1 = when the file is streamed */
-    if (one_sweep == 1) {
-        one_sweep = 0;
-        for (int g = 0; g < ngpu; g++)
-            if (papr_hip_shard_fits(sh[g].ctx, sh[g].count) == 0)
-                one_sweep = 1;
+    const int one_sweep = env && env[0] != '\0' ? (atoi(env) > 0 ? 2 : 0) : 1; /* 2 = always, 1 = when the file is streamed */
+    papr_exchange *xs[MAX_GPUS];
+    if (papr_exchange_open_local(xs, ngpu) != PAPR_OK) {
+        fprintf(stderr, "papr: out of memory\n");
+        return 253;
     }
-    if (!exact && one_sweep && run_all_quiet(sh, ngpu, estimate_thread) == PAPR_OK) {
-        papr_stats est_total;
-        papr_stats_init(&est_total);
-        for (int g = 0; g < ngpu; g++)
-            papr_stats_merge(&est_total, &sh[g].estimate);
-        guess = (float *)malloc(PAPR_HIP_MAX_LEVELS * sizeof(float));
-        const int nguess = guess ? papr_guess_levels(&est_total, graph, graph ? 48.0 : 60.0, guess, PAPR_HIP_MAX_LEVELS) : 0;
-        for (int g = 0; g < ngpu && nguess > 0; g++) {
-            sh[g].guess = guess;
-            sh[g].nguess = nguess;
+    for (int g = 0; g < ngpu; g++) {
+        sh[g].xch = xs[g];
+        sh[g].ingest_sweep = exact ? 0 : one_sweep;
+        sh[g].levels = (float *)malloc(PAPR_HIP_MAX_LEVELS * sizeof(float));
+        sh[g].counts = (uint64_t *)calloc(PAPR_HIP_MAX_LEVELS, sizeof(uint64_t));
+        if (!sh[g].levels || !sh[g].counts) {
+            fprintf(stderr, "papr: out of memory\n");
+            return 253;
         }
-    }
-    const double t_est = now_s();
-
-    /* ---- pass 1 on every shard, then fold in file order (papr.c:100-129) ---- */
-    if (run_all(sh, ngpu, pass1_thread) != PAPR_OK)
-        return 253;
-    const double t1 = now_s();
-    papr_stats total;
-    papr_stats_init(&total);
-    for (int g = 0; g < ngpu; g++) {
-        sh[g].before = total.sum; /* accurate sum of everything before shard g */
-        sh[g].n_total = nsamples;
-        papr_stats_merge(&total, &sh[g].stats);
-    }
-    /* ---- host scalars (papr.c:131-141 / 164-173), here from the tree sum ---- */
-    double mean;
-    float papr;
-    int nlevels = papr_levels(&total, graph, &mean, &papr, NULL, 0);
-    if (nlevels > PAPR_HIP_MAX_LEVELS) {
-        fprintf(stderr, "papr: %d levels exceed the supported maximum of %d\n", nlevels, PAPR_HIP_MAX_LEVELS);
-        return 253;
-    }
-    float *level = (float *)malloc((size_t)(nlevels + 1) * sizeof(float));
-    uint64_t *count = (uint64_t *)calloc((size_t)(nlevels + 1), sizeof(uint64_t));
-    papr_levels(&total, graph, NULL, NULL, level, nlevels);
-    for (int g = 0; g < ngpu; g++) {
-        sh[g].levels = level;
-        sh[g].nlevels = nlevels;
-        sh[g].counts = (uint64_t *)calloc((size_t)(nlevels + 1), sizeof(uint64_t));
     }
 
-    /* ---- pass 2 on every shard (papr.c:142-153 / 174-185).  papr.c:104 adds in file order in double; by
-     * default that rounding sequence is reproduced exactly from the same sweep (papr_hip_ccdf_exact); with
-     * NaN/Inf present the merged record already carries the reference's value. ---- */
-    int exact_done = 0, need_pass2 = nlevels > 0;
-    double t1x = now_s();
-    int exact_rc = PAPR_OK;
-    if (exact && isfinite(total.sum) && (exact_rc = run_all_quiet(sh, ngpu, exact_thread)) == PAPR_OK) {
-        const void *progs[MAX_GPUS];
-        size_t sizes[MAX_GPUS];
-        double seq;
-        for (int g = 0; g < ngpu; g++) {
-            progs[g] = sh[g].program;
-            sizes[g] = sh[g].program_bytes;
-        }
-        exact_rc = papr_exact_chain(progs, sizes, ngpu, &seq);
-        if (exact_rc == PAPR_OK) {
-            total.sum = seq;
-            exact_done = 1;
-            need_pass2 = 0;
-            /* the exact sum almost never moves a float threshold; when it does, pass 2 runs again */
-            float *level2 = (float *)malloc((size_t)(nlevels + 1) * sizeof(float));
-            const int nlevels2 = papr_levels(&total, graph, &mean, &papr, level2, nlevels);
-            if (nlevels2 != nlevels || memcmp(level, level2, (size_t)nlevels * sizeof(float)) != 0) {
-                free(level2);
-                if (nlevels2 > PAPR_HIP_MAX_LEVELS)
-                    return 253;
-                nlevels = nlevels2;
-                level = (float *)realloc(level, (size_t)(nlevels + 1) * sizeof(float));
-                count = (uint64_t *)realloc(count, (size_t)(nlevels + 1) * sizeof(uint64_t));
-                papr_levels(&total, graph, NULL, NULL, level, nlevels);
-                for (int g = 0; g < ngpu; g++) {
-                    sh[g].levels = level;
-                    sh[g].nlevels = nlevels;
-                    sh[g].counts = (uint64_t *)realloc(sh[g].counts, (size_t)(nlevels + 1) * sizeof(uint64_t));
-                }
-                need_pass2 = nlevels > 0;
-            } else {
-                free(level2);
-            }
-        }
-        t1x = now_s();
-    }
-    if (exact_rc != PAPR_OK) {
-        /* stdout stays the reference's format; the mean (and, rarely, a threshold) now comes from the parallel
-         * tree sum, which may differ from the reference's sequential sum in the last printed digit: say so */
-        const char *why = "";
+    /* ---- one thread per shard (a shard whose thread cannot be created runs inline, last) ---- */
+    pthread_t th[MAX_GPUS];
+    int started[MAX_GPUS];
+    for (int g = 1; g < ngpu; g++)
+        started[g] = pthread_create(&th[g], NULL, shard_thread, &sh[g]) == 0;
+    int inline_late = 0;
+    for (int g = 1; g < ngpu; g++)
+        inline_late |= !started[g];
+    if (inline_late) { /* cannot meet the others at the exchange from one thread: give up cleanly */
         for (int g = 0; g < ngpu; g++)
-            if (sh[g].rc != PAPR_OK)
-                why = papr_hip_last_error(sh[g].ctx);
-        fprintf(stderr, "papr: warning: bit-exact sequential sum abandoned (code %d%s%s); using the parallel sum\n",
-                exact_rc, why[0] ? ": " : "", why);
-    }
-    if (need_pass2 && run_all(sh, ngpu, pass2_thread) != PAPR_OK)
+            papr_exchange_abort(xs[g]);
+        for (int g = 1; g < ngpu; g++)
+            if (started[g])
+                pthread_join(th[g], NULL);
+        fprintf(stderr, "papr: cannot start a thread per GPU shard\n");
         return 253;
-    memset(count, 0, (size_t)(nlevels + 1) * sizeof(uint64_t));
+    }
+    shard_thread(&sh[0]);
+    for (int g = 1; g < ngpu; g++)
+        pthread_join(th[g], NULL);
     for (int g = 0; g < ngpu; g++)
-        for (int j = 0; j < nlevels; j++)
-            count[j] += sh[g].counts[j];
+        if (sh[g].rc != PAPR_OK && sh[g].rc != PAPR_E_STATE) { /* (E_STATE: cancelled because another shard failed) */
+            fprintf(stderr, "papr: GPU %d: %s\n", sh[g].device, sh[g].err);
+            return sh[g].ctx ? 253 : 254;
+        }
+    for (int g = 0; g < ngpu; g++)
+        if (sh[g].rc != PAPR_OK) {
+            fprintf(stderr, "papr: GPU %d: %s\n", sh[g].device, sh[g].err);
+            return 253;
+        }
     const double t2 = now_s();
+
+    /* every thread holds the same result; print shard 0's */
+    const papr_result *r = &sh[0].res;
+    const papr_stats total = r->total;
+    const double mean = r->mean;
+    const float papr = r->papr;
+    const int nlevels = r->nlevels;
+    const uint64_t *count = sh[0].counts;
+    if (exact && !r->exact_sum && isfinite(total.sum))
+        /* stdout stays the reference's format; the mean (and, rarely, a threshold) now comes from the parallel tree
+         * sum, which may differ from the reference's sequential sum in the last printed digit: say so */
+        fprintf(stderr, "papr: warning: bit-exact sequential sum abandoned; using the parallel sum\n");
 
     /* ---- output, byte for byte the reference's (papr.c:132-135,154-161 / 186-190) ---- */
     const long long offset = (long long)total.n;
@@ -369,36 +310,33 @@ int main(int argc, char **argv)
     env = getenv("PAPR_STATS");
     if (env && atoi(env) > 0) {
         const double t3 = now_s();
-        papr_hip_ingest_timing it;
-        memset(&it, 0, sizeof(it));
-        papr_hip_get_ingest_timing(sh[0].ctx, &it);
         int swept = 0, resolved = 0;
+        double t_open = t0, t_loaded = t0;
         for (int g = 0; g < ngpu; g++) {
-            papr_hip_sweep_info si;
-            memset(&si, 0, sizeof(si));
-            papr_hip_get_sweep_info(sh[g].ctx, &si);
-            swept += si.swept;
-            resolved += si.resolved;
+            swept += sh[g].sweep.swept;
+            resolved += sh[g].sweep.resolved;
+            if (sh[g].t_open > t_open) t_open = sh[g].t_open;
+            if (sh[g].t_loaded > t_loaded) t_loaded = sh[g].t_loaded;
         }
+        const papr_hip_ingest_timing *it = &sh[0].ingest;
         fprintf(stderr,
                 "{\"samples\": %llu, \"bytes\": %llu, \"gpus\": %d, \"levels\": %d, \"open_s\": %.6f, "
-                "\"estimate_s\": %.6f, \"shards_swept\": %d, \"shards_resolved_from_sweep\": %d, "
-                "\"ingest_pass1_s\": %.6f, \"exact_sum\": %d, \"exact_sum_s\": %.6f, \"pass2_s\": %.6f, \"total_s\": %.6f, \"msamples_per_s\": %.3f, "
-                "\"ingest_GBps\": %.2f, \"gpu0_ingest\": {\"setup_s\": %.4f, \"read_s\": %.4f, \"buffer_wait_s\": %.4f, "
-                "\"issue_s\": %.4f, \"drain_s\": %.4f, \"chunks\": %llu, \"reader_threads\": %d, \"resident\": %d, \"o_direct\": %d, \"numa_bound\": %d}}\n",
-                (unsigned long long)nsamples, (unsigned long long)nsamples * 8, ngpu, nlevels, t_open - t0,
-                t_est - t_open, swept, resolved, t1 - t_est,
-                exact_done, t1x - t1, t2 - t1x, t3 - t0, (double)nsamples / (t3 - t0) / 1e6, (double)nsamples * 8 / (t1 - t_est) / 1e9,
-                it.setup_s, it.read_s, it.buffer_wait_s, it.issue_s, it.drain_s, (unsigned long long)it.chunks,
-                it.reader_threads, it.resident, it.o_direct, it.numa_bound);
+                "\"shards_swept\": %d, \"shards_resolved_from_sweep\": %d, "
+                "\"ingest_pass1_s\": %.6f, \"exact_sum\": %d, \"exact_redo_tiles\": %u, \"analysis_s\": %.6f, \"total_s\": %.6f, "
+                "\"msamples_per_s\": %.3f, \"ingest_GBps\": %.2f, \"gpu0_ingest\": {\"setup_s\": %.4f, \"read_s\": %.4f, "
+                "\"buffer_wait_s\": %.4f, \"issue_s\": %.4f, \"drain_s\": %.4f, \"chunks\": %llu, \"reader_threads\": %d, "
+                "\"resident\": %d, \"o_direct\": %d, \"numa_bound\": %d}}\n",
+                (unsigned long long)nsamples, (unsigned long long)nsamples * 8, ngpu, nlevels, t_open - t0, swept, resolved,
+                t_loaded - t_open, r->exact_sum, r->exact_redo_tiles, t2 - t_loaded, t3 - t0, (double)nsamples / (t3 - t0) / 1e6,
+                (double)nsamples * 8 / (t_loaded - t_open) / 1e9, it->setup_s, it->read_s, it->buffer_wait_s, it->issue_s,
+                it->drain_s, (unsigned long long)it->chunks, it->reader_threads, it->resident, it->o_direct, it->numa_bound);
     }
 
     for (int g = 0; g < ngpu; g++) {
         free(sh[g].counts);
+        free(sh[g].levels);
         papr_hip_close(sh[g].ctx);
+        papr_exchange_close(xs[g]);
     }
-    free(count);
-    free(level);
-    free(guess);
     return 0;
 }

@@ -279,6 +279,15 @@ int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_s
  * dB above the mean whatever the peak turns out to be (the real table's length depends on the true
  * peak; bands above it cost nothing).  Returns the number of levels written (<= cap). */
 int papr_guess_levels(const papr_stats *est_total, int graph, double max_db, float *levels, int cap);
+/* How wide the bands must be for THIS estimate: papr_hip_estimate also measures the scatter of its sample pieces and
+ * leaves the estimate's relative standard error in est->peak (papr_stats_merge keeps the largest of the shards').
+ * papr_sweep_band_for turns it into a band half-width (log2 of float bit patterns, 10..20) that the true
+ * thresholds miss with a probability of a few in a million: 2^14 for a stationary capture sampled 1 in 64, wider
+ * for a bursty one — which then stashes more samples but is still answered from one read — narrower when the
+ * sample was (nearly) everything.  papr_hip_set_band hands it to the next papr_hip_stats_sweep /
+ * papr_hip_load_file_sweep of the context (0 = the built-in default; PAPR_HIP_TUNE band= overrides both). */
+int papr_sweep_band_for(const papr_stats *est_total);
+int papr_hip_set_band(papr_hip_ctx *ctx, int band_log2);
 int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, papr_stats *out);
 /* papr_hip_load_file as a one-sweep ingest: the kernel that runs on every chunk as it lands also bins against the
  * guessed bands and stashes, so papr_hip_stats returns the file's pass-1 record as usual and papr_hip_ccdf needs
@@ -339,6 +348,42 @@ int papr_exchange_stats(papr_exchange *x, const papr_stats *local, papr_stats *t
 int papr_exchange_counts(papr_exchange *x, uint64_t *counts, int n);
 int papr_exchange_exact_sum(papr_exchange *x, const void *program, size_t bytes, double *sum);
 int papr_exchange_get_timing(papr_exchange *x, papr_exchange_timing *out, int reset);
+
+/* An in-process transport for papr_exchange: n handles for n threads of ONE process that each drive one GPU (what
+ * bin/papr does): the same exchange calls, met at a barrier instead of on a wire. xs receives n handles. */
+int papr_exchange_open_local(papr_exchange **xs, int n);
+/* a thread that cannot go on (its GPU failed) cancels the in-process exchange: the other threads' pending and future
+ * exchange calls return PAPR_E_STATE instead of waiting for it (no-op for the other transports) */
+void papr_exchange_abort(papr_exchange *x);
+
+/* ---- the whole result in one call --------------------------------------------------------------------
+ * papr_hip_analyze runs, for the shard loaded in `ctx` and — through `x` — together with the other shards'
+ * processes / threads, everything papr.c:100-153 / 164-185 computes: the mean estimate and its exchange, the
+ * guessed bands, ONE sweep over the samples (pass 1 + banded pass 2, in exact-sum mode also the rounding functions of
+ * the sequential sum), the exchange of the pass-1 records and their ordered merge, mean / PAPR / level table exactly
+ * as the reference derives them, the stash recount (or, speculation missed, pass 2), in exact-sum mode the chained
+ * sequential sum (papr_hip_set_exact), and the exchange of the counters.  It is the sequence bench.py times and
+ * bin/papr prints from; every step is one of the calls above and can be made separately.  `x` may be NULL for a
+ * single shard.  levels / counts_above: caller's arrays of `cap` entries (PAPR_HIP_MAX_LEVELS always suffices);
+ * all ranks receive the same result. */
+#define PAPR_ANALYZE_TWO_PASS 1u /* no speculation: pass 1, then pass 2 (two reads of the shard) */
+#define PAPR_ANALYZE_SPOIL_GUESS 2u /* diagnostics: feed the sweep a guess that is 3 % off (what a missed speculation costs) */
+typedef struct papr_result {
+    papr_stats total;       /* whole file; .sum is the reference's sequential sum when exact_sum != 0 */
+    double mean;            /* papr.c:131 / 164 */
+    float papr;             /* papr.c:134 / 165 */
+    int nlevels;            /* papr.c:136 / 166 */
+    int exact_sum;          /* 1 = total.sum reproduces papr.c:104 bit for bit; 0 = parallel tree sum */
+    int swept;              /* 1 = this shard went through the one-sweep kernel */
+    int resolved;           /* 1 = this shard's counts came from the sweep (no second read) */
+    int reason;             /* PAPR_SWEEP_* when not */
+    int pass2_reruns;       /* exact mode: 1 if the exact sum moved a float threshold and the counts were redone */
+    uint32_t exact_redo_tiles;
+    int band_log2;
+    int reserved;
+} papr_result;
+int papr_hip_analyze(papr_hip_ctx *ctx, papr_exchange *x, int graph, unsigned flags, papr_result *res, float *levels,
+                     uint64_t *counts_above, int cap);
 
 /* ---- pass 2 (papr.c:143-153 / 175-185) ---------------------------------- */
 /* counts_above[j] = number of shard samples whose power is > levels[j]

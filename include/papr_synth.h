@@ -37,9 +37,21 @@ typedef struct papr_synth_override {
 typedef struct papr_synth_spec {
     uint64_t seed;
     float scale; /* 0 => 2^-16 */
-    uint32_t n_overrides;
+    uint32_t n_overrides; /* bits 0-7: forced samples in ov[]; bits 8-15: envelope, PAPR_SYNTH_ENV_* */
     papr_synth_override ov[PAPR_SYNTH_MAX_OVERRIDES];
 } papr_synth_spec;
+
+/* Envelopes (what the one-sweep speculation finds easy or hard):
+ *   GAUSS     the default above: stationary, near-Gaussian
+ *   CONSTANT  constant envelope (|I| = |Q| = 53510 * scale, signs from the hash: a QPSK-like phase-only signal): every
+ *             power is the same number, i.e. every sample sits exactly on the 0 dB threshold
+ *   BURSTY    on/off keying in bursts of 4096 samples, a quarter of them silent (exact zeros): a 1/64 sample of such
+ *             a capture estimates its mean ten times worse than that of a stationary one */
+#define PAPR_SYNTH_ENV_GAUSS 0u
+#define PAPR_SYNTH_ENV_CONSTANT 1u
+#define PAPR_SYNTH_ENV_BURSTY 2u
+#define PAPR_SYNTH_ENV(sp) (((sp)->n_overrides >> 8) & 0xffu)
+#define PAPR_SYNTH_NOV(sp) ((sp)->n_overrides & 0xffu)
 
 PAPR_SYNTH_FN uint64_t papr_synth_mix(uint64_t x)
 {
@@ -72,7 +84,17 @@ PAPR_SYNTH_FN void papr_synth_sample(const papr_synth_spec *sp, uint64_t index, 
     float scale = sp->scale != 0.0f ? sp->scale : (1.0f / 65536.0f);
     float vi = papr_synth_component(sp->seed, scale, index, 0);
     float vq = papr_synth_component(sp->seed, scale, index, 1);
-    for (uint32_t k = 0; k < sp->n_overrides && k < PAPR_SYNTH_MAX_OVERRIDES; k++) {
+    const uint32_t env = PAPR_SYNTH_ENV(sp);
+    if (env == PAPR_SYNTH_ENV_CONSTANT) {
+        vi = (vi < 0.0f ? -53510.0f : 53510.0f) * scale;
+        vq = (vq < 0.0f ? -53510.0f : 53510.0f) * scale;
+    } else if (env == PAPR_SYNTH_ENV_BURSTY) {
+        if ((papr_synth_mix(sp->seed ^ ((index >> 12) * 0xA24BAED4963EE407ull)) & 3u) == 0) {
+            vi = 0.0f;
+            vq = 0.0f;
+        }
+    }
+    for (uint32_t k = 0; k < PAPR_SYNTH_NOV(sp) && k < PAPR_SYNTH_MAX_OVERRIDES; k++) {
         if (sp->ov[k].index == index) {
             vi = sp->ov[k].i;
             vq = sp->ov[k].q;

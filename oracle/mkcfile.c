@@ -4,7 +4,7 @@
  * include/papr_synth.h and is shared with the HIP generator kernel.
  *
  * usage: mkcfile <out> <nsamples> [--seed S] [--scale F] [--spike]
- *                [--set IDX I Q]... [--extra-floats K] [--extra-bytes B]
+ *                [--set IDX I Q]... [--extra-floats K] [--extra-bytes B] [--envelope constant|bursty]
  *   --spike         the bench workload: two equal 30 dB spikes (papr_synth_spike_spec)
  *   --set           force sample IDX to (I,Q); accepts nan/inf; up to 8
  *   --extra-floats  append K more floats (continuing the I/Q stream) => odd tails
@@ -31,6 +31,7 @@ int main(int argc, char **argv)
     sp.seed = PAPR_SYNTH_DEFAULT_SEED;
     uint64_t extra_floats = 0;
     int extra_bytes = 0, spike = 0;
+    uint32_t envelope = 0;
     for (int a = 3; a < argc; a++) {
         if (!strcmp(argv[a], "--seed") && a + 1 < argc) {
             sp.seed = strtoull(argv[++a], NULL, 0);
@@ -39,7 +40,7 @@ int main(int argc, char **argv)
         } else if (!strcmp(argv[a], "--spike")) {
             spike = 1;
         } else if (!strcmp(argv[a], "--set") && a + 3 < argc) {
-            if (sp.n_overrides >= PAPR_SYNTH_MAX_OVERRIDES) {
+            if (PAPR_SYNTH_NOV(&sp) >= PAPR_SYNTH_MAX_OVERRIDES) {
                 fprintf(stderr, "mkcfile: too many --set\n");
                 return 2;
             }
@@ -47,6 +48,9 @@ int main(int argc, char **argv)
             o->index = strtoull(argv[++a], NULL, 0);
             o->i = strtof(argv[++a], NULL);
             o->q = strtof(argv[++a], NULL);
+        } else if (!strcmp(argv[a], "--envelope") && a + 1 < argc) {
+            ++a;
+            envelope = !strcmp(argv[a], "constant") ? PAPR_SYNTH_ENV_CONSTANT : !strcmp(argv[a], "bursty") ? PAPR_SYNTH_ENV_BURSTY : 0u;
         } else if (!strcmp(argv[a], "--extra-floats") && a + 1 < argc) {
             extra_floats = strtoull(argv[++a], NULL, 0);
         } else if (!strcmp(argv[a], "--extra-bytes") && a + 1 < argc) {
@@ -62,6 +66,7 @@ int main(int argc, char **argv)
         papr_synth_spike_spec(&sp, seed, n);
         sp.scale = scale;
     }
+    sp.n_overrides |= envelope << 8;
     FILE *fp = fopen(path, "wb");
     if (!fp) {
         perror(path);

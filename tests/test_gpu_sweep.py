@@ -415,3 +415,78 @@ def test_golden_fixtures_through_the_one_sweep_ingest(pkg, gpu, name, graph):
     mean, papr, table = pkg.levels(st, graph)
     counts = gpu.ccdf(table)
     assert pkg.format_report(st, mean, papr, counts, graph).encode() == golden_text(name, graph)
+
+
+# ---- papr_hip_analyze: the whole result in one call, alone and with peers ------------------------------------------
+
+@pytest.mark.parametrize("exact", [False, True], ids=["tree", "exact"])
+@pytest.mark.parametrize("graph", [False, True], ids=["default", "graph"])
+def test_analyze_is_the_reference_result(pkg, orc, graph, exact):
+    """papr_hip_analyze (one call: estimate, sweep, host scalars, recount, exact chain) against the oracle, also with
+    the speculation switched off or spoiled — the result may not depend on how many reads it took."""
+    n = 3 * 1048576 + 4099
+    with pkg.PaprHip(0) as g:
+        g.set_exact(exact)
+        g.generate(pkg.SynthSpec.spike(n, seed=321), 0, n)
+        iq = g.download(0, n)
+        ref = orc.run_mem(iq, graph)
+        for kw in (dict(), dict(two_pass=True), dict(spoil_guess=True)):
+            res, table, counts = g.analyze(None, graph, **kw)
+            check_stats(res.total, ref)
+            assert res.nlevels == table.size == ref["level"].size and res.exact_sum == int(exact)
+            if exact:
+                assert res.total.sum == ref["sum"] and res.mean == ref["mean"] and res.papr == ref["papr"]
+                assert np.array_equal(table, ref["level"]) and np.array_equal(counts.astype(np.int64), ref["count"])
+            else:
+                assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
+            if not kw:
+                assert res.swept == 1 and res.resolved == 1
+            elif "two_pass" in kw:
+                assert res.swept == 0 and res.resolved == 0
+            else:
+                assert res.swept == 1 and res.resolved == 0   # out of band: the counts came from a second read
+
+
+@pytest.mark.parametrize("exact", [False, True], ids=["tree", "exact"])
+def test_analyze_with_peers_over_the_in_process_exchange(pkg, orc, exact):
+    """three shards of one stream, three threads, three contexts on one GPU, papr_exchange_open_local between them
+    (what bin/papr does): every thread must return the oracle's whole-file result."""
+    import threading
+    from dtv_utils_amd import exchange
+    n = 3 * 700000 + 123
+    with pkg.PaprHip(0) as g0:
+        g0.generate(pkg.SynthSpec.spike(n, seed=17), 0, n)
+        iq = g0.download(0, n)
+    ref = orc.run_mem(iq, True)
+    world = 3
+    xs = exchange.Exchange.local(world)
+    out, errs = [None] * world, []
+
+    def work(r):
+        try:
+            first, cnt = exchange.shard_range(n, r, world)
+            with pkg.PaprHip(0) as g:
+                g.set_exact(exact)
+                g.upload(iq[2 * first:2 * (first + cnt)], base_index=first)
+                out[r] = g.analyze(xs[r], True)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+            pkg.lib().papr_exchange_abort(xs[r]._x)
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for r in range(world):
+        res, table, counts = out[r]
+        check_stats(res.total, ref)
+        if exact:
+            assert res.total.sum == ref["sum"] and np.array_equal(table, ref["level"])
+            assert np.array_equal(counts.astype(np.int64), ref["count"])
+        else:
+            assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
+        assert res.total.to_bytes() == out[0][0].total.to_bytes() and np.array_equal(counts, out[0][2])
+    for x in xs:
+        x.close()
