@@ -7,7 +7,8 @@ ARCH    ?= gfx950
 PKG     := dtv-utils_amd
 CSRC    := $(PKG)/csrc
 LIB     := $(PKG)/libpaprhip.so
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-result
+# MEASURE=1 also compiles the kernel geometries / ablations that only the measurement tools under tools/ select
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-result $(if $(MEASURE),-DPAPR_MEASURE)
 CFLAGS  := -O2 -fPIC -ffp-contract=off -Wall -Wextra -Iinclude -I$(CSRC)
 
 all: lib cli oracle tools

@@ -87,6 +87,43 @@ def cpu_baseline(pkg, mode: str, sample_gib: float):
             os.unlink(path)
 
 
+def e2e_block(pkg, gib: float):
+    """End to end (PCIe-inclusive; never `value`): `bin/papr` — the drop-in — on a file of the bench workload in
+    /dev/shm: process start -> last byte of stdout, both modes, against the reference's recorded stdout."""
+    orc = ge.load_oracle()
+    n = int(gib * (1 << 30)) // 8 // 8192 * 8192
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    path = os.path.join(tmpdir, f"papr_bench_e2e_{os.getpid()}.cfile")
+    out = {"file": f"{gib:g} GiB spike workload in {tmpdir} (page cache)", "bytes": n * 8}
+    try:
+        subprocess.check_call([orc.MKCFILE, path, str(n), "--spike"])
+        for graph, tag in ((False, "default"), (True, "graph")):
+            best = None
+            for _ in range(2):   # the first run of a session also pays for loading the GPU runtime
+                t0 = time.perf_counter()
+                p = subprocess.run([pkg.CLI_PATH] + (["-g"] if graph else []) + [path], capture_output=True,
+                                   env=dict(os.environ, PAPR_STATS="1"))
+                dt = time.perf_counter() - t0
+                if best is None or dt < best[0]:
+                    best = (dt, p)
+            dt, p = best
+            golden, name = golden_report(1, gib, graph)
+            info = {}
+            try:
+                info = json.loads(p.stderr.decode().splitlines()[-1])
+            except Exception:
+                pass
+            out[tag] = {"seconds": dt, "msamples_per_s": n / dt / 1e6, "rc": p.returncode,
+                        "stdout_identical_to_reference": None if golden is None else p.stdout == golden,
+                        "ingest_GBps": info.get("ingest_GBps"), "open_s": info.get("open_s"),
+                        "ingest_pass1_s": info.get("ingest_pass1_s"), "analysis_s": info.get("analysis_s"),
+                        "exact_sum": info.get("exact_sum"), "gpus": info.get("gpus")}
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+    return out
+
+
 def golden_report(world: int, gib: float, graph: bool):
     """The reference's recorded stdout for this run's global stream (tests/golden/, produced by the reference
     binary in the build container), or None when no golden exists for the configuration."""
@@ -359,6 +396,8 @@ def main():
                          "code path can be exercised on a box with fewer GPUs than ranks")
     ap.add_argument("--cpu-sample-gib", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e", action="store_true",
+                    help="also time the drop-in CLI end to end (file in /dev/shm -> stdout; PCIe-inclusive) and add it as \"e2e\"")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): library chatter during set-up (e.g. the RCCL
@@ -430,6 +469,11 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 cb = {"error": repr(e)}
             line["cpu_baseline"] = cb
+        if world == 1 and args.e2e and args.signal == "gauss":
+            try:
+                line["e2e"] = e2e_block(pkg, args.gib)
+            except Exception as e:
+                line["e2e"] = {"error": repr(e)}
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)

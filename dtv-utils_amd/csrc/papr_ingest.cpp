@@ -573,6 +573,19 @@ int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_s
     const uint64_t nbatches = (ngroups + per_batch - 1) / per_batch;
     const int blocks_max = (int)std::min<uint64_t>(per_batch, (uint64_t)ctx->num_cus * 8);
     rc = ensure_partials(ctx, (size_t)nbatches * blocks_max + 1);
+    // per-workgroup sums of squared piece sums, for the estimate's standard error (as papr_hip_estimate)
+    const size_t sq_count = (size_t)nbatches * (size_t)blocks_max;
+    double *d_sq = nullptr;
+    std::vector<double> h_sq;
+    if (rc == PAPR_OK) {
+        try {
+            h_sq.resize(sq_count);
+        } catch (...) {
+            rc = fail(ctx, PAPR_E_NOMEM, "out of host memory");
+        }
+        if (rc == PAPR_OK && hipMalloc((void **)&d_sq, sq_count * sizeof(double)) != hipSuccess)
+            rc = fail(ctx, PAPR_E_NOMEM, "hipMalloc for the estimate failed");
+    }
     std::vector<ReadBatch> batches(nbatches);
     const FileSrc *fsp = &fs;
     auto submit = [&](uint64_t bi) {
@@ -613,7 +626,7 @@ int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_s
         }
         const int blocks = (int)std::min<uint64_t>(cnt, (uint64_t)blocks_max);
         time_begin(ctx, 4, cnt * kTileBytes);
-        papr_launch_estimate(ctx->stream, blocks, ctx->d_stage[b], cnt, 1, ctx->d_partials + records, nullptr, nullptr);
+        papr_launch_estimate(ctx->stream, blocks, ctx->d_stage[b], cnt, 1, ctx->d_partials + records, nullptr, d_sq + records);
         time_end(ctx);
         records += (size_t)blocks;
         if (hipEventRecord(ctx->ev_copy[b], ctx->stream) != hipSuccess)
@@ -629,14 +642,27 @@ int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_s
     for (uint64_t k = 0; k < submitted; k++)
         (void)ctx->pool->wait(&batches[k]);
     close_file_src(&fs);
+    if (rc == PAPR_OK) {
+        papr_launch_stats_finalize(ctx->stream, nullptr, 0, 0, ctx->d_partials, (uint32_t)records, ctx->h_result_dev);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(h_sq.data(), d_sq, records * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = fail(ctx, PAPR_E_HIP, "the estimate's reduction failed");
+    }
+    if (d_sq)
+        (void)hipFree(d_sq);
     if (rc)
         return rc;
-    papr_launch_stats_finalize(ctx->stream, nullptr, 0, 0, ctx->d_partials, (uint32_t)records, ctx->h_result_dev);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    // as papr_hip_estimate: the record describes the whole range (sampled sum scaled to all of its samples)
+    // as papr_hip_estimate: the record describes the whole range (sampled sum scaled to all of its samples), and
+    // est->peak carries the estimate's relative standard error
     const uint64_t sampled = ngroups * PAPR_ESTIMATE_TILE_SAMPLES;
-    est->sum = ctx->h_result->sum * ((double)nsamples / (double)sampled);
+    double sq = 0.0;
+    for (size_t k = 0; k < records; k++)
+        sq += h_sq[k];
+    const double S = ctx->h_result->sum, P = 4.0 * (double)ngroups;
+    const double var_total = P > 1.0 ? P / (P - 1.0) * std::max(0.0, sq - S * S / P) : 0.0;
+    est->peak = (S > 0.0 && ratio > 1) ? (float)(std::sqrt(var_total) / S) : 0.0f;
+    est->sum = S * ((double)nsamples / (double)sampled);
     est->n = nsamples;
     ctx->sweep_info.estimate_samples = sampled;
     return PAPR_OK;

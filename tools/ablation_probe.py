@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""ablation_probe.py — what each ingredient of the one-sweep kernel costs: papr_sweep_kernel<1024, 4> with one part
+left out (variants 60-69, measurement only: their results are meaningless), kernel time by HIP events.
+
+  python tools/ablation_probe.py [--gib 10] [--reps 10]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+NAMES = {4: "full", 60: "no stash", 61: "no histogram", 62: "no stash, no histogram", 63: "no LUT lookup", 64: "no trackers",
+         65: "no sum", 66: "nothing (loads + power only)", 67: "no spill check", 68: "no LUT, stash, histogram", 69: "no trackers, no sum"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gib", type=float, default=10.0)
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
+    pkg = ge.load_package()
+    n = int(args.gib * (1 << 30)) // 8 // 8192 * 8192
+    shard = torch.empty(n * 8 + 65536, dtype=torch.uint8, device="cuda:0")
+    g = pkg.PaprHip(0)
+    g.adopt(shard.data_ptr(), n, base_index=0, keepalive=shard)
+    g.generate(pkg.SynthSpec.spike(n), 0, n)
+    for graph in (False, True):
+        est = g.estimate()
+        guess = pkg.guess_levels(est, graph)
+        for rnd in range(2):
+            for v in (4, 60, 61, 62, 63, 64, 65, 67, 68, 69, 66):
+                g.set_tuning(sweep_variant=v, sweep_blocks=1024)
+                g.set_timing(True)
+                for _ in range(args.reps):
+                    g.stats_sweep(guess)
+                tm = g.timing()
+                g.set_timing(False)
+                ms = tm.sweep_ms / max(tm.sweep_launches, 1)
+                print(f"mode={'graph' if graph else 'default'} round {rnd} v={v:2d} {NAMES[v]:34s} {ms:.3f} ms  {n * 8 / ms / 1e6:.0f} GB/s", flush=True)
+    g.close()
+
+
+if __name__ == "__main__":
+    main()
