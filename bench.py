@@ -205,9 +205,11 @@ def run_mode(args, mode, env):
         b_sweep = tm.sweep_bytes / max(tm.sweep_launches, 1)
         gbs_sweep = b_sweep / (k_sweep * 1e-3) / 1e9 if k_sweep else 0.0
         aux_ms = tm.aux_ms / args.steps       # estimate + stash recount kernels, per step
+        # with --exact the sweep is the wave-private-segment kernel that also builds the rounding-function pairs
+        sweep_name = "papr_sweep2_kernel<EXACT>" if (args.exact and not args.exact_two_pass) else "papr_sweep_kernel"
         dom, dom_gbs, dom_ms = max([("papr_stats_kernel", gbs_stats, k_stats), ("papr_ccdf_kernel", gbs_ccdf, k_ccdf),
                                     ("papr_exact_seg_kernel<CCDF>", gbs_exact, k_exact),
-                                    ("papr_sweep_kernel", gbs_sweep, k_sweep)], key=lambda e: e[2])
+                                    (sweep_name, gbs_sweep, k_sweep)], key=lambda e: e[2])
         kernel_ms_per_step = (tm.stats_ms + tm.ccdf_ms + tm.exact_ms + tm.sweep_ms + tm.aux_ms) / args.steps
         bytes_per_step = (tm.stats_bytes + tm.ccdf_bytes + tm.exact_bytes + tm.sweep_bytes + tm.aux_bytes) / args.steps
         traffic, traffic_src = None, None
@@ -215,9 +217,9 @@ def run_mode(args, mode, env):
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                ent = tj.get(dom, {}).get(args.mode if dom in ("papr_ccdf_kernel", "papr_sweep_kernel") else "any")
+                ent = tj.get(dom, {}).get(args.mode if args.mode in tj.get(dom, {}) else "any")
                 if ent and abs(ent.get("gib_per_gpu", 0) - args.gib) < 1e-9:
-                    traffic, traffic_src = ent["hbm_bytes_per_launch"], tj.get("source")
+                    traffic, traffic_src = ent["hbm_bytes_per_launch"], ent.get("source", tj.get("source"))
             except Exception:
                 pass
         # in-run parity: what this run would print, against what the REFERENCE printed for the same global stream
@@ -260,7 +262,7 @@ def run_mode(args, mode, env):
             "report_sha256": hashlib.sha256(report).hexdigest(),
             "kernels": {"papr_stats_kernel": {"avg_ms": k_stats, "GB/s": gbs_stats, "launches": int(tm.stats_launches)},
                         "papr_ccdf_kernel": {"avg_ms": k_ccdf, "GB/s": gbs_ccdf, "launches": int(tm.ccdf_launches)},
-                        "papr_sweep_kernel": {"avg_ms": k_sweep, "GB/s": gbs_sweep, "launches": int(tm.sweep_launches)},
+                        sweep_name: {"avg_ms": k_sweep, "GB/s": gbs_sweep, "launches": int(tm.sweep_launches)},
                         "estimate_and_recount_kernels": {"ms_per_step": aux_ms, "launches": int(tm.aux_launches),
                                                          "bytes_per_step": tm.aux_bytes / args.steps},
                         "all_kernels_frac_of_peak": bytes_per_step / (kernel_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -396,8 +398,9 @@ def main():
                          "code path can be exercised on a box with fewer GPUs than ranks")
     ap.add_argument("--cpu-sample-gib", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e", action="store_true",
-                    help="also time the drop-in CLI end to end (file in /dev/shm -> stdout; PCIe-inclusive) and add it as \"e2e\"")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the end-to-end leg (the drop-in CLI on a file in /dev/shm -> stdout; PCIe-inclusive, reported "
+                         "under \"e2e\", never as `value`)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): library chatter during set-up (e.g. the RCCL
@@ -469,7 +472,7 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 cb = {"error": repr(e)}
             line["cpu_baseline"] = cb
-        if world == 1 and args.e2e and args.signal == "gauss":
+        if world == 1 and not args.no_e2e and not args.no_cpu_baseline and args.signal == "gauss":
             try:
                 line["e2e"] = e2e_block(pkg, args.gib)
             except Exception as e:

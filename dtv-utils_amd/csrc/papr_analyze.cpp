@@ -8,7 +8,7 @@ using namespace papr_rt;
 
 extern "C" {
 
-int papr_hip_analyze(papr_hip_ctx *ctx, papr_exchange *x, int graph, unsigned flags, papr_result *res, float *levels,
+static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph, unsigned flags, papr_result *res, float *levels,
                      uint64_t *counts_above, int cap)
 {
     if (!ctx || !res || cap < 0 || (cap && (!levels || !counts_above)))
@@ -126,6 +126,12 @@ int papr_hip_analyze(papr_hip_ctx *ctx, papr_exchange *x, int graph, unsigned fl
     res->exact_redo_tiles = ctx->sweep_info.exact_redo_tiles;
     res->band_log2 = ctx->sweep_info.band_log2;
     return PAPR_OK;
+}
+
+int papr_hip_analyze(papr_hip_ctx *ctx, papr_exchange *x, int graph, unsigned flags, papr_result *res, float *levels,
+                     uint64_t *counts_above, int cap)
+{
+    return guarded(ctx, [&] { return papr_hip_analyze_impl(ctx, x, graph, flags, res, levels, counts_above, cap); });
 }
 
 }  // extern "C"

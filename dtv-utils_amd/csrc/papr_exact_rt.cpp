@@ -367,7 +367,7 @@ int assemble_program_on_host(papr_hip_ctx *ctx, const void **program, size_t *by
 
 extern "C" {
 
-int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, const void **program, size_t *bytes)
+static int papr_hip_exact_program_impl(papr_hip_ctx *ctx, double before, uint64_t n_total, const void **program, size_t *bytes)
 {
     if (!ctx || !program || !bytes)
         return PAPR_E_ARG;
@@ -397,7 +397,7 @@ int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, c
     return *bytes ? PAPR_OK : assemble_program_on_host(ctx, program, bytes);
 }
 
-int papr_hip_ccdf_exact(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above, double before,
+static int papr_hip_ccdf_exact_impl(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above, double before,
                         uint64_t n_total, const void **program, size_t *bytes)
 {
     if (!ctx || !program || !bytes || nlevels < 0 || (nlevels && (!levels || !counts_above)))
@@ -465,6 +465,17 @@ int papr_hip_ccdf_exact(papr_hip_ctx *ctx, const float *levels, int nlevels, uin
     if (!ctx->resident)  // the raw tiles of a re-streamed shard are gone once their chunk has left the device
         return fail(ctx, PAPR_E_LIMIT, "too many binade crossings for the device-side program lists");
     return assemble_program_on_host(ctx, program, bytes);
+}
+
+int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, const void **program, size_t *bytes)
+{
+    return guarded(ctx, [&] { return papr_hip_exact_program_impl(ctx, before, n_total, program, bytes); });
+}
+
+int papr_hip_ccdf_exact(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above, double before,
+                        uint64_t n_total, const void **program, size_t *bytes)
+{
+    return guarded(ctx, [&] { return papr_hip_ccdf_exact_impl(ctx, levels, nlevels, counts_above, before, n_total, program, bytes); });
 }
 
 }  // extern "C"

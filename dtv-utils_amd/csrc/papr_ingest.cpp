@@ -514,7 +514,7 @@ int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, u
 
 extern "C" {
 
-int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples)
+static int papr_hip_load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples)
 {
     return load_file_impl(ctx, path, first_sample, nsamples, nullptr, 0);
 }
@@ -526,7 +526,7 @@ int papr_hip_shard_fits(const papr_hip_ctx *ctx, uint64_t nsamples)
     return (nsamples + PAPR_TILE_SAMPLES_MAX) * 8 <= ctx->hbm_budget ? 1 : 0;
 }
 
-int papr_hip_load_file_sweep(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples,
+static int papr_hip_load_file_sweep_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples,
                              const float *guess_levels, int nlevels)
 {
     if (nlevels < 0 || (nlevels && !guess_levels))
@@ -537,7 +537,7 @@ int papr_hip_load_file_sweep(papr_hip_ctx *ctx, const char *path, uint64_t first
 
 // Mean estimate of a file range without loading it: the same 1-in-`ratio` tile sample as papr_hip_estimate, read
 // by the ingest's reader threads into the staging buffers and summed on the device.
-int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples, papr_stats *est)
+static int papr_hip_estimate_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples, papr_stats *est)
 {
     if (!ctx || !path || !est)
         return PAPR_E_ARG;
@@ -674,6 +674,22 @@ int papr_hip_get_ingest_timing(const papr_hip_ctx *ctx, papr_hip_ingest_timing *
         return PAPR_E_ARG;
     *out = ctx->ingest;
     return PAPR_OK;
+}
+
+int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples, papr_stats *est)
+{
+    return guarded(ctx, [&] { return papr_hip_estimate_file_impl(ctx, path, first_sample, nsamples, est); });
+}
+
+int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples)
+{
+    return guarded(ctx, [&] { return papr_hip_load_file_impl(ctx, path, first_sample, nsamples); });
+}
+
+int papr_hip_load_file_sweep(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples,
+                             const float *guess_levels, int nlevels)
+{
+    return guarded(ctx, [&] { return papr_hip_load_file_sweep_impl(ctx, path, first_sample, nsamples, guess_levels, nlevels); });
 }
 
 }  // extern "C"

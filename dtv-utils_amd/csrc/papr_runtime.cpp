@@ -789,7 +789,7 @@ extern "C" {
 
 // ---- pass 2 ---------------------------------------------------------------------
 
-int papr_hip_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above)
+static int papr_hip_ccdf_impl(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above)
 {
     if (!ctx || nlevels < 0 || (nlevels && (!levels || !counts_above)))
         return PAPR_E_ARG;
@@ -832,6 +832,11 @@ int papr_hip_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t 
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     counts_from_histogram(ctx, plan, nlevels, counts_above);
     return PAPR_OK;
+}
+
+int papr_hip_ccdf(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above)
+{
+    return guarded(ctx, [&] { return papr_hip_ccdf_impl(ctx, levels, nlevels, counts_above); });
 }
 
 }  // extern "C"

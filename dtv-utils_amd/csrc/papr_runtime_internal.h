@@ -316,6 +316,20 @@ struct SweepRun {
 
 enum StreamPass { PASS_LOAD_STATS, PASS_STREAM_STATS, PASS_STREAM_CCDF, PASS_STREAM_CCDF_EXACT, PASS_STREAM_NAN };
 
+// Nothing may unwind through the C ABI: the entry points that build std::vector / std::string state run inside this.
+template <class F>
+inline int guarded(papr_hip_ctx *ctx, F &&body) noexcept
+{
+    int fail(papr_hip_ctx *ctx, int code, const char *fmt, ...);
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, PAPR_E_NOMEM, "out of host memory");
+    } catch (...) {
+        return fail(ctx, PAPR_E_INTERNAL, "unexpected C++ exception inside libpaprhip");
+    }
+}
+
 // ---- functions shared between the translation units ----
 double now_s();
 CpuSet numa_cpus_of_device(int device);

@@ -405,7 +405,7 @@ int papr_hip_set_exact_hint(papr_hip_ctx *ctx, double before_estimate)
     return PAPR_OK;
 }
 
-int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, papr_stats *out)
+static int papr_hip_stats_sweep_impl(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, papr_stats *out)
 {
     if (!ctx || !out || nlevels < 0 || (nlevels && !guess_levels))
         return PAPR_E_ARG;
@@ -475,6 +475,11 @@ int papr_hip_get_sweep_info(const papr_hip_ctx *ctx, papr_hip_sweep_info *out)
         return PAPR_E_ARG;
     *out = ctx->sweep_info;
     return PAPR_OK;
+}
+
+int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, papr_stats *out)
+{
+    return guarded(ctx, [&] { return papr_hip_stats_sweep_impl(ctx, guess_levels, nlevels, out); });
 }
 
 }  // extern "C"
