@@ -18,7 +18,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libpaprhip.so")
+LIB_PATH = os.environ.get("PAPR_LIB_PATH") or os.path.join(_HERE, "libpaprhip.so")   # (the override: A/B builds of tools/)
 CLI_PATH = os.path.join(REPO_ROOT, "bin", "papr")
 
 MAX_OVERRIDES = 8
@@ -110,7 +110,7 @@ class SweepInfo(C.Structure):
     """papr_hip_sweep_info: what the last one-sweep pass / papr_hip_ccdf did."""
     _fields_ = [("stash_samples", C.c_uint64), ("stash_capacity", C.c_uint64), ("estimate_samples", C.c_uint64),
                 ("swept", C.c_int), ("resolved", C.c_int), ("reason", C.c_int), ("band_log2", C.c_int),
-                ("exact_redo_tiles", C.c_uint32), ("reserved", C.c_uint32)]
+                ("exact_redo_tiles", C.c_uint32), ("gave_up", C.c_uint32)]
 
     def as_dict(self) -> dict:
         d = {name: getattr(self, name) for name, _ in self._fields_}

@@ -28,6 +28,17 @@ __device__ __forceinline__ float4 load16(const float4 *p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// The same from a wave-uniform base address (scalar registers) + a per-lane element index: the compiler addresses
+// with a scalar base and one 32-bit offset register instead of a 64-bit pointer per lane.  (The base arrives as an
+// integer — v_readfirstlane'd — so the global address space has to be said: a plain pointer cast gives flat_load.)
+__device__ __forceinline__ float4 load16_nt_at(unsigned long long uniform_base, uint32_t element)
+{
+    typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+    gf32x4 *q = reinterpret_cast<gf32x4 *>(uniform_base) + element;
+    const f32x4 v = __builtin_nontemporal_load(q);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // Wave64 sum of a double with DPP row shifts/broadcasts (VALU latency only, no LDS
 // round trips): inclusive scan inside each 16-lane row, then row_bcast:15 / :31 carry
 // the row totals forward.  The total ends up in LANE 63; fixed order => deterministic.

@@ -130,7 +130,7 @@ int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
                        uint64_t base_index, int map, papr_partial *out, const void *tail, uint32_t tail_samples,
                        const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist, float *stash,
-                       unsigned long long *seg_counts, uint64_t seg_cap);
+                       unsigned long long *seg_counts, uint64_t seg_cap, unsigned long long *gave_up);
 void papr_launch_ccdf_power(hipStream_t st, int blocks, bool lut, size_t lds_bytes, const float *stash,
                             const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs, uint32_t split,
                             const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist);
@@ -161,6 +161,7 @@ struct papr_sweep2_params {
     float *stash;                 // one segment of seg_cap floats per workgroup
     unsigned long long *seg_slots;// per workgroup: floats used in its stash segment (incl. padding; multiple of 4)
     unsigned long long *seg_real; // per workgroup: in-band powers stashed (the invariant: == sum of the odd bins)
+    unsigned long long *gave_up;  // one counter: how often a wave gave the sweep up for its workgroup (papr_sweep.hip)
     uint64_t seg_cap;
     // exact-sum mode
     const int32_t *tile_E_spec;   // per 2048-sample tile: speculated binade of the running sum, or PAPR_EXACT_AMBIG

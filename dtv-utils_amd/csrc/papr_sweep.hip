@@ -58,20 +58,53 @@ __device__ __forceinline__ uint32_t papr_estimate_pick(uint64_t g, uint32_t rati
 // Per-wave append buffer in LDS + its spill to the workgroup's segment of the HBM stash.  Lanes that
 // hold an in-band power reserve a slot with a returning LDS atomic on the wave's own counter (three
 // VALU instructions per sample; a ballot/mbcnt compaction costs seven).
+// A sweep whose bands catch most of the stream (a constant-envelope capture: every power sits next to the mean)
+// cannot be answered from the stash, and must not cost more than the pass it replaces: each spill compares what the
+// workgroup stashed in this launch with what it folded, and once more than half of it was in band — or the segment is
+// full — the wave GIVES UP for the whole workgroup: it overwrites the LUT in LDS with "bin 0 everywhere" (no counter,
+// no stash: the rest of the launch runs at pass-1 speed) and pushes the segment's length past its capacity, which the
+// host reads as `stash full` and answers with the plain pass 2.  Pass-1 results do not depend on the LUT.
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)  // the first active lane's value
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ void sweep_give_up(uint32_t *tab, uint32_t table_words, uint32_t neutral_x,
+                                              unsigned long long *seg_fill, uint64_t seg_cap,
+                                              unsigned long long *gave_up)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    for (uint32_t k = lane; 2 * k + 1 < table_words; k += kWave) {
+        tab[2 * k] = neutral_x;
+        tab[2 * k + 1] = 0xFFFFFFFFu;
+    }
+    if (lane == 0) {
+        atomicAdd(seg_fill, (unsigned long long)seg_cap + 1ull);
+        atomicAdd(gave_up, 1ull);  // (for papr_hip_sweep_info: how often the rule fired)
+    }
+}
+constexpr uint32_t kGiveUpMin = 16384;  // in-band samples of a workgroup before the ratio test means anything
+
 struct WaveStash {
     float *buf;                         // this wave's slice of LDS
     uint32_t *fill;                     // LDS: entries in buf (this wave's counter)
     float *__restrict__ seg;            // this workgroup's stash segment
     unsigned long long *seg_fill;       // LDS: floats reserved in the segment so far (may run past seg_cap)
     uint64_t seg_cap;
+    uint32_t *tab;                      // LDS: the LUT (sweep_give_up)
+    uint32_t table_words, neutral_x;
+    unsigned long long seg_start;       // the segment's length when this launch began
+    unsigned long long *gave_up;        // device counter of give-ups
 
     __device__ __forceinline__ void put(float pw, bool take)
     {
         if (take)
             buf[atomicAdd(fill, 1u)] = pw;
     }
-    // spill if more than `limit` entries are waiting (wave-uniform decision)
-    __device__ __forceinline__ void spill_if_above(uint32_t limit)
+    // spill if more than `limit` entries are waiting (wave-uniform decision); `folded` = samples this workgroup
+    // has folded in this launch, about
+    __device__ __forceinline__ void spill_if_above(uint32_t limit, uint32_t folded)
     {
         __builtin_amdgcn_wave_barrier();  // LDS is in-order per wave; this pins the compiler's order too
         // other lanes' atomics: never cached.  The cast matters: through a generic pointer the volatile read is a
@@ -85,11 +118,14 @@ struct WaveStash {
             pos = atomicAdd(seg_fill, (unsigned long long)n);  // counts even what no longer fits: the host sees the overflow
             *(volatile lds_u32 *)(lds_u32 *)fill = 0;
         }
-        pos = __shfl((unsigned long long)pos, 0, kWave);
+        pos = uniform_u64(pos);  // lane 0's value, in scalar registers
         for (uint32_t i = lane; i < n; i += kWave)
             if (pos + i < seg_cap)  // write-through (sc0 sc1): 1-3 % faster than leaving these lines dirty in L2 for a later eviction
                 __hip_atomic_store(&seg[pos + i], buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __builtin_amdgcn_wave_barrier();
+        const uint32_t got = (uint32_t)(pos - seg_start) + n;  // (a workgroup folds < 2^32 samples per launch)
+        if (pos <= seg_cap && (pos + n > seg_cap || (got >= kGiveUpMin && got > folded / 2)))
+            sweep_give_up(tab, table_words, neutral_x, seg_fill, seg_cap, gave_up);  // (pos > seg_cap: someone already did)
     }
 };
 
@@ -336,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
                                                             unsigned long long *__restrict__ ghist,
                                                             float *__restrict__ stash,
                                                             unsigned long long *__restrict__ seg_counts,
-                                                            uint64_t seg_cap)
+                                                            uint64_t seg_cap, unsigned long long *__restrict__ gave_up)
 {
     constexpr uint64_t TILE_F4 = (uint64_t)BLOCK * U;
     constexpr uint32_t SLICE = papr_sweep_slice_floats(U);
@@ -362,7 +398,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
     const uint2 *lut_biased = reinterpret_cast<const uint2 *>(tab) - ((int32_t)P.cell_lo - 1);
     uint32_t *my = hist + ((t / kWave) % P.copies) * nbins;
     WaveStash ws{slices + (t / kWave) * SLICE, &wave_fill[t / kWave], stash + (uint64_t)blockIdx.x * seg_cap, &seg_fill,
-                 seg_cap};
+                 seg_cap, tab, P.table_words, LUT2 ? PAPR_LUT2_NEVER : 0u, seg_fill, gave_up};
     // cell index straight from the bit pattern: lut_biased[cell] with cell clamped to [cell_lo - 1, cell_lo + ncells]
     const int32_t cell_last = (int32_t)(P.cell_lo + P.ncells);
     int32_t cell_first;  // pinned in a VGPR for the whole kernel (v_med3 takes one scalar operand)
@@ -417,7 +453,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
         for (int u = 0; u < 2 * U; u++)
             count_and_stash(pw[u], k[u]);
         if constexpr (!(ABL & 32))
-            ws.spill_if_above(SLICE - 2 * U * kWave);  // the next tile might not fit
+            ws.spill_if_above(SLICE - 2 * U * kWave, (it + 1) * (uint32_t)(2 * TILE_F4));  // the next tile might not fit
     };
 
     const float4 *p = data + w.first * TILE_F4 + t;
@@ -465,10 +501,10 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
             const float2 x = valid ? tail[k0 + t] : make_float2(0.f, 0.f);
             const float pw = power_of(x.x, x.y);
             count_and_stash(pw, valid ? bin_of(pw) : 0u);
-            ws.spill_if_above(SLICE - kWave);
+            ws.spill_if_above(SLICE - kWave, ~0u);
         }
     }
-    ws.spill_if_above(0);
+    ws.spill_if_above(0, ~0u);
 
     sweep_record<BLOCK, BLOCK, U>(sum, tr, w, data, base_index, t, out);
     hist_flush<BLOCK>(hist, nbins, P.copies, ghist);  // (starts with a barrier: every wave has spilled)
@@ -507,7 +543,11 @@ template <int WT>
 __device__ __forceinline__ void store16(float *p, f32x4s v)
 {
     if constexpr (WT == 2) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+        // The s_nop belongs to the store: hipcc's hazard recogniser does not look inside inline asm, and gfx940+ needs
+        // two wait states between a VMEM store of more than 8 bytes and a VALU write to its data registers — without
+        // them the next instruction can overwrite the powers before the store has read them (seen as wrong, run-to-run
+        // different stash contents whenever the scheduler happened to put a VALU write right behind this store).
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" : : "v"(p), "v"(v) : "memory");
     } else if constexpr (WT == 1) {
         __builtin_nontemporal_store(v, reinterpret_cast<f32x4s *>(p));
     } else {
@@ -524,6 +564,20 @@ struct StashRing {
     unsigned long long *seg_fill;     // LDS: floats reserved in the segment (may run past seg_cap: overflow)
     unsigned long long *seg_real;     // LDS: powers stashed (without padding)
     uint64_t seg_cap;
+    uint32_t *tab;                    // LDS: the LUT (sweep_give_up)
+    uint32_t table_words;
+    unsigned long long seg_start;     // the segment's length when this launch began
+    unsigned long long *gave_up;      // device counter of give-ups
+    uint32_t folded;                  // samples this workgroup has folded in this launch, about (kept by the kernel)
+    bool give_up;                     // wave-uniform: this wave found the bands too full (see sweep_give_up)
+
+    __device__ __forceinline__ void give_up_if_asked()
+    {
+        if (give_up) {
+            sweep_give_up(tab, table_words, PAPR_LUT2_NEVER, seg_fill, seg_cap, gave_up);
+            give_up = false;
+        }
+    }
 
     // One reservation per lane for ALL its in-band powers of a batch (one LDS round trip per batch; a returning
     // atomic per sample serialises up to 2 * BATCH of them behind s_waitcnt lgkmcnt(0)), then plain LDS writes.
@@ -565,7 +619,7 @@ struct StashRing {
             pos = atomicAdd(seg_fill, (unsigned long long)n4);
             atomicAdd(seg_real, (unsigned long long)n);
         }
-        pos = __shfl((unsigned long long)pos, 0, kWave);
+        pos = uniform_u64(pos);  // lane 0's value, in scalar registers
         if (4 * lane < n4) {
             f32x4s v = *reinterpret_cast<const f32x4s *>(ring + (tail & (RING - 1)) + 4 * lane);
             const float pad = __uint_as_float(PAPR_STASH_PAD_BITS);
@@ -576,6 +630,11 @@ struct StashRing {
                 store16<WT>(seg + pos + 4 * lane, v);
         }
         tail += n;
+        // (32-bit on purpose: a workgroup folds < 2^32 samples per launch, and the 64-bit compare-with-literal forms
+        // cost registers this kernel does not have)
+        const uint32_t got = (uint32_t)(pos - seg_start) + n4;
+        if (pos <= seg_cap && (pos + n4 > seg_cap || (got >= kGiveUpMin && got > folded / 2)))
+            give_up = true;  // (pos > seg_cap: someone already did); acted on between two segments
     }
     __device__ __forceinline__ uint32_t pending()
     {
@@ -827,7 +886,13 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
                            p.stash + (uint64_t)blockIdx.x * p.seg_cap,
                            &seg_fill,
                            &seg_real_sh,
-                           p.seg_cap};
+                           p.seg_cap,
+                           tab,
+                           P.table_words,
+                           seg_fill,
+                           p.gave_up,
+                           0,
+                           false};
     const int32_t cell_last = (int32_t)(P.cell_lo + P.ncells);
     int32_t cell_first;  // pinned in a VGPR (v_med3 takes one scalar operand)
     asm volatile("v_mov_b32 %0, %1" : "=v"(cell_first) : "s"((int32_t)P.cell_lo - 1));
@@ -893,10 +958,12 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
     };
 
     auto load_seg = [&](float4(&x)[U], uint64_t seg) {
-        const float4 *q = data + seg * SEG_F4 + lane;
+        // the segment's base is wave-uniform: kept in scalar registers (scalar base + 32-bit lane offset addressing),
+        // not as a 64-bit pointer per lane
+        const unsigned long long base = uniform_u64((unsigned long long)(data + seg * SEG_F4));
 #pragma unroll
         for (int u = 0; u < U; u++)
-            x[u] = load16<true>(q + u * kWave);
+            x[u] = load16_nt_at(base, lane + u * kWave);
     };
 
     if constexpr (EXACT) {
@@ -908,6 +975,7 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
             load_seg(x, seg0);
         for (uint32_t it = 0; it < count; it++) {
             const uint64_t seg = seg0 + (uint64_t)it * seg_stride;
+            ws.folded = (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4);
             const int E = tile_E[(p.seg_offset + seg) >> 1];
 #pragma unroll
             for (int r = 0; r < U; r++) {
@@ -939,10 +1007,12 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
             f = wave_compose2(f, m0);
             if (lane == 0)
                 seg_D[p.seg_offset + seg] = make_double2(f.d0, f.d1);
+            ws.give_up_if_asked();
         }
     } else {
         double none0 = 0.0, none1 = 0.0;
         auto fold_seg = [&](const float4(&x)[U], uint32_t it) {
+            ws.folded = (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4);
             SegMax m = {0u, 0u, 0u, INT32_MIN, INT32_MIN};
 #pragma unroll
             for (int b = 0; b < U / BATCH; b++) {
@@ -953,6 +1023,7 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
                 fold_batch(y, m, none0, none1);
             }
             segmax_commit(tr, m, it);
+            ws.give_up_if_asked();
         };
         if constexpr (PIPE == 1) {
             float4 cur[U], nxt[U];
@@ -976,6 +1047,7 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
     }
     // remainder of the launch: binned here (its pass-1 part is folded in by papr_stats_finalize, its exact-sum
     // part travels raw in the sum program)
+    ws.folded = ~0u;
     if (blockIdx.x == gridDim.x - 1) {
         const float2 *tail = reinterpret_cast<const float2 *>(p.tail);
         for (uint32_t k0 = 0; k0 < p.tail_samples; k0 += BLOCK) {  // wave-uniform trip count
@@ -1123,14 +1195,14 @@ int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
                        uint64_t base_index, int map, papr_partial *out, const void *tail, uint32_t tail_samples,
                        const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist, float *stash,
-                       unsigned long long *seg_counts, uint64_t seg_cap)
+                       unsigned long long *seg_counts, uint64_t seg_cap, unsigned long long *gave_up)
 {
     switch (variant) {
 #define X(V, A)                                                                                                      \
     case V:                                                                                                           \
         hipLaunchKernelGGL((papr_sweep_kernel<1024, 4, true, 0, A>), dim3(blocks), dim3(1024), lds_bytes, st,         \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
-                           table, P, ghist, stash, seg_counts, seg_cap);                                              \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up);                                            \
         break;
         PAPR_FOR_EACH_ABLATION(X)
 #undef X
@@ -1138,7 +1210,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     case V:                                                                                                           \
         hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP, 0, true>), dim3(blocks), dim3(B), lds_bytes, st,        \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
-                           table, P, ghist, stash, seg_counts, seg_cap);                                              \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up);                                            \
         break;
         PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X)
 #undef X
@@ -1146,7 +1218,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     case V:                                                                                                           \
         hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP>), dim3(blocks), dim3(B), lds_bytes, st,                 \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
-                           table, P, ghist, stash, seg_counts, seg_cap);                                              \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up);                                            \
         break;
         PAPR_FOR_EACH_SWEEP_VARIANT(X)
 #undef X

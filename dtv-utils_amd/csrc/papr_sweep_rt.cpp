@@ -151,7 +151,7 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
     // (as floats: 1/8 of its bytes), one equal segment per workgroup
     constexpr size_t kMaxSweepBlocks = 65536;
     if (!ctx->d_sweep_hist) {
-        const size_t bytes = (2 * (size_t)PAPR_HIP_MAX_LEVELS + 2 + 2 * kMaxSweepBlocks) * sizeof(unsigned long long);
+        const size_t bytes = (2 * (size_t)PAPR_HIP_MAX_LEVELS + 2 + 2 * kMaxSweepBlocks + 1) * sizeof(unsigned long long);
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_sweep_hist, bytes));
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_sweep_hist, bytes, hipHostMallocDefault));
     }
@@ -195,8 +195,9 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_table, ctx->h_table, (size_t)bands.P.table_words * 4, hipMemcpyHostToDevice,
                                ctx->stream));
+    // (+ 1: the give-up counter behind the segment arrays)
     HIPCHK(ctx, hipMemsetAsync(ctx->d_sweep_hist, 0,
-                               ((size_t)run->nbins + (size_t)(run->v2 ? 2 : 1) * run->blocks) * sizeof(unsigned long long),
+                               ((size_t)run->nbins + (size_t)(run->v2 ? 2 : 1) * run->blocks + 1) * sizeof(unsigned long long),
                                ctx->stream));
     *reason = PAPR_SWEEP_OK;
     return PAPR_OK;
@@ -230,6 +231,7 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
         p.seg_slots = ctx->d_sweep_hist + run.nbins;
         p.seg_real = ctx->d_sweep_hist + run.nbins + run.blocks;
         p.seg_cap = run.seg_cap;
+        p.gave_up = ctx->d_sweep_hist + run.nbins + 2 * run.blocks;
         p.tile_E_spec = ctx->d_tile_E_spec;
         p.seg_D = ctx->d_seg_D;
         p.seg_offset = (base_index - ctx->base) / PAPR_EXACT_SEG_SAMPLES;
@@ -248,7 +250,7 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
     time_begin(ctx, 3, n * 8);
     papr_launch_sweep(ctx->stream, run.variant, blocks, run.bands.lds_bytes + run.stash_lds, data, ntiles, base_index, map,
                       ctx->d_partials + slot, data + 2 * (n - tail), tail, ctx->d_table, run.bands.P, ctx->d_sweep_hist,
-                      ctx->d_stash, ctx->d_sweep_hist + run.nbins, run.seg_cap);
+                      ctx->d_stash, ctx->d_sweep_hist + run.nbins, run.seg_cap, ctx->d_sweep_hist + run.nbins + run.blocks);
     time_end(ctx);
     HIPCHK(ctx, hipGetLastError());
     *nrecords = blocks;
@@ -259,7 +261,7 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
 int sweep_fetch(papr_hip_ctx *ctx, const SweepRun &run)
 {
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_sweep_hist, ctx->d_sweep_hist,
-                               ((size_t)run.nbins + (size_t)(run.v2 ? 2 : 1) * run.blocks) * sizeof(unsigned long long),
+                               ((size_t)run.nbins + (size_t)(run.v2 ? 2 : 1) * run.blocks + 1) * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, ctx->stream));
     return PAPR_OK;
 }
@@ -277,7 +279,8 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
     }
     for (uint32_t b = 1; b < run.nbins; b += 2)
         in_bands += H[b];
-    if (in_bands != stash_count && !(run.variant >= 60 && run.variant <= 69))  // (ablation launches: timing only)
+    // (a workgroup that gave up — papr_sweep.hip sweep_give_up — leaves both numbers meaningless: `overflow` says so)
+    if (in_bands != stash_count && !overflow && !(run.variant >= 60 && run.variant <= 69))  // (ablation launches: timing only)
         return fail(ctx, PAPR_E_INTERNAL, "one-sweep invariant broken: %llu samples binned inside bands, %llu stashed",
                     (unsigned long long)in_bands, (unsigned long long)stash_count);
     const size_t m = run.gkeys.size();
@@ -299,6 +302,7 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
     info.reason = PAPR_SWEEP_OK;
     info.stash_samples = stash_count;
     info.stash_capacity = run.seg_cap * (uint64_t)run.blocks;  // what this sweep could use (one segment per workgroup)
+    info.gave_up = (uint32_t)std::min<unsigned long long>(H[run.nbins + (run.v2 ? 2 : 1) * run.blocks], 0xFFFFFFFFull);
     return PAPR_OK;
 }
 

@@ -21,10 +21,13 @@
 namespace {
 
 constexpr int kBlock = 1024;
+constexpr int kMergeBlock = 256;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 }  // namespace
 
+// UNR = packets per lane between two workgroup barriers (their header loads are in flight together).
+template <int UNR>
 __global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t ts_smem[];  // 3 x TS_PIDS words = 96 KiB (one workgroup per CU)
@@ -47,59 +50,68 @@ __global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
     const uint64_t per = (p.nunits + gridDim.x - 1) / gridDim.x;
     const uint64_t j0 = (uint64_t)blockIdx.x * per;
     const uint64_t j1 = j0 + per < p.nunits ? j0 + per : p.nunits;
-    for (uint64_t jb = j0; jb < j1; jb += kBlock) {  // workgroup-uniform trip count
-        const uint64_t j = jb + t;
-        bool regular = true, have = j < j1, quirk = false;
-        uint32_t pid = 0, tei = 0;
-        if (have) {
+    for (uint64_t jb = j0; jb < j1; jb += (uint64_t)UNR * kBlock) {  // workgroup-uniform trip count
+        // the five bytes that matter — sync, two PID bytes, adaptation_field_control, adaptation_field_length — out of
+        // two aligned dwords per packet; all UNR packets' loads issued before the first is looked at
+        uint32_t w0[UNR], w1[UNR];
+        bool whole[UNR];
+#pragma unroll
+        for (int r = 0; r < UNR; r++) {
+            const uint64_t j = jb + (uint64_t)r * kBlock + t;
             const uint64_t s = p.first_unit + j * p.stride + p.sync_offset;  // file offset of the sync byte
-            if (s + 188 > p.nbytes) {
-                regular = false;  // cut off by the end of the stream
-            } else {
-                // the five bytes that matter — sync, two PID bytes, adaptation_field_control, adaptation_field_length —
-                // out of two aligned dwords
-                const uint64_t a = s & ~3ull;
-                const uint32_t w0 = *reinterpret_cast<const uint32_t *>(p.data + a);
-                const uint32_t w1 = *reinterpret_cast<const uint32_t *>(p.data + a + 4);
-                const uint32_t sh = (uint32_t)(s & 3u);
-                const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh);  // bytes s .. s+3
-                const uint32_t b4 = (w1 >> (8 * sh)) & 0xffu;                // byte s+4 (sh <= 3: inside w1)
-                const uint32_t b0 = lo & 0xffu, b1 = (lo >> 8) & 0xffu, b2 = (lo >> 16) & 0xffu, b3 = lo >> 24;
-                tei = b1 >> 7;
-                pid = ((b1 & 0x1fu) << 8) | b2;
-                const bool has_af = (b3 & 0x20u) != 0;
-                const uint32_t af_len = has_af ? b4 : 0u;
-                regular = b0 == 0x47u && af_len <= 183u;
-                // the reference's one-step payload skip, entered before the last byte of a packet that ends one
-                // byte past a 16384-byte read, finishes the packet a byte early (xport.c:4302): its last byte goes
-                // to the sync search.  Unless that byte is 0x47 (a false sync: irregular) the search skips it,
-                // reports `skipped 1 bytes` and locks on the next packet where it would have anyway — an event for
-                // the list, nothing else changes.
-                const bool on_boundary = ((s + 187) & (TS_READ_CHUNK - 1)) == 0;
-                if (regular && on_boundary && pid != 0u && pid != 0x1ffbu && (!has_af || af_len <= 181u)) {
-                    if (p.data[s + 187] == 0x47u || p.event_cap == 0) {
-                        regular = false;
-                    } else {
-                        quirk = true;
-                    }
-                }
+            whole[r] = j < j1 && s + 188 <= p.nbytes;
+            const uint64_t a = whole[r] ? (s & ~3ull) : 0ull;
+            w0[r] = *reinterpret_cast<const uint32_t *>(p.data + a);
+            w1[r] = *reinterpret_cast<const uint32_t *>(p.data + a + 4);
+        }
+        bool regular[UNR], quirk[UNR];
+        uint32_t pid[UNR], tei[UNR];
+#pragma unroll
+        for (int r = 0; r < UNR; r++) {
+            const uint64_t j = jb + (uint64_t)r * kBlock + t;
+            const uint64_t s = p.first_unit + j * p.stride + p.sync_offset;
+            const uint32_t sh = (uint32_t)(s & 3u);
+            const uint32_t lo = __builtin_amdgcn_alignbyte(w1[r], w0[r], sh);  // bytes s .. s+3
+            const uint32_t b4 = (w1[r] >> (8 * sh)) & 0xffu;                   // byte s+4 (sh <= 3: inside w1)
+            const uint32_t b0 = lo & 0xffu, b1 = (lo >> 8) & 0xffu, b2 = (lo >> 16) & 0xffu, b3 = lo >> 24;
+            tei[r] = b1 >> 7;
+            pid[r] = ((b1 & 0x1fu) << 8) | b2;
+            const bool has_af = (b3 & 0x20u) != 0;
+            const uint32_t af_len = has_af ? b4 : 0u;
+            regular[r] = whole[r] && b0 == 0x47u && af_len <= 183u;  // (!whole: cut off by the end of the stream)
+            quirk[r] = false;
+            // the reference's one-step payload skip, entered before the last byte of a packet that ends one byte
+            // past a 16384-byte read, finishes the packet a byte early (xport.c:4302): its last byte goes to the
+            // sync search.  Unless that byte is 0x47 (a false sync: irregular) the search skips it, reports
+            // `skipped 1 bytes` and locks on the next packet where it would have anyway — an event for the list,
+            // nothing else changes.
+            const bool on_boundary = ((s + 187) & (TS_READ_CHUNK - 1)) == 0;
+            if (regular[r] && on_boundary && pid[r] != 0u && pid[r] != 0x1ffbu && (!has_af || af_len <= 181u)) {
+                if (p.data[s + 187] == 0x47u || p.event_cap == 0)
+                    regular[r] = false;
+                else
+                    quirk[r] = true;
             }
-            if (!regular)
+            if (j < j1 && !regular[r])
                 atomicMin(&s_irregular, (uint32_t)(j - j0));
         }
         __syncthreads();
         const uint32_t stop = s_irregular;  // relative to j0
-        if (have && (uint32_t)(j - j0) < stop) {
-            const uint32_t rel = (uint32_t)j;  // unit number within the launch (a launch takes < 2^32 units)
-            if (tei == 0) {
-                atomicAdd(&s_count[pid], 1u);
-                atomicMin(&s_first[pid], rel);
-                atomicMax(&s_last[pid], rel);
-            }
-            if (quirk) {  // (about one packet in 4096 of a stream whose packets sit at odd offsets)
-                const uint32_t at = atomicAdd(&s_events, 1u);
-                if (at < p.event_cap)
-                    p.events[(size_t)blockIdx.x * p.event_cap + at] = rel;
+#pragma unroll
+        for (int r = 0; r < UNR; r++) {
+            const uint64_t j = jb + (uint64_t)r * kBlock + t;
+            if (j < j1 && (uint32_t)(j - j0) < stop) {
+                const uint32_t rel = (uint32_t)j;  // unit number within the launch (a launch takes < 2^32 units)
+                if (tei[r] == 0) {
+                    atomicAdd(&s_count[pid[r]], 1u);
+                    atomicMin(&s_first[pid[r]], rel);
+                    atomicMax(&s_last[pid[r]], rel);
+                }
+                if (quirk[r]) {  // (about one packet in 4096 of a stream whose packets sit at odd offsets)
+                    const uint32_t at = atomicAdd(&s_events, 1u);
+                    if (at < p.event_cap)
+                        p.events[(size_t)blockIdx.x * p.event_cap + at] = rel;
+                }
             }
         }
         if (stop != kNone)
@@ -131,57 +143,68 @@ __global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
     }
 }
 
-// One workgroup: fold the tables of the spans up to and including the first that stopped into the stream-wide tables
-// (absolute 1-based packet numbers = packet_base + unit number + 1) and tell the host how many units were taken.
-__global__ __launch_bounds__(kBlock) void ts_merge_kernel(const ts_scan_params p, uint32_t nspans, uint64_t packet_base,
-                                                          uint32_t *__restrict__ g_count,
-                                                          unsigned long long *__restrict__ g_first,
-                                                          unsigned long long *__restrict__ g_last,
-                                                          unsigned long long *__restrict__ taken_out)
+// One workgroup per span: fold the tables of the spans up to and including the first that stopped into the stream-wide
+// tables (absolute 1-based packet numbers = packet_base + unit number + 1; count: add, first: min over a table that
+// starts at all-ones, last: max — order-independent, so the spans go in parallel) and tell the host how many units
+// were taken.  Every workgroup works out the stop for itself from the nspans-long span tables (a few hundred words).
+__global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_params p, uint32_t nspans, uint64_t packet_base,
+                                                               uint32_t *__restrict__ g_count,
+                                                               unsigned long long *__restrict__ g_first,
+                                                               unsigned long long *__restrict__ g_last,
+                                                               unsigned long long *__restrict__ taken_out)
 {
-    __shared__ uint32_t s_last_span;
-    if (threadIdx.x == 0) {
-        uint32_t b = 0;
+    __shared__ uint32_t s_stop;
+    __shared__ unsigned long long s_taken;
+    __shared__ uint32_t s_ev_before, s_ev_total;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) {
+        s_stop = nspans;
+        s_taken = 0;
+        s_ev_before = 0;
+        s_ev_total = 0;
+    }
+    __syncthreads();
+    for (uint32_t b = t; b < nspans; b += kMergeBlock)
+        if (p.span_stopped[b])
+            atomicMin(&s_stop, b);
+    __syncthreads();
+    const uint32_t last_span = s_stop < nspans ? s_stop : nspans - 1;  // the span that stopped counts up to its stop
+    const uint32_t me = blockIdx.x;
+    if (me > last_span)
+        return;  // (workgroup-uniform)
+    {
         unsigned long long taken = 0;
-        for (; b < nspans; b++) {
+        uint32_t ev_before = 0, ev_total = 0;
+        for (uint32_t b = t; b <= last_span; b += kMergeBlock) {
             taken += p.span_done[b];
-            if (p.span_stopped[b])
-                break;
+            const uint32_t n = p.event_counts[b];
+            ev_total += n;
+            ev_before += b < me ? n : 0u;
         }
-        s_last_span = b < nspans ? b : nspans - 1;
-        *taken_out = taken;
+        if (taken)
+            atomicAdd(&s_taken, taken);
+        if (ev_total)
+            atomicAdd(&s_ev_total, ev_total);
+        if (ev_before)
+            atomicAdd(&s_ev_before, ev_before);
     }
     __syncthreads();
-    const uint32_t last_span = s_last_span;
-    // the valid spans' quirk events, compacted (unordered within a span: the host sorts)
-    __shared__ uint32_t s_nevents;
-    if (threadIdx.x == 0)
-        s_nevents = 0;
-    __syncthreads();
-    for (uint32_t b = 0; b <= last_span; b++) {
-        const uint32_t n = p.event_counts[b];
-        for (uint32_t k = threadIdx.x; k < n; k += kBlock) {
-            const uint32_t at = atomicAdd(&s_nevents, 1u);
-            if (at < p.merged_event_cap)
-                p.merged_events[at] = p.events[(size_t)b * p.event_cap + k];
-        }
+    if (me == 0 && t == 0) {
+        taken_out[0] = s_taken;
+        taken_out[1] = s_ev_total;
     }
-    __syncthreads();
-    if (threadIdx.x == 0)
-        taken_out[1] = s_nevents;
-    for (uint32_t b = 0; b <= last_span; b++) {
-        const ts_wg_entry *list = p.lists + (size_t)b * TS_PIDS;
-        const uint32_t n = p.list_counts[b];
-        for (uint32_t k = threadIdx.x; k < n; k += kBlock) {  // PIDs are distinct within a list, spans run one after the other
-            const ts_wg_entry e = list[k];
-            g_count[e.pid] += e.count;
-            const unsigned long long f = packet_base + e.first + 1, l = packet_base + e.last + 1;
-            if (g_first[e.pid] == 0 || f < g_first[e.pid])
-                g_first[e.pid] = f;
-            if (l > g_last[e.pid])
-                g_last[e.pid] = l;
-        }
-        __syncthreads();
+    // this span's quirk events, behind those of the spans in front of it (unordered within a span: the host sorts)
+    const uint32_t nev = p.event_counts[me], ev_at = s_ev_before;
+    for (uint32_t k = t; k < nev; k += kMergeBlock)
+        if (ev_at + k < p.merged_event_cap)
+            p.merged_events[ev_at + k] = p.events[(size_t)me * p.event_cap + k];
+    const ts_wg_entry *list = p.lists + (size_t)me * TS_PIDS;
+    const uint32_t n = p.list_counts[me];
+    for (uint32_t k = t; k < n; k += kMergeBlock) {
+        const ts_wg_entry e = list[k];
+        atomicAdd(&g_count[e.pid], e.count);
+        atomicMin(&g_first[e.pid], packet_base + e.first + 1);
+        atomicMax(&g_last[e.pid], packet_base + e.last + 1);
     }
 }
 
@@ -203,20 +226,28 @@ __global__ __launch_bounds__(256) void ts_generate_kernel(unsigned char *__restr
 
 void ts_kernels_prepare_device(void)  // function attributes belong to the current device
 {
-    (void)hipFuncSetAttribute((const void *)ts_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              3 * TS_PIDS * (int)sizeof(uint32_t));
+    const int lds = 3 * TS_PIDS * (int)sizeof(uint32_t);
+    (void)hipFuncSetAttribute((const void *)ts_scan_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)ts_scan_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)ts_scan_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
-void ts_launch_scan(hipStream_t st, int blocks, const ts_scan_params &p)
+void ts_launch_scan(hipStream_t st, int blocks, int unroll, const ts_scan_params &p)
 {
-    hipLaunchKernelGGL(ts_scan_kernel, dim3(blocks), dim3(kBlock), 3 * TS_PIDS * sizeof(uint32_t), st, p);
+    const size_t lds = 3 * TS_PIDS * sizeof(uint32_t);
+    if (unroll == 1)
+        hipLaunchKernelGGL(ts_scan_kernel<1>, dim3(blocks), dim3(kBlock), lds, st, p);
+    else if (unroll == 2)
+        hipLaunchKernelGGL(ts_scan_kernel<2>, dim3(blocks), dim3(kBlock), lds, st, p);
+    else
+        hipLaunchKernelGGL(ts_scan_kernel<4>, dim3(blocks), dim3(kBlock), lds, st, p);
 }
 
 void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t nspans, uint64_t packet_base, uint32_t *g_count,
                      unsigned long long *g_first, unsigned long long *g_last, unsigned long long *taken_out)
 {
-    hipLaunchKernelGGL(ts_merge_kernel, dim3(1), dim3(kBlock), 0, st, p, nspans, packet_base, g_count, g_first, g_last,
-                       taken_out);
+    hipLaunchKernelGGL(ts_merge_kernel, dim3(nspans), dim3(kMergeBlock), 0, st, p, nspans, packet_base, g_count, g_first,
+                       g_last, taken_out);
 }
 
 void ts_launch_generate(hipStream_t st, void *out, uint64_t nunits, uint32_t unit, uint64_t seed, int hdmv)

@@ -40,7 +40,8 @@ struct ts_hip_ctx {
     unsigned char *h_window = nullptr;                      // pinned: what the walker looks at
     void *h_tables = nullptr;                               // pinned: count / first / last read back at the end
     int spans = 0;
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    int unroll = 1;  // TS_SCAN_UNROLL (measurement knob): packets per lane between two barriers of the scan kernel
+    hipEvent_t ev_a = nullptr, ev_m = nullptr, ev_b = nullptr;
 };
 
 namespace {
@@ -135,6 +136,11 @@ int ts_hip_open(ts_hip_ctx **out, int device)
     OPENCHK(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->spans = ctx->num_cus;  // one 1024-thread workgroup (96 KiB of LDS) per CU
+    if (const char *e = getenv("TS_SCAN_UNROLL")) {
+        const int u = atoi(e);
+        if (u == 1 || u == 2 || u == 4)
+            ctx->unroll = u;
+    }
     OPENCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     OPENCHK(hipMalloc((void **)&ctx->d_lists, (size_t)ctx->spans * TS_PIDS * sizeof(ts_wg_entry)));
     OPENCHK(hipMalloc((void **)&ctx->d_list_counts, ctx->spans * sizeof(uint32_t)));
@@ -153,6 +159,7 @@ int ts_hip_open(ts_hip_ctx **out, int device)
     OPENCHK(hipHostMalloc(&ctx->h_tables, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long)), hipHostMallocDefault));
     OPENCHK(hipEventCreate(&ctx->ev_a));
     OPENCHK(hipEventCreate(&ctx->ev_b));
+    OPENCHK(hipEventCreate(&ctx->ev_m));
 #undef OPENCHK
     ts_kernels_prepare_device();
     *out = ctx;
@@ -183,6 +190,7 @@ void ts_hip_close(ts_hip_ctx *ctx)
     if (ctx->h_tables) (void)hipHostFree(ctx->h_tables);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+    if (ctx->ev_m) (void)hipEventDestroy(ctx->ev_m);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -319,9 +327,10 @@ int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
     out->bytes = ctx->n;
     const uint32_t stride = hdmv ? 192u : 188u, sync_offset = hdmv ? 4u : 0u;
     TSCHK(ctx, hipMemsetAsync(ctx->d_count, 0, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long)), ctx->stream));
+    TSCHK(ctx, hipMemsetAsync(ctx->d_first, 0xFF, TS_PIDS * sizeof(unsigned long long), ctx->stream));  // min table
     ts_walk_state st;
     ts_walk_init(&st, hdmv);
-    float ms_total = 0.f;
+    float ms_total = 0.f, ms_merge = 0.f;
     for (;;) {
         // ---- GPU: every regular unit from a clean position on ----
         if (ts_walk_is_clean(&st) && st.pos + sync_offset + 188 <= ctx->n) {
@@ -344,15 +353,18 @@ int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
             p.merged_event_cap = kMergedEventCap;
             const int blocks = (int)std::min<uint64_t>((uint64_t)ctx->spans, (units + 1023) / 1024);
             TSCHK(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
-            ts_launch_scan(ctx->stream, blocks, p);
+            ts_launch_scan(ctx->stream, blocks, ctx->unroll, p);
+            TSCHK(ctx, hipEventRecord(ctx->ev_m, ctx->stream));
             ts_launch_merge(ctx->stream, p, (uint32_t)blocks, out->packets, ctx->d_count, ctx->d_first, ctx->d_last, ctx->d_taken);
             TSCHK(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
             TSCHK(ctx, hipGetLastError());
             TSCHK(ctx, hipMemcpyAsync(ctx->h_taken, ctx->d_taken, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
             TSCHK(ctx, hipStreamSynchronize(ctx->stream));
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_b) == hipSuccess)
+            if (hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_m) == hipSuccess)
                 ms_total += ms;
+            if (hipEventElapsedTime(&ms, ctx->ev_m, ctx->ev_b) == hipSuccess)
+                ms_merge += ms;
             const uint64_t taken = ctx->h_taken[0];
             uint64_t nev = ctx->h_taken[1];
             if (nev > kMergedEventCap)
@@ -404,8 +416,8 @@ int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
     const uint32_t *gc = (const uint32_t *)ctx->h_tables;
     const unsigned long long *gf = (const unsigned long long *)(gc + TS_PIDS), *gl = gf + TS_PIDS;
     for (int pid = 0; pid < TS_PIDS; pid++) {
-        if (!gc[pid])
-            continue;
+        if (gf[pid] == ~0ull)
+            continue;  // never seen by a launch
         out->count[pid] += gc[pid];
         if (out->first[pid] == 0 || gf[pid] < out->first[pid])
             out->first[pid] = gf[pid];
@@ -413,6 +425,7 @@ int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
             out->last[pid] = gl[pid];
     }
     out->kernel_ms = ms_total;
+    out->merge_ms = ms_merge;
     return PAPR_OK;
 }
 

@@ -29,7 +29,7 @@ class ScanResult(C.Structure):
     _fields_ = [("packets", C.c_uint64), ("count", C.c_uint32 * PIDS), ("first", C.c_uint64 * PIDS),
                 ("last", C.c_uint64 * PIDS), ("nsync_errors", C.c_uint64), ("sync_errors", SyncError * MAX_SYNC_ERRORS),
                 ("bytes", C.c_uint64), ("gpu_packets", C.c_uint64), ("launches", C.c_uint32), ("walks", C.c_uint32),
-                ("kernel_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("merge_ms", C.c_double)]
 
     def report(self) -> bytes:
         """The reference's report lines (ts_format_report)."""

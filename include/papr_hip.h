@@ -260,7 +260,8 @@ typedef struct papr_hip_sweep_info {
     int band_log2;
     uint32_t exact_redo_tiles; /* exact-sum mode, last papr_hip_ccdf_exact / _exact_program after a sweep: 2048-sample tiles whose
                                 * speculated running-sum binade was wrong and whose rounding functions were rebuilt */
-    uint32_t reserved;
+    uint32_t gave_up;        /* waves that gave the sweep up for their workgroup because most of what it folded was in band
+                              * (constant-envelope captures); any > 0 shows as PAPR_SWEEP_STASH_FULL */
 } papr_hip_sweep_info;
 int papr_hip_estimate(papr_hip_ctx *ctx, papr_stats *est);
 /* Exact-sum mode (papr_hip_set_exact(ctx, 1)) is served by the same single read: papr_hip_estimate then also keeps

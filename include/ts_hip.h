@@ -63,6 +63,7 @@ typedef struct ts_scan_result {
     uint32_t launches;         /* scan-kernel launches */
     uint32_t walks;            /* hand-overs to the host walker */
     double kernel_ms;          /* sum of the scan kernels' durations (HIP events) */
+    double merge_ms;           /* sum of the merge kernels' durations */
 } ts_scan_result;
 
 /* ---- the host walker: the scan's exact state between packets, and one step of it (GPU-free) ---------------------- */
