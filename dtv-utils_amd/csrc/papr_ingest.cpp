@@ -3,6 +3,7 @@
 // lands; resident and re-streamed shards; the one-sweep ingest and the mean estimate of a file that is not loaded yet.
 
 #include "papr_runtime_internal.h"
+#include "papr_uring.h"
 
 using namespace papr_rt;
 
@@ -277,6 +278,16 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
         ctx->ingest.o_direct = fs.fd_direct >= 0;
         ctx->ingest.numa_bound = ctx->ingest_numa ? 1 : 0;
     }
+    // A file read with O_DIRECT goes through one io_uring (papr_uring.h) where the kernel offers it: the reads need no
+    // CPU, only enough of them in flight.  PAPR_IO_URING=0 keeps the reader threads.
+    if (fs.fd_direct >= 0 && !ctx->uring_tried) {
+        ctx->uring_tried = true;
+        if (env_int("PAPR_IO_URING", 1) != 0)
+            ctx->uring = UringReader::create(256);
+    }
+    UringReader *ring = fs.fd_direct >= 0 ? ctx->uring : nullptr;
+    if (timed)
+        ctx->ingest.io_uring = ring ? 1 : 0;
     // queue the slices of chunk c for the reader threads (buffer c % kNumBuf must be free)
     std::vector<ReadBatch> batches(nchunks);
     const FileSrc *fsp = &fs;
@@ -286,6 +297,19 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
         const uint64_t s0 = c * chunk_samples;
         const uint64_t cnt = std::min(chunk_samples, shard_n - s0);
         unsigned char *hbuf = (unsigned char *)ctx->h_stage[b];
+        if (ring) {
+            // the whole 4 KiB blocks of the chunk through the direct descriptor in 1 MiB requests, the sub-block rest
+            // (only the end of the file has one) through the buffered one; never a byte more than was asked for
+            const uint64_t byte0 = (file_first + s0) * 8, file_bytes = fs.nfloats * 4;
+            const uint64_t want = byte0 < file_bytes ? std::min<uint64_t>(cnt * 8, file_bytes - byte0) : 0;
+            const bool aligned = (byte0 & 4095) == 0 && ((uintptr_t)hbuf & 4095) == 0;
+            const uint64_t direct = aligned ? (want & ~4095ull) : 0;
+            if (direct)
+                ring->submit(&batches[c], fs.fd_direct, fs.fd, byte0, direct, hbuf, (uint64_t)1 << 20);
+            if (want > direct)
+                ring->submit(&batches[c], fs.fd, fs.fd, byte0 + direct, want - direct, hbuf + direct, (uint64_t)1 << 20);
+            return;
+        }
         const int nthr = ctx->reader_threads;
         const uint64_t per = ((cnt + nthr - 1) / nthr + 511) & ~511ull;
         for (int t = 0; t < nthr; t++) {
@@ -350,8 +374,16 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
         submit_chunk(submitted);
     for (uint64_t c = 0; c < nchunks && rc == PAPR_OK; c++) {
         t_mark = now_s();
-        if (ctx->pool->wait(&batches[c]))
+        if (ring) {
+            if (ring->wait(&batches[c]))
+                rc = fail(ctx, PAPR_E_IO, "read error in %s (io_uring: errno %d)", ctx->path.c_str(), batches[c].error);
+            // (the reader threads patch the phantom sample's partner in read_samples: here it is done once per chunk)
+            const uint64_t s0 = c * chunk_samples, cnt = std::min(chunk_samples, shard_n - s0);
+            if (!rc && fs.odd && file_first + s0 + cnt == fs.nsamples && cnt > 0)
+                memcpy((unsigned char *)ctx->h_stage[c % kNumBuf] + cnt * 8 - 4, &fs.partner, 4);
+        } else if (ctx->pool->wait(&batches[c])) {
             rc = fail(ctx, PAPR_E_IO, "read error in %s", ctx->path.c_str());
+        }
         if (timed)
             ctx->ingest.read_s += now_s() - t_mark;
         if (rc)
@@ -374,8 +406,12 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
         }
     }
     // on any failure let the reads already queued finish before `fs` and the batches go away
-    for (uint64_t k = 0; k < submitted; k++)
-        (void)ctx->pool->wait(&batches[k]);
+    for (uint64_t k = 0; k < submitted; k++) {
+        if (ring)
+            (void)ring->wait(&batches[k]);
+        else
+            (void)ctx->pool->wait(&batches[k]);
+    }
     close_file_src(&fs);
     if (nrecords_out)
         *nrecords_out = records;

@@ -7,6 +7,7 @@
 // builds the <= 16 K-entry level tables and folds a handful of scalars.
 
 #include "papr_runtime_internal.h"
+#include "papr_uring.h"
 
 using namespace papr_rt;
 
@@ -527,6 +528,7 @@ void papr_hip_close(papr_hip_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     delete ctx->pool;
+    delete ctx->uring;
     release_shard(ctx);
     for (auto &t : ctx->timed) {
         (void)hipEventDestroy(t.a);

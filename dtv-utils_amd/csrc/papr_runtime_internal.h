@@ -7,6 +7,7 @@
 #include "papr_hip.h"
 #include "papr_exact_format.h"
 #include "papr_kernels.h"
+#include "papr_readbatch.h"
 
 #include <hip/hip_runtime.h>
 
@@ -44,10 +45,7 @@ constexpr int kMaxTimed = 4096;
 // Jobs are grouped in batches (one batch = the slices of one chunk); the
 // submitter can queue the next chunk's batch before waiting for the current
 // one, so the readers never go idle between chunks.
-struct ReadBatch {
-    int pending = 0;
-    int error = 0;
-};
+// (struct ReadBatch {pending, error}: papr_readbatch.h, shared with papr_uring.h)
 
 // CPUs of the NUMA node the GPU hangs off (its PCIe root): the ingest's reader threads run there and the pinned
 // staging buffers are first touched there, so that the H2D DMA never crosses the socket interconnect.
@@ -56,6 +54,8 @@ struct CpuSet {
     cpu_set_t set;
     bool valid = false;
 };
+
+class UringReader;  // papr_uring.h
 
 class ReaderPool {
   public:
@@ -184,6 +184,8 @@ struct papr_hip_ctx {
     hipEvent_t ev_kernel[papr_rt::kNumBuf] = {};
     size_t stage_bytes = 0;
     papr_rt::ReaderPool *pool = nullptr;
+    papr_rt::UringReader *uring = nullptr;  // papr_uring.h: the reader for O_DIRECT streams (nullptr: not tried / not offered)
+    bool uring_tried = false;
     int reader_threads = 0;
     bool ingest_numa = false;   // reader threads and staging buffers are bound to the GPU's NUMA node
 

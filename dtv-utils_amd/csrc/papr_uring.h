@@ -23,7 +23,7 @@
 #include <atomic>
 #include <deque>
 
-#include "papr_runtime_internal.h"  // ReadBatch {pending, error}
+#include "papr_readbatch.h"  // ReadBatch {pending, error}
 
 namespace papr_rt {
 

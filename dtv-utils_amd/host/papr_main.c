@@ -325,11 +325,11 @@ int main(int argc, char **argv)
                 "\"ingest_pass1_s\": %.6f, \"exact_sum\": %d, \"exact_redo_tiles\": %u, \"analysis_s\": %.6f, \"total_s\": %.6f, "
                 "\"msamples_per_s\": %.3f, \"ingest_GBps\": %.2f, \"gpu0_ingest\": {\"setup_s\": %.4f, \"read_s\": %.4f, "
                 "\"buffer_wait_s\": %.4f, \"issue_s\": %.4f, \"drain_s\": %.4f, \"chunks\": %llu, \"reader_threads\": %d, "
-                "\"resident\": %d, \"o_direct\": %d, \"numa_bound\": %d}}\n",
+                "\"resident\": %d, \"o_direct\": %d, \"numa_bound\": %d, \"io_uring\": %d}}\n",
                 (unsigned long long)nsamples, (unsigned long long)nsamples * 8, ngpu, nlevels, t_open - t0, swept, resolved,
                 t_loaded - t_open, r->exact_sum, r->exact_redo_tiles, t2 - t_loaded, t3 - t0, (double)nsamples / (t3 - t0) / 1e6,
                 (double)nsamples * 8 / (t_loaded - t_open) / 1e9, it->setup_s, it->read_s, it->buffer_wait_s, it->issue_s,
-                it->drain_s, (unsigned long long)it->chunks, it->reader_threads, it->resident, it->o_direct, it->numa_bound);
+                it->drain_s, (unsigned long long)it->chunks, it->reader_threads, it->resident, it->o_direct, it->numa_bound, it->io_uring);
     }
 
     for (int g = 0; g < ngpu; g++) {

@@ -337,9 +337,23 @@ def _disk_dir():
     return None
 
 
+def _io_uring_offered():
+    """does io_uring_setup work here (kernel + seccomp profile)?  (425 = __NR_io_uring_setup on x86-64)"""
+    import ctypes
+    libc = ctypes.CDLL(None, use_errno=True)
+    params = (ctypes.c_ubyte * 120)()
+    fd = libc.syscall(425, 4, params)
+    if fd < 0:
+        return False
+    os.close(fd)
+    return True
+
+
+@pytest.mark.parametrize("uring", ["1", "0"], ids=["io_uring", "reader-threads"])
 @pytest.mark.parametrize("budget", [None, "4"], ids=["resident", "streamed"])
-def test_file_ingest_o_direct(pkg, orc, monkeypatch, budget):
-    """PAPR_O_DIRECT=1 (what a cold file >= 64 MiB gets automatically): 4 KiB-aligned direct reads into the pinned
+def test_file_ingest_o_direct(pkg, orc, monkeypatch, budget, uring):
+    """PAPR_O_DIRECT=1 (what a cold file >= 64 MiB gets automatically), through one io_uring where the kernel offers it
+    and through the reader threads (PAPR_IO_URING=0): 4 KiB-aligned direct reads into the pinned
     staging buffers, the unaligned end of the file finished by the buffered descriptor, odd-float tail + stray
     bytes patched after a direct read, a shard whose start is not 4 KiB-aligned (falls through to buffered reads),
     many chunks; resident and re-streamed.  Everything against the oracle on the same file."""
@@ -352,6 +366,7 @@ def test_file_ingest_o_direct(pkg, orc, monkeypatch, budget):
         subprocess.check_call([orc.MKCFILE, path, str(n), "--spike", "--extra-floats", "1", "--extra-bytes", "3"])
         ref = orc.run_file(path, True)
         monkeypatch.setenv("PAPR_O_DIRECT", "1")
+        monkeypatch.setenv("PAPR_IO_URING", uring)
         monkeypatch.setenv("PAPR_CHUNK_MB", "1")
         monkeypatch.setenv("PAPR_READ_THREADS", "5")    # slices that are not 4 KiB multiples of each other
         if budget:
@@ -360,6 +375,7 @@ def test_file_ingest_o_direct(pkg, orc, monkeypatch, budget):
             g.load_file(path)
             t = g.ingest_timing()
             assert t.o_direct == 1 and t.resident == (0 if budget else 1), t.as_dict()
+            assert t.io_uring == (int(uring) if _io_uring_offered() else 0), t.as_dict()
             st = g.stats()
             check_stats(st, ref)
             assert st.flags & pkg.FLAG_ODD_TAIL

@@ -28,5 +28,10 @@ for RUN in "default:" "exact:--exact" "ts:--workload ts"; do
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$NAME -- \
       $B --steps 3 --warmup 1 --no-cpu-baseline $FLAGS > $O/pmc_write_$NAME.json 2> $O/pmc_write_$NAME.err
 done
+# the TS scan's memory-side requests: one per 128-byte header line, no L2 reuse (what its roofline is priced on)
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --kernel-trace --output-format csv -d $O/pmc_tcc_ts -- \
+    $B --workload ts --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_tcc_ts.json 2> $O/pmc_tcc_ts.err
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_hit_ts -- \
+    $B --workload ts --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_hit_ts.json 2> $O/pmc_hit_ts.err
 find $O -name "*.csv" -size +8M -delete
 ls $O

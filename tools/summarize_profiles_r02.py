@@ -109,7 +109,9 @@ def main():
         fetch = counters(os.path.join(src, f"pmc_fetch_{run}"), "FETCH_SIZE")
         write = counters(os.path.join(src, f"pmc_write_{run}"), "WRITE_SIZE")
         try:
-            nbytes = json.load(open(os.path.join(src, f"pmc_fetch_{run}.json")))["roofline"]["algorithmic_bytes_per_launch"]
+            pl = json.load(open(os.path.join(src, f"pmc_fetch_{run}.json")))
+            # (TS: the bytes of the stream — what the generate kernel wrote — not the header lines the scan is priced on)
+            nbytes = pl["config"]["bytes_per_gpu"] if run == "ts" else pl["roofline"]["algorithmic_bytes_per_launch"]
         except Exception:
             pass
         g = write.get(gen, {})
@@ -129,6 +131,19 @@ def main():
                     "hbm_bytes_per_launch": rd + wr, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                     "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE, separate pass, x2 gfx950 "
                               "correction; + the kernel's writes from the WRITE_SIZE pass calibrated on the generate kernel)"}
+    # TS scan: requests the L2 sent to memory and its hit / miss counts (one miss = one 128-byte line)
+    tcc = {}
+    for d, names in (("pmc_tcc_ts", ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum")), ("pmc_hit_ts", ("TCC_HIT_sum", "TCC_MISS_sum"))):
+        for c in names:
+            v = counters(os.path.join(src, d), c).get("ts_scan_kernel")
+            if v:
+                tcc[c] = v.get("any", v.get("default"))
+    if tcc:
+        if "TCC_EA0_RDREQ_sum" in tcc:
+            tcc["hbm_read_bytes_if_128B_requests"] = tcc["TCC_EA0_RDREQ_sum"] * 128
+        tcc["note"] = ("one memory-side request per L2 miss, none of them 32-byte: every request fills one 128-byte L2 line, "
+                       "the line that holds a packet header (1.03125 lines per 188-byte packet)")
+        summary["ts_tcc"] = tcc
     json.dump(durations, open(os.path.join(dst, f"{tag}_kernel_durations.json"), "w"), indent=1, sort_keys=True)
     json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     json.dump(traffic, open(traffic_path, "w"), indent=1, sort_keys=True)
