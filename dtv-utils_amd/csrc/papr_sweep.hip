@@ -86,6 +86,8 @@ __device__ __forceinline__ void sweep_give_up(uint32_t *tab, uint32_t table_word
 }
 constexpr uint32_t kGiveUpMin = 16384;  // in-band samples of a workgroup before the ratio test means anything
 
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
 struct WaveStash {
     float *buf;                         // this wave's slice of LDS
     uint32_t *fill;                     // LDS: entries in buf (this wave's counter)
@@ -513,6 +515,169 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
 }
 
 // =============================================================================
+// 3a'. the sweep with the two passes on different waves of one workgroup
+// =============================================================================
+// papr_sweep_kernel makes every wave do everything: loads, pass 1, LUT lookups, LDS atomics, stash — 21.8 VALU per
+// sample and a wait on the LDS between issuing a tile's loads and folding it.  Here a workgroup's first PW waves are
+// LOADERS: they run pass 1's loop (loads one tile ahead, power, sum, per-tile trackers) and leave the tile's POWERS
+// (4 bytes per sample: half the input) in a small LDS ring, in slots of 8 powers per lane (2 KiB); every loader feeds
+// NB BINNER waves, which take its slots in turn and do the band lookup, the histogram and the stash.  No barrier in
+// the loop: a loader and its binners talk through two LDS words per slot (filled / consumed sequence numbers), and LDS
+// operations of one wave execute in order, so a slot's data is there when its sequence number is.  Compact LUT (two
+// edges per cell) always: the ring takes the LDS the wide table would need.
+template <int PW, int NB, int LU, int DEPTH>
+__global__ __launch_bounds__((PW + PW * NB) * kWave) void papr_sweep_split_kernel(
+    const float4 *__restrict__ data, uint64_t ntiles, uint64_t base_index, int map, papr_partial *__restrict__ out,
+    const float2 *__restrict__ tail, uint32_t tail_samples, const uint32_t *__restrict__ table, papr_ccdf_params P,
+    unsigned long long *__restrict__ ghist, float *__restrict__ stash, unsigned long long *__restrict__ seg_counts,
+    uint64_t seg_cap, unsigned long long *__restrict__ gave_up)
+{
+    constexpr int ROW = PW * kWave;                      // loader lanes: one tile row
+    constexpr int BW = PW * NB;                          // binner waves
+    constexpr int BLOCK = (PW + BW) * kWave;
+    constexpr uint64_t TILE_F4 = (uint64_t)ROW * LU;
+    constexpr uint32_t SLICE = papr_sweep_slice_floats(4);
+    constexpr uint32_t SLOT = 8 * kWave;                 // floats per slot: 8 powers per lane
+    constexpr uint32_t SPT = LU / 4;                     // slots a loader fills per tile
+    static_assert(LU % 4 == 0 && DEPTH % NB == 0 && DEPTH >= NB, "slot bookkeeping");
+    __shared__ unsigned long long seg_fill;
+    __shared__ uint32_t wave_fill[BW];
+    __shared__ uint32_t slot_filled[PW][DEPTH], slot_consumed[PW][DEPTH];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t nbins = P.nkeys + 2;  // + the NaN trash bin
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *hist = tab + P.table_words;
+    float *slices = reinterpret_cast<float *>(hist + ((P.copies * nbins + 3u) & ~3u));
+    float *ring = slices + BW * SLICE;                   // PW x DEPTH slots (16-byte aligned: everything above is)
+
+    const uint32_t t = threadIdx.x;
+    for (uint32_t k = t; k < P.table_words; k += BLOCK)
+        tab[k] = table[k];
+    for (uint32_t k = t; k < P.copies * nbins; k += BLOCK)
+        hist[k] = 0;
+    if (t == 0)
+        seg_fill = seg_counts[blockIdx.x];
+    if (t < BW)
+        wave_fill[t] = 0;
+    if (t < PW * DEPTH) {
+        (&slot_filled[0][0])[t] = 0;
+        (&slot_consumed[0][0])[t] = 0;
+    }
+    __syncthreads();
+
+    const uint32_t lane = t & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(t / kWave);
+    const bool loader = wave < PW;
+    const uint32_t bidx = loader ? 0u : wave - PW;       // binner number
+    const uint32_t feed = loader ? wave : bidx / NB;     // the loader this wave is, or is fed by
+    float *my_ring = ring + feed * (DEPTH * SLOT);
+    const TileWalk w = tile_walk(blockIdx.x, gridDim.x, ntiles, map);
+
+    double sum = 0.0;
+    TileTrack tr = {{0.f, 0.f, 0.f, 0.f, 0.f}, {0, 0, 0, 0, 0}};
+    if (loader) {
+        __builtin_amdgcn_s_setprio(2);  // the load stream first
+        const float4 *p = data + w.first * TILE_F4 + t;
+        const uint64_t step = w.stride * TILE_F4;
+        float4 cur[LU], nxt[LU];
+        if (w.count)
+            load_tile<ROW, LU, true>(cur, p);
+        for (uint32_t it = 0; it < w.count; it++) {
+            p += step;
+            if (it + 1 < w.count)
+                load_tile<ROW, LU, true>(nxt, p);
+            float pw[2 * LU];
+#pragma unroll
+            for (int u = 0; u < LU; u++) {
+                pw[2 * u] = power_of(cur[u].x, cur[u].y);
+                pw[2 * u + 1] = power_of(cur[u].z, cur[u].w);
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * LU; u++)
+                sum += (double)pw[u];  // same order as papr_stats_kernel
+            track_tile<LU>(tr, cur, pw, it);
+#pragma unroll
+            for (uint32_t h = 0; h < SPT; h++) {
+                const uint32_t q = it * SPT + h, d = q % DEPTH;
+                // the slot's previous content (sequence number q - DEPTH) must have been taken
+                lds_u32 *taken = (lds_u32 *)&slot_consumed[feed][d];
+                while ((int32_t)(__builtin_amdgcn_readfirstlane(*(volatile lds_u32 *)taken) + DEPTH - (q + 1)) < 0)
+                    __builtin_amdgcn_s_sleep(1);
+                float *slot = my_ring + d * SLOT;
+                *reinterpret_cast<f32x4s *>(slot + 4 * lane) = f32x4s{pw[8 * h], pw[8 * h + 1], pw[8 * h + 2], pw[8 * h + 3]};
+                *reinterpret_cast<f32x4s *>(slot + 4 * kWave + 4 * lane) =
+                    f32x4s{pw[8 * h + 4], pw[8 * h + 5], pw[8 * h + 6], pw[8 * h + 7]};
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0)  // (behind the data: LDS operations of a wave execute in order)
+                    *(volatile lds_u32 *)(lds_u32 *)&slot_filled[feed][d] = q + 1;
+            }
+#pragma unroll
+            for (int u = 0; u < LU; u++)
+                cur[u] = nxt[u];
+        }
+    } else {
+        const uint2 *lut_biased = reinterpret_cast<const uint2 *>(tab) - ((int32_t)P.cell_lo - 1);
+        uint32_t *my = hist + (bidx % P.copies) * nbins;
+        WaveStash ws{slices + bidx * SLICE, &wave_fill[bidx], stash + (uint64_t)blockIdx.x * seg_cap, &seg_fill,
+                     seg_cap, tab, P.table_words, PAPR_LUT2_NEVER, seg_fill, gave_up};
+        const int32_t cell_last = (int32_t)(P.cell_lo + P.ncells);
+        int32_t cell_first;  // pinned in a VGPR for the whole kernel (v_med3 takes one scalar operand)
+        asm volatile("v_mov_b32 %0, %1" : "=v"(cell_first) : "s"((int32_t)P.cell_lo - 1));
+        const uint32_t shift = P.shift, offmask = (1u << shift) - 1u;
+        auto bin_of = [&](float v) -> uint32_t {
+            const int32_t cell = __float_as_int(v) >> shift;  // arithmetic shift: sign-bit patterns go below
+            const uint2 e = lut_biased[clamp_cell(cell, cell_first, cell_last)];
+            const uint32_t off = __float_as_uint(v) & offmask;
+            return (e.x >> PAPR_LUT2_OFF_BITS) + (off >= (e.x & PAPR_LUT2_NEVER) ? 1u : 0u) + (off >= e.y ? 1u : 0u);
+        };
+        auto count_and_stash = [&](float v, uint32_t k) {
+            if (k)
+                atomicAdd(&my[k], 1u);
+            ws.put(v, (k & 1u) != 0u);
+        };
+        const uint32_t nslots = w.count * SPT;
+        for (uint32_t q = bidx % NB; q < nslots; q += NB) {
+            const uint32_t d = q % DEPTH;
+            lds_u32 *filled = (lds_u32 *)&slot_filled[feed][d];
+            while ((int32_t)(__builtin_amdgcn_readfirstlane(*(volatile lds_u32 *)filled) - (q + 1)) < 0)
+                __builtin_amdgcn_s_sleep(1);
+            const float *slot = my_ring + d * SLOT;
+            const f32x4s a = *reinterpret_cast<const f32x4s *>(slot + 4 * lane);
+            const f32x4s b = *reinterpret_cast<const f32x4s *>(slot + 4 * kWave + 4 * lane);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0)  // (behind the reads: they have executed when this does)
+                *(volatile lds_u32 *)(lds_u32 *)&slot_consumed[feed][d] = q + 1;
+            const float pw[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint32_t k[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                k[u] = bin_of(pw[u]);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                count_and_stash(pw[u], k[u]);
+            ws.spill_if_above(SLICE - 8 * kWave, (q / SPT + 1) * (uint32_t)(2 * TILE_F4));
+        }
+        // sub-tile remainder of the shard: binned here (its pass-1 part is folded in by papr_stats_finalize)
+        if (blockIdx.x == gridDim.x - 1) {
+            const uint32_t tc = t - ROW;
+            for (uint32_t k0 = 0; k0 < tail_samples; k0 += BW * kWave) {  // wave-uniform trip count
+                const bool valid = k0 + tc < tail_samples;
+                const float2 x = valid ? tail[k0 + tc] : make_float2(0.f, 0.f);
+                const float v = power_of(x.x, x.y);
+                count_and_stash(v, valid ? bin_of(v) : 0u);
+                ws.spill_if_above(SLICE - kWave, ~0u);
+            }
+        }
+        ws.spill_if_above(0, ~0u);
+    }
+
+    sweep_record<BLOCK, ROW, LU>(sum, tr, w, data, base_index, loader ? t : 0u, out);
+    hist_flush<BLOCK>(hist, nbins, P.copies, ghist);  // (starts with a barrier: every binner has spilled)
+    if (t == 0)
+        seg_counts[blockIdx.x] = seg_fill;
+}
+
+// =============================================================================
 // 3b. the sweep, second generation: wave-private segments, compact LUT, ring stash, optional exact-sum pairs
 // =============================================================================
 // What changed against papr_sweep_kernel, and why (measurements: DESIGN.md section 7):
@@ -536,7 +701,6 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
 
 namespace {
 
-typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 // store policies for the stash: 0 plain, 1 nontemporal, 2 write-through (sc0 sc1)
 template <int WT>
@@ -1144,6 +1308,14 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
 #define PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X) X(20, 256, 4, 1) X(24, 1024, 4, 0)
 #endif
 
+// loader / binner split (papr_sweep_split_kernel): id, loader waves, binners per loader, loads per lane per tile, ring depth
+// (measured slower than papr_sweep_kernel in every shape — DESIGN.md section 4b — so only `make MEASURE=1` builds it)
+#ifdef PAPR_MEASURE
+#define PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X) X(70, 8, 1, 4, 4) X(71, 4, 3, 8, 6) X(72, 4, 3, 4, 6) X(73, 4, 2, 8, 4) X(74, 5, 2, 8, 4) X(75, 2, 7, 8, 14)
+#else
+#define PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X)
+#endif
+
 int papr_sweep_variant(int variant)
 {
 #ifdef PAPR_MEASURE
@@ -1151,6 +1323,9 @@ int papr_sweep_variant(int variant)
         return variant;  // ablations of <1024, 4> (measurement only)
 #endif
     switch (variant) {
+#define X(V, PW, NB, LU, D) case V: return V;
+        PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X)
+#undef X
 #define X(V, B, U, P) case V: return V;
         PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X)
 #undef X
@@ -1166,6 +1341,15 @@ int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_
     if (variant >= 60 && variant <= 69)
         variant = 4;
     switch (variant) {
+#define X(V, PW, NB, LU, D)                                                                                      \
+    case V:                                                                                                       \
+        *threads = (PW + PW * NB) * kWave;                                                                        \
+        *tile_samples = 2ull * PW * kWave * LU;                                                                   \
+        *stash_lds = (size_t)(PW * NB) * papr_sweep_slice_floats(4) * sizeof(float) +                             \
+                     (size_t)PW * D * 512 * sizeof(float) + 16;                                                   \
+        return 0;
+        PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X)
+#undef X
 #define X(V, B, U, P)                                                                     \
     case V:                                                                                \
         *threads = B;                                                                      \
@@ -1198,6 +1382,14 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
                        unsigned long long *seg_counts, uint64_t seg_cap, unsigned long long *gave_up)
 {
     switch (variant) {
+#define X(V, PW, NB, LU, D)                                                                                          \
+    case V:                                                                                                           \
+        hipLaunchKernelGGL((papr_sweep_split_kernel<PW, NB, LU, D>), dim3(blocks), dim3((PW + PW * NB) * kWave),      \
+                           lds_bytes, st, (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail,   \
+                           tail_samples, table, P, ghist, stash, seg_counts, seg_cap, gave_up);                       \
+        break;
+        PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X)
+#undef X
 #define X(V, A)                                                                                                      \
     case V:                                                                                                           \
         hipLaunchKernelGGL((papr_sweep_kernel<1024, 4, true, 0, A>), dim3(blocks), dim3(1024), lds_bytes, st,         \
@@ -1299,6 +1491,11 @@ void papr_sweep_prepare_device(void)
     (void)hipFuncSetAttribute((const void *)papr_sweep2_kernel<W, U, PP, EX, WT>,                                \
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
     PAPR_FOR_EACH_SWEEP2_VARIANT(X)
+#undef X
+#define X(V, PW, NB, LU, D)                                                                                          \
+    (void)hipFuncSetAttribute((const void *)papr_sweep_split_kernel<PW, NB, LU, D>,                                   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X)
 #undef X
     (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
     (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
