@@ -132,3 +132,21 @@ def test_one_sweep_equals_two_pass_at_every_rank_count(mode):
             assert got["config"][key] == ref["config"][key], (ranks, key)
         assert abs(float.fromhex(got["config"]["sum_hex"]) - float.fromhex(ref["config"]["sum_hex"])) <= \
             1e-12 * float.fromhex(ref["config"]["sum_hex"])
+
+
+@pytest.mark.parametrize("extra", [[], ["--exact"]], ids=["tree", "exact"])
+def test_two_rank_bench_line_proves_itself_at_full_size(extra):
+    """What a driver's 2-GPU run prints, on one GPU (two ranks over gloo share it): 2 x 10 GiB shards of the 20 GiB
+    stream, `parity_in_run` = the run's report equals the REFERENCE's recorded stdout for that stream, both tables;
+    with --exact also the reference's sequential sum over the two chained shards."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", *extra]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert d["n_gpus"] == 2 and d["config"]["samples_total"] == 2 * 1342177280
+    assert d["parity_in_run"] is True and d["parity_golden"] == "big_spike20g.default.txt"
+    assert d["graph"]["parity_in_run"] is True and d["graph"]["parity_golden"] == "big_spike20g.graph.txt"
+    if extra:
+        assert d["config"]["sum_hex"] == "0x1.aaaa011478022p+31" and d["config"]["exact_sequential_sum"]
