@@ -133,7 +133,7 @@ class IngestTiming(C.Structure):
     _fields_ = [("total_s", C.c_double), ("setup_s", C.c_double), ("read_s", C.c_double),
                 ("buffer_wait_s", C.c_double), ("issue_s", C.c_double), ("drain_s", C.c_double),
                 ("bytes", C.c_uint64), ("chunks", C.c_uint64), ("reader_threads", C.c_int), ("resident", C.c_int),
-                ("o_direct", C.c_int), ("numa_bound", C.c_int), ("io_uring", C.c_int), ("reserved", C.c_int)]
+                ("o_direct", C.c_int), ("numa_bound", C.c_int), ("io_uring", C.c_int), ("file_passes", C.c_int)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}

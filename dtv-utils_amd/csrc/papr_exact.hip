@@ -260,13 +260,16 @@ __global__ __launch_bounds__(BLOCK) void papr_exact_seg_kernel(const float4 *__r
                                                               const uint32_t *__restrict__ table, papr_ccdf_params P,
                                                               unsigned long long *__restrict__ ghist,
                                                               const uint32_t *__restrict__ tile_list,
-                                                              const uint32_t *__restrict__ tile_count, uint32_t list_cap)
+                                                              const uint32_t *__restrict__ tile_count, uint32_t list_cap,
+                                                              uint32_t compact)
 {
     constexpr int kWaves = BLOCK / kWave;
-    // list form (the one-read sweep's redo pass): only the two segments of each listed tile
+    // list form (the one-read sweep's redo pass): only the two segments of each listed tile; `compact`: the samples
+    // of the k-th listed tile are the k-th tile of `data` (a streamed shard: the tiles were read back from the file)
     if (tile_list)
         nsegs = 2ull * min(*tile_count, list_cap);
     auto seg_of = [&](uint64_t i) -> uint64_t { return tile_list ? 2ull * tile_list[i >> 1] + (i & 1) : i; };
+    auto src_of = [&](uint64_t i, uint64_t seg) -> uint64_t { return compact ? i : seg; };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4 *lds = reinterpret_cast<float4 *>(smem);                    // kWaves x (64 runs x 8 float4)
     uint32_t *tab = reinterpret_cast<uint32_t *>(lds + kWaves * kSegF4);
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(BLOCK) void papr_exact_seg_kernel(const float4 *__r
     if (item < nsegs) {
         seg = seg_of(item);
         curE = tile_E[seg >> 1];
-        const float4 *p = data + seg * kSegF4 + lane;
+        const float4 *p = data + src_of(item, seg) * kSegF4 + lane;
 #pragma unroll
         for (int r = 0; r < kRows; r++)
             x[r] = load16<true>(p + r * kWave);
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(BLOCK) void papr_exact_seg_kernel(const float4 *__r
         if (item + nwaves < nsegs) {
             nseg = seg_of(item + nwaves);
             nextE = tile_E[nseg >> 1];  // fetched a whole iteration before it is needed
-            const float4 *p = data + nseg * kSegF4 + lane;
+            const float4 *p = data + src_of(item + nwaves, nseg) * kSegF4 + lane;
 #pragma unroll
             for (int r = 0; r < kRows; r++)
                 nx[r] = load16<true>(p + r * kWave);
@@ -630,7 +633,8 @@ void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, ui
 // from the speculated one (`spec`) is listed for papr_launch_exact_redo.  *redo_count must be zero on entry.
 void papr_launch_exact_classify_swept(hipStream_t st, const void *seg_D, uint64_t ntiles, double *block_sums, double before,
                                       double delta, int32_t *tile_E, const int32_t *spec, uint32_t *redo_list,
-                                      uint32_t redo_cap, uint32_t *redo_count)
+                                      uint32_t redo_cap, uint32_t *redo_count, uint32_t *ambig_list, uint32_t ambig_cap,
+                                      uint32_t *ambig_count, uint32_t *ambig_sorted)
 {
     const uint32_t nb = (uint32_t)((ntiles + kTilesPerBlock - 1) / kTilesPerBlock);
     if (nb == 0)
@@ -639,7 +643,32 @@ void papr_launch_exact_classify_swept(hipStream_t st, const void *seg_D, uint64_
     hipLaunchKernelGGL(papr_exact_block_sums<true>, dim3(nb), dim3(256), 0, st, sums, ntiles, block_sums);
     hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before);
     hipLaunchKernelGGL(papr_exact_classify<true>, dim3(nb), dim3(256), 0, st, sums, ntiles, block_sums, delta, tile_E,
-                       (uint32_t *)nullptr, 0u, (uint32_t *)nullptr, spec, redo_list, redo_cap, redo_count);
+                       ambig_list, ambig_cap, ambig_count, spec, redo_list, redo_cap, redo_count);
+    if (ambig_list)  // a streamed shard: the unprovable tiles, ascending (they are read back from the file for the program)
+        hipLaunchKernelGGL(papr_exact_sort_list_kernel, dim3(1), dim3(512), 0, st, ambig_list, ambig_count, ambig_cap,
+                           ambig_sorted);
+}
+
+// the segment sums a one-read sweep left (D0 of either segment's pair) in the layout pass 1 writes its per-tile wave
+// sums in, so that papr_launch_exact_classify can take over from them (same order of addition: s0 + s1)
+__global__ __launch_bounds__(256) void papr_exact_segsums_to_tilesums_kernel(const double *__restrict__ seg_D, uint64_t ntiles,
+                                                                             double *__restrict__ tws)
+{
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < ntiles; t += (uint64_t)gridDim.x * 256) {
+        tws[t * PAPR_EXACT_TILE_WAVES + 0] = seg_D[4 * t];
+        tws[t * PAPR_EXACT_TILE_WAVES + 1] = seg_D[4 * t + 2];
+        for (int k = 2; k < PAPR_EXACT_TILE_WAVES; k++)
+            tws[t * PAPR_EXACT_TILE_WAVES + k] = 0.0;
+    }
+}
+
+void papr_launch_exact_segsums_to_tilesums(hipStream_t st, const void *seg_D, uint64_t ntiles, double *tile_wave_sums)
+{
+    if (ntiles == 0)
+        return;
+    const int blocks = (int)std::min<uint64_t>((ntiles + 255) / 256, 4096);
+    hipLaunchKernelGGL(papr_exact_segsums_to_tilesums_kernel, dim3(blocks), dim3(256), 0, st, (const double *)seg_D, ntiles,
+                       tile_wave_sums);
 }
 
 void papr_launch_exact_capture(hipStream_t st, const void *chunk, uint64_t chunk_tile0, uint64_t chunk_ntiles,
@@ -679,19 +708,19 @@ void papr_launch_exact_segments(hipStream_t st, int blocks, const void *data, ui
     hipLaunchKernelGGL((papr_exact_seg_kernel<false, kSegBlock>), dim3(blocks), dim3(kSegBlock),
                        (size_t)(kSegBlock / kWave) * kSegF4 * sizeof(float4), st, (const float4 *)data, nsegs, tile_E,
                        (double2 *)seg_D, (const float2 *)nullptr, 0u, (const uint32_t *)nullptr, none,
-                       (unsigned long long *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u);
+                       (unsigned long long *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u);
 }
 
 // the rounding functions of the LISTED tiles only (count read on the device: no host round trip in between)
 void papr_launch_exact_redo(hipStream_t st, int blocks, const void *data, const int32_t *tile_E, void *seg_D,
-                            const uint32_t *tile_list, const uint32_t *tile_count, uint32_t list_cap)
+                            const uint32_t *tile_list, const uint32_t *tile_count, uint32_t list_cap, int compact)
 {
     papr_ccdf_params none;
     memset(&none, 0, sizeof(none));
     hipLaunchKernelGGL((papr_exact_seg_kernel<false, kSegBlock>), dim3(blocks), dim3(kSegBlock),
                        (size_t)(kSegBlock / kWave) * kSegF4 * sizeof(float4), st, (const float4 *)data, (uint64_t)0, tile_E,
                        (double2 *)seg_D, (const float2 *)nullptr, 0u, (const uint32_t *)nullptr, none,
-                       (unsigned long long *)nullptr, tile_list, tile_count, list_cap);
+                       (unsigned long long *)nullptr, tile_list, tile_count, list_cap, compact ? 1u : 0u);
 }
 
 // ---- one-read sweep: speculated binades from the mean estimate's per-group sums ----------------------------
@@ -796,7 +825,7 @@ void papr_launch_exact_segments_ccdf(hipStream_t st, int blocks, const void *dat
     hipLaunchKernelGGL((papr_exact_seg_kernel<true, kFusedBlock>), dim3(blocks), dim3(kFusedBlock),
                        papr_exact_transpose_lds_bytes() + lds_table_bytes, st, (const float4 *)data, nsegs, tile_E,
                        (double2 *)seg_D, (const float2 *)tail, tail_samples, table, P, ghist, (const uint32_t *)nullptr,
-                       (const uint32_t *)nullptr, 0u);
+                       (const uint32_t *)nullptr, 0u, 0u);
 }
 
 void papr_launch_exact_groups(hipStream_t st, const int32_t *tile_E, uint64_t ntiles, const void *seg_D,

@@ -201,6 +201,9 @@ int run_exact_device(papr_hip_ctx *ctx, double before, uint64_t n_total, const C
 // (normally a fraction of a per cent of them), group composition and the program gather.  Everything is queued on
 // the stream; the caller synchronises.  *redo_overflow (valid after that synchronisation) != 0: more tiles to redo
 // than the list holds — the caller then runs the full rounding-function sweep (run_exact_full_redo).
+int run_exact_swept_streamed(papr_hip_ctx *ctx, double before, double delta, uint64_t ntiles, uint64_t ngroups, uint32_t tail,
+                             unsigned char *program_dev);
+
 int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total)
 {
     const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
@@ -224,11 +227,14 @@ int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total)
     unsigned char *program_dev = nullptr;
     HIPCHK(ctx, hipHostGetDevicePointer((void **)&program_dev, ctx->h_program, 0));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_redo + kCapRedo, 0, sizeof(uint32_t), ctx->stream));
+    if (!ctx->resident)
+        return run_exact_swept_streamed(ctx, before, delta, ntiles, ngroups, tail, program_dev);
     time_begin(ctx, 2, 0);
     papr_launch_exact_classify_swept(ctx->stream, ctx->d_seg_D, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E,
-                                     ctx->d_tile_E_spec, ctx->d_redo, kCapRedo, ctx->d_redo + kCapRedo);
+                                     ctx->d_tile_E_spec, ctx->d_redo, kCapRedo, ctx->d_redo + kCapRedo, nullptr, 0, nullptr,
+                                     nullptr);
     papr_launch_exact_redo(ctx->stream, ctx->num_cus, ctx->d_iq, ctx->d_tile_E, ctx->d_seg_D, ctx->d_redo,
-                           ctx->d_redo + kCapRedo, kCapRedo);
+                           ctx->d_redo + kCapRedo, kCapRedo, 0);
     papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
     time_end(ctx);
     papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, ctx->d_iq, nullptr,
@@ -237,6 +243,93 @@ int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total)
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_redo_count, ctx->d_redo + kCapRedo, sizeof(uint32_t), hipMemcpyDeviceToHost,
                                ctx->stream));
+    return PAPR_OK;
+}
+
+// The same for a shard that STREAMED through the sweep (papr_hip_load_file_sweep in exact-sum mode) and is gone: the
+// few tiles whose samples are needed once more — those whose speculated binade was wrong (their pairs are rebuilt) and
+// the unprovable ones (they travel raw in the sum program) — are read back from the file, a few MB instead of a
+// second pass over it.  More of them than the lists hold: *h_redo_count says so and the caller reads the file again.
+int run_exact_swept_streamed(papr_hip_ctx *ctx, double before, double delta, uint64_t ntiles, uint64_t ngroups, uint32_t tail,
+                             unsigned char *program_dev)
+{
+    if (!ctx->d_ambig) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_ambig, (2 * kCapRaw + 1) * sizeof(uint32_t)));
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_raw_store, (size_t)kCapRaw * PAPR_EXACT_TILE_SAMPLES * 8));
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_ambig + 2 * kCapRaw, 0, sizeof(uint32_t), ctx->stream));
+    time_begin(ctx, 2, 0);
+    papr_launch_exact_classify_swept(ctx->stream, ctx->d_seg_D, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E,
+                                     ctx->d_tile_E_spec, ctx->d_redo, kCapRedo, ctx->d_redo + kCapRedo, ctx->d_ambig, kCapRaw,
+                                     ctx->d_ambig + 2 * kCapRaw, ctx->d_ambig + kCapRaw);
+    time_end(ctx);
+    HIPCHK(ctx, hipGetLastError());
+    // which tiles?  (one round trip; the lists are a few KB)
+    // tiles (of 16 KiB: 512 MiB in all) read back before a second pass over the file is the better deal
+    // (PAPR_STREAM_REDO_CAP lowers it: the tests force the fall-back with 0)
+    const uint32_t kStreamRedoCap = (uint32_t)std::max(0, std::min(32768, env_int("PAPR_STREAM_REDO_CAP", 32768)));
+    std::vector<uint32_t> redo((size_t)kStreamRedoCap + 1), ambig(kCapRaw);
+    uint32_t nambig = 0;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_redo_count, ctx->d_redo + kCapRedo, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&nambig, ctx->d_ambig + 2 * kCapRaw, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t nredo = *ctx->h_redo_count;
+    if (nredo > kStreamRedoCap || nambig > kCapRaw) {
+        *ctx->h_redo_count = kCapRedo + 1;  // "too many": the caller falls back to the second read
+        return PAPR_OK;
+    }
+    if (nredo)
+        HIPCHK(ctx, hipMemcpyAsync(redo.data(), ctx->d_redo, nredo * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (nambig)
+        HIPCHK(ctx, hipMemcpyAsync(ambig.data(), ctx->d_ambig + kCapRaw, nambig * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->redo_store_tiles < nredo) {
+        if (ctx->d_redo_store) HIPCHK(ctx, hipFree(ctx->d_redo_store));
+        ctx->d_redo_store = nullptr;
+        ctx->redo_store_tiles = 0;
+        const size_t want = std::max<size_t>(nredo, 256);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_redo_store, want * PAPR_EXACT_TILE_SAMPLES * 8));
+        ctx->redo_store_tiles = want;
+    }
+    // read the tiles (through read_samples: the phantom sample of an odd-float file is patched there)
+    FileSrc fs;
+    int rc = open_file_src(ctx, ctx->path.c_str(), &fs);
+    if (rc)
+        return rc;
+    constexpr size_t kTileBytes = (size_t)PAPR_EXACT_TILE_SAMPLES * 8;
+    std::vector<unsigned char> host;
+    try {
+        host.resize(((size_t)nredo + nambig) * kTileBytes);
+    } catch (...) {
+        close_file_src(&fs);
+        return fail(ctx, PAPR_E_NOMEM, "out of host memory");
+    }
+    for (uint32_t k = 0; k < nredo + nambig && rc == PAPR_OK; k++) {
+        const uint64_t tile = k < nredo ? redo[k] : ambig[k - nredo];
+        if (read_samples(fs, ctx->file_first + tile * PAPR_EXACT_TILE_SAMPLES, PAPR_EXACT_TILE_SAMPLES,
+                         host.data() + (size_t)k * kTileBytes))
+            rc = fail(ctx, PAPR_E_IO, "read error in %s", ctx->path.c_str());
+    }
+    close_file_src(&fs);
+    if (rc)
+        return rc;
+    if (nredo)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_redo_store, host.data(), (size_t)nredo * kTileBytes, hipMemcpyHostToDevice, ctx->stream));
+    if (nambig)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_raw_store, host.data() + (size_t)nredo * kTileBytes, (size_t)nambig * kTileBytes,
+                                   hipMemcpyHostToDevice, ctx->stream));
+    time_begin(ctx, 2, 0);
+    if (nredo)
+        papr_launch_exact_redo(ctx->stream, (int)std::min<uint32_t>((uint32_t)ctx->num_cus, (nredo + 1) / 2), ctx->d_redo_store,
+                               ctx->d_tile_E, ctx->d_seg_D, ctx->d_redo, ctx->d_redo + kCapRedo, kCapRedo, 1);
+    papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
+    time_end(ctx);
+    papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, nullptr, ctx->d_raw_store,
+                           ctx->d_tail, ctx->n, tail, ctx->d_mixed_list, kCapMixed, ctx->d_raw_list, kCapRaw, ctx->d_plan,
+                           program_dev);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (`host` must outlive the copies)
     return PAPR_OK;
 }
 
@@ -371,7 +464,7 @@ static int papr_hip_exact_program_impl(papr_hip_ctx *ctx, double before, uint64_
 {
     if (!ctx || !program || !bytes)
         return PAPR_E_ARG;
-    int rc = exact_preconditions(ctx, before, false);
+    int rc = exact_preconditions(ctx, before, ctx->exact_swept);
     if (rc)
         return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -382,6 +475,9 @@ static int papr_hip_exact_program_impl(papr_hip_ctx *ctx, double before, uint64_
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         ctx->sweep_info.exact_redo_tiles = *ctx->h_redo_count;
         if (*ctx->h_redo_count > kCapRedo) {
+            if (!ctx->resident)
+                return fail(ctx, PAPR_E_LIMIT, "the streamed shard's binade speculation missed on too many tiles: use "
+                                               "papr_hip_ccdf_exact (it reads the file once more)");
             rc = run_exact_full_redo(ctx);
             if (rc)
                 return rc;
@@ -408,11 +504,27 @@ static int papr_hip_ccdf_exact_impl(papr_hip_ctx *ctx, const float *levels, int 
     if (rc)
         return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (ctx->exact_swept && ctx->resident) {
-        // one-read form: the sweep already holds what both results need (papr_hip_stats_sweep in exact-sum mode)
+    bool swept_form = ctx->exact_swept;
+    if (swept_form) {
+        // one-read form: the sweep already holds what both results need (papr_hip_stats_sweep, or a one-sweep ingest,
+        // in exact-sum mode)
         rc = run_exact_swept(ctx, before, n_total);
         if (rc)
             return rc;
+        if (!ctx->resident && *ctx->h_redo_count > kCapRedo) {
+            // a streamed shard whose speculation missed on more tiles than are worth reading back: the file goes
+            // through the fused sweep once more (below), classified from the segment sums the first pass left
+            ctx->sweep_info.exact_redo_tiles = *ctx->h_redo_count;
+            rc = ensure_exact_buffers(ctx);
+            if (rc)
+                return rc;
+            papr_launch_exact_segsums_to_tilesums(ctx->stream, ctx->d_seg_D, ctx->n / PAPR_EXACT_TILE_SAMPLES, ctx->d_tile_sums);
+            HIPCHK(ctx, hipGetLastError());
+            ctx->exact_swept = false;
+            swept_form = false;
+        }
+    }
+    if (swept_form) {
         rc = papr_hip_ccdf(ctx, levels, nlevels, counts_above);  // the stash recount (or, speculation missed, pass 2)
         if (rc)
             return rc;

@@ -252,6 +252,7 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
     int rc = open_file_src(ctx, ctx->path.c_str(), &fs);
     if (rc)
         return rc;
+    ctx->ingest.file_passes++;
     const bool to_resident = (pass == PASS_LOAD_STATS);
     const bool timed = (pass == PASS_LOAD_STATS || pass == PASS_STREAM_STATS);
     double t_mark = now_s();
@@ -467,10 +468,26 @@ int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, u
     SweepRun run;
     if (guess) {
         int reason = PAPR_SWEEP_MODE;
-        if (!ctx->exact && nsamples) {
+        // exact-sum mode rides along too when papr_hip_estimate_file left the per-tile sums of THIS range behind
+        // (the sweep then also builds every segment's rounding-function pair for a speculated binade, section 5)
+        const bool exact_ok = ctx->exact && ctx->est_file_valid && ctx->est_file_first == first_sample &&
+                              ctx->est_file_n == nsamples;
+        if ((!ctx->exact || exact_ok) && nsamples) {
+            ctx->est_groups_valid = exact_ok;
             rc = ensure_ingest(ctx, !fits);  // fixes the chunk size
             if (rc == PAPR_OK)
                 rc = sweep_prepare(ctx, guess, nguess, nsamples, ctx->stage_bytes / 8, &run, &reason);
+            if (rc == PAPR_OK && reason == PAPR_SWEEP_OK && run.exact) {
+                rc = ensure_exact_buffers(ctx);
+                if (rc == PAPR_OK) {
+                    papr_launch_exact_spec(ctx->stream, ctx->d_est_groups, ctx->est_ngroups, (uint32_t)ctx->est_ratio,
+                                           (double)ctx->est_ratio, ctx->exact_before_hint,
+                                           ctx->d_est_groups + 4 * ctx->est_groups_cap, nsamples / PAPR_EXACT_TILE_SAMPLES,
+                                           ctx->d_tile_E_spec);
+                    if (hipGetLastError() != hipSuccess)
+                        rc = fail(ctx, PAPR_E_HIP, "the binade speculation failed to launch");
+                }
+            }
             if (rc) {
                 ctx->loaded = false;
                 return rc;
@@ -522,6 +539,10 @@ int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, u
         if (rc) {
             ctx->loaded = false;
             return rc;
+        }
+        if (run.exact) {  // d_seg_D holds every segment's sum and its pair for the speculated binade
+            ctx->exact_swept = true;
+            ctx->exact_valid = true;
         }
     }
     if (std::isnan(st.sum)) {
@@ -622,6 +643,23 @@ static int papr_hip_estimate_file_impl(papr_hip_ctx *ctx, const char *path, uint
         if (rc == PAPR_OK && hipMalloc((void **)&d_sq, sq_count * sizeof(double)) != hipSuccess)
             rc = fail(ctx, PAPR_E_NOMEM, "hipMalloc for the estimate failed");
     }
+    // exact-sum mode: keep the per-tile sampled sums on the device (as papr_hip_estimate does) — a one-sweep ingest of
+    // the same range speculates every tile's running-sum binade from them
+    ctx->est_file_valid = false;
+    double *group_sums = nullptr;
+    if (rc == PAPR_OK && ctx->exact) {
+        if (ctx->est_groups_cap < ngroups) {
+            if (ctx->d_est_groups) (void)hipFree(ctx->d_est_groups);
+            ctx->d_est_groups = nullptr;
+            ctx->est_groups_cap = 0;
+            const uint64_t cap = std::max<uint64_t>(ngroups, 4096);
+            if (hipMalloc((void **)&ctx->d_est_groups, cap * 5 * sizeof(double)) != hipSuccess)
+                rc = fail(ctx, PAPR_E_NOMEM, "hipMalloc for the estimate failed");
+            else
+                ctx->est_groups_cap = cap;
+        }
+        group_sums = ctx->d_est_groups;
+    }
     std::vector<ReadBatch> batches(nbatches);
     const FileSrc *fsp = &fs;
     auto submit = [&](uint64_t bi) {
@@ -662,7 +700,8 @@ static int papr_hip_estimate_file_impl(papr_hip_ctx *ctx, const char *path, uint
         }
         const int blocks = (int)std::min<uint64_t>(cnt, (uint64_t)blocks_max);
         time_begin(ctx, 4, cnt * kTileBytes);
-        papr_launch_estimate(ctx->stream, blocks, ctx->d_stage[b], cnt, 1, ctx->d_partials + records, nullptr, d_sq + records);
+        papr_launch_estimate(ctx->stream, blocks, ctx->d_stage[b], cnt, 1, ctx->d_partials + records,
+                             group_sums ? group_sums + 4 * bi * per_batch : nullptr, d_sq + records);
         time_end(ctx);
         records += (size_t)blocks;
         if (hipEventRecord(ctx->ev_copy[b], ctx->stream) != hipSuccess)
@@ -701,6 +740,13 @@ static int papr_hip_estimate_file_impl(papr_hip_ctx *ctx, const char *path, uint
     est->sum = S * ((double)nsamples / (double)sampled);
     est->n = nsamples;
     ctx->sweep_info.estimate_samples = sampled;
+    if (group_sums) {
+        ctx->est_ngroups = ngroups;
+        ctx->est_ratio = ratio;
+        ctx->est_file_valid = true;
+        ctx->est_file_first = first_sample;
+        ctx->est_file_n = nsamples;
+    }
     return PAPR_OK;
 }
 

@@ -88,11 +88,15 @@ void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, ui
 void papr_launch_exact_spec(hipStream_t st, const double *group_sums, uint64_t ngroups, uint32_t ratio, double scale,
                             double before, double *group_prefix, uint64_t ntiles, int32_t *spec);
 void papr_launch_exact_fill_spec(hipStream_t st, int32_t *spec, uint64_t ntiles, int32_t E);
+/* ambig_* may be null (resident shards); otherwise the unprovable tiles are also listed, ascending, in ambig_sorted */
 void papr_launch_exact_classify_swept(hipStream_t st, const void *seg_D, uint64_t ntiles, double *block_sums, double before,
                                       double delta, int32_t *tile_E, const int32_t *spec, uint32_t *redo_list,
-                                      uint32_t redo_cap, uint32_t *redo_count);
+                                      uint32_t redo_cap, uint32_t *redo_count, uint32_t *ambig_list, uint32_t ambig_cap,
+                                      uint32_t *ambig_count, uint32_t *ambig_sorted);
+/* compact != 0: the k-th listed tile's samples are the k-th tile of `data` (tiles read back from the file) */
 void papr_launch_exact_redo(hipStream_t st, int blocks, const void *data, const int32_t *tile_E, void *seg_D,
-                            const uint32_t *tile_list, const uint32_t *tile_count, uint32_t list_cap);
+                            const uint32_t *tile_list, const uint32_t *tile_count, uint32_t list_cap, int compact);
+void papr_launch_exact_segsums_to_tilesums(hipStream_t st, const void *seg_D, uint64_t ntiles, double *tile_wave_sums);
 void papr_launch_exact_capture(hipStream_t st, const void *chunk, uint64_t chunk_tile0, uint64_t chunk_ntiles,
                                const uint32_t *sorted, const uint32_t *count, uint32_t cap, void *raw_store);
 void papr_launch_exact_segments(hipStream_t st, int blocks, const void *data, uint64_t nsegs, const int32_t *tile_E,
@@ -125,12 +129,13 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
                           papr_partial *out, double *group_sums /* may be null: 4 sampled sums per group */,
                           double *block_sq /* may be null: per workgroup, sum of squared piece sums */);
 int papr_sweep_variant(int variant); /* the sweep geometry used for a variant id, or -1 */
-#define PAPR_SWEEP_VARIANT_IS_LUT2(v) (((v) >= 20 && (v) <= 29) || ((v) >= 70 && (v) <= 79)) /* compact table: papr_sweep_kernel<LUT2>, papr_sweep_split_kernel */
+#define PAPR_SWEEP_VARIANT_IS_LUT2(v) (((v) >= 20 && (v) <= 29) || ((v) >= 70 && (v) <= 79) || (v) == 18) /* compact table: papr_sweep_kernel<LUT2>, papr_sweep_split_kernel */
 int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_t *stash_lds); /* 0, or -1 */
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
                        uint64_t base_index, int map, papr_partial *out, const void *tail, uint32_t tail_samples,
                        const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist, float *stash,
-                       unsigned long long *seg_counts, uint64_t seg_cap, unsigned long long *gave_up);
+                       unsigned long long *seg_counts, uint64_t seg_cap, unsigned long long *gave_up,
+                       unsigned long long *seg_real /* per workgroup: powers stashed, without padding */);
 void papr_launch_ccdf_power(hipStream_t st, int blocks, bool lut, size_t lds_bytes, const float *stash,
                             const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs, uint32_t split,
                             const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist);

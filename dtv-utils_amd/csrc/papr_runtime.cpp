@@ -561,6 +561,7 @@ void papr_hip_close(papr_hip_ctx *ctx)
     if (ctx->d_plan) (void)hipFree(ctx->d_plan);
     if (ctx->d_ambig) (void)hipFree(ctx->d_ambig);
     if (ctx->d_raw_store) (void)hipFree(ctx->d_raw_store);
+    if (ctx->d_redo_store) (void)hipFree(ctx->d_redo_store);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->d_hist) (void)hipFree(ctx->d_hist);

@@ -225,6 +225,10 @@ struct papr_hip_ctx {
     double *d_est_groups = nullptr;              // papr_hip_estimate: sampled sum per estimate group (exact one-read sweep)
     uint64_t est_groups_cap = 0, est_ngroups = 0, est_ratio = 0;
     bool est_groups_valid = false;               // ... describe the CURRENT shard
+    bool est_file_valid = false;                 // ... came from papr_hip_estimate_file for this file range (exact mode):
+    uint64_t est_file_first = 0, est_file_n = 0; //     papr_hip_load_file_sweep of the same range may speculate from them
+    float *d_redo_store = nullptr;               // streamed shards: the tiles to redo, read back from the file
+    size_t redo_store_tiles = 0;
     int band_hint = 0;                           // papr_hip_set_band: half-width (log2) for the next sweeps, 0 = default
     double exact_before_hint = 0.0;              // estimated sum of everything before this shard (papr_hip_set_exact_hint)
     uint32_t *h_redo_count = nullptr;            // pinned

@@ -88,7 +88,26 @@ constexpr uint32_t kGiveUpMin = 16384;  // in-band samples of a workgroup before
 
 typedef float f32x4s __attribute__((ext_vector_type(4)));
 
-struct WaveStash {
+// store policies for the stash: 0 plain, 1 nontemporal, 2 write-through (sc0 sc1)
+template <int WT>
+__device__ __forceinline__ void store16(float *p, f32x4s v)
+{
+    if constexpr (WT == 2) {
+        // The s_nop belongs to the store: hipcc's hazard recogniser does not look inside inline asm, and gfx940+ needs
+        // two wait states between a VMEM store of more than 8 bytes and a VALU write to its data registers — without
+        // them the next instruction can overwrite the powers before the store has read them (seen as wrong, run-to-run
+        // different stash contents whenever the scheduler happened to put a VALU write right behind this store).
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" : : "v"(p), "v"(v) : "memory");
+    } else if constexpr (WT == 1) {
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4s *>(p));
+    } else {
+        *reinterpret_cast<f32x4s *>(p) = v;
+    }
+}
+
+// SP16: spill in 16-byte stores (a partial quad padded with quiet NaNs, which the recount ignores) instead of dwords
+template <bool SP16 = false>
+struct WaveStashT {
     float *buf;                         // this wave's slice of LDS
     uint32_t *fill;                     // LDS: entries in buf (this wave's counter)
     float *__restrict__ seg;            // this workgroup's stash segment
@@ -98,6 +117,7 @@ struct WaveStash {
     uint32_t table_words, neutral_x;
     unsigned long long seg_start;       // the segment's length when this launch began
     unsigned long long *gave_up;        // device counter of give-ups
+    unsigned long long *seg_real;       // LDS: powers stashed without padding (SP16)
 
     __device__ __forceinline__ void put(float pw, bool take)
     {
@@ -115,21 +135,37 @@ struct WaveStash {
         if (n <= limit)
             return;
         const uint32_t lane = threadIdx.x & (kWave - 1);
+        const uint32_t nres = SP16 ? ((n + 3u) & ~3u) : n;  // floats reserved in the segment
         unsigned long long pos = 0;
         if (lane == 0) {
-            pos = atomicAdd(seg_fill, (unsigned long long)n);  // counts even what no longer fits: the host sees the overflow
+            pos = atomicAdd(seg_fill, (unsigned long long)nres);  // counts even what no longer fits: the host sees the overflow
+            if constexpr (SP16)
+                atomicAdd(seg_real, (unsigned long long)n);
             *(volatile lds_u32 *)(lds_u32 *)fill = 0;
         }
         pos = uniform_u64(pos);  // lane 0's value, in scalar registers
-        for (uint32_t i = lane; i < n; i += kWave)
-            if (pos + i < seg_cap)  // write-through (sc0 sc1): 1-3 % faster than leaving these lines dirty in L2 for a later eviction
-                __hip_atomic_store(&seg[pos + i], buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if constexpr (SP16) {
+            for (uint32_t i = 4 * lane; i < nres; i += 4 * kWave) {  // (the slice and the segment are 16-byte aligned)
+                f32x4s v = *reinterpret_cast<const f32x4s *>(buf + i);
+                const float pad = __uint_as_float(PAPR_STASH_PAD_BITS);
+                v.y = i + 1 < n ? v.y : pad;
+                v.z = i + 2 < n ? v.z : pad;
+                v.w = i + 3 < n ? v.w : pad;
+                if (pos + i + 4 <= seg_cap)
+                    store16<2>(seg + pos + i, v);
+            }
+        } else {
+            for (uint32_t i = lane; i < n; i += kWave)
+                if (pos + i < seg_cap)  // write-through (sc0 sc1): 1-3 % faster than leaving these lines dirty in L2 for a later eviction
+                    __hip_atomic_store(&seg[pos + i], buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         __builtin_amdgcn_wave_barrier();
-        const uint32_t got = (uint32_t)(pos - seg_start) + n;  // (a workgroup folds < 2^32 samples per launch)
-        if (pos <= seg_cap && (pos + n > seg_cap || (got >= kGiveUpMin && got > folded / 2)))
+        const uint32_t got = (uint32_t)(pos - seg_start) + nres;  // (a workgroup folds < 2^32 samples per launch)
+        if (pos <= seg_cap && (pos + nres > seg_cap || (got >= kGiveUpMin && got > folded / 2)))
             sweep_give_up(tab, table_words, neutral_x, seg_fill, seg_cap, gave_up);  // (pos > seg_cap: someone already did)
     }
 };
+typedef WaveStashT<false> WaveStash;
 
 }  // namespace
 
@@ -365,7 +401,7 @@ __device__ __forceinline__ void sweep_record(double sum, const TileTrack &tr, co
 // 4 LUT lookup, 8 trackers, 16 sum, 32 spill check.  The results of such a launch are meaningless.
 // LUT2: the compact band-edge table of papr_kernels.h (two edges per cell: 1-8 KiB instead of 32-40), which lets small
 // workgroups — the geometry papr_stats_kernel runs best in — afford a table of their own.
-template <int BLOCK, int U, bool NT, int PIPE, int ABL = 0, bool LUT2 = false>
+template <int BLOCK, int U, bool NT, int PIPE, int ABL = 0, bool LUT2 = false, bool SP16 = false>
 __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restrict__ data, uint64_t ntiles,
                                                             uint64_t base_index, int map,
                                                             papr_partial *__restrict__ out,
@@ -374,33 +410,38 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
                                                             unsigned long long *__restrict__ ghist,
                                                             float *__restrict__ stash,
                                                             unsigned long long *__restrict__ seg_counts,
-                                                            uint64_t seg_cap, unsigned long long *__restrict__ gave_up)
+                                                            uint64_t seg_cap, unsigned long long *__restrict__ gave_up,
+                                                            unsigned long long *__restrict__ seg_real)
 {
     constexpr uint64_t TILE_F4 = (uint64_t)BLOCK * U;
     constexpr uint32_t SLICE = papr_sweep_slice_floats(U);
-    __shared__ unsigned long long seg_fill;
+    __shared__ unsigned long long seg_fill, seg_real_sh;
     __shared__ uint32_t wave_fill[BLOCK / kWave];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t nbins = P.nkeys + 2;  // + the NaN trash bin
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
     uint32_t *hist = tab + P.table_words;
-    float *slices = reinterpret_cast<float *>(hist + P.copies * nbins);
+    // (16-byte aligned: the table and the slices are read 16 bytes at a time; the launch reserves the 12 bytes)
+    float *slices = reinterpret_cast<float *>(hist + ((P.copies * nbins + 3u) & ~3u));
 
     const uint32_t t = threadIdx.x;
     for (uint32_t k = t; k < P.table_words; k += BLOCK)
         tab[k] = table[k];
     for (uint32_t k = t; k < P.copies * nbins; k += BLOCK)
         hist[k] = 0;
-    if (t == 0)
+    if (t == 0) {
         seg_fill = seg_counts[blockIdx.x];  // segments keep filling over the launches of a chunked ingest
+        seg_real_sh = seg_real[blockIdx.x];
+    }
     if (t < BLOCK / kWave)
         wave_fill[t] = 0;
     __syncthreads();
 
     const uint2 *lut_biased = reinterpret_cast<const uint2 *>(tab) - ((int32_t)P.cell_lo - 1);
     uint32_t *my = hist + ((t / kWave) % P.copies) * nbins;
-    WaveStash ws{slices + (t / kWave) * SLICE, &wave_fill[t / kWave], stash + (uint64_t)blockIdx.x * seg_cap, &seg_fill,
-                 seg_cap, tab, P.table_words, LUT2 ? PAPR_LUT2_NEVER : 0u, seg_fill, gave_up};
+    WaveStashT<SP16> ws{slices + (t / kWave) * SLICE, &wave_fill[t / kWave], stash + (uint64_t)blockIdx.x * seg_cap,
+                        &seg_fill, seg_cap, tab, P.table_words, LUT2 ? PAPR_LUT2_NEVER : 0u, seg_fill, gave_up,
+                        &seg_real_sh};
     // cell index straight from the bit pattern: lut_biased[cell] with cell clamped to [cell_lo - 1, cell_lo + ncells]
     const int32_t cell_last = (int32_t)(P.cell_lo + P.ncells);
     int32_t cell_first;  // pinned in a VGPR for the whole kernel (v_med3 takes one scalar operand)
@@ -510,8 +551,10 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
 
     sweep_record<BLOCK, BLOCK, U>(sum, tr, w, data, base_index, t, out);
     hist_flush<BLOCK>(hist, nbins, P.copies, ghist);  // (starts with a barrier: every wave has spilled)
-    if (t == 0)
+    if (t == 0) {
         seg_counts[blockIdx.x] = seg_fill;
+        seg_real[blockIdx.x] = SP16 ? seg_real_sh : seg_fill;  // (dword spills: no padding, the two are the same)
+    }
 }
 
 // =============================================================================
@@ -530,7 +573,7 @@ __global__ __launch_bounds__((PW + PW * NB) * kWave) void papr_sweep_split_kerne
     const float4 *__restrict__ data, uint64_t ntiles, uint64_t base_index, int map, papr_partial *__restrict__ out,
     const float2 *__restrict__ tail, uint32_t tail_samples, const uint32_t *__restrict__ table, papr_ccdf_params P,
     unsigned long long *__restrict__ ghist, float *__restrict__ stash, unsigned long long *__restrict__ seg_counts,
-    uint64_t seg_cap, unsigned long long *__restrict__ gave_up)
+    uint64_t seg_cap, unsigned long long *__restrict__ gave_up, unsigned long long *__restrict__ seg_real)
 {
     constexpr int ROW = PW * kWave;                      // loader lanes: one tile row
     constexpr int BW = PW * NB;                          // binner waves
@@ -619,7 +662,7 @@ __global__ __launch_bounds__((PW + PW * NB) * kWave) void papr_sweep_split_kerne
         const uint2 *lut_biased = reinterpret_cast<const uint2 *>(tab) - ((int32_t)P.cell_lo - 1);
         uint32_t *my = hist + (bidx % P.copies) * nbins;
         WaveStash ws{slices + bidx * SLICE, &wave_fill[bidx], stash + (uint64_t)blockIdx.x * seg_cap, &seg_fill,
-                     seg_cap, tab, P.table_words, PAPR_LUT2_NEVER, seg_fill, gave_up};
+                     seg_cap, tab, P.table_words, PAPR_LUT2_NEVER, seg_fill, gave_up, nullptr};
         const int32_t cell_last = (int32_t)(P.cell_lo + P.ncells);
         int32_t cell_first;  // pinned in a VGPR for the whole kernel (v_med3 takes one scalar operand)
         asm volatile("v_mov_b32 %0, %1" : "=v"(cell_first) : "s"((int32_t)P.cell_lo - 1));
@@ -673,8 +716,10 @@ __global__ __launch_bounds__((PW + PW * NB) * kWave) void papr_sweep_split_kerne
 
     sweep_record<BLOCK, ROW, LU>(sum, tr, w, data, base_index, loader ? t : 0u, out);
     hist_flush<BLOCK>(hist, nbins, P.copies, ghist);  // (starts with a barrier: every binner has spilled)
-    if (t == 0)
+    if (t == 0) {
         seg_counts[blockIdx.x] = seg_fill;
+        seg_real[blockIdx.x] = seg_fill;
+    }
 }
 
 // =============================================================================
@@ -701,23 +746,6 @@ __global__ __launch_bounds__((PW + PW * NB) * kWave) void papr_sweep_split_kerne
 
 namespace {
 
-
-// store policies for the stash: 0 plain, 1 nontemporal, 2 write-through (sc0 sc1)
-template <int WT>
-__device__ __forceinline__ void store16(float *p, f32x4s v)
-{
-    if constexpr (WT == 2) {
-        // The s_nop belongs to the store: hipcc's hazard recogniser does not look inside inline asm, and gfx940+ needs
-        // two wait states between a VMEM store of more than 8 bytes and a VALU write to its data registers — without
-        // them the next instruction can overwrite the powers before the store has read them (seen as wrong, run-to-run
-        // different stash contents whenever the scheduler happened to put a VALU write right behind this store).
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" : : "v"(p), "v"(v) : "memory");
-    } else if constexpr (WT == 1) {
-        __builtin_nontemporal_store(v, reinterpret_cast<f32x4s *>(p));
-    } else {
-        *reinterpret_cast<f32x4s *>(p) = v;
-    }
-}
 
 template <uint32_t RING, int WT>
 struct StashRing {
@@ -1308,6 +1336,9 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
 #define PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X) X(20, 256, 4, 1) X(24, 1024, 4, 0)
 #endif
 
+// papr_sweep_kernel with 16-byte stash spills: id, workgroup size, loads per lane, loop form, compact table
+#define PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X) X(5, 1024, 4, 0, false) X(18, 1024, 4, 0, true) X(19, 512, 4, 0, false)
+
 // loader / binner split (papr_sweep_split_kernel): id, loader waves, binners per loader, loads per lane per tile, ring depth
 // (measured slower than papr_sweep_kernel in every shape — DESIGN.md section 4b — so only `make MEASURE=1` builds it)
 #ifdef PAPR_MEASURE
@@ -1325,6 +1356,9 @@ int papr_sweep_variant(int variant)
     switch (variant) {
 #define X(V, PW, NB, LU, D) case V: return V;
         PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X)
+#undef X
+#define X(V, B, U, P, L2) case V: return V;
+        PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X)
 #undef X
 #define X(V, B, U, P) case V: return V;
         PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X)
@@ -1350,11 +1384,19 @@ int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_
         return 0;
         PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X)
 #undef X
+#define X(V, B, U, P, L2)                                                                 \
+    case V:                                                                                \
+        *threads = B;                                                                      \
+        *tile_samples = 2ull * B * U;                                                      \
+        *stash_lds = (size_t)(B / kWave) * papr_sweep_slice_floats(U) * sizeof(float) + 16; \
+        return 0;
+        PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X)
+#undef X
 #define X(V, B, U, P)                                                                     \
     case V:                                                                                \
         *threads = B;                                                                      \
         *tile_samples = 2ull * B * U;                                                      \
-        *stash_lds = (size_t)(B / kWave) * papr_sweep_slice_floats(U) * sizeof(float);     \
+        *stash_lds = (size_t)(B / kWave) * papr_sweep_slice_floats(U) * sizeof(float) + 16; \
         return 0;
         PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X)
 #undef X
@@ -1362,7 +1404,7 @@ int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_
     case V:                                                                                \
         *threads = B;                                                                      \
         *tile_samples = 2ull * B * U;                                                      \
-        *stash_lds = (size_t)(B / kWave) * papr_sweep_slice_floats(U) * sizeof(float);     \
+        *stash_lds = (size_t)(B / kWave) * papr_sweep_slice_floats(U) * sizeof(float) + 16; \
         return 0;
         PAPR_FOR_EACH_SWEEP_VARIANT(X)
 #undef X
@@ -1379,22 +1421,31 @@ int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
                        uint64_t base_index, int map, papr_partial *out, const void *tail, uint32_t tail_samples,
                        const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist, float *stash,
-                       unsigned long long *seg_counts, uint64_t seg_cap, unsigned long long *gave_up)
+                       unsigned long long *seg_counts, uint64_t seg_cap, unsigned long long *gave_up,
+                       unsigned long long *seg_real)
 {
     switch (variant) {
 #define X(V, PW, NB, LU, D)                                                                                          \
     case V:                                                                                                           \
         hipLaunchKernelGGL((papr_sweep_split_kernel<PW, NB, LU, D>), dim3(blocks), dim3((PW + PW * NB) * kWave),      \
                            lds_bytes, st, (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail,   \
-                           tail_samples, table, P, ghist, stash, seg_counts, seg_cap, gave_up);                       \
+                           tail_samples, table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real);                       \
         break;
         PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X)
+#undef X
+#define X(V, B, U, PP, L2)                                                                                           \
+    case V:                                                                                                           \
+        hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP, 0, L2, true>), dim3(blocks), dim3(B), lds_bytes, st,    \
+                           (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real);                           \
+        break;
+        PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X)
 #undef X
 #define X(V, A)                                                                                                      \
     case V:                                                                                                           \
         hipLaunchKernelGGL((papr_sweep_kernel<1024, 4, true, 0, A>), dim3(blocks), dim3(1024), lds_bytes, st,         \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
-                           table, P, ghist, stash, seg_counts, seg_cap, gave_up);                                            \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real);                                            \
         break;
         PAPR_FOR_EACH_ABLATION(X)
 #undef X
@@ -1402,7 +1453,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     case V:                                                                                                           \
         hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP, 0, true>), dim3(blocks), dim3(B), lds_bytes, st,        \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
-                           table, P, ghist, stash, seg_counts, seg_cap, gave_up);                                            \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real);                                            \
         break;
         PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X)
 #undef X
@@ -1410,7 +1461,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     case V:                                                                                                           \
         hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP>), dim3(blocks), dim3(B), lds_bytes, st,                 \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
-                           table, P, ghist, stash, seg_counts, seg_cap, gave_up);                                            \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real);                                            \
         break;
         PAPR_FOR_EACH_SWEEP_VARIANT(X)
 #undef X
@@ -1496,6 +1547,11 @@ void papr_sweep_prepare_device(void)
     (void)hipFuncSetAttribute((const void *)papr_sweep_split_kernel<PW, NB, LU, D>,                                   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
     PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X)
+#undef X
+#define X(V, B, U, PP, L2)                                                                                           \
+    (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<B, U, true, PP, 0, L2, true>,                          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X)
 #undef X
     (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
     (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, want);

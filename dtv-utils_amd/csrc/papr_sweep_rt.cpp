@@ -197,7 +197,7 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
                                ctx->stream));
     // (+ 1: the give-up counter behind the segment arrays)
     HIPCHK(ctx, hipMemsetAsync(ctx->d_sweep_hist, 0,
-                               ((size_t)run->nbins + (size_t)(run->v2 ? 2 : 1) * run->blocks + 1) * sizeof(unsigned long long),
+                               ((size_t)run->nbins + 2 * (size_t)run->blocks + 1) * sizeof(unsigned long long),
                                ctx->stream));
     *reason = PAPR_SWEEP_OK;
     return PAPR_OK;
@@ -250,7 +250,8 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
     time_begin(ctx, 3, n * 8);
     papr_launch_sweep(ctx->stream, run.variant, blocks, run.bands.lds_bytes + run.stash_lds, data, ntiles, base_index, map,
                       ctx->d_partials + slot, data + 2 * (n - tail), tail, ctx->d_table, run.bands.P, ctx->d_sweep_hist,
-                      ctx->d_stash, ctx->d_sweep_hist + run.nbins, run.seg_cap, ctx->d_sweep_hist + run.nbins + run.blocks);
+                      ctx->d_stash, ctx->d_sweep_hist + run.nbins, run.seg_cap, ctx->d_sweep_hist + run.nbins + 2 * run.blocks,
+                      ctx->d_sweep_hist + run.nbins + run.blocks);
     time_end(ctx);
     HIPCHK(ctx, hipGetLastError());
     *nrecords = blocks;
@@ -261,7 +262,7 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
 int sweep_fetch(papr_hip_ctx *ctx, const SweepRun &run)
 {
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_sweep_hist, ctx->d_sweep_hist,
-                               ((size_t)run.nbins + (size_t)(run.v2 ? 2 : 1) * run.blocks + 1) * sizeof(unsigned long long),
+                               ((size_t)run.nbins + 2 * (size_t)run.blocks + 1) * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, ctx->stream));
     return PAPR_OK;
 }
@@ -274,7 +275,7 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
     uint64_t stash_count = 0, in_bands = 0;
     bool overflow = false;
     for (int b = 0; b < run.blocks; b++) {
-        stash_count += H[run.nbins + (run.v2 ? run.blocks : 0) + b];  // v2: the powers stashed, without padding
+        stash_count += H[run.nbins + run.blocks + b];  // the powers stashed, without padding
         overflow = overflow || H[run.nbins + b] > run.seg_cap;
     }
     for (uint32_t b = 1; b < run.nbins; b += 2)
@@ -302,7 +303,7 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
     info.reason = PAPR_SWEEP_OK;
     info.stash_samples = stash_count;
     info.stash_capacity = run.seg_cap * (uint64_t)run.blocks;  // what this sweep could use (one segment per workgroup)
-    info.gave_up = (uint32_t)std::min<unsigned long long>(H[run.nbins + (run.v2 ? 2 : 1) * run.blocks], 0xFFFFFFFFull);
+    info.gave_up = (uint32_t)std::min<unsigned long long>(H[run.nbins + 2 * run.blocks], 0xFFFFFFFFull);
     return PAPR_OK;
 }
 

@@ -116,6 +116,8 @@ static void *shard_thread(void *arg)
         }
         const int nguess = est_total.n ? papr_guess_levels(&est_total, s->graph, s->graph ? 48.0 : 60.0, s->levels, PAPR_HIP_MAX_LEVELS) : 0;
         papr_hip_set_band(s->ctx, papr_sweep_band_for(&est_total));
+        if (s->exact) /* the running sum in front of this shard, about: the sweep speculates the sum's binades from it */
+            (void)papr_hip_set_exact_hint(s->ctx, isfinite(before) && before >= 0.0 ? before : 0.0);
         rc = papr_hip_load_file_sweep(s->ctx, s->path, s->first, s->count, s->levels, nguess);
     } else {
         rc = papr_hip_load_file(s->ctx, s->path, s->first, s->count);
@@ -132,6 +134,11 @@ static void *shard_thread(void *arg)
         return NULL;
     }
     papr_hip_get_sweep_info(s->ctx, &s->sweep);
+    {
+        papr_hip_ingest_timing after;
+        if (papr_hip_get_ingest_timing(s->ctx, &after) == PAPR_OK)
+            s->ingest.file_passes = after.file_passes; /* (the analysis may have had to stream the file again) */
+    }
     s->t_done = now_s();
     return NULL;
 }
@@ -222,8 +229,9 @@ int main(int argc, char **argv)
     }
     ngpu = used;
 
-    /* one-sweep ingest (tree-sum mode): by default for shards that will not stay in HBM, where it saves a whole
-     * second read of the file (the shard threads settle that between them once their contexts know the budget) */
+    /* one-sweep ingest: by default for shards that will not stay in HBM, where it saves a whole second read of the
+     * file — in exact-sum mode too: the few tiles the sum program needs again are read back from the file (the shard
+     * threads settle that between them once their contexts know the budget) */
     env = getenv("PAPR_ONE_SWEEP");
     const int one_sweep = env && env[0] != '\0' ? (atoi(env) > 0 ? 2 : 0) : 1; /* 2 = always, 1 = when the file is streamed */
     papr_exchange *xs[MAX_GPUS];
@@ -233,7 +241,7 @@ int main(int argc, char **argv)
     }
     for (int g = 0; g < ngpu; g++) {
         sh[g].xch = xs[g];
-        sh[g].ingest_sweep = exact ? 0 : one_sweep;
+        sh[g].ingest_sweep = one_sweep;
         sh[g].levels = (float *)malloc(PAPR_HIP_MAX_LEVELS * sizeof(float));
         sh[g].counts = (uint64_t *)calloc(PAPR_HIP_MAX_LEVELS, sizeof(uint64_t));
         if (!sh[g].levels || !sh[g].counts) {
@@ -325,11 +333,11 @@ int main(int argc, char **argv)
                 "\"ingest_pass1_s\": %.6f, \"exact_sum\": %d, \"exact_redo_tiles\": %u, \"analysis_s\": %.6f, \"total_s\": %.6f, "
                 "\"msamples_per_s\": %.3f, \"ingest_GBps\": %.2f, \"gpu0_ingest\": {\"setup_s\": %.4f, \"read_s\": %.4f, "
                 "\"buffer_wait_s\": %.4f, \"issue_s\": %.4f, \"drain_s\": %.4f, \"chunks\": %llu, \"reader_threads\": %d, "
-                "\"resident\": %d, \"o_direct\": %d, \"numa_bound\": %d, \"io_uring\": %d}}\n",
+                "\"resident\": %d, \"o_direct\": %d, \"numa_bound\": %d, \"io_uring\": %d, \"file_passes\": %d}}\n",
                 (unsigned long long)nsamples, (unsigned long long)nsamples * 8, ngpu, nlevels, t_open - t0, swept, resolved,
                 t_loaded - t_open, r->exact_sum, r->exact_redo_tiles, t2 - t_loaded, t3 - t0, (double)nsamples / (t3 - t0) / 1e6,
                 (double)nsamples * 8 / (t_loaded - t_open) / 1e9, it->setup_s, it->read_s, it->buffer_wait_s, it->issue_s,
-                it->drain_s, (unsigned long long)it->chunks, it->reader_threads, it->resident, it->o_direct, it->numa_bound, it->io_uring);
+                it->drain_s, (unsigned long long)it->chunks, it->reader_threads, it->resident, it->o_direct, it->numa_bound, it->io_uring, it->file_passes);
     }
 
     for (int g = 0; g < ngpu; g++) {

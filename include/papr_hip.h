@@ -104,7 +104,7 @@ typedef struct papr_hip_ingest_timing {
     int o_direct;         /* 1 = the file was read with O_DIRECT (not in the page cache, or PAPR_O_DIRECT=1) */
     int numa_bound;       /* 1 = reader threads and pinned staging buffers sit on the GPU's NUMA node (PAPR_NUMA=0 disables) */
     int io_uring;         /* 1 = the O_DIRECT reads went through one io_uring instead of the reader threads (PAPR_IO_URING=0 disables) */
-    int reserved;
+    int file_passes;      /* whole passes over the shard's file range so far: 1 after the ingest, more when later calls had to re-stream it */
 } papr_hip_ingest_timing;
 
 /* Launch geometry knobs.  0 always means "built-in default" (chosen from the

@@ -71,7 +71,7 @@ def test_sweep_equals_oracle_sizes(pkg, orc, gpu, n, graph):
                                   for v, b, m in [(1, 96, 1), (1, 1000, 2), (4, 7, 0), (4, 1, 0), (4, 0, 2), (8, 0, 0),
                                                   (8, 64, 2), (13, 0, 0), (13, 1536, 2), (13, 300, 1), (14, 0, 0),
                                                   (14, 8, 2), (20, 0, 0), (20, 96, 1), (24, 0, 0), (24, 7, 2),
-                                                  (32, 0, 0), (32, 3, 0), (41, 0, 0), (41, 100, 0)]] +
+                                                  (32, 0, 0), (32, 3, 0), (41, 0, 0), (41, 100, 0), (5, 0, 0), (5, 9, 2), (18, 0, 0), (19, 700, 1)]] +
                          [dict(sweep_band_log2=b) for b in (13, 15, 16, 17)] +
                          [dict(estimate_ratio=r) for r in (1, 7, 1000)] + [dict(hist_copies=1), dict(hist_copies=8)],
                          ids=str)
@@ -400,6 +400,68 @@ def test_cli_tree_sum_mode_reads_the_file_once(pkg, orc, tmp_path, shards):
             want = shards if (budget or force) else 0      # by default only shards that do not fit in HBM are swept
             assert info["shards_swept"] == want and info["shards_resolved_from_sweep"] == want, info
             assert info["gpu0_ingest"]["resident"] == (0 if budget else 1)
+
+
+@pytest.mark.parametrize("hint", [0.0, 3.0e5], ids=["good-hint", "bad-hint"])
+@pytest.mark.parametrize("redo_cap", [None, "0"], ids=["read-back", "second-pass"])
+def test_exact_one_sweep_ingest_of_a_streamed_shard(pkg, orc, tmp_path, monkeypatch, redo_cap, hint):
+    """papr_hip_estimate_file + papr_hip_load_file_sweep in exact-sum mode on a shard that does not stay in HBM: the
+    sequential sum and the counts of the reference from ONE pass over the file (the tiles whose binade speculation
+    failed and the unprovable ones are read back); with the read-back switched off the file is streamed once more."""
+    import subprocess
+    n = 5 * 1048576 + 4099
+    path = str(tmp_path / "x.cfile")
+    subprocess.check_call([orc.MKCFILE, path, str(n), "--spike", "--extra-floats", "1", "--extra-bytes", "2"])
+    monkeypatch.setenv("PAPR_HBM_BUDGET_MB", "2")
+    monkeypatch.setenv("PAPR_CHUNK_MB", "1")
+    if redo_cap is not None:
+        monkeypatch.setenv("PAPR_STREAM_REDO_CAP", redo_cap)
+    for graph in (False, True):
+        ref = orc.run_file(path, graph)
+        with pkg.PaprHip(0) as g:
+            g.set_exact(True)
+            est = g.estimate_file(path)
+            g.set_band(pkg.band_for(est))
+            g.set_exact_hint(hint)    # (a wrong hint shifts every speculated prefix: hundreds of tiles to rebuild)
+            g.load_file_sweep(path, pkg.guess_levels(est, graph))
+            assert g.ingest_timing().resident == 0 and g.sweep_info().swept == 1
+            res, table, counts = g.analyze(None, graph)
+            check_stats(res.total, ref)
+            assert res.exact_sum == 1 and res.total.sum == ref["sum"] and res.mean == ref["mean"] and res.papr == ref["papr"]
+            assert np.array_equal(table, ref["level"]) and np.array_equal(counts.astype(np.int64), ref["count"])
+            redone = res.exact_redo_tiles
+            assert (redone > 100) if hint else (redone < 100), redone
+            # (nothing to rebuild and nothing unprovable would need no second pass either way)
+            assert g.ingest_timing().file_passes == (2 if (redo_cap is not None and redone) else 1), g.ingest_timing().as_dict()
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+def test_cli_exact_sum_streams_the_file_once(pkg, orc, tmp_path, shards):
+    """bin/papr in its default (exact-sum) mode on a file that does not fit the HBM budget: estimate sample + ONE pass
+    over the file — the sweep builds the rounding functions for speculated binades, the tiles that need another look
+    are read back from the file — and the reference's stdout, sequential sum and all; also forced on resident shards."""
+    import json
+    import os
+    import subprocess
+    n = 6 * 1048576 + 12345          # odd float count: the phantom sample sits in the last tile's tail
+    path = str(tmp_path / "cli.cfile")
+    subprocess.check_call([orc.MKCFILE, path, str(n), "--spike", "--extra-floats", "1"])
+    base = dict(os.environ, PAPR_STATS="1", PAPR_GPUS=str(shards), PAPR_OVERSUBSCRIBE="1", PAPR_CHUNK_MB="1")
+    for graph in (False, True):
+        args = (["-g"] if graph else []) + [path]
+        want = subprocess.run([orc.REF_CLI if os.path.exists(orc.REF_CLI) else orc.CLI_PATH] + args, capture_output=True)
+        for budget, force in (("2", None), (None, "1")):
+            env = dict(base, **({"PAPR_HBM_BUDGET_MB": budget} if budget else {}), **({"PAPR_ONE_SWEEP": force} if force else {}))
+            got = subprocess.run([pkg.CLI_PATH] + args, capture_output=True, env=env)
+            assert got.returncode == 0 and got.stdout == want.stdout, (graph, budget, got.stderr[-500:])
+            info = json.loads(got.stderr.decode().splitlines()[-1])
+            assert info["exact_sum"] == 1 and info["shards_swept"] == shards, info
+            assert info["shards_resolved_from_sweep"] == shards and info["gpu0_ingest"]["file_passes"] == 1, info
+            assert info["gpu0_ingest"]["resident"] == (0 if budget else 1)
+        # the two-pass form of the same (PAPR_ONE_SWEEP=0) reads the streamed file twice, same output
+        two = subprocess.run([pkg.CLI_PATH] + args, capture_output=True, env=dict(base, PAPR_HBM_BUDGET_MB="2", PAPR_ONE_SWEEP="0"))
+        info = json.loads(two.stderr.decode().splitlines()[-1])
+        assert two.stdout == want.stdout and info["exact_sum"] == 1 and info["gpu0_ingest"]["file_passes"] == 2, info
 
 
 # ---- the committed golden fixtures through the one-sweep ingest ------------------------------------------------
