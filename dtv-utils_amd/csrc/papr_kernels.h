@@ -129,7 +129,7 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
                           papr_partial *out, double *group_sums /* may be null: 4 sampled sums per group */,
                           double *block_sq /* may be null: per workgroup, sum of squared piece sums */);
 int papr_sweep_variant(int variant); /* the sweep geometry used for a variant id, or -1 */
-#define PAPR_SWEEP_VARIANT_IS_LUT2(v) (((v) >= 20 && (v) <= 29) || ((v) >= 70 && (v) <= 79) || (v) == 18) /* compact table: papr_sweep_kernel<LUT2>, papr_sweep_split_kernel */
+#define PAPR_SWEEP_VARIANT_IS_LUT2(v) (((v) >= 20 && (v) <= 29) || ((v) >= 70 && (v) <= 79) || (v) == 18 || (v) == 38) /* compact table: papr_sweep_kernel<LUT2>, papr_sweep_split_kernel */
 int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_t *stash_lds); /* 0, or -1 */
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
                        uint64_t base_index, int map, papr_partial *out, const void *tail, uint32_t tail_samples,

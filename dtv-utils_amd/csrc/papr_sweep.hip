@@ -105,9 +105,13 @@ __device__ __forceinline__ void store16(float *p, f32x4s v)
     }
 }
 
-// SP16: spill in 16-byte stores (a partial quad padded with quiet NaNs, which the recount ignores) instead of dwords
-template <bool SP16 = false>
+// MODE bit 0 (SP16): spill in 16-byte stores (a partial quad padded with quiet NaNs, which the recount ignores)
+// instead of dwords.  MODE bit 1 (BALLOT): the slice is this wave's alone, so its fill count can live in a scalar
+// register and slots be handed out by ballot + mbcnt — no returning LDS atomic (and no wait for it) per in-band sample.
+template <int MODE = 0>
 struct WaveStashT {
+    static constexpr bool SP16 = (MODE & 1) != 0, BALLOT = (MODE & 2) != 0;
+    uint32_t nfill = 0;                 // BALLOT: entries in buf (wave-uniform)
     float *buf;                         // this wave's slice of LDS
     uint32_t *fill;                     // LDS: entries in buf (this wave's counter)
     float *__restrict__ seg;            // this workgroup's stash segment
@@ -121,19 +125,38 @@ struct WaveStashT {
 
     __device__ __forceinline__ void put(float pw, bool take)
     {
-        if (take)
-            buf[atomicAdd(fill, 1u)] = pw;
+        if constexpr (BALLOT) {
+            const unsigned long long m = __ballot(take);
+            if (m) {  // (wave-uniform)
+                const uint32_t at = nfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (take)
+                    buf[at] = pw;
+                nfill += (uint32_t)__popcll(m);
+            }
+        } else {
+            if (take)
+                buf[atomicAdd(fill, 1u)] = pw;
+        }
     }
     // spill if more than `limit` entries are waiting (wave-uniform decision); `folded` = samples this workgroup
     // has folded in this launch, about
     __device__ __forceinline__ void spill_if_above(uint32_t limit, uint32_t folded)
     {
+        uint32_t n;
+        if constexpr (BALLOT) {
+            n = nfill;
+            if (n <= limit)
+                return;
+            nfill = 0;
+        }
         __builtin_amdgcn_wave_barrier();  // LDS is in-order per wave; this pins the compiler's order too
-        // other lanes' atomics: never cached.  The cast matters: through a generic pointer the volatile read is a
-        // flat_load sc0 sc1 followed by s_waitcnt vmcnt(0) — it drains the prefetched tile's loads every iteration
-        const uint32_t n = __builtin_amdgcn_readfirstlane(*(volatile lds_u32 *)(lds_u32 *)fill);
-        if (n <= limit)
-            return;
+        if constexpr (!BALLOT) {
+            // other lanes' atomics: never cached.  The cast matters: through a generic pointer the volatile read is a
+            // flat_load sc0 sc1 followed by s_waitcnt vmcnt(0) — it drains the prefetched tile's loads every iteration
+            n = __builtin_amdgcn_readfirstlane(*(volatile lds_u32 *)(lds_u32 *)fill);
+            if (n <= limit)
+                return;
+        }
         const uint32_t lane = threadIdx.x & (kWave - 1);
         const uint32_t nres = SP16 ? ((n + 3u) & ~3u) : n;  // floats reserved in the segment
         unsigned long long pos = 0;
@@ -141,7 +164,8 @@ struct WaveStashT {
             pos = atomicAdd(seg_fill, (unsigned long long)nres);  // counts even what no longer fits: the host sees the overflow
             if constexpr (SP16)
                 atomicAdd(seg_real, (unsigned long long)n);
-            *(volatile lds_u32 *)(lds_u32 *)fill = 0;
+            if constexpr (!BALLOT)
+                *(volatile lds_u32 *)(lds_u32 *)fill = 0;
         }
         pos = uniform_u64(pos);  // lane 0's value, in scalar registers
         if constexpr (SP16) {
@@ -165,7 +189,7 @@ struct WaveStashT {
             sweep_give_up(tab, table_words, neutral_x, seg_fill, seg_cap, gave_up);  // (pos > seg_cap: someone already did)
     }
 };
-typedef WaveStashT<false> WaveStash;
+typedef WaveStashT<0> WaveStash;
 
 }  // namespace
 
@@ -401,7 +425,7 @@ __device__ __forceinline__ void sweep_record(double sum, const TileTrack &tr, co
 // 4 LUT lookup, 8 trackers, 16 sum, 32 spill check.  The results of such a launch are meaningless.
 // LUT2: the compact band-edge table of papr_kernels.h (two edges per cell: 1-8 KiB instead of 32-40), which lets small
 // workgroups — the geometry papr_stats_kernel runs best in — afford a table of their own.
-template <int BLOCK, int U, bool NT, int PIPE, int ABL = 0, bool LUT2 = false, bool SP16 = false>
+template <int BLOCK, int U, bool NT, int PIPE, int ABL = 0, bool LUT2 = false, int SMODE = 0>
 __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restrict__ data, uint64_t ntiles,
                                                             uint64_t base_index, int map,
                                                             papr_partial *__restrict__ out,
@@ -439,7 +463,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
 
     const uint2 *lut_biased = reinterpret_cast<const uint2 *>(tab) - ((int32_t)P.cell_lo - 1);
     uint32_t *my = hist + ((t / kWave) % P.copies) * nbins;
-    WaveStashT<SP16> ws{slices + (t / kWave) * SLICE, &wave_fill[t / kWave], stash + (uint64_t)blockIdx.x * seg_cap,
+    WaveStashT<SMODE> ws{0u, slices + (t / kWave) * SLICE, &wave_fill[t / kWave], stash + (uint64_t)blockIdx.x * seg_cap,
                         &seg_fill, seg_cap, tab, P.table_words, LUT2 ? PAPR_LUT2_NEVER : 0u, seg_fill, gave_up,
                         &seg_real_sh};
     // cell index straight from the bit pattern: lut_biased[cell] with cell clamped to [cell_lo - 1, cell_lo + ncells]
@@ -553,7 +577,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
     hist_flush<BLOCK>(hist, nbins, P.copies, ghist);  // (starts with a barrier: every wave has spilled)
     if (t == 0) {
         seg_counts[blockIdx.x] = seg_fill;
-        seg_real[blockIdx.x] = SP16 ? seg_real_sh : seg_fill;  // (dword spills: no padding, the two are the same)
+        seg_real[blockIdx.x] = (SMODE & 1) ? seg_real_sh : seg_fill;  // (dword spills: no padding, the two are the same)
     }
 }
 
@@ -661,7 +685,7 @@ __global__ __launch_bounds__((PW + PW * NB) * kWave) void papr_sweep_split_kerne
     } else {
         const uint2 *lut_biased = reinterpret_cast<const uint2 *>(tab) - ((int32_t)P.cell_lo - 1);
         uint32_t *my = hist + (bidx % P.copies) * nbins;
-        WaveStash ws{slices + bidx * SLICE, &wave_fill[bidx], stash + (uint64_t)blockIdx.x * seg_cap, &seg_fill,
+        WaveStash ws{0u, slices + bidx * SLICE, &wave_fill[bidx], stash + (uint64_t)blockIdx.x * seg_cap, &seg_fill,
                      seg_cap, tab, P.table_words, PAPR_LUT2_NEVER, seg_fill, gave_up, nullptr};
         const int32_t cell_last = (int32_t)(P.cell_lo + P.ncells);
         int32_t cell_first;  // pinned in a VGPR for the whole kernel (v_med3 takes one scalar operand)
@@ -1336,8 +1360,11 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
 #define PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X) X(20, 256, 4, 1) X(24, 1024, 4, 0)
 #endif
 
-// papr_sweep_kernel with 16-byte stash spills: id, workgroup size, loads per lane, loop form, compact table
-#define PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X) X(5, 1024, 4, 0, false) X(18, 1024, 4, 0, true) X(19, 512, 4, 0, false)
+// papr_sweep_kernel with other stash forms: id, workgroup size, loads per lane, loop form, compact table,
+// stash mode (bit 0: 16-byte spills, bit 1: ballot compaction)
+#define PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X) \
+    X(5, 1024, 4, 0, false, 1) X(18, 1024, 4, 0, true, 1) X(19, 512, 4, 0, false, 1) X(36, 1024, 4, 0, false, 2)          \
+    X(37, 1024, 4, 0, false, 3) X(38, 1024, 4, 0, true, 2) X(39, 512, 4, 0, false, 2)
 
 // loader / binner split (papr_sweep_split_kernel): id, loader waves, binners per loader, loads per lane per tile, ring depth
 // (measured slower than papr_sweep_kernel in every shape — DESIGN.md section 4b — so only `make MEASURE=1` builds it)
@@ -1357,7 +1384,7 @@ int papr_sweep_variant(int variant)
 #define X(V, PW, NB, LU, D) case V: return V;
         PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X)
 #undef X
-#define X(V, B, U, P, L2) case V: return V;
+#define X(V, B, U, P, L2, SM) case V: return V;
         PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X)
 #undef X
 #define X(V, B, U, P) case V: return V;
@@ -1384,7 +1411,7 @@ int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_
         return 0;
         PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X)
 #undef X
-#define X(V, B, U, P, L2)                                                                 \
+#define X(V, B, U, P, L2, SM)                                                             \
     case V:                                                                                \
         *threads = B;                                                                      \
         *tile_samples = 2ull * B * U;                                                      \
@@ -1433,9 +1460,9 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
         break;
         PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X)
 #undef X
-#define X(V, B, U, PP, L2)                                                                                           \
+#define X(V, B, U, PP, L2, SM)                                                                                       \
     case V:                                                                                                           \
-        hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP, 0, L2, true>), dim3(blocks), dim3(B), lds_bytes, st,    \
+        hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP, 0, L2, SM>), dim3(blocks), dim3(B), lds_bytes, st,    \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
                            table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real);                           \
         break;
@@ -1548,8 +1575,8 @@ void papr_sweep_prepare_device(void)
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
     PAPR_FOR_EACH_SWEEP_SPLIT_VARIANT(X)
 #undef X
-#define X(V, B, U, PP, L2)                                                                                           \
-    (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<B, U, true, PP, 0, L2, true>,                          \
+#define X(V, B, U, PP, L2, SM)                                                                                       \
+    (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<B, U, true, PP, 0, L2, SM>,                          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
     PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X)
 #undef X
