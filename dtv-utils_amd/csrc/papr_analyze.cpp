@@ -72,20 +72,39 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
     if (ctx->exact && std::isfinite(total.sum)) {
         const void *program = nullptr;
         size_t bytes = 0;
-        const int xrc = papr_hip_ccdf_exact(ctx, levels, L, counts_above, before, total.n, &program, &bytes);
-        counted = xrc == PAPR_OK;
         double seq = 0.0;
-        int crc;
-        if (x) {
-            // a shard that could not build its program sends an empty one: the chain then fails on EVERY rank alike
-            static const unsigned char none[8] = {0};
-            crc = papr_exchange_exact_sum(x, xrc == PAPR_OK ? program : none, xrc == PAPR_OK ? bytes : 0, &seq);
-        } else if (xrc == PAPR_OK) {
-            const void *progs[1] = {program};
-            const size_t sizes[1] = {bytes};
-            crc = papr_exact_chain(progs, sizes, 1, &seq);
-        } else {
-            crc = xrc;
+        int crc = PAPR_OK;
+        auto replay = [&](const void *prog, size_t nbytes, bool have) {  // exchange (if any) + the chained replay
+            if (x) {
+                // a shard that could not build its program sends an empty one: the chain then fails on EVERY rank alike
+                static const unsigned char none[8] = {0};
+                crc = papr_exchange_exact_sum(x, have ? prog : none, have ? nbytes : 0, &seq);
+            } else if (have) {
+                const void *progs[1] = {prog};
+                const size_t sizes[1] = {nbytes};
+                crc = papr_exact_chain(progs, sizes, 1, &seq);
+            }
+        };
+        // One-read form: the program is complete before the stash recount has run, so its replay (0.07 ms of dependent
+        // additions for a 10 GiB shard) is done inside that window instead of behind it (papr_hip_ctx::overlap_work).
+        bool replayed = false;
+        ctx->overlap_work = [&] {
+            if (*ctx->h_redo_count > kCapRedo)
+                return;  // too many tiles to rebuild: the program is not final yet
+            const size_t nbytes = swept_program_bytes(ctx);
+            if (!nbytes)
+                return;  // the device-side gather overflowed its lists: assembled by the host afterwards
+            replay(ctx->h_program, nbytes, true);
+            replayed = true;
+        };
+        const int xrc = papr_hip_ccdf_exact(ctx, levels, L, counts_above, before, total.n, &program, &bytes);
+        ctx->overlap_work = nullptr;
+        counted = xrc == PAPR_OK;
+        if (!replayed) {
+            if (x || xrc == PAPR_OK)
+                replay(program, bytes, xrc == PAPR_OK);
+            else
+                crc = xrc;
         }
         if (crc == PAPR_OK) {
             total.sum = seq;

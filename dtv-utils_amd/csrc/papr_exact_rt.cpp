@@ -243,6 +243,12 @@ int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total)
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_redo_count, ctx->d_redo + kCapRedo, sizeof(uint32_t), hipMemcpyDeviceToHost,
                                ctx->stream));
+    // from here on the program (mapped host memory) and the redo count are complete: whoever waits for this event
+    // may use them while the stream goes on with the recount (run_overlap_work)
+    if (!ctx->ev_program)
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_program, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_program, ctx->stream));
+    ctx->program_pending = true;
     return PAPR_OK;
 }
 
@@ -529,6 +535,7 @@ static int papr_hip_ccdf_exact_impl(papr_hip_ctx *ctx, const float *levels, int 
         if (rc)
             return rc;
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->program_pending = false;
         ctx->sweep_info.exact_redo_tiles = *ctx->h_redo_count;
         if (*ctx->h_redo_count > kCapRedo) {
             rc = run_exact_full_redo(ctx);

@@ -74,6 +74,21 @@ void parse_tune_env(papr_hip_tuning *t)
     }
 }
 
+// Host work that only needs the exact-sum program, done while the GPU is still busy with what was queued behind it
+void run_overlap_work(papr_hip_ctx *ctx)
+{
+    if (!ctx->overlap_work)
+        return;
+    std::function<void()> work;
+    work.swap(ctx->overlap_work);  // (once)
+    if (!ctx->program_pending || !ctx->ev_program)
+        return;
+    ctx->program_pending = false;
+    if (hipEventSynchronize(ctx->ev_program) != hipSuccess)
+        return;
+    work();
+}
+
 int variant_of(const papr_hip_ctx *ctx, Pass p)
 {
     if (p == PASS1 && ctx->exact)
@@ -562,6 +577,7 @@ void papr_hip_close(papr_hip_ctx *ctx)
     if (ctx->d_ambig) (void)hipFree(ctx->d_ambig);
     if (ctx->d_raw_store) (void)hipFree(ctx->d_raw_store);
     if (ctx->d_redo_store) (void)hipFree(ctx->d_redo_store);
+    if (ctx->ev_program) (void)hipEventDestroy(ctx->ev_program);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->d_hist) (void)hipFree(ctx->d_hist);
@@ -832,6 +848,7 @@ static int papr_hip_ccdf_impl(papr_hip_ctx *ctx, const float *levels, int nlevel
         return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(m + 1) * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, ctx->stream));
+    run_overlap_work(ctx);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     counts_from_histogram(ctx, plan, nlevels, counts_above);
     return PAPR_OK;

@@ -182,6 +182,12 @@ struct papr_hip_ctx {
     void *d_stage[papr_rt::kNumBuf] = {};
     hipEvent_t ev_copy[papr_rt::kNumBuf] = {};
     hipEvent_t ev_kernel[papr_rt::kNumBuf] = {};
+    // exact-sum one-read step: the sum program is complete (ev_program) before the stash recount has run; work the caller
+    // wants done in that window (papr_hip_analyze: the exchange / replay of the programs) — run once, by the next call
+    // that is about to wait for the stream (run_overlap_work), then cleared
+    hipEvent_t ev_program = nullptr;
+    bool program_pending = false;        // ev_program was recorded for the current step
+    std::function<void()> overlap_work;
     size_t stage_bytes = 0;
     papr_rt::ReaderPool *pool = nullptr;
     papr_rt::UringReader *uring = nullptr;  // papr_uring.h: the reader for O_DIRECT streams (nullptr: not tried / not offered)
@@ -266,7 +272,7 @@ constexpr int kCcdfVariant = 13, kCcdfPerCU = 2, kCcdfMap = PAPR_MAP_GRID_STRIDE
 
 // one-sweep kernel (pass 1 + banded pass 2 in one read)
 constexpr int kSweepVariant = 4, kSweepPerCU = 4, kSweepMap = PAPR_MAP_GRID_STRIDE;
-constexpr int kSweepExactVariant = 48;  // papr_sweep2_kernel<12 waves, exact-sum pairs>
+constexpr int kSweepExactVariant = 56;  // papr_sweep2_kernel<12 waves, exact-sum pairs>
 
 constexpr int kSweepBandLog2 = 14, kEstimateRatio = 64;
 
@@ -356,6 +362,7 @@ int ensure_owned_capacity(papr_hip_ctx *ctx, uint64_t nsamples);
 void time_begin(papr_hip_ctx *ctx, int kind, uint64_t bytes);
 void time_end(papr_hip_ctx *ctx);
 int ensure_exact_buffers(papr_hip_ctx *ctx);
+void run_overlap_work(papr_hip_ctx *ctx);  // (see papr_hip_ctx::overlap_work)
 int launch_stats_range(papr_hip_ctx *ctx, const float *data, uint64_t n, uint64_t base_index, size_t slot,
                        int *nrecords);
 void partial_to_stats(const papr_partial &r, uint64_t n, papr_stats *out);

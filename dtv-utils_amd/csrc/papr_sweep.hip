@@ -771,8 +771,11 @@ __global__ __launch_bounds__((PW + PW * NB) * kWave) void papr_sweep_split_kerne
 namespace {
 
 
-template <uint32_t RING, int WT>
+// BALLOT: the ring is this wave's alone, so its head can live in a scalar register and slots be handed out by
+// ballot + mbcnt — no returning LDS atomic (which hipcc expands into a dozen instructions) per in-band sample
+template <uint32_t RING, int WT, bool BALLOT = false>
 struct StashRing {
+    uint32_t nhead = 0;               // BALLOT: slots handed out so far (wave-uniform)
     float *ring;                      // this wave's ring in LDS (RING floats, 16-byte aligned)
     uint32_t *head;                   // LDS: slots reserved by this wave's lanes so far
     uint32_t tail;                    // wave-uniform: slots already written out (multiple of the spill size)
@@ -822,8 +825,18 @@ struct StashRing {
     }
     __device__ __forceinline__ void put(float pw, bool take)
     {
-        if (take)
-            ring[atomicAdd(head, 1u) & (RING - 1)] = pw;
+        if constexpr (BALLOT) {
+            const unsigned long long m = __ballot(take);
+            if (m) {  // (wave-uniform)
+                const uint32_t at = nhead + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (take)
+                    ring[at & (RING - 1)] = pw;
+                nhead += (uint32_t)__popcll(m);
+            }
+        } else {
+            if (take)
+                ring[atomicAdd(head, 1u) & (RING - 1)] = pw;
+        }
     }
     // write ring[tail, tail + n) to the segment; n <= 256, tail is a multiple of 256
     __device__ __forceinline__ void chunk(uint32_t n)
@@ -855,7 +868,10 @@ struct StashRing {
     __device__ __forceinline__ uint32_t pending()
     {
         __builtin_amdgcn_wave_barrier();  // LDS is in-order per wave; this pins the compiler's order too
-        return __builtin_amdgcn_readfirstlane(*(volatile lds_u32 *)(lds_u32 *)head) - tail;
+        if constexpr (BALLOT)
+            return nhead - tail;
+        else
+            return __builtin_amdgcn_readfirstlane(*(volatile lds_u32 *)(lds_u32 *)head) - tail;
     }
     // spill whole 256-float chunks; `seen` = what put_batch returned (any lane's value is the wave's head)
     __device__ __forceinline__ void spill_from(uint32_t seen)
@@ -887,7 +903,9 @@ struct StashRing {
             chunk(n);
         tail = (tail + PAPR_SWEEP2_SPILL - 1) & ~(PAPR_SWEEP2_SPILL - 1);  // (keeps the ring reads 16-byte aligned)
         __builtin_amdgcn_wave_barrier();
-        if ((threadIdx.x & (kWave - 1)) == 0)
+        if constexpr (BALLOT)
+            nhead = tail;
+        else if ((threadIdx.x & (kWave - 1)) == 0)
             *(volatile lds_u32 *)(lds_u32 *)head = tail;
         __builtin_amdgcn_wave_barrier();
     }
@@ -1067,8 +1085,9 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
     constexpr bool LEAN_SUM = (WTB & 8) != 0; // exact mode: the lane's sum is x0 - m0 (no separate accurate accumulation)
     constexpr int BLOCK = WAVES * kWave;
     constexpr uint64_t SEG_F4 = 64ull * U;
-    constexpr uint32_t RING = EXACT ? 512u : 1024u;  // >= 255 + 64 * (samples per lane between two ring checks)
-    constexpr int BATCH = EXACT ? 2 : 4;             // float4 per lane folded between two ring checks
+    constexpr bool WIDE = (WTB & 32) != 0;           // exact mode: batches of 4 float4 (ring of 1024) like the plain form
+    constexpr uint32_t RING = (EXACT && !WIDE) ? 512u : 1024u;  // >= 255 + 64 * (samples per lane between two ring checks)
+    constexpr int BATCH = (EXACT && !WIDE) ? 2 : 4;  // float4 per lane folded between two ring checks
     __shared__ unsigned long long seg_fill, seg_real_sh;
     __shared__ uint32_t ring_head[WAVES];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1096,7 +1115,9 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
 
     const uint2 *lut_biased = reinterpret_cast<const uint2 *>(tab) - ((int32_t)P.cell_lo - 1);
     uint32_t *my = hist + (wave % P.copies) * nbins;
-    StashRing<RING, (WTB & 3)> ws{rings + wave * RING,
+    constexpr bool BALLOT = (WTB & 16) != 0;  // stash slots by ballot + mbcnt instead of a returning LDS atomic
+    static_assert(!(BALLOT && BATCHED), "the batched reservation is an LDS atomic");
+    StashRing<RING, (WTB & 3), BALLOT> ws{0u, rings + wave * RING,
                            &ring_head[wave],
                            0u,
                            p.stash + (uint64_t)blockIdx.x * p.seg_cap,
@@ -1502,9 +1523,13 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     X(32, 16, 8, 0, false, 2) X(34, 16, 4, 0, false, 2) X(35, 16, 4, 1, false, 2) X(40, 12, 8, 0, false, 2)      \
     X(41, 12, 8, 1, false, 2) X(42, 8, 4, 1, false, 2) X(44, 16, 8, 0, false, 6) X(45, 12, 8, 1, false, 6)       \
     X(48, 12, 8, 0, true, 2) X(49, 12, 8, 0, true, 6) X(50, 12, 8, 0, true, 10) X(51, 12, 8, 0, true, 0)         \
-    X(52, 12, 8, 0, true, 14) X(54, 11, 8, 0, true, 10)
-#else  // 48: the exact-sum default; 32 / 41: the same kernel without the pairs (tests), plain and prefetching
-#define PAPR_FOR_EACH_SWEEP2_VARIANT(X) X(32, 16, 8, 0, false, 2) X(41, 12, 8, 1, false, 2) X(48, 12, 8, 0, true, 2)
+    X(52, 12, 8, 0, true, 14) X(54, 11, 8, 0, true, 10) X(55, 12, 8, 0, true, 18) X(56, 12, 8, 0, true, 26)                \
+    X(57, 16, 8, 0, false, 18) X(58, 12, 8, 1, false, 18) X(59, 12, 8, 0, true, 50) X(53, 12, 8, 0, true, 16)        \
+    X(46, 12, 8, 0, true, 17) X(47, 12, 8, 0, true, 58)
+#else  // 56: the exact-sum default (ballot ring, lean sum); 48 / 55 / 59: its other forms; 32 / 41 / 57: without the pairs
+#define PAPR_FOR_EACH_SWEEP2_VARIANT(X) \
+    X(32, 16, 8, 0, false, 2) X(41, 12, 8, 1, false, 2) X(48, 12, 8, 0, true, 2) X(55, 12, 8, 0, true, 18)             \
+    X(56, 12, 8, 0, true, 26) X(57, 16, 8, 0, false, 18) X(59, 12, 8, 0, true, 50)
 #endif
 
 int papr_sweep2_geometry(int variant, int *threads, uint64_t *seg_samples, size_t *lds_fixed, int *exact)
@@ -1514,7 +1539,7 @@ int papr_sweep2_geometry(int variant, int *threads, uint64_t *seg_samples, size_
     case V:                                                                                                      \
         *threads = W * kWave;                                                                                    \
         *seg_samples = 2ull * kWave * U;                                                                         \
-        *lds_fixed = (size_t)W * (EX ? 512u : 1024u) * sizeof(float) + (EX ? (size_t)W * 8192u : 0u);            \
+        *lds_fixed = (size_t)W * ((EX && !((WT) & 32)) ? 512u : 1024u) * sizeof(float) + (EX ? (size_t)W * 8192u : 0u); \
         *exact = EX ? 1 : 0;                                                                                     \
         return 0;
         PAPR_FOR_EACH_SWEEP2_VARIANT(X)

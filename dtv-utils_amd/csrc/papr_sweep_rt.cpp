@@ -527,6 +527,7 @@ int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *lev
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(m + 1) * sizeof(unsigned long long),
                                    hipMemcpyDeviceToHost, ctx->stream));
+        run_overlap_work(ctx);  // (exact-sum step: the program's replay, while the recount runs)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     } else {
         memset(ctx->h_hist, 0, (size_t)(m + 1) * sizeof(unsigned long long));

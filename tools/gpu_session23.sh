@@ -1,0 +1,16 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$R"; O=gpurun_out/s23; mkdir -p $O
+for ROUND in 1 2 3 4; do
+for T in "" "wvariant=56" "wvariant=59"; do
+  PAPR_HIP_TUNE="$T" timeout 300 python bench.py --exact --steps 30 --warmup 3 --no-cpu-baseline --no-e2e > $O/b.json 2> $O/b.err
+  python - <<PY
+import json
+try:
+    d=json.load(open("$O/b.json"))
+    print("round $ROUND tune '%s': kernel %.4f / -g %.4f  step %.4f / %.4f parity %s %s" % ("$T", d["roofline"]["kernel_ms"], d["graph"]["roofline"]["kernel_ms"], d["ms_per_step"], d["graph"]["ms_per_step"], d["parity_in_run"], d["graph"]["parity_in_run"]))
+except Exception as e:
+    print("failed", e, open("$O/b.err").read()[-600:])
+PY
+done
+done
