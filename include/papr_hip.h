@@ -276,7 +276,8 @@ int papr_hip_estimate(papr_hip_ctx *ctx, papr_stats *est);
  * earlier shards' estimate records) before the sweep; a poor hint costs re-examined tiles, never a result. */
 int papr_hip_set_exact_hint(papr_hip_ctx *ctx, double estimated_sum_before_shard);
 /* The same estimate for a range of a FILE that is not loaded yet (the 1-in-64 tiles are read by the
- * ingest's reader threads and summed on the GPU): what a one-sweep ingest needs before it starts. */
+ * ingest's reader threads and summed on the GPU): what a one-sweep ingest needs before it starts.  In exact-sum
+ * mode the sampled tiles' sums stay on the device for papr_hip_load_file_sweep of the same range. */
 int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples, papr_stats *est);
 /* Host helper: the table papr_levels would build for the (merged) estimate's mean, carried on to max_db
  * dB above the mean whatever the peak turns out to be (the real table's length depends on the true
@@ -295,7 +296,13 @@ int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nleve
 /* papr_hip_load_file as a one-sweep ingest: the kernel that runs on every chunk as it lands also bins against the
  * guessed bands and stashes, so papr_hip_stats returns the file's pass-1 record as usual and papr_hip_ccdf needs
  * no second pass — neither over a resident shard nor, for a shard larger than the HBM budget, over the FILE
- * (which papr.c:142-144 and the plain path read twice).  Same fall-backs as papr_hip_stats_sweep. */
+ * (which papr.c:142-144 and the plain path read twice).  Same fall-backs as papr_hip_stats_sweep.
+ * Exact-sum mode rides along when papr_hip_estimate_file (in that mode) was called for the SAME range before: it
+ * keeps the sampled tiles' sums, the ingest speculates the running sum's binades from them (papr_hip_set_exact_hint
+ * for shards that are not the first) and builds the rounding functions in the same pass; papr_hip_ccdf_exact then
+ * reads back from the file just the tiles it needs again (a few hundred of a 10 GiB shard's 655 360) — or, if the
+ * speculation missed on more than 32 768 of them, streams the file once more.  papr_hip_ingest_timing.file_passes
+ * tells which.  Without a matching estimate the ingest in exact-sum mode is the plain one (pass 1 only). */
 int papr_hip_load_file_sweep(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples,
                              const float *guess_levels, int nlevels);
 int papr_hip_get_sweep_info(const papr_hip_ctx *ctx, papr_hip_sweep_info *out);
