@@ -1525,7 +1525,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     X(48, 12, 8, 0, true, 2) X(49, 12, 8, 0, true, 6) X(50, 12, 8, 0, true, 10) X(51, 12, 8, 0, true, 0)         \
     X(52, 12, 8, 0, true, 14) X(54, 11, 8, 0, true, 10) X(55, 12, 8, 0, true, 18) X(56, 12, 8, 0, true, 26)                \
     X(57, 16, 8, 0, false, 18) X(58, 12, 8, 1, false, 18) X(59, 12, 8, 0, true, 50) X(53, 12, 8, 0, true, 16)        \
-    X(46, 12, 8, 0, true, 17) X(47, 12, 8, 0, true, 58)
+    X(46, 12, 8, 0, true, 17) X(47, 12, 8, 0, true, 58) X(43, 14, 8, 0, true, 26) X(33, 13, 8, 0, true, 26)
 #else  // 56: the exact-sum default (ballot ring, lean sum); 48 / 55 / 59: its other forms; 32 / 41 / 57: without the pairs
 #define PAPR_FOR_EACH_SWEEP2_VARIANT(X) \
     X(32, 16, 8, 0, false, 2) X(41, 12, 8, 1, false, 2) X(48, 12, 8, 0, true, 2) X(55, 12, 8, 0, true, 18)             \

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"; O=gpurun_out/s19; mkdir -p $O
 export PAPR_LIB_PATH=$R/build_measure/libpaprhip_measure.so
 for ROUND in 1 2; do
-for V in 48 55 56 59 47 53 46; do
+for V in 56 43 33 56 43 33; do
   PAPR_HIP_TUNE="wvariant=$V" timeout 300 python bench.py --exact --steps 30 --warmup 3 --no-cpu-baseline --no-e2e > $O/b.json 2> $O/b.err
   python - <<PY
 import json
