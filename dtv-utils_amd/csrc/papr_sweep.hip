@@ -1383,9 +1383,14 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
 
 // papr_sweep_kernel with other stash forms: id, workgroup size, loads per lane, loop form, compact table,
 // stash mode (bit 0: 16-byte spills, bit 1: ballot compaction)
+// (none of them beats the default — DESIGN.md section 4b — so only `make MEASURE=1` builds them)
+#ifdef PAPR_MEASURE
 #define PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X) \
     X(5, 1024, 4, 0, false, 1) X(18, 1024, 4, 0, true, 1) X(19, 512, 4, 0, false, 1) X(36, 1024, 4, 0, false, 2)          \
     X(37, 1024, 4, 0, false, 3) X(38, 1024, 4, 0, true, 2) X(39, 512, 4, 0, false, 2)
+#else
+#define PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X)
+#endif
 
 // loader / binner split (papr_sweep_split_kernel): id, loader waves, binners per loader, loads per lane per tile, ring depth
 // (measured slower than papr_sweep_kernel in every shape — DESIGN.md section 4b — so only `make MEASURE=1` builds it)
@@ -1526,10 +1531,10 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     X(52, 12, 8, 0, true, 14) X(54, 11, 8, 0, true, 10) X(55, 12, 8, 0, true, 18) X(56, 12, 8, 0, true, 26)                \
     X(57, 16, 8, 0, false, 18) X(58, 12, 8, 1, false, 18) X(59, 12, 8, 0, true, 50) X(53, 12, 8, 0, true, 16)        \
     X(46, 12, 8, 0, true, 17) X(47, 12, 8, 0, true, 58) X(43, 14, 8, 0, true, 26) X(33, 13, 8, 0, true, 26)
-#else  // 56: the exact-sum default (ballot ring, lean sum); 48 / 55 / 59: its other forms; 32 / 41 / 57: without the pairs
+#else  // 56: the exact-sum default (ballot ring, lean sum); 48: its first form (returning-atomic ring, separate sum);
+       // 32 / 41: the kernel without the pairs (tests)
 #define PAPR_FOR_EACH_SWEEP2_VARIANT(X) \
-    X(32, 16, 8, 0, false, 2) X(41, 12, 8, 1, false, 2) X(48, 12, 8, 0, true, 2) X(55, 12, 8, 0, true, 18)             \
-    X(56, 12, 8, 0, true, 26) X(57, 16, 8, 0, false, 18) X(59, 12, 8, 0, true, 50)
+    X(32, 16, 8, 0, false, 2) X(41, 12, 8, 1, false, 2) X(48, 12, 8, 0, true, 2) X(56, 12, 8, 0, true, 26)
 #endif
 
 int papr_sweep2_geometry(int variant, int *threads, uint64_t *seg_samples, size_t *lds_fixed, int *exact)

@@ -71,8 +71,7 @@ def test_sweep_equals_oracle_sizes(pkg, orc, gpu, n, graph):
                                   for v, b, m in [(1, 96, 1), (1, 1000, 2), (4, 7, 0), (4, 1, 0), (4, 0, 2), (8, 0, 0),
                                                   (8, 64, 2), (13, 0, 0), (13, 1536, 2), (13, 300, 1), (14, 0, 0),
                                                   (14, 8, 2), (20, 0, 0), (20, 96, 1), (24, 0, 0), (24, 7, 2),
-                                                  (32, 0, 0), (32, 3, 0), (41, 0, 0), (41, 100, 0), (5, 0, 0), (5, 9, 2), (18, 0, 0), (19, 700, 1), (36, 0, 0), (36, 11, 1), (37, 0, 2), (38, 0, 0),
-                                                  (39, 640, 0), (57, 0, 0), (57, 13, 0)]] +
+                                                  (32, 0, 0), (32, 3, 0), (41, 0, 0), (41, 100, 0)]] +
                          [dict(sweep_band_log2=b) for b in (13, 15, 16, 17)] +
                          [dict(estimate_ratio=r) for r in (1, 7, 1000)] + [dict(hist_copies=1), dict(hist_copies=8)],
                          ids=str)
@@ -583,7 +582,7 @@ def test_analyze_constant_envelope_gives_up_the_sweep(pkg, orc, exact):
                 assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
 
 
-@pytest.mark.parametrize("variant", [48, 55, 56, 59])
+@pytest.mark.parametrize("variant", [48, 56])
 def test_exact_sweep_variants_agree_with_the_reference(pkg, orc, variant):
     """the exact-sum forms of the sweep kernel (returning-atomic and ballot ring stash), whole result against the oracle"""
     n = 7 * 1048576 + 2049
