@@ -507,13 +507,6 @@ int papr_hip_open(papr_hip_ctx **out, int device)
         }                                                                                          \
     } while (0)
     OPENCHK(hipSetDevice(device));
-    // a step is three or four kernel + wait round trips of ~1.7 ms in all: waiting by spinning instead of by interrupt
-    // takes the wake-up latency out of every one of them (PAPR_SPIN_SYNC=0 keeps the runtime's default; an already
-    // active context may refuse the flag, which is fine)
-    if (env_int("PAPR_SPIN_SYNC", 0) != 0) {
-        (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
-        (void)hipGetLastError();
-    }
     hipDeviceProp_t prop;
     OPENCHK(hipGetDeviceProperties(&prop, device));
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
