@@ -25,7 +25,17 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
     papr_stats local;
     int rc;
     bool swept_path = false;
-    if (!(flags & PAPR_ANALYZE_TWO_PASS)) {
+    bool fused = false;
+    if (!(flags & PAPR_ANALYZE_TWO_PASS) && papr_exchange_is_identity(x)) {
+        // no peers: estimate, guess (on the device) and sweep in one sequence of launches, one wait (papr_sweep_rt.cpp)
+        rc = stats_sweep_fused(ctx, graph, graph ? 48.0 : 60.0, (flags & PAPR_ANALYZE_SPOIL_GUESS) ? 1.03f : 1.0f, &local, &fused);
+        if (rc)
+            return rc;
+        swept_path = fused;
+    }
+    if (fused) {
+        // (done)
+    } else if (!(flags & PAPR_ANALYZE_TWO_PASS)) {
         papr_stats est, est_total;
         double est_before = 0.0;
         rc = papr_hip_estimate(ctx, &est);

@@ -272,6 +272,12 @@ int papr_exchange_unique_id(void *id)
     return PAPR_OK;
 }
 
+// (internal) nobody to talk to and nothing to run: every exchange of this handle is the identity
+bool papr_exchange_is_identity(const papr_exchange *x)
+{
+    return !x || (x->world == 1 && x->use_ops);
+}
+
 int papr_exchange_open_rccl(papr_exchange **out, papr_hip_ctx *ctx, const void *id, int rank, int world)
 {
     if (!out || !ctx || !id || world < 1 || rank < 0 || rank >= world)

@@ -128,6 +128,26 @@ void papr_launch_generate(hipStream_t st, int blocks, void *out, uint64_t nsampl
 void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t ngroups, uint32_t ratio,
                           papr_partial *out, double *group_sums /* may be null: 4 sampled sums per group */,
                           double *block_sq /* may be null: per workgroup, sum of squared piece sums */);
+/* papr_guess_bands_kernel: what the host half of the speculation (papr_guess_levels, papr_sweep_band_for,
+ * papr_sweep_bands, the compact LUT plan) produces, made on the device between the estimate kernel and the sweep
+ * kernel so that the step needs no host round trip there.  Written to device memory (the sweep kernel reads P) and to
+ * mapped host memory (the host reads the rest after the sweep). */
+#define PAPR_GUESS_MAX_BANDS 512
+struct papr_guess_out {
+    papr_ccdf_params P;     /* LUT form of the band edges (nkeys = 2 * nbands); an empty table if !ok */
+    uint32_t ok;            /* 1: bands, table and keys are valid; 0: the guess has no band form (plain pass 1 ran) */
+    uint32_t band_log2;
+    uint32_t nbands;
+    uint32_t pad;
+    double est_sum;         /* sampled sum scaled to the shard */
+    double est_rel_se;      /* relative standard error of the estimated mean */
+    uint32_t gkeys[PAPR_GUESS_MAX_BANDS]; /* keys of the guessed thresholds, ascending */
+};
+void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, const double *est_sq, uint32_t est_blocks,
+                             uint64_t ngroups, uint64_t sampled, uint64_t nsamples, uint32_t ratio, int graph, float max_db,
+                             float spoil, int band_override, uint32_t copies, int compact /* LUT form: two edges per cell */,
+                             uint32_t soft_lds /* bytes table + histogram copies should stay under */, uint32_t *table,
+                             uint32_t table_cap_words, papr_guess_out *out_dev, papr_guess_out *out_host);
 int papr_sweep_variant(int variant); /* the sweep geometry used for a variant id, or -1 */
 #define PAPR_SWEEP_VARIANT_IS_LUT2(v) (((v) >= 20 && (v) <= 29) || ((v) >= 70 && (v) <= 79) || (v) == 18 || (v) == 38) /* compact table: papr_sweep_kernel<LUT2>, papr_sweep_split_kernel */
 int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_t *stash_lds); /* 0, or -1 */
@@ -135,7 +155,8 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
                        uint64_t base_index, int map, papr_partial *out, const void *tail, uint32_t tail_samples,
                        const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist, float *stash,
                        unsigned long long *seg_counts, uint64_t seg_cap, unsigned long long *gave_up,
-                       unsigned long long *seg_real /* per workgroup: powers stashed, without padding */);
+                       unsigned long long *seg_real /* per workgroup: powers stashed, without padding */,
+                       const papr_ccdf_params *Pdev /* null, or the table geometry in device memory (overrides P) */);
 void papr_launch_ccdf_power(hipStream_t st, int blocks, bool lut, size_t lds_bytes, const float *stash,
                             const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs, uint32_t split,
                             const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist);

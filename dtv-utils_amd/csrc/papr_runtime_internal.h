@@ -222,7 +222,8 @@ struct papr_hip_ctx {
     std::vector<uint64_t> sweep_even_above;      // per guessed key j: samples in even bins >= 2 j + 2
     uint64_t sweep_stash_count = 0;
     uint64_t sweep_seg_cap = 0;                  // floats per stash segment
-    uint32_t sweep_nsegs = 0, sweep_nbins = 0;
+    uint32_t sweep_nsegs = 0, sweep_nbins = 0, sweep_seg_off = 0;
+    papr_guess_out *d_guess = nullptr, *h_guess = nullptr, *h_guess_dev = nullptr;  // papr_guess_bands_kernel's output (device; mapped host)
     bool sweep_overflow = false;
     papr_hip_sweep_info sweep_info{};
     const papr_rt::SweepRun *ingest_run = nullptr;        // set while papr_hip_load_file_sweep streams the file in
@@ -323,6 +324,7 @@ struct SweepRun {
     uint64_t tile = 0;            // samples per workgroup iteration (v2: per wave segment; exact: per 2048-sample tile)
     size_t stash_lds = 0;         // LDS besides table and histogram (v2: rings + transpose buffers)
     uint32_t nbins = 0;           // v1: 2 * bands + 1 + the NaN trash bin; v2: 2 * bands + 1
+    uint32_t seg_off = 0;         // where the per-segment arrays start in d_sweep_hist (0 = right behind the nbins bins)
     uint64_t seg_cap = 0;         // floats per stash segment
 };
 
@@ -362,6 +364,10 @@ int ensure_owned_capacity(papr_hip_ctx *ctx, uint64_t nsamples);
 void time_begin(papr_hip_ctx *ctx, int kind, uint64_t bytes);
 void time_end(papr_hip_ctx *ctx);
 int ensure_exact_buffers(papr_hip_ctx *ctx);
+}  // namespace papr_rt
+extern "C" bool papr_exchange_is_identity(const papr_exchange *x);  // papr_exchange.cpp (not part of the ABI)
+namespace papr_rt {
+int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, papr_stats *out, bool *done);
 void run_overlap_work(papr_hip_ctx *ctx);  // (see papr_hip_ctx::overlap_work)
 int launch_stats_range(papr_hip_ctx *ctx, const float *data, uint64_t n, uint64_t base_index, size_t slot,
                        int *nrecords);

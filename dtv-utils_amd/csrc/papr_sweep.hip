@@ -270,6 +270,219 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_estimate_kernel(const float4 
 }
 
 // =============================================================================
+// 2. the guess, on the device
+// =============================================================================
+// One workgroup between the estimate kernel and the sweep kernel: mean estimate and its standard error from the
+// estimate's partial records, band width (papr_sweep_band_for), guessed level table (papr_guess_levels; the GUESS
+// needs no libm exactness — the bands absorb its error, and the TRUE table is still built by papr_levels on the host
+// after the sweep), band edges (papr_sweep_bands) and their compact LUT (plan_compact_lut / fill_compact_lut of
+// papr_sweep_rt.cpp, same layout).  Everything the host needs afterwards goes to mapped host memory.
+__global__ __launch_bounds__(1024) void papr_guess_bands_kernel(
+    const papr_partial *__restrict__ est_partials, const double *__restrict__ est_sq, uint32_t est_blocks, uint64_t ngroups,
+    uint64_t sampled, uint64_t nsamples, uint32_t ratio, int graph, float max_db, float spoil, int band_override,
+    uint32_t copies, int compact, uint32_t soft_lds, uint32_t *__restrict__ table, uint32_t table_cap_words,
+    papr_guess_out *__restrict__ out_dev, papr_guess_out *__restrict__ out_host)
+{
+    constexpr uint32_t kNeverHi = 0xFFFFFFFFu;
+    __shared__ double red[1024];
+    __shared__ uint32_t keys[PAPR_GUESS_MAX_BANDS];
+    __shared__ uint32_t edges[2 * PAPR_GUESS_MAX_BANDS];
+    __shared__ uint32_t s_m, s_bad;
+    const uint32_t t = threadIdx.x;
+    // ---- the estimate: sum and sum of squared piece sums (fixed order: deterministic) ----
+    double a = 0.0, q = 0.0;
+    for (uint32_t b = t; b < est_blocks; b += 1024) {
+        a += est_partials[b].sum;
+        q += est_sq[b];
+    }
+    red[t] = a;
+    __syncthreads();
+    for (uint32_t w = 512; w > 0; w >>= 1) {
+        if (t < w)
+            red[t] += red[t + w];
+        __syncthreads();
+    }
+    const double S = red[0];
+    __syncthreads();
+    red[t] = q;
+    __syncthreads();
+    for (uint32_t w = 512; w > 0; w >>= 1) {
+        if (t < w)
+            red[t] += red[t + w];
+        __syncthreads();
+    }
+    const double sq = red[0];
+    const double pieces = 4.0 * (double)ngroups;
+    const double var_total = pieces > 1.0 ? pieces / (pieces - 1.0) * fmax(0.0, sq - S * S / pieces) : 0.0;
+    const double rel = (S > 0.0 && ratio > 1) ? sqrt(var_total) / S : 0.0;
+    const double mean = sampled ? S / (double)sampled : 0.0;
+    // ---- band half-width: 4.5 standard errors, 2^10 .. 2^20 (papr_sweep_band_for) ----
+    int band = 10;
+    {
+        const double want = 4.5 * rel * 16777216.0;
+        while (band < 20 && (double)(1u << band) < want)
+            band++;
+        if (!(rel >= 0.0) || !(rel < 1.0))
+            band = 14;
+        if (band_override > 0)
+            band = band_override;
+        else if (!compact && band < 14)
+            band = 14;  // (the one-edge table's cells are as narrow as the bands: below 2^14 a 20-octave table does not fit)
+    }
+    // ---- guessed thresholds and their keys ----
+    uint32_t nl = graph ? (uint32_t)(max_db * 10.0f) + 1u : (uint32_t)max_db + 1u;
+    nl = nl > PAPR_GUESS_MAX_BANDS ? PAPR_GUESS_MAX_BANDS : nl;
+    if (t == 0)
+        s_m = (mean > 0.0 && mean <= 3e38) ? nl : 0u;
+    __syncthreads();
+    const bool have = s_m != 0;
+    __syncthreads();
+    uint32_t key = kNeverHi;
+    if (t < nl && have) {
+        const float db = graph ? (float)t * 0.1f : (float)t;
+        const float lv = (float)(pow(10.0, (double)(db / 10.0f)) * mean) * spoil;
+        const uint32_t bits = __float_as_uint(lv);
+        key = (lv != lv || bits >= 0x7F800000u) ? kNeverHi : (lv <= 0.0f ? (lv < 0.0f ? 0u : 1u) : bits + 1u);
+        keys[t] = key;
+    }
+    __syncthreads();
+    if (t < nl && have && (key == kNeverHi || (t > 0 && key <= keys[t - 1])))
+        atomicMin(&s_m, t);  // the table ends in front of the first key that is not a finite step up
+    __syncthreads();
+    const uint32_t m = s_m;
+    // ---- widest band (down to three steps narrower) whose bands are normal floats and do not touch ----
+    uint32_t half = 0;
+    for (int w = band; m && w >= (band - 3 > 8 ? band - 3 : 8) && !half; w--) {
+        if (t == 0)
+            s_bad = 0;
+        __syncthreads();
+        const uint32_t h = 1u << w;
+        if (t < m) {
+            const uint32_t g = keys[t];
+            if (g < 0x00800000u + h || g >= 0x7F800000u - h || (t && g - h <= keys[t - 1] + h))
+                s_bad = 1;
+        }
+        __syncthreads();
+        if (!s_bad) {
+            half = h;
+            band = w;
+        }
+        __syncthreads();
+    }
+    const uint32_t n = half ? 2 * m : 0;  // edges
+    if (t < m && half) {
+        edges[2 * t] = keys[t] - half;
+        edges[2 * t + 1] = keys[t] + half;
+    }
+    __syncthreads();
+    // ---- the LUT: the coarsest cell that leaves at most two edges (compact form) / one edge (papr_sweep_kernel's
+    // plain form: finish_plan) in any cell ----
+    int shift = -1;
+    const uint32_t reach = compact ? 2u : 1u;  // edges[i + reach] must not share a cell with edges[i]
+    for (int s = compact ? PAPR_LUT2_MAX_SHIFT : 23; n && s >= 8 && shift < 0; s--) {
+        if (t == 0)
+            s_bad = 0;
+        __syncthreads();
+        for (uint32_t i = t; i + reach < n; i += 1024)
+            if ((edges[i + reach] >> s) == (edges[i] >> s))
+                s_bad = 1;
+        __syncthreads();
+        if (!s_bad)
+            shift = s;
+        __syncthreads();
+    }
+    papr_ccdf_params P;
+    P.shift = 8;
+    P.cell_lo = 1;
+    P.ncells = 0;
+    P.nkeys = 0;
+    P.above_lo = P.above_count = 0;
+    P.table_words = 4;
+    P.copies = copies;
+    P.search_step = 0;
+    uint32_t ok = 0;
+    if (shift >= 0 && n <= PAPR_LUT2_MAX_EDGES) {
+        const uint32_t c0 = edges[0] >> shift, c1 = edges[n - 1] >> shift;
+        const uint64_t ncells = (uint64_t)c1 - c0 + 1;
+        const uint64_t words = compact ? ((2 * (ncells + 2) + 3) & ~3ull) : 2 * (ncells + 2);
+        if ((compact ? (ncells + 2) * 8 <= 48 * 1024 : ncells * 8 <= 40 * 1024) && words <= table_cap_words) {
+            P.shift = (uint32_t)shift;
+            P.cell_lo = c0;
+            P.ncells = (uint32_t)ncells;
+            P.nkeys = n;
+            P.table_words = (uint32_t)words;
+            // histogram copies: fewer for big tables (as finish_plan: the workgroup's share of the LDS)
+            while (P.copies > 1 && (size_t)P.table_words * 4 + (size_t)P.copies * (n + 2) * 4 > soft_lds)
+                P.copies--;
+            ok = 1;
+        }
+    }
+    // ---- the table: one entry per cell + a sentinel at either end ----
+    //   compact (fill_compact_lut): { edges below << 22 | offset of the 1st edge inside, offset of the 2nd }
+    //   plain (sweep_prepare):      { edges below, the edge inside or never }
+    for (uint32_t w = t; w < P.table_words; w += 1024)
+        table[w] = 0;
+    __syncthreads();
+    if (t == 0) {
+        table[0] = compact ? PAPR_LUT2_NEVER : 0u;  // below everything: no edge below, none inside
+        table[1] = kNeverHi;
+        table[2 * (P.ncells + 1)] = compact ? ((P.nkeys << PAPR_LUT2_OFF_BITS) | PAPR_LUT2_NEVER) : P.nkeys;  // above every edge
+        table[2 * (P.ncells + 1) + 1] = compact ? kNeverHi : 0x7F800001u;  // (plain: NaN patterns land in the trash bin)
+    }
+    if (ok) {
+        const uint32_t mask = (1u << P.shift) - 1u;
+        for (uint32_t c = t; c < P.ncells; c += 1024) {
+            const uint32_t cell = P.cell_lo + c;
+            uint32_t lo = 0, hi = n;  // first edge whose cell is >= `cell`
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) / 2;
+                if ((edges[mid] >> P.shift) < cell)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            const bool in1 = lo < n && (edges[lo] >> P.shift) == cell;
+            const bool in2 = lo + 1 < n && (edges[lo + 1] >> P.shift) == cell;
+            if (compact) {
+                table[2 * (c + 1)] = (lo << PAPR_LUT2_OFF_BITS) | (in1 ? (edges[lo] & mask) : PAPR_LUT2_NEVER);
+                table[2 * (c + 1) + 1] = in2 ? (edges[lo + 1] & mask) : kNeverHi;
+            } else {
+                table[2 * (c + 1)] = lo;
+                table[2 * (c + 1) + 1] = in1 ? edges[lo] : kNeverHi;
+            }
+        }
+    }
+    // ---- what the sweep kernel and the host need ----
+    if (t == 0) {
+        papr_guess_out *outs[2] = {out_dev, out_host};
+        for (int k = 0; k < 2; k++) {
+            papr_guess_out *o = outs[k];
+            o->P = P;
+            o->ok = ok;
+            o->band_log2 = (uint32_t)band;
+            o->nbands = ok ? m : 0u;
+            o->pad = 0;
+            o->est_sum = sampled ? S * ((double)nsamples / (double)sampled) : 0.0;
+            o->est_rel_se = rel;
+        }
+    }
+    for (uint32_t j = t; j < m && ok; j += 1024) {
+        out_dev->gkeys[j] = keys[j];
+        out_host->gkeys[j] = keys[j];
+    }
+}
+
+void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, const double *est_sq, uint32_t est_blocks,
+                             uint64_t ngroups, uint64_t sampled, uint64_t nsamples, uint32_t ratio, int graph, float max_db,
+                             float spoil, int band_override, uint32_t copies, int compact, uint32_t soft_lds, uint32_t *table,
+                             uint32_t table_cap_words, papr_guess_out *out_dev, papr_guess_out *out_host)
+{
+    hipLaunchKernelGGL(papr_guess_bands_kernel, dim3(1), dim3(1024), 0, st, est_partials, est_sq, est_blocks, ngroups, sampled,
+                       nsamples, ratio, graph, max_db, spoil, band_override, copies, compact, soft_lds, table, table_cap_words,
+                       out_dev, out_host);
+}
+
+// =============================================================================
 // 3. the sweep: pass 1 + band binning + stash, one read
 // =============================================================================
 // Doing both passes' arithmetic per sample costs more VALU work than either pass alone (a CU has 64
@@ -430,13 +643,17 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
                                                             uint64_t base_index, int map,
                                                             papr_partial *__restrict__ out,
                                                             const float2 *__restrict__ tail, uint32_t tail_samples,
-                                                            const uint32_t *__restrict__ table, papr_ccdf_params P,
+                                                            const uint32_t *__restrict__ table, papr_ccdf_params Parg,
                                                             unsigned long long *__restrict__ ghist,
                                                             float *__restrict__ stash,
                                                             unsigned long long *__restrict__ seg_counts,
                                                             uint64_t seg_cap, unsigned long long *__restrict__ gave_up,
-                                                            unsigned long long *__restrict__ seg_real)
+                                                            unsigned long long *__restrict__ seg_real,
+                                                            const papr_ccdf_params *__restrict__ Pdev)
 {
+    // the table's geometry: an argument, or — when papr_guess_bands_kernel built the table just before this launch,
+    // without the host in between — read from where that kernel left it (wave-uniform loads: scalar registers)
+    const papr_ccdf_params P = Pdev ? *Pdev : Parg;
     constexpr uint64_t TILE_F4 = (uint64_t)BLOCK * U;
     constexpr uint32_t SLICE = papr_sweep_slice_floats(U);
     __shared__ unsigned long long seg_fill, seg_real_sh;
@@ -1475,7 +1692,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
                        uint64_t base_index, int map, papr_partial *out, const void *tail, uint32_t tail_samples,
                        const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist, float *stash,
                        unsigned long long *seg_counts, uint64_t seg_cap, unsigned long long *gave_up,
-                       unsigned long long *seg_real)
+                       unsigned long long *seg_real, const papr_ccdf_params *Pdev)
 {
     switch (variant) {
 #define X(V, PW, NB, LU, D)                                                                                          \
@@ -1490,7 +1707,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     case V:                                                                                                           \
         hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP, 0, L2, SM>), dim3(blocks), dim3(B), lds_bytes, st,    \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
-                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real);                           \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                           \
         break;
         PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X)
 #undef X
@@ -1498,7 +1715,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     case V:                                                                                                           \
         hipLaunchKernelGGL((papr_sweep_kernel<1024, 4, true, 0, A>), dim3(blocks), dim3(1024), lds_bytes, st,         \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
-                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real);                                            \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                                            \
         break;
         PAPR_FOR_EACH_ABLATION(X)
 #undef X
@@ -1506,7 +1723,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     case V:                                                                                                           \
         hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP, 0, true>), dim3(blocks), dim3(B), lds_bytes, st,        \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
-                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real);                                            \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                                            \
         break;
         PAPR_FOR_EACH_SWEEP_LUT2_VARIANT(X)
 #undef X
@@ -1514,7 +1731,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     case V:                                                                                                           \
         hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP>), dim3(blocks), dim3(B), lds_bytes, st,                 \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
-                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real);                                            \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                                            \
         break;
         PAPR_FOR_EACH_SWEEP_VARIANT(X)
 #undef X

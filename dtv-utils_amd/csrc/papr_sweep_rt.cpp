@@ -251,7 +251,7 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
     papr_launch_sweep(ctx->stream, run.variant, blocks, run.bands.lds_bytes + run.stash_lds, data, ntiles, base_index, map,
                       ctx->d_partials + slot, data + 2 * (n - tail), tail, ctx->d_table, run.bands.P, ctx->d_sweep_hist,
                       ctx->d_stash, ctx->d_sweep_hist + run.nbins, run.seg_cap, ctx->d_sweep_hist + run.nbins + 2 * run.blocks,
-                      ctx->d_sweep_hist + run.nbins + run.blocks);
+                      ctx->d_sweep_hist + run.nbins + run.blocks, nullptr);
     time_end(ctx);
     HIPCHK(ctx, hipGetLastError());
     *nrecords = blocks;
@@ -262,7 +262,8 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
 int sweep_fetch(papr_hip_ctx *ctx, const SweepRun &run)
 {
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_sweep_hist, ctx->d_sweep_hist,
-                               ((size_t)run.nbins + 2 * (size_t)run.blocks + 1) * sizeof(unsigned long long),
+                               ((size_t)(run.seg_off ? run.seg_off : run.nbins) + 2 * (size_t)run.blocks + 1) *
+                                   sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, ctx->stream));
     return PAPR_OK;
 }
@@ -274,9 +275,10 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
     const unsigned long long *H = ctx->h_sweep_hist;
     uint64_t stash_count = 0, in_bands = 0;
     bool overflow = false;
+    const uint32_t seg_off = run.seg_off ? run.seg_off : run.nbins;
     for (int b = 0; b < run.blocks; b++) {
-        stash_count += H[run.nbins + run.blocks + b];  // the powers stashed, without padding
-        overflow = overflow || H[run.nbins + b] > run.seg_cap;
+        stash_count += H[seg_off + run.blocks + b];  // the powers stashed, without padding
+        overflow = overflow || H[seg_off + b] > run.seg_cap;
     }
     for (uint32_t b = 1; b < run.nbins; b += 2)
         in_bands += H[b];
@@ -297,14 +299,147 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
     ctx->sweep_seg_cap = run.seg_cap;
     ctx->sweep_nsegs = (uint32_t)run.blocks;
     ctx->sweep_nbins = run.nbins;
+    ctx->sweep_seg_off = seg_off;
     ctx->sweep_overflow = overflow;
     ctx->sweep_valid = true;
     info.swept = 1;
     info.reason = PAPR_SWEEP_OK;
     info.stash_samples = stash_count;
     info.stash_capacity = run.seg_cap * (uint64_t)run.blocks;  // what this sweep could use (one segment per workgroup)
-    info.gave_up = (uint32_t)std::min<unsigned long long>(H[run.nbins + 2 * run.blocks], 0xFFFFFFFFull);
+    info.gave_up = (uint32_t)std::min<unsigned long long>(H[seg_off + 2 * run.blocks], 0xFFFFFFFFull);
     return PAPR_OK;
+}
+
+// The default step's first half as ONE uninterrupted sequence of launches — estimate kernel, papr_guess_bands_kernel
+// (the host half of the speculation, on the device), histogram memset, sweep kernel, finalize — and one wait, instead of
+// estimate / wait / host guess + LUT + upload / sweep / wait.  For a shard without peers (the estimate crosses no
+// exchange), resident, in tree-sum mode, with the default kernel choice; anything else: *done stays false and the
+// caller takes the host path.  The TRUE level table is the host's (papr_levels) as before; only the guess moved.
+int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, papr_stats *out, bool *done)
+{
+    *done = false;
+    if (!ctx->loaded || !ctx->resident || ctx->exact || ctx->have_file_stats || ctx->tune.sweep_variant > 0 ||
+        ctx->tune.sweep_map > 0 || !env_int("PAPR_FUSED_GUESS", 1))
+        return PAPR_OK;
+    const uint64_t ntiles_est = ctx->n / PAPR_ESTIMATE_TILE_SAMPLES;
+    const uint32_t nl = graph ? (uint32_t)(max_db * 10.0) + 1u : (uint32_t)max_db + 1u;
+    if (ntiles_est == 0 || nl > PAPR_GUESS_MAX_BANDS || !(max_db >= 0))
+        return PAPR_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    papr_hip_sweep_info &info = ctx->sweep_info;
+    // ---- geometry: the default papr_sweep_kernel<1024, 4> with its one-edge-per-cell table, built on the device ----
+    SweepRun run;
+    run.variant = kSweepVariant;
+    run.lut2 = PAPR_SWEEP_VARIANT_IS_LUT2(run.variant);
+    int vblock = 0;
+    if (papr_sweep_geometry(run.variant, &vblock, &run.tile, &run.stash_lds) != 0)
+        return PAPR_OK;
+    run.threads = vblock;
+    if (ctx->n / run.tile == 0)
+        return PAPR_OK;
+    run.blocks = pick_blocks(ctx, SWEEP, ctx->n / run.tile);
+    constexpr uint32_t kBinsMax = 2 * PAPR_GUESS_MAX_BANDS + 2;
+    constexpr uint32_t kTableWords = 48 * 1024 / 4 + 8;
+    constexpr uint32_t kCopies = 4;
+    run.seg_off = kBinsMax;
+    // ---- estimate geometry (as papr_hip_estimate) ----
+    uint64_t ratio = ctx->tune.estimate_ratio > 0 ? (uint64_t)ctx->tune.estimate_ratio : (uint64_t)kEstimateRatio;
+    ratio = std::max<uint64_t>(1, std::min<uint64_t>(ratio, ntiles_est / kEstimateMinTiles));
+    const uint64_t ngroups = ntiles_est / ratio;
+    const int est_blocks = (int)std::min<uint64_t>(ngroups, (uint64_t)ctx->num_cus * 8);
+    // ---- buffers ----
+    int rc = ensure_partials(ctx, (size_t)run.blocks + 1 + (size_t)est_blocks + 1);
+    if (rc)
+        return rc;
+    papr_partial *est_partials = ctx->d_partials + run.blocks + 1;
+    if (!ctx->d_est_sq) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double)));
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double), hipHostMallocDefault));
+    }
+    if (!ctx->d_guess) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_guess, sizeof(papr_guess_out)));
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_guess, sizeof(papr_guess_out), hipHostMallocMapped));
+        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_guess_dev, ctx->h_guess, 0));
+    }
+    constexpr size_t kMaxSweepBlocks = 65536;
+    if (!ctx->d_sweep_hist) {
+        const size_t bytes = (2 * (size_t)PAPR_HIP_MAX_LEVELS + 2 + 2 * kMaxSweepBlocks + 1) * sizeof(unsigned long long);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_sweep_hist, bytes));
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_sweep_hist, bytes, hipHostMallocDefault));
+    }
+    run.seg_cap = std::max<uint64_t>((ctx->n / 4 / (uint64_t)run.blocks + 255) & ~255ull, 4096);
+    const uint64_t want_stash = run.seg_cap * (uint64_t)run.blocks;
+    if (ctx->stash_cap < want_stash) {
+        if (ctx->d_stash) HIPCHK(ctx, hipFree(ctx->d_stash));
+        ctx->d_stash = nullptr;
+        ctx->stash_cap = 0;
+        if (hipMalloc((void **)&ctx->d_stash, want_stash * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->d_stash = nullptr;
+            return PAPR_OK;  // (no room for the stash: the host path reports it)
+        }
+        ctx->stash_cap = want_stash;
+    }
+    rc = ensure_table(ctx, kTableWords);
+    if (rc)
+        return rc;
+    const size_t lds_bytes = (size_t)kTableWords * 4 + (((size_t)kCopies * kBinsMax + 3) & ~(size_t)3) * 4 + run.stash_lds;
+    if (lds_bytes > (size_t)papr_ccdf_max_dynamic_lds())
+        return PAPR_OK;
+    info.swept = info.resolved = 0;
+    info.stash_samples = 0;
+    ctx->sweep_valid = false;
+    ctx->exact_swept = false;
+    ctx->est_groups_valid = false;
+    // ---- the launches ----
+    time_begin(ctx, 4, ngroups * PAPR_ESTIMATE_TILE_SAMPLES * 8);
+    papr_launch_estimate(ctx->stream, est_blocks, ctx->d_iq, ngroups, (uint32_t)ratio, est_partials, nullptr, ctx->d_est_sq);
+    time_end(ctx);
+    HIPCHK(ctx, hipGetLastError());
+    const int band_override = ctx->tune.sweep_band_log2 > 0 ? ctx->tune.sweep_band_log2 : 0;
+    papr_launch_guess_bands(ctx->stream, est_partials, ctx->d_est_sq, (uint32_t)est_blocks, ngroups,
+                            ngroups * PAPR_ESTIMATE_TILE_SAMPLES, ctx->n, (uint32_t)ratio, graph, (float)max_db, spoil,
+                            band_override, kCopies, run.lut2 ? 1 : 0,
+                            (uint32_t)std::max<long long>(0, (long long)vblock * 80 - (long long)run.stash_lds), ctx->d_table,
+                            kTableWords, ctx->d_guess, ctx->h_guess_dev);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_sweep_hist, 0, ((size_t)kBinsMax + 2 * (size_t)run.blocks + 1) * sizeof(unsigned long long),
+                               ctx->stream));
+    const uint64_t ntiles = ctx->n / run.tile;
+    const uint32_t tail = (uint32_t)(ctx->n - ntiles * run.tile);
+    const int map = effective_map(ctx, SWEEP, run.blocks);
+    papr_ccdf_params none{};
+    time_begin(ctx, 3, ctx->n * 8);
+    papr_launch_sweep(ctx->stream, run.variant, run.blocks, lds_bytes, ctx->d_iq, ntiles, ctx->base, map, ctx->d_partials,
+                      ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->d_table, none, ctx->d_sweep_hist, ctx->d_stash,
+                      ctx->d_sweep_hist + kBinsMax, run.seg_cap, ctx->d_sweep_hist + kBinsMax + 2 * run.blocks,
+                      ctx->d_sweep_hist + kBinsMax + run.blocks, &ctx->d_guess->P);
+    time_end(ctx);
+    HIPCHK(ctx, hipGetLastError());
+    rc = sweep_fetch(ctx, run);
+    if (rc)
+        return rc;
+    rc = finish_stats(ctx, (size_t)run.blocks, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->base + ctx->n - tail, out);  // synchronises
+    if (rc)
+        return rc;
+    *done = true;
+    // ---- what the device decided ----
+    const papr_guess_out &g = *ctx->h_guess;
+    info.estimate_samples = ngroups * PAPR_ESTIMATE_TILE_SAMPLES;
+    info.band_log2 = (int)g.band_log2;
+    if (std::isnan(out->sum)) {  // NaN in the data: the sweep's integer-max trackers do not apply (papr_sweep.hip)
+        info.reason = PAPR_SWEEP_NO_BANDS;
+        return papr_hip_stats(ctx, out);
+    }
+    if (!g.ok || g.nbands == 0 || g.nbands > PAPR_GUESS_MAX_BANDS) {
+        info.reason = PAPR_SWEEP_NO_BANDS;  // the guess had no band form: this was a plain pass 1 (its record stands)
+        return PAPR_OK;
+    }
+    run.gkeys.assign(g.gkeys, g.gkeys + g.nbands);
+    run.half = 1u << g.band_log2;
+    run.bands.P = g.P;
+    run.nbins = g.P.nkeys + 2;
+    return sweep_collect(ctx, run);
 }
 
 }  // namespace papr_rt
@@ -521,7 +656,7 @@ int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *lev
         // enough workgroups to fill the chip: every segment is split over `split` of them
         const uint32_t split = std::max<uint32_t>(1, (uint32_t)(ctx->num_cus * 8) / ctx->sweep_nsegs);
         papr_launch_ccdf_power(ctx->stream, (int)(ctx->sweep_nsegs * split), plan.lut, plan.lds_bytes, ctx->d_stash,
-                               ctx->d_sweep_hist + ctx->sweep_nbins, ctx->sweep_seg_cap, ctx->sweep_nsegs, split,
+                               ctx->d_sweep_hist + ctx->sweep_seg_off, ctx->sweep_seg_cap, ctx->sweep_nsegs, split,
                                ctx->d_table, plan.P, ctx->d_hist);
         time_end(ctx);
         HIPCHK(ctx, hipGetLastError());

@@ -597,3 +597,30 @@ def test_exact_sweep_variants_agree_with_the_reference(pkg, orc, variant):
             check_stats(res.total, ref)
             assert res.exact_sum == 1 and res.total.sum == ref["sum"] and res.swept == 1 and res.resolved == 1
             assert np.array_equal(table, ref["level"]) and np.array_equal(counts.astype(np.int64), ref["count"])
+
+
+@pytest.mark.parametrize("envelope", ["gauss", "bursty", "constant"])
+def test_device_side_guess_equals_the_host_side_guess(pkg, orc, monkeypatch, envelope):
+    """papr_hip_analyze without peers builds the guessed bands on the device between the estimate and the sweep
+    (papr_guess_bands_kernel: no host round trip); PAPR_FUSED_GUESS=0 is the host path (papr_guess_levels +
+    papr_sweep_bands + the LUT plan).  Same result either way — and the reference's — at sizes where the sample is
+    everything and where it is not, with the guess spoiled, both tables."""
+    for n in (2047, 300007, 20 * 1048576 + 333):
+        with pkg.PaprHip(0) as g:
+            g.generate(pkg.SynthSpec.spike(n, seed=1000 + n % 97, envelope=envelope), 0, n)
+            iq = g.download(0, n)
+            for graph in (False, True):
+                ref = orc.run_mem(iq, graph)
+                got = {}
+                for fused in ("1", "0"):
+                    monkeypatch.setenv("PAPR_FUSED_GUESS", fused)
+                    for kw in (dict(), dict(spoil_guess=True)):
+                        res, table, counts = g.analyze(None, graph, **kw)
+                        check_stats(res.total, ref)
+                        assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
+                        got[(fused, bool(kw))] = (res.total.sum, res.nlevels, tuple(counts.tolist()), res.swept, res.resolved,
+                                                  res.band_log2 if res.swept else None)
+                for spoiled in (False, True):
+                    a, b = got[("1", spoiled)], got[("0", spoiled)]
+                    assert a[:3] == b[:3], (n, graph, spoiled)          # sum, levels, counts: bit for bit
+                    assert a[3:] == b[3:], (n, graph, spoiled, a, b)    # ... and the same decisions on the way
