@@ -147,7 +147,8 @@ void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, c
                              uint64_t ngroups, uint64_t sampled, uint64_t nsamples, uint32_t ratio, int graph, float max_db,
                              float spoil, int band_override, uint32_t copies, int compact /* LUT form: two edges per cell */,
                              uint32_t soft_lds /* bytes table + histogram copies should stay under */, uint32_t *table,
-                             uint32_t table_cap_words, papr_guess_out *out_dev, papr_guess_out *out_host);
+                             uint32_t table_cap_words, papr_guess_out *out_dev, papr_guess_out *out_host,
+                             unsigned long long *zero /* words the kernel clears on its way */, uint32_t zero_words);
 int papr_sweep_variant(int variant); /* the sweep geometry used for a variant id, or -1 */
 #define PAPR_SWEEP_VARIANT_IS_LUT2(v) (((v) >= 20 && (v) <= 29) || ((v) >= 70 && (v) <= 79) || (v) == 18 || (v) == 38) /* compact table: papr_sweep_kernel<LUT2>, papr_sweep_split_kernel */
 int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_t *stash_lds); /* 0, or -1 */
@@ -159,7 +160,21 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
                        const papr_ccdf_params *Pdev /* null, or the table geometry in device memory (overrides P) */);
 void papr_launch_ccdf_power(hipStream_t st, int blocks, bool lut, size_t lds_bytes, const float *stash,
                             const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs, uint32_t split,
-                            const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist);
+                            const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist,
+                            const papr_ccdf_params *Pdev /* null, or the table geometry in device memory (overrides P) */);
+/* papr_true_table_kernel: the reference's level table from the pass-1 record, with the device's libm, and the recount
+ * LUT for it — a speculation the host checks against papr_levels bit for bit */
+#define PAPR_TRUE_MAX_LEVELS 1024
+struct papr_true_out {
+    papr_ccdf_params P;
+    uint32_t ok;       /* 1: levels and table are there (normal, increasing levels with a LUT form) */
+    uint32_t nlevels;
+    uint32_t pad[2];
+    float levels[PAPR_TRUE_MAX_LEVELS];  /* (host copy only) */
+};
+void papr_launch_true_table(hipStream_t st, const papr_partial *result, uint64_t nsamples, int graph, uint32_t copies,
+                            uint32_t soft_lds, uint32_t *table, uint32_t table_cap_words, papr_true_out *out_dev,
+                            papr_true_out *out_host, unsigned long long *zero, uint32_t zero_words);
 void papr_sweep_prepare_device(void);
 
 // ---- one-sweep kernel, second generation (papr_sweep.hip: papr_sweep2_kernel) -----------------------------------

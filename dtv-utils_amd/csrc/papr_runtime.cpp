@@ -577,6 +577,8 @@ void papr_hip_close(papr_hip_ctx *ctx)
     if (ctx->d_ambig) (void)hipFree(ctx->d_ambig);
     if (ctx->d_raw_store) (void)hipFree(ctx->d_raw_store);
     if (ctx->d_redo_store) (void)hipFree(ctx->d_redo_store);
+    if (ctx->d_true) (void)hipFree(ctx->d_true);
+    if (ctx->h_true) (void)hipHostFree(ctx->h_true);
     if (ctx->d_guess) (void)hipFree(ctx->d_guess);
     if (ctx->h_guess) (void)hipHostFree(ctx->h_guess);
     if (ctx->ev_program) (void)hipEventDestroy(ctx->ev_program);

@@ -224,6 +224,8 @@ struct papr_hip_ctx {
     uint64_t sweep_seg_cap = 0;                  // floats per stash segment
     uint32_t sweep_nsegs = 0, sweep_nbins = 0, sweep_seg_off = 0;
     papr_guess_out *d_guess = nullptr, *h_guess = nullptr, *h_guess_dev = nullptr;  // papr_guess_bands_kernel's output (device; mapped host)
+    papr_true_out *d_true = nullptr, *h_true = nullptr, *h_true_dev = nullptr;     // papr_true_table_kernel's output
+    bool spec_recount_valid = false;  // h_hist holds the stash recount for the table in h_true (stats_sweep_fused)
     bool sweep_overflow = false;
     papr_hip_sweep_info sweep_info{};
     const papr_rt::SweepRun *ingest_run = nullptr;        // set while papr_hip_load_file_sweep streams the file in

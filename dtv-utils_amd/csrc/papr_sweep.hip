@@ -281,9 +281,12 @@ __global__ __launch_bounds__(1024) void papr_guess_bands_kernel(
     const papr_partial *__restrict__ est_partials, const double *__restrict__ est_sq, uint32_t est_blocks, uint64_t ngroups,
     uint64_t sampled, uint64_t nsamples, uint32_t ratio, int graph, float max_db, float spoil, int band_override,
     uint32_t copies, int compact, uint32_t soft_lds, uint32_t *__restrict__ table, uint32_t table_cap_words,
-    papr_guess_out *__restrict__ out_dev, papr_guess_out *__restrict__ out_host)
+    papr_guess_out *__restrict__ out_dev, papr_guess_out *__restrict__ out_host, unsigned long long *__restrict__ zero,
+    uint32_t zero_words)
 {
     constexpr uint32_t kNeverHi = 0xFFFFFFFFu;
+    for (uint32_t w = threadIdx.x; w < zero_words; w += 1024)
+        zero[w] = 0;  // (the sweep's histogram and segment counters: saves a memset between the launches)
     __shared__ double red[1024];
     __shared__ uint32_t keys[PAPR_GUESS_MAX_BANDS];
     __shared__ uint32_t edges[2 * PAPR_GUESS_MAX_BANDS];
@@ -377,20 +380,23 @@ __global__ __launch_bounds__(1024) void papr_guess_bands_kernel(
     __syncthreads();
     // ---- the LUT: the coarsest cell that leaves at most two edges (compact form) / one edge (papr_sweep_kernel's
     // plain form: finish_plan) in any cell ----
+    // (two patterns lie in different cells of size 2^s exactly when their highest differing bit is >= s: the coarsest
+    // admissible cell is the minimum of that bit over all pairs that must be apart — one reduction, no search)
     int shift = -1;
     const uint32_t reach = compact ? 2u : 1u;  // edges[i + reach] must not share a cell with edges[i]
-    for (int s = compact ? PAPR_LUT2_MAX_SHIFT : 23; n && s >= 8 && shift < 0; s--) {
-        if (t == 0)
-            s_bad = 0;
-        __syncthreads();
-        for (uint32_t i = t; i + reach < n; i += 1024)
-            if ((edges[i + reach] >> s) == (edges[i] >> s))
-                s_bad = 1;
-        __syncthreads();
-        if (!s_bad)
-            shift = s;
-        __syncthreads();
+    if (t == 0)
+        s_bad = 31;
+    __syncthreads();
+    for (uint32_t i = t; i + reach < n; i += 1024)
+        atomicMin(&s_bad, 31u - (uint32_t)__clz((int)(edges[i + reach] ^ edges[i])));
+    __syncthreads();
+    if (n) {
+        const int top = compact ? PAPR_LUT2_MAX_SHIFT : 23;
+        shift = (int)s_bad < top ? (int)s_bad : top;
+        if (shift < 8)
+            shift = -1;
     }
+    __syncthreads();
     papr_ccdf_params P;
     P.shift = 8;
     P.cell_lo = 1;
@@ -475,11 +481,155 @@ __global__ __launch_bounds__(1024) void papr_guess_bands_kernel(
 void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, const double *est_sq, uint32_t est_blocks,
                              uint64_t ngroups, uint64_t sampled, uint64_t nsamples, uint32_t ratio, int graph, float max_db,
                              float spoil, int band_override, uint32_t copies, int compact, uint32_t soft_lds, uint32_t *table,
-                             uint32_t table_cap_words, papr_guess_out *out_dev, papr_guess_out *out_host)
+                             uint32_t table_cap_words, papr_guess_out *out_dev, papr_guess_out *out_host,
+                             unsigned long long *zero, uint32_t zero_words)
 {
     hipLaunchKernelGGL(papr_guess_bands_kernel, dim3(1), dim3(1024), 0, st, est_partials, est_sq, est_blocks, ngroups, sampled,
                        nsamples, ratio, graph, max_db, spoil, band_override, copies, compact, soft_lds, table, table_cap_words,
-                       out_dev, out_host);
+                       out_dev, out_host, zero, zero_words);
+}
+
+// =============================================================================
+// 2b. the true table, speculated on the device
+// =============================================================================
+// After the sweep the host builds the reference's level table from the pass-1 record with libm (papr_levels) — that
+// stays — but waiting for it before the stash recount can start costs a launch + wait round trip.  So one workgroup
+// builds the same table right behind the finalize kernel with the device's pow / log10, plans the recount's LUT for it
+// (finish_plan's LUT form) and the recount runs on that table at once; the host then compares its own table with this
+// one bit for bit (a double-precision pow differs from libm's in the last place once in a few million levels) and uses
+// the recount's histogram if they agree, or recounts as before if they do not.  Speculation decides how long the step
+// takes, never a count.
+__global__ __launch_bounds__(1024) void papr_true_table_kernel(const papr_partial *__restrict__ result, uint64_t nsamples, int graph,
+                                                                uint32_t copies, uint32_t soft_lds, uint32_t *__restrict__ table,
+                                                                uint32_t table_cap_words, papr_true_out *__restrict__ out_dev,
+                                                                papr_true_out *__restrict__ out_host,
+                                                                unsigned long long *__restrict__ zero, uint32_t zero_words)
+{
+    for (uint32_t w = threadIdx.x; w < zero_words; w += 1024)
+        zero[w] = 0;  // (the recount's histogram)
+    __shared__ uint32_t keys[PAPR_TRUE_MAX_LEVELS];
+    __shared__ uint32_t s_bad;
+    const uint32_t t = threadIdx.x;
+    const double sum = result->sum;
+    const float peak = result->val[0];
+    // papr.c:131 / 164, :134 / 165, :136 / 166 (papr_levels)
+    const double mean = sum / (double)(long long)nsamples;
+    const float papr = (float)(10 * log10((double)peak / mean));
+    const float scaled = graph ? papr * 10 : papr;
+    const int top = (!(scaled == scaled) || scaled >= 2147483648.0f || scaled < -2147483648.0f) ? INT32_MIN : (int)scaled;
+    const uint32_t nl = top < 0 ? 0u : (uint32_t)top + 1u;
+    bool ok = nl >= 1 && nl <= PAPR_TRUE_MAX_LEVELS && sum == sum && mean > 0.0;
+    if (t == 0)
+        s_bad = 0;
+    __syncthreads();
+    float level = 0.f;
+    uint32_t key = 0;
+    if (ok && t < nl) {
+        if (graph) {
+            float tenth_db = 0.0f;  // papr.c:168-173: the float accumulation, step by step
+            for (uint32_t j = 0; j < t; j++)
+                tenth_db = (float)(tenth_db + 0.1);
+            level = (float)(pow(10.0, (double)(tenth_db / 10)) * mean);
+        } else {
+            level = (float)(pow(10.0, (double)((float)t / 10)) * mean);  // papr.c:138-141
+        }
+        const uint32_t bits = __float_as_uint(level);
+        // the recount's LUT form wants normal, finite, positive levels (anything else: the host does it)
+        if (!(level > 0.0f) || bits < 0x00800000u || bits >= 0x7F7FFFFFu)
+            s_bad = 1;
+        key = bits + 1u;
+        keys[t] = key;
+    }
+    __syncthreads();
+    if (ok && t > 0 && t < nl && key <= keys[t - 1])
+        s_bad = 1;  // (not strictly increasing: duplicates are the host's business)
+    __syncthreads();
+    ok = ok && !s_bad;
+    const uint32_t m = ok ? nl : 0u;
+    // ---- LUT: the coarsest cell that isolates every key (finish_plan) ----
+    int shift = -1;
+    if (t == 0)
+        s_bad = 31;
+    __syncthreads();
+    for (uint32_t k = t + 1; k < m; k += 1024)
+        atomicMin(&s_bad, 31u - (uint32_t)__clz((int)(keys[k] ^ keys[k - 1])));  // highest bit in which neighbours differ
+    __syncthreads();
+    if (m) {
+        shift = (int)s_bad < 23 ? (int)s_bad : 23;
+        const uint64_t ncells = (uint64_t)(keys[m - 1] >> shift) - (keys[0] >> shift) + 1;
+        if (shift < 8 || ncells * 8 > 40 * 1024)
+            shift = -1;
+    }
+    __syncthreads();
+    papr_ccdf_params P;
+    P.shift = 8;
+    P.cell_lo = 1;
+    P.ncells = 0;
+    P.nkeys = 0;
+    P.above_lo = 0x7F800001u;
+    P.above_count = 0;
+    P.table_words = 0;
+    P.copies = copies;
+    P.search_step = 0;
+    uint32_t good = 0;
+    if (shift >= 0) {
+        const uint32_t c0 = keys[0] >> shift, c1 = keys[m - 1] >> shift;
+        const uint32_t ncells = c1 - c0 + 1;
+        if (2 * ncells <= table_cap_words) {
+            P.shift = (uint32_t)shift;
+            P.cell_lo = c0;
+            P.ncells = ncells;
+            P.nkeys = m;
+            const uint64_t above = ((uint64_t)c1 + 1) << shift;
+            P.above_lo = above <= 0x7F800000u ? (uint32_t)above : 0x7F800001u;
+            P.above_count = above <= 0x7F800000u ? 0x7F800001u - P.above_lo : 0u;
+            P.table_words = 2 * ncells;
+            while (P.copies > 1 && (size_t)P.table_words * 4 + (size_t)P.copies * (m + 1) * 4 > soft_lds)
+                P.copies--;
+            // (soft_lds is also what the recount was launched with: a table that needs more is the host's business)
+            good = (size_t)P.table_words * 4 + (size_t)P.copies * (m + 1) * 4 <= soft_lds ? 1u : 0u;
+            // lut[cell] = { keys strictly below this cell, the key inside this cell or never } (upload_ccdf_table)
+            for (uint32_t c = t; c < ncells; c += 1024) {
+                const uint32_t cell = c0 + c;
+                uint32_t lo = 0, hi = m;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) / 2;
+                    if ((keys[mid] >> shift) < cell)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                table[2 * c] = lo;
+                table[2 * c + 1] = (lo < m && (keys[lo] >> shift) == cell) ? keys[lo] : 0xFFFFFFFFu;
+            }
+            if (!good) {  // (the recount then runs on an empty table: harmless, unused)
+                P.nkeys = 0;
+                P.ncells = 0;
+                P.table_words = 0;
+                P.above_lo = 0x7F800001u;
+                P.above_count = 0;
+            }
+        }
+    }
+    if (t == 0) {
+        papr_true_out *outs[2] = {out_dev, out_host};
+        for (int k = 0; k < 2; k++) {
+            outs[k]->P = P;
+            outs[k]->ok = good;
+            outs[k]->nlevels = good ? nl : 0u;
+            outs[k]->pad[0] = outs[k]->pad[1] = 0;
+        }
+    }
+    if (good && t < nl)
+        out_host->levels[t] = level;
+}
+
+void papr_launch_true_table(hipStream_t st, const papr_partial *result, uint64_t nsamples, int graph, uint32_t copies,
+                            uint32_t soft_lds, uint32_t *table, uint32_t table_cap_words, papr_true_out *out_dev,
+                            papr_true_out *out_host, unsigned long long *zero, uint32_t zero_words)
+{
+    hipLaunchKernelGGL(papr_true_table_kernel, dim3(1), dim3(1024), 0, st, result, nsamples, graph, copies, soft_lds, table,
+                       table_cap_words, out_dev, out_host, zero, zero_words);
 }
 
 // =============================================================================
@@ -1531,9 +1681,11 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_ccdf_power_kernel(const float
                                                                       const unsigned long long *__restrict__ seg_counts,
                                                                       uint64_t seg_cap, uint32_t nsegs, uint32_t split,
                                                                       const uint32_t *__restrict__ table,
-                                                                      papr_ccdf_params P,
-                                                                      unsigned long long *__restrict__ ghist)
+                                                                      papr_ccdf_params Parg,
+                                                                      unsigned long long *__restrict__ ghist,
+                                                                      const papr_ccdf_params *__restrict__ Pdev)
 {
+    const papr_ccdf_params P = Pdev ? *Pdev : Parg;  // (the table may have been planned on the device: papr_true_table_kernel)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t nbins = P.nkeys + 1;
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
@@ -1784,14 +1936,15 @@ void papr_launch_sweep2(hipStream_t st, int variant, int blocks, size_t lds_byte
 
 void papr_launch_ccdf_power(hipStream_t st, int blocks, bool lut, size_t lds_bytes, const float *stash,
                             const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs, uint32_t split,
-                            const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist)
+                            const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist,
+                            const papr_ccdf_params *Pdev)
 {
     if (lut)
         hipLaunchKernelGGL((papr_ccdf_power_kernel<true>), dim3(blocks), dim3(PAPR_BLOCK), lds_bytes, st, stash,
-                           seg_counts, seg_cap, nsegs, split, table, P, ghist);
+                           seg_counts, seg_cap, nsegs, split, table, P, ghist, Pdev);
     else
         hipLaunchKernelGGL((papr_ccdf_power_kernel<false>), dim3(blocks), dim3(PAPR_BLOCK), lds_bytes, st, stash,
-                           seg_counts, seg_cap, nsegs, split, table, P, ghist);
+                           seg_counts, seg_cap, nsegs, split, table, P, ghist, Pdev);
 }
 
 void papr_sweep_prepare_device(void)

@@ -302,6 +302,7 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
     ctx->sweep_seg_off = seg_off;
     ctx->sweep_overflow = overflow;
     ctx->sweep_valid = true;
+    ctx->spec_recount_valid = false;  // (stats_sweep_fused sets it behind this call)
     info.swept = 1;
     info.reason = PAPR_SWEEP_OK;
     info.stash_samples = stash_count;
@@ -356,6 +357,11 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double)));
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double), hipHostMallocDefault));
     }
+    if (!ctx->d_true) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_true, sizeof(papr_true_out)));
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_true, sizeof(papr_true_out), hipHostMallocMapped));
+        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_true_dev, ctx->h_true, 0));
+    }
     if (!ctx->d_guess) {
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_guess, sizeof(papr_guess_out)));
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_guess, sizeof(papr_guess_out), hipHostMallocMapped));
@@ -401,10 +407,9 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
                             ngroups * PAPR_ESTIMATE_TILE_SAMPLES, ctx->n, (uint32_t)ratio, graph, (float)max_db, spoil,
                             band_override, kCopies, run.lut2 ? 1 : 0,
                             (uint32_t)std::max<long long>(0, (long long)vblock * 80 - (long long)run.stash_lds), ctx->d_table,
-                            kTableWords, ctx->d_guess, ctx->h_guess_dev);
+                            kTableWords, ctx->d_guess, ctx->h_guess_dev, ctx->d_sweep_hist,
+                            kBinsMax + 2u * (uint32_t)run.blocks + 1u);  // (also clears the sweep's bins and segment counters)
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_sweep_hist, 0, ((size_t)kBinsMax + 2 * (size_t)run.blocks + 1) * sizeof(unsigned long long),
-                               ctx->stream));
     const uint64_t ntiles = ctx->n / run.tile;
     const uint32_t tail = (uint32_t)(ctx->n - ntiles * run.tile);
     const int map = effective_map(ctx, SWEEP, run.blocks);
@@ -419,9 +424,34 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     rc = sweep_fetch(ctx, run);
     if (rc)
         return rc;
-    rc = finish_stats(ctx, (size_t)run.blocks, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->base + ctx->n - tail, out);  // synchronises
-    if (rc)
-        return rc;
+    // pass 1's record (tail + merge of the workgroups' records) ...
+    papr_launch_stats_finalize(ctx->stream, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->base + ctx->n - tail, ctx->d_partials,
+                               (uint32_t)run.blocks, ctx->h_result_dev);
+    HIPCHK(ctx, hipGetLastError());
+    // ... and, speculatively, what follows from it: the reference's level table with the device's libm, the recount LUT
+    // for it, and the recount of the stash — so that the step's second half needs no launch + wait round trip either
+    // (resolve_from_sweep takes the histogram if the host's own table turns out to be this one, bit for bit)
+    constexpr uint32_t kTrueCopies = 4;
+    constexpr uint32_t true_soft = 20 * 1024;  // LDS the recount is launched with (as the host path: table + histogram copies)
+    ctx->h_true->ok = 0;
+    papr_launch_true_table(ctx->stream, ctx->h_result_dev, ctx->n, graph, kTrueCopies, true_soft, ctx->d_table, kTableWords,
+                           ctx->d_true, ctx->h_true_dev, ctx->d_hist, PAPR_TRUE_MAX_LEVELS + 1);  // (also clears the recount's bins)
+    HIPCHK(ctx, hipGetLastError());
+    {
+        const uint32_t split = std::max<uint32_t>(1, (uint32_t)(ctx->num_cus * 8) / (uint32_t)run.blocks);
+        const size_t recount_lds = true_soft;
+        time_begin(ctx, 4, 0);
+        papr_launch_ccdf_power(ctx->stream, (int)((uint32_t)run.blocks * split), true, recount_lds, ctx->d_stash,
+                               ctx->d_sweep_hist + kBinsMax, run.seg_cap, (uint32_t)run.blocks, split, ctx->d_table, none,
+                               ctx->d_hist, &ctx->d_true->P);
+        time_end(ctx);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(PAPR_TRUE_MAX_LEVELS + 1) * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    partial_to_stats(*ctx->h_result, ctx->n, out);
+    out->flags |= ctx->shard_flags;
     *done = true;
     // ---- what the device decided ----
     const papr_guess_out &g = *ctx->h_guess;
@@ -439,7 +469,10 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     run.half = 1u << g.band_log2;
     run.bands.P = g.P;
     run.nbins = g.P.nkeys + 2;
-    return sweep_collect(ctx, run);
+    rc = sweep_collect(ctx, run);
+    if (rc == PAPR_OK)
+        ctx->spec_recount_valid = ctx->h_true->ok != 0;  // (whether it is the RIGHT table is for resolve_from_sweep to say)
+    return rc;
 }
 
 }  // namespace papr_rt
@@ -647,7 +680,16 @@ int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *lev
         return PAPR_OK;
     }
     const uint32_t m = plan.P.nkeys;
-    if (ctx->sweep_stash_count) {
+    // the recount may already be there: stats_sweep_fused ran it against the table the device expected (papr_true_table_kernel)
+    const papr_true_out *sp = ctx->spec_recount_valid ? ctx->h_true : nullptr;
+    ctx->spec_recount_valid = false;
+    // (PAPR_SPEC_RECOUNT=0: never take it — the tests compare the two ways)
+    const bool speculated = sp && sp->ok && env_int("PAPR_SPEC_RECOUNT", 1) && (int)sp->nlevels == nlevels && plan.lut && sp->P.nkeys == m &&
+                            sp->P.shift == plan.P.shift && sp->P.cell_lo == plan.P.cell_lo &&
+                            memcmp(sp->levels, levels, (size_t)nlevels * sizeof(float)) == 0;
+    if (speculated) {
+        // (h_hist holds it)
+    } else if (ctx->sweep_stash_count) {
         int rc = upload_ccdf_table(ctx, plan);
         if (rc)
             return rc;
@@ -657,7 +699,7 @@ int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *lev
         const uint32_t split = std::max<uint32_t>(1, (uint32_t)(ctx->num_cus * 8) / ctx->sweep_nsegs);
         papr_launch_ccdf_power(ctx->stream, (int)(ctx->sweep_nsegs * split), plan.lut, plan.lds_bytes, ctx->d_stash,
                                ctx->d_sweep_hist + ctx->sweep_seg_off, ctx->sweep_seg_cap, ctx->sweep_nsegs, split,
-                               ctx->d_table, plan.P, ctx->d_hist);
+                               ctx->d_table, plan.P, ctx->d_hist, nullptr);
         time_end(ctx);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(m + 1) * sizeof(unsigned long long),

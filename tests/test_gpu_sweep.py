@@ -602,9 +602,11 @@ def test_exact_sweep_variants_agree_with_the_reference(pkg, orc, variant):
 @pytest.mark.parametrize("envelope", ["gauss", "bursty", "constant"])
 def test_device_side_guess_equals_the_host_side_guess(pkg, orc, monkeypatch, envelope):
     """papr_hip_analyze without peers builds the guessed bands on the device between the estimate and the sweep
-    (papr_guess_bands_kernel: no host round trip); PAPR_FUSED_GUESS=0 is the host path (papr_guess_levels +
-    papr_sweep_bands + the LUT plan).  Same result either way — and the reference's — at sizes where the sample is
-    everything and where it is not, with the guess spoiled, both tables."""
+    (papr_guess_bands_kernel: no host round trip) and runs the stash recount speculatively against the level table the
+    device expects (papr_true_table_kernel; taken only if the host's libm table is that table bit for bit);
+    PAPR_FUSED_GUESS=0 is the host path, PAPR_SPEC_RECOUNT=0 recounts on the host's table.  Same result every way —
+    and the reference's — at sizes where the sample is everything and where it is not, with the guess spoiled, both
+    tables."""
     for n in (2047, 300007, 20 * 1048576 + 333):
         with pkg.PaprHip(0) as g:
             g.generate(pkg.SynthSpec.spike(n, seed=1000 + n % 97, envelope=envelope), 0, n)
@@ -612,8 +614,9 @@ def test_device_side_guess_equals_the_host_side_guess(pkg, orc, monkeypatch, env
             for graph in (False, True):
                 ref = orc.run_mem(iq, graph)
                 got = {}
-                for fused in ("1", "0"):
-                    monkeypatch.setenv("PAPR_FUSED_GUESS", fused)
+                for fused in ("1", "0", "1 without the speculated recount"):
+                    monkeypatch.setenv("PAPR_FUSED_GUESS", fused[0])
+                    monkeypatch.setenv("PAPR_SPEC_RECOUNT", "0" if len(fused) > 1 else "1")
                     for kw in (dict(), dict(spoil_guess=True)):
                         res, table, counts = g.analyze(None, graph, **kw)
                         check_stats(res.total, ref)
@@ -621,6 +624,6 @@ def test_device_side_guess_equals_the_host_side_guess(pkg, orc, monkeypatch, env
                         got[(fused, bool(kw))] = (res.total.sum, res.nlevels, tuple(counts.tolist()), res.swept, res.resolved,
                                                   res.band_log2 if res.swept else None)
                 for spoiled in (False, True):
-                    a, b = got[("1", spoiled)], got[("0", spoiled)]
-                    assert a[:3] == b[:3], (n, graph, spoiled)          # sum, levels, counts: bit for bit
-                    assert a[3:] == b[3:], (n, graph, spoiled, a, b)    # ... and the same decisions on the way
+                    a, b, c = got[("1", spoiled)], got[("0", spoiled)], got[("1 without the speculated recount", spoiled)]
+                    assert a[:3] == b[:3] == c[:3], (n, graph, spoiled)       # sum, levels, counts: bit for bit
+                    assert a[3:] == b[3:] == c[3:], (n, graph, spoiled, a, b)  # ... and the same decisions on the way

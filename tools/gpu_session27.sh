@@ -2,7 +2,7 @@
 # GPU session 27: the fused estimate -> device guess -> sweep sequence (default step, no peers)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"; O=gpurun_out/s27; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -6 $O/pytest.log | cut -c1-300
+timeout 900 python -m pytest tests/test_gpu_sweep.py tests/test_bench_contract.py -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log | cut -c1-300
 for ROUND in 1 2 3; do
 for F in 1 0; do
   PAPR_FUSED_GUESS=$F timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-e2e > $O/b.json 2> $O/b.err
