@@ -174,7 +174,8 @@ struct papr_true_out {
 };
 void papr_launch_true_table(hipStream_t st, const papr_partial *result, uint64_t nsamples, int graph, uint32_t copies,
                             uint32_t soft_lds, uint32_t *table, uint32_t table_cap_words, papr_true_out *out_dev,
-                            papr_true_out *out_host, unsigned long long *zero, uint32_t zero_words);
+                            papr_true_out *out_host, unsigned long long *zero, uint32_t zero_words,
+                            const unsigned long long *gave_up /* the sweep's give-up counter: non-zero = nothing to recount */);
 void papr_sweep_prepare_device(void);
 
 // ---- one-sweep kernel, second generation (papr_sweep.hip: papr_sweep2_kernel) -----------------------------------

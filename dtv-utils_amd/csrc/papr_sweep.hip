@@ -503,10 +503,12 @@ __global__ __launch_bounds__(1024) void papr_true_table_kernel(const papr_partia
                                                                 uint32_t copies, uint32_t soft_lds, uint32_t *__restrict__ table,
                                                                 uint32_t table_cap_words, papr_true_out *__restrict__ out_dev,
                                                                 papr_true_out *__restrict__ out_host,
-                                                                unsigned long long *__restrict__ zero, uint32_t zero_words)
+                                                                unsigned long long *__restrict__ zero, uint32_t zero_words,
+                                                                const unsigned long long *__restrict__ gave_up)
 {
     for (uint32_t w = threadIdx.x; w < zero_words; w += 1024)
         zero[w] = 0;  // (the recount's histogram)
+    const bool hopeless = *gave_up != 0;  // the sweep gave itself up: its stash is void, nothing to recount
     __shared__ uint32_t keys[PAPR_TRUE_MAX_LEVELS];
     __shared__ uint32_t s_bad;
     const uint32_t t = threadIdx.x;
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(1024) void papr_true_table_kernel(const papr_partia
     const float scaled = graph ? papr * 10 : papr;
     const int top = (!(scaled == scaled) || scaled >= 2147483648.0f || scaled < -2147483648.0f) ? INT32_MIN : (int)scaled;
     const uint32_t nl = top < 0 ? 0u : (uint32_t)top + 1u;
-    bool ok = nl >= 1 && nl <= PAPR_TRUE_MAX_LEVELS && sum == sum && mean > 0.0;
+    bool ok = nl >= 1 && nl <= PAPR_TRUE_MAX_LEVELS && sum == sum && mean > 0.0 && !hopeless;
     if (t == 0)
         s_bad = 0;
     __syncthreads();
@@ -626,10 +628,11 @@ __global__ __launch_bounds__(1024) void papr_true_table_kernel(const papr_partia
 
 void papr_launch_true_table(hipStream_t st, const papr_partial *result, uint64_t nsamples, int graph, uint32_t copies,
                             uint32_t soft_lds, uint32_t *table, uint32_t table_cap_words, papr_true_out *out_dev,
-                            papr_true_out *out_host, unsigned long long *zero, uint32_t zero_words)
+                            papr_true_out *out_host, unsigned long long *zero, uint32_t zero_words,
+                            const unsigned long long *gave_up)
 {
     hipLaunchKernelGGL(papr_true_table_kernel, dim3(1), dim3(1024), 0, st, result, nsamples, graph, copies, soft_lds, table,
-                       table_cap_words, out_dev, out_host, zero, zero_words);
+                       table_cap_words, out_dev, out_host, zero, zero_words, gave_up);
 }
 
 // =============================================================================
@@ -1686,6 +1689,8 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_ccdf_power_kernel(const float
                                                                       const papr_ccdf_params *__restrict__ Pdev)
 {
     const papr_ccdf_params P = Pdev ? *Pdev : Parg;  // (the table may have been planned on the device: papr_true_table_kernel)
+    if (P.nkeys == 0)
+        return;  // (... which found nothing worth recounting)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t nbins = P.nkeys + 1;
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);

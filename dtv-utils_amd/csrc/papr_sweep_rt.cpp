@@ -435,7 +435,8 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     constexpr uint32_t true_soft = 20 * 1024;  // LDS the recount is launched with (as the host path: table + histogram copies)
     ctx->h_true->ok = 0;
     papr_launch_true_table(ctx->stream, ctx->h_result_dev, ctx->n, graph, kTrueCopies, true_soft, ctx->d_table, kTableWords,
-                           ctx->d_true, ctx->h_true_dev, ctx->d_hist, PAPR_TRUE_MAX_LEVELS + 1);  // (also clears the recount's bins)
+                           ctx->d_true, ctx->h_true_dev, ctx->d_hist, PAPR_TRUE_MAX_LEVELS + 1,  // (also clears the recount's bins)
+                           ctx->d_sweep_hist + kBinsMax + 2 * run.blocks);
     HIPCHK(ctx, hipGetLastError());
     {
         const uint32_t split = std::max<uint32_t>(1, (uint32_t)(ctx->num_cus * 8) / (uint32_t)run.blocks);
