@@ -627,3 +627,32 @@ def test_device_side_guess_equals_the_host_side_guess(pkg, orc, monkeypatch, env
                     a, b, c = got[("1", spoiled)], got[("0", spoiled)], got[("1 without the speculated recount", spoiled)]
                     assert a[:3] == b[:3] == c[:3], (n, graph, spoiled)       # sum, levels, counts: bit for bit
                     assert a[3:] == b[3:] == c[3:], (n, graph, spoiled, a, b)  # ... and the same decisions on the way
+
+
+def test_analyze_hostile_inputs_through_the_single_wait_step(pkg, orc):
+    """papr_hip_analyze without peers (estimate, device-side guess, sweep, device-side table, recount: one wait) on
+    inputs that break its assumptions one at a time — NaN and Inf in the data, all-zero and denormal-power streams
+    (no band form), an amplitude whose powers overflow float, a peak that makes the table longer than the device
+    speculates (> 1024 levels) — against the oracle, both tables."""
+    n = 600011
+    rng = np.random.default_rng(2024)
+    base = rng.standard_normal(2 * n).astype(np.float32)
+    cases = {}
+    x = base.copy(); x[2 * 123457] = np.nan; cases["nan"] = x
+    x = base.copy(); x[2 * 77 + 1] = -np.nan; x[2 * 500000] = np.inf; cases["nan and inf"] = x
+    x = base.copy(); x[2 * 400001 + 1] = -np.inf; cases["inf"] = x
+    cases["zeros"] = np.zeros(2 * n, np.float32)
+    cases["denormal powers"] = (base * np.float32(1e-21)).astype(np.float32)
+    cases["overflowing powers"] = (base * np.float32(3e19)).astype(np.float32)
+    x = (base * np.float32(1e-3)).astype(np.float32); x[2 * (n - 5)] = np.float32(3e5); cases["170 dB peak"] = x   # -g: > 1024 levels
+    # (the peak near the end: a sequential double sum that met it early would drop the low bits of everything after it)
+    with pkg.PaprHip(0) as g:
+        for name, iq in cases.items():
+            g.upload(iq)
+            for graph in (False, True):
+                ref = orc.run_mem(iq, graph)
+                res, table, counts = g.analyze(None, graph)
+                check_stats(res.total, ref)
+                assert res.nlevels == table.size == ref["level"].size, (name, graph)
+                # (the tree sum may differ from the reference's sequential sum in the last places: count against OUR table)
+                assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table)), (name, graph)
