@@ -25,10 +25,39 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
     papr_stats local;
     int rc;
     bool swept_path = false;
+    // exact-sum mode: the shards' programs are exchanged (if there are peers) and replayed as soon as this shard's is
+    // complete — inside whichever call is about to wait for the stream while the GPU still has work queued behind the
+    // program (papr_hip_ctx::overlap_work): the single-wait step's final wait, or papr_hip_ccdf_exact's
+    double seq = 0.0;
+    int crc = PAPR_OK;
+    bool replayed = false;
+    auto replay = [&](const void *prog, size_t nbytes, bool have) {  // exchange (if any) + the chained replay
+        if (x) {
+            // a shard that could not build its program sends an empty one: the chain then fails on EVERY rank alike
+            static const unsigned char none[8] = {0};
+            crc = papr_exchange_exact_sum(x, have ? prog : none, have ? nbytes : 0, &seq);
+        } else if (have) {
+            const void *progs[1] = {prog};
+            const size_t sizes[1] = {nbytes};
+            crc = papr_exact_chain(progs, sizes, 1, &seq);
+        }
+    };
+    auto replay_when_ready = [&] {
+        if (*ctx->h_redo_count > kCapRedo)
+            return;  // too many tiles to rebuild: the program is not final yet
+        const size_t nbytes = swept_program_bytes(ctx);
+        if (!nbytes)
+            return;  // the device-side gather overflowed its lists: assembled by the host afterwards
+        replay(ctx->h_program, nbytes, true);
+        replayed = true;
+    };
     bool fused = false;
     if (!(flags & PAPR_ANALYZE_TWO_PASS) && papr_exchange_is_identity(x)) {
+        if (ctx->exact)
+            ctx->overlap_work = replay_when_ready;
         // no peers: estimate, guess (on the device) and sweep in one sequence of launches, one wait (papr_sweep_rt.cpp)
         rc = stats_sweep_fused(ctx, graph, graph ? 48.0 : 60.0, (flags & PAPR_ANALYZE_SPOIL_GUESS) ? 1.03f : 1.0f, &local, &fused);
+        ctx->overlap_work = nullptr;
         if (rc)
             return rc;
         swept_path = fused;
@@ -82,31 +111,10 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
     if (ctx->exact && std::isfinite(total.sum)) {
         const void *program = nullptr;
         size_t bytes = 0;
-        double seq = 0.0;
-        int crc = PAPR_OK;
-        auto replay = [&](const void *prog, size_t nbytes, bool have) {  // exchange (if any) + the chained replay
-            if (x) {
-                // a shard that could not build its program sends an empty one: the chain then fails on EVERY rank alike
-                static const unsigned char none[8] = {0};
-                crc = papr_exchange_exact_sum(x, have ? prog : none, have ? nbytes : 0, &seq);
-            } else if (have) {
-                const void *progs[1] = {prog};
-                const size_t sizes[1] = {nbytes};
-                crc = papr_exact_chain(progs, sizes, 1, &seq);
-            }
-        };
         // One-read form: the program is complete before the stash recount has run, so its replay (0.07 ms of dependent
-        // additions for a 10 GiB shard) is done inside that window instead of behind it (papr_hip_ctx::overlap_work).
-        bool replayed = false;
-        ctx->overlap_work = [&] {
-            if (*ctx->h_redo_count > kCapRedo)
-                return;  // too many tiles to rebuild: the program is not final yet
-            const size_t nbytes = swept_program_bytes(ctx);
-            if (!nbytes)
-                return;  // the device-side gather overflowed its lists: assembled by the host afterwards
-            replay(ctx->h_program, nbytes, true);
-            replayed = true;
-        };
+        // additions for a 10 GiB shard) is done inside that window instead of behind it
+        if (!replayed)
+            ctx->overlap_work = replay_when_ready;
         const int xrc = papr_hip_ccdf_exact(ctx, levels, L, counts_above, before, total.n, &program, &bytes);
         ctx->overlap_work = nullptr;
         counted = xrc == PAPR_OK;

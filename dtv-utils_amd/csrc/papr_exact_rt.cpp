@@ -475,7 +475,9 @@ static int papr_hip_exact_program_impl(papr_hip_ctx *ctx, double before, uint64_
         return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (ctx->exact_swept) {
-        rc = run_exact_swept(ctx, before, n_total);
+        const bool launched = ctx->exact_program_launched && before == 0.0;  // (stats_sweep_fused did it, for before = 0)
+        ctx->exact_program_launched = false;
+        rc = launched ? PAPR_OK : run_exact_swept(ctx, before, n_total);
         if (rc)
             return rc;
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -514,7 +516,9 @@ static int papr_hip_ccdf_exact_impl(papr_hip_ctx *ctx, const float *levels, int 
     if (swept_form) {
         // one-read form: the sweep already holds what both results need (papr_hip_stats_sweep, or a one-sweep ingest,
         // in exact-sum mode)
-        rc = run_exact_swept(ctx, before, n_total);
+        const bool launched = ctx->exact_program_launched && before == 0.0;  // (stats_sweep_fused did it, for before = 0)
+        ctx->exact_program_launched = false;
+        rc = launched ? PAPR_OK : run_exact_swept(ctx, before, n_total);
         if (rc)
             return rc;
         if (!ctx->resident && *ctx->h_redo_count > kCapRedo) {

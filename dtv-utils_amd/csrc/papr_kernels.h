@@ -199,6 +199,7 @@ struct papr_sweep2_params {
     uint32_t tail_samples;
     const uint32_t *table;        // compact LUT incl. the two sentinel cells
     papr_ccdf_params P;           // shift, cell_lo, ncells, nkeys (= edges), table_words, copies
+    const papr_ccdf_params *Pdev; // null, or the same in device memory (papr_guess_bands_kernel's output; overrides P)
     unsigned long long *ghist;    // nkeys + 1 bins
     float *stash;                 // one segment of seg_cap floats per workgroup
     unsigned long long *seg_slots;// per workgroup: floats used in its stash segment (incl. padding; multiple of 4)

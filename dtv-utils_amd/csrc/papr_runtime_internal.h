@@ -187,6 +187,7 @@ struct papr_hip_ctx {
     // that is about to wait for the stream (run_overlap_work), then cleared
     hipEvent_t ev_program = nullptr;
     bool program_pending = false;        // ev_program was recorded for the current step
+    bool exact_program_launched = false; // stats_sweep_fused already ran run_exact_swept for the current sweep (before = 0)
     std::function<void()> overlap_work;
     size_t stage_bytes = 0;
     papr_rt::ReaderPool *pool = nullptr;
@@ -370,6 +371,7 @@ int ensure_exact_buffers(papr_hip_ctx *ctx);
 extern "C" bool papr_exchange_is_identity(const papr_exchange *x);  // papr_exchange.cpp (not part of the ABI)
 namespace papr_rt {
 int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, papr_stats *out, bool *done);
+int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total);
 void run_overlap_work(papr_hip_ctx *ctx);  // (see papr_hip_ctx::overlap_work)
 int launch_stats_range(papr_hip_ctx *ctx, const float *data, uint64_t n, uint64_t base_index, size_t slot,
                        int *nrecords);

@@ -70,6 +70,31 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// the table's geometry: the kernel argument, or — when a kernel on the same stream has just built the table — what that
+// kernel left in device memory; either way in scalar registers (every lane reads the same words)
+__device__ __forceinline__ papr_ccdf_params uniform_params(const papr_ccdf_params *dev, const papr_ccdf_params &arg)
+{
+    static_assert(sizeof(papr_ccdf_params) == 9 * sizeof(uint32_t), "nine words");
+    papr_ccdf_params P = arg;
+    if (dev) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(dev);
+        uint32_t w[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            w[k] = __builtin_amdgcn_readfirstlane(q[k]);
+        P.shift = w[0];
+        P.cell_lo = w[1];
+        P.ncells = w[2];
+        P.nkeys = w[3];
+        P.above_lo = w[4];
+        P.above_count = w[5];
+        P.table_words = w[6];
+        P.copies = w[7];
+        P.search_step = w[8];
+    }
+    return P;
+}
+
 __device__ __forceinline__ void sweep_give_up(uint32_t *tab, uint32_t table_words, uint32_t neutral_x,
                                               unsigned long long *seg_fill, uint64_t seg_cap,
                                               unsigned long long *gave_up)
@@ -806,7 +831,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
 {
     // the table's geometry: an argument, or — when papr_guess_bands_kernel built the table just before this launch,
     // without the host in between — read from where that kernel left it (wave-uniform loads: scalar registers)
-    const papr_ccdf_params P = Pdev ? *Pdev : Parg;
+    const papr_ccdf_params P = uniform_params(Pdev, Parg);
     constexpr uint64_t TILE_F4 = (uint64_t)BLOCK * U;
     constexpr uint32_t SLICE = papr_sweep_slice_floats(U);
     __shared__ unsigned long long seg_fill, seg_real_sh;
@@ -1461,7 +1486,7 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
     __shared__ unsigned long long seg_fill, seg_real_sh;
     __shared__ uint32_t ring_head[WAVES];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const papr_ccdf_params &P = p.P;
+    const papr_ccdf_params P = uniform_params(p.Pdev, p.P);
     const uint32_t nbins = P.nkeys + 1;
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
     uint32_t *hist = tab + P.table_words;                                         // table_words is a multiple of 4
@@ -1688,7 +1713,7 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_ccdf_power_kernel(const float
                                                                       unsigned long long *__restrict__ ghist,
                                                                       const papr_ccdf_params *__restrict__ Pdev)
 {
-    const papr_ccdf_params P = Pdev ? *Pdev : Parg;  // (the table may have been planned on the device: papr_true_table_kernel)
+    const papr_ccdf_params P = uniform_params(Pdev, Parg);  // (the table may have been planned on the device: papr_true_table_kernel)
     if (P.nkeys == 0)
         return;  // (... which found nothing worth recounting)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -311,16 +311,21 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
     return PAPR_OK;
 }
 
-// The default step's first half as ONE uninterrupted sequence of launches — estimate kernel, papr_guess_bands_kernel
-// (the host half of the speculation, on the device), histogram memset, sweep kernel, finalize — and one wait, instead of
-// estimate / wait / host guess + LUT + upload / sweep / wait.  For a shard without peers (the estimate crosses no
-// exchange), resident, in tree-sum mode, with the default kernel choice; anything else: *done stays false and the
-// caller takes the host path.  The TRUE level table is the host's (papr_levels) as before; only the guess moved.
+// A whole step's GPU work as ONE uninterrupted sequence of launches and one wait, for a shard without peers (nothing
+// crosses an exchange), resident, with the default kernel choice — instead of estimate / wait / host guess + LUT +
+// upload / sweep / wait / host table + LUT + upload / recount / wait:
+//   estimate kernel -> papr_guess_bands_kernel (the host half of the speculation, on the device) -> [exact-sum mode:
+//   binade speculation] -> sweep kernel (its table geometry read from device memory) -> finalize -> [exact-sum mode:
+//   classification, redo, groups, program] -> papr_true_table_kernel (the reference's level table with the device's
+//   libm: a speculation the host checks bit for bit) -> stash recount on that table.
+// Anything else: *done stays false and the caller takes the host path.  The TRUE level table is the host's
+// (papr_levels) as before; what moved to the device are guesses.
 int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, papr_stats *out, bool *done)
 {
     *done = false;
-    if (!ctx->loaded || !ctx->resident || ctx->exact || ctx->have_file_stats || ctx->tune.sweep_variant > 0 ||
-        ctx->tune.sweep_map > 0 || !env_int("PAPR_FUSED_GUESS", 1))
+    const bool exact = ctx->exact;
+    if (!ctx->loaded || !ctx->resident || ctx->have_file_stats || ctx->tune.sweep_variant > 0 || ctx->tune.sweep_map > 0 ||
+        ctx->tune.sweep_blocks > 0 || !env_int(exact ? "PAPR_FUSED_EXACT" : "PAPR_FUSED_GUESS", 1))
         return PAPR_OK;
     const uint64_t ntiles_est = ctx->n / PAPR_ESTIMATE_TILE_SAMPLES;
     const uint32_t nl = graph ? (uint32_t)(max_db * 10.0) + 1u : (uint32_t)max_db + 1u;
@@ -328,20 +333,42 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
         return PAPR_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     papr_hip_sweep_info &info = ctx->sweep_info;
-    // ---- geometry: the default papr_sweep_kernel<1024, 4> with its one-edge-per-cell table, built on the device ----
+    // ---- geometry: the default kernel of the mode; its table is what the device builds ----
     SweepRun run;
-    run.variant = kSweepVariant;
-    run.lut2 = PAPR_SWEEP_VARIANT_IS_LUT2(run.variant);
     int vblock = 0;
-    if (papr_sweep_geometry(run.variant, &vblock, &run.tile, &run.stash_lds) != 0)
-        return PAPR_OK;
+    if (exact) {
+        int v2_exact = 0;
+        run.variant = kSweepExactVariant;
+        if (papr_sweep2_geometry(run.variant, &vblock, &run.tile, &run.stash_lds, &v2_exact) != 0 || !v2_exact)
+            return PAPR_OK;
+        run.v2 = run.lut2 = run.exact = true;
+        run.tile = PAPR_EXACT_TILE_SAMPLES;  // the launch covers whole 2048-sample tiles (two segments each)
+    } else {
+        run.variant = kSweepVariant;
+        run.lut2 = PAPR_SWEEP_VARIANT_IS_LUT2(run.variant);
+        if (papr_sweep_geometry(run.variant, &vblock, &run.tile, &run.stash_lds) != 0)
+            return PAPR_OK;
+    }
     run.threads = vblock;
-    if (ctx->n / run.tile == 0)
+    const uint64_t ntiles = ctx->n / run.tile;
+    if (ntiles == 0)
         return PAPR_OK;
-    run.blocks = pick_blocks(ctx, SWEEP, ctx->n / run.tile);
+    const int waves = vblock / 64;
+    if (exact)
+        run.blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus, (2 * ntiles + waves - 1) / waves));
+    else
+        run.blocks = pick_blocks(ctx, SWEEP, ntiles);
     constexpr uint32_t kBinsMax = 2 * PAPR_GUESS_MAX_BANDS + 2;
-    constexpr uint32_t kTableWords = 48 * 1024 / 4 + 8;
     constexpr uint32_t kCopies = 4;
+    const size_t lds_cap = (size_t)papr_ccdf_max_dynamic_lds();
+    // LDS for table + histogram copies: what the launch is given, and what the device-side plan has to fit into
+    const size_t table_lds = exact ? (lds_cap - 2048 > run.stash_lds ? lds_cap - 2048 - run.stash_lds : 0)
+                                   : (size_t)(48 * 1024 + 32) + (((size_t)kCopies * kBinsMax + 3) & ~(size_t)3) * 4;
+    if (table_lds < 16 * 1024 || table_lds + run.stash_lds > lds_cap)
+        return PAPR_OK;
+    const uint32_t table_cap_words = exact ? (uint32_t)(table_lds / 4) : 48 * 1024 / 4 + 8;
+    const uint32_t soft_lds = exact ? (uint32_t)table_lds
+                                    : (uint32_t)std::max<long long>(0, (long long)vblock * 80 - (long long)run.stash_lds);
     run.seg_off = kBinsMax;
     // ---- estimate geometry (as papr_hip_estimate) ----
     uint64_t ratio = ctx->tune.estimate_ratio > 0 ? (uint64_t)ctx->tune.estimate_ratio : (uint64_t)kEstimateRatio;
@@ -386,40 +413,83 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
         }
         ctx->stash_cap = want_stash;
     }
-    rc = ensure_table(ctx, kTableWords);
+    rc = ensure_table(ctx, std::max<uint32_t>(table_cap_words, 48 * 1024 / 4 + 8));
     if (rc)
         return rc;
-    const size_t lds_bytes = (size_t)kTableWords * 4 + (((size_t)kCopies * kBinsMax + 3) & ~(size_t)3) * 4 + run.stash_lds;
-    if (lds_bytes > (size_t)papr_ccdf_max_dynamic_lds())
-        return PAPR_OK;
+    double *group_sums = nullptr;
+    if (exact) {
+        rc = ensure_exact_buffers(ctx);
+        if (rc)
+            return rc;
+        if (ctx->est_groups_cap < ngroups) {
+            if (ctx->d_est_groups) HIPCHK(ctx, hipFree(ctx->d_est_groups));
+            ctx->d_est_groups = nullptr;
+            ctx->est_groups_cap = 0;
+            const uint64_t cap = std::max<uint64_t>(ngroups, 4096);
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_est_groups, cap * 5 * sizeof(double)));  // 4 wave sums + 1 prefix per group
+            ctx->est_groups_cap = cap;
+        }
+        group_sums = ctx->d_est_groups;
+    }
     info.swept = info.resolved = 0;
     info.stash_samples = 0;
     ctx->sweep_valid = false;
     ctx->exact_swept = false;
     ctx->est_groups_valid = false;
+    ctx->exact_program_launched = false;
     // ---- the launches ----
     time_begin(ctx, 4, ngroups * PAPR_ESTIMATE_TILE_SAMPLES * 8);
-    papr_launch_estimate(ctx->stream, est_blocks, ctx->d_iq, ngroups, (uint32_t)ratio, est_partials, nullptr, ctx->d_est_sq);
+    papr_launch_estimate(ctx->stream, est_blocks, ctx->d_iq, ngroups, (uint32_t)ratio, est_partials, group_sums, ctx->d_est_sq);
     time_end(ctx);
     HIPCHK(ctx, hipGetLastError());
     const int band_override = ctx->tune.sweep_band_log2 > 0 ? ctx->tune.sweep_band_log2 : 0;
     papr_launch_guess_bands(ctx->stream, est_partials, ctx->d_est_sq, (uint32_t)est_blocks, ngroups,
                             ngroups * PAPR_ESTIMATE_TILE_SAMPLES, ctx->n, (uint32_t)ratio, graph, (float)max_db, spoil,
-                            band_override, kCopies, run.lut2 ? 1 : 0,
-                            (uint32_t)std::max<long long>(0, (long long)vblock * 80 - (long long)run.stash_lds), ctx->d_table,
-                            kTableWords, ctx->d_guess, ctx->h_guess_dev, ctx->d_sweep_hist,
+                            band_override, kCopies, run.lut2 ? 1 : 0, soft_lds, ctx->d_table, table_cap_words, ctx->d_guess,
+                            ctx->h_guess_dev, ctx->d_sweep_hist,
                             kBinsMax + 2u * (uint32_t)run.blocks + 1u);  // (also clears the sweep's bins and segment counters)
     HIPCHK(ctx, hipGetLastError());
-    const uint64_t ntiles = ctx->n / run.tile;
     const uint32_t tail = (uint32_t)(ctx->n - ntiles * run.tile);
-    const int map = effective_map(ctx, SWEEP, run.blocks);
     papr_ccdf_params none{};
-    time_begin(ctx, 3, ctx->n * 8);
-    papr_launch_sweep(ctx->stream, run.variant, run.blocks, lds_bytes, ctx->d_iq, ntiles, ctx->base, map, ctx->d_partials,
-                      ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->d_table, none, ctx->d_sweep_hist, ctx->d_stash,
-                      ctx->d_sweep_hist + kBinsMax, run.seg_cap, ctx->d_sweep_hist + kBinsMax + 2 * run.blocks,
-                      ctx->d_sweep_hist + kBinsMax + run.blocks, &ctx->d_guess->P);
-    time_end(ctx);
+    if (exact) {
+        // every tile's running-sum binade, speculated from the estimate's per-group sums (nothing in front of this shard)
+        ctx->est_ngroups = ngroups;
+        ctx->est_ratio = ratio;
+        ctx->est_groups_valid = true;
+        papr_launch_exact_spec(ctx->stream, ctx->d_est_groups, ngroups, (uint32_t)ratio, (double)ratio, 0.0,
+                               ctx->d_est_groups + 4 * ctx->est_groups_cap, ctx->n / PAPR_EXACT_TILE_SAMPLES, ctx->d_tile_E_spec);
+        HIPCHK(ctx, hipGetLastError());
+        papr_sweep2_params p{};
+        p.data = ctx->d_iq;
+        p.nsegs = 2 * ntiles;
+        p.base_index = ctx->base;
+        p.out = ctx->d_partials;
+        p.tail = ctx->d_iq + 2 * (ctx->n - tail);
+        p.tail_samples = tail;
+        p.table = ctx->d_table;
+        p.P = none;
+        p.Pdev = &ctx->d_guess->P;
+        p.ghist = ctx->d_sweep_hist;
+        p.stash = ctx->d_stash;
+        p.seg_slots = ctx->d_sweep_hist + kBinsMax;
+        p.seg_real = ctx->d_sweep_hist + kBinsMax + run.blocks;
+        p.gave_up = ctx->d_sweep_hist + kBinsMax + 2 * run.blocks;
+        p.seg_cap = run.seg_cap;
+        p.tile_E_spec = ctx->d_tile_E_spec;
+        p.seg_D = ctx->d_seg_D;
+        p.seg_offset = 0;
+        time_begin(ctx, 3, ctx->n * 8);
+        papr_launch_sweep2(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, p);
+        time_end(ctx);
+    } else {
+        const int map = effective_map(ctx, SWEEP, run.blocks);
+        time_begin(ctx, 3, ctx->n * 8);
+        papr_launch_sweep(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, ctx->d_iq, ntiles, ctx->base, map,
+                          ctx->d_partials, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->d_table, none, ctx->d_sweep_hist,
+                          ctx->d_stash, ctx->d_sweep_hist + kBinsMax, run.seg_cap, ctx->d_sweep_hist + kBinsMax + 2 * run.blocks,
+                          ctx->d_sweep_hist + kBinsMax + run.blocks, &ctx->d_guess->P);
+        time_end(ctx);
+    }
     HIPCHK(ctx, hipGetLastError());
     rc = sweep_fetch(ctx, run);
     if (rc)
@@ -428,21 +498,28 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     papr_launch_stats_finalize(ctx->stream, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->base + ctx->n - tail, ctx->d_partials,
                                (uint32_t)run.blocks, ctx->h_result_dev);
     HIPCHK(ctx, hipGetLastError());
-    // ... and, speculatively, what follows from it: the reference's level table with the device's libm, the recount LUT
-    // for it, and the recount of the stash — so that the step's second half needs no launch + wait round trip either
-    // (resolve_from_sweep takes the histogram if the host's own table turns out to be this one, bit for bit)
+    if (exact) {
+        // ... the sum program from the pairs the sweep built (true prefix, the refuted tiles rebuilt, groups, gather) ...
+        rc = run_exact_swept(ctx, 0.0, ctx->n);
+        if (rc)
+            return rc;
+        ctx->exact_program_launched = true;
+    }
+    // ... and, speculatively, what follows from the record: the reference's level table with the device's libm, the
+    // recount LUT for it, and the recount of the stash — so that the step's second half needs no launch + wait round
+    // trip either (resolve_from_sweep takes the histogram if the host's own table turns out to be this one, bit for bit)
     constexpr uint32_t kTrueCopies = 4;
     constexpr uint32_t true_soft = 20 * 1024;  // LDS the recount is launched with (as the host path: table + histogram copies)
     ctx->h_true->ok = 0;
-    papr_launch_true_table(ctx->stream, ctx->h_result_dev, ctx->n, graph, kTrueCopies, true_soft, ctx->d_table, kTableWords,
-                           ctx->d_true, ctx->h_true_dev, ctx->d_hist, PAPR_TRUE_MAX_LEVELS + 1,  // (also clears the recount's bins)
+    papr_launch_true_table(ctx->stream, ctx->h_result_dev, ctx->n, graph, kTrueCopies, true_soft, ctx->d_table,
+                           std::max<uint32_t>(table_cap_words, 48 * 1024 / 4 + 8), ctx->d_true, ctx->h_true_dev, ctx->d_hist,
+                           PAPR_TRUE_MAX_LEVELS + 1,  // (also clears the recount's bins)
                            ctx->d_sweep_hist + kBinsMax + 2 * run.blocks);
     HIPCHK(ctx, hipGetLastError());
     {
         const uint32_t split = std::max<uint32_t>(1, (uint32_t)(ctx->num_cus * 8) / (uint32_t)run.blocks);
-        const size_t recount_lds = true_soft;
         time_begin(ctx, 4, 0);
-        papr_launch_ccdf_power(ctx->stream, (int)((uint32_t)run.blocks * split), true, recount_lds, ctx->d_stash,
+        papr_launch_ccdf_power(ctx->stream, (int)((uint32_t)run.blocks * split), true, true_soft, ctx->d_stash,
                                ctx->d_sweep_hist + kBinsMax, run.seg_cap, (uint32_t)run.blocks, split, ctx->d_table, none,
                                ctx->d_hist, &ctx->d_true->P);
         time_end(ctx);
@@ -450,7 +527,9 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(PAPR_TRUE_MAX_LEVELS + 1) * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, ctx->stream));
+    run_overlap_work(ctx);  // (exact-sum mode: the program's replay, while the recount runs)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->program_pending = false;
     partial_to_stats(*ctx->h_result, ctx->n, out);
     out->flags |= ctx->shard_flags;
     *done = true;
@@ -458,21 +537,31 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     const papr_guess_out &g = *ctx->h_guess;
     info.estimate_samples = ngroups * PAPR_ESTIMATE_TILE_SAMPLES;
     info.band_log2 = (int)g.band_log2;
-    if (std::isnan(out->sum)) {  // NaN in the data: the sweep's integer-max trackers do not apply (papr_sweep.hip)
+    const bool usable = !std::isnan(out->sum) && g.ok && g.nbands != 0 && g.nbands <= PAPR_GUESS_MAX_BANDS;
+    if (!usable) {
+        // NaN in the data (the sweep's integer-max trackers do not apply), or a guess without a band form (the sweep
+        // was a plain pass 1): the plain pass of the mode takes over (exact-sum mode: with its per-tile sums)
         info.reason = PAPR_SWEEP_NO_BANDS;
-        return papr_hip_stats(ctx, out);
-    }
-    if (!g.ok || g.nbands == 0 || g.nbands > PAPR_GUESS_MAX_BANDS) {
-        info.reason = PAPR_SWEEP_NO_BANDS;  // the guess had no band form: this was a plain pass 1 (its record stands)
-        return PAPR_OK;
+        ctx->exact_program_launched = false;
+        ctx->est_groups_valid = false;
+        if (exact || std::isnan(out->sum))
+            return papr_hip_stats(ctx, out);
+        return PAPR_OK;  // (tree-sum mode: the launch's pass-1 record stands)
     }
     run.gkeys.assign(g.gkeys, g.gkeys + g.nbands);
     run.half = 1u << g.band_log2;
     run.bands.P = g.P;
-    run.nbins = g.P.nkeys + 2;
+    run.nbins = g.P.nkeys + (run.v2 ? 1 : 2);
     rc = sweep_collect(ctx, run);
-    if (rc == PAPR_OK)
+    if (rc == PAPR_OK) {
         ctx->spec_recount_valid = ctx->h_true->ok != 0;  // (whether it is the RIGHT table is for resolve_from_sweep to say)
+        if (exact) {
+            ctx->exact_swept = true;  // d_seg_D holds every segment's sum and its pair (speculated, or rebuilt)
+            ctx->exact_valid = true;
+        }
+    } else {
+        ctx->exact_program_launched = false;
+    }
     return rc;
 }
 

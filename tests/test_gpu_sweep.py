@@ -599,8 +599,9 @@ def test_exact_sweep_variants_agree_with_the_reference(pkg, orc, variant):
             assert np.array_equal(table, ref["level"]) and np.array_equal(counts.astype(np.int64), ref["count"])
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["tree", "exact"])
 @pytest.mark.parametrize("envelope", ["gauss", "bursty", "constant"])
-def test_device_side_guess_equals_the_host_side_guess(pkg, orc, monkeypatch, envelope):
+def test_device_side_guess_equals_the_host_side_guess(pkg, orc, monkeypatch, envelope, exact):
     """papr_hip_analyze without peers builds the guessed bands on the device between the estimate and the sweep
     (papr_guess_bands_kernel: no host round trip) and runs the stash recount speculatively against the level table the
     device expects (papr_true_table_kernel; taken only if the host's libm table is that table bit for bit);
@@ -609,6 +610,7 @@ def test_device_side_guess_equals_the_host_side_guess(pkg, orc, monkeypatch, env
     tables."""
     for n in (2047, 300007, 20 * 1048576 + 333):
         with pkg.PaprHip(0) as g:
+            g.set_exact(exact)
             g.generate(pkg.SynthSpec.spike(n, seed=1000 + n % 97, envelope=envelope), 0, n)
             iq = g.download(0, n)
             for graph in (False, True):
@@ -616,11 +618,14 @@ def test_device_side_guess_equals_the_host_side_guess(pkg, orc, monkeypatch, env
                 got = {}
                 for fused in ("1", "0", "1 without the speculated recount"):
                     monkeypatch.setenv("PAPR_FUSED_GUESS", fused[0])
+                    monkeypatch.setenv("PAPR_FUSED_EXACT", fused[0])
                     monkeypatch.setenv("PAPR_SPEC_RECOUNT", "0" if len(fused) > 1 else "1")
                     for kw in (dict(), dict(spoil_guess=True)):
                         res, table, counts = g.analyze(None, graph, **kw)
                         check_stats(res.total, ref)
                         assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
+                        if exact:
+                            assert res.exact_sum == 1 and res.total.sum == ref["sum"] and np.array_equal(table, ref["level"])
                         got[(fused, bool(kw))] = (res.total.sum, res.nlevels, tuple(counts.tolist()), res.swept, res.resolved,
                                                   res.band_log2 if res.swept else None)
                 for spoiled in (False, True):
