@@ -73,7 +73,7 @@ int papr_hip_set_exact(papr_hip_ctx *ctx, int enabled)
     if ((enabled != 0) != ctx->exact) {
         ctx->exact = enabled != 0;
         ctx->exact_valid = false;
-        ctx->exact_swept = ctx->est_groups_valid = false;
+        ctx->exact_swept = ctx->est_groups_valid = ctx->exact_program_launched = false;
         if (ctx->resident)
             ctx->have_file_stats = false;  // pass 1 is re-run over the resident shard in the other mode
     }
@@ -531,6 +531,7 @@ static int papr_hip_ccdf_exact_impl(papr_hip_ctx *ctx, const float *levels, int 
             papr_launch_exact_segsums_to_tilesums(ctx->stream, ctx->d_seg_D, ctx->n / PAPR_EXACT_TILE_SAMPLES, ctx->d_tile_sums);
             HIPCHK(ctx, hipGetLastError());
             ctx->exact_swept = false;
+            ctx->exact_program_launched = false;
             swept_form = false;
         }
     }

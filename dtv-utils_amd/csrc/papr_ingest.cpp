@@ -462,7 +462,7 @@ int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, u
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
     ctx->sweep_valid = false;
-    ctx->est_groups_valid = ctx->exact_swept = false;
+    ctx->est_groups_valid = ctx->exact_swept = ctx->exact_program_launched = false;
     ctx->shard_flags = (fs.odd && first_sample + nsamples == fs.nsamples && nsamples > 0) ? PAPR_FLAG_ODD_TAIL : 0;
 
     SweepRun run;

@@ -205,7 +205,7 @@ void release_shard(papr_hip_ctx *ctx)
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
     ctx->sweep_valid = false;
-    ctx->est_groups_valid = ctx->exact_swept = false;
+    ctx->est_groups_valid = ctx->exact_swept = ctx->exact_program_launched = false;
     ctx->shard_flags = 0;
     ctx->path.clear();
 }
@@ -705,7 +705,7 @@ int papr_hip_upload(papr_hip_ctx *ctx, const float *iq, uint64_t nsamples, uint6
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
     ctx->sweep_valid = false;
-    ctx->est_groups_valid = ctx->exact_swept = false;
+    ctx->est_groups_valid = ctx->exact_swept = ctx->exact_program_launched = false;
     ctx->shard_flags = 0;
     ctx->path.clear();
     return PAPR_OK;
@@ -733,7 +733,7 @@ int papr_hip_generate(papr_hip_ctx *ctx, const papr_synth_spec *spec, uint64_t f
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
     ctx->sweep_valid = false;
-    ctx->est_groups_valid = ctx->exact_swept = false;
+    ctx->est_groups_valid = ctx->exact_swept = ctx->exact_program_launched = false;
     ctx->shard_flags = 0;
     ctx->path.clear();
     return PAPR_OK;
@@ -767,6 +767,7 @@ int papr_hip_stats(papr_hip_ctx *ctx, papr_stats *out)
     }
     ctx->sweep_valid = false;  // a sweep only serves the papr_hip_ccdf calls that directly follow it
     ctx->exact_swept = false;
+    ctx->exact_program_launched = false;
     if (!ctx->resident)
         return fail(ctx, PAPR_E_STATE, "the shard is not resident and has no pass-1 result: reload it");
     HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -435,6 +435,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     info.stash_samples = 0;
     ctx->sweep_valid = false;
     ctx->exact_swept = false;
+    ctx->exact_program_launched = false;
     ctx->est_groups_valid = false;
     ctx->exact_program_launched = false;
     // ---- the launches ----
@@ -689,6 +690,7 @@ static int papr_hip_stats_sweep_impl(papr_hip_ctx *ctx, const float *guess_level
     if (!ctx->resident)
         return plain(PAPR_SWEEP_MODE);
     ctx->exact_swept = false;
+    ctx->exact_program_launched = false;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     SweepRun run;
     int reason = PAPR_SWEEP_OK;
