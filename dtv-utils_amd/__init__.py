@@ -384,7 +384,8 @@ class PaprHip:
                    sweep_blocks, pick(sweep_variant, None), pick(sweep_map, None), sweep_band_log2, estimate_ratio, 0)
         self._chk(self._L.papr_hip_set_tuning(self._ctx, C.byref(t)), "papr_hip_set_tuning")
 
-    def set_timing(self, enabled: bool):
+    def set_timing(self, enabled):
+        """False / 0 off, True / 1 every timed kernel, 2 only the kernels that read the shard (include/papr_hip.h)."""
         self._chk(self._L.papr_hip_set_timing(self._ctx, int(enabled)), "papr_hip_set_timing")
 
     def timing(self) -> Timing:

@@ -229,7 +229,7 @@ int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total)
     HIPCHK(ctx, hipMemsetAsync(ctx->d_redo + kCapRedo, 0, sizeof(uint32_t), ctx->stream));
     if (!ctx->resident)
         return run_exact_swept_streamed(ctx, before, delta, ntiles, ngroups, tail, program_dev);
-    time_begin(ctx, 2, 0);
+    time_begin(ctx, 5, 0);  // (helper kernels: timed like the estimate / recount kernels, reported with kind 2)
     papr_launch_exact_classify_swept(ctx->stream, ctx->d_seg_D, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E,
                                      ctx->d_tile_E_spec, ctx->d_redo, kCapRedo, ctx->d_redo + kCapRedo, nullptr, 0, nullptr,
                                      nullptr);
@@ -264,7 +264,7 @@ int run_exact_swept_streamed(papr_hip_ctx *ctx, double before, double delta, uin
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_raw_store, (size_t)kCapRaw * PAPR_EXACT_TILE_SAMPLES * 8));
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ambig + 2 * kCapRaw, 0, sizeof(uint32_t), ctx->stream));
-    time_begin(ctx, 2, 0);
+    time_begin(ctx, 5, 0);  // (helper kernels: timed like the estimate / recount kernels, reported with kind 2)
     papr_launch_exact_classify_swept(ctx->stream, ctx->d_seg_D, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E,
                                      ctx->d_tile_E_spec, ctx->d_redo, kCapRedo, ctx->d_redo + kCapRedo, ctx->d_ambig, kCapRaw,
                                      ctx->d_ambig + 2 * kCapRaw, ctx->d_ambig + kCapRaw);
@@ -325,7 +325,7 @@ int run_exact_swept_streamed(papr_hip_ctx *ctx, double before, double delta, uin
     if (nambig)
         HIPCHK(ctx, hipMemcpyAsync(ctx->d_raw_store, host.data() + (size_t)nredo * kTileBytes, (size_t)nambig * kTileBytes,
                                    hipMemcpyHostToDevice, ctx->stream));
-    time_begin(ctx, 2, 0);
+    time_begin(ctx, 5, 0);  // (helper kernels: timed like the estimate / recount kernels, reported with kind 2)
     if (nredo)
         papr_launch_exact_redo(ctx->stream, (int)std::min<uint32_t>((uint32_t)ctx->num_cus, (nredo + 1) / 2), ctx->d_redo_store,
                                ctx->d_tile_E, ctx->d_seg_D, ctx->d_redo, ctx->d_redo + kCapRedo, kCapRedo, 1);

@@ -116,7 +116,11 @@ void papr_launch_stats(hipStream_t st, int variant, int blocks, bool nt, const v
 void papr_launch_stats_tilesums(hipStream_t st, int blocks, const void *data, uint64_t ntiles, uint64_t base_index,
                                 int map, papr_partial *out, double *tile_sums, uint64_t tile_offset);
 void papr_launch_stats_finalize(hipStream_t st, const void *tail, uint32_t tail_samples, uint64_t tail_base_index,
-                                const papr_partial *partials, uint32_t npartials, papr_partial *result);
+                                const papr_partial *partials, uint32_t npartials, papr_partial *result,
+                                papr_partial *result_dev = nullptr /* a second copy of the record, in device memory */,
+                                const unsigned long long *copy_src = nullptr /* copy_words words copied to copy_dst ... */,
+                                unsigned long long *copy_dst = nullptr /* ... (mapped host memory) on the way */,
+                                uint32_t copy_words = 0);
 void papr_launch_first_nan(hipStream_t st, int blocks, const void *data, uint64_t nsamples, uint64_t base_index,
                            unsigned long long *key);
 void papr_launch_ccdf(hipStream_t st, int variant, int blocks, bool nt, bool lut, size_t lds_bytes, const void *data,
@@ -125,6 +129,14 @@ void papr_launch_ccdf(hipStream_t st, int variant, int blocks, bool nt, bool lut
 void papr_launch_generate(hipStream_t st, int blocks, void *out, uint64_t nsamples, uint64_t first_index,
                           const papr_synth_spec &spec);
 /* one-sweep mode (papr_sweep.hip) */
+/* Kernel timing without marker packets: the NEXT papr_launch_estimate / _sweep / _sweep2 / _ccdf_power call of this
+ * thread binds the two events to its dispatch (hipExtLaunchKernelGGL: both take the kernel's own start and end from its
+ * completion signal), once.  hipEventRecord in front of and behind a kernel costs a barrier packet each (~5 us of
+ * stream time per record on this chip, profiles/r02_step_timeline.txt). */
+struct papr_launch_timer {
+    hipEvent_t start, stop;
+};
+void papr_time_next_launch(const papr_launch_timer *t);
 void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t ngroups, uint32_t ratio,
                           papr_partial *out, double *group_sums /* may be null: 4 sampled sums per group */,
                           double *block_sq /* may be null: per workgroup, sum of squared piece sums */);
@@ -158,8 +170,9 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
                        unsigned long long *seg_counts, uint64_t seg_cap, unsigned long long *gave_up,
                        unsigned long long *seg_real /* per workgroup: powers stashed, without padding */,
                        const papr_ccdf_params *Pdev /* null, or the table geometry in device memory (overrides P) */);
-void papr_launch_ccdf_power(hipStream_t st, int blocks, bool lut, size_t lds_bytes, const float *stash,
-                            const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs, uint32_t split,
+/* (the geometry follows from the chip: 2 workgroups of 1024 threads per CU, segments split or shared to match) */
+void papr_launch_ccdf_power(hipStream_t st, int num_cus, bool lut, size_t lds_bytes, const float *stash,
+                            const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs,
                             const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist,
                             const papr_ccdf_params *Pdev /* null, or the table geometry in device memory (overrides P) */);
 /* papr_true_table_kernel: the reference's level table from the pass-1 record, with the device's libm, and the recount

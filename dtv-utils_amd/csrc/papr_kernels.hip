@@ -112,8 +112,16 @@ __global__ __launch_bounds__(BLOCK) void papr_stats_kernel(const float4 *__restr
 __global__ __launch_bounds__(PAPR_BLOCK) void papr_stats_finalize(const float2 *__restrict__ tail, uint32_t tail_samples,
                                                                    uint64_t tail_base_index,
                                                                    const papr_partial *__restrict__ partials,
-                                                                   uint32_t npartials, papr_partial *__restrict__ result)
+                                                                   uint32_t npartials, papr_partial *__restrict__ result,
+                                                                   papr_partial *__restrict__ result_dev,
+                                                                   const unsigned long long *__restrict__ copy_src,
+                                                                   unsigned long long *__restrict__ copy_dst,
+                                                                   uint32_t copy_words)
 {
+    // (single-wait step: the sweep's bins and segment counters go to mapped host memory from here — a D2H copy of
+    // their own would be one more packet pair in the stream)
+    for (uint32_t w = threadIdx.x; w < copy_words; w += PAPR_BLOCK)
+        copy_dst[w] = copy_src[w];
     LaneStats s;
     s.sum = 0.0;
 #pragma unroll
@@ -146,6 +154,8 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_stats_finalize(const float2 *
         }
         r.pad = 0;
         *result = r;
+        if (result_dev)
+            *result_dev = r;  // (for papr_true_table_kernel: `result` is host memory)
     }
 }
 
@@ -344,10 +354,12 @@ void papr_launch_stats_tilesums(hipStream_t st, int blocks, const void *data, ui
 }
 
 void papr_launch_stats_finalize(hipStream_t st, const void *tail, uint32_t tail_samples, uint64_t tail_base_index,
-                                const papr_partial *partials, uint32_t npartials, papr_partial *result)
+                                const papr_partial *partials, uint32_t npartials, papr_partial *result,
+                                papr_partial *result_dev, const unsigned long long *copy_src, unsigned long long *copy_dst,
+                                uint32_t copy_words)
 {
     hipLaunchKernelGGL(papr_stats_finalize, dim3(1), dim3(PAPR_BLOCK), 0, st, (const float2 *)tail, tail_samples,
-                       tail_base_index, partials, npartials, result);
+                       tail_base_index, partials, npartials, result, result_dev, copy_src, copy_dst, copy_words);
 }
 
 void papr_launch_first_nan(hipStream_t st, int blocks, const void *data, uint64_t nsamples, uint64_t base_index,

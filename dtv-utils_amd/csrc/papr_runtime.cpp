@@ -227,8 +227,21 @@ int ensure_owned_capacity(papr_hip_ctx *ctx, uint64_t nsamples)
     return PAPR_OK;
 }
 
+// PAPR_TIME_KINDS: bit mask of the launch kinds that are timed at all (experiment knob; default: all)
+static bool kind_timed(int kind)
+{
+    static const int mask = [] {
+        const char *e = getenv("PAPR_TIME_KINDS");
+        return e && *e ? atoi(e) : 0xFF;
+    }();
+    return (mask >> kind) & 1;
+}
+
 void time_begin(papr_hip_ctx *ctx, int kind, uint64_t bytes)
 {
+    ctx->time_skipped = !kind_timed(kind) || (kind >= 4 && !ctx->timing_aux);
+    if (ctx->time_skipped)
+        return;
     if (!ctx->timing || ctx->timed_used >= (size_t)kMaxTimed)
         return;
     if (ctx->timed_used == ctx->timed.size()) {
@@ -245,9 +258,61 @@ void time_begin(papr_hip_ctx *ctx, int kind, uint64_t bytes)
 
 void time_end(papr_hip_ctx *ctx)
 {
+    if (ctx->time_skipped)
+        return;
     if (!ctx->timing || ctx->timed_used >= ctx->timed.size() || ctx->timed_used >= (size_t)kMaxTimed)
         return;
     (void)hipEventRecord(ctx->timed[ctx->timed_used].b, ctx->stream);
+    ctx->timed_used++;
+}
+
+// The same bracket around exactly ONE kernel launch (estimate / sweep / recount wrappers of papr_sweep.hip): the two
+// events are bound to the dispatch itself, so no marker packet goes into the stream on either side of the kernel and
+// the elapsed time is the kernel's own.  PAPR_EXT_TIMING=0 keeps the event records.
+static bool ext_timing()
+{
+    static const bool on = [] {
+        const char *e = getenv("PAPR_EXT_TIMING");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+void time_begin_kernel(papr_hip_ctx *ctx, int kind, uint64_t bytes)
+{
+    if (!ext_timing()) {
+        time_begin(ctx, kind, bytes);
+        return;
+    }
+    ctx->time_skipped = !kind_timed(kind) || (kind >= 4 && !ctx->timing_aux);
+    if (ctx->time_skipped)
+        return;
+    if (!ctx->timing || ctx->timed_used >= (size_t)kMaxTimed)
+        return;
+    if (ctx->timed_used == ctx->timed.size()) {
+        TimedLaunch t{};
+        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess)
+            return;
+        ctx->timed.push_back(t);
+    }
+    TimedLaunch &t = ctx->timed[ctx->timed_used];
+    t.kind = kind;
+    t.bytes = bytes;
+    const papr_launch_timer timer{t.a, t.b};
+    papr_time_next_launch(&timer);
+}
+
+void time_end_kernel(papr_hip_ctx *ctx)
+{
+    if (!ext_timing()) {
+        time_end(ctx);
+        return;
+    }
+    papr_time_next_launch(nullptr);  // (nothing was launched in between: disarm)
+    if (ctx->time_skipped)
+        return;
+    if (!ctx->timing || ctx->timed_used >= ctx->timed.size() || ctx->timed_used >= (size_t)kMaxTimed)
+        return;
     ctx->timed_used++;
 }
 
@@ -578,6 +643,7 @@ void papr_hip_close(papr_hip_ctx *ctx)
     if (ctx->d_raw_store) (void)hipFree(ctx->d_raw_store);
     if (ctx->d_redo_store) (void)hipFree(ctx->d_redo_store);
     if (ctx->d_true) (void)hipFree(ctx->d_true);
+    if (ctx->d_result_copy) (void)hipFree(ctx->d_result_copy);
     if (ctx->h_true) (void)hipHostFree(ctx->h_true);
     if (ctx->d_guess) (void)hipFree(ctx->d_guess);
     if (ctx->h_guess) (void)hipHostFree(ctx->h_guess);
@@ -630,6 +696,7 @@ int papr_hip_set_timing(papr_hip_ctx *ctx, int enabled)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->timing = enabled != 0;
+    ctx->timing_aux = enabled == 1;
     ctx->timed_used = 0;
     return PAPR_OK;
 }
@@ -652,7 +719,7 @@ int papr_hip_get_timing(papr_hip_ctx *ctx, papr_hip_timing *out)
             out->aux_ms += ms;
             out->aux_launches++;
             out->aux_bytes += ctx->timed[k].bytes;
-        } else if (ctx->timed[k].kind == 2) {
+        } else if (ctx->timed[k].kind == 2 || ctx->timed[k].kind == 5) {
             out->exact_ms += ms;
             out->exact_launches++;
             out->exact_bytes += ctx->timed[k].bytes;

@@ -131,7 +131,8 @@ class ReaderPool {
 
 struct TimedLaunch {
     hipEvent_t a, b;
-    int kind;  // 0 stats, 1 ccdf, 2 exact-sum kernels, 3 one-sweep kernel, 4 estimate / stash recount
+    int kind;  // 0 stats, 1 ccdf, 2 exact-sum kernels, 3 one-sweep kernel, 4 estimate / stash recount, 5 exact-sum helpers
+               // (4 and 5: only at papr_hip_set_timing level 1)
     uint64_t bytes;
 };
 
@@ -226,6 +227,8 @@ struct papr_hip_ctx {
     uint32_t sweep_nsegs = 0, sweep_nbins = 0, sweep_seg_off = 0;
     papr_guess_out *d_guess = nullptr, *h_guess = nullptr, *h_guess_dev = nullptr;  // papr_guess_bands_kernel's output (device; mapped host)
     papr_true_out *d_true = nullptr, *h_true = nullptr, *h_true_dev = nullptr;     // papr_true_table_kernel's output
+    papr_partial *d_result_copy = nullptr;  // the finalize kernel's record once more, for papr_true_table_kernel
+    unsigned long long *h_sweep_hist_dev = nullptr;  // device address of h_sweep_hist
     bool spec_recount_valid = false;  // h_hist holds the stash recount for the table in h_true (stats_sweep_fused)
     bool sweep_overflow = false;
     papr_hip_sweep_info sweep_info{};
@@ -247,9 +250,10 @@ struct papr_hip_ctx {
 
     papr_hip_ingest_timing ingest{};
     papr_hip_tuning tune{};
-    bool timing = false;
+    bool timing = false, timing_aux = false;  // (timing_aux: also the small estimate / recount kernels, kind 4)
     std::vector<papr_rt::TimedLaunch> timed;
     size_t timed_used = 0;
+    bool time_skipped = false;  // the bracket that is open is not being timed
 };
 
 namespace papr_rt {
@@ -366,6 +370,8 @@ void release_shard(papr_hip_ctx *ctx);
 int ensure_owned_capacity(papr_hip_ctx *ctx, uint64_t nsamples);
 void time_begin(papr_hip_ctx *ctx, int kind, uint64_t bytes);
 void time_end(papr_hip_ctx *ctx);
+void time_begin_kernel(papr_hip_ctx *ctx, int kind, uint64_t bytes);  // around exactly one papr_sweep.hip launch
+void time_end_kernel(papr_hip_ctx *ctx);
 int ensure_exact_buffers(papr_hip_ctx *ctx);
 }  // namespace papr_rt
 extern "C" bool papr_exchange_is_identity(const papr_exchange *x);  // papr_exchange.cpp (not part of the ABI)

@@ -29,6 +29,7 @@
 // reservation across the 8 XCDs — measured: it doubled the kernel time of the 0.1 dB table.)
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "papr_kernels.h"
@@ -1703,15 +1704,18 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
 // =============================================================================
 // 4. pass 2 over the stash (float powers, not IQ)
 // =============================================================================
-// `split` workgroups per stash segment (= per workgroup of the sweep), segment lengths read from the device.
-template <bool LUT>
-__global__ __launch_bounds__(PAPR_BLOCK) void papr_ccdf_power_kernel(const float *__restrict__ stash,
-                                                                      const unsigned long long *__restrict__ seg_counts,
-                                                                      uint64_t seg_cap, uint32_t nsegs, uint32_t split,
-                                                                      const uint32_t *__restrict__ table,
-                                                                      papr_ccdf_params Parg,
-                                                                      unsigned long long *__restrict__ ghist,
-                                                                      const papr_ccdf_params *__restrict__ Pdev)
+// Whole-chip geometry rather than one workgroup per segment: 2 x 1024 threads per CU, every segment cut into `split`
+// parts, jobs taken round robin.  (2048 workgroups of 256 threads took 31 us for the default table's 28 MB: every one of
+// them stages the table and ends with one global atomic per non-empty bin, and 2048 atomics on the same 31 addresses
+// are ~20 us of serialised memory-side read-modify-writes.)  Four 16-byte loads per lane are in flight.
+template <bool LUT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void papr_ccdf_power_kernel(const float *__restrict__ stash,
+                                                                 const unsigned long long *__restrict__ seg_counts,
+                                                                 uint64_t seg_cap, uint32_t nsegs, uint32_t split,
+                                                                 const uint32_t *__restrict__ table,
+                                                                 papr_ccdf_params Parg,
+                                                                 unsigned long long *__restrict__ ghist,
+                                                                 const papr_ccdf_params *__restrict__ Pdev)
 {
     const papr_ccdf_params P = uniform_params(Pdev, Parg);  // (the table may have been planned on the device: papr_true_table_kernel)
     if (P.nkeys == 0)
@@ -1720,9 +1724,9 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_ccdf_power_kernel(const float
     const uint32_t nbins = P.nkeys + 1;
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
     uint32_t *hist = tab + P.table_words;
-    for (uint32_t k = threadIdx.x; k < P.table_words; k += PAPR_BLOCK)
+    for (uint32_t k = threadIdx.x; k < P.table_words; k += BLOCK)
         tab[k] = table[k];
-    for (uint32_t k = threadIdx.x; k < P.copies * nbins; k += PAPR_BLOCK)
+    for (uint32_t k = threadIdx.x; k < P.copies * nbins; k += BLOCK)
         hist[k] = 0;
     __syncthreads();
     const uint2 *lut = reinterpret_cast<const uint2 *>(tab);
@@ -1733,23 +1737,59 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_ccdf_power_kernel(const float
         if (k)
             atomicAdd(&my[k], 1u);
     };
+    constexpr int UNR = 4;
     for (uint32_t job = blockIdx.x; job < nsegs * split; job += gridDim.x) {
         const uint32_t seg = job / split, part = job % split;
         const float *pw = stash + (uint64_t)seg * seg_cap;  // seg_cap is a multiple of 4: 16-byte aligned
         const uint64_t n = min((uint64_t)seg_counts[seg], seg_cap);
         const uint64_t nquads = n / 4;
         const float4 *q = reinterpret_cast<const float4 *>(pw);
-        for (uint64_t i = (uint64_t)part * PAPR_BLOCK + threadIdx.x; i < nquads; i += (uint64_t)split * PAPR_BLOCK) {
-            const float4 x = load16<true>(q + i);
-            count(x.x);
-            count(x.y);
-            count(x.z);
-            count(x.w);
+        const uint64_t step = (uint64_t)split * BLOCK;
+        for (uint64_t i = (uint64_t)part * BLOCK + threadIdx.x; i < nquads; i += UNR * step) {
+            float4 x[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++)
+                if (i + u * step < nquads)
+                    x[u] = load16<true>(q + i + u * step);
+#pragma unroll
+            for (int u = 0; u < UNR; u++)
+                if (i + u * step < nquads) {
+                    count(x[u].x);
+                    count(x[u].y);
+                    count(x[u].z);
+                    count(x[u].w);
+                }
         }
         if (part == 0 && threadIdx.x < (uint32_t)(n - 4 * nquads))
             count(pw[4 * nquads + threadIdx.x]);
     }
-    hist_flush<PAPR_BLOCK>(hist, nbins, P.copies, ghist);
+    hist_flush<BLOCK>(hist, nbins, P.copies, ghist);
+    // (handing the histogram to the host from here — a ticket per workgroup, the last one copies — was measured: the
+    // device-scope fence every workgroup needs in front of its ticket makes this kernel take 139 us instead of 14;
+    // profiles/r02_step_timeline.txt.  The D2H copy behind the kernel stays.)
+}
+
+// ---- timed launches (papr_time_next_launch) ---------------------------------------------
+static thread_local papr_launch_timer tl_timer;
+static thread_local bool tl_timer_armed = false;
+
+void papr_time_next_launch(const papr_launch_timer *t)
+{
+    tl_timer_armed = t != nullptr;
+    if (t)
+        tl_timer = *t;
+}
+
+// hipLaunchKernelGGL, or — when a timer is armed — the same dispatch with the timer's events bound to it
+template <typename... Args, typename F = void (*)(Args...)>
+static inline void launch_maybe_timed(F kernel, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, Args... args)
+{
+    if (tl_timer_armed) {
+        tl_timer_armed = false;
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds_bytes, st, tl_timer.start, tl_timer.stop, 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds_bytes, st, args...);
+    }
 }
 
 // ---- launch wrappers -------------------------------------------------------------------
@@ -1757,7 +1797,7 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_ccdf_power_kernel(const float
 void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t ngroups, uint32_t ratio,
                           papr_partial *out, double *group_sums, double *block_sq)
 {
-    hipLaunchKernelGGL(papr_estimate_kernel, dim3(blocks), dim3(PAPR_BLOCK), 0, st, (const float4 *)data, ngroups, ratio,
+    launch_maybe_timed(papr_estimate_kernel, dim3(blocks), dim3(PAPR_BLOCK), 0, st, (const float4 *)data, ngroups, ratio,
                        out, group_sums, block_sq);
 }
 
@@ -1879,7 +1919,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     switch (variant) {
 #define X(V, PW, NB, LU, D)                                                                                          \
     case V:                                                                                                           \
-        hipLaunchKernelGGL((papr_sweep_split_kernel<PW, NB, LU, D>), dim3(blocks), dim3((PW + PW * NB) * kWave),      \
+        launch_maybe_timed((papr_sweep_split_kernel<PW, NB, LU, D>), dim3(blocks), dim3((PW + PW * NB) * kWave),      \
                            lds_bytes, st, (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail,   \
                            tail_samples, table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real);                       \
         break;
@@ -1887,7 +1927,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
 #undef X
 #define X(V, B, U, PP, L2, SM)                                                                                       \
     case V:                                                                                                           \
-        hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP, 0, L2, SM>), dim3(blocks), dim3(B), lds_bytes, st,    \
+        launch_maybe_timed((papr_sweep_kernel<B, U, true, PP, 0, L2, SM>), dim3(blocks), dim3(B), lds_bytes, st,    \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
                            table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                           \
         break;
@@ -1895,7 +1935,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
 #undef X
 #define X(V, A)                                                                                                      \
     case V:                                                                                                           \
-        hipLaunchKernelGGL((papr_sweep_kernel<1024, 4, true, 0, A>), dim3(blocks), dim3(1024), lds_bytes, st,         \
+        launch_maybe_timed((papr_sweep_kernel<1024, 4, true, 0, A>), dim3(blocks), dim3(1024), lds_bytes, st,         \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
                            table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                                            \
         break;
@@ -1903,7 +1943,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
 #undef X
 #define X(V, B, U, PP)                                                                                               \
     case V:                                                                                                           \
-        hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP, 0, true>), dim3(blocks), dim3(B), lds_bytes, st,        \
+        launch_maybe_timed((papr_sweep_kernel<B, U, true, PP, 0, true>), dim3(blocks), dim3(B), lds_bytes, st,        \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
                            table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                                            \
         break;
@@ -1911,7 +1951,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
 #undef X
 #define X(V, B, U, PP)                                                                                               \
     case V:                                                                                                           \
-        hipLaunchKernelGGL((papr_sweep_kernel<B, U, true, PP>), dim3(blocks), dim3(B), lds_bytes, st,                 \
+        launch_maybe_timed((papr_sweep_kernel<B, U, true, PP>), dim3(blocks), dim3(B), lds_bytes, st,                 \
                            (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
                            table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                                            \
         break;
@@ -1957,24 +1997,28 @@ void papr_launch_sweep2(hipStream_t st, int variant, int blocks, size_t lds_byte
     switch (variant) {
 #define X(V, W, U, PP, EX, WT)                                                                                  \
     case V:                                                                                                      \
-        hipLaunchKernelGGL((papr_sweep2_kernel<W, U, PP, EX, WT>), dim3(blocks), dim3(W * kWave), lds_bytes, st, p); \
+        launch_maybe_timed((papr_sweep2_kernel<W, U, PP, EX, WT>), dim3(blocks), dim3(W * kWave), lds_bytes, st, p); \
         break;
         PAPR_FOR_EACH_SWEEP2_VARIANT(X)
 #undef X
     }
 }
 
-void papr_launch_ccdf_power(hipStream_t st, int blocks, bool lut, size_t lds_bytes, const float *stash,
-                            const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs, uint32_t split,
-                            const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist,
-                            const papr_ccdf_params *Pdev)
+void papr_launch_ccdf_power(hipStream_t st, int num_cus, bool lut, size_t lds_bytes, const float *stash,
+                            const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs, const uint32_t *table,
+                            const papr_ccdf_params &P, unsigned long long *ghist, const papr_ccdf_params *Pdev)
 {
+    constexpr int kBlock = 1024;
+    const uint32_t chip = 2u * (uint32_t)(num_cus > 0 ? num_cus : 1);  // workgroups that are resident together
+    const uint32_t split = nsegs && nsegs < chip ? chip / nsegs : 1u;
+    const uint32_t jobs = nsegs * split;
+    const dim3 grid(jobs < chip ? (jobs ? jobs : 1u) : chip);
     if (lut)
-        hipLaunchKernelGGL((papr_ccdf_power_kernel<true>), dim3(blocks), dim3(PAPR_BLOCK), lds_bytes, st, stash,
-                           seg_counts, seg_cap, nsegs, split, table, P, ghist, Pdev);
+        launch_maybe_timed((papr_ccdf_power_kernel<true, kBlock>), grid, dim3(kBlock), lds_bytes, st, stash, seg_counts,
+                           seg_cap, nsegs, split, table, P, ghist, Pdev);
     else
-        hipLaunchKernelGGL((papr_ccdf_power_kernel<false>), dim3(blocks), dim3(PAPR_BLOCK), lds_bytes, st, stash,
-                           seg_counts, seg_cap, nsegs, split, table, P, ghist, Pdev);
+        launch_maybe_timed((papr_ccdf_power_kernel<false, kBlock>), grid, dim3(kBlock), lds_bytes, st, stash, seg_counts,
+                           seg_cap, nsegs, split, table, P, ghist, Pdev);
 }
 
 void papr_sweep_prepare_device(void)
@@ -2010,6 +2054,6 @@ void papr_sweep_prepare_device(void)
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
     PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X)
 #undef X
-    (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
-    (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
 }

@@ -235,9 +235,9 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
         p.tile_E_spec = ctx->d_tile_E_spec;
         p.seg_D = ctx->d_seg_D;
         p.seg_offset = (base_index - ctx->base) / PAPR_EXACT_SEG_SAMPLES;
-        time_begin(ctx, 3, n * 8);
+        time_begin_kernel(ctx, 3, n * 8);
         papr_launch_sweep2(ctx->stream, run.variant, blocks, run.bands.lds_bytes + run.stash_lds, p);
-        time_end(ctx);
+        time_end_kernel(ctx);
         HIPCHK(ctx, hipGetLastError());
         *nrecords = blocks;
         return PAPR_OK;
@@ -247,12 +247,12 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
     int rc = ensure_partials(ctx, slot + (size_t)blocks + 1);
     if (rc)
         return rc;
-    time_begin(ctx, 3, n * 8);
+    time_begin_kernel(ctx, 3, n * 8);
     papr_launch_sweep(ctx->stream, run.variant, blocks, run.bands.lds_bytes + run.stash_lds, data, ntiles, base_index, map,
                       ctx->d_partials + slot, data + 2 * (n - tail), tail, ctx->d_table, run.bands.P, ctx->d_sweep_hist,
                       ctx->d_stash, ctx->d_sweep_hist + run.nbins, run.seg_cap, ctx->d_sweep_hist + run.nbins + 2 * run.blocks,
                       ctx->d_sweep_hist + run.nbins + run.blocks, nullptr);
-    time_end(ctx);
+    time_end_kernel(ctx);
     HIPCHK(ctx, hipGetLastError());
     *nrecords = blocks;
     return PAPR_OK;
@@ -384,6 +384,9 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double)));
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double), hipHostMallocDefault));
     }
+    if (!ctx->d_result_copy) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_result_copy, sizeof(papr_partial)));
+    }
     if (!ctx->d_true) {
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_true, sizeof(papr_true_out)));
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_true, sizeof(papr_true_out), hipHostMallocMapped));
@@ -400,6 +403,8 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_sweep_hist, bytes));
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_sweep_hist, bytes, hipHostMallocDefault));
     }
+    if (!ctx->h_sweep_hist_dev)
+        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_sweep_hist_dev, ctx->h_sweep_hist, 0));
     run.seg_cap = std::max<uint64_t>((ctx->n / 4 / (uint64_t)run.blocks + 255) & ~255ull, 4096);
     const uint64_t want_stash = run.seg_cap * (uint64_t)run.blocks;
     if (ctx->stash_cap < want_stash) {
@@ -439,9 +444,9 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     ctx->est_groups_valid = false;
     ctx->exact_program_launched = false;
     // ---- the launches ----
-    time_begin(ctx, 4, ngroups * PAPR_ESTIMATE_TILE_SAMPLES * 8);
+    time_begin_kernel(ctx, 4, ngroups * PAPR_ESTIMATE_TILE_SAMPLES * 8);
     papr_launch_estimate(ctx->stream, est_blocks, ctx->d_iq, ngroups, (uint32_t)ratio, est_partials, group_sums, ctx->d_est_sq);
-    time_end(ctx);
+    time_end_kernel(ctx);
     HIPCHK(ctx, hipGetLastError());
     const int band_override = ctx->tune.sweep_band_log2 > 0 ? ctx->tune.sweep_band_log2 : 0;
     papr_launch_guess_bands(ctx->stream, est_partials, ctx->d_est_sq, (uint32_t)est_blocks, ngroups,
@@ -479,25 +484,30 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
         p.tile_E_spec = ctx->d_tile_E_spec;
         p.seg_D = ctx->d_seg_D;
         p.seg_offset = 0;
-        time_begin(ctx, 3, ctx->n * 8);
+        time_begin_kernel(ctx, 3, ctx->n * 8);
         papr_launch_sweep2(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, p);
-        time_end(ctx);
+        time_end_kernel(ctx);
     } else {
         const int map = effective_map(ctx, SWEEP, run.blocks);
-        time_begin(ctx, 3, ctx->n * 8);
+        time_begin_kernel(ctx, 3, ctx->n * 8);
         papr_launch_sweep(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, ctx->d_iq, ntiles, ctx->base, map,
                           ctx->d_partials, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->d_table, none, ctx->d_sweep_hist,
                           ctx->d_stash, ctx->d_sweep_hist + kBinsMax, run.seg_cap, ctx->d_sweep_hist + kBinsMax + 2 * run.blocks,
                           ctx->d_sweep_hist + kBinsMax + run.blocks, &ctx->d_guess->P);
-        time_end(ctx);
+        time_end_kernel(ctx);
     }
     HIPCHK(ctx, hipGetLastError());
-    rc = sweep_fetch(ctx, run);
-    if (rc)
-        return rc;
-    // pass 1's record (tail + merge of the workgroups' records) ...
+    // pass 1's record (tail + merge of the workgroups' records) — and, on the way, the sweep's bins and segment counters
+    // into mapped host memory (sweep_fetch without a copy in the stream; PAPR_FUSED_COPIES=1 keeps the copies) ...
+    const bool by_kernel = env_int("PAPR_FUSED_COPIES", 0) == 0;
+    if (!by_kernel) {
+        rc = sweep_fetch(ctx, run);
+        if (rc)
+            return rc;
+    }
     papr_launch_stats_finalize(ctx->stream, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->base + ctx->n - tail, ctx->d_partials,
-                               (uint32_t)run.blocks, ctx->h_result_dev);
+                               (uint32_t)run.blocks, ctx->h_result_dev, ctx->d_result_copy, ctx->d_sweep_hist,
+                               ctx->h_sweep_hist_dev, by_kernel ? kBinsMax + 2u * (uint32_t)run.blocks + 1u : 0u);
     HIPCHK(ctx, hipGetLastError());
     if (exact) {
         // ... the sum program from the pairs the sweep built (true prefix, the refuted tiles rebuilt, groups, gather) ...
@@ -512,18 +522,16 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     constexpr uint32_t kTrueCopies = 4;
     constexpr uint32_t true_soft = 20 * 1024;  // LDS the recount is launched with (as the host path: table + histogram copies)
     ctx->h_true->ok = 0;
-    papr_launch_true_table(ctx->stream, ctx->h_result_dev, ctx->n, graph, kTrueCopies, true_soft, ctx->d_table,
+    papr_launch_true_table(ctx->stream, ctx->d_result_copy, ctx->n, graph, kTrueCopies, true_soft, ctx->d_table,
                            std::max<uint32_t>(table_cap_words, 48 * 1024 / 4 + 8), ctx->d_true, ctx->h_true_dev, ctx->d_hist,
                            PAPR_TRUE_MAX_LEVELS + 1,  // (also clears the recount's bins)
                            ctx->d_sweep_hist + kBinsMax + 2 * run.blocks);
     HIPCHK(ctx, hipGetLastError());
     {
-        const uint32_t split = std::max<uint32_t>(1, (uint32_t)(ctx->num_cus * 8) / (uint32_t)run.blocks);
-        time_begin(ctx, 4, 0);
-        papr_launch_ccdf_power(ctx->stream, (int)((uint32_t)run.blocks * split), true, true_soft, ctx->d_stash,
-                               ctx->d_sweep_hist + kBinsMax, run.seg_cap, (uint32_t)run.blocks, split, ctx->d_table, none,
-                               ctx->d_hist, &ctx->d_true->P);
-        time_end(ctx);
+        time_begin_kernel(ctx, 4, 0);
+        papr_launch_ccdf_power(ctx->stream, ctx->num_cus, true, true_soft, ctx->d_stash, ctx->d_sweep_hist + kBinsMax,
+                               run.seg_cap, (uint32_t)run.blocks, ctx->d_table, none, ctx->d_hist, &ctx->d_true->P);
+        time_end_kernel(ctx);
         HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(PAPR_TRUE_MAX_LEVELS + 1) * sizeof(unsigned long long),
@@ -617,9 +625,9 @@ int papr_hip_estimate(papr_hip_ctx *ctx, papr_stats *est)
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double)));
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double), hipHostMallocDefault));
     }
-    time_begin(ctx, 4, ngroups * PAPR_ESTIMATE_TILE_SAMPLES * 8);
+    time_begin_kernel(ctx, 4, ngroups * PAPR_ESTIMATE_TILE_SAMPLES * 8);
     papr_launch_estimate(ctx->stream, blocks, ctx->d_iq, ngroups, (uint32_t)ratio, ctx->d_partials, group_sums, ctx->d_est_sq);
-    time_end(ctx);
+    time_end_kernel(ctx);
     HIPCHK(ctx, hipGetLastError());
     papr_launch_stats_finalize(ctx->stream, nullptr, 0, 0, ctx->d_partials, (uint32_t)blocks, ctx->h_result_dev);
     HIPCHK(ctx, hipGetLastError());
@@ -786,13 +794,11 @@ int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *lev
         if (rc)
             return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_hist, 0, (size_t)(m + 1) * sizeof(unsigned long long), ctx->stream));
-        time_begin(ctx, 4, ctx->sweep_stash_count * 4);
-        // enough workgroups to fill the chip: every segment is split over `split` of them
-        const uint32_t split = std::max<uint32_t>(1, (uint32_t)(ctx->num_cus * 8) / ctx->sweep_nsegs);
-        papr_launch_ccdf_power(ctx->stream, (int)(ctx->sweep_nsegs * split), plan.lut, plan.lds_bytes, ctx->d_stash,
-                               ctx->d_sweep_hist + ctx->sweep_seg_off, ctx->sweep_seg_cap, ctx->sweep_nsegs, split,
-                               ctx->d_table, plan.P, ctx->d_hist, nullptr);
-        time_end(ctx);
+        time_begin_kernel(ctx, 4, ctx->sweep_stash_count * 4);
+        papr_launch_ccdf_power(ctx->stream, ctx->num_cus, plan.lut, plan.lds_bytes, ctx->d_stash,
+                               ctx->d_sweep_hist + ctx->sweep_seg_off, ctx->sweep_seg_cap, ctx->sweep_nsegs, ctx->d_table,
+                               plan.P, ctx->d_hist, nullptr);
+        time_end_kernel(ctx);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(m + 1) * sizeof(unsigned long long),
                                    hipMemcpyDeviceToHost, ctx->stream));

@@ -141,7 +141,11 @@ void papr_hip_close(papr_hip_ctx *ctx);
 const char *papr_hip_last_error(const papr_hip_ctx *ctx); /* ctx may be NULL: last open error */
 int papr_hip_device_name(const papr_hip_ctx *ctx, char *buf, int buflen);
 int papr_hip_set_tuning(papr_hip_ctx *ctx, const papr_hip_tuning *t);
-int papr_hip_set_timing(papr_hip_ctx *ctx, int enabled); /* also resets the counters */
+/* Kernel timing (papr_hip_get_timing): 0 off, 1 every timed kernel, 2 only the kernels that read the shard (pass 1,
+ * pass 2, the sweep, the exact-sum pass) — a timed kernel carries a completion signal of its own, which costs the stream
+ * ~5 us on either side of it (profiles/r02_step_timeline.txt), so a benchmark times the small estimate / recount
+ * kernels in separate steps.  Also resets the counters. */
+int papr_hip_set_timing(papr_hip_ctx *ctx, int enabled);
 int papr_hip_get_timing(papr_hip_ctx *ctx, papr_hip_timing *out);
 
 /* ---- shard residency (replaces the fread ingest, papr.c:100-101,143-144) -- */
