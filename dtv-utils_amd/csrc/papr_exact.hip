@@ -128,6 +128,40 @@ __device__ __forceinline__ Pair wave_compose(Pair f, double m0)
 
 }  // namespace
 
+// exclusive scan of one value per thread over the workgroup, in thread order (wave shuffles, then the wave totals):
+// what a single thread walking an LDS array did in 256 / 1024 dependent steps (17 us / 37 us per kernel,
+// profiles/r02_step_timeline.txt).  `wave_tot`: BLOCK / 64 entries of LDS; `total` (optional): the sum of all values.
+template <typename T, int BLOCK>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *wave_tot, T *total)
+{
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    T inc = v;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const T o = __shfl_up(inc, d);
+        if (lane >= d)
+            inc += o;
+    }
+    T ex = __shfl_up(inc, 1);
+    if (lane == 0)
+        ex = T(0);
+    __syncthreads();  // (wave_tot may still be read from a previous call)
+    if (lane == kWave - 1)
+        wave_tot[w] = inc;
+    __syncthreads();
+    T base = T(0), all = T(0);
+#pragma unroll
+    for (int k = 0; k < BLOCK / kWave; k++) {
+        const T x = wave_tot[k];
+        if (k < w)
+            base += x;
+        all += x;
+    }
+    if (total)
+        *total = all;
+    return base + ex;
+}
+
 // ---- tile prefix sums and classification ------------------------------------------
 
 template <bool SEGD>
@@ -153,8 +187,10 @@ __global__ __launch_bounds__(256) void papr_exact_block_sums(const double *__res
 // in-place exclusive scan of the block sums, starting from `before` (the accurate
 // sum of everything that precedes this shard in the file)
 __global__ __launch_bounds__(256) void papr_exact_scan_blocks(double *__restrict__ block_sums, uint32_t nblocks,
-                                                               double before)
+                                                               double before, uint32_t *__restrict__ zero_word)
 {
+    if (zero_word && threadIdx.x == 0)
+        *zero_word = 0;  // (the redo list's counter, for the classification that follows: saves a memset in the stream)
     __shared__ double sh[256];
     const uint32_t per = (nblocks + 255) / 256;
     const uint32_t a = threadIdx.x * per, e = min(a + per, nblocks);
@@ -466,23 +502,10 @@ __global__ __launch_bounds__(256) void papr_exact_plan_kernel(const papr_exact_g
                                                                uint32_t *__restrict__ raw_list, uint32_t cap_raw,
                                                                papr_exact_plan *__restrict__ out)
 {
-    __shared__ uint32_t sh[256];
-    __shared__ uint32_t sh_total;
+    __shared__ uint32_t sh[256 / kWave];
+    uint32_t sh_total = 0;
     auto ordered_offsets = [&](uint32_t mine) -> uint32_t {  // exclusive scan over the 256 threads, in order
-        __syncthreads();
-        sh[threadIdx.x] = mine;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (int k = 0; k < 256; k++) {
-                const uint32_t v = sh[k];
-                sh[k] = run;
-                run += v;
-            }
-            sh_total = run;
-        }
-        __syncthreads();
-        return sh[threadIdx.x];
+        return block_exclusive_scan<uint32_t, 256>(mine, sh, &sh_total);
     };
     // mixed groups
     const uint64_t per_g = (ngroups + 255) / 256;
@@ -542,7 +565,9 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(const papr_exact_p
                                                                const float *__restrict__ tail_src, uint64_t nsamples,
                                                                uint32_t tail_samples, uint32_t group_blocks,
                                                                uint32_t cap_mixed, uint32_t cap_raw,
-                                                               unsigned char *__restrict__ out)
+                                                               unsigned char *__restrict__ out,
+                                                               const uint32_t *__restrict__ count_src,
+                                                               uint32_t *__restrict__ count_dst)
 {
     const uint32_t nmixed = plan->nmixed, nraw = plan->nraw;
     const size_t off_groups = 48;  // sizeof(papr_exact_header)
@@ -607,6 +632,8 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(const papr_exact_p
         h32[9] = nmixed;
         h32[10] = nraw;
         h32[11] = plan->overflow;  // reserved word: non-zero = lists were truncated, do not use this program
+        if (count_dst)
+            *count_dst = *count_src;  // (the redo count, to mapped host memory with the program: saves a D2H copy)
     }
 }
 
@@ -620,7 +647,7 @@ void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, ui
     if (nb == 0)
         return;
     hipLaunchKernelGGL(papr_exact_block_sums<false>, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums);
-    hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before);
+    hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before, (uint32_t *)nullptr);
     hipLaunchKernelGGL(papr_exact_classify<false>, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums, delta,
                        tile_E, ambig_list, ambig_cap, ambig_count, (const int32_t *)nullptr, (uint32_t *)nullptr, 0u,
                        (uint32_t *)nullptr);
@@ -630,7 +657,7 @@ void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, ui
 }
 
 // One-read sweep: the tile sums are D0 of the segments' pairs (seg_D), and every tile whose proven binade differs
-// from the speculated one (`spec`) is listed for papr_launch_exact_redo.  *redo_count must be zero on entry.
+// from the speculated one (`spec`) is listed for papr_launch_exact_redo.  *redo_count is zeroed here.
 void papr_launch_exact_classify_swept(hipStream_t st, const void *seg_D, uint64_t ntiles, double *block_sums, double before,
                                       double delta, int32_t *tile_E, const int32_t *spec, uint32_t *redo_list,
                                       uint32_t redo_cap, uint32_t *redo_count, uint32_t *ambig_list, uint32_t ambig_cap,
@@ -641,7 +668,7 @@ void papr_launch_exact_classify_swept(hipStream_t st, const void *seg_D, uint64_
         return;
     const double *sums = (const double *)seg_D;
     hipLaunchKernelGGL(papr_exact_block_sums<true>, dim3(nb), dim3(256), 0, st, sums, ntiles, block_sums);
-    hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before);
+    hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before, redo_count);
     hipLaunchKernelGGL(papr_exact_classify<true>, dim3(nb), dim3(256), 0, st, sums, ntiles, block_sums, delta, tile_E,
                        ambig_list, ambig_cap, ambig_count, spec, redo_list, redo_cap, redo_count);
     if (ambig_list)  // a streamed shard: the unprovable tiles, ascending (they are read back from the file for the program)
@@ -731,28 +758,35 @@ __global__ __launch_bounds__(1024) void papr_exact_spec_scan_kernel(const double
                                                                     double scale, double before,
                                                                     double *__restrict__ group_prefix)
 {
-    __shared__ double sh[1024];
+    __shared__ double sh[1024 / kWave];
     const uint64_t per = (ngroups + 1023) / 1024;
     const uint64_t a = threadIdx.x * per, e = min(a + per, ngroups);
-    double s = 0.0;
     auto gsum = [&](uint64_t k) { return (((group_sums[4 * k] + group_sums[4 * k + 1]) + group_sums[4 * k + 2]) + group_sums[4 * k + 3]) * scale; };
-    for (uint64_t k = a; k < e; k++)
-        s += gsum(k);
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double run = before;
-        for (int k = 0; k < 1024; k++) {
-            const double v = sh[k];
-            sh[k] = run;
-            run += v;
-        }
+    // (eight groups' loads in flight at a time: one group after the other was 20 dependent trips to the L2)
+    constexpr int CH = 8;
+    double s = 0.0;
+    for (uint64_t k0 = a; k0 < e; k0 += CH) {
+        double g[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            g[j] = k0 + j < e ? gsum(k0 + j) : 0.0;
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            s += g[j];
     }
-    __syncthreads();
-    double run = sh[threadIdx.x];
-    for (uint64_t k = a; k < e; k++) {
-        group_prefix[k] = run;
-        run += gsum(k);
+    // (an estimate: the order of these additions decides nothing but which tiles get redone)
+    double run = before + block_exclusive_scan<double, 1024>(s, sh, (double *)nullptr);
+    for (uint64_t k0 = a; k0 < e; k0 += CH) {
+        double g[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            g[j] = k0 + j < e ? gsum(k0 + j) : 0.0;
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            if (k0 + j < e) {
+                group_prefix[k0 + j] = run;
+                run += g[j];
+            }
     }
 }
 
@@ -842,7 +876,7 @@ void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint
                             uint64_t ntiles, const void *seg_D, const void *data, const void *raw_store,
                             const void *tail_src, uint64_t nsamples, uint32_t tail_samples, uint32_t *mixed_list,
                             uint32_t cap_mixed, uint32_t *raw_list, uint32_t cap_raw, papr_exact_plan *plan,
-                            unsigned char *out_mapped)
+                            unsigned char *out_mapped, const uint32_t *count_src, uint32_t *count_dst)
 {
     hipLaunchKernelGGL(papr_exact_plan_kernel, dim3(1), dim3(256), 0, st, groups, ngroups, tile_E, ntiles, mixed_list,
                        cap_mixed, raw_list, cap_raw, plan);
@@ -850,5 +884,5 @@ void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint
     hipLaunchKernelGGL(papr_exact_pack_kernel, dim3(group_blocks + cap_mixed + cap_raw + 1), dim3(256), 0, st, plan,
                        mixed_list, raw_list, groups, ngroups, tile_E, ntiles, (const double *)seg_D, (const float *)data,
                        (const float *)raw_store, (const float *)tail_src, nsamples, tail_samples, group_blocks, cap_mixed,
-                       cap_raw, out_mapped);
+                       cap_raw, out_mapped, count_src, count_dst);
 }

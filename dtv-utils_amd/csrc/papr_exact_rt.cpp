@@ -218,6 +218,7 @@ int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total)
     if (!ctx->d_redo) {
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_redo, (kCapRedo + 1) * sizeof(uint32_t)));
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_redo_count, sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_redo_count_dev, ctx->h_redo_count, 0));
     }
     int rc = reserve_program(ctx, sizeof(papr_exact_header) + ngroups * sizeof(papr_exact_group_rec) +
                                       (size_t)kCapMixed * sizeof(papr_exact_mixed_rec) +
@@ -226,7 +227,7 @@ int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total)
         return rc;
     unsigned char *program_dev = nullptr;
     HIPCHK(ctx, hipHostGetDevicePointer((void **)&program_dev, ctx->h_program, 0));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_redo + kCapRedo, 0, sizeof(uint32_t), ctx->stream));
+    // (the redo counter is zeroed by papr_launch_exact_classify_swept)
     if (!ctx->resident)
         return run_exact_swept_streamed(ctx, before, delta, ntiles, ngroups, tail, program_dev);
     time_begin(ctx, 5, 0);  // (helper kernels: timed like the estimate / recount kernels, reported with kind 2)
@@ -239,10 +240,8 @@ int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total)
     time_end(ctx);
     papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, ctx->d_iq, nullptr,
                            ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, ctx->n, tail, ctx->d_mixed_list, kCapMixed,
-                           ctx->d_raw_list, kCapRaw, ctx->d_plan, program_dev);
+                           ctx->d_raw_list, kCapRaw, ctx->d_plan, program_dev, ctx->d_redo + kCapRedo, ctx->h_redo_count_dev);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_redo_count, ctx->d_redo + kCapRedo, sizeof(uint32_t), hipMemcpyDeviceToHost,
-                               ctx->stream));
     // from here on the program (mapped host memory) and the redo count are complete: whoever waits for this event
     // may use them while the stream goes on with the recount (run_overlap_work)
     if (!ctx->ev_program)

@@ -79,7 +79,9 @@ void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint
                             uint64_t ntiles, const void *seg_D, const void *data, const void *raw_store,
                             const void *tail_src, uint64_t nsamples, uint32_t tail_samples, uint32_t *mixed_list,
                             uint32_t cap_mixed, uint32_t *raw_list, uint32_t cap_raw, papr_exact_plan *plan,
-                            unsigned char *out_mapped);
+                            unsigned char *out_mapped,
+                            const uint32_t *count_src = nullptr /* one word (the redo count) copied along ... */,
+                            uint32_t *count_dst = nullptr /* ... to mapped host memory */);
 /* ambig_* may be null (resident shards); otherwise the unprovable tiles are also listed, ascending, in ambig_sorted */
 void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, uint64_t ntiles, double *block_sums,
                                 double before, double delta, int32_t *tile_E, uint32_t *ambig_list, uint32_t ambig_cap,

@@ -244,7 +244,7 @@ struct papr_hip_ctx {
     size_t redo_store_tiles = 0;
     int band_hint = 0;                           // papr_hip_set_band: half-width (log2) for the next sweeps, 0 = default
     double exact_before_hint = 0.0;              // estimated sum of everything before this shard (papr_hip_set_exact_hint)
-    uint32_t *h_redo_count = nullptr;            // pinned
+    uint32_t *h_redo_count = nullptr, *h_redo_count_dev = nullptr;  // pinned (and its device address)
     uint32_t *d_redo = nullptr;                  // [0, kCapRedo) tiles whose pairs must be rebuilt, [kCapRedo] their count
     bool exact_swept = false;                    // the last sweep left speculated pairs in d_seg_D / d_tile_E_spec
 
