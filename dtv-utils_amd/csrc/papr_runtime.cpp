@@ -498,10 +498,10 @@ int launch_ccdf_range(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *data
 
 // finalize pass 1: tail + merge of `records` partials, NaN bookkeeping
 int finish_stats(papr_hip_ctx *ctx, size_t records, const float *tail_ptr, uint32_t tail_samples, uint64_t tail_base,
-                 papr_stats *out)
+                 papr_stats *out, const unsigned long long *copy_src, unsigned long long *copy_dst, uint32_t copy_words)
 {
     papr_launch_stats_finalize(ctx->stream, tail_ptr, tail_samples, tail_base, ctx->d_partials, (uint32_t)records,
-                               ctx->h_result_dev);
+                               ctx->h_result_dev, nullptr, copy_src, copy_dst, copy_words);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     partial_to_stats(*ctx->h_result, ctx->n, out);

@@ -401,7 +401,8 @@ int sweep_fetch(papr_hip_ctx *ctx, const SweepRun &run);
 int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run);
 int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t *nrecords_out);
 int finish_stats(papr_hip_ctx *ctx, size_t records, const float *tail_ptr, uint32_t tail_samples, uint64_t tail_base,
-                 papr_stats *out);
+                 papr_stats *out, const unsigned long long *copy_src = nullptr /* words the finalize kernel copies ... */,
+                 unsigned long long *copy_dst = nullptr /* ... to mapped host memory on the way */, uint32_t copy_words = 0);
 int resolve_resident_nan(papr_hip_ctx *ctx, papr_stats *out);
 int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples, const float *guess,
                    int nguess);

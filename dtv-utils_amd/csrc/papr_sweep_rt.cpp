@@ -725,11 +725,20 @@ static int papr_hip_stats_sweep_impl(papr_hip_ctx *ctx, const float *guess_level
     rc = sweep_launch(ctx, run, ctx->d_iq, ctx->n, ctx->base, 0, &nrec);
     if (rc)
         return rc;
-    rc = sweep_fetch(ctx, run);
-    if (rc)
-        return rc;
+    // (the sweep's bins and segment counters reach the host through the finalize kernel, as in stats_sweep_fused)
+    const size_t fetch_words = (size_t)(run.seg_off ? run.seg_off : run.nbins) + 2 * (size_t)run.blocks + 1;
+    const bool by_kernel = env_int("PAPR_FUSED_COPIES", 0) == 0 && fetch_words <= 16384;  // (one workgroup copies them)
+    if (!ctx->h_sweep_hist_dev)
+        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_sweep_hist_dev, ctx->h_sweep_hist, 0));
+    if (!by_kernel) {
+        rc = sweep_fetch(ctx, run);
+        if (rc)
+            return rc;
+    }
     const uint32_t tail = (uint32_t)(ctx->n % run.tile);
-    rc = finish_stats(ctx, (size_t)nrec, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->base + ctx->n - tail, out);  // synchronises
+    rc = finish_stats(ctx, (size_t)nrec, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->base + ctx->n - tail, out,
+                      ctx->d_sweep_hist, ctx->h_sweep_hist_dev,
+                      by_kernel ? (uint32_t)fetch_words : 0u);  // synchronises
     if (rc)
         return rc;
     if (std::isnan(out->sum))  // NaN in the data: the sweep's integer-max trackers do not apply (papr_sweep.hip)
