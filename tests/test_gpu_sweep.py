@@ -661,3 +661,62 @@ def test_analyze_hostile_inputs_through_the_single_wait_step(pkg, orc):
                 assert res.nlevels == table.size == ref["level"].size, (name, graph)
                 # (the tree sum may differ from the reference's sequential sum in the last places: count against OUR table)
                 assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table)), (name, graph)
+
+
+@pytest.mark.parametrize("exact", [False, True], ids=["tree", "exact"])
+def test_counters_through_the_finalize_kernel_equal_the_copied_ones(pkg, orc, monkeypatch, exact):
+    """The sweep's bins and segment counters reach the host through papr_stats_finalize (mapped host memory) — in the
+    single-wait step and in the with-peers path (estimate / stats_sweep / ccdf called one by one) — or, with
+    PAPR_FUSED_COPIES=1, by a D2H copy as before.  Same results, same decisions, and the reference's."""
+    for n in (4099, 5 * 1048576 + 77):
+        with pkg.PaprHip(0) as g:
+            g.set_exact(exact)
+            g.generate(pkg.SynthSpec.spike(n, seed=4242 + n % 89), 0, n)
+            iq = g.download(0, n)
+            for graph in (False, True):
+                ref = orc.run_mem(iq, graph)
+                got = {}
+                for copies in ("0", "1"):
+                    monkeypatch.setenv("PAPR_FUSED_COPIES", copies)
+                    res, table, counts = g.analyze(None, graph)
+                    check_stats(res.total, ref)
+                    assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
+                    # the with-peers sequence, by hand
+                    est = g.estimate()
+                    g.set_band(pkg.band_for(est))
+                    st = g.stats_sweep(pkg.guess_levels(est, graph))
+                    mean, papr, table2 = pkg.levels(st, graph)
+                    counts2 = g.ccdf(table2)
+                    info = g.sweep_info()
+                    check_stats(st, ref)
+                    assert np.array_equal(counts2.astype(np.int64), orc.count_mem(iq, table2))
+                    got[copies] = (res.total.sum, tuple(counts.tolist()), res.swept, res.resolved, st.sum,
+                                   tuple(counts2.tolist()), info.swept, info.resolved, info.stash_samples)
+                assert got["0"] == got["1"], (n, graph)
+
+
+def test_timing_levels(pkg):
+    """papr_hip_set_timing: 1 times every bracketed kernel, 2 only the kernels that read the shard (the estimate and
+    recount kernels are left alone: a timed dispatch costs the stream a few microseconds on either side), 0 nothing.
+    The events are bound to the dispatches, so the sweep's figure is the kernel's own duration."""
+    n = 8 * 1048576
+    with pkg.PaprHip(0) as g:
+        g.generate(pkg.SynthSpec.spike(n, seed=77), 0, n)
+        g.analyze(None, False)
+        seen = {}
+        for level in (1, 2, 0):
+            g.set_timing(level)
+            for _ in range(3):
+                res, _, _ = g.analyze(None, False)
+                assert res.swept and res.resolved
+            tm = g.timing()
+            seen[level] = (tm.sweep_launches, tm.aux_launches, tm.sweep_ms, tm.aux_ms, tm.sweep_bytes)
+        g.set_timing(0)
+    assert seen[1][0] == 3 and seen[1][1] >= 6 and seen[1][2] > 0 and seen[1][3] > 0  # (estimate + recount per step)
+    assert seen[2][0] == 3 and seen[2][1] == 0 and seen[2][2] > 0 and seen[2][3] == 0
+    assert seen[0][:2] == (0, 0)
+    assert seen[1][4] == seen[2][4] == 3 * n * 8
+    # 64 MiB at < 8 TB/s takes > 8 us per launch; a duration that included the neighbours' launches would be far above 1 ms
+    for level in (1, 2):
+        per_launch = seen[level][2] / 3
+        assert 0.008 < per_launch < 1.0, seen
