@@ -69,7 +69,7 @@ bin/papr: $(PKG)/host/papr_main.c include/papr_hip.h $(LIB)
 oracle:
 	$(MAKE) -C oracle all
 
-tools: bin/hbm_read_probe bin/ingest_probe
+tools: bin/hbm_read_probe bin/ingest_probe bin/work_probe
 
 bin/ingest_probe: tools/ingest_probe.cpp
 	@mkdir -p bin
@@ -79,8 +79,12 @@ bin/hbm_read_probe: tools/hbm_read_probe.hip
 	@mkdir -p bin
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Wno-unused-result -Wno-unused-value $< -o $@
 
+bin/work_probe: tools/work_probe.hip
+	@mkdir -p bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -Wno-unused-result -Wno-unused-value $< -o $@
+
 clean:
-	rm -f $(CSRC)/*.o $(LIB) bin/papr bin/hbm_read_probe bin/ingest_probe
+	rm -f $(CSRC)/*.o $(LIB) bin/papr bin/hbm_read_probe bin/ingest_probe bin/work_probe
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib cli oracle tools clean

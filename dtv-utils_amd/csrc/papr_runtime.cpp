@@ -116,7 +116,11 @@ int variant_of(const papr_hip_ctx *ctx, Pass p)
 int blocks_of(const papr_hip_ctx *ctx, Pass p)
 {
     const int b = p == PASS1 ? ctx->tune.stats_blocks : p == PASS2 ? ctx->tune.ccdf_blocks : ctx->tune.sweep_blocks;
-    return b > 0 ? b : ctx->num_cus * (p == PASS1 ? kStatsPerCU : p == PASS2 ? kCcdfPerCU : kSweepPerCU);
+    if (b > 0)
+        return b;
+    if (p == SWEEP && PAPR_SWEEP_VARIANT_IS_PERSISTENT(variant_of(ctx, SWEEP)))
+        return ctx->num_cus;
+    return ctx->num_cus * (p == PASS1 ? kStatsPerCU : p == PASS2 ? kCcdfPerCU : kSweepPerCU);
 }
 
 // samples one workgroup consumes per loop iteration under the pass's kernel variant

@@ -279,7 +279,7 @@ constexpr int kStatsVariant = 1, kStatsPerCU = 2, kStatsMap = PAPR_MAP_GRID_STRI
 constexpr int kCcdfVariant = 13, kCcdfPerCU = 2, kCcdfMap = PAPR_MAP_GRID_STRIDE;
 
 // one-sweep kernel (pass 1 + banded pass 2 in one read)
-constexpr int kSweepVariant = 4, kSweepPerCU = 4, kSweepMap = PAPR_MAP_GRID_STRIDE;
+constexpr int kSweepVariant = 40, kSweepPerCU = 4, kSweepMap = PAPR_MAP_GRID_STRIDE;  // (variant 40: one workgroup per CU)
 constexpr int kSweepExactVariant = 56;  // papr_sweep2_kernel<12 waves, exact-sum pairs>
 
 constexpr int kSweepBandLog2 = 14, kEstimateRatio = 64;

@@ -136,7 +136,7 @@ __device__ __forceinline__ void store16(float *p, f32x4s v)
 // register and slots be handed out by ballot + mbcnt — no returning LDS atomic (and no wait for it) per in-band sample.
 template <int MODE = 0>
 struct WaveStashT {
-    static constexpr bool SP16 = (MODE & 1) != 0, BALLOT = (MODE & 2) != 0;
+    static constexpr bool SP16 = (MODE & 1) != 0, BALLOT = (MODE & 2) != 0, NOBR = (MODE & 8) != 0;
     uint32_t nfill = 0;                 // BALLOT: entries in buf (wave-uniform)
     float *buf;                         // this wave's slice of LDS
     uint32_t *fill;                     // LDS: entries in buf (this wave's counter)
@@ -148,10 +148,21 @@ struct WaveStashT {
     unsigned long long seg_start;       // the segment's length when this launch began
     unsigned long long *gave_up;        // device counter of give-ups
     unsigned long long *seg_real;       // LDS: powers stashed without padding (SP16)
+    uint32_t trash = 0;                 // NOBR: this lane's own word at the end of the slice, where what is not in band goes
 
     __device__ __forceinline__ void put(float pw, bool take)
     {
-        if constexpr (BALLOT) {
+        if constexpr (BALLOT && NOBR) {
+            // no branch at all: every lane writes — its power to its slot, or to its own trash word (a wave with only two
+            // waves per SIMD beside it cannot hide a v_cmp -> s_cbranch round per sample)
+            // (the select is written out: from `take ? at : trash` hipcc makes an exec-masked region per sample)
+            const unsigned long long m = __ballot(take);
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, nfill));
+            uint32_t dest;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(dest) : "v"(trash), "v"(at), "s"(m));
+            buf[dest] = pw;
+            nfill += (uint32_t)__popcll(m);
+        } else if constexpr (BALLOT) {
             const unsigned long long m = __ballot(take);
             if (m) {  // (wave-uniform)
                 const uint32_t at = nfill + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -202,12 +213,16 @@ struct WaveStashT {
                 v.z = i + 2 < n ? v.z : pad;
                 v.w = i + 3 < n ? v.w : pad;
                 if (pos + i + 4 <= seg_cap)
-                    store16<2>(seg + pos + i, v);
+                    store16<(MODE & 16) ? 0 : 2>(seg + pos + i, v);
             }
         } else {
             for (uint32_t i = lane; i < n; i += kWave)
-                if (pos + i < seg_cap)  // write-through (sc0 sc1): 1-3 % faster than leaving these lines dirty in L2 for a later eviction
-                    __hip_atomic_store(&seg[pos + i], buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (pos + i < seg_cap) {  // write-through (sc0 sc1): 1-3 % faster than leaving these lines dirty in L2 for a later eviction
+                    if constexpr ((MODE & 16) != 0)
+                        seg[pos + i] = buf[i];  // (MODE bit 4: plain stores — measurement)
+                    else
+                        __hip_atomic_store(&seg[pos + i], buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
         }
         __builtin_amdgcn_wave_barrier();
         const uint32_t got = (uint32_t)(pos - seg_start) + nres;  // (a workgroup folds < 2^32 samples per launch)
@@ -834,7 +849,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
     // without the host in between — read from where that kernel left it (wave-uniform loads: scalar registers)
     const papr_ccdf_params P = uniform_params(Pdev, Parg);
     constexpr uint64_t TILE_F4 = (uint64_t)BLOCK * U;
-    constexpr uint32_t SLICE = papr_sweep_slice_floats(U);
+    constexpr uint32_t SLICE = papr_sweep_slice_floats(U) * ((SMODE & 32) ? 2u : 1u);  // (bit 5: twice the slice — measurement)
     __shared__ unsigned long long seg_fill, seg_real_sh;
     __shared__ uint32_t wave_fill[BLOCK / kWave];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -858,10 +873,17 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
     __syncthreads();
 
     const uint2 *lut_biased = reinterpret_cast<const uint2 *>(tab) - ((int32_t)P.cell_lo - 1);
-    uint32_t *my = hist + ((t / kWave) % P.copies) * nbins;
+    // SMODE bit 2 (HSETS): histogram laid out [bin][copy] with a power-of-two number of copies, and the lanes of a wave
+    // spread over eight of them: the samples pile up in a handful of bins (63 % below the first band, 8 % in the next
+    // bin, ...), and 64 lanes adding to five addresses is what the LDS spends its time on (profiles/r02_work_probe.txt)
+    constexpr bool HSETS = (SMODE & 4) != 0;
+    const uint32_t csh = HSETS ? 31u - (uint32_t)__clz((int)P.copies) : 0u;
+    const uint32_t mycopy = HSETS ? (((t / kWave) * 8u + (t & 7u)) & ((1u << csh) - 1u)) : 0u;
+    uint32_t *my = HSETS ? hist + mycopy : hist + ((t / kWave) % P.copies) * nbins;
     WaveStashT<SMODE> ws{0u, slices + (t / kWave) * SLICE, &wave_fill[t / kWave], stash + (uint64_t)blockIdx.x * seg_cap,
                         &seg_fill, seg_cap, tab, P.table_words, LUT2 ? PAPR_LUT2_NEVER : 0u, seg_fill, gave_up,
                         &seg_real_sh};
+    ws.trash = SLICE - kWave + (t & (kWave - 1));
     // cell index straight from the bit pattern: lut_biased[cell] with cell clamped to [cell_lo - 1, cell_lo + ncells]
     const int32_t cell_last = (int32_t)(P.cell_lo + P.ncells);
     int32_t cell_first;  // pinned in a VGPR for the whole kernel (v_med3 takes one scalar operand)
@@ -880,9 +902,19 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
         }
     };
     auto count_and_stash = [&](float pw, uint32_t k) {
-        if constexpr (!(ABL & 2))
-            if (k)
-                atomicAdd(&my[k], 1u);
+        if constexpr (!(ABL & 2)) {
+            if constexpr ((SMODE & 8) != 0) {
+                // branch-free: bin 0 (below every band: not counted) adds to this lane's trash word instead
+                const unsigned long long nz = __ballot(k != 0u);
+                const uint32_t a_bin = (uint32_t)(uintptr_t)(lds_u32 *)&my[HSETS ? (k << csh) : k];
+                const uint32_t a_trash = (uint32_t)(uintptr_t)(lds_u32 *)&ws.buf[ws.trash];
+                uint32_t a;
+                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a) : "v"(a_trash), "v"(a_bin), "s"(nz));
+                (void)__hip_atomic_fetch_add((lds_u32 *)(uintptr_t)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (k) {
+                atomicAdd(&my[HSETS ? (k << csh) : k], 1u);
+            }
+        }
         if constexpr (!(ABL & 1))
             ws.put(pw, (k & 1u) != 0u);
     };
@@ -916,7 +948,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
         for (int u = 0; u < 2 * U; u++)
             count_and_stash(pw[u], k[u]);
         if constexpr (!(ABL & 32))
-            ws.spill_if_above(SLICE - 2 * U * kWave, (it + 1) * (uint32_t)(2 * TILE_F4));  // the next tile might not fit
+            ws.spill_if_above(SLICE - 2 * U * kWave - ((SMODE & 8) ? kWave : 0), (it + 1) * (uint32_t)(2 * TILE_F4));  // the next tile might not fit
     };
 
     const float4 *p = data + w.first * TILE_F4 + t;
@@ -964,13 +996,24 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
             const float2 x = valid ? tail[k0 + t] : make_float2(0.f, 0.f);
             const float pw = power_of(x.x, x.y);
             count_and_stash(pw, valid ? bin_of(pw) : 0u);
-            ws.spill_if_above(SLICE - kWave, ~0u);
+            ws.spill_if_above(SLICE - kWave - ((SMODE & 8) ? kWave : 0), ~0u);
         }
     }
     ws.spill_if_above(0, ~0u);
 
     sweep_record<BLOCK, BLOCK, U>(sum, tr, w, data, base_index, t, out);
-    hist_flush<BLOCK>(hist, nbins, P.copies, ghist);  // (starts with a barrier: every wave has spilled)
+    if constexpr (HSETS) {
+        __syncthreads();  // every wave has spilled and counted
+        for (uint32_t b = t; b < nbins; b += BLOCK) {
+            unsigned long long sb = 0;
+            for (uint32_t c = 0; c < (1u << csh); c++)
+                sb += hist[(b << csh) + c];
+            if (sb)
+                atomicAdd(&ghist[b], sb);
+        }
+    } else {
+        hist_flush<BLOCK>(hist, nbins, P.copies, ghist);  // (starts with a barrier: every wave has spilled)
+    }
     if (t == 0) {
         seg_counts[blockIdx.x] = seg_fill;
         seg_real[blockIdx.x] = (SMODE & 1) ? seg_real_sh : seg_fill;  // (dword spills: no padding, the two are the same)
@@ -1821,14 +1864,26 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
 #endif
 
 // papr_sweep_kernel with other stash forms: id, workgroup size, loads per lane, loop form, compact table,
-// stash mode (bit 0: 16-byte spills, bit 1: ballot compaction)
-// (none of them beats the default — DESIGN.md section 4b — so only `make MEASURE=1` builds them)
+// stash mode (bit 0: 16-byte spills, bit 1: ballot compaction, bit 2: [bin][copy] histogram sets, bit 3: no branch and
+// no exec-masked region in the per-sample code, bit 4: plain instead of write-through spill stores, bit 5: twice the
+// LDS slice per wave).  40 — 512 threads x 8 loads per lane, ONE persistent workgroup per CU, branch-free ballot stash,
+// 16-byte spills out of a double slice — is the default: eight waves per CU with eight 16-byte loads each in flight is
+// the shape a stripped kernel reads fastest in (tools/work_probe.hip); with only two waves per SIMD nothing hides a
+// v_cmp -> s_and_saveexec round per sample or a spill's store latency, hence the branch-free code and the rarer, wider
+// spills.  The others did not pay and are built by `make MEASURE=1` only.
 #ifdef PAPR_MEASURE
 #define PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X) \
+    X(40, 512, 8, 0, false, 43) X(100, 512, 8, 0, false, 10)                                                              \
     X(5, 1024, 4, 0, false, 1) X(18, 1024, 4, 0, true, 1) X(19, 512, 4, 0, false, 1) X(36, 1024, 4, 0, false, 2)          \
-    X(37, 1024, 4, 0, false, 3) X(38, 1024, 4, 0, true, 2) X(39, 512, 4, 0, false, 2)
+    X(37, 1024, 4, 0, false, 3) X(38, 1024, 4, 0, true, 2) X(39, 512, 4, 0, false, 2)                                  \
+    X(80, 256, 8, 0, false, 2) X(81, 256, 8, 0, false, 3) X(82, 256, 8, 1, false, 2) X(83, 512, 8, 0, false, 2)       \
+    X(84, 256, 8, 0, false, 6) X(85, 256, 8, 0, false, 14) X(86, 256, 8, 0, false, 10) X(87, 512, 8, 0, false, 14)         \
+    X(88, 1024, 4, 0, false, 14) X(89, 256, 8, 1, false, 14) X(101, 512, 8, 1, false, 10)                                  \
+    X(102, 512, 4, 0, false, 10) X(103, 1024, 8, 0, false, 10) X(104, 512, 8, 0, false, 11) X(105, 512, 8, 0, false, 26)   \
+    X(106, 512, 8, 0, false, 27) X(107, 512, 8, 0, false, 42) X(109, 512, 8, 0, false, 59)   \
+    X(110, 512, 8, 1, false, 11) X(111, 512, 8, 1, false, 43) X(112, 256, 8, 0, false, 43) X(113, 1024, 4, 0, false, 43)
 #else
-#define PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X)
+#define PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X) X(40, 512, 8, 0, false, 43)
 #endif
 
 // loader / binner split (papr_sweep_split_kernel): id, loader waves, binners per loader, loads per lane per tile, ring depth
@@ -1842,8 +1897,8 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
 int papr_sweep_variant(int variant)
 {
 #ifdef PAPR_MEASURE
-    if (variant >= 60 && variant <= 69)
-        return variant;  // ablations of <1024, 4> (measurement only)
+    if ((variant >= 60 && variant <= 69) || (variant >= 90 && variant <= 99 && variant != 93 && variant != 96))
+        return variant;  // ablations of <1024, 4> / <256, 8> (measurement only)
 #endif
     switch (variant) {
 #define X(V, PW, NB, LU, D) case V: return V;
@@ -1866,6 +1921,8 @@ int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_
 {
     if (variant >= 60 && variant <= 69)
         variant = 4;
+    if (variant >= 90 && variant <= 99)
+        variant = 0;
     switch (variant) {
 #define X(V, PW, NB, LU, D)                                                                                      \
     case V:                                                                                                       \
@@ -1880,7 +1937,7 @@ int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_
     case V:                                                                                \
         *threads = B;                                                                      \
         *tile_samples = 2ull * B * U;                                                      \
-        *stash_lds = (size_t)(B / kWave) * papr_sweep_slice_floats(U) * sizeof(float) + 16; \
+        *stash_lds = (size_t)(B / kWave) * papr_sweep_slice_floats(U) * ((SM & 32) ? 2 : 1) * sizeof(float) + 16; \
         return 0;
         PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X)
 #undef X
@@ -1906,8 +1963,11 @@ int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_
 
 #ifdef PAPR_MEASURE  // (tools/ablation_probe.py)
 #define PAPR_FOR_EACH_ABLATION(X) X(60, 1) X(61, 2) X(62, 3) X(63, 4) X(64, 8) X(65, 16) X(66, 63) X(67, 32) X(68, 7) X(69, 24)
+// (the same of <256, 8>: eight loads in flight per lane, two workgroups per CU — the geometry a stripped kernel reads fastest in)
+#define PAPR_FOR_EACH_ABLATION2(X) X(90, 1) X(91, 2) X(92, 3) X(94, 8) X(95, 16) X(97, 32) X(98, 7) X(99, 24)
 #else
 #define PAPR_FOR_EACH_ABLATION(X)
+#define PAPR_FOR_EACH_ABLATION2(X)
 #endif
 
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
@@ -1940,6 +2000,14 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
                            table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                                            \
         break;
         PAPR_FOR_EACH_ABLATION(X)
+#undef X
+#define X(V, A)                                                                                                      \
+    case V:                                                                                                           \
+        launch_maybe_timed((papr_sweep_kernel<256, 8, true, 0, A>), dim3(blocks), dim3(256), lds_bytes, st,           \
+                           (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                     \
+        break;
+        PAPR_FOR_EACH_ABLATION2(X)
 #undef X
 #define X(V, B, U, PP)                                                                                               \
     case V:                                                                                                           \
@@ -2033,6 +2101,11 @@ void papr_sweep_prepare_device(void)
     (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<1024, 4, true, 0, A>,                                  \
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
     PAPR_FOR_EACH_ABLATION(X)
+#undef X
+#define X(V, A)                                                                                                      \
+    (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<256, 8, true, 0, A>,                                   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    PAPR_FOR_EACH_ABLATION2(X)
 #undef X
 #define X(V, B, U, PP)                                                                                               \
     (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<B, U, true, PP, 0, true>,                              \

@@ -141,6 +141,13 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
             const int waves = vblock / 64;
             bands.P.copies = (uint32_t)(ctx->tune.hist_copies > 0 ? std::min(ctx->tune.hist_copies, waves) : std::min(waves, 4));
         }
+        if (PAPR_SWEEP_VARIANT_HAS_HIST_SETS(run->variant)) {
+            // [bin][copy] histogram: as many copies (a power of two, at most 32) as 16 KiB hold
+            uint32_t c = 32;
+            while (c > 1 && (size_t)c * run->nbins * 4 > 16 * 1024)
+                c >>= 1;
+            bands.P.copies = c;
+        }
         bands.lds_bytes = (size_t)bands.P.table_words * 4 + (size_t)bands.P.copies * run->nbins * 4;
         if (bands.lds_bytes + run->stash_lds > lds_cap)
             return PAPR_OK;
@@ -283,7 +290,7 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
     for (uint32_t b = 1; b < run.nbins; b += 2)
         in_bands += H[b];
     // (a workgroup that gave up — papr_sweep.hip sweep_give_up — leaves both numbers meaningless: `overflow` says so)
-    if (in_bands != stash_count && !overflow && !(run.variant >= 60 && run.variant <= 69))  // (ablation launches: timing only)
+    if (in_bands != stash_count && !overflow && !((run.variant >= 60 && run.variant <= 69) || (run.variant >= 90 && run.variant <= 99)))  // (ablation launches: timing only)
         return fail(ctx, PAPR_E_INTERNAL, "one-sweep invariant broken: %llu samples binned inside bands, %llu stashed",
                     (unsigned long long)in_bands, (unsigned long long)stash_count);
     const size_t m = run.gkeys.size();
@@ -363,12 +370,16 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     const size_t lds_cap = (size_t)papr_ccdf_max_dynamic_lds();
     // LDS for table + histogram copies: what the launch is given, and what the device-side plan has to fit into
     const size_t table_lds = exact ? (lds_cap - 2048 > run.stash_lds ? lds_cap - 2048 - run.stash_lds : 0)
-                                   : (size_t)(48 * 1024 + 32) + (((size_t)kCopies * kBinsMax + 3) & ~(size_t)3) * 4;
+                                   : (size_t)((PAPR_SWEEP_VARIANT_IS_LUT2(run.variant) ? 48 : 40) * 1024 + 32) +
+                                         (((size_t)kCopies * kBinsMax + 3) & ~(size_t)3) * 4;  // (one-edge table: <= 40 KiB)
     if (table_lds < 16 * 1024 || table_lds + run.stash_lds > lds_cap)
         return PAPR_OK;
     const uint32_t table_cap_words = exact ? (uint32_t)(table_lds / 4) : 48 * 1024 / 4 + 8;
+    // (the workgroup's share of the CU's LDS: 80 bytes per thread where several are resident, everything for a persistent one)
     const uint32_t soft_lds = exact ? (uint32_t)table_lds
-                                    : (uint32_t)std::max<long long>(0, (long long)vblock * 80 - (long long)run.stash_lds);
+                              : PAPR_SWEEP_VARIANT_IS_PERSISTENT(run.variant)
+                                  ? (uint32_t)(lds_cap - 2048 - run.stash_lds)
+                                  : (uint32_t)std::max<long long>(0, (long long)vblock * 80 - (long long)run.stash_lds);
     run.seg_off = kBinsMax;
     // ---- estimate geometry (as papr_hip_estimate) ----
     uint64_t ratio = ctx->tune.estimate_ratio > 0 ? (uint64_t)ctx->tune.estimate_ratio : (uint64_t)kEstimateRatio;

@@ -68,7 +68,8 @@ def test_sweep_equals_oracle_sizes(pkg, orc, gpu, n, graph):
 
 
 @pytest.mark.parametrize("tune", [dict(sweep_variant=v, sweep_blocks=b, sweep_map=m)
-                                  for v, b, m in [(1, 96, 1), (1, 1000, 2), (4, 7, 0), (4, 1, 0), (4, 0, 2), (8, 0, 0),
+                                  for v, b, m in [(40, 0, 0), (40, 7, 0), (40, 1, 0), (40, 700, 2), (40, 300, 1),
+                                                  (1, 96, 1), (1, 1000, 2), (4, 7, 0), (4, 1, 0), (4, 0, 2), (4, 0, 0), (8, 0, 0),
                                                   (8, 64, 2), (13, 0, 0), (13, 1536, 2), (13, 300, 1), (14, 0, 0),
                                                   (14, 8, 2), (20, 0, 0), (20, 96, 1), (24, 0, 0), (24, 7, 2),
                                                   (32, 0, 0), (32, 3, 0), (41, 0, 0), (41, 100, 0)]] +
@@ -86,7 +87,7 @@ def test_sweep_geometries_agree(pkg, orc, gpu, tune):
             st, table, counts, info = one_sweep(pkg, gpu, graph)
             check_stats(st, ref)
             assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
-            if tune.get("sweep_band_log2", 14) >= 14 or tune.get("sweep_variant", 4) >= 20:   # (narrower bands need a finer one-edge LUT than fits: plain pass 1)
+            if tune.get("sweep_band_log2", 14) >= 14 or 20 <= tune.get("sweep_variant", 40) < 40 or tune.get("sweep_variant", 40) == 41:   # (narrower bands need a finer one-edge LUT than fits: plain pass 1)
                 assert info.swept == 1 and info.resolved == 1, info.as_dict()
     finally:
         gpu.set_tuning()
@@ -103,7 +104,8 @@ def test_sweep_first_index_wins(pkg, orc, gpu):
         iq[2 * s] = 9.5
         iq[2 * s + 1] = -9.5
     gpu.upload(iq)
-    for tune in (dict(), dict(sweep_variant=1, sweep_blocks=3), dict(sweep_variant=8, sweep_map=2), dict(sweep_variant=20),
+    for tune in (dict(), dict(sweep_variant=40, sweep_blocks=3), dict(sweep_variant=4), dict(sweep_variant=1, sweep_blocks=3),
+                 dict(sweep_variant=8, sweep_map=2), dict(sweep_variant=20),
                  dict(sweep_variant=32), dict(sweep_variant=41, sweep_blocks=5)):
         gpu.set_tuning(**tune)
         st, table, counts, info = one_sweep(pkg, gpu, False)

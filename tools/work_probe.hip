@@ -1,0 +1,194 @@
+// work_probe — how much of the HBM read ceiling survives a given amount of per-sample work, geometry by geometry.
+// A synthetic kernel with the sweep's access pattern (16 B per lane, U loads in flight, grid-stride tiles, nt) and a
+// selectable instruction mix of the sweep's KIND but none of its logic:
+//   W0  xor of the dwords                                   (tools/hbm_read_probe.hip's kernel: the read ceiling)
+//   W1  power (2 mul + 1 add, no FMA) + per-lane double sum  (pass 1 without trackers)
+//   W2  W1 + one LDS table lookup (ds_read_b64) + compare + one LDS histogram atomic per sample   (pass 2's binning)
+//   W3  W2 + 6 integer VALU per sample (stand-in for trackers + stash test)
+//   W4  W3 + 8 more                                          (beyond the sweep's 21.8 VALU per sample)
+// Measurement tool only; one JSON line per configuration.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/work_probe.hip -o bin/work_probe
+//   bin/work_probe [GiB=10] [rounds=8]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kCells = 4096;  // 32 KiB table, as the sweep's one-edge LUT
+constexpr int kBins = 64;
+
+template <int BLOCK, int U, int W>
+__global__ __launch_bounds__(BLOCK) void work_kernel(const f32x4 *__restrict__ data, uint64_t ntiles, const uint2 *__restrict__ table,
+                                                     unsigned long long *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint2 *lut = reinterpret_cast<uint2 *>(smem);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lut + kCells);
+    if (W >= 2) {
+        for (int k = threadIdx.x; k < kCells; k += BLOCK)
+            lut[k] = table[k];
+        for (int k = threadIdx.x; k < 4 * kBins; k += BLOCK)
+            hist[k] = 0;
+        __syncthreads();
+    }
+    uint32_t *my = hist + ((threadIdx.x / 64) & 3) * kBins;
+    const f32x4 *p = data + (uint64_t)blockIdx.x * (BLOCK * U) + threadIdx.x;
+    const uint64_t step = (uint64_t)gridDim.x * (BLOCK * U);
+    unsigned acc = 0, a1 = 0, a2 = 0;
+    double sum = 0.0;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x, p += step) {
+        f32x4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            x[u] = __builtin_nontemporal_load(p + u * BLOCK);
+        if (W == 0) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                acc ^= __float_as_uint(x[u].x) ^ __float_as_uint(x[u].y) ^ __float_as_uint(x[u].z) ^ __float_as_uint(x[u].w);
+            continue;
+        }
+        float pw[2 * U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            pw[2 * u] = __fadd_rn(__fmul_rn(x[u].x, x[u].x), __fmul_rn(x[u].y, x[u].y));
+            pw[2 * u + 1] = __fadd_rn(__fmul_rn(x[u].z, x[u].z), __fmul_rn(x[u].w, x[u].w));
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * U; j++)
+            sum += (double)pw[j];
+        if (W >= 2) {
+            uint2 e[2 * U];
+#pragma unroll
+            for (int j = 0; j < 2 * U; j++)
+                e[j] = lut[(__float_as_uint(pw[j]) >> 17) & (kCells - 1)];
+#pragma unroll
+            for (int j = 0; j < 2 * U; j++) {
+                const uint32_t k = (e[j].x + (__float_as_uint(pw[j]) >= e[j].y ? 1u : 0u)) & (kBins - 1);
+                atomicAdd(&my[k], 1u);
+            }
+        }
+        if (W >= 3) {
+#pragma unroll
+            for (int j = 0; j < 2 * U; j++) {
+                const uint32_t b = __float_as_uint(pw[j]);
+                a1 = max(a1, b);                 // 1
+                a2 = min(a2 ^ 0x55u, b >> 3);    // 3
+                acc += (b >> 7) & 0x1ffu;        // 2 (v_bfe + add)
+            }
+        }
+        if (W >= 4) {
+#pragma unroll
+            for (int j = 0; j < 2 * U; j++) {
+                uint32_t b = __float_as_uint(pw[j]);
+                b = (b ^ (b >> 5)) + a1;         // 3
+                b = (b ^ (b << 9)) + a2;         // 3
+                acc ^= b + (b >> 11);            // 2-3
+            }
+        }
+    }
+    unsigned long long r = acc ^ a1 ^ a2 ^ (unsigned long long)__double_as_longlong(sum);
+    if (W >= 2) {
+        __syncthreads();
+        if (threadIdx.x < kBins)
+            r += hist[threadIdx.x] + hist[kBins + threadIdx.x] + hist[2 * kBins + threadIdx.x] + hist[3 * kBins + threadIdx.x];
+    }
+    if (r == 0x123456789abcull)
+        out[0] = r;  // keeps everything alive
+}
+
+__global__ void fill_kernel(float *p, uint64_t n)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned h = (unsigned)(k * 2654435761u);
+        p[k] = (float)((int)(h >> 8) - (1 << 23)) * (1.0f / (1 << 23));  // (-1, 1)
+    }
+}
+
+__global__ void table_kernel(uint2 *t)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < kCells)
+        t[k] = make_uint2((unsigned)(k * 7) & 63u, ((unsigned)k << 17) | 0x8000u);
+}
+
+template <int BLOCK, int U, int W>
+static void run(const void *d, size_t bytes, const uint2 *table, unsigned long long *out, int blocks, int rounds)
+{
+    const uint64_t ntiles = bytes / ((size_t)BLOCK * U * 16);
+    const size_t lds = W >= 2 ? kCells * 8 + 4 * kBins * 4 : 0;
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    std::vector<float> ms;
+    for (int r = 0; r < rounds + 2; r++) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((work_kernel<BLOCK, U, W>), dim3(blocks), dim3(BLOCK), lds, 0, (const f32x4 *)d, ntiles, table, out);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float t;
+        hipEventElapsedTime(&t, a, b);
+        if (r >= 2)
+            ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    const double used = (double)ntiles * BLOCK * U * 16;
+    printf("{\"probe\": \"work\", \"W\": %d, \"block\": %d, \"unroll\": %d, \"blocks\": %d, \"median_ms\": %.4f, \"min_ms\": %.4f, "
+           "\"GB/s_median\": %.1f}\n",
+           W, BLOCK, U, blocks, ms[ms.size() / 2], ms[0], used / ms[ms.size() / 2] / 1e6);
+    fflush(stdout);
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+}
+
+template <int BLOCK, int U>
+static void run_all(const void *d, size_t bytes, const uint2 *table, unsigned long long *out, int blocks, int rounds)
+{
+    run<BLOCK, U, 0>(d, bytes, table, out, blocks, rounds);
+    run<BLOCK, U, 1>(d, bytes, table, out, blocks, rounds);
+    run<BLOCK, U, 2>(d, bytes, table, out, blocks, rounds);
+    run<BLOCK, U, 3>(d, bytes, table, out, blocks, rounds);
+    run<BLOCK, U, 4>(d, bytes, table, out, blocks, rounds);
+}
+
+int main(int argc, char **argv)
+{
+    const double gib = argc > 1 ? atof(argv[1]) : 10.0;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 8;
+    const size_t bytes = (size_t)(gib * (1 << 30)) / 131072 * 131072;
+    void *d;
+    uint2 *table;
+    unsigned long long *out;
+    if (hipMalloc(&d, bytes) != hipSuccess || hipMalloc((void **)&out, 8) != hipSuccess ||
+        hipMalloc((void **)&table, kCells * 8) != hipSuccess) {
+        fprintf(stderr, "hipMalloc failed\n");
+        return 1;
+    }
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (float *)d, bytes / 4);
+    hipLaunchKernelGGL(table_kernel, dim3(kCells / 256), dim3(256), 0, 0, table);
+    hipDeviceSynchronize();
+    int cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) == hipSuccess)
+        cus = prop.multiProcessorCount;
+    // workgroups per CU x geometry
+    run_all<256, 8>(d, bytes, table, out, 2 * cus, rounds);
+    run_all<256, 8>(d, bytes, table, out, 3 * cus, rounds);
+    run_all<256, 8>(d, bytes, table, out, 4 * cus, rounds);
+    run_all<256, 4>(d, bytes, table, out, 4 * cus, rounds);
+    run_all<256, 4>(d, bytes, table, out, 8 * cus, rounds);
+    run_all<512, 4>(d, bytes, table, out, 2 * cus, rounds);
+    run_all<512, 4>(d, bytes, table, out, 4 * cus, rounds);
+    run_all<512, 8>(d, bytes, table, out, 1 * cus, rounds);
+    run_all<512, 8>(d, bytes, table, out, 2 * cus, rounds);
+    run_all<1024, 4>(d, bytes, table, out, 1 * cus, rounds);
+    run_all<1024, 4>(d, bytes, table, out, 2 * cus, rounds);
+    run_all<1024, 4>(d, bytes, table, out, 4 * cus, rounds);
+    run_all<1024, 2>(d, bytes, table, out, 4 * cus, rounds);
+    run_all<1024, 8>(d, bytes, table, out, 1 * cus, rounds);
+    return 0;
+}
