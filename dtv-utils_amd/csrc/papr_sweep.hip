@@ -149,6 +149,7 @@ struct WaveStashT {
     unsigned long long *gave_up;        // device counter of give-ups
     unsigned long long *seg_real;       // LDS: powers stashed without padding (SP16)
     uint32_t trash = 0;                 // NOBR: this lane's own word at the end of the slice, where what is not in band goes
+    uint32_t sbase = 0, sbytes = 0;     // NOBR: LDS byte address of the slice, and of its next free slot (wave-uniform)
 
     __device__ __forceinline__ void put(float pw, bool take)
     {
@@ -156,12 +157,19 @@ struct WaveStashT {
             // no branch at all: every lane writes — its power to its slot, or to its own trash word (a wave with only two
             // waves per SIMD beside it cannot hide a v_cmp -> s_cbranch round per sample)
             // (the select is written out: from `take ? at : trash` hipcc makes an exec-masked region per sample)
+            // Addresses in bytes: slot = rank among the takers * 4 + (slice base + nfill * 4), the bracket wave-uniform
+            // (one SALU op, one scalar operand of the v_lshl_add) — no copy of nfill into a vector register per sample.
             const unsigned long long m = __ballot(take);
-            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, nfill));
-            uint32_t dest;
-            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(dest) : "v"(trash), "v"(at), "s"(m));
-            buf[dest] = pw;
-            nfill += (uint32_t)__popcll(m);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            // (sbytes: the LDS address of the next free slot, wave-uniform.  Both steps are written out: hipcc turns the
+            // byte address back into base + 4 * (count + rank), one more vector addition per sample)
+            uint32_t a_slot;
+            asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a_slot) : "v"(rank), "s"(__builtin_amdgcn_readfirstlane(sbytes)));
+            const uint32_t a_trash = (uint32_t)(uintptr_t)(lds_u32 *)&buf[trash];
+            uint32_t a;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a) : "v"(a_trash), "v"(a_slot), "s"(m));
+            *(__attribute__((address_space(3))) float *)(uintptr_t)a = pw;
+            asm("s_lshl2_add_u32 %0, %1, %2" : "=s"(sbytes) : "s"((uint32_t)__popcll(m)), "s"(__builtin_amdgcn_readfirstlane(sbytes)));
         } else if constexpr (BALLOT) {
             const unsigned long long m = __ballot(take);
             if (m) {  // (wave-uniform)
@@ -180,7 +188,12 @@ struct WaveStashT {
     __device__ __forceinline__ void spill_if_above(uint32_t limit, uint32_t folded)
     {
         uint32_t n;
-        if constexpr (BALLOT) {
+        if constexpr (BALLOT && NOBR) {
+            n = (sbytes - sbase) >> 2;
+            if (n <= limit)
+                return;
+            sbytes = sbase;
+        } else if constexpr (BALLOT) {
             n = nfill;
             if (n <= limit)
                 return;
@@ -884,6 +897,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
                         &seg_fill, seg_cap, tab, P.table_words, LUT2 ? PAPR_LUT2_NEVER : 0u, seg_fill, gave_up,
                         &seg_real_sh};
     ws.trash = SLICE - kWave + (t & (kWave - 1));
+    ws.sbase = ws.sbytes = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u32 *)ws.buf);
     // cell index straight from the bit pattern: lut_biased[cell] with cell clamped to [cell_lo - 1, cell_lo + ncells]
     const int32_t cell_last = (int32_t)(P.cell_lo + P.ncells);
     int32_t cell_first;  // pinned in a VGPR for the whole kernel (v_med3 takes one scalar operand)
@@ -926,8 +940,14 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
         float pw[2 * U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            pw[2 * u] = power_of(x[u].x, x[u].y);
-            pw[2 * u + 1] = power_of(x[u].z, x[u].w);
+            // power_of, with the addition written out: hipcc multiplies (I, Q) as a pair (v_pk_mul_f32: the two squares
+            // are where the sum needs them) but then also pairs the ADDITIONS of two samples, which costs three
+            // v_mov per float4 to line the operands up — as many instructions as it saves
+            typedef float f32x2v __attribute__((ext_vector_type(2)));
+            const f32x2v a = {x[u].x, x[u].y}, b = {x[u].z, x[u].w};
+            const f32x2v aa = a * a, bb = b * b;  // (two IEEE multiplications each; nothing to contract: -ffp-contract=off)
+            asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u]) : "v"(aa.x), "v"(aa.y));
+            asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u + 1]) : "v"(bb.x), "v"(bb.y));
         }
         if constexpr (!(ABL & 16)) {
 #pragma unroll
@@ -1897,7 +1917,8 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
 int papr_sweep_variant(int variant)
 {
 #ifdef PAPR_MEASURE
-    if ((variant >= 60 && variant <= 69) || (variant >= 90 && variant <= 99 && variant != 93 && variant != 96))
+    if ((variant >= 60 && variant <= 69) || (variant >= 90 && variant <= 99 && variant != 93 && variant != 96) ||
+        (variant >= 120 && variant <= 129 && variant != 123 && variant != 126))
         return variant;  // ablations of <1024, 4> / <256, 8> (measurement only)
 #endif
     switch (variant) {
@@ -1923,6 +1944,8 @@ int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_
         variant = 4;
     if (variant >= 90 && variant <= 99)
         variant = 0;
+    if (variant >= 120 && variant <= 129)
+        variant = 40;
     switch (variant) {
 #define X(V, PW, NB, LU, D)                                                                                      \
     case V:                                                                                                       \
@@ -1965,9 +1988,12 @@ int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_
 #define PAPR_FOR_EACH_ABLATION(X) X(60, 1) X(61, 2) X(62, 3) X(63, 4) X(64, 8) X(65, 16) X(66, 63) X(67, 32) X(68, 7) X(69, 24)
 // (the same of <256, 8>: eight loads in flight per lane, two workgroups per CU — the geometry a stripped kernel reads fastest in)
 #define PAPR_FOR_EACH_ABLATION2(X) X(90, 1) X(91, 2) X(92, 3) X(94, 8) X(95, 16) X(97, 32) X(98, 7) X(99, 24)
+// (and of the default, <512, 8> with the branch-free stash)
+#define PAPR_FOR_EACH_ABLATION3(X) X(120, 1) X(121, 2) X(122, 3) X(124, 8) X(125, 16) X(127, 32) X(128, 7) X(129, 24)
 #else
 #define PAPR_FOR_EACH_ABLATION(X)
 #define PAPR_FOR_EACH_ABLATION2(X)
+#define PAPR_FOR_EACH_ABLATION3(X)
 #endif
 
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
@@ -2008,6 +2034,14 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
                            table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                     \
         break;
         PAPR_FOR_EACH_ABLATION2(X)
+#undef X
+#define X(V, A)                                                                                                      \
+    case V:                                                                                                           \
+        launch_maybe_timed((papr_sweep_kernel<512, 8, true, 0, A, false, 43>), dim3(blocks), dim3(512), lds_bytes, st, \
+                           (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                     \
+        break;
+        PAPR_FOR_EACH_ABLATION3(X)
 #undef X
 #define X(V, B, U, PP)                                                                                               \
     case V:                                                                                                           \
@@ -2106,6 +2140,11 @@ void papr_sweep_prepare_device(void)
     (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<256, 8, true, 0, A>,                                   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
     PAPR_FOR_EACH_ABLATION2(X)
+#undef X
+#define X(V, A)                                                                                                      \
+    (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<512, 8, true, 0, A, false, 43>,                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    PAPR_FOR_EACH_ABLATION3(X)
 #undef X
 #define X(V, B, U, PP)                                                                                               \
     (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<B, U, true, PP, 0, true>,                              \

@@ -290,7 +290,7 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
     for (uint32_t b = 1; b < run.nbins; b += 2)
         in_bands += H[b];
     // (a workgroup that gave up — papr_sweep.hip sweep_give_up — leaves both numbers meaningless: `overflow` says so)
-    if (in_bands != stash_count && !overflow && !((run.variant >= 60 && run.variant <= 69) || (run.variant >= 90 && run.variant <= 99)))  // (ablation launches: timing only)
+    if (in_bands != stash_count && !overflow && !((run.variant >= 60 && run.variant <= 69) || (run.variant >= 90 && run.variant <= 99) || (run.variant >= 120 && run.variant <= 129)))  // (ablation launches: timing only)
         return fail(ctx, PAPR_E_INTERNAL, "one-sweep invariant broken: %llu samples binned inside bands, %llu stashed",
                     (unsigned long long)in_bands, (unsigned long long)stash_count);
     const size_t m = run.gkeys.size();
