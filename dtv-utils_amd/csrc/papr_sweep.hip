@@ -1232,7 +1232,7 @@ namespace {
 
 // BALLOT: the ring is this wave's alone, so its head can live in a scalar register and slots be handed out by
 // ballot + mbcnt — no returning LDS atomic (which hipcc expands into a dozen instructions) per in-band sample
-template <uint32_t RING, int WT, bool BALLOT = false>
+template <uint32_t RING, int WT, bool BALLOT = false, bool NOBR = false>
 struct StashRing {
     uint32_t nhead = 0;               // BALLOT: slots handed out so far (wave-uniform)
     float *ring;                      // this wave's ring in LDS (RING floats, 16-byte aligned)
@@ -1248,6 +1248,7 @@ struct StashRing {
     unsigned long long *gave_up;      // device counter of give-ups
     uint32_t folded;                  // samples this workgroup has folded in this launch, about (kept by the kernel)
     bool give_up;                     // wave-uniform: this wave found the bands too full (see sweep_give_up)
+    uint32_t ring_addr = 0, trash_addr = 0;  // NOBR: LDS byte address of the ring (wave-uniform) / of this lane's trash word
 
     __device__ __forceinline__ void give_up_if_asked()
     {
@@ -1284,7 +1285,17 @@ struct StashRing {
     }
     __device__ __forceinline__ void put(float pw, bool take)
     {
-        if constexpr (BALLOT) {
+        if constexpr (BALLOT && NOBR) {
+            // no branch, no exec-masked region (as WaveStashT's): what is not in band goes to the lane's trash word
+            const unsigned long long m = __ballot(take);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint32_t at = (nhead + rank) & (RING - 1);
+            uint32_t a_slot, a;
+            asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a_slot) : "v"(at), "s"(__builtin_amdgcn_readfirstlane(ring_addr)));
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a) : "v"(trash_addr), "v"(a_slot), "s"(m));
+            *(__attribute__((address_space(3))) float *)(uintptr_t)a = pw;
+            nhead += (uint32_t)__popcll(m);
+        } else if constexpr (BALLOT) {
             const unsigned long long m = __ballot(take);
             if (m) {  // (wave-uniform)
                 const uint32_t at = nhead + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -1575,8 +1586,14 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
     const uint2 *lut_biased = reinterpret_cast<const uint2 *>(tab) - ((int32_t)P.cell_lo - 1);
     uint32_t *my = hist + (wave % P.copies) * nbins;
     constexpr bool BALLOT = (WTB & 16) != 0;  // stash slots by ballot + mbcnt instead of a returning LDS atomic
+    // ... and no branch / exec-masked region per sample (bin 0 and out-of-band powers go to a trash word).  Measured
+    // (variant 31, `make MEASURE=1`): the exact kernel is VALU-bound — 38 VALU per sample, the two double-precision chains at
+    // half rate — and executing the stash code for every sample costs more than its branches: 1.916 against 1.851 ms
+    // (-g: 2.057 against 2.090)
+    constexpr bool NOBR = (WTB & 64) != 0;
     static_assert(!(BALLOT && BATCHED), "the batched reservation is an LDS atomic");
-    StashRing<RING, (WTB & 3), BALLOT> ws{0u, rings + wave * RING,
+    static_assert(!NOBR || (BALLOT && EXACT), "the trash word is the lane's first transposition slot");
+    StashRing<RING, (WTB & 3), BALLOT, NOBR> ws{0u, rings + wave * RING,
                            &ring_head[wave],
                            0u,
                            p.stash + (uint64_t)blockIdx.x * p.seg_cap,
@@ -1601,9 +1618,21 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
         const uint32_t off = __float_as_uint(pw) & offmask;
         return (e.x >> PAPR_LUT2_OFF_BITS) + (off >= (e.x & PAPR_LUT2_NEVER) ? 1u : 0u) + (off >= e.y ? 1u : 0u);
     };
+    if constexpr (NOBR) {
+        // the lane's own first transposition slot: read (by this lane only) before anything of the segment is folded
+        ws.ring_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u32 *)ws.ring);
+        ws.trash_addr = (uint32_t)(uintptr_t)(lds_u32 *)(xpose + wave * (kWave * 8) + xpose_slot((int)lane, 0));
+    }
     auto count_and_stash = [&](float pw, uint32_t k) {
-        if (k)
+        if constexpr (NOBR) {
+            const unsigned long long nz = __ballot(k != 0u);
+            const uint32_t a_bin = (uint32_t)(uintptr_t)(lds_u32 *)&my[k];
+            uint32_t a;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a) : "v"(ws.trash_addr), "v"(a_bin), "s"(nz));
+            (void)__hip_atomic_fetch_add((lds_u32 *)(uintptr_t)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (k) {
             atomicAdd(&my[k], 1u);
+        }
         ws.put(pw, (k & 1u) != 0u);
     };
 
@@ -2066,12 +2095,13 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
 // next-segment prefetch, exact-sum pairs, stash store policy (0 plain, 1 nontemporal, 2 write-through).
 #ifdef PAPR_MEASURE
 #define PAPR_FOR_EACH_SWEEP2_VARIANT(X)                                                                         \
-    X(32, 16, 8, 0, false, 2) X(34, 16, 4, 0, false, 2) X(35, 16, 4, 1, false, 2) X(40, 12, 8, 0, false, 2)      \
+    X(32, 16, 8, 0, false, 2) X(34, 16, 4, 0, false, 2) X(35, 16, 4, 1, false, 2) X(30, 12, 8, 0, false, 2)      \
     X(41, 12, 8, 1, false, 2) X(42, 8, 4, 1, false, 2) X(44, 16, 8, 0, false, 6) X(45, 12, 8, 1, false, 6)       \
     X(48, 12, 8, 0, true, 2) X(49, 12, 8, 0, true, 6) X(50, 12, 8, 0, true, 10) X(51, 12, 8, 0, true, 0)         \
     X(52, 12, 8, 0, true, 14) X(54, 11, 8, 0, true, 10) X(55, 12, 8, 0, true, 18) X(56, 12, 8, 0, true, 26)                \
     X(57, 16, 8, 0, false, 18) X(58, 12, 8, 1, false, 18) X(59, 12, 8, 0, true, 50) X(53, 12, 8, 0, true, 16)        \
-    X(46, 12, 8, 0, true, 17) X(47, 12, 8, 0, true, 58) X(43, 14, 8, 0, true, 26) X(33, 13, 8, 0, true, 26)
+    X(46, 12, 8, 0, true, 17) X(47, 12, 8, 0, true, 58) X(43, 14, 8, 0, true, 26) X(33, 13, 8, 0, true, 26)       \
+    X(31, 12, 8, 0, true, 90) X(29, 12, 8, 0, true, 82)
 #else  // 56: the exact-sum default (ballot ring, lean sum); 48: its first form (returning-atomic ring, separate sum);
        // 32 / 41: the kernel without the pairs (tests)
 #define PAPR_FOR_EACH_SWEEP2_VARIANT(X) \
