@@ -31,7 +31,8 @@ struct ts_scan_params {
 
 void ts_kernels_prepare_device(void);
 // unroll: packets per lane between two workgroup barriers (1, 2 or 4)
-void ts_launch_scan(hipStream_t st, int blocks, int unroll, const ts_scan_params &p);
+void ts_launch_scan(hipStream_t st, int blocks, int unroll, int block, int agg, const ts_scan_params &p);
+int ts_scan_form_exists(int unroll, int block, int agg); /* 1 if that (packets per lane, workgroup size, aggregated update) form is built */
 void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t nspans, uint64_t packet_base, uint32_t *g_count,
                      unsigned long long *g_first, unsigned long long *g_last, unsigned long long *taken_out);
 void ts_launch_generate(hipStream_t st, void *out, uint64_t nunits, uint32_t unit, uint64_t seed, int hdmv);

@@ -20,14 +20,18 @@
 
 namespace {
 
-constexpr int kBlock = 1024;
 constexpr int kMergeBlock = 256;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 }  // namespace
 
-// UNR = packets per lane between two workgroup barriers (their header loads are in flight together).
-template <int UNR>
+// UNR = packets per lane between two workgroup barriers (their header loads are in flight together); kBlock = threads.
+// AGG: the per-PID tables are updated once per (wave, PID) instead of once per packet — a transport stream is a
+// handful of PIDs, one of them most of the packets, so 64 lanes adding to the same three LDS words is the common case:
+// the wave takes the PID of its lowest unserved lane, ballots who else has it (count = popcount; the unit numbers grow
+// with the lane, so first = the lowest of them, last = the highest), lets that one lane do the three atomics, and goes
+// on with who is left; after eight rounds the remaining lanes (a wave full of different PIDs) update one by one.
+template <int UNR, int kBlock, bool AGG>
 __global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t ts_smem[];  // 3 x TS_PIDS words = 96 KiB (one workgroup per CU)
@@ -100,9 +104,37 @@ __global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
 #pragma unroll
         for (int r = 0; r < UNR; r++) {
             const uint64_t j = jb + (uint64_t)r * kBlock + t;
+            if constexpr (AGG) {
+                const uint32_t rel_all = (uint32_t)j;
+                const bool counts = j < j1 && (uint32_t)(j - j0) < stop && tei[r] == 0;
+                unsigned long long todo = __ballot(counts);
+                const uint32_t lane = t & 63u;
+                for (int round = 0; todo != 0ull; round++) {  // (wave-uniform)
+                    if (round == 8) {  // a wave full of different PIDs: the rest one by one
+                        if ((todo >> lane) & 1ull) {
+                            atomicAdd(&s_count[pid[r]], 1u);
+                            atomicMin(&s_first[pid[r]], rel_all);
+                            atomicMax(&s_last[pid[r]], rel_all);
+                        }
+                        break;
+                    }
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const uint32_t lp = (uint32_t)__builtin_amdgcn_readlane((int)pid[r], leader);
+                    const unsigned long long same = __ballot(counts && pid[r] == lp);
+                    const int top = 63 - __clzll((long long)same);
+                    const uint32_t rel_lo = (uint32_t)__builtin_amdgcn_readlane((int)rel_all, leader);
+                    const uint32_t rel_hi = (uint32_t)__builtin_amdgcn_readlane((int)rel_all, top);
+                    if ((int)lane == leader) {
+                        atomicAdd(&s_count[lp], (uint32_t)__popcll(same));
+                        atomicMin(&s_first[lp], rel_lo);
+                        atomicMax(&s_last[lp], rel_hi);
+                    }
+                    todo &= ~same;
+                }
+            }
             if (j < j1 && (uint32_t)(j - j0) < stop) {
                 const uint32_t rel = (uint32_t)j;  // unit number within the launch (a launch takes < 2^32 units)
-                if (tei[r] == 0) {
+                if (!AGG && tei[r] == 0) {
                     atomicAdd(&s_count[pid[r]], 1u);
                     atomicMin(&s_first[pid[r]], rel);
                     atomicMax(&s_last[pid[r]], rel);
@@ -224,23 +256,45 @@ __global__ __launch_bounds__(256) void ts_generate_kernel(unsigned char *__restr
     }
 }
 
+// the (packets per lane, workgroup size, aggregated update) forms that are built: the default and the measurement knobs
+// TS_SCAN_UNROLL / TS_SCAN_BLOCK / TS_SCAN_AGG of ts_runtime.cpp
+// (measured, tools/gpu_session45.sh: 1.213-1.233 ms for every non-aggregated form, 1.22-1.31 for the aggregated ones —
+// neither the LDS atomics nor the geometry is what holds the scan at 0.77-0.78 of peak on its header lines; the default
+// stays <1, 1024, false> and the rest is built by `make MEASURE=1` only)
+#ifdef PAPR_MEASURE
+#define TS_FOR_EACH_SCAN_FORM(X) \
+    X(1, 1024, false) X(2, 1024, false) X(4, 1024, false) X(1, 1024, true) X(2, 1024, true) X(4, 1024, true) \
+    X(2, 512, false) X(4, 512, false) X(8, 512, false) X(2, 512, true) X(4, 512, true) X(8, 512, true)
+#else
+#define TS_FOR_EACH_SCAN_FORM(X) X(1, 1024, false) X(2, 1024, false) X(4, 1024, false)
+#endif
+
 void ts_kernels_prepare_device(void)  // function attributes belong to the current device
 {
     const int lds = 3 * TS_PIDS * (int)sizeof(uint32_t);
-    (void)hipFuncSetAttribute((const void *)ts_scan_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)ts_scan_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)ts_scan_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#define X(U, B, A) (void)hipFuncSetAttribute((const void *)ts_scan_kernel<U, B, A>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    TS_FOR_EACH_SCAN_FORM(X)
+#undef X
 }
 
-void ts_launch_scan(hipStream_t st, int blocks, int unroll, const ts_scan_params &p)
+int ts_scan_form_exists(int unroll, int block, int agg)
+{
+#define X(U, B, A) if (unroll == U && block == B && (agg != 0) == A) return 1;
+    TS_FOR_EACH_SCAN_FORM(X)
+#undef X
+    return 0;
+}
+
+void ts_launch_scan(hipStream_t st, int blocks, int unroll, int block, int agg, const ts_scan_params &p)
 {
     const size_t lds = 3 * TS_PIDS * sizeof(uint32_t);
-    if (unroll == 1)
-        hipLaunchKernelGGL(ts_scan_kernel<1>, dim3(blocks), dim3(kBlock), lds, st, p);
-    else if (unroll == 2)
-        hipLaunchKernelGGL(ts_scan_kernel<2>, dim3(blocks), dim3(kBlock), lds, st, p);
-    else
-        hipLaunchKernelGGL(ts_scan_kernel<4>, dim3(blocks), dim3(kBlock), lds, st, p);
+#define X(U, B, A)                                                                                   \
+    if (unroll == U && block == B && (agg != 0) == A) {                                               \
+        hipLaunchKernelGGL((ts_scan_kernel<U, B, A>), dim3(blocks), dim3(B), lds, st, p);             \
+        return;                                                                                       \
+    }
+    TS_FOR_EACH_SCAN_FORM(X)
+#undef X
 }
 
 void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t nspans, uint64_t packet_base, uint32_t *g_count,

@@ -41,6 +41,7 @@ struct ts_hip_ctx {
     void *h_tables = nullptr;                               // pinned: count / first / last read back at the end
     int spans = 0;
     int unroll = 1;  // TS_SCAN_UNROLL (measurement knob): packets per lane between two barriers of the scan kernel
+    int block = 1024, agg = 0;  // TS_SCAN_BLOCK / TS_SCAN_AGG: threads per workgroup; per-(wave, PID) table updates
     hipEvent_t ev_a = nullptr, ev_m = nullptr, ev_b = nullptr;
 };
 
@@ -136,10 +137,16 @@ int ts_hip_open(ts_hip_ctx **out, int device)
     OPENCHK(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->spans = ctx->num_cus;  // one 1024-thread workgroup (96 KiB of LDS) per CU
-    if (const char *e = getenv("TS_SCAN_UNROLL")) {
-        const int u = atoi(e);
-        if (u == 1 || u == 2 || u == 4)
+    {   // measurement knobs: packets per lane between barriers, workgroup size, aggregated table update
+        int u = ctx->unroll, b = ctx->block, a = ctx->agg;
+        if (const char *e = getenv("TS_SCAN_UNROLL")) u = atoi(e);
+        if (const char *e = getenv("TS_SCAN_BLOCK")) b = atoi(e);
+        if (const char *e = getenv("TS_SCAN_AGG")) a = atoi(e) != 0;
+        if (ts_scan_form_exists(u, b, a)) {
             ctx->unroll = u;
+            ctx->block = b;
+            ctx->agg = a;
+        }
     }
     OPENCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     OPENCHK(hipMalloc((void **)&ctx->d_lists, (size_t)ctx->spans * TS_PIDS * sizeof(ts_wg_entry)));
@@ -353,7 +360,7 @@ int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
             p.merged_event_cap = kMergedEventCap;
             const int blocks = (int)std::min<uint64_t>((uint64_t)ctx->spans, (units + 1023) / 1024);
             TSCHK(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
-            ts_launch_scan(ctx->stream, blocks, ctx->unroll, p);
+            ts_launch_scan(ctx->stream, blocks, ctx->unroll, ctx->block, ctx->agg, p);
             TSCHK(ctx, hipEventRecord(ctx->ev_m, ctx->stream));
             ts_launch_merge(ctx->stream, p, (uint32_t)blocks, out->packets, ctx->d_count, ctx->d_first, ctx->d_last, ctx->d_taken);
             TSCHK(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
