@@ -97,8 +97,8 @@ __global__ __launch_bounds__(BLOCK) void work_kernel(const f32x4 *__restrict__ d
         if (threadIdx.x < kBins)
             r += hist[threadIdx.x] + hist[kBins + threadIdx.x] + hist[2 * kBins + threadIdx.x] + hist[3 * kBins + threadIdx.x];
     }
-    if (r == 0x123456789abcull)
-        out[0] = r;  // keeps everything alive
+    if ((uint32_t)r == 0x12345678u)
+        out[0] = r;  // keeps everything alive (32 bits: W0's result has no more)
 }
 
 __global__ void fill_kernel(float *p, uint64_t n)
