@@ -23,10 +23,15 @@
 // 4.6 % (-g), instead of 100 %.
 //
 // The stash is filled without workgroup barriers and without global atomics: every workgroup owns one
-// segment of the HBM stash, every wave owns a slice of LDS in which its lanes reserve slots for their
-// in-band powers with a returning LDS atomic; when a third of the slice is used the wave reserves a
-// range of the workgroup's segment with one more LDS atomic and writes it out coalesced.  (A single global counter serialises at ~11 ns per
-// reservation across the 8 XCDs — measured: it doubled the kernel time of the 0.1 dB table.)
+// segment of the HBM stash, every wave owns a slice of LDS in which its lanes get slots for their in-band
+// powers (default kernel: by ballot + mbcnt, without a branch; older forms: with a returning LDS atomic);
+// when the slice is about to run out the wave reserves a range of the workgroup's segment with one LDS
+// atomic and writes it out coalesced.  (A single global counter serialises at ~11 ns per reservation across
+// the 8 XCDs — measured: it doubled the kernel time of the 0.1 dB table.)
+//
+// The default form (variant 40) is papr_sweep_kernel<512, 8, ..., SMODE 43> launched as ONE persistent workgroup
+// per CU: eight waves per CU with eight 16-byte loads each in flight is what reads fastest, and with two waves
+// per SIMD the per-sample code has to be free of branches and exec-masked regions.
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -134,6 +139,9 @@ __device__ __forceinline__ void store16(float *p, f32x4s v)
 // MODE bit 0 (SP16): spill in 16-byte stores (a partial quad padded with quiet NaNs, which the recount ignores)
 // instead of dwords.  MODE bit 1 (BALLOT): the slice is this wave's alone, so its fill count can live in a scalar
 // register and slots be handed out by ballot + mbcnt — no returning LDS atomic (and no wait for it) per in-band sample.
+// MODE bit 3 (NOBR, with BALLOT): no branch and no exec-masked region per sample — every lane writes, its power to
+// its slot or to a trash word of its own at the end of the slice.  MODE bit 4: plain instead of write-through spill
+// stores (measurement).  (Bits 2 and 5 — histogram sets, double slice — belong to the kernel, not to this struct.)
 template <int MODE = 0>
 struct WaveStashT {
     static constexpr bool SP16 = (MODE & 1) != 0, BALLOT = (MODE & 2) != 0, NOBR = (MODE & 8) != 0;
