@@ -1595,12 +1595,12 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
     uint32_t *my = hist + (wave % P.copies) * nbins;
     constexpr bool BALLOT = (WTB & 16) != 0;  // stash slots by ballot + mbcnt instead of a returning LDS atomic
     // ... and no branch / exec-masked region per sample (bin 0 and out-of-band powers go to a trash word).  Measured
-    // (variant 31, `make MEASURE=1`): the exact kernel is VALU-bound — 38 VALU per sample, the two double-precision chains at
+    // (variants 28 / 29 / 31, `make MEASURE=1`): the exact kernel is VALU-bound — 38 VALU per sample, the two double-precision chains at
     // half rate — and executing the stash code for every sample costs more than its branches: 1.916 against 1.851 ms
     // (-g: 2.057 against 2.090)
-    constexpr bool NOBR = (WTB & 64) != 0;
+    constexpr bool NOBR_HIST = (WTB & 64) != 0, NOBR = (WTB & 128) != 0;  // (histogram / stash without a branch, separately)
     static_assert(!(BALLOT && BATCHED), "the batched reservation is an LDS atomic");
-    static_assert(!NOBR || (BALLOT && EXACT), "the trash word is the lane's first transposition slot");
+    static_assert(!(NOBR || NOBR_HIST) || (BALLOT && EXACT), "the trash word is the lane's first transposition slot");
     StashRing<RING, (WTB & 3), BALLOT, NOBR> ws{0u, rings + wave * RING,
                            &ring_head[wave],
                            0u,
@@ -1626,13 +1626,13 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
         const uint32_t off = __float_as_uint(pw) & offmask;
         return (e.x >> PAPR_LUT2_OFF_BITS) + (off >= (e.x & PAPR_LUT2_NEVER) ? 1u : 0u) + (off >= e.y ? 1u : 0u);
     };
-    if constexpr (NOBR) {
+    if constexpr (NOBR || NOBR_HIST) {
         // the lane's own first transposition slot: read (by this lane only) before anything of the segment is folded
         ws.ring_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u32 *)ws.ring);
         ws.trash_addr = (uint32_t)(uintptr_t)(lds_u32 *)(xpose + wave * (kWave * 8) + xpose_slot((int)lane, 0));
     }
     auto count_and_stash = [&](float pw, uint32_t k) {
-        if constexpr (NOBR) {
+        if constexpr (NOBR_HIST) {
             const unsigned long long nz = __ballot(k != 0u);
             const uint32_t a_bin = (uint32_t)(uintptr_t)(lds_u32 *)&my[k];
             uint32_t a;
@@ -2109,7 +2109,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
     X(52, 12, 8, 0, true, 14) X(54, 11, 8, 0, true, 10) X(55, 12, 8, 0, true, 18) X(56, 12, 8, 0, true, 26)                \
     X(57, 16, 8, 0, false, 18) X(58, 12, 8, 1, false, 18) X(59, 12, 8, 0, true, 50) X(53, 12, 8, 0, true, 16)        \
     X(46, 12, 8, 0, true, 17) X(47, 12, 8, 0, true, 58) X(43, 14, 8, 0, true, 26) X(33, 13, 8, 0, true, 26)       \
-    X(31, 12, 8, 0, true, 90) X(29, 12, 8, 0, true, 82)
+    X(31, 12, 8, 0, true, 218) X(29, 12, 8, 0, true, 90) X(28, 12, 8, 0, true, 154)
 #else  // 56: the exact-sum default (ballot ring, lean sum); 48: its first form (returning-atomic ring, separate sum);
        // 32 / 41: the kernel without the pairs (tests)
 #define PAPR_FOR_EACH_SWEEP2_VARIANT(X) \
