@@ -1657,8 +1657,12 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
         float pw[2 * BATCH];
 #pragma unroll
         for (int u = 0; u < BATCH; u++) {
-            pw[2 * u] = power_of(x[u].x, x[u].y);
-            pw[2 * u + 1] = power_of(x[u].z, x[u].w);
+            // (power_of with the squares as one packed multiplication and the additions written out: see papr_sweep_kernel)
+            typedef float f32x2v __attribute__((ext_vector_type(2)));
+            const f32x2v a = {x[u].x, x[u].y}, b = {x[u].z, x[u].w};
+            const f32x2v aa = a * a, bb = b * b;
+            asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u]) : "v"(aa.x), "v"(aa.y));
+            asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u + 1]) : "v"(bb.x), "v"(bb.y));
             segmax_fold(m, x[u], pw[2 * u], pw[2 * u + 1]);
         }
 #pragma unroll
