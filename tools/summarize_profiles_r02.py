@@ -72,6 +72,8 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
+    if not glob.glob(os.path.join(src, "stats_*")):  # (a gpurun call that found no box leaves nothing: do not write empty summaries)
+        sys.exit(f"{src}: no collection to distil")
     for f in glob.glob(os.path.join(src, "bench_*.json")):
         if os.path.getsize(f):
             shutil.copy(f, os.path.join(dst, f"{tag}_{os.path.basename(f)}"))
