@@ -9,10 +9,14 @@
  *   --set           force sample IDX to (I,Q); accepts nan/inf; up to 8
  *   --extra-floats  append K more floats (continuing the I/Q stream) => odd tails
  *   --extra-bytes   append B (1..3) stray bytes 0xA5,0x5A,0xC3 => size % 4 != 0
+ *   --part K M      write only samples [K, K+M) of the n-sample stream, at their place in <out> (the file is
+ *                   created if need be and never truncated), so that several mkcfile processes can fill one
+ *                   large file side by side; tails (--extra-*) belong to a run without --part
  */
 #define _FILE_OFFSET_BITS 64
 #include "papr_synth.h"
 
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -29,8 +33,8 @@ int main(int argc, char **argv)
     papr_synth_spec sp;
     memset(&sp, 0, sizeof(sp));
     sp.seed = PAPR_SYNTH_DEFAULT_SEED;
-    uint64_t extra_floats = 0;
-    int extra_bytes = 0, spike = 0;
+    uint64_t extra_floats = 0, part_first = 0, part_count = 0;
+    int extra_bytes = 0, spike = 0, part = 0;
     uint32_t envelope = 0;
     for (int a = 3; a < argc; a++) {
         if (!strcmp(argv[a], "--seed") && a + 1 < argc) {
@@ -51,6 +55,10 @@ int main(int argc, char **argv)
         } else if (!strcmp(argv[a], "--envelope") && a + 1 < argc) {
             ++a;
             envelope = !strcmp(argv[a], "constant") ? PAPR_SYNTH_ENV_CONSTANT : !strcmp(argv[a], "bursty") ? PAPR_SYNTH_ENV_BURSTY : 0u;
+        } else if (!strcmp(argv[a], "--part") && a + 2 < argc) {
+            part = 1;
+            part_first = strtoull(argv[++a], NULL, 0);
+            part_count = strtoull(argv[++a], NULL, 0);
         } else if (!strcmp(argv[a], "--extra-floats") && a + 1 < argc) {
             extra_floats = strtoull(argv[++a], NULL, 0);
         } else if (!strcmp(argv[a], "--extra-bytes") && a + 1 < argc) {
@@ -67,14 +75,28 @@ int main(int argc, char **argv)
         sp.scale = scale;
     }
     sp.n_overrides |= envelope << 8;
-    FILE *fp = fopen(path, "wb");
+    if (part && (part_first > n || part_count > n - part_first || extra_floats || extra_bytes)) {
+        fprintf(stderr, "mkcfile: --part outside the stream, or combined with a tail\n");
+        return 2;
+    }
+    FILE *fp;
+    if (part) { /* create without truncating: other writers may already have filled their parts */
+        int fd = open(path, O_WRONLY | O_CREAT, 0644);
+        fp = fd >= 0 ? fdopen(fd, "wb") : NULL;
+    } else {
+        fp = fopen(path, "wb");
+    }
     if (!fp) {
         perror(path);
         return 1;
     }
+    if (part && fseeko(fp, (off_t)(part_first * 8), SEEK_SET) != 0) {
+        perror("fseeko");
+        return 1;
+    }
     enum { BLK = 8192 };
     static float buf[2 * BLK];
-    uint64_t total_floats = 2 * n + extra_floats, done = 0;
+    uint64_t total_floats = part ? 2 * (part_first + part_count) : 2 * n + extra_floats, done = 2 * part_first;
     while (done < total_floats) {
         uint64_t want = total_floats - done;
         if (want > 2 * BLK)

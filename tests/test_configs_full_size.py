@@ -1,0 +1,124 @@
+"""BASELINE.json configs[3] and configs[4] at their own workloads, on the one-GPU box.
+
+configs[3] — `papr -g` on 80 GiB sharded over 8 ranks: eight ranks share the one 288 GB GPU (10 GiB shard each, gloo
+carrying the C exchange), and the line must prove itself against the reference's recorded stdout for the 80 GiB
+stream (tests/golden/big_spike80g.*.txt: 47 minutes of reference CPU time), with --exact also the reference's
+sequential sum over the eight chained shards.
+
+configs[4] — a file larger than the HBM budget, streamed through double-buffered staging: a 40 GiB file (more than one
+GPU's 32 GiB share of the 256 GiB config; the reference streams any size, papr.c:100-101, 142-144) goes through
+`bin/papr [-g]` under a 4 GiB budget, as one shard and as eight, and stdout must be the reference's recording
+(big_spike40g.*.txt) after ONE pass over the file.
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _golden(name):
+    with open(os.path.join(GOLDEN, name), "rb") as f:
+        return f.read()
+
+
+@pytest.mark.parametrize("extra", [[], ["--exact"]], ids=["tree", "exact"])
+def test_eight_rank_bench_line_proves_itself_at_full_size(extra, manifest):
+    import torch
+    free, total = torch.cuda.mem_get_info(0)
+    if free < 110 * (1 << 30):
+        pytest.skip(f"8 x 10 GiB shards + stashes need ~100 GiB of HBM; {free >> 30} GiB free")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", *extra]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    assert d["n_gpus"] == 8 and d["config"]["samples_total"] == 8 * 1342177280 == manifest["big_spike80g"]["nsamples"]
+    assert d["parity_in_run"] is True and d["parity_golden"] == "big_spike80g.default.txt"
+    assert d["graph"]["parity_in_run"] is True and d["graph"]["parity_golden"] == "big_spike80g.graph.txt"
+    assert d["report_sha256"] == manifest["big_spike80g"]["default"]["sha256"]
+    assert d["graph"]["report_sha256"] == manifest["big_spike80g"]["graph"]["sha256"]
+    assert d["graph"]["config"]["levels"] == manifest["big_spike80g"]["graph"]["lines"] == 302
+    assert d["config"]["one_sweep"]["steps_resolved_from_the_sweep"] == 2     # one read of every shard per step
+    if extra:
+        assert d["config"]["exact_sequential_sum"] is True
+        assert d["config"]["sum_hex"] == manifest["big_spike80g"]["oracle_sequential_sum_hex"]
+        assert d["graph"]["config"]["sum_hex"] == manifest["big_spike80g"]["oracle_sequential_sum_hex"]
+
+
+def _big_file_dir(need):
+    """Where a `need`-byte file can live on this box: a real disk first (the box's own; what configs[4] means), tmpfs
+    only if the disk is too small."""
+    cands = [os.environ.get("PAPR_TEST_DISK_DIR"), os.path.join(ROOT, "gpurun_out"), "/var/tmp", "/tmp", "/dev/shm"]
+    for cand in cands:
+        if not cand:
+            continue
+        try:
+            os.makedirs(cand, exist_ok=True)
+            if shutil.disk_usage(cand).free > need + (4 << 30):
+                if cand == "/dev/shm":   # tmpfs is memory: leave room for the page cache of nothing else, and the staging
+                    with open("/proc/meminfo") as f:
+                        avail = next(int(l.split()[1]) for l in f if l.startswith("MemAvailable")) * 1024
+                    if avail < need + (24 << 30):
+                        continue
+                return cand
+        except OSError:
+            continue
+    return None
+
+
+@pytest.fixture(scope="module")
+def file40g(orc):
+    n = 5368709120   # 40 GiB
+    d = _big_file_dir(n * 8)
+    if d is None:
+        pytest.skip("no filesystem on this box has 44 GiB free")
+    path = os.path.join(d, f"papr_big_spike40g_{os.getpid()}.cfile")
+    workers = min(32, os.cpu_count() or 8)
+    per = (n // workers + 8191) // 8192 * 8192
+    try:
+        procs = []
+        for w in range(workers):
+            first = w * per
+            if first >= n:
+                break
+            procs.append(subprocess.Popen([orc.MKCFILE, path, str(n), "--spike", "--part", str(first), str(min(per, n - first))]))
+        assert all(p.wait() == 0 for p in procs)
+        assert os.path.getsize(path) == n * 8
+        yield path
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["default", "graph"])
+@pytest.mark.parametrize("gpus", [1, 8], ids=["one-shard", "eight-shards"])
+def test_40_gib_file_streams_once_under_a_4_gib_budget(pkg, file40g, manifest, gpus, graph):
+    env = dict(os.environ, PAPR_STATS="1", PAPR_HBM_BUDGET_MB="4096", PAPR_GPUS=str(gpus))
+    if gpus > 1:
+        env["PAPR_OVERSUBSCRIBE"] = "1"
+    p = subprocess.run([pkg.CLI_PATH] + (["-g"] if graph else []) + [file40g], capture_output=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    tag = "graph" if graph else "default"
+    assert p.stdout == _golden(f"big_spike40g.{tag}.txt")
+    assert len(p.stdout.splitlines()) == manifest["big_spike40g"][tag]["lines"]
+    info = json.loads(p.stderr.decode().splitlines()[-1])
+    assert info["samples"] == manifest["big_spike40g"]["nsamples"] and info["gpus"] == gpus
+    assert info["exact_sum"] == 1                       # the CLI's default arithmetic: the reference's sequential sum
+    assert info["gpu0_ingest"]["resident"] == 0         # 40 GiB (5 GiB per shard at eight) against a 4 GiB budget
+    assert info["gpu0_ingest"]["file_passes"] == 1      # ... and still ONE pass over the file
+    assert info["shards_swept"] == gpus and info["shards_resolved_from_sweep"] == gpus
