@@ -43,6 +43,16 @@ import __graft_entry__ as ge  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def make_cfile(orc, path, n):
+    """The bench workload (spike stream of n samples) as a file: oracle/mkcfile, one process per 1/16 of it."""
+    workers = max(1, min(16, os.cpu_count() or 1, n // (1 << 22)))
+    per = (n // workers + 8191) // 8192 * 8192
+    procs = [subprocess.Popen([orc.MKCFILE, path, str(n), "--spike", "--part", str(w * per), str(min(per, n - w * per))])
+             for w in range(workers) if w * per < n]
+    if any(p.wait() != 0 for p in procs) or os.path.getsize(path) != n * 8:
+        raise RuntimeError("mkcfile failed")
+
+
 def cpu_baseline(pkg, mode: str, sample_gib: float):
     """Time the reference program (oracle/_ref/papr, compiled from the reference's
     own papr.c) — or, if it is absent, the oracle port — on a bounded sample of the
@@ -57,10 +67,10 @@ def cpu_baseline(pkg, mode: str, sample_gib: float):
     path = os.path.join(tmpdir, f"papr_bench_sample_{os.getpid()}.cfile")
     try:
         t0 = time.perf_counter()
-        subprocess.check_call([orc.MKCFILE, path, str(n), "--spike"])
+        make_cfile(orc, path, n)
         gen_s = time.perf_counter() - t0
         args = [binary] + (["-g"] if mode == "graph" else []) + [path]
-        subprocess.run(args, capture_output=True)  # page-cache warm, untimed
+        # (no warm-up run: the file was written a moment ago and sits in the page cache)
         t0 = time.perf_counter()
         p = subprocess.run(args, capture_output=True)
         cpu_s = time.perf_counter() - t0
@@ -96,7 +106,7 @@ def e2e_block(pkg, gib: float):
     path = os.path.join(tmpdir, f"papr_bench_e2e_{os.getpid()}.cfile")
     out = {"file": f"{gib:g} GiB spike workload in {tmpdir} (page cache)", "bytes": n * 8}
     try:
-        subprocess.check_call([orc.MKCFILE, path, str(n), "--spike"])
+        make_cfile(orc, path, n)
         for graph, tag in ((False, "default"), (True, "graph")):
             best = None
             for _ in range(2):   # the first run of a session also pays for loading the GPU runtime
@@ -227,14 +237,21 @@ def run_mode(args, mode, env):
         kernel_ms_per_step = (tm.stats_ms + tm.ccdf_ms + tm.sweep_ms) / args.steps + tm_x.exact_ms / steps_x + aux_ms
         bytes_per_step = ((tm.stats_bytes + tm.ccdf_bytes + tm.sweep_bytes) / args.steps + tm_x.exact_bytes / steps_x
                           + aux_bytes)
-        traffic, traffic_src = None, None
+        # HBM traffic from the PMC pass of the same command (profiles/pmc_traffic.json), taken over only if that pass ran
+        # the kernel FORM this run ran (the library reports the form's id; a stale file says so instead of a number)
+        kernel_variant = int(result.get("sweep_info", {}).get("kernel_variant", -1)) if one_sweep else None
+        traffic, traffic_src, traffic_stale = None, None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 ent = tj.get(dom, {}).get(args.mode if args.mode in tj.get(dom, {}) else "any")
                 if ent and abs(ent.get("gib_per_gpu", 0) - args.gib) < 1e-9:
-                    traffic, traffic_src = ent["hbm_bytes_per_launch"], ent.get("source", tj.get("source"))
+                    if kernel_variant is None or ent.get("kernel_variant") == kernel_variant:
+                        traffic, traffic_src = ent["hbm_bytes_per_launch"], ent.get("source", tj.get("source"))
+                    else:
+                        traffic_stale = (f"profiles/pmc_traffic.json was measured on kernel form {ent.get('kernel_variant')}, "
+                                         f"this run used form {kernel_variant}")
             except Exception:
                 pass
         # in-run parity: what this run would print, against what the REFERENCE printed for the same global stream
@@ -270,7 +287,14 @@ def run_mode(args, mode, env):
             "roofline": {"bound": "hbm", "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": per_gpu * 8,
-                         "traffic_source": traffic_src},
+                         "kernel_variant": kernel_variant, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                         # SURVEY.md 8(d) prices a papr result at 16 B/sample (two reads: 500 000 Msamples/s = 100 %).  The
+                         # sweep kernel does the work of both passes in ONE read, so `frac` above is priced on the 8 B/sample
+                         # it actually moves; on the survey's two-pass convention the same launch retires 16 B/sample:
+                         "survey_two_pass_equiv": ({"achieved": 2 * dom_gbs, "frac": 2 * dom_gbs / HBM_PEAK_GBS,
+                                                    "note": "2 x achieved: one read doing both passes' work, on SURVEY 8(d)'s "
+                                                            "16 B/sample scale (may exceed 1; not a bandwidth claim)"}
+                                                   if one_sweep and result.get("resolved", 0) == args.steps else None)},
             # stdout of this run (last step) == the reference program's recorded stdout for the same stream
             # (tests/golden/<name>; null: no golden for this size / rank count)
             "parity_in_run": parity, "parity_golden": golden_name,
@@ -293,7 +317,7 @@ def run_mode(args, mode, env):
     return None
 
 
-def run_ts(args, rank, world, local_rank, use_dist, real_stdout):
+def run_ts(args, rank, world, local_rank, use_dist):
     """--workload ts: the transport-stream packet scan (include/ts_hip.h).  One step = one
     complete scan of the HBM-resident stream: sync lock, per-PID count / first / last.  Every rank owns its own
     10 GiB stream (independent streams: no exchange)."""
@@ -323,7 +347,8 @@ def run_ts(args, rank, world, local_rank, use_dist, real_stdout):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank != 0:
-        return
+        gpu.close()
+        return None
     nbytes = npackets * 188
     k_ms = kernel_ms / args.steps
     # Algorithmic bytes of the scan kernel: the 128-byte lines that hold a packet header (its sync byte, PID,
@@ -366,11 +391,8 @@ def run_ts(args, rank, world, local_rank, use_dist, real_stdout):
             line["cpu_baseline"] = ts_cpu_baseline(gpu, ts, args.cpu_sample_gib or 2.0)
         except Exception as e:
             line["cpu_baseline"] = {"error": repr(e)}
-    sys.stdout.flush()
-    os.dup2(real_stdout, 1)
-    print(json.dumps(line), flush=True)
-    os.dup2(2, 1)
     gpu.close()
+    return line
 
 
 def ts_cpu_baseline(gpu, ts, sample_gib: float):
@@ -436,6 +458,10 @@ def main():
                          "code path can be exercised on a box with fewer GPUs than ranks")
     ap.add_argument("--cpu-sample-gib", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline (+ graph) legs: no exact-sum member, no TS member, no -g CPU baseline")
+    ap.add_argument("--no-ts", action="store_true", help="leave the transport-stream member out of the plain invocation's line")
+    ap.add_argument("--member-steps", type=int, default=20, help="steps of the exact / ts members of the plain invocation")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the end-to-end leg (the drop-in CLI on a file in /dev/shm -> stdout; PCIe-inclusive, reported "
                          "under \"e2e\", never as `value`)")
@@ -470,7 +496,12 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     if args.workload == "ts":
-        run_ts(args, rank, world, local_rank, use_dist, real_stdout)
+        line = run_ts(args, rank, world, local_rank, use_dist)
+        if rank == 0:
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
+            print(json.dumps(line), flush=True)
+            os.dup2(2, 1)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -496,11 +527,51 @@ def main():
                total=total, one_sweep=one_sweep)
     modes = ["default", "graph"] if args.mode == "both" else [args.mode]
     lines = [run_mode(args, m, env) for m in modes]
+    GRAPH_KEYS = ("value", "unit", "ms_per_step", "config", "roofline", "kernels", "parity_in_run", "parity_golden",
+                  "report_sha256")
+    # The plain invocation (what the driver runs) carries every leg in its ONE line: configs[1] as the headline,
+    # configs[2] under "graph", the same two tables with the reference's sequential sum reproduced (what bin/papr does
+    # by default) under "exact", the transport-stream scan under "ts", the reference's own CPU time for both tables.
+    full = (args.mode == "both" and not args.exact and not args.two_pass and not args.force_miss and args.signal == "gauss"
+            and not args.headline_only)
+    exact_lines = None
+    if full:
+        gpu.set_exact(True)
+        exact_args = argparse.Namespace(**{**vars(args), "exact": True, "steps": max(1, min(args.steps, args.member_steps)),
+                                           "warmup": min(args.warmup, 2)})
+        exact_lines = [run_mode(exact_args, m, env) for m in modes]
+        gpu.set_exact(False)
+    gpu.close()
+    del shard
+    torch.cuda.empty_cache()
+    ts_line = None
+    if full and not args.no_ts:
+        ts_args = argparse.Namespace(**{**vars(args), "steps": max(1, min(args.steps, args.member_steps)),
+                                        "warmup": min(args.warmup, 2)})
+        ts_line = run_ts(ts_args, rank, world, local_rank, use_dist)
     if rank == 0:
         line = lines[0]
         if len(lines) > 1:   # configs[2] rides along: same shard, same code path, the 0.1 dB table
-            line["graph"] = {k: lines[1][k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "kernels",
-                                                       "parity_in_run", "parity_golden", "report_sha256")}
+            line["graph"] = {k: lines[1][k] for k in GRAPH_KEYS}
+        if exact_lines:
+            want_sum = None
+            try:
+                mf = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))
+                if abs(args.gib - 10.0) < 1e-12:
+                    want_sum = mf.get(f"big_spike{10 * world}g", {}).get("oracle_sequential_sum_hex")
+            except Exception:
+                pass
+            ex = {k: exact_lines[0][k] for k in GRAPH_KEYS + ("steps", "warmup")}
+            ex["graph"] = {k: exact_lines[1][k] for k in GRAPH_KEYS}
+            for leg in (ex, ex["graph"]):
+                leg["sum_hex"] = leg["config"]["sum_hex"]
+                # the reference's own accumulator (papr.c:104) for this stream, recorded in tests/golden/manifest.json
+                leg["sum_is_the_reference_s"] = None if want_sum is None else leg["sum_hex"] == want_sum
+            ex["what"] = ("the same step with the reference's sequential double sum (papr.c:104) reproduced bit for bit in "
+                          "the same single read: bin/papr's default arithmetic")
+            line["exact"] = ex
+        if ts_line:
+            line["ts"] = ts_line
         if world == 1 and not args.no_cpu_baseline:
             mode0 = modes[0]
             sample = args.cpu_sample_gib if args.cpu_sample_gib else (1.0 if mode0 == "graph" else 4.0)   # ~10-15 s of reference CPU time
@@ -510,6 +581,11 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 cb = {"error": repr(e)}
             line["cpu_baseline"] = cb
+            if full:   # the reference's -g loop is O(N x 301): a quarter of the sample keeps it at ~15 s
+                try:
+                    line["cpu_baseline_graph"] = cpu_baseline(pkg, "graph", min(args.cpu_sample_gib or 0.5, args.gib))
+                except Exception as e:
+                    line["cpu_baseline_graph"] = {"error": repr(e)}
         if world == 1 and not args.no_e2e and not args.no_cpu_baseline and args.signal == "gauss":
             try:
                 line["e2e"] = e2e_block(pkg, args.gib)
@@ -520,7 +596,6 @@ def main():
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
 
-    gpu.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

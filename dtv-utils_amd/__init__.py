@@ -110,7 +110,8 @@ class SweepInfo(C.Structure):
     """papr_hip_sweep_info: what the last one-sweep pass / papr_hip_ccdf did."""
     _fields_ = [("stash_samples", C.c_uint64), ("stash_capacity", C.c_uint64), ("estimate_samples", C.c_uint64),
                 ("swept", C.c_int), ("resolved", C.c_int), ("reason", C.c_int), ("band_log2", C.c_int),
-                ("exact_redo_tiles", C.c_uint32), ("gave_up", C.c_uint32)]
+                ("exact_redo_tiles", C.c_uint32), ("gave_up", C.c_uint32), ("kernel_variant", C.c_int),
+                ("reserved", C.c_int)]
 
     def as_dict(self) -> dict:
         d = {name: getattr(self, name) for name, _ in self._fields_}

@@ -52,11 +52,15 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
         replayed = true;
     };
     bool fused = false;
-    if (!(flags & PAPR_ANALYZE_TWO_PASS) && papr_exchange_is_identity(x)) {
-        if (ctx->exact)
+    PeerStep peer;
+    if (!(flags & PAPR_ANALYZE_TWO_PASS)) {
+        const bool alone = papr_exchange_is_identity(x);
+        if (ctx->exact && alone)
             ctx->overlap_work = replay_when_ready;
-        // no peers: estimate, guess (on the device) and sweep in one sequence of launches, one wait (papr_sweep_rt.cpp)
-        rc = stats_sweep_fused(ctx, graph, graph ? 48.0 : 60.0, (flags & PAPR_ANALYZE_SPOIL_GUESS) ? 1.03f : 1.0f, &local, &fused);
+        // estimate, guess (on the device) and sweep in one sequence of launches, one wait (papr_sweep_rt.cpp) — alone, or
+        // with the exchanges as collectives on the stream when the transport has them (RCCL)
+        rc = stats_sweep_fused(ctx, alone ? nullptr : x, graph, graph ? 48.0 : 60.0,
+                               (flags & PAPR_ANALYZE_SPOIL_GUESS) ? 1.03f : 1.0f, &local, &fused, &peer);
         ctx->overlap_work = nullptr;
         if (rc)
             return rc;
@@ -98,8 +102,12 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
     // ---- exchange 1 + host scalars ----
     papr_stats total = local;
     double before = 0.0;
-    if (x && (rc = papr_exchange_stats(x, &local, &total, &before, nullptr)) != PAPR_OK)
+    if (peer.global) {  // (the records crossed in the stream)
+        total = peer.total;
+        before = peer.before;
+    } else if (x && (rc = papr_exchange_stats(x, &local, &total, &before, nullptr)) != PAPR_OK) {
         return xfail(rc);
+    }
     double mean = 0.0;
     float papr = 0.f;
     int L = papr_levels(&total, graph, &mean, &papr, nullptr, 0);
@@ -150,9 +158,10 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
         if (rc)
             return rc;
     }
-    // ---- exchange 2 ----
-    if (x && (rc = papr_exchange_counts(x, counts_above, L)) != PAPR_OK)
+    // ---- exchange 2 (unless the counters are the file's already: they were added up in the stream) ----
+    if (x && !ctx->counts_global && (rc = papr_exchange_counts(x, counts_above, L)) != PAPR_OK)
         return xfail(rc);
+    ctx->counts_global = false;
     res->total = total;
     res->mean = mean;
     res->papr = papr;

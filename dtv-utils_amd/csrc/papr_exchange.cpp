@@ -278,6 +278,38 @@ bool papr_exchange_is_identity(const papr_exchange *x)
     return !x || (x->world == 1 && x->use_ops);
 }
 
+}  // extern "C"
+
+// ---- in-stream collectives on device buffers (papr_sweep_rt.cpp: the single-wait step with peers) -----------------
+// Only the RCCL transport has them: the collective is queued on the context's stream between the kernels that produce
+// and consume its buffers — no host staging, no wait.  The caller-callback and in-process transports move host memory.
+namespace papr_rt {
+
+bool xch_in_stream(const papr_exchange *x, const papr_hip_ctx *ctx)
+{
+    return x && x->comm && x->ctx == ctx && env_int("PAPR_XCH_IN_STREAM", 1) != 0;
+}
+int xch_rank(const papr_exchange *x) { return x ? x->rank : 0; }
+int xch_world(const papr_exchange *x) { return x ? x->world : 1; }
+
+int xch_allgather_dev(papr_exchange *x, const void *send_dev, void *recv_dev, size_t bytes_per_rank)
+{
+    XNCCL(x, rccl()->AllGather(send_dev, recv_dev, bytes_per_rank, ncclUint8, x->comm, x->ctx->stream));
+    x->timing.in_stream_calls++;
+    return PAPR_OK;
+}
+
+int xch_allreduce_u64_dev(papr_exchange *x, const void *send_dev, void *recv_dev, size_t count)
+{
+    XNCCL(x, rccl()->AllReduce(send_dev, recv_dev, count, ncclUint64, ncclSum, x->comm, x->ctx->stream));
+    x->timing.in_stream_calls++;
+    return PAPR_OK;
+}
+
+}  // namespace papr_rt
+
+extern "C" {
+
 int papr_exchange_open_rccl(papr_exchange **out, papr_hip_ctx *ctx, const void *id, int rank, int world)
 {
     if (!out || !ctx || !id || world < 1 || rank < 0 || rank >= world)

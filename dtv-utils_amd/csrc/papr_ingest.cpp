@@ -286,7 +286,7 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
         if (env_int("PAPR_IO_URING", 1) != 0)
             ctx->uring = UringReader::create(256);
     }
-    UringReader *ring = fs.fd_direct >= 0 ? ctx->uring : nullptr;
+    UringReader *ring = fs.fd_direct >= 0 && ctx->uring && !ctx->uring->dead() ? ctx->uring : nullptr;  // (a ring that failed once: threads)
     if (timed)
         ctx->ingest.io_uring = ring ? 1 : 0;
     // queue the slices of chunk c for the reader threads (buffer c % kNumBuf must be free)

@@ -155,17 +155,49 @@ struct papr_guess_out {
     uint32_t pad;
     double est_sum;         /* sampled sum scaled to the shard */
     double est_rel_se;      /* relative standard error of the estimated mean */
+    double est_before;      /* peers: the estimated sum of the shards in front of this one */
     uint32_t gkeys[PAPR_GUESS_MAX_BANDS]; /* keys of the guessed thresholds, ascending */
 };
+/* With peers (papr_exchange over RCCL) the step's exchanges are collectives queued on the stream, between these:
+ *   papr_est_record_kernel  one 48-byte record of this shard's estimate -> all-gather -> papr_guess_bands_kernel(recs)
+ *   papr_record_merge_kernel after the all-gather of the shards' pass-1 records: the ordered merge (rank = file order;
+ *                           papr_stats_merge's rules), the sum of the shards in front of this one, the file's length
+ *   papr_xpack_kernel       the sweep's bins, the recount's bins and four flags as ONE vector for the all-reduce */
+struct papr_est_record {
+    double S, sq;                          /* sampled sum; sum of squared piece sums */
+    unsigned long long sampled, n, pieces; /* samples read; samples in the shard; pieces (4 per group) */
+    unsigned long long ratio;              /* 1 = everything was read */
+    unsigned long long flags;              /* the shard's PAPR_FLAG_* (odd tail) */
+    unsigned long long pad;
+};
+struct papr_peer_out {
+    papr_partial total;            /* the file's pass-1 record */
+    double before;                 /* sum of the shards in front of this one */
+    unsigned long long n_total;    /* samples in the file */
+    unsigned long long nan_ranks;  /* shards whose sum came out NaN (then the host path takes over, on every rank) */
+    unsigned long long flags;      /* OR of the shards' flags */
+};
+#define PAPR_XVEC_FLAGS 4 /* [0] stash overflow / give-up on some rank, [1] guess without a band form, [2] no speculated table, [3] reserved */
+void papr_launch_est_record(hipStream_t st, const papr_partial *est_partials, const double *est_sq, uint32_t est_blocks,
+                            uint64_t ngroups, uint64_t sampled, uint64_t nsamples, uint32_t ratio, uint32_t flags,
+                            papr_est_record *out);
+void papr_launch_record_merge(hipStream_t st, const papr_partial *recs, const papr_est_record *est, uint32_t world, uint32_t rank,
+                              papr_partial *total_dev, unsigned long long *n_total_dev, papr_peer_out *out_host);
+void papr_launch_xpack(hipStream_t st, const unsigned long long *sweep_hist, uint32_t sweep_words, const unsigned long long *seg_fill,
+                       uint32_t nsegs, uint64_t seg_cap, const unsigned long long *gave_up, const unsigned long long *recount_hist,
+                       uint32_t recount_words, const struct papr_guess_out *guess, const struct papr_true_out *tru,
+                       unsigned long long *vec);
 void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, const double *est_sq, uint32_t est_blocks,
                              uint64_t ngroups, uint64_t sampled, uint64_t nsamples, uint32_t ratio, int graph, float max_db,
                              float spoil, int band_override, uint32_t copies, int compact /* LUT form: two edges per cell */,
                              uint32_t soft_lds /* bytes table + histogram copies should stay under */, uint32_t *table,
                              uint32_t table_cap_words, papr_guess_out *out_dev, papr_guess_out *out_host,
-                             unsigned long long *zero /* words the kernel clears on its way */, uint32_t zero_words);
+                             unsigned long long *zero /* words the kernel clears on its way */, uint32_t zero_words,
+                             const papr_est_record *recs = nullptr /* all shards' estimate records, rank order (peers) */,
+                             uint32_t nrecs = 0, uint32_t my_rank = 0);
 int papr_sweep_variant(int variant); /* the sweep geometry used for a variant id, or -1 */
 #define PAPR_SWEEP_VARIANT_IS_LUT2(v) (((v) >= 20 && (v) <= 29) || ((v) >= 70 && (v) <= 79) || (v) == 18 || (v) == 38) /* compact table: papr_sweep_kernel<LUT2>, papr_sweep_split_kernel */
-#define PAPR_SWEEP_VARIANT_IS_PERSISTENT(v) ((v) == 40) /* launched as ONE workgroup per CU (512 threads x 8 loads per lane) */
+#define PAPR_SWEEP_VARIANT_IS_PERSISTENT(v) ((v) == 40 || (v) == 111 || (v) == 114) /* launched as ONE workgroup per CU (512 threads x 8 loads per lane) */
 #define PAPR_SWEEP_VARIANT_HAS_HIST_SETS(v) (((v) >= 84 && (v) <= 85) || ((v) >= 87 && (v) <= 89)) /* SMODE bit 2 (measurement variants) */
 int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_t *stash_lds); /* 0, or -1 */
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
@@ -192,7 +224,8 @@ struct papr_true_out {
 void papr_launch_true_table(hipStream_t st, const papr_partial *result, uint64_t nsamples, int graph, uint32_t copies,
                             uint32_t soft_lds, uint32_t *table, uint32_t table_cap_words, papr_true_out *out_dev,
                             papr_true_out *out_host, unsigned long long *zero, uint32_t zero_words,
-                            const unsigned long long *gave_up /* the sweep's give-up counter: non-zero = nothing to recount */);
+                            const unsigned long long *gave_up /* the sweep's give-up counter: non-zero = nothing to recount */,
+                            const unsigned long long *nsamples_dev = nullptr /* peers: the file's length, in device memory */);
 void papr_sweep_prepare_device(void);
 
 // ---- one-sweep kernel, second generation (papr_sweep.hip: papr_sweep2_kernel) -----------------------------------
@@ -227,8 +260,15 @@ struct papr_sweep2_params {
     const int32_t *tile_E_spec;   // per 2048-sample tile: speculated binade of the running sum, or PAPR_EXACT_AMBIG
     void *seg_D;                  // per segment: double2 (D0, D1); D0 doubles as the segment's sum
     uint64_t seg_offset;          // index of the launch's first segment within the shard (chunked launches)
+    uint32_t lds_bytes;           // papr_sweep3_kernel: the launch's dynamic LDS (set by its launch wrapper)
 };
 int papr_sweep2_geometry(int variant, int *threads, uint64_t *seg_samples, size_t *lds_fixed, int *exact);
+// ---- the exact-sum sweep, third form (papr_sweep.hip: papr_sweep3_kernel) ----------------------------------------
+// Same parameter block and segment numbering as papr_sweep2_kernel<EXACT>; the band-edge table is papr_sweep_kernel's
+// (ONE edge per cell, a sentinel cell at either end, nkeys + 2 bins), the stash leaves through per-wave LDS slices.
+#define PAPR_SWEEP3_SLICE_FLOATS 1408u /* per wave: what the 160 KiB leave beside 8 x 8 KiB of transposition buffers and a 40 KiB table */
+int papr_sweep3_geometry(int variant, int *threads, size_t *lds_fixed, int *exact = nullptr); /* 0, or -1 if `variant` is not one of its ids */
+void papr_launch_sweep3(hipStream_t st, int variant, int blocks, size_t lds_bytes, const papr_sweep2_params &p);
 void papr_launch_sweep2(hipStream_t st, int variant, int blocks, size_t lds_bytes, const papr_sweep2_params &p);
 int papr_ccdf_max_dynamic_lds(void);
 void papr_kernels_prepare_device(void); /* call once per device after hipSetDevice */

@@ -99,9 +99,11 @@ int variant_of(const papr_hip_ctx *ctx, Pass p)
         uint64_t seg;
         size_t lds;
         const bool is_v2 = want >= 0 && papr_sweep2_geometry(want, &threads, &seg, &lds, &exact) == 0;
+        int exact3 = 0;
+        const bool is_v3 = want >= 0 && papr_sweep3_geometry(want, &threads, &lds, &exact3) == 0;
         if (ctx->exact)  // exact-sum mode: only the variants that also build the rounding-function pairs
-            return is_v2 && exact ? want : kSweepExactVariant;
-        if (is_v2 && !exact)
+            return (is_v2 && exact) || (is_v3 && exact3) ? want : kSweepExactVariant;
+        if ((is_v2 && !exact) || (is_v3 && !exact3))
             return want;
         const int v = papr_sweep_variant(want);
         return v >= 0 ? v : kSweepVariant;
@@ -685,7 +687,8 @@ int papr_hip_set_tuning(papr_hip_ctx *ctx, const papr_hip_tuning *t)
         (t->ccdf_variant != 0 && papr_variant_geometry(t->ccdf_variant - 1, &vb, &vu) != 0) ||
         t->sweep_blocks < 0 || t->sweep_blocks > 65536 || t->sweep_map < 0 || t->sweep_map > 3 ||
         (t->sweep_variant != 0 && papr_sweep_variant(t->sweep_variant - 1) < 0 &&
-         papr_sweep2_geometry(t->sweep_variant - 1, &vb, &v2seg, &v2lds, &vu) != 0) ||
+         papr_sweep2_geometry(t->sweep_variant - 1, &vb, &v2seg, &v2lds, &vu) != 0 &&
+         papr_sweep3_geometry(t->sweep_variant - 1, &vb, &v2lds) != 0) ||
         (t->sweep_band_log2 != 0 && (t->sweep_band_log2 < 8 || t->sweep_band_log2 > 20)) || t->estimate_ratio < 0 ||
         t->estimate_ratio > 65536)
         return fail(ctx, PAPR_E_ARG, "bad tuning values");
@@ -893,6 +896,7 @@ static int papr_hip_ccdf_impl(papr_hip_ctx *ctx, const float *levels, int nlevel
     if (nlevels > PAPR_HIP_MAX_LEVELS)
         return fail(ctx, PAPR_E_LIMIT, "%d levels exceeds PAPR_HIP_MAX_LEVELS (%d)", nlevels, PAPR_HIP_MAX_LEVELS);
     ctx->sweep_info.resolved = 0;
+    ctx->counts_global = false;
     if (nlevels == 0)
         return PAPR_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));

@@ -231,6 +231,17 @@ struct papr_hip_ctx {
     unsigned long long *h_sweep_hist_dev = nullptr;  // device address of h_sweep_hist
     bool spec_recount_valid = false;  // h_hist holds the stash recount for the table in h_true (stats_sweep_fused)
     bool sweep_overflow = false;
+    // the single-wait step with peers (stats_sweep_fused over an in-stream exchange): what the collectives left behind
+    unsigned char *d_peer = nullptr;             // device scratch: estimate records, pass-1 records, the all-reduce vector
+    size_t peer_cap = 0;
+    papr_peer_out *h_peer = nullptr, *h_peer_dev = nullptr;  // mapped: the merged record, `before`, the file's length
+    unsigned long long *h_xvec = nullptr;        // pinned: the all-reduced [sweep bins | recount bins | flags]
+    bool peer_global = false;                    // sweep_even_above_global / recount_global hold the FILE's numbers
+    bool counts_global = false;                  // the last papr_hip_ccdf answered with the file's counts (no exchange needed)
+    std::vector<uint64_t> sweep_even_above_global;
+    std::vector<unsigned long long> recount_global;
+    uint64_t peer_agreed_key = 0;                // the shard state for which the ranks agreed ...
+    bool peer_agreed_ok = false;                 // ... that every one of them can take the single-wait step
     papr_hip_sweep_info sweep_info{};
     const papr_rt::SweepRun *ingest_run = nullptr;        // set while papr_hip_load_file_sweep streams the file in
     int32_t *d_tile_E_spec = nullptr;            // exact one-read sweep: speculated binade per tile (same capacity as d_tile_E)
@@ -280,7 +291,8 @@ constexpr int kCcdfVariant = 13, kCcdfPerCU = 2, kCcdfMap = PAPR_MAP_GRID_STRIDE
 
 // one-sweep kernel (pass 1 + banded pass 2 in one read)
 constexpr int kSweepVariant = 40, kSweepPerCU = 4, kSweepMap = PAPR_MAP_GRID_STRIDE;  // (variant 40: one workgroup per CU)
-constexpr int kSweepExactVariant = 56;  // papr_sweep2_kernel<12 waves, exact-sum pairs>
+constexpr int kStashSkewFloats = 0;  // (see stash_segment_floats; 1 KiB units)
+constexpr int kSweepExactVariant = 130;  // papr_sweep3_kernel<8 waves> (56: papr_sweep2_kernel<12 waves, exact-sum pairs>, its predecessor)
 
 constexpr int kSweepBandLog2 = 14, kEstimateRatio = 64;
 
@@ -325,7 +337,8 @@ struct SweepRun {
     int variant = 0;
     bool lut2 = false;            // the compact two-edges-per-cell table (papr_sweep2_kernel always; papr_sweep_kernel variants 20-29)
     bool v2 = false;              // papr_sweep2_kernel (wave-private segments, compact LUT) instead of papr_sweep_kernel
-    bool exact = false;           // v2: the kernel also builds the exact-sum pairs for speculated binades
+    bool exact = false;           // v2 / v3: the kernel also builds the exact-sum pairs for speculated binades
+    bool v3 = false;              // papr_sweep3_kernel: v2's launch and segments, papr_sweep_kernel's table and bins (always exact)
     int threads = 0;              // v2: workgroup size
     int blocks = 0;               // workgroups of the largest launch (= stash segments)
     uint64_t tile = 0;            // samples per workgroup iteration (v2: per wave segment; exact: per 2048-sample tile)
@@ -376,7 +389,19 @@ int ensure_exact_buffers(papr_hip_ctx *ctx);
 }  // namespace papr_rt
 extern "C" bool papr_exchange_is_identity(const papr_exchange *x);  // papr_exchange.cpp (not part of the ABI)
 namespace papr_rt {
-int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, papr_stats *out, bool *done);
+struct PeerStep {       // what the single-wait step with peers hands papr_hip_analyze besides the shard's own record
+    bool global = false;  // total / before are valid: exchange 1 has happened, in the stream
+    papr_stats total;
+    double before = 0.0;
+};
+int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max_db, float spoil, papr_stats *out, bool *done,
+                      PeerStep *peer);
+// papr_exchange.cpp: collectives queued on the context's stream (RCCL transport only)
+bool xch_in_stream(const papr_exchange *x, const papr_hip_ctx *ctx);
+int xch_rank(const papr_exchange *x);
+int xch_world(const papr_exchange *x);
+int xch_allgather_dev(papr_exchange *x, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
+int xch_allreduce_u64_dev(papr_exchange *x, const void *send_dev, void *recv_dev, size_t count);
 int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total);
 void run_overlap_work(papr_hip_ctx *ctx);  // (see papr_hip_ctx::overlap_work)
 int launch_stats_range(papr_hip_ctx *ctx, const float *data, uint64_t n, uint64_t base_index, size_t slot,

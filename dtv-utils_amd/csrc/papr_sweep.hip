@@ -177,7 +177,8 @@ struct WaveStashT {
             uint32_t a;
             asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a) : "v"(a_trash), "v"(a_slot), "s"(m));
             *(__attribute__((address_space(3))) float *)(uintptr_t)a = pw;
-            asm("s_lshl2_add_u32 %0, %1, %2" : "=s"(sbytes) : "s"((uint32_t)__popcll(m)), "s"(__builtin_amdgcn_readfirstlane(sbytes)));
+            // (s_lshl2_add_u32 writes SCC: said, so that the compiler never schedules it between a compare and its consumer)
+            asm("s_lshl2_add_u32 %0, %1, %2" : "=s"(sbytes) : "s"((uint32_t)__popcll(m)), "s"(__builtin_amdgcn_readfirstlane(sbytes)) : "scc");
         } else if constexpr (BALLOT) {
             const unsigned long long m = __ballot(take);
             if (m) {  // (wave-uniform)
@@ -339,12 +340,157 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_estimate_kernel(const float4 
 // needs no libm exactness — the bands absorb its error, and the TRUE table is still built by papr_levels on the host
 // after the sweep), band edges (papr_sweep_bands) and their compact LUT (plan_compact_lut / fill_compact_lut of
 // papr_sweep_rt.cpp, same layout).  Everything the host needs afterwards goes to mapped host memory.
+namespace {
+// sum of n doubles by a 1024-thread workgroup, in a fixed order (deterministic); every thread gets the result
+__device__ __forceinline__ double strided(const double *v, uint32_t k) { return v[k]; }
+__device__ __forceinline__ double strided(const papr_partial *v, uint32_t k) { return v[k].sum; }
+template <typename T>
+__device__ __forceinline__ double block_sum_1024(const T *v, uint32_t n, double *red)
+{
+    const uint32_t t = threadIdx.x;
+    double a = 0.0;
+    for (uint32_t b = t; b < n; b += 1024)
+        a += strided(v, b);
+    red[t] = a;
+    __syncthreads();
+    for (uint32_t w = 512; w > 0; w >>= 1) {
+        if (t < w)
+            red[t] += red[t + w];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+}  // namespace
+
+// this shard's estimate as one record, for the all-gather between the estimate kernel and papr_guess_bands_kernel
+__global__ __launch_bounds__(1024) void papr_est_record_kernel(const papr_partial *__restrict__ est_partials,
+                                                                const double *__restrict__ est_sq, uint32_t est_blocks,
+                                                                uint64_t ngroups, uint64_t sampled, uint64_t nsamples, uint32_t ratio,
+                                                                uint32_t flags, papr_est_record *__restrict__ out)
+{
+    __shared__ double red[1024];
+    const double S = block_sum_1024(est_partials, est_blocks, red);
+    const double sq = block_sum_1024(est_sq, est_blocks, red);
+    if (threadIdx.x == 0) {
+        papr_est_record e;
+        e.S = S;
+        e.sq = sq;
+        e.sampled = sampled;
+        e.n = nsamples;
+        e.pieces = 4ull * ngroups;
+        e.ratio = ratio;
+        e.flags = flags;
+        e.pad = 0;
+        *out = e;
+    }
+}
+
+void papr_launch_est_record(hipStream_t st, const papr_partial *est_partials, const double *est_sq, uint32_t est_blocks,
+                            uint64_t ngroups, uint64_t sampled, uint64_t nsamples, uint32_t ratio, uint32_t flags,
+                            papr_est_record *out)
+{
+    hipLaunchKernelGGL(papr_est_record_kernel, dim3(1), dim3(1024), 0, st, est_partials, est_sq, est_blocks, ngroups, sampled,
+                       nsamples, ratio, flags, out);
+}
+
+// the shards' pass-1 records (rank = file order) folded as papr_stats_merge folds them: sums added in rank order,
+// trackers by "more extreme value, else smaller index" from the reference's initial state (0.0 at index 0)
+__global__ void papr_record_merge_kernel(const papr_partial *__restrict__ recs, const papr_est_record *__restrict__ est,
+                                         uint32_t world, uint32_t rank, papr_partial *__restrict__ total_dev,
+                                         unsigned long long *__restrict__ n_total_dev, papr_peer_out *__restrict__ out_host)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    papr_partial acc;
+    acc.sum = 0.0;
+    acc.pad = 0;
+    for (int k = 0; k < 5; k++) {
+        acc.val[k] = 0.f;
+        acc.idx[k] = 0;
+    }
+    double before = 0.0;
+    unsigned long long n = 0, nans = 0, flags = 0;
+    for (uint32_t r = 0; r < world; r++) {
+        const papr_partial q = recs[r];
+        flags |= est[r].flags;
+        if (r == rank)
+            before = acc.sum;
+        acc.sum = acc.sum + q.sum;
+        nans += q.sum != q.sum ? 1ull : 0ull;
+        n += est[r].n;
+        for (int k = 0; k < 5; k++) {
+            const bool is_min = k == 2 || k == 4;
+            const bool more = is_min ? q.val[k] < acc.val[k] : q.val[k] > acc.val[k];
+            if (more || (q.val[k] == acc.val[k] && q.idx[k] < acc.idx[k])) {
+                acc.val[k] = q.val[k];
+                acc.idx[k] = q.idx[k];
+            }
+        }
+    }
+    *total_dev = acc;
+    *n_total_dev = n;
+    out_host->total = acc;
+    out_host->before = before;
+    out_host->n_total = n;
+    out_host->nan_ranks = nans;
+    out_host->flags = flags;
+}
+
+void papr_launch_record_merge(hipStream_t st, const papr_partial *recs, const papr_est_record *est, uint32_t world, uint32_t rank,
+                              papr_partial *total_dev, unsigned long long *n_total_dev, papr_peer_out *out_host)
+{
+    hipLaunchKernelGGL(papr_record_merge_kernel, dim3(1), dim3(64), 0, st, recs, est, world, rank, total_dev, n_total_dev, out_host);
+}
+
+// everything the ranks have to add up after the recount, as one vector: [sweep bins | recount bins | flags]
+__global__ __launch_bounds__(1024) void papr_xpack_kernel(const unsigned long long *__restrict__ sweep_hist, uint32_t sweep_words,
+                                                           const unsigned long long *__restrict__ seg_fill, uint32_t nsegs,
+                                                           uint64_t seg_cap, const unsigned long long *__restrict__ gave_up,
+                                                           const unsigned long long *__restrict__ recount_hist,
+                                                           uint32_t recount_words, const papr_guess_out *__restrict__ guess,
+                                                           const papr_true_out *__restrict__ tru,
+                                                           unsigned long long *__restrict__ vec)
+{
+    __shared__ uint32_t s_over;
+    const uint32_t t = threadIdx.x;
+    if (t == 0)
+        s_over = 0;
+    __syncthreads();
+    for (uint32_t k = t; k < sweep_words; k += 1024)
+        vec[k] = sweep_hist[k];
+    for (uint32_t k = t; k < recount_words; k += 1024)
+        vec[sweep_words + k] = recount_hist[k];
+    uint32_t over = 0;
+    for (uint32_t b = t; b < nsegs; b += 1024)
+        over |= seg_fill[b] > seg_cap ? 1u : 0u;
+    if (over)
+        atomicOr(&s_over, 1u);
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long *f = vec + sweep_words + recount_words;
+        f[0] = (s_over || *gave_up != 0) ? 1ull : 0ull;
+        f[1] = guess->ok ? 0ull : 1ull;
+        f[2] = tru->ok ? 0ull : 1ull;
+        f[3] = 0ull;
+    }
+}
+
+void papr_launch_xpack(hipStream_t st, const unsigned long long *sweep_hist, uint32_t sweep_words, const unsigned long long *seg_fill,
+                       uint32_t nsegs, uint64_t seg_cap, const unsigned long long *gave_up, const unsigned long long *recount_hist,
+                       uint32_t recount_words, const papr_guess_out *guess, const papr_true_out *tru, unsigned long long *vec)
+{
+    hipLaunchKernelGGL(papr_xpack_kernel, dim3(1), dim3(1024), 0, st, sweep_hist, sweep_words, seg_fill, nsegs, seg_cap, gave_up,
+                       recount_hist, recount_words, guess, tru, vec);
+}
+
 __global__ __launch_bounds__(1024) void papr_guess_bands_kernel(
     const papr_partial *__restrict__ est_partials, const double *__restrict__ est_sq, uint32_t est_blocks, uint64_t ngroups,
     uint64_t sampled, uint64_t nsamples, uint32_t ratio, int graph, float max_db, float spoil, int band_override,
     uint32_t copies, int compact, uint32_t soft_lds, uint32_t *__restrict__ table, uint32_t table_cap_words,
     papr_guess_out *__restrict__ out_dev, papr_guess_out *__restrict__ out_host, unsigned long long *__restrict__ zero,
-    uint32_t zero_words)
+    uint32_t zero_words, const papr_est_record *__restrict__ recs, uint32_t nrecs, uint32_t my_rank)
 {
     constexpr uint32_t kNeverHi = 0xFFFFFFFFu;
     for (uint32_t w = threadIdx.x; w < zero_words; w += 1024)
@@ -354,33 +500,38 @@ __global__ __launch_bounds__(1024) void papr_guess_bands_kernel(
     __shared__ uint32_t edges[2 * PAPR_GUESS_MAX_BANDS];
     __shared__ uint32_t s_m, s_bad;
     const uint32_t t = threadIdx.x;
-    // ---- the estimate: sum and sum of squared piece sums (fixed order: deterministic) ----
-    double a = 0.0, q = 0.0;
-    for (uint32_t b = t; b < est_blocks; b += 1024) {
-        a += est_partials[b].sum;
-        q += est_sq[b];
+    double mean, rel, est_sum, est_before = 0.0;
+    if (recs) {
+        // ---- peers: every shard's record (rank = file order), the same on every rank: the FILE's mean, the largest of
+        // the shards' relative standard errors (papr_stats_merge keeps the maximum), what lies in front of this shard ----
+        double tot = 0.0, ntot = 0.0, relmax = 0.0, mine = 0.0;
+        for (uint32_t r = 0; r < nrecs; r++) {
+            const papr_est_record e = recs[r];
+            const double scaled = e.sampled ? e.S * ((double)e.n / (double)e.sampled) : 0.0;
+            const double pieces = (double)e.pieces;
+            const double var_total = pieces > 1.0 ? pieces / (pieces - 1.0) * fmax(0.0, e.sq - e.S * e.S / pieces) : 0.0;
+            const double rel_r = (e.S > 0.0 && e.ratio > 1) ? (double)(float)(sqrt(var_total) / e.S) : 0.0;  // (the host path carries it as a float)
+            if (r < my_rank)
+                est_before += scaled;
+            if (r == my_rank)
+                mine = scaled;
+            tot += scaled;
+            ntot += (double)e.n;
+            relmax = rel_r > relmax || !(rel_r == rel_r) ? rel_r : relmax;
+        }
+        mean = ntot > 0.0 ? tot / ntot : 0.0;
+        rel = relmax;
+        est_sum = mine;
+    } else {
+        // ---- the estimate: sum and sum of squared piece sums (fixed order: deterministic) ----
+        const double S = block_sum_1024(est_partials, est_blocks, red);
+        const double sq = block_sum_1024(est_sq, est_blocks, red);
+        const double pieces = 4.0 * (double)ngroups;
+        const double var_total = pieces > 1.0 ? pieces / (pieces - 1.0) * fmax(0.0, sq - S * S / pieces) : 0.0;
+        rel = (S > 0.0 && ratio > 1) ? sqrt(var_total) / S : 0.0;
+        mean = sampled ? S / (double)sampled : 0.0;
+        est_sum = sampled ? S * ((double)nsamples / (double)sampled) : 0.0;
     }
-    red[t] = a;
-    __syncthreads();
-    for (uint32_t w = 512; w > 0; w >>= 1) {
-        if (t < w)
-            red[t] += red[t + w];
-        __syncthreads();
-    }
-    const double S = red[0];
-    __syncthreads();
-    red[t] = q;
-    __syncthreads();
-    for (uint32_t w = 512; w > 0; w >>= 1) {
-        if (t < w)
-            red[t] += red[t + w];
-        __syncthreads();
-    }
-    const double sq = red[0];
-    const double pieces = 4.0 * (double)ngroups;
-    const double var_total = pieces > 1.0 ? pieces / (pieces - 1.0) * fmax(0.0, sq - S * S / pieces) : 0.0;
-    const double rel = (S > 0.0 && ratio > 1) ? sqrt(var_total) / S : 0.0;
-    const double mean = sampled ? S / (double)sampled : 0.0;
     // ---- band half-width: 4.5 standard errors, 2^10 .. 2^20 (papr_sweep_band_for) ----
     int band = 10;
     {
@@ -530,8 +681,9 @@ __global__ __launch_bounds__(1024) void papr_guess_bands_kernel(
             o->band_log2 = (uint32_t)band;
             o->nbands = ok ? m : 0u;
             o->pad = 0;
-            o->est_sum = sampled ? S * ((double)nsamples / (double)sampled) : 0.0;
+            o->est_sum = est_sum;
             o->est_rel_se = rel;
+            o->est_before = est_before;
         }
     }
     for (uint32_t j = t; j < m && ok; j += 1024) {
@@ -544,11 +696,12 @@ void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, c
                              uint64_t ngroups, uint64_t sampled, uint64_t nsamples, uint32_t ratio, int graph, float max_db,
                              float spoil, int band_override, uint32_t copies, int compact, uint32_t soft_lds, uint32_t *table,
                              uint32_t table_cap_words, papr_guess_out *out_dev, papr_guess_out *out_host,
-                             unsigned long long *zero, uint32_t zero_words)
+                             unsigned long long *zero, uint32_t zero_words, const papr_est_record *recs, uint32_t nrecs,
+                             uint32_t my_rank)
 {
     hipLaunchKernelGGL(papr_guess_bands_kernel, dim3(1), dim3(1024), 0, st, est_partials, est_sq, est_blocks, ngroups, sampled,
                        nsamples, ratio, graph, max_db, spoil, band_override, copies, compact, soft_lds, table, table_cap_words,
-                       out_dev, out_host, zero, zero_words);
+                       out_dev, out_host, zero, zero_words, recs, nrecs, my_rank);
 }
 
 // =============================================================================
@@ -566,8 +719,11 @@ __global__ __launch_bounds__(1024) void papr_true_table_kernel(const papr_partia
                                                                 uint32_t table_cap_words, papr_true_out *__restrict__ out_dev,
                                                                 papr_true_out *__restrict__ out_host,
                                                                 unsigned long long *__restrict__ zero, uint32_t zero_words,
-                                                                const unsigned long long *__restrict__ gave_up)
+                                                                const unsigned long long *__restrict__ gave_up,
+                                                                const unsigned long long *__restrict__ nsamples_dev)
 {
+    if (nsamples_dev)
+        nsamples = *nsamples_dev;  // (peers: the file's length, known once the shards' records have been gathered)
     for (uint32_t w = threadIdx.x; w < zero_words; w += 1024)
         zero[w] = 0;  // (the recount's histogram)
     const bool hopeless = *gave_up != 0;  // the sweep gave itself up: its stash is void, nothing to recount
@@ -691,10 +847,10 @@ __global__ __launch_bounds__(1024) void papr_true_table_kernel(const papr_partia
 void papr_launch_true_table(hipStream_t st, const papr_partial *result, uint64_t nsamples, int graph, uint32_t copies,
                             uint32_t soft_lds, uint32_t *table, uint32_t table_cap_words, papr_true_out *out_dev,
                             papr_true_out *out_host, unsigned long long *zero, uint32_t zero_words,
-                            const unsigned long long *gave_up)
+                            const unsigned long long *gave_up, const unsigned long long *nsamples_dev)
 {
     hipLaunchKernelGGL(papr_true_table_kernel, dim3(1), dim3(1024), 0, st, result, nsamples, graph, copies, soft_lds, table,
-                       table_cap_words, out_dev, out_host, zero, zero_words, gave_up);
+                       table_cap_words, out_dev, out_host, zero, zero_words, gave_up, nsamples_dev);
 }
 
 // =============================================================================
@@ -975,7 +1131,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
 #pragma unroll
         for (int u = 0; u < 2 * U; u++)
             count_and_stash(pw[u], k[u]);
-        if constexpr (!(ABL & 32))
+        if constexpr (!(ABL & 32) && !(SMODE & 64))
             ws.spill_if_above(SLICE - 2 * U * kWave - ((SMODE & 8) ? kWave : 0), (it + 1) * (uint32_t)(2 * TILE_F4));  // the next tile might not fit
     };
 
@@ -983,6 +1139,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
     const uint64_t step = w.stride * TILE_F4;
     if constexpr (PIPE == 2) {
         // true double buffering (two register sets, loop unrolled by two): no cur = nxt copies
+        static_assert(!(SMODE & 64), "the early spill check belongs to the prefetching loop");
         float4 a[U], b[U];
         const float4 *plast = data + (w.first + (uint64_t)(w.count ? w.count - 1 : 0) * w.stride) * TILE_F4 + t;
         if (w.count)
@@ -1005,12 +1162,17 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
             p += step;
             if (it + 1 < w.count)
                 load_tile<BLOCK, U, NT>(nxt, p);
+            // SMODE bit 6: the spill check IN FRONT of the fold, behind the next tile's loads — a spill's stores then have
+            // the fold's duration to drain before this wave waits for memory again (vmcnt is in order and counts stores)
+            if constexpr ((SMODE & 64) != 0)
+                ws.spill_if_above(SLICE - 2 * U * kWave - ((SMODE & 8) ? kWave : 0), (it + 1) * (uint32_t)(2 * TILE_F4));
             fold(cur, it);
 #pragma unroll
             for (int u = 0; u < U; u++)
                 cur[u] = nxt[u];
         }
     } else {
+        static_assert(!(SMODE & 64), "the early spill check belongs to the prefetching loop");
         for (uint32_t it = 0; it < w.count; it++, p += step) {
             float4 x[U];
             load_tile<BLOCK, U, NT>(x, p);
@@ -1019,6 +1181,8 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_kernel(const float4 *__restr
     }
     // sub-tile remainder of the shard: binned here (its pass-1 part is folded in by papr_stats_finalize)
     if (blockIdx.x == gridDim.x - 1) {
+        if constexpr ((SMODE & 64) != 0)
+            ws.spill_if_above(SLICE - 2 * kWave, ~0u);
         for (uint32_t k0 = 0; k0 < tail_samples; k0 += BLOCK) {  // wave-uniform trip count
             const bool valid = k0 + t < tail_samples;
             const float2 x = valid ? tail[k0 + t] : make_float2(0.f, 0.f);
@@ -1806,6 +1970,244 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
 }
 
 // =============================================================================
+// 3c. the exact-sum sweep, third form: papr_sweep_kernel's per-sample code on wave-private segments
+// =============================================================================
+// papr_sweep2_kernel<EXACT> is instruction-bound: 37 VALU + 18 SALU per sample at three waves per SIMD (compact-table
+// lookup 9, one exec-masked region each for the histogram and the stash, an ordered 64-lane composition of the
+// segment's pairs worth 6).  This form keeps its data flow — a wave owns 1024-sample segments, lanes own 16 consecutive
+// samples through the XOR-swizzled LDS transposition, the next segment's loads fly while this one is folded out of
+// LDS — and replaces the rest:
+//   * geometry and per-sample code of the default kernel (papr_sweep_kernel<512, 8, SMODE 43>): one persistent
+//     workgroup of eight waves per CU, the ONE-edge-per-cell table (five VALU per lookup), histogram and stash without
+//     a branch or an exec-masked region, 16-byte write-through spills out of a per-wave slice;
+//   * the segment's pair without an ordered tree.  A lane's run maps the parity of the running sum onto itself:
+//     pi(0) = lsb of x0, pi(1) = lsb of x1 (the sums it formed from the even and the odd canonical entry state), and its
+//     increment is d0 or d1 = d0 + delta * ulp, delta in {-1, 0, +1}.  The parity with which the running sum ENTERS
+//     lane l, for segment entry parity p, follows from the 64 one-bit maps alone — ballots and a dozen 64-bit scalar
+//     operations: a prefix XOR over the lanes that swap, restarted behind every lane whose map is constant — and then
+//     D[p] = sum(d0) + ulp * (#{delta = +1, entered odd} - #{delta = -1, entered odd}): ONE unordered wave sum (every
+//     term is a multiple of the ulp: exact in any order) and four popcounts.
+template <int WAVES, int SMODE, int HALF, bool EXACT>
+__global__ __launch_bounds__(WAVES *kWave) void papr_sweep3_kernel(const papr_sweep2_params p)
+{
+    constexpr int U = 8;
+    constexpr int BLOCK = WAVES * kWave;
+    constexpr uint64_t SEG_F4 = 64ull * U;
+    // HALF = float4 per lane between two spill checks: 4 (two batches per segment), or 8 — the whole segment as ONE batch:
+    // its eight LDS reads, then its sixteen table lookups, are in flight together and the double-precision chains run
+    // under them; with two waves per SIMD it is the LDS round trips per segment that decide how long a wave is stalled
+    static_assert(HALF == 4 || HALF == 8, "batches per segment");
+    static_assert((SMODE & 11) == 11, "branch-free ballot stash with 16-byte spills");
+    __shared__ unsigned long long seg_fill, seg_real_sh;
+    __shared__ uint32_t wave_fill[WAVES];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const papr_ccdf_params P = uniform_params(p.Pdev, p.P);
+    const uint32_t nbins = P.nkeys + 2;  // + the NaN trash bin (as papr_sweep_kernel)
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *hist = tab + P.table_words;
+    float *slices = reinterpret_cast<float *>(hist + ((P.copies * nbins + 3u) & ~3u));
+    // the stash slices take what table and histogram leave of the launch's LDS (p.lds_bytes): a small table (the 1 dB
+    // one) means rare, wide spills; at least PAPR_SWEEP3_SLICE_FLOATS (what the geometry function promises), at most 4096
+    const uint32_t used_words = (uint32_t)(slices - reinterpret_cast<float *>(smem));
+    constexpr uint32_t kXposeWords = EXACT ? WAVES * 2048u : 0u;
+    const uint32_t free_words = p.lds_bytes / 4u > used_words + kXposeWords ? p.lds_bytes / 4u - used_words - kXposeWords : 0u;
+    uint32_t slice_words = (free_words / WAVES) & ~63u;
+    slice_words = slice_words < PAPR_SWEEP3_SLICE_FLOATS ? PAPR_SWEEP3_SLICE_FLOATS : (slice_words > 4096u ? 4096u : slice_words);
+    const uint32_t SLICE = __builtin_amdgcn_readfirstlane(slice_words);
+    float4 *xpose = reinterpret_cast<float4 *>(slices + WAVES * SLICE);  // WAVES x 8 KiB
+
+    const uint32_t t = threadIdx.x;
+    const uint32_t lane = t & (kWave - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(t / kWave);
+    for (uint32_t k = t; k < P.table_words; k += BLOCK)
+        tab[k] = p.table[k];
+    for (uint32_t k = t; k < P.copies * nbins; k += BLOCK)
+        hist[k] = 0;
+    if (t == 0) {
+        seg_fill = p.seg_slots[blockIdx.x];  // segments keep filling over the launches of a chunked ingest
+        seg_real_sh = p.seg_real[blockIdx.x];
+    }
+    if (t < WAVES)
+        wave_fill[t] = 0;
+    __syncthreads();
+
+    const uint2 *lut_biased = reinterpret_cast<const uint2 *>(tab) - ((int32_t)P.cell_lo - 1);
+    uint32_t *my = hist + (wave % P.copies) * nbins;
+    WaveStashT<SMODE> ws{0u, slices + wave * SLICE, &wave_fill[wave], p.stash + (uint64_t)blockIdx.x * p.seg_cap,
+                        &seg_fill, p.seg_cap, tab, P.table_words, 0u, seg_fill, p.gave_up, &seg_real_sh};
+    ws.trash = SLICE - kWave + lane;
+    ws.sbase = ws.sbytes = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u32 *)ws.buf);
+    const int32_t cell_last = (int32_t)(P.cell_lo + P.ncells);
+    int32_t cell_first;  // pinned in a VGPR (v_med3 takes one scalar operand)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(cell_first) : "s"((int32_t)P.cell_lo - 1));
+    const uint32_t shift = P.shift;
+    auto bin_of = [&](float pw) -> uint32_t {
+        const int32_t cell = __float_as_int(pw) >> shift;  // arithmetic shift: sign-bit patterns go below the table
+        const uint2 e = lut_biased[clamp_cell(cell, cell_first, cell_last)];
+        return e.x + (__float_as_uint(pw) >= e.y ? 1u : 0u);
+    };
+    auto count_and_stash = [&](float pw, uint32_t k) {
+        // bin 0 (below every band: not counted) adds to this lane's trash word instead of being skipped
+        const unsigned long long nz = __ballot(k != 0u);
+        const uint32_t a_bin = (uint32_t)(uintptr_t)(lds_u32 *)&my[k];
+        const uint32_t a_trash = (uint32_t)(uintptr_t)(lds_u32 *)&ws.buf[ws.trash];
+        uint32_t a;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a) : "v"(a_trash), "v"(a_bin), "s"(nz));
+        (void)__hip_atomic_fetch_add((lds_u32 *)(uintptr_t)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ws.put(pw, (k & 1u) != 0u);
+    };
+
+    const float4 *data = reinterpret_cast<const float4 *>(p.data);
+    const uint64_t seg_stride = (uint64_t)gridDim.x * WAVES;
+    const uint64_t seg0 = (uint64_t)blockIdx.x * WAVES + wave;
+    const uint32_t count = p.nsegs > seg0 ? (uint32_t)((p.nsegs - seg0 + seg_stride - 1) / seg_stride) : 0u;
+    auto load_seg = [&](float4(&x)[U], uint64_t seg) {
+        const unsigned long long base = uniform_u64((unsigned long long)(data + seg * SEG_F4));  // wave-uniform: scalar base
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            x[u] = load16_nt_at(base, lane + u * kWave);
+    };
+
+    double sum = 0.0;
+    TileTrack tr = {{0.f, 0.f, 0.f, 0.f, 0.f}, {0, 0, 0, 0, 0}};
+    // one batch of HALF float4 per lane: powers, extremes, (exact mode: the two canonical sums), bins, stash
+    auto fold_batch = [&](const float4(&y)[HALF], SegMax &m, double &x0, double &x1) {
+        float pw[2 * HALF];
+#pragma unroll
+        for (int u = 0; u < HALF; u++) {
+            // (power_of with the squares as one packed multiplication and the additions written out: see papr_sweep_kernel)
+            typedef float f32x2v __attribute__((ext_vector_type(2)));
+            const f32x2v a = {y[u].x, y[u].y}, b = {y[u].z, y[u].w};
+            const f32x2v aa = a * a, bb = b * b;
+            asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u]) : "v"(aa.x), "v"(aa.y));
+            asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u + 1]) : "v"(bb.x), "v"(bb.y));
+            segmax_fold(m, y[u], pw[2 * u], pw[2 * u + 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * HALF; u++) {
+            const double v = (double)pw[u];
+            x0 += v;  // exact mode: the reference's additions themselves (papr.c:104), from the two canonical entry states;
+            if constexpr (EXACT)
+                x1 += v;  // otherwise x0 is the lane's accurate sum (as papr_stats_kernel)
+        }
+        uint32_t k[2 * HALF];
+#pragma unroll
+        for (int u = 0; u < 2 * HALF; u++)
+            k[u] = bin_of(pw[u]);  // the LUT reads in flight together
+#pragma unroll
+        for (int u = 0; u < 2 * HALF; u++)
+            count_and_stash(pw[u], k[u]);
+    };
+    if constexpr (EXACT) {
+    float4 *mine = xpose + wave * (kWave * 8);
+    const int32_t *__restrict__ tile_E = p.tile_E_spec;
+    double2 *__restrict__ seg_D = reinterpret_cast<double2 *>(p.seg_D);
+    float4 x[U];
+    if (count)
+        load_seg(x, seg0);
+    for (uint32_t it = 0; it < count; it++) {
+        const uint64_t seg = seg0 + (uint64_t)it * seg_stride;
+        const int E = __builtin_amdgcn_readfirstlane(tile_E[(p.seg_offset + seg) >> 1]);
+#pragma unroll
+        for (int r = 0; r < U; r++) {
+            const int f = r * kWave + (int)lane;  // float4 slot within the segment, file order
+            mine[xpose_slot(f >> 3, f & 7)] = x[r];
+        }
+        // the registers are free again: the next segment's loads fly while this one is folded out of LDS — in front of
+        // any spill store of this segment, so that a spill never stands between the wave and its next data
+        // (same wave wrote and reads the buffer: LDS operations of one wave complete in order)
+        if (it + 1 < count)
+            load_seg(x, seg + seg_stride);
+        const bool valid = E != PAPR_EXACT_AMBIG;
+        const double m0 = valid ? pow2_f64(E) : 0.0, ulp = valid ? pow2_f64(E - 52) : 0.0, m1 = m0 + ulp;
+        double x0 = m0, x1 = m1;
+        SegMax m = {0u, 0u, 0u, INT32_MIN, INT32_MIN};
+#pragma unroll
+        for (int h = 0; h < U / HALF; h++) {
+            // room for the next 2 * HALF samples of every lane (and the trash words)?  Checked IN FRONT of the fold, behind
+            // the next segment's loads: a spill's stores then have the fold's duration to drain before this wave waits
+            // for memory again (vmcnt is in order and counts stores too)
+            ws.spill_if_above(SLICE - (2 * HALF + 1) * kWave, (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
+            float4 y[HALF];
+#pragma unroll
+            for (int j = 0; j < HALF; j++)
+                y[j] = mine[xpose_slot((int)lane, h * HALF + j)];
+            fold_batch(y, m, x0, x1);
+        }
+        segmax_commit(tr, m, it);
+        // ---- the segment's pair ----
+        const double d0 = x0 - m0, d1 = x1 - m1;  // exact: multiples of the ulp inside the binade (plain sums when no binade was given)
+        sum += d0;
+        const unsigned long long A = __ballot((__double2loint(x0) & 1) != 0), B = __ballot((__double2loint(x1) & 1) != 0);
+        const unsigned long long up = __ballot(d1 > d0), dn = __ballot(d1 < d0);
+        const unsigned long long C = ~(A ^ B), N = A & ~B;  // lanes whose map is constant / swaps the parity
+        unsigned long long px = N;                            // prefix XOR (inclusive), then exclusive
+        px ^= px << 1;
+        px ^= px << 2;
+        px ^= px << 4;
+        px ^= px << 8;
+        px ^= px << 16;
+        px ^= px << 32;
+        px <<= 1;
+        // fill forward from the constant lanes: the carry of an addition runs through the ones of ~C up to the next marker
+        const unsigned long long Z = ~C, Y = (A ^ px) & C;
+        const unsigned long long fwd = (Z + (Y << 1)) ^ Z;    // bit l: (A ^ px) of the last constant lane below l, 0 if none
+        const unsigned long long has = (Z + (C << 1)) ^ Z;    // bit l: there is a constant lane below l
+        const unsigned long long odd0 = px ^ fwd, odd1 = odd0 ^ ~has;  // lanes the sum enters with odd parity, for p = 0 / 1
+        const int k0 = __popcll(up & odd0) - __popcll(dn & odd0), k1 = __popcll(up & odd1) - __popcll(dn & odd1);
+        const double S = wave_sum_to_lane63(d0);
+        if (lane == kWave - 1)
+            seg_D[p.seg_offset + seg] = make_double2(S + (double)k0 * ulp, S + (double)k1 * ulp);
+    }
+    } else {
+        // plain form: folded straight out of the registers (lane l owns float4 u * 64 + l), the next segment's loads
+        // issued — and the spill check made — in front of the fold
+        float4 cur[U], nxt[U];
+        if (count)
+            load_seg(cur, seg0);
+        double none = 0.0;
+        for (uint32_t it = 0; it < count; it++) {
+            if (it + 1 < count)
+                load_seg(nxt, seg0 + (uint64_t)(it + 1) * seg_stride);
+            SegMax m = {0u, 0u, 0u, INT32_MIN, INT32_MIN};
+#pragma unroll
+            for (int h = 0; h < U / HALF; h++) {
+                ws.spill_if_above(SLICE - (2 * HALF + 1) * kWave, (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
+                float4 y[HALF];
+#pragma unroll
+                for (int j = 0; j < HALF; j++)
+                    y[j] = cur[h * HALF + j];
+                fold_batch(y, m, sum, none);
+            }
+            segmax_commit(tr, m, it);
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                cur[u] = nxt[u];
+        }
+    }
+    // remainder of the launch: binned here (its pass-1 part is folded in by papr_stats_finalize, its exact-sum part
+    // travels raw in the sum program)
+    if (blockIdx.x == gridDim.x - 1) {
+        const float2 *tail = reinterpret_cast<const float2 *>(p.tail);
+        for (uint32_t k0 = 0; k0 < p.tail_samples; k0 += BLOCK) {  // wave-uniform trip count
+            const bool ok = k0 + t < p.tail_samples;
+            const float2 v = ok ? tail[k0 + t] : make_float2(0.f, 0.f);
+            const float pw = power_of(v.x, v.y);
+            ws.spill_if_above(SLICE - 2 * kWave, ~0u);
+            count_and_stash(pw, ok ? bin_of(pw) : 0u);
+        }
+    }
+    ws.spill_if_above(0, ~0u);
+
+    sweep2_record<WAVES, U, EXACT>(sum, tr, seg0, seg_stride, data, p.base_index, p.out);
+    hist_flush<BLOCK>(hist, nbins, P.copies, p.ghist);  // (starts with a barrier: every wave has spilled)
+    if (t == 0) {
+        p.seg_slots[blockIdx.x] = seg_fill;
+        p.seg_real[blockIdx.x] = seg_real_sh;
+    }
+}
+
+// =============================================================================
 // 4. pass 2 over the stash (float powers, not IQ)
 // =============================================================================
 // Whole-chip geometry rather than one workgroup per segment: 2 x 1024 threads per CU, every segment cut into `split`
@@ -1942,9 +2344,10 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
     X(88, 1024, 4, 0, false, 14) X(89, 256, 8, 1, false, 14) X(101, 512, 8, 1, false, 10)                                  \
     X(102, 512, 4, 0, false, 10) X(103, 1024, 8, 0, false, 10) X(104, 512, 8, 0, false, 11) X(105, 512, 8, 0, false, 26)   \
     X(106, 512, 8, 0, false, 27) X(107, 512, 8, 0, false, 42) X(109, 512, 8, 0, false, 59)   \
-    X(110, 512, 8, 1, false, 11) X(111, 512, 8, 1, false, 43) X(112, 256, 8, 0, false, 43) X(113, 1024, 4, 0, false, 43)
+    X(110, 512, 8, 1, false, 11) X(111, 512, 8, 1, false, 43) X(112, 256, 8, 0, false, 43) X(113, 1024, 4, 0, false, 43) \
+    X(114, 512, 8, 1, false, 107)
 #else
-#define PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X) X(40, 512, 8, 0, false, 43)
+#define PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X) X(40, 512, 8, 0, false, 43) X(111, 512, 8, 1, false, 43) X(114, 512, 8, 1, false, 107)
 #endif
 
 // loader / binner split (papr_sweep_split_kernel): id, loader waves, binners per loader, loads per lane per tile, ring depth
@@ -2148,6 +2551,40 @@ void papr_launch_sweep2(hipStream_t st, int variant, int blocks, size_t lds_byte
     }
 }
 
+// Third form of the exact-sum sweep: id, waves per workgroup, stash mode (as papr_sweep_kernel's SMODE)
+#define PAPR_FOR_EACH_SWEEP3_VARIANT(X) X(130, 8, 43, 4, true) X(131, 8, 43, 8, true) X(132, 8, 43, 8, false) X(133, 12, 43, 8, false) X(134, 12, 43, 4, false)
+
+int papr_sweep3_geometry(int variant, int *threads, size_t *lds_fixed, int *exact)
+{
+    switch (variant) {
+#define X(V, W, SM, H, EX)                                                                           \
+    case V:                                                                                           \
+        *threads = W * kWave;                                                                         \
+        *lds_fixed = (size_t)W * PAPR_SWEEP3_SLICE_FLOATS * sizeof(float) + (EX ? (size_t)W * 8192u : 0u) + 16; \
+        if (exact)                                                                                    \
+            *exact = EX ? 1 : 0;                                                                      \
+        return 0;
+        PAPR_FOR_EACH_SWEEP3_VARIANT(X)
+#undef X
+    default: return -1;
+    }
+}
+
+void papr_launch_sweep3(hipStream_t st, int variant, int blocks, size_t lds_bytes, const papr_sweep2_params &p)
+{
+    switch (variant) {
+#define X(V, W, SM, H, EX)                                                                                       \
+    case V: {                                                                                                     \
+        papr_sweep2_params q = p;                                                                                 \
+        q.lds_bytes = (uint32_t)lds_bytes;                                                                        \
+        launch_maybe_timed((papr_sweep3_kernel<W, SM, H, EX>), dim3(blocks), dim3(W * kWave), lds_bytes, st, q);  \
+        break;                                                                                                    \
+    }
+        PAPR_FOR_EACH_SWEEP3_VARIANT(X)
+#undef X
+    }
+}
+
 void papr_launch_ccdf_power(hipStream_t st, int num_cus, bool lut, size_t lds_bytes, const float *stash,
                             const unsigned long long *seg_counts, uint64_t seg_cap, uint32_t nsegs, const uint32_t *table,
                             const papr_ccdf_params &P, unsigned long long *ghist, const papr_ccdf_params *Pdev)
@@ -2207,6 +2644,10 @@ void papr_sweep_prepare_device(void)
     (void)hipFuncSetAttribute((const void *)papr_sweep_kernel<B, U, true, PP, 0, L2, SM>,                          \
                               hipFuncAttributeMaxDynamicSharedMemorySize, want);
     PAPR_FOR_EACH_SWEEP_SP16_VARIANT(X)
+#undef X
+#define X(V, W, SM, H, EX) \
+    (void)hipFuncSetAttribute((const void *)papr_sweep3_kernel<W, SM, H, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    PAPR_FOR_EACH_SWEEP3_VARIANT(X)
 #undef X
     (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
     (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, want);

@@ -7,6 +7,16 @@ using namespace papr_rt;
 
 namespace papr_rt {
 
+// Floats per workgroup segment of the HBM stash (capacity and stride): 1/4 of the workgroup's samples, in whole 1 KiB
+// spills, plus a skew — equal shares of a power-of-two shard are a multiple of the memory channels' interleave apart,
+// so that all workgroups, filling their segments at the same pace, would write to the same channels at the same time.
+static uint64_t stash_segment_floats(uint64_t n_shard, int blocks)
+{
+    const uint64_t share = std::max<uint64_t>((n_shard / 4 / (uint64_t)blocks + 255) & ~255ull, 4096);
+    const uint64_t skew = (uint64_t)std::max(0, env_int("PAPR_STASH_SKEW", kStashSkewFloats)) & ~255ull;
+    return share + skew;
+}
+
 // Compact LUT (papr_kernels.h) for ascending, distinct band edges: the coarsest cell size that leaves at most two
 // edges in any cell.  False: no such form (more than PAPR_LUT2_MAX_EDGES edges, or the table would not fit).
 static bool plan_compact_lut(const std::vector<uint32_t> &edges, papr_ccdf_params *P)
@@ -70,6 +80,9 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
     int vblock = 512, v2_exact = 0;
     run->variant = variant_of(ctx, SWEEP);
     run->v2 = papr_sweep2_geometry(run->variant, &vblock, &run->tile, &run->stash_lds, &v2_exact) == 0;
+    run->v3 = !run->v2 && papr_sweep3_geometry(run->variant, &vblock, &run->stash_lds, &v2_exact) == 0;
+    if (run->v3)
+        run->tile = PAPR_EXACT_SEG_SAMPLES;  // (a wave's segment; exact mode: whole 2048-sample tiles, below)
     // papr_sweep_kernel's LUT has one band edge per cell: its cells are as narrow as the bands, and a 20-octave table of
     // them fits the LDS budget from 2^14 on (a narrower hint is simply not taken up; papr_sweep2_kernel's cells hold two)
     run->lut2 = run->v2 || PAPR_SWEEP_VARIANT_IS_LUT2(run->variant);
@@ -77,7 +90,7 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
         info.band_log2 = kSweepBandLog2;
     run->exact = v2_exact != 0;
     run->threads = vblock;
-    if (!run->v2)
+    if (!run->v2 && !run->v3)
         (void)papr_sweep_geometry(run->variant, &vblock, &run->tile, &run->stash_lds);
     const size_t lds_cap = (size_t)papr_ccdf_max_dynamic_lds();
     std::vector<uint32_t> &gkeys = run->gkeys;
@@ -109,19 +122,26 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
     }
     if (!run->half)
         return PAPR_OK;
-    if (run->v2) {
-        run->nbins = bands.P.nkeys + 1;
-        const int waves = vblock / 64;
+    // a persistent workgroup has the CU's LDS to itself: as many histogram copies (up to 4) as fit beside table and stash
+    auto copies_that_fit = [&](uint32_t nbins, int waves) {
         int copies = ctx->tune.hist_copies > 0 ? std::min(ctx->tune.hist_copies, waves) : std::min(waves, 4);
         auto lds_of = [&](int c) {
-            return (size_t)bands.P.table_words * 4 + (((size_t)c * run->nbins + 3) & ~(size_t)3) * 4 + run->stash_lds;
+            return (size_t)bands.P.table_words * 4 + (((size_t)c * nbins + 3) & ~(size_t)3) * 4 + run->stash_lds;
         };
         while (copies > 1 && lds_of(copies) > lds_cap - 2048)  // (2 KiB: the kernel's static LDS)
             copies--;
-        if (lds_of(copies) > lds_cap - 2048)
+        return lds_of(copies) > lds_cap - 2048 ? 0 : copies;
+    };
+    if (run->v2 || run->v3) {
+        if (run->v3)  // papr_sweep_kernel's table: a sentinel cell at either end, one more (NaN) bin
+            bands.P.table_words = 2 * (bands.P.ncells + 2);
+        run->nbins = bands.P.nkeys + (run->v3 ? 2 : 1);
+        const int waves = vblock / 64;
+        const int copies = copies_that_fit(run->nbins, waves);
+        if (!copies)
             return PAPR_OK;
         bands.P.copies = (uint32_t)copies;
-        bands.lds_bytes = lds_of(copies) - run->stash_lds;
+        bands.lds_bytes = (size_t)bands.P.table_words * 4 + (((size_t)copies * run->nbins + 3) & ~(size_t)3) * 4;
         if (run->exact) {
             if (!ctx->exact || (!ctx->est_groups_valid && !env_int("PAPR_SWEEP2_FAKE_E", 0))) {
                 *reason = PAPR_SWEEP_MODE;  // no per-group estimate to speculate the binades from
@@ -147,8 +167,13 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
             while (c > 1 && (size_t)c * run->nbins * 4 > 16 * 1024)
                 c >>= 1;
             bands.P.copies = c;
+        } else if (PAPR_SWEEP_VARIANT_IS_PERSISTENT(run->variant)) {
+            // (finish_plan sized the copies for a CU shared between workgroups: one, next to a 96 KiB stash slice)
+            const int copies = copies_that_fit(run->nbins, vblock / 64);
+            if (copies)
+                bands.P.copies = (uint32_t)copies;
         }
-        bands.lds_bytes = (size_t)bands.P.table_words * 4 + (size_t)bands.P.copies * run->nbins * 4;
+        bands.lds_bytes = (size_t)bands.P.table_words * 4 + (((size_t)bands.P.copies * run->nbins + 3) & ~(size_t)3) * 4;
         if (bands.lds_bytes + run->stash_lds > lds_cap)
             return PAPR_OK;
         run->blocks = pick_blocks(ctx, SWEEP, n_launch / run->tile);
@@ -162,7 +187,7 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_sweep_hist, bytes));
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_sweep_hist, bytes, hipHostMallocDefault));
     }
-    run->seg_cap = std::max<uint64_t>((n_shard / 4 / (uint64_t)run->blocks + 255) & ~255ull, 4096);
+    run->seg_cap = stash_segment_floats(n_shard, run->blocks);
     const uint64_t want_stash = run->seg_cap * (uint64_t)run->blocks;
     if (ctx->stash_cap < want_stash) {
         if (ctx->d_stash) HIPCHK(ctx, hipFree(ctx->d_stash));
@@ -217,7 +242,7 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
 {
     const uint64_t ntiles = n / run.tile;
     const uint32_t tail = (uint32_t)(n - ntiles * run.tile);
-    if (run.v2) {
+    if (run.v2 || run.v3) {
         const int waves = run.threads / 64;
         const uint64_t nsegs = run.exact ? 2 * ntiles : ntiles;
         const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)run.blocks, (nsegs + waves - 1) / waves));
@@ -243,7 +268,11 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
         p.seg_D = ctx->d_seg_D;
         p.seg_offset = (base_index - ctx->base) / PAPR_EXACT_SEG_SAMPLES;
         time_begin_kernel(ctx, 3, n * 8);
-        papr_launch_sweep2(ctx->stream, run.variant, blocks, run.bands.lds_bytes + run.stash_lds, p);
+        if (run.v3)  // (a persistent workgroup: all of the CU's LDS — what the table leaves goes to the stash slices)
+            papr_launch_sweep3(ctx->stream, run.variant, blocks,
+                               std::max<size_t>(run.bands.lds_bytes + run.stash_lds, (size_t)papr_ccdf_max_dynamic_lds() - 2048), p);
+        else
+            papr_launch_sweep2(ctx->stream, run.variant, blocks, run.bands.lds_bytes + run.stash_lds, p);
         time_end_kernel(ctx);
         HIPCHK(ctx, hipGetLastError());
         *nrecords = blocks;
@@ -311,6 +340,7 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
     ctx->sweep_valid = true;
     ctx->spec_recount_valid = false;  // (stats_sweep_fused sets it behind this call)
     info.swept = 1;
+    info.kernel_variant = run.variant;
     info.reason = PAPR_SWEEP_OK;
     info.stash_samples = stash_count;
     info.stash_capacity = run.seg_cap * (uint64_t)run.blocks;  // what this sweep could use (one segment per workgroup)
@@ -327,17 +357,56 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
 //   libm: a speculation the host checks bit for bit) -> stash recount on that table.
 // Anything else: *done stays false and the caller takes the host path.  The TRUE level table is the host's
 // (papr_levels) as before; what moved to the device are guesses.
-int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, papr_stats *out, bool *done)
+// With peers over an in-stream exchange (RCCL) the same sequence carries the step's three exchanges as collectives ON the
+// stream, between the kernels that produce and consume them — still one wait:
+//   estimate -> record of it -> ALL-GATHER -> guess from every shard's record -> sweep -> finalize -> ALL-GATHER of the
+//   pass-1 records -> ordered merge -> the FILE's level table -> recount -> [sweep bins | recount bins | flags] ->
+//   ALL-REDUCE -> host.
+// Every rank then holds the same global numbers and takes the same decisions from them.  (Exact-sum mode with peers
+// keeps the host path: its programs are exchanged and chained on the host.)
+int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max_db, float spoil, papr_stats *out, bool *done,
+                      PeerStep *peer)
 {
     *done = false;
+    ctx->peer_global = false;
     const bool exact = ctx->exact;
-    if (!ctx->loaded || !ctx->resident || ctx->have_file_stats || ctx->tune.sweep_variant > 0 || ctx->tune.sweep_map > 0 ||
-        ctx->tune.sweep_blocks > 0 || !env_int(exact ? "PAPR_FUSED_EXACT" : "PAPR_FUSED_GUESS", 1))
+    const bool peers = x && !papr_exchange_is_identity(x);
+    if (peers && (!xch_in_stream(x, ctx) || exact || !peer))
         return PAPR_OK;
+    // (a chosen kernel form goes through the host path, except the forms that share the default's launch shape: one
+    // persistent workgroup per CU)
+    const int chosen = ctx->tune.sweep_variant > 0 ? variant_of(ctx, SWEEP) : -1;
+    int dummy_threads = 0;
+    size_t dummy_lds = 0;
+    int chosen_exact3 = 0;
+    const bool chosen_v3 = chosen >= 0 && papr_sweep3_geometry(chosen, &dummy_threads, &dummy_lds, &chosen_exact3) == 0;
+    const bool chosen_ok = chosen < 0 || (exact ? (chosen_v3 && chosen_exact3) || chosen == 56
+                                                : (chosen_v3 && !chosen_exact3) || PAPR_SWEEP_VARIANT_IS_PERSISTENT(chosen));
     const uint64_t ntiles_est = ctx->n / PAPR_ESTIMATE_TILE_SAMPLES;
     const uint32_t nl = graph ? (uint32_t)(max_db * 10.0) + 1u : (uint32_t)max_db + 1u;
-    if (ntiles_est == 0 || nl > PAPR_GUESS_MAX_BANDS || !(max_db >= 0))
+    const bool eligible = ctx->loaded && ctx->resident && !ctx->have_file_stats && chosen_ok && ctx->tune.sweep_map <= 0 &&
+                          ctx->tune.sweep_blocks <= 0 && env_int(exact ? "PAPR_FUSED_EXACT" : "PAPR_FUSED_GUESS", 1) &&
+                          ntiles_est != 0 && nl <= PAPR_GUESS_MAX_BANDS && max_db >= 0 &&
+                          ctx->n / (exact ? (uint64_t)PAPR_EXACT_TILE_SAMPLES : 8192ull) != 0;
+    if (peers) {
+        // a rank that left this path while the others queue their collectives would hang them: the ranks agree ONCE per
+        // shard state (one host all-reduce, in the first step) that every one of them takes it
+        const uint64_t key = ((uint64_t)(uintptr_t)ctx->d_iq * 0x9E3779B97F4A7C15ull) ^ (ctx->n * 0xC2B2AE3D27D4EB4Full) ^ ctx->base ^
+                             ((uint64_t)graph << 62) ^ ((uint64_t)ctx->tune.sweep_variant << 40) ^ ((uint64_t)ctx->tune.estimate_ratio << 20) ^
+                             (uint64_t)ctx->tune.sweep_band_log2 ^ 1ull;
+        if (ctx->peer_agreed_key != key) {
+            uint64_t ok = eligible ? 1u : 0u;
+            const int xrc = papr_exchange_counts(x, &ok, 1);
+            if (xrc)
+                return fail(ctx, xrc, "exchange: %s", papr_exchange_last_error(x));
+            ctx->peer_agreed_key = key;
+            ctx->peer_agreed_ok = ok == (uint64_t)xch_world(x);
+        }
+        if (!ctx->peer_agreed_ok)
+            return PAPR_OK;
+    } else if (!eligible) {
         return PAPR_OK;
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     papr_hip_sweep_info &info = ctx->sweep_info;
     // ---- geometry: the default kernel of the mode; its table is what the device builds ----
@@ -345,38 +414,48 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     int vblock = 0;
     if (exact) {
         int v2_exact = 0;
-        run.variant = kSweepExactVariant;
-        if (papr_sweep2_geometry(run.variant, &vblock, &run.tile, &run.stash_lds, &v2_exact) != 0 || !v2_exact)
-            return PAPR_OK;
-        run.v2 = run.lut2 = run.exact = true;
+        run.variant = chosen >= 0 ? chosen : kSweepExactVariant;
+        if (papr_sweep3_geometry(run.variant, &vblock, &run.stash_lds) == 0) {
+            run.v3 = run.exact = true;  // papr_sweep_kernel's one-edge table, papr_sweep2_kernel's segments and launch
+        } else {
+            if (papr_sweep2_geometry(run.variant, &vblock, &run.tile, &run.stash_lds, &v2_exact) != 0 || !v2_exact)
+                return PAPR_OK;
+            run.v2 = run.lut2 = run.exact = true;
+        }
         run.tile = PAPR_EXACT_TILE_SAMPLES;  // the launch covers whole 2048-sample tiles (two segments each)
     } else {
-        run.variant = kSweepVariant;
+        run.variant = chosen >= 0 ? chosen : kSweepVariant;
         run.lut2 = PAPR_SWEEP_VARIANT_IS_LUT2(run.variant);
-        if (papr_sweep_geometry(run.variant, &vblock, &run.tile, &run.stash_lds) != 0)
+        if (papr_sweep3_geometry(run.variant, &vblock, &run.stash_lds) == 0) {
+            run.v3 = true;  // the plain form of papr_sweep3_kernel: wave-private 1024-sample segments
+            run.tile = PAPR_EXACT_SEG_SAMPLES;
+        } else if (papr_sweep_geometry(run.variant, &vblock, &run.tile, &run.stash_lds) != 0) {
             return PAPR_OK;
+        }
     }
     run.threads = vblock;
     const uint64_t ntiles = ctx->n / run.tile;
     if (ntiles == 0)
         return PAPR_OK;
     const int waves = vblock / 64;
-    if (exact)
-        run.blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus, (2 * ntiles + waves - 1) / waves));
+    const bool by_segments = exact || run.v3;  // launched through papr_sweep2_params: one persistent workgroup per CU
+    const uint64_t nsegs_launch = exact ? 2 * ntiles : ntiles;
+    if (by_segments)
+        run.blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus, (nsegs_launch + waves - 1) / waves));
     else
         run.blocks = pick_blocks(ctx, SWEEP, ntiles);
     constexpr uint32_t kBinsMax = 2 * PAPR_GUESS_MAX_BANDS + 2;
     constexpr uint32_t kCopies = 4;
     const size_t lds_cap = (size_t)papr_ccdf_max_dynamic_lds();
     // LDS for table + histogram copies: what the launch is given, and what the device-side plan has to fit into
-    const size_t table_lds = exact ? (lds_cap - 2048 > run.stash_lds ? lds_cap - 2048 - run.stash_lds : 0)
+    const size_t table_lds = by_segments ? (lds_cap - 2048 > run.stash_lds ? lds_cap - 2048 - run.stash_lds : 0)
                                    : (size_t)((PAPR_SWEEP_VARIANT_IS_LUT2(run.variant) ? 48 : 40) * 1024 + 32) +
                                          (((size_t)kCopies * kBinsMax + 3) & ~(size_t)3) * 4;  // (one-edge table: <= 40 KiB)
     if (table_lds < 16 * 1024 || table_lds + run.stash_lds > lds_cap)
         return PAPR_OK;
-    const uint32_t table_cap_words = exact ? (uint32_t)(table_lds / 4) : 48 * 1024 / 4 + 8;
+    const uint32_t table_cap_words = by_segments ? (uint32_t)(table_lds / 4) : 48 * 1024 / 4 + 8;
     // (the workgroup's share of the CU's LDS: 80 bytes per thread where several are resident, everything for a persistent one)
-    const uint32_t soft_lds = exact ? (uint32_t)table_lds
+    const uint32_t soft_lds = by_segments ? (uint32_t)table_lds
                               : PAPR_SWEEP_VARIANT_IS_PERSISTENT(run.variant)
                                   ? (uint32_t)(lds_cap - 2048 - run.stash_lds)
                                   : (uint32_t)std::max<long long>(0, (long long)vblock * 80 - (long long)run.stash_lds);
@@ -408,6 +487,37 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_guess, sizeof(papr_guess_out), hipHostMallocMapped));
         HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_guess_dev, ctx->h_guess, 0));
     }
+    // peers: device scratch [my estimate record | all of them | all pass-1 records | the merged one | n | vector | reduced vector]
+    constexpr uint32_t kXvecWords = kBinsMax + (PAPR_TRUE_MAX_LEVELS + 1) + PAPR_XVEC_FLAGS;
+    const uint32_t world = peers ? (uint32_t)xch_world(x) : 1u, my_rank = peers ? (uint32_t)xch_rank(x) : 0u;
+    papr_est_record *d_est_mine = nullptr, *d_est_all = nullptr;
+    papr_partial *d_recs_all = nullptr, *d_total = nullptr;
+    unsigned long long *d_n_total = nullptr, *d_xvec = nullptr, *d_xvec_sum = nullptr;
+    if (peers) {
+        const size_t a_est = 64, a_all = (size_t)world * sizeof(papr_est_record), a_recs = (size_t)world * sizeof(papr_partial);
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t need = up(a_est) + up(a_all) + up(a_recs) + up(sizeof(papr_partial)) + 256 + 2 * up((size_t)kXvecWords * 8);
+        if (ctx->peer_cap < need) {
+            if (ctx->d_peer) HIPCHK(ctx, hipFree(ctx->d_peer));
+            ctx->d_peer = nullptr;
+            ctx->peer_cap = 0;
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_peer, need));
+            ctx->peer_cap = need;
+        }
+        if (!ctx->h_peer) {
+            HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_peer, sizeof(papr_peer_out), hipHostMallocMapped));
+            HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_peer_dev, ctx->h_peer, 0));
+            HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_xvec, (size_t)kXvecWords * 8, hipHostMallocDefault));
+        }
+        unsigned char *q = ctx->d_peer;
+        d_est_mine = (papr_est_record *)q;          q += up(a_est);
+        d_est_all = (papr_est_record *)q;           q += up(a_all);
+        d_recs_all = (papr_partial *)q;             q += up(a_recs);
+        d_total = (papr_partial *)q;                q += up(sizeof(papr_partial));
+        d_n_total = (unsigned long long *)q;        q += 256;
+        d_xvec = (unsigned long long *)q;           q += up((size_t)kXvecWords * 8);
+        d_xvec_sum = (unsigned long long *)q;
+    }
     constexpr size_t kMaxSweepBlocks = 65536;
     if (!ctx->d_sweep_hist) {
         const size_t bytes = (2 * (size_t)PAPR_HIP_MAX_LEVELS + 2 + 2 * kMaxSweepBlocks + 1) * sizeof(unsigned long long);
@@ -416,7 +526,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     }
     if (!ctx->h_sweep_hist_dev)
         HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_sweep_hist_dev, ctx->h_sweep_hist, 0));
-    run.seg_cap = std::max<uint64_t>((ctx->n / 4 / (uint64_t)run.blocks + 255) & ~255ull, 4096);
+    run.seg_cap = stash_segment_floats(ctx->n, run.blocks);
     const uint64_t want_stash = run.seg_cap * (uint64_t)run.blocks;
     if (ctx->stash_cap < want_stash) {
         if (ctx->d_stash) HIPCHK(ctx, hipFree(ctx->d_stash));
@@ -460,25 +570,36 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     time_end_kernel(ctx);
     HIPCHK(ctx, hipGetLastError());
     const int band_override = ctx->tune.sweep_band_log2 > 0 ? ctx->tune.sweep_band_log2 : 0;
+    if (peers) {  // exchange 1a, in the stream: every shard's estimate record
+        papr_launch_est_record(ctx->stream, est_partials, ctx->d_est_sq, (uint32_t)est_blocks, ngroups,
+                               ngroups * PAPR_ESTIMATE_TILE_SAMPLES, ctx->n, (uint32_t)ratio, ctx->shard_flags, d_est_mine);
+        HIPCHK(ctx, hipGetLastError());
+        rc = xch_allgather_dev(x, d_est_mine, d_est_all, sizeof(papr_est_record));
+        if (rc)
+            return fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x));
+    }
     papr_launch_guess_bands(ctx->stream, est_partials, ctx->d_est_sq, (uint32_t)est_blocks, ngroups,
                             ngroups * PAPR_ESTIMATE_TILE_SAMPLES, ctx->n, (uint32_t)ratio, graph, (float)max_db, spoil,
                             band_override, kCopies, run.lut2 ? 1 : 0, soft_lds, ctx->d_table, table_cap_words, ctx->d_guess,
                             ctx->h_guess_dev, ctx->d_sweep_hist,
-                            kBinsMax + 2u * (uint32_t)run.blocks + 1u);  // (also clears the sweep's bins and segment counters)
+                            kBinsMax + 2u * (uint32_t)run.blocks + 1u,  // (also clears the sweep's bins and segment counters)
+                            d_est_all, peers ? world : 0u, my_rank);
     HIPCHK(ctx, hipGetLastError());
     const uint32_t tail = (uint32_t)(ctx->n - ntiles * run.tile);
     papr_ccdf_params none{};
-    if (exact) {
-        // every tile's running-sum binade, speculated from the estimate's per-group sums (nothing in front of this shard)
-        ctx->est_ngroups = ngroups;
-        ctx->est_ratio = ratio;
-        ctx->est_groups_valid = true;
-        papr_launch_exact_spec(ctx->stream, ctx->d_est_groups, ngroups, (uint32_t)ratio, (double)ratio, 0.0,
-                               ctx->d_est_groups + 4 * ctx->est_groups_cap, ctx->n / PAPR_EXACT_TILE_SAMPLES, ctx->d_tile_E_spec);
-        HIPCHK(ctx, hipGetLastError());
+    if (by_segments) {
+        if (exact) {
+            // every tile's running-sum binade, speculated from the estimate's per-group sums (nothing in front of this shard)
+            ctx->est_ngroups = ngroups;
+            ctx->est_ratio = ratio;
+            ctx->est_groups_valid = true;
+            papr_launch_exact_spec(ctx->stream, ctx->d_est_groups, ngroups, (uint32_t)ratio, (double)ratio, 0.0,
+                                   ctx->d_est_groups + 4 * ctx->est_groups_cap, ctx->n / PAPR_EXACT_TILE_SAMPLES, ctx->d_tile_E_spec);
+            HIPCHK(ctx, hipGetLastError());
+        }
         papr_sweep2_params p{};
         p.data = ctx->d_iq;
-        p.nsegs = 2 * ntiles;
+        p.nsegs = nsegs_launch;
         p.base_index = ctx->base;
         p.out = ctx->d_partials;
         p.tail = ctx->d_iq + 2 * (ctx->n - tail);
@@ -496,7 +617,10 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
         p.seg_D = ctx->d_seg_D;
         p.seg_offset = 0;
         time_begin_kernel(ctx, 3, ctx->n * 8);
-        papr_launch_sweep2(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, p);
+        if (run.v3)
+            papr_launch_sweep3(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, p);
+        else
+            papr_launch_sweep2(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, p);
         time_end_kernel(ctx);
     } else {
         const int map = effective_map(ctx, SWEEP, run.blocks);
@@ -533,10 +657,17 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     constexpr uint32_t kTrueCopies = 4;
     constexpr uint32_t true_soft = 20 * 1024;  // LDS the recount is launched with (as the host path: table + histogram copies)
     ctx->h_true->ok = 0;
-    papr_launch_true_table(ctx->stream, ctx->d_result_copy, ctx->n, graph, kTrueCopies, true_soft, ctx->d_table,
+    if (peers) {  // exchange 1b, in the stream: the shards' pass-1 records, folded in rank (= file) order on every rank
+        rc = xch_allgather_dev(x, ctx->d_result_copy, d_recs_all, sizeof(papr_partial));
+        if (rc)
+            return fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x));
+        papr_launch_record_merge(ctx->stream, d_recs_all, d_est_all, world, my_rank, d_total, d_n_total, ctx->h_peer_dev);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    papr_launch_true_table(ctx->stream, peers ? d_total : ctx->d_result_copy, ctx->n, graph, kTrueCopies, true_soft, ctx->d_table,
                            std::max<uint32_t>(table_cap_words, 48 * 1024 / 4 + 8), ctx->d_true, ctx->h_true_dev, ctx->d_hist,
                            PAPR_TRUE_MAX_LEVELS + 1,  // (also clears the recount's bins)
-                           ctx->d_sweep_hist + kBinsMax + 2 * run.blocks);
+                           ctx->d_sweep_hist + kBinsMax + 2 * run.blocks, peers ? d_n_total : nullptr);
     HIPCHK(ctx, hipGetLastError());
     {
         time_begin_kernel(ctx, 4, 0);
@@ -547,11 +678,30 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(PAPR_TRUE_MAX_LEVELS + 1) * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, ctx->stream));
+    if (peers) {  // exchange 2, in the stream: what the sweep decided, what the recount found, and whether either may be used
+        papr_launch_xpack(ctx->stream, ctx->d_sweep_hist, kBinsMax, ctx->d_sweep_hist + kBinsMax, (uint32_t)run.blocks, run.seg_cap,
+                          ctx->d_sweep_hist + kBinsMax + 2 * run.blocks, ctx->d_hist, PAPR_TRUE_MAX_LEVELS + 1, ctx->d_guess,
+                          ctx->d_true, d_xvec);
+        HIPCHK(ctx, hipGetLastError());
+        rc = xch_allreduce_u64_dev(x, d_xvec, d_xvec_sum, kXvecWords);
+        if (rc)
+            return fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_xvec, d_xvec_sum, (size_t)kXvecWords * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
     run_overlap_work(ctx);  // (exact-sum mode: the program's replay, while the recount runs)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->program_pending = false;
     partial_to_stats(*ctx->h_result, ctx->n, out);
     out->flags |= ctx->shard_flags;
+    if (peers) {
+        // decisions from GLOBAL numbers only: every rank takes the same way from here.  A NaN anywhere, or a guess without
+        // a band form: the host path, from the start, on every rank.
+        const unsigned long long *flags = ctx->h_xvec + kBinsMax + (PAPR_TRUE_MAX_LEVELS + 1);
+        if (ctx->h_peer->nan_ranks != 0 || flags[1] != 0) {
+            ctx->sweep_info.reason = PAPR_SWEEP_NO_BANDS;
+            return PAPR_OK;  // (*done stays false)
+        }
+    }
     *done = true;
     // ---- what the device decided ----
     const papr_guess_out &g = *ctx->h_guess;
@@ -573,7 +723,25 @@ int stats_sweep_fused(papr_hip_ctx *ctx, int graph, double max_db, float spoil, 
     run.bands.P = g.P;
     run.nbins = g.P.nkeys + (run.v2 ? 1 : 2);
     rc = sweep_collect(ctx, run);
-    if (rc == PAPR_OK) {
+    if (rc == PAPR_OK && peers) {
+        // the file's numbers beside the shard's: bins above each band, the recount against the (common) speculated table
+        const unsigned long long *G = ctx->h_xvec, *flags = G + kBinsMax + (PAPR_TRUE_MAX_LEVELS + 1);
+        const size_t m = run.gkeys.size();
+        ctx->sweep_even_above_global.assign(m, 0);
+        uint64_t above = 0;
+        for (size_t j = m; j-- > 0;) {
+            above += G[2 * j + 2];
+            ctx->sweep_even_above_global[j] = above;
+        }
+        ctx->recount_global.assign(G + kBinsMax, G + kBinsMax + PAPR_TRUE_MAX_LEVELS + 1);
+        ctx->sweep_overflow = flags[0] != 0;  // (on ANY rank: then every rank reads its shard again)
+        ctx->peer_global = true;
+        partial_to_stats(ctx->h_peer->total, ctx->h_peer->n_total, &peer->total);
+        peer->total.flags |= (uint32_t)ctx->h_peer->flags;
+        peer->before = ctx->h_peer->before;
+        peer->global = true;
+        ctx->spec_recount_valid = ctx->h_true->ok != 0 && flags[2] == 0;
+    } else if (rc == PAPR_OK) {
         ctx->spec_recount_valid = ctx->h_true->ok != 0;  // (whether it is the RIGHT table is for resolve_from_sweep to say)
         if (exact) {
             ctx->exact_swept = true;  // d_seg_D holds every segment's sum and its pair (speculated, or rebuilt)
@@ -790,6 +958,10 @@ int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *lev
     // every true threshold must lie inside one of the bands (papr_sweep_resolve, first without stash counts: a dry run)
     const int band_log2 = __builtin_ctz(ctx->sweep_half);  // of the sweep that left this state behind
     std::vector<uint64_t> stash_above((size_t)nlevels, 0);
+    // (peers, single-wait step: the FILE's bins and recount came through the stream — usable as long as the recount ran
+    // against the right table; every input of that decision is the same on every rank)
+    const bool global = ctx->peer_global;
+    ctx->peer_global = false;
     if (!papr_sweep_resolve(ctx->sweep_keys.data(), (int)ctx->sweep_keys.size(), band_log2, ctx->sweep_even_above.data(),
                             levels, nlevels, stash_above.data(), counts_above)) {
         info.reason = PAPR_SWEEP_OUT_OF_BAND;
@@ -808,7 +980,9 @@ int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *lev
                             sp->P.shift == plan.P.shift && sp->P.cell_lo == plan.P.cell_lo &&
                             memcmp(sp->levels, levels, (size_t)nlevels * sizeof(float)) == 0;
     if (speculated) {
-        // (h_hist holds it)
+        // (h_hist holds it — the shard's; with peers the file's is taken instead)
+        if (global)
+            memcpy(ctx->h_hist, ctx->recount_global.data(), (size_t)(m + 1) * sizeof(unsigned long long));
     } else if (ctx->sweep_stash_count) {
         int rc = upload_ccdf_table(ctx, plan);
         if (rc)
@@ -828,8 +1002,11 @@ int resolve_from_sweep(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *lev
         memset(ctx->h_hist, 0, (size_t)(m + 1) * sizeof(unsigned long long));
     }
     counts_from_histogram(ctx, plan, nlevels, stash_above.data());  // stash powers above each level ...
-    (void)papr_sweep_resolve(ctx->sweep_keys.data(), (int)ctx->sweep_keys.size(), band_log2, ctx->sweep_even_above.data(),
-                             levels, nlevels, stash_above.data(), counts_above);  // ... + everything above its band
+    const bool file_wide = global && speculated;
+    (void)papr_sweep_resolve(ctx->sweep_keys.data(), (int)ctx->sweep_keys.size(), band_log2,
+                             file_wide ? ctx->sweep_even_above_global.data() : ctx->sweep_even_above.data(), levels, nlevels,
+                             stash_above.data(), counts_above);  // ... + everything above its band
+    ctx->counts_global = file_wide;  // (the caller then needs no exchange of the counters)
     info.resolved = 1;
     info.reason = PAPR_SWEEP_OK;
     *done = true;

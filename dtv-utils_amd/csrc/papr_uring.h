@@ -22,6 +22,7 @@
 
 #include <atomic>
 #include <deque>
+#include <vector>
 
 #include "papr_readbatch.h"  // ReadBatch {pending, error}
 
@@ -40,6 +41,7 @@ class UringReader {
     }
     ~UringReader()
     {
+        abandon();
         if (sqes_ && sqes_ != MAP_FAILED)
             munmap(sqes_, sqe_bytes_);
         if (cq_ptr_ && cq_ptr_ != MAP_FAILED && cq_ptr_ != sq_ptr_)
@@ -59,8 +61,13 @@ class UringReader {
             const uint64_t n = len < piece ? len : piece;
             Req *r = new Req{batch, fd, fd_buffered, off, n, dst};
             batch->pending++;
-            if (!backlog_.empty() || !enqueue(r))
+            if (dead_) {  // (not used after a failure; if it is, the request fails instead of hanging)
+                batch->error = batch->error ? batch->error : EIO;
+                batch->pending--;
+                delete r;
+            } else if (!backlog_.empty() || !enqueue(r)) {
                 backlog_.push_back(r);
+            }
             off += n;
             len -= n;
             dst += n;
@@ -79,8 +86,12 @@ class UringReader {
                 batch->pending = 0;
                 break;
             }
-            if (!enter(1)) {  // the ring itself failed: give the batch up (the kernel keeps the pages until it is done)
+            if (!enter(1)) {
+                // the ring itself failed.  Requests may still be in flight — the kernel may still be writing into the
+                // staging buffers, and their completions would touch this batch: take what completes, cut the rest off
+                // from every batch, and never use this ring again (the caller goes back to the reader threads)
                 batch->error = batch->error ? batch->error : EIO;
+                abandon();
                 batch->pending = 0;
                 break;
             }
@@ -89,6 +100,7 @@ class UringReader {
     }
 
     unsigned entries() const { return entries_; }
+    bool dead() const { return dead_; }
 
   private:
     struct Req {
@@ -96,7 +108,31 @@ class UringReader {
         int fd, fd_buffered;
         uint64_t off, len;
         unsigned char *dst;
+        size_t live_at = 0;  // position in live_ while the kernel has it
     };
+
+    // Give the ring up: requests that were never handed to the kernel are dropped; for those the kernel has, completions
+    // are taken for up to five seconds (the completion ring is shared memory: no system call needed); whatever is still
+    // out then is detached from its batch (a late completion lands in `orphans_`) and leaked rather than freed under it.
+    void abandon()
+    {
+        if (dead_ && live_.empty() && backlog_.empty())
+            return;
+        dead_ = true;
+        for (Req *r : backlog_) {
+            if (r->batch->pending > 0)
+                r->batch->pending--;
+            delete r;
+        }
+        backlog_.clear();
+        for (int spin = 0; spin < 50000 && !live_.empty(); spin++) {
+            if (!reap())
+                usleep(100);
+        }
+        for (Req *r : live_)
+            r->batch = &orphans_;
+        live_.clear();
+    }
 
     bool init(unsigned entries)
     {
@@ -154,6 +190,8 @@ class UringReader {
         sq_tail_->store(tail + 1, std::memory_order_release);
         unsubmitted_++;
         inflight_++;
+        r->live_at = live_.size();
+        live_.push_back(r);
         return true;
     }
 
@@ -220,10 +258,16 @@ class UringReader {
             head++;
             cq_head_->store(head, std::memory_order_release);
             inflight_--;
-            complete((Req *)(uintptr_t)c.user_data, c.res);
+            Req *r = (Req *)(uintptr_t)c.user_data;
+            if (r->live_at < live_.size() && live_[r->live_at] == r) {  // (swap-remove from the in-flight set)
+                live_[r->live_at] = live_.back();
+                live_[r->live_at]->live_at = r->live_at;
+                live_.pop_back();
+            }
+            complete(r, c.res);
             n++;
         }
-        while (!backlog_.empty() && enqueue(backlog_.front()))
+        while (!dead_ && !backlog_.empty() && enqueue(backlog_.front()))
             backlog_.pop_front();
         return n;
     }
@@ -238,6 +282,9 @@ class UringReader {
     uint32_t *sq_array_ = nullptr;
     struct io_uring_cqe *cqes_ = nullptr;
     std::deque<Req *> backlog_;
+    std::vector<Req *> live_;  // what the kernel has
+    ReadBatch orphans_{};      // where completions of a given-up ring's stragglers go
+    bool dead_ = false;
 };
 
 }  // namespace papr_rt

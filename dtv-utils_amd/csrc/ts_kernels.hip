@@ -91,7 +91,15 @@ __global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
             // nothing else changes.
             const bool on_boundary = ((s + 187) & (TS_READ_CHUNK - 1)) == 0;
             if (regular[r] && on_boundary && pid[r] != 0u && pid[r] != 0x1ffbu && (!has_af || af_len <= 181u)) {
-                if (p.data[s + 187] == 0x47u || p.event_cap == 0)
+                // `skipped 1 bytes` and nothing else happens only if the search that starts on the packet's last byte
+                // ends on the NEXT unit's sync byte: that unit must be there, whole, with its 0x47 in place, and the byte
+                // the search tests first — the packet's last byte, or in HDMV mode (which swallows four bytes in front
+                // of every search, xport.c:4317) the last byte of the next tp_extra_header — must not be a 0x47 itself.
+                // Anything else (last packet of the stream: no line at all; damage behind it: ONE line with the sum of
+                // the bytes skipped; a false sync: a re-lock one byte early) is the walker's.
+                const uint64_t probe = s + 187 + p.sync_offset, next_sync = s + p.stride;
+                const bool next_whole = next_sync + 188 <= p.nbytes;
+                if (p.event_cap == 0 || !next_whole || p.data[probe] == 0x47u || p.data[next_sync] != 0x47u)
                     regular[r] = false;
                 else
                     quirk[r] = true;

@@ -26,10 +26,11 @@ ID_BYTES = 128
 
 class ExchangeTiming(C.Structure):
     _fields_ = [("stats_calls", C.c_uint64), ("counts_calls", C.c_uint64), ("exact_calls", C.c_uint64),
-                ("stats_us", C.c_double), ("counts_us", C.c_double), ("exact_us", C.c_double)]
+                ("stats_us", C.c_double), ("counts_us", C.c_double), ("exact_us", C.c_double),
+                ("in_stream_calls", C.c_uint64)]
 
     def as_dict(self) -> dict:
-        d = {}
+        d = {"in_stream_collectives": int(self.in_stream_calls)}
         for kind in ("stats", "counts", "exact"):
             calls = getattr(self, kind + "_calls")
             d[kind] = {"calls": int(calls), "us_per_call": (getattr(self, kind + "_us") / calls) if calls else None}

@@ -15,7 +15,7 @@ from . import PaprError, lib
 PIDS = 0x2000
 MAX_SYNC_ERRORS = 4096
 
-ABI_SYMBOLS = ("ts_walk_init", "ts_walk_is_clean", "ts_walk", "ts_format_report", "ts_hip_open", "ts_hip_close",
+ABI_SYMBOLS = ("ts_walk_init", "ts_walk_is_clean", "ts_walk", "ts_format_report", "ts_format_report_all", "ts_hip_open", "ts_hip_close",
                "ts_hip_last_error", "ts_hip_upload", "ts_hip_load_file", "ts_hip_adopt", "ts_hip_generate",
                "ts_hip_download", "ts_hip_scan")
 

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PAPR_HIP_ABI_VERSION 3
+#define PAPR_HIP_ABI_VERSION 4
 
 enum {
     PAPR_OK = 0,
@@ -268,6 +268,9 @@ typedef struct papr_hip_sweep_info {
                                 * speculated running-sum binade was wrong and whose rounding functions were rebuilt */
     uint32_t gave_up;        /* waves that gave the sweep up for their workgroup because most of what it folded was in band
                               * (constant-envelope captures); any > 0 shows as PAPR_SWEEP_STASH_FULL */
+    int kernel_variant;      /* id of the kernel form the last sweep was launched as (papr_sweep.hip's tables); measurements
+                              * quote it so that numbers taken with another form are recognised as stale */
+    int reserved;
 } papr_hip_sweep_info;
 int papr_hip_estimate(papr_hip_ctx *ctx, papr_stats *est);
 /* Exact-sum mode (papr_hip_set_exact(ctx, 1)) is served by the same single read: papr_hip_estimate then also keeps
@@ -350,6 +353,8 @@ typedef struct papr_exchange_ops {
 typedef struct papr_exchange_timing { /* host wall time spent inside the exchanges since open / the last reset */
     uint64_t stats_calls, counts_calls, exact_calls;
     double stats_us, counts_us, exact_us;
+    uint64_t in_stream_calls; /* collectives queued on the context's stream between kernels (RCCL transport, papr_hip_analyze's
+                               * single-wait step): no host staging and no wait of their own, so no time to report */
 } papr_exchange_timing;
 #define PAPR_EXCHANGE_ID_BYTES 128
 int papr_exchange_unique_id(void *id /* PAPR_EXCHANGE_ID_BYTES */);
@@ -379,7 +384,15 @@ void papr_exchange_abort(papr_exchange *x);
  * sequential sum (papr_hip_set_exact), and the exchange of the counters.  It is the sequence bench.py times and
  * bin/papr prints from; every step is one of the calls above and can be made separately.  `x` may be NULL for a
  * single shard.  levels / counts_above: caller's arrays of `cap` entries (PAPR_HIP_MAX_LEVELS always suffices);
- * all ranks receive the same result. */
+ * all ranks receive the same result.
+ * With the RCCL transport the three exchanges are collectives queued on the context's stream between the kernels that
+ * produce and consume them (no host staging; the whole step is one wait); with the callback and in-process transports
+ * they are host calls between three waits.
+ * FAILURE WITH PEERS: a rank whose call fails locally (a HIP error, out of memory, a shard that cannot be read) returns
+ * at once and does not enter the collectives that were still to come — the other ranks would wait in them for ever.
+ * Whoever gets a non-zero return must therefore tear the exchange down so that its peers are released: the in-process
+ * transport has papr_exchange_abort for that (bin/papr calls it); with RCCL or caller-supplied collectives destroy the
+ * communicator / leave the process group (ncclCommAbort, or exit), as with any collective program. */
 #define PAPR_ANALYZE_TWO_PASS 1u /* no speculation: pass 1, then pass 2 (two reads of the shard) */
 #define PAPR_ANALYZE_SPOIL_GUESS 2u /* diagnostics: feed the sweep a guess that is 3 % off (what a missed speculation costs) */
 typedef struct papr_result {

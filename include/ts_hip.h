@@ -87,6 +87,9 @@ uint64_t ts_walk(ts_walk_state *st, const unsigned char *data, uint64_t base, ui
 /* the report lines of the reference for a result (xport.c:245-250 and :4326 / :4364); returns the bytes written
  * (excluding the terminating NUL), at most cap - 1 */
 size_t ts_format_report(const ts_scan_result *res, char *buf, size_t cap);
+/* the same with a complete list of sync errors (ts_hip_get_sync_errors) when res->nsync_errors exceeds what the result
+ * holds inline: the reference prints every one of them (xport.c:4325-4327) */
+size_t ts_format_report_all(const ts_scan_result *res, const ts_sync_error *errors, uint64_t nerrors, char *buf, size_t cap);
 
 /* ---- GPU scan -------------------------------------------------------------------------------------------------- */
 typedef struct ts_hip_ctx ts_hip_ctx;

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(pkg):
     L = pkg.lib()
     for name in declared_functions():
         assert hasattr(L, name), f"libpaprhip.so does not export {name}"
-    assert L.papr_hip_abi_version() == 3
+    assert L.papr_hip_abi_version() == 4
     # struct layouts the binding assumes
     assert C.sizeof(pkg.Stats) == 96
     assert C.sizeof(pkg.SynthSpec) == 16 + 16 * 8

@@ -57,10 +57,12 @@ def packet(rng, pid: int, cc: int, *, tei=0, pusi=0, af_len=None, payload: bytes
 
 def make_stream(seed: int, npackets: int, *, hdmv=False, pat=True, pids=(0x100, 0x101, 0x102, 0x1FFB, 0x1FFF, 0x31),
                 af_rate=0.2, bad_af_rate=0.0, tei_rate=0.01, offset_garbage=0, garbage_has_sync=False, damage=(),
-                truncate=0, last_byte_sync_at=None) -> bytes:
+                truncate=0, last_byte_sync_at=None, plain_at=(), extra_header_at=None) -> bytes:
     """damage: list of (packet_index, kind, amount): kind 'insert' (amount garbage bytes before that packet),
     'delete' (drop `amount` bytes from the start of that packet).  last_byte_sync_at: packet index whose last
-    payload byte is forced to 0x47 (a false sync byte for the chunk-boundary quirk)."""
+    payload byte is forced to 0x47 (a false sync byte for the chunk-boundary quirk).  plain_at: packet indices that are
+    forced to be an ordinary payload-only packet on PID 0x100 (what the quirk needs).  extra_header_at: {packet index: the
+    four tp_extra_header bytes of that HDMV unit}."""
     rng = np.random.default_rng(seed)
     cc = {}
     out = bytearray()
@@ -87,11 +89,17 @@ def make_stream(seed: int, npackets: int, *, hdmv=False, pat=True, pids=(0x100, 
             af_len = int(rng.choice([0, 1, 7, 20, 100, 181, 182, 183]))
             if rng.random() < bad_af_rate:
                 af_len = int(rng.choice([184, 200, 255]))
-        p = bytearray(packet(rng, pid, c, tei=int(rng.random() < tei_rate), pusi=pusi, af_len=af_len, payload=payload))
+        tei = int(rng.random() < tei_rate)
+        if k in plain_at:
+            pid, payload, pusi, af_len, tei = 0x100, None, 0, None, 0
+        p = bytearray(packet(rng, pid, c, tei=tei, pusi=pusi, af_len=af_len, payload=payload))
         if last_byte_sync_at is not None and k == last_byte_sync_at:
             p[187] = 0x47
         if hdmv:
-            p = bytearray(rng.integers(0, 256, 4, dtype=np.uint8).tobytes()) + p
+            extra = bytearray(rng.integers(0, 256, 4, dtype=np.uint8).tobytes())
+            if extra_header_at and k in extra_header_at:
+                extra = bytearray(extra_header_at[k])
+            p = extra + p
         if k in dmg:
             _, kind, amount = dmg[k]
             if kind == "insert":
@@ -105,8 +113,9 @@ def make_stream(seed: int, npackets: int, *, hdmv=False, pat=True, pids=(0x100, 
 
 
 def quirk_offset(packet_index: int, packet_size: int = 188) -> int:
-    """Leading garbage that makes packet `packet_index` start at 16197 (mod 16384): it then ends one byte past a read."""
-    return (16197 - packet_index * packet_size) % 16384
+    """Leading garbage that makes packet `packet_index` start at 16197 (mod 16384): it then ends one byte past a read.
+    (192-byte units: the packet starts four bytes into its unit.)"""
+    return (16197 - (packet_size - 188) - packet_index * packet_size) % 16384
 
 
 # name -> kwargs: the committed fixtures (tests/golden/make_golden_ts.py records the reference's lines for them)
@@ -130,6 +139,21 @@ FIXTURES = {
     "ts_hdmv_damaged": dict(seed=117, npackets=900, hdmv=True, damage=[(250, "insert", 33), (600, "delete", 5)]),
     "ts_only_garbage": dict(seed=118, npackets=0, offset_garbage=3000),
     "ts_two_packets": dict(seed=119, npackets=2, pat=False),
+    # the read-boundary quirk where `skipped 1 bytes` is NOT the whole story: the quirk packet ends the stream (no line
+    # at all), damage follows it (one line with the sum), the byte the HDMV search tests first is a 0x47 (re-lock one
+    # byte early)
+    "ts_quirk_last": dict(seed=120, npackets=91, pat=False, offset_garbage=quirk_offset(90), plain_at=(90,)),
+    "ts_quirk_then_garbage": dict(seed=121, npackets=400, pat=False, offset_garbage=quirk_offset(90), plain_at=(90,),
+                                  damage=[(91, "insert", 50)]),
+    "ts_quirk_then_delete": dict(seed=122, npackets=400, pat=False, offset_garbage=quirk_offset(90), plain_at=(90,),
+                                 damage=[(91, "delete", 3)]),
+    "ts_quirk_then_truncated": dict(seed=123, npackets=92, pat=False, offset_garbage=quirk_offset(90), plain_at=(90,),
+                                    truncate=40),
+    "ts_hdmv_quirk": dict(seed=124, npackets=500, hdmv=True, pat=False, offset_garbage=quirk_offset(85, 192), plain_at=(85,),
+                          extra_header_at={86: b"\x11\x22\x33\x44"}),
+    "ts_hdmv_quirk_false_sync": dict(seed=125, npackets=500, hdmv=True, pat=False, offset_garbage=quirk_offset(85, 192),
+                                     plain_at=(85,), extra_header_at={86: b"\x11\x22\x33\x47"}),
+    "ts_hdmv_quirk_last": dict(seed=126, npackets=86, hdmv=True, pat=False, offset_garbage=quirk_offset(85, 192), plain_at=(85,)),
 }
 
 
