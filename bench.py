@@ -229,8 +229,8 @@ def run_mode(args, mode, env):
         gbs_sweep = b_sweep / (k_sweep * 1e-3) / 1e9 if k_sweep else 0.0
         aux_ms = tm_aux.aux_ms / aux_steps    # estimate + stash recount kernels, per step (from the extra steps)
         aux_bytes = tm_aux.aux_bytes / aux_steps
-        # with --exact the sweep is the wave-private-segment kernel that also builds the rounding-function pairs
-        sweep_name = "papr_sweep2_kernel<EXACT>" if (args.exact and not args.exact_two_pass) else "papr_sweep_kernel"
+        # with --exact the sweep is the wave-private-segment kernel that also builds the rounding-function pairs (papr_sweep3_kernel)
+        sweep_name = "papr_sweep3_kernel" if (args.exact and not args.exact_two_pass) else "papr_sweep_kernel"
         dom, dom_gbs, dom_ms = max([("papr_stats_kernel", gbs_stats, k_stats), ("papr_ccdf_kernel", gbs_ccdf, k_ccdf),
                                     ("papr_exact_seg_kernel<CCDF>", gbs_exact, k_exact),
                                     (sweep_name, gbs_sweep, k_sweep)], key=lambda e: e[2])
@@ -325,7 +325,12 @@ def run_ts(args, rank, world, local_rank, use_dist):
     from dtv_utils_amd import ts
     npackets = int(args.gib * (1 << 30)) // 188
     gpu = ts.TsHip(local_rank)
-    gpu.generate(npackets, seed=0x7500001 + rank)
+    period = int(round(1.0 / args.damage)) if args.damage > 0 else 0
+    if period:   # one damaged spot (inserted / missing bytes, an overwritten sync byte) every `period` packets
+        npackets = npackets // (4 * period) * (4 * period)
+        gpu.generate_damaged(npackets, period, seed=0x7500001 + rank)
+    else:
+        gpu.generate(npackets, seed=0x7500001 + rank)
     res = None
     for _ in range(args.warmup):
         res = gpu.scan()
@@ -349,7 +354,7 @@ def run_ts(args, rank, world, local_rank, use_dist):
     if rank != 0:
         gpu.close()
         return None
-    nbytes = npackets * 188
+    nbytes = npackets * 188 - (npackets // (4 * period) if period else 0)
     k_ms = kernel_ms / args.steps
     # Algorithmic bytes of the scan kernel: the 128-byte lines that hold a packet header (its sync byte, PID,
     # adaptation_field_control and adaptation_field_length: an aligned 8-byte window that starts at the sync byte) —
@@ -374,6 +379,8 @@ def run_ts(args, rank, world, local_rank, use_dist):
         "config": {"workload": f"xport -p packet scan (sync lock, per-PID count/first/last) on {args.gib:g} GiB synthetic "
                                f"MPEG-2 TS per GPU, HBM-resident, {world}xMI355X", "packets_per_gpu": npackets,
                    "bytes_per_gpu": nbytes, "launches_per_scan": int(res.launches), "walks_per_scan": int(res.walks),
+                   "damage": (f"one damaged spot every {period} packets (include/ts_synth.h: ts_synth_damaged_byte)" if period else None),
+                   "sync_error_lines": int(res.nsync_errors), "packets_counted": int(res.packets),
                    "pids_seen": int(np.count_nonzero(res.tables()[0])), "sharding": "independent streams, no exchange",
                    "report_sha256": hashlib.sha256(res.report()).hexdigest(),
                    "stream_GBps": nbytes * world * args.steps / elapsed / 1e9},
@@ -388,23 +395,30 @@ def run_ts(args, rank, world, local_rank, use_dist):
     }
     if world == 1 and not args.no_cpu_baseline:
         try:
-            line["cpu_baseline"] = ts_cpu_baseline(gpu, ts, args.cpu_sample_gib or 2.0)
+            line["cpu_baseline"] = ts_cpu_baseline(gpu, ts, args.cpu_sample_gib or 2.0, period)
         except Exception as e:
             line["cpu_baseline"] = {"error": repr(e)}
     gpu.close()
     return line
 
 
-def ts_cpu_baseline(gpu, ts, sample_gib: float):
+def ts_cpu_baseline(gpu, ts, sample_gib: float, period: int = 0):
     """The reference's xport (oracle/_ref/xport, compiled from its own source) — or the oracle port — on a bounded
     sample of the same synthetic stream, single thread, and the GPU scan's report against it on that sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ts_oracle
     n = int(sample_gib * (1 << 30)) // 188
+    if period:
+        n = n // (4 * period) * (4 * period)
     tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
     path = os.path.join(tmpdir, f"ts_bench_sample_{os.getpid()}.ts")
     try:
-        subprocess.check_call([os.path.join(ROOT, "oracle", "mkts"), path, str(n)])
+        # (the sample file comes from the device-side generator — byte-identical to oracle/mkts's, which the tests pin —
+        # because the host tool makes 0.1 GB/s)
+        size = gpu.generate_damaged(n, period) if period else (gpu.generate(n) or n * 188)
+        with open(path, "wb") as f:
+            for off in range(0, size, 1 << 28):
+                f.write(gpu.download(off, min(1 << 28, size - off)))
         use_ref = os.path.exists(ts_oracle.REF_CLI)
         cmd = [ts_oracle.REF_CLI, "-ps", path, ts_oracle.REF_PROGRAM, "1", "1"] if use_ref else [ts_oracle.CLI_PATH, path]
         subprocess.run(cmd, capture_output=True)   # page-cache warm, untimed
@@ -445,6 +459,8 @@ def main():
     ap.add_argument("--workload", choices=["papr", "ts"], default="papr",
                     help="papr = BASELINE.json's metric (the default); ts = the transport-stream packet scan of "
                          "xport.c (SURVEY.md 8(f) N4), a second line of its own")
+    ap.add_argument("--damage", type=float, default=0.0,
+                    help="--workload ts: damaged spots per packet (1e-4 = one every 10^4 packets): the scan's unfriendly case")
     ap.add_argument("--exact", action="store_true",
                     help="also reproduce the reference's sequential double sum bit for bit every step "
                          "(rounding functions computed in the pass-2 sweep + a short host chain); off by default")

@@ -38,7 +38,7 @@ ABI_SYMBOLS = (
     "papr_hip_estimate", "papr_hip_stats_sweep", "papr_hip_get_sweep_info", "papr_guess_levels",
     "papr_hip_estimate_file", "papr_hip_load_file_sweep", "papr_hip_shard_fits",
     "papr_level_key", "papr_sweep_bands", "papr_sweep_resolve", "papr_hip_set_exact_hint",
-    "papr_sweep_band_for", "papr_hip_set_band", "papr_hip_analyze",
+    "papr_sweep_band_for", "papr_hip_set_band", "papr_hip_analyze", "papr_hip_sweep_variant_built",
 )
 
 
@@ -156,6 +156,14 @@ class PaprError(RuntimeError):
 
 
 _lib: Optional[C.CDLL] = None
+SWEEP_VARIANT, SWEEP_EXACT_VARIANT = 111, 131   # the product's one-sweep kernel forms (csrc/papr_kernels.h)
+
+
+def sweep_variant_built(variant: int) -> bool:
+    """Does this build of libpaprhip.so carry the one-sweep kernel form with that id?  (The product has two; the
+    laboratory's forms — csrc/measure/papr_sweep_lab.hip — only exist in a `make MEASURE=1` build.)"""
+    return bool(lib().papr_hip_sweep_variant_built(int(variant)))
+
 
 
 def lib() -> C.CDLL:
@@ -179,6 +187,8 @@ def lib() -> C.CDLL:
     L.papr_hip_device_name.argtypes = [vp, C.c_char_p, i32]
     L.papr_hip_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
     L.papr_hip_set_timing.argtypes = [vp, i32]
+    L.papr_hip_sweep_variant_built.argtypes = [i32]
+    L.papr_hip_sweep_variant_built.restype = i32
     L.papr_hip_get_timing.argtypes = [vp, C.POINTER(Timing)]
     L.papr_file_samples.argtypes = [C.c_char_p, C.POINTER(u64)]
     L.papr_hip_load_file.argtypes = [vp, C.c_char_p, u64, u64]

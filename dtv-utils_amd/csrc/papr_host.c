@@ -16,6 +16,7 @@
 
 #include "papr_exact_format.h"
 #include "papr_hip.h"
+#include "papr_hip_measure.h"
 
 int papr_hip_abi_version(void)
 {

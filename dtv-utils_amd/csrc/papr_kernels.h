@@ -195,9 +195,16 @@ void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, c
                              unsigned long long *zero /* words the kernel clears on its way */, uint32_t zero_words,
                              const papr_est_record *recs = nullptr /* all shards' estimate records, rank order (peers) */,
                              uint32_t nrecs = 0, uint32_t my_rank = 0);
+/* the product form of the sweep: papr_sweep_kernel = 512 threads x 8 loads per lane (64 KiB tiles), one persistent
+ * workgroup per CU, 12 KiB of stash slice per wave; its variant id, and papr_sweep3_kernel's (exact-sum mode) */
+#define PAPR_SWEEP_THREADS 512
+#define PAPR_SWEEP_LOADS 8
+#define PAPR_SWEEP_SLICE_FLOATS 3072u
+#define PAPR_SWEEP_VARIANT 111
+#define PAPR_SWEEP3_VARIANT 131
 int papr_sweep_variant(int variant); /* the sweep geometry used for a variant id, or -1 */
 #define PAPR_SWEEP_VARIANT_IS_LUT2(v) (((v) >= 20 && (v) <= 29) || ((v) >= 70 && (v) <= 79) || (v) == 18 || (v) == 38) /* compact table: papr_sweep_kernel<LUT2>, papr_sweep_split_kernel */
-#define PAPR_SWEEP_VARIANT_IS_PERSISTENT(v) ((v) == 40 || (v) == 111 || (v) == 114) /* launched as ONE workgroup per CU (512 threads x 8 loads per lane) */
+#define PAPR_SWEEP_VARIANT_IS_PERSISTENT(v) ((v) == PAPR_SWEEP_VARIANT || (v) == 40 || (v) == 114) /* launched as ONE workgroup per CU (512 threads x 8 loads per lane) */
 #define PAPR_SWEEP_VARIANT_HAS_HIST_SETS(v) (((v) >= 84 && (v) <= 85) || ((v) >= 87 && (v) <= 89)) /* SMODE bit 2 (measurement variants) */
 int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_t *stash_lds); /* 0, or -1 */
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
@@ -227,6 +234,16 @@ void papr_launch_true_table(hipStream_t st, const papr_partial *result, uint64_t
                             const unsigned long long *gave_up /* the sweep's give-up counter: non-zero = nothing to recount */,
                             const unsigned long long *nsamples_dev = nullptr /* peers: the file's length, in device memory */);
 void papr_sweep_prepare_device(void);
+#ifdef PAPR_MEASURE /* measure/papr_sweep_lab.hip: every other kernel form, behind the same variant ids */
+int papr_lab_sweep_variant(int variant);
+int papr_lab_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_t *stash_lds);
+void papr_lab_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
+                           uint64_t base_index, int map, papr_partial *out, const void *tail, uint32_t tail_samples,
+                           const uint32_t *table, const papr_ccdf_params &P, unsigned long long *ghist, float *stash,
+                           unsigned long long *seg_counts, uint64_t seg_cap, unsigned long long *gave_up,
+                           unsigned long long *seg_real, const papr_ccdf_params *Pdev);
+void papr_lab_prepare_device(void);
+#endif
 
 // ---- one-sweep kernel, second generation (papr_sweep.hip: papr_sweep2_kernel) -----------------------------------
 // Every WAVE owns whole segments of 64 * U float4 (U = 8: 1024 samples, 8 KiB): wave w of workgroup b takes segment
@@ -270,6 +287,10 @@ int papr_sweep2_geometry(int variant, int *threads, uint64_t *seg_samples, size_
 int papr_sweep3_geometry(int variant, int *threads, size_t *lds_fixed, int *exact = nullptr); /* 0, or -1 if `variant` is not one of its ids */
 void papr_launch_sweep3(hipStream_t st, int variant, int blocks, size_t lds_bytes, const papr_sweep2_params &p);
 void papr_launch_sweep2(hipStream_t st, int variant, int blocks, size_t lds_bytes, const papr_sweep2_params &p);
+#ifdef PAPR_MEASURE
+int papr_lab_sweep2_geometry(int variant, int *threads, uint64_t *seg_samples, size_t *lds_fixed, int *exact);
+void papr_lab_launch_sweep2(hipStream_t st, int variant, int blocks, size_t lds_bytes, const papr_sweep2_params &p);
+#endif
 int papr_ccdf_max_dynamic_lds(void);
 void papr_kernels_prepare_device(void); /* call once per device after hipSetDevice */
 void papr_exact_prepare_device(void);

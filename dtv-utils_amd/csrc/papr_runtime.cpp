@@ -577,9 +577,20 @@ int papr_hip_open(papr_hip_ctx **out, int device)
             return bail(PAPR_E_HIP);                                                               \
         }                                                                                          \
     } while (0)
+    const bool trace = env_int("PAPR_OPEN_TRACE", 0) != 0;  // where the time of opening a context goes (stderr)
+    double t_prev = now_s();
+    auto lap = [&](const char *what) {
+        if (trace) {
+            const double t = now_s();
+            fprintf(stderr, "papr_hip_open: %-28s %8.3f ms\n", what, (t - t_prev) * 1e3);
+            t_prev = t;
+        }
+    };
     OPENCHK(hipSetDevice(device));
+    lap("hipSetDevice");
     hipDeviceProp_t prop;
     OPENCHK(hipGetDeviceProperties(&prop, device));
+    lap("hipGetDeviceProperties");
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     OPENCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     OPENCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -589,6 +600,7 @@ int papr_hip_open(papr_hip_ctx **out, int device)
     OPENCHK(hipHostMalloc((void **)&ctx->h_hist, (PAPR_HIP_MAX_LEVELS + 1) * sizeof(unsigned long long),
                           hipHostMallocDefault));
     OPENCHK(hipMalloc((void **)&ctx->d_nan_key, sizeof(unsigned long long)));
+    lap("streams + small buffers");
 #undef OPENCHK
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
@@ -598,9 +610,11 @@ int papr_hip_open(papr_hip_ctx **out, int device)
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     parse_tune_env(&ctx->tune);
 
+    lap("hipMemGetInfo");
     if (ensure_partials(ctx, 4096) != PAPR_OK)
         return bail(PAPR_E_HIP);
     papr_kernels_prepare_device();  // function attributes are per device
+    lap("kernel attributes (module load)");
     *out = ctx;
     return PAPR_OK;
 }
@@ -694,6 +708,17 @@ int papr_hip_set_tuning(papr_hip_ctx *ctx, const papr_hip_tuning *t)
         return fail(ctx, PAPR_E_ARG, "bad tuning values");
     ctx->tune = *t;
     return PAPR_OK;
+}
+
+int papr_hip_sweep_variant_built(int variant)
+{
+    int vb, vu;
+    uint64_t seg;
+    size_t lds;
+    return papr_sweep_variant(variant) >= 0 || papr_sweep2_geometry(variant, &vb, &seg, &lds, &vu) == 0 ||
+                   papr_sweep3_geometry(variant, &vb, &lds) == 0
+               ? 1
+               : 0;
 }
 
 int papr_hip_set_timing(papr_hip_ctx *ctx, int enabled)

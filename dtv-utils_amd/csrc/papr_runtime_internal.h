@@ -5,6 +5,8 @@
 #define PAPR_RUNTIME_INTERNAL_H
 
 #include "papr_hip.h"
+#include "papr_exchange.h"
+#include "papr_hip_measure.h"
 #include "papr_exact_format.h"
 #include "papr_kernels.h"
 #include "papr_readbatch.h"
@@ -290,9 +292,9 @@ constexpr int kStatsVariant = 1, kStatsPerCU = 2, kStatsMap = PAPR_MAP_GRID_STRI
 constexpr int kCcdfVariant = 13, kCcdfPerCU = 2, kCcdfMap = PAPR_MAP_GRID_STRIDE;
 
 // one-sweep kernel (pass 1 + banded pass 2 in one read)
-constexpr int kSweepVariant = 40, kSweepPerCU = 4, kSweepMap = PAPR_MAP_GRID_STRIDE;  // (variant 40: one workgroup per CU)
+constexpr int kSweepVariant = PAPR_SWEEP_VARIANT, kSweepPerCU = 4, kSweepMap = PAPR_MAP_GRID_STRIDE;  // (papr_sweep_kernel: one workgroup per CU)
 constexpr int kStashSkewFloats = 0;  // (see stash_segment_floats; 1 KiB units)
-constexpr int kSweepExactVariant = 130;  // papr_sweep3_kernel<8 waves> (56: papr_sweep2_kernel<12 waves, exact-sum pairs>, its predecessor)
+constexpr int kSweepExactVariant = PAPR_SWEEP3_VARIANT;  // papr_sweep3_kernel
 
 constexpr int kSweepBandLog2 = 14, kEstimateRatio = 64;
 

@@ -6,35 +6,75 @@
 #include <stddef.h>
 #include <stdint.h>
 
-// one PID of one workgroup's span: packets, first and last unit number (within the launch)
+#include "ts_hip.h"
+
+// one PID of one span: packets, first and last packet number (relative to the span's first packet)
 struct ts_wg_entry {
     uint32_t pid, count, first, last;
+};
+
+// What a span leaves behind: where it started, the walker's state where it ended, what it counted.  The chain of spans
+// is valid where every span started exactly where the one in front of it ended (ts_merge_kernel).
+struct ts_span_rec {
+    uint64_t entry;          // file offset the span started from (TS_NO_ENTRY: no packet grid found at its start)
+    uint64_t exit_pos;       // walker state behind its last packet
+    uint64_t exit_skipped;
+    uint32_t exit_stale_af, exit_extra;
+    uint64_t packets;        // packets it counted ...
+    uint64_t block_packets;  // ... of them by the one-lane-per-packet blocks (the rest: the walker)
+    uint32_t walks;          // times the walker took over
+    uint32_t nlist;          // PIDs in its list
+    uint32_t attempt;        // id of the launch that wrote this record (its events carry the same)
+    uint32_t explicit_entry; // 1: started from a walker state handed in by the host, clean or not
+};
+#define TS_NO_ENTRY 0xFFFFFFFFFFFFFFFFull
+#define TS_MAX_SPANS 512 /* spans per scan (one per CU; ts_merge_kernel keeps their records in LDS) */
+
+// a `Transport Sync Error` line, before the span's packets have their stream-wide numbers
+struct ts_event {
+    uint64_t skipped;
+    uint64_t at_rel;   // packets the span had counted at that moment
+    uint32_t span, attempt;
 };
 
 struct ts_scan_params {
     const unsigned char *data;  // the stream, file offset 0 at data[0]
     uint64_t nbytes;
-    uint64_t first_unit;        // file offset of unit 0 of this launch (a clean position)
-    uint64_t nunits;            // units the launch may take (< 2^32)
+    uint64_t span_bytes;        // span k = the packets that start in bytes [k, k + 1) * span_bytes
+    uint32_t first_span, nspans_total;
     uint32_t stride;            // 188, or 192 (HDMV)
     uint32_t sync_offset;       // 0, or 4 (HDMV: behind the tp_extra_header)
-    ts_wg_entry *lists;         // per workgroup: up to TS_PIDS entries
-    uint32_t *list_counts;      // per workgroup
-    unsigned long long *span_done;  // per workgroup: units taken (in front of its first irregular one)
-    uint32_t *span_stopped;     // per workgroup: 1 = it met an irregular unit
-    uint32_t *events;           // per workgroup: event_cap unit numbers whose packet hit the read-boundary quirk harmlessly
-    uint32_t *event_counts;     // per workgroup
-    uint32_t event_cap;         // 0 = treat every quirk packet as irregular
-    uint32_t *merged_events;    // the valid spans' events, compacted by ts_merge_kernel
-    uint32_t merged_event_cap;
+    uint32_t hdmv;
+    uint32_t attempt;
+    uint32_t explicit_entry;    // 1: a launch of ONE span from `entry` (the state the chain arrived with)
+    uint32_t quirk_events;      // 0: every read-boundary quirk goes to the walker (tests)
+    ts_walk_state entry;
+    ts_wg_entry *lists;         // per span: up to TS_PIDS entries
+    ts_span_rec *recs;          // per span
+    ts_event *events;           // one list for the launch(es) of a scan, slots handed out by an atomic counter
+    uint32_t event_cap;
+    unsigned int *event_count;  // events wanted so far (may run past event_cap: the host then repeats the scan with more room)
+};
+
+// what ts_merge_kernel tells the host
+struct ts_merge_out {
+    uint32_t valid_upto;        // first span the chain did NOT reach validly (== nspans_total: done)
+    uint32_t pad;
+    uint64_t packets;           // packets of the valid chain (stream-wide packet_counter so far)
+    ts_walk_state cur;          // the walker state the chain arrived with in front of span `valid_upto`
+    uint64_t block_packets;
+    uint64_t walks;
 };
 
 void ts_kernels_prepare_device(void);
-// unroll: packets per lane between two workgroup barriers (1, 2 or 4)
-void ts_launch_scan(hipStream_t st, int blocks, int unroll, int block, int agg, const ts_scan_params &p);
-int ts_scan_form_exists(int unroll, int block, int agg); /* 1 if that (packets per lane, workgroup size, aggregated update) form is built */
-void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t nspans, uint64_t packet_base, uint32_t *g_count,
-                     unsigned long long *g_first, unsigned long long *g_last, unsigned long long *taken_out);
+void ts_launch_scan(hipStream_t st, int blocks, const ts_scan_params &p);
+// folds spans [from_span, ...) as far as the chain holds, starting from state `cur` with `packet_base` packets counted;
+// span_base / span_attempt (nspans_total each): per span its first packet's stream-wide number and the attempt whose
+// record was taken (0: the span was not taken)
+void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t from_span, uint64_t packet_base, const ts_walk_state &cur,
+                     uint32_t *g_count, unsigned long long *g_first, unsigned long long *g_last, unsigned long long *span_base,
+                     uint32_t *span_attempt, ts_merge_out *out);
 void ts_launch_generate(hipStream_t st, void *out, uint64_t nunits, uint32_t unit, uint64_t seed, int hdmv);
+void ts_launch_generate_damaged(hipStream_t st, void *out, uint64_t nbytes, uint64_t period, uint64_t seed);
 
 #endif

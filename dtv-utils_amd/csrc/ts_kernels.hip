@@ -1,15 +1,24 @@
 // ts_kernels.hip — gfx950 kernels of the transport-stream packet scan (include/ts_hip.h; reference xport.c).
 //
-// From a clean sync position every "regular" packet sits at a fixed stride and is independent of the others, so
-// one launch takes a whole stretch of them: each lane ONE packet header (8 aligned bytes out of the unit's 188 /
-// 192: the scan touches a third of the stream's 64-byte sectors, not its payload), per-workgroup count / first /
-// last tables in LDS (3 x 32 KiB), and — because a launch cannot know in advance where the stretch ends — every
-// workgroup works on one contiguous span and stops at ITS first irregular packet; ts_merge_kernel then folds the
-// tables of the workgroups up to and including the first one that stopped and reports where the stretch ended.
-// Irregular = anything whose effect on the reference's state machine is not local to the packet (ts_host.c walks
-// those): sync byte missing, packet cut off by the end of the stream, adaptation field longer than the packet, or
-// the packet ends exactly one byte past a 16384-byte read of the reference while its payload is skipped in one
-// step (xport.c:4302).
+// The stream is cut into one byte range ("span") per CU.  Inside a span the packets are taken the fast way as long as
+// they sit on their grid: from a clean position the next 1024 units are classified one lane per packet header (8
+// aligned bytes out of the unit's 188 / 192: the scan touches a third of the stream's 64-byte sectors, not its payload)
+// and everything in front of the first irregular one is counted into per-workgroup tables in LDS (count / first /
+// last per PID, 96 KiB).  Irregular = anything whose effect on the reference's state machine is not local to the
+// packet: sync byte missing, packet cut off by the end of the stream, adaptation field longer than the packet, the
+// packet ends exactly one byte past a 16384-byte read of the reference while its payload is skipped in one step
+// (xport.c:4302) and what follows is not simply the next sync byte.  Across those, wave 0 of the workgroup runs the
+// packet walker itself — ts_walk_core.h, the same closed-form step the host library exports as ts_walk and the tests
+// pin against the reference without a GPU — until the stream is back on a grid (any grid: an inserted or deleted
+// byte moves it), and the workgroup goes on in blocks from there.  Damage therefore costs its own bytes, once, on
+// the device: there is no hand-over to the host and no relaunch per irregularity.
+//
+// A span cannot know where the chain of packets enters it, so it SPECULATES: the first position in its first
+// stride-ful of bytes from which eight sync bytes in a row sit at the packet stride.  ts_merge_kernel then checks
+// the chain — every span must have started exactly where, and in the state in which, the one in front of it ended —
+// and folds the spans' tables (with stream-wide packet numbers) as far as it holds; where it does not (damage across
+// a span boundary, a payload that imitates a grid), the host launches THAT span again from the true state and the
+// merge goes on.  Speculation decides how many launches a scan takes, never a number in its result.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,146 +29,334 @@
 
 namespace {
 
+constexpr int kScanBlock = 1024;
 constexpr int kMergeBlock = 256;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr int kEntrySyncs = 8;  // sync bytes in a row, at the stride, that make a position a span's speculated entry
+
+// ---- the walker on the device: ts_walk_core.h with these hooks, run by wave 0 with all 64 lanes in step ----
+struct DevWalk {
+    const unsigned char *data;
+    uint32_t *s_count, *s_first, *s_last;  // the workgroup's tables (LDS); the other waves wait at a barrier meanwhile
+    uint64_t packets;                      // the span's packet counter (the same in every lane)
+    ts_event *events;
+    unsigned int *event_count;
+    uint32_t event_cap, span, attempt, lane;
+};
+
+__device__ __forceinline__ bool walk_is_clean(const ts_walk_state &st)
+{
+    return st.skipped == 0 && st.stale_af == 0 && (!st.hdmv || st.extra_pending == 4u);
+}
+
+// first offset in [from, end) that holds 0x47, or end: 1 KiB per step (16 bytes per lane) where the address allows,
+// single bytes up to the next 16-byte boundary and at the end
+__device__ __forceinline__ uint64_t dev_find_sync(const DevWalk *w, uint64_t from, uint64_t end)
+{
+    const unsigned char *d = w->data;
+    const uint32_t lane = w->lane;
+    uint64_t pos = from;
+    while (pos < end) {  // (wave-uniform)
+        if ((((uintptr_t)d + pos) & 15u) == 0 && pos + 1024 <= end) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(d + pos + 16u * lane);
+            const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+            uint32_t idx = 16;
+#pragma unroll
+            for (int k = 3; k >= 0; k--) {
+                const uint32_t x = wd[k] ^ 0x47474747u;
+                const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;  // (the LOWEST flagged byte is always a true match)
+                if (z)
+                    idx = 4u * (uint32_t)k + ((uint32_t)__ffs((int)z) - 1u) / 8u;
+            }
+            const unsigned long long m = __ballot(idx < 16u);
+            if (m) {
+                const int l = __ffsll((long long)m) - 1;
+                return pos + 16u * (uint32_t)l + (uint32_t)__builtin_amdgcn_readlane((int)idx, l);
+            }
+            pos += 1024;
+        } else {
+            uint64_t n = (((uintptr_t)d + pos) & 15u) ? 16u - (((uintptr_t)d + pos) & 15u) : 64u;
+            n = n < end - pos ? n : end - pos;
+            const bool hit = lane < n && d[pos + lane] == 0x47u;
+            const unsigned long long m = __ballot(hit);
+            if (m)
+                return pos + (uint64_t)(__ffsll((long long)m) - 1);
+            pos += n;
+        }
+    }
+    return end;
+}
+
+__device__ __forceinline__ void dev_count(DevWalk *w, unsigned h1, unsigned h2)
+{
+    const uint32_t rel = (uint32_t)w->packets;  // (a span counts < 2^32 packets)
+    w->packets++;
+    if (w->lane == 0 && (h1 & 0x80u) == 0) {  // transport_error_indicator clear, xport.c:2861-2867
+        const uint32_t pid = ((h1 & 0x1fu) << 8) | h2;
+        w->s_count[pid]++;
+        if (rel < w->s_first[pid])
+            w->s_first[pid] = rel;
+        if (rel > w->s_last[pid])
+            w->s_last[pid] = rel;
+    }
+}
+
+__device__ __forceinline__ void dev_event(const DevWalk *w, uint64_t skipped, uint64_t at_rel)
+{
+    if (w->lane == 0) {
+        const unsigned int slot = atomicAdd(w->event_count, 1u);  // (counts what no longer fits: the host sees the overflow)
+        if (slot < w->event_cap) {
+            ts_event e;
+            e.skipped = skipped;
+            e.at_rel = at_rel;
+            e.span = w->span;
+            e.attempt = w->attempt;
+            w->events[slot] = e;
+        }
+    }
+}
+
+#define TS_CORE_QUAL __device__ __forceinline__
+#define TS_CORE_NAME dev_walk_step
+#define TS_CORE_CTX DevWalk *
+#define TS_CORE_BYTE(ctx, off) ((unsigned)(ctx)->data[(off)])
+#define TS_CORE_FIND_SYNC(ctx, from, end) dev_find_sync(ctx, from, end)
+#define TS_CORE_COUNT(ctx, h1, h2) dev_count(ctx, h1, h2)
+#define TS_CORE_SYNC_ERROR(ctx, skipped) dev_event(ctx, skipped, (ctx)->packets)
+#include "ts_walk_core.h"
 
 }  // namespace
 
-// UNR = packets per lane between two workgroup barriers (their header loads are in flight together); kBlock = threads.
-// AGG: the per-PID tables are updated once per (wave, PID) instead of once per packet — a transport stream is a
-// handful of PIDs, one of them most of the packets, so 64 lanes adding to the same three LDS words is the common case:
-// the wave takes the PID of its lowest unserved lane, ballots who else has it (count = popcount; the unit numbers grow
-// with the lane, so first = the lowest of them, last = the highest), lets that one lane do the three atomics, and goes
-// on with who is left; after eight rounds the remaining lanes (a wave full of different PIDs) update one by one.
-template <int UNR, int kBlock, bool AGG>
-__global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
+__global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_params prm)
 {
+    // (the fields the loop needs, as values: taken out of the by-value argument block once — left inside the struct the
+    // compiler re-reads them from its stack copy in every iteration)
+    struct {
+        const unsigned char *data;
+        uint64_t nbytes, span_bytes;
+        uint32_t first_span, nspans_total, stride, sync_offset, hdmv, attempt, explicit_entry, quirk_events, event_cap;
+        ts_wg_entry *lists;
+        ts_span_rec *recs;
+        ts_event *events;
+        unsigned int *event_count;
+    } p;
+    p.data = prm.data;
+    p.nbytes = prm.nbytes;
+    p.span_bytes = prm.span_bytes;
+    p.first_span = prm.first_span;
+    p.nspans_total = prm.nspans_total;
+    p.stride = prm.stride;
+    p.sync_offset = prm.sync_offset;
+    p.hdmv = prm.hdmv;
+    p.attempt = prm.attempt;
+    p.explicit_entry = prm.explicit_entry;
+    p.quirk_events = prm.quirk_events;
+    p.event_cap = prm.event_cap;
+    p.lists = prm.lists;
+    p.recs = prm.recs;
+    p.events = prm.events;
+    p.event_count = prm.event_count;
     extern __shared__ __attribute__((aligned(16))) uint32_t ts_smem[];  // 3 x TS_PIDS words = 96 KiB (one workgroup per CU)
     uint32_t *s_count = ts_smem, *s_first = ts_smem + TS_PIDS, *s_last = ts_smem + 2 * TS_PIDS;
-    __shared__ uint32_t s_irregular, s_entries, s_events;
-    const uint32_t t = threadIdx.x;
-    for (uint32_t k = t; k < TS_PIDS; k += kBlock) {
+    __shared__ ts_walk_state s_st;
+    __shared__ unsigned long long s_packets, s_block_packets;
+    __shared__ uint32_t s_stop, s_walks, s_entries, s_cand;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t span = p.first_span + blockIdx.x;
+    const uint64_t B0 = (uint64_t)span * p.span_bytes;
+    const uint64_t B1 = (span + 1 == p.nspans_total || B0 + p.span_bytes > p.nbytes) ? p.nbytes : B0 + p.span_bytes;
+    for (uint32_t k = t; k < TS_PIDS; k += kScanBlock) {
         s_count[k] = 0;
         s_first[k] = kNone;
         s_last[k] = 0;
     }
     if (t == 0) {
-        s_irregular = kNone;
+        s_stop = kNone;
+        s_walks = 0;
         s_entries = 0;
-        s_events = 0;
+        s_cand = kNone;
+        s_packets = 0;
+        s_block_packets = 0;
+        ts_walk_state st;
+        st.pos = 0;
+        st.skipped = 0;
+        st.stale_af = 0;
+        st.extra_pending = p.hdmv ? 4u : 0u;
+        st.hdmv = (int)p.hdmv;
+        if (p.explicit_entry) {
+            st.pos = prm.entry.pos;
+            st.skipped = prm.entry.skipped;
+            st.stale_af = prm.entry.stale_af;
+            st.extra_pending = prm.entry.extra_pending;
+        }
+        s_st = st;
     }
     __syncthreads();
-
-    // this workgroup's span of units (unit = 188 or 192 bytes; the sync byte sits p.sync_offset bytes into it)
-    const uint64_t per = (p.nunits + gridDim.x - 1) / gridDim.x;
-    const uint64_t j0 = (uint64_t)blockIdx.x * per;
-    const uint64_t j1 = j0 + per < p.nunits ? j0 + per : p.nunits;
-    for (uint64_t jb = j0; jb < j1; jb += (uint64_t)UNR * kBlock) {  // workgroup-uniform trip count
-        // the five bytes that matter — sync, two PID bytes, adaptation_field_control, adaptation_field_length — out of
-        // two aligned dwords per packet; all UNR packets' loads issued before the first is looked at
-        uint32_t w0[UNR], w1[UNR];
-        bool whole[UNR];
-#pragma unroll
-        for (int r = 0; r < UNR; r++) {
-            const uint64_t j = jb + (uint64_t)r * kBlock + t;
-            const uint64_t s = p.first_unit + j * p.stride + p.sync_offset;  // file offset of the sync byte
-            whole[r] = j < j1 && s + 188 <= p.nbytes;
-            const uint64_t a = whole[r] ? (s & ~3ull) : 0ull;
-            w0[r] = *reinterpret_cast<const uint32_t *>(p.data + a);
-            w1[r] = *reinterpret_cast<const uint32_t *>(p.data + a + 4);
-        }
-        bool regular[UNR], quirk[UNR];
-        uint32_t pid[UNR], tei[UNR];
-#pragma unroll
-        for (int r = 0; r < UNR; r++) {
-            const uint64_t j = jb + (uint64_t)r * kBlock + t;
-            const uint64_t s = p.first_unit + j * p.stride + p.sync_offset;
-            const uint32_t sh = (uint32_t)(s & 3u);
-            const uint32_t lo = __builtin_amdgcn_alignbyte(w1[r], w0[r], sh);  // bytes s .. s+3
-            const uint32_t b4 = (w1[r] >> (8 * sh)) & 0xffu;                   // byte s+4 (sh <= 3: inside w1)
-            const uint32_t b0 = lo & 0xffu, b1 = (lo >> 8) & 0xffu, b2 = (lo >> 16) & 0xffu, b3 = lo >> 24;
-            tei[r] = b1 >> 7;
-            pid[r] = ((b1 & 0x1fu) << 8) | b2;
-            const bool has_af = (b3 & 0x20u) != 0;
-            const uint32_t af_len = has_af ? b4 : 0u;
-            regular[r] = whole[r] && b0 == 0x47u && af_len <= 183u;  // (!whole: cut off by the end of the stream)
-            quirk[r] = false;
-            // the reference's one-step payload skip, entered before the last byte of a packet that ends one byte
-            // past a 16384-byte read, finishes the packet a byte early (xport.c:4302): its last byte goes to the
-            // sync search.  Unless that byte is 0x47 (a false sync: irregular) the search skips it, reports
-            // `skipped 1 bytes` and locks on the next packet where it would have anyway — an event for the list,
-            // nothing else changes.
-            const bool on_boundary = ((s + 187) & (TS_READ_CHUNK - 1)) == 0;
-            if (regular[r] && on_boundary && pid[r] != 0u && pid[r] != 0x1ffbu && (!has_af || af_len <= 181u)) {
-                // `skipped 1 bytes` and nothing else happens only if the search that starts on the packet's last byte
-                // ends on the NEXT unit's sync byte: that unit must be there, whole, with its 0x47 in place, and the byte
-                // the search tests first — the packet's last byte, or in HDMV mode (which swallows four bytes in front
-                // of every search, xport.c:4317) the last byte of the next tp_extra_header — must not be a 0x47 itself.
-                // Anything else (last packet of the stream: no line at all; damage behind it: ONE line with the sum of
-                // the bytes skipped; a false sync: a re-lock one byte early) is the walker's.
-                const uint64_t probe = s + 187 + p.sync_offset, next_sync = s + p.stride;
-                const bool next_whole = next_sync + 188 <= p.nbytes;
-                if (p.event_cap == 0 || !next_whole || p.data[probe] == 0x47u || p.data[next_sync] != 0x47u)
-                    regular[r] = false;
-                else
-                    quirk[r] = true;
+    // ---- where does the chain of packets enter this span?  (span 0: at the stream's first byte; a launch of one span
+    // from a state the host hands in: there; otherwise speculated — the first unit start in the span's first stride-ful
+    // of bytes behind which the sync bytes sit on the grid) ----
+    if (!p.explicit_entry && span != 0) {
+        if (t < p.stride) {
+            const uint64_t sy = B0 + t + p.sync_offset;
+            bool ok = sy < p.nbytes;
+            for (int i = 0; ok && i < kEntrySyncs; i++) {
+                const uint64_t at = sy + (uint64_t)i * p.stride;
+                if (at >= p.nbytes)
+                    break;
+                ok = p.data[at] == 0x47u;
             }
-            if (j < j1 && !regular[r])
-                atomicMin(&s_irregular, (uint32_t)(j - j0));
+            if (ok)
+                atomicMin(&s_cand, t);
         }
         __syncthreads();
-        const uint32_t stop = s_irregular;  // relative to j0
-#pragma unroll
-        for (int r = 0; r < UNR; r++) {
-            const uint64_t j = jb + (uint64_t)r * kBlock + t;
-            if constexpr (AGG) {
-                const uint32_t rel_all = (uint32_t)j;
-                const bool counts = j < j1 && (uint32_t)(j - j0) < stop && tei[r] == 0;
-                unsigned long long todo = __ballot(counts);
-                const uint32_t lane = t & 63u;
-                for (int round = 0; todo != 0ull; round++) {  // (wave-uniform)
-                    if (round == 8) {  // a wave full of different PIDs: the rest one by one
-                        if ((todo >> lane) & 1ull) {
-                            atomicAdd(&s_count[pid[r]], 1u);
-                            atomicMin(&s_first[pid[r]], rel_all);
-                            atomicMax(&s_last[pid[r]], rel_all);
-                        }
-                        break;
-                    }
-                    const int leader = __ffsll((long long)todo) - 1;
-                    const uint32_t lp = (uint32_t)__builtin_amdgcn_readlane((int)pid[r], leader);
-                    const unsigned long long same = __ballot(counts && pid[r] == lp);
-                    const int top = 63 - __clzll((long long)same);
-                    const uint32_t rel_lo = (uint32_t)__builtin_amdgcn_readlane((int)rel_all, leader);
-                    const uint32_t rel_hi = (uint32_t)__builtin_amdgcn_readlane((int)rel_all, top);
-                    if ((int)lane == leader) {
-                        atomicAdd(&s_count[lp], (uint32_t)__popcll(same));
-                        atomicMin(&s_first[lp], rel_lo);
-                        atomicMax(&s_last[lp], rel_hi);
-                    }
-                    todo &= ~same;
-                }
+        if (s_cand == kNone) {  // (workgroup-uniform) nothing regular here: the span in front carries the chain across
+            if (t == 0) {
+                ts_span_rec r;
+                r.entry = TS_NO_ENTRY;
+                r.exit_pos = r.exit_skipped = 0;
+                r.exit_stale_af = r.exit_extra = 0;
+                r.packets = r.block_packets = 0;
+                r.walks = r.nlist = 0;
+                r.attempt = p.attempt;
+                r.explicit_entry = 0;
+                p.recs[span] = r;
             }
-            if (j < j1 && (uint32_t)(j - j0) < stop) {
-                const uint32_t rel = (uint32_t)j;  // unit number within the launch (a launch takes < 2^32 units)
-                if (!AGG && tei[r] == 0) {
-                    atomicAdd(&s_count[pid[r]], 1u);
-                    atomicMin(&s_first[pid[r]], rel);
-                    atomicMax(&s_last[pid[r]], rel);
-                }
-                if (quirk[r]) {  // (about one packet in 4096 of a stream whose packets sit at odd offsets)
-                    const uint32_t at = atomicAdd(&s_events, 1u);
-                    if (at < p.event_cap)
-                        p.events[(size_t)blockIdx.x * p.event_cap + at] = rel;
-                }
-            }
+            return;
         }
-        if (stop != kNone)
-            break;  // (uniform: every thread read the same value after the barrier)
+        if (t == 0)
+            s_st.pos = B0 + s_cand;
     }
     __syncthreads();
-    ts_wg_entry *mine = p.lists + (size_t)blockIdx.x * TS_PIDS;
-    for (uint32_t k = t; k < TS_PIDS; k += kBlock) {
+    // The state every thread carries (the same in all of them): while the stream is on its grid only `pos` and the
+    // counters move, and they move by the same amount in every thread — no LDS, no extra barrier.  Only the walker's
+    // result goes through LDS (s_st, s_packets).
+    ts_walk_state st = s_st;
+    const uint64_t entry_pos = st.pos;
+    uint64_t packets = 0, block_packets = 0;
+    uint32_t units_seen = 0;  // units the blocks of this span have looked at so far: block-independent indices for s_stop
+    uint32_t walks = 0;
+    bool walk_next = false;
+    for (;;) {
+        const bool clean = walk_is_clean(st);
+        if (st.pos >= p.nbytes || (clean && !walk_next && st.pos >= B1))
+            break;  // (workgroup-uniform)
+        if (clean && !walk_next) {
+            // ---- a block: the next units on the grid, one lane each (those that START in this span) ----
+            // (all 1024 units start inside the span — the usual case, decided without the 64-bit division)
+            const uint64_t room = B1 - st.pos;
+            const uint32_t nblk = room > (uint64_t)(kScanBlock - 1) * p.stride ? (uint32_t)kScanBlock
+                                                                                : (uint32_t)((room + p.stride - 1) / p.stride);
+            const uint64_t sy = st.pos + (uint64_t)t * p.stride + p.sync_offset;  // file offset of this lane's sync byte
+            const bool mine = t < nblk, whole = mine && sy + 188 <= p.nbytes;
+            // the five bytes that matter — sync, two PID bytes, adaptation_field_control, adaptation_field_length — out of
+            // two aligned dwords
+            const uint64_t a = whole ? (sy & ~3ull) : 0ull;
+            const uint32_t w0 = *reinterpret_cast<const uint32_t *>(p.data + a);
+            const uint32_t w1 = *reinterpret_cast<const uint32_t *>(p.data + a + 4);
+            const uint32_t sh = (uint32_t)(sy & 3u);
+            const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh);  // bytes sy .. sy+3
+            const uint32_t b4 = (w1 >> (8 * sh)) & 0xffu;                // byte sy+4 (sh <= 3: inside w1)
+            const uint32_t b0 = lo & 0xffu, b1 = (lo >> 8) & 0xffu, b2 = (lo >> 16) & 0xffu, b3 = lo >> 24;
+            const uint32_t tei = b1 >> 7, pid = ((b1 & 0x1fu) << 8) | b2;
+            const bool has_af = (b3 & 0x20u) != 0;
+            const uint32_t af_len = has_af ? b4 : 0u;
+            bool regular = whole && b0 == 0x47u && af_len <= 183u;  // (!whole: cut off by the end of the stream)
+            bool quirk = false;
+            // the reference's one-step payload skip, entered before the last byte of a packet that ends one byte past a
+            // 16384-byte read, finishes the packet a byte early (xport.c:4302): its last byte goes to the sync search.
+            // `skipped 1 bytes` and nothing else happens only if that search ends on the NEXT unit's sync byte: that unit
+            // must be there, whole, with its 0x47 in place, and the byte the search tests first — the packet's last byte,
+            // or in HDMV mode (which swallows four bytes in front of every search, xport.c:4317) the last byte of the next
+            // tp_extra_header — must not be a 0x47 itself.  Anything else (last packet of the stream: no line at all;
+            // damage behind it: ONE line with the sum of the bytes skipped; a false sync: a re-lock one byte early) is
+            // the walker's.
+            if (regular && ((sy + 187) & (TS_READ_CHUNK - 1)) == 0 && pid != 0u && pid != 0x1ffbu && (!has_af || af_len <= 181u)) {
+                const uint64_t probe = sy + 187 + p.sync_offset, next_sync = sy + p.stride;
+                if (!p.quirk_events || next_sync + 188 > p.nbytes || p.data[probe] == 0x47u || p.data[next_sync] != 0x47u)
+                    regular = false;
+                else
+                    quirk = true;
+            }
+            // (indices that keep growing over the span's blocks: a thread that is already in the next block cannot
+            // disturb what a slower one still reads of this block — the one barrier per block is enough)
+            if (mine && !regular)
+                atomicMin(&s_stop, units_seen + t);
+            __syncthreads();
+            const uint32_t stop = s_stop - units_seen;  // (kNone - units_seen >= nblk: a span looks at < 2^32 - 1024 units)
+            const uint32_t take = stop < nblk ? stop : nblk;  // units in front of the first irregular one
+            if (t < take) {
+                const uint32_t rel = (uint32_t)packets + t;  // packet number within the span (a span counts < 2^32)
+                if (tei == 0) {
+                    atomicAdd(&s_count[pid], 1u);
+                    atomicMin(&s_first[pid], rel);
+                    atomicMax(&s_last[pid], rel);
+                }
+                if (quirk) {  // (about one packet in 4096 of a stream whose packets sit at odd offsets): the line is
+                    DevWalk w;  // printed when the stream locks again, i.e. with this packet counted
+                    w.events = p.events;
+                    w.event_count = p.event_count;
+                    w.event_cap = p.event_cap;
+                    w.span = span;
+                    w.attempt = p.attempt;
+                    w.lane = 0;
+                    dev_event(&w, 1, (uint64_t)rel + 1);
+                }
+            }
+            packets += take;
+            block_packets += take;
+            units_seen += nblk;
+            st.pos += (uint64_t)take * p.stride;
+            walk_next = take < nblk;  // the unit at the new position is the walker's
+            continue;
+        }
+        // ---- the walker: wave 0 across whatever is not on the grid, until the stream is clean again — and the byte
+        // where the next sync is due is one (else the next block would only find that out) ----
+        walk_next = false;
+        walks++;
+        __syncthreads();  // every thread has committed its packets and read s_stop
+        if (wave == 0) {
+            DevWalk w;
+            w.data = p.data;
+            w.s_count = s_count;
+            w.s_first = s_first;
+            w.s_last = s_last;
+            w.packets = packets;
+            w.events = p.events;
+            w.event_count = p.event_count;
+            w.event_cap = p.event_cap;
+            w.span = span;
+            w.attempt = p.attempt;
+            w.lane = lane;
+            ts_walk_state s2 = st;
+            for (;;) {
+                if (!dev_walk_step(&s2, &w, p.nbytes, 1))
+                    break;  // the stream ended in front of the next packet (s2.pos == nbytes)
+                if (s2.pos >= p.nbytes)
+                    break;
+                if (walk_is_clean(s2) && (s2.pos >= B1 || s2.pos + p.sync_offset >= p.nbytes || p.data[s2.pos + p.sync_offset] == 0x47u))
+                    break;  // (behind the span's end the next span takes over, grid or not: the merge sorts that out)
+            }
+            if (lane == 0) {
+                s_st = s2;
+                s_packets = w.packets;
+                s_stop = kNone;
+            }
+        }
+        __syncthreads();
+        st = s_st;
+        packets = s_packets;
+    }
+    __syncthreads();
+    if (t == 0) {
+        s_st = st;
+        s_packets = packets;
+        s_block_packets = block_packets;
+        s_walks = walks;
+    }
+    __syncthreads();
+    // ---- what the span leaves behind: its PIDs as a list, and its record ----
+    ts_wg_entry *list = p.lists + (size_t)span * TS_PIDS;
+    for (uint32_t k = t; k < TS_PIDS; k += kScanBlock) {
         if (s_count[k]) {
             const uint32_t at = atomicAdd(&s_entries, 1u);
             ts_wg_entry e;
@@ -167,84 +364,164 @@ __global__ __launch_bounds__(kBlock) void ts_scan_kernel(const ts_scan_params p)
             e.count = s_count[k];
             e.first = s_first[k];
             e.last = s_last[k];
-            mine[at] = e;
+            list[at] = e;
         }
     }
     __syncthreads();
     if (t == 0) {
-        p.list_counts[blockIdx.x] = s_entries;
-        // units of this span in front of its first irregular one (all of them if there is none)
-        p.span_done[blockIdx.x] = s_irregular != kNone ? (uint64_t)s_irregular : (j1 > j0 ? j1 - j0 : 0);
-        // more quirk events than the list holds: as good as an irregular packet (the host walker then reports them)
-        p.span_stopped[blockIdx.x] = (s_irregular != kNone || s_events > p.event_cap) ? 1u : 0u;
-        if (s_events > p.event_cap)
-            p.span_done[blockIdx.x] = 0, p.list_counts[blockIdx.x] = 0;
-        p.event_counts[blockIdx.x] = s_events <= p.event_cap ? s_events : 0u;
+        ts_span_rec r;
+        r.entry = entry_pos;
+        r.exit_pos = s_st.pos;
+        r.exit_skipped = s_st.skipped;
+        r.exit_stale_af = s_st.stale_af;
+        r.exit_extra = s_st.extra_pending;
+        r.packets = s_packets;
+        r.block_packets = s_block_packets;
+        r.walks = s_walks;
+        r.nlist = s_entries;
+        r.attempt = p.attempt;
+        r.explicit_entry = p.explicit_entry;
+        p.recs[span] = r;
     }
 }
 
-// One workgroup per span: fold the tables of the spans up to and including the first that stopped into the stream-wide
-// tables (absolute 1-based packet numbers = packet_base + unit number + 1; count: add, first: min over a table that
-// starts at all-ones, last: max — order-independent, so the spans go in parallel) and tell the host how many units
-// were taken.  Every workgroup works out the stop for itself from the nspans-long span tables (a few hundred words).
-__global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_params p, uint32_t nspans, uint64_t packet_base,
-                                                               uint32_t *__restrict__ g_count,
+// One workgroup per span from `from_span` on.  Every workgroup walks the chain of records for itself (a few hundred
+// entries): a span is taken if the chain arrives, clean, exactly where the span started (or the span was launched from
+// the very state the chain arrived with); a span the chain has already passed (the span in front ran on across it: a
+// stretch without a grid) is skipped; the first span that fits neither ends the valid part.  Taken spans fold their
+// lists into the stream-wide tables with their first packet's stream-wide number as base (count: add, first: min over
+// a table that starts at all-ones, last: max — order-independent, so the spans go in parallel).
+__global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_params p, uint32_t from_span, uint64_t packet_base,
+                                                               ts_walk_state cur0, uint32_t *__restrict__ g_count,
                                                                unsigned long long *__restrict__ g_first,
                                                                unsigned long long *__restrict__ g_last,
-                                                               unsigned long long *__restrict__ taken_out)
+                                                               unsigned long long *__restrict__ span_base,
+                                                               uint32_t *__restrict__ span_attempt,
+                                                               ts_merge_out *__restrict__ out)
 {
-    __shared__ uint32_t s_stop;
-    __shared__ unsigned long long s_taken;
-    __shared__ uint32_t s_ev_before, s_ev_total;
+    __shared__ uint32_t s_taken;
+    __shared__ unsigned long long s_base;
+    __shared__ ts_span_rec s_recs[TS_MAX_SPANS];  // (the chain walk is a serial loop: out of LDS, not out of HBM)
     const uint32_t t = threadIdx.x;
+    const uint32_t me = from_span + blockIdx.x;
+    __shared__ uint32_t s_broken;
+    __shared__ unsigned long long s_sum_before, s_sum_all, s_sum_block, s_sum_walks;
+    for (uint32_t k = from_span + t; k < p.nspans_total; k += kMergeBlock)
+        s_recs[k] = p.recs[k];
     if (t == 0) {
-        s_stop = nspans;
-        s_taken = 0;
-        s_ev_before = 0;
-        s_ev_total = 0;
+        s_broken = 0;
+        s_sum_before = s_sum_all = s_sum_block = s_sum_walks = 0;
     }
     __syncthreads();
-    for (uint32_t b = t; b < nspans; b += kMergeBlock)
-        if (p.span_stopped[b])
-            atomicMin(&s_stop, b);
-    __syncthreads();
-    const uint32_t last_span = s_stop < nspans ? s_stop : nspans - 1;  // the span that stopped counts up to its stop
-    const uint32_t me = blockIdx.x;
-    if (me > last_span)
-        return;  // (workgroup-uniform)
+    // The common case in parallel: every span started exactly where — clean — the one in front of it ended, inside its
+    // own range.  Then nothing has to be walked: a span's base is the sum of the packets in front of it.
     {
-        unsigned long long taken = 0;
-        uint32_t ev_before = 0, ev_total = 0;
-        for (uint32_t b = t; b <= last_span; b += kMergeBlock) {
-            taken += p.span_done[b];
-            const uint32_t n = p.event_counts[b];
-            ev_total += n;
-            ev_before += b < me ? n : 0u;
+        unsigned long long before = 0, all = 0, blk = 0, wk = 0;
+        for (uint32_t k = from_span + t; k < p.nspans_total; k += kMergeBlock) {
+            const ts_span_rec r = s_recs[k];
+            ts_walk_state prev = cur0;
+            bool explicit_ok = r.explicit_entry != 0;
+            if (k > from_span) {
+                const ts_span_rec q = s_recs[k - 1];
+                prev.pos = q.exit_pos;
+                prev.skipped = q.exit_skipped;
+                prev.stale_af = q.exit_stale_af;
+                prev.extra_pending = q.exit_extra;
+                explicit_ok = false;
+            }
+            const uint64_t B1 = (k + 1 == p.nspans_total || (uint64_t)(k + 1) * p.span_bytes > p.nbytes) ? p.nbytes
+                                                                                                        : (uint64_t)(k + 1) * p.span_bytes;
+            const bool clean = prev.skipped == 0 && prev.stale_af == 0 && (!prev.hdmv || prev.extra_pending == 4u);
+            if (!(prev.pos < B1 && r.entry == prev.pos && (clean || explicit_ok)))
+                s_broken = 1;
+            all += r.packets;
+            blk += r.block_packets;
+            wk += r.walks;
+            if (k < me)
+                before += r.packets;
         }
-        if (taken)
-            atomicAdd(&s_taken, taken);
-        if (ev_total)
-            atomicAdd(&s_ev_total, ev_total);
-        if (ev_before)
-            atomicAdd(&s_ev_before, ev_before);
+        atomicAdd(&s_sum_before, before);
+        atomicAdd(&s_sum_all, all);
+        atomicAdd(&s_sum_block, blk);
+        atomicAdd(&s_sum_walks, wk);
     }
     __syncthreads();
-    if (me == 0 && t == 0) {
-        taken_out[0] = s_taken;
-        taken_out[1] = s_ev_total;
+    if (!s_broken) {
+        if (t == 0) {
+            s_taken = s_recs[me].attempt;
+            s_base = packet_base + s_sum_before;
+            if (blockIdx.x == 0) {
+                const ts_span_rec last = s_recs[p.nspans_total - 1];
+                out->valid_upto = p.nspans_total;
+                out->pad = 0;
+                out->packets = packet_base + s_sum_all;
+                ts_walk_state cur = cur0;
+                cur.pos = last.exit_pos;
+                cur.skipped = last.exit_skipped;
+                cur.stale_af = last.exit_stale_af;
+                cur.extra_pending = last.exit_extra;
+                out->cur = cur;
+                out->block_packets = s_sum_block;
+                out->walks = s_sum_walks;
+            }
+        }
+    } else if (t == 0) {
+        ts_walk_state cur = cur0;
+        uint64_t base = packet_base, blockp = 0, walks = 0;
+        uint32_t k = from_span, taken_me = 0;
+        uint64_t base_me = 0;
+        for (; k < p.nspans_total; k++) {
+            const uint64_t B1 = (k + 1 == p.nspans_total || (uint64_t)(k + 1) * p.span_bytes > p.nbytes) ? p.nbytes
+                                                                                                        : (uint64_t)(k + 1) * p.span_bytes;
+            if (cur.pos >= B1) {  // the chain is past this span already
+                if (k == me)
+                    taken_me = 0;
+                continue;
+            }
+            const ts_span_rec r = s_recs[k];
+            const bool clean = cur.skipped == 0 && cur.stale_af == 0 && (!cur.hdmv || cur.extra_pending == 4u);
+            const bool fits = r.entry == cur.pos && (clean || (r.explicit_entry && k == from_span));
+            if (!fits)
+                break;
+            if (k == me) {
+                taken_me = r.attempt;
+                base_me = base;
+            }
+            base += r.packets;
+            blockp += r.block_packets;
+            walks += r.walks;
+            cur.pos = r.exit_pos;
+            cur.skipped = r.exit_skipped;
+            cur.stale_af = r.exit_stale_af;
+            cur.extra_pending = r.exit_extra;
+        }
+        s_taken = k > me ? taken_me : 0u;  // (k <= me: the chain broke in front of this span)
+        s_base = base_me;
+        if (blockIdx.x == 0) {
+            out->valid_upto = k;
+            out->pad = 0;
+            out->packets = base;
+            out->cur = cur;
+            out->block_packets = blockp;
+            out->walks = walks;
+        }
     }
-    // this span's quirk events, behind those of the spans in front of it (unordered within a span: the host sorts)
-    const uint32_t nev = p.event_counts[me], ev_at = s_ev_before;
-    for (uint32_t k = t; k < nev; k += kMergeBlock)
-        if (ev_at + k < p.merged_event_cap)
-            p.merged_events[ev_at + k] = p.events[(size_t)me * p.event_cap + k];
+    __syncthreads();
+    const uint32_t taken = s_taken;
+    const uint64_t base = s_base;
+    if (t == 0) {
+        span_attempt[me] = taken;
+        span_base[me] = base;
+    }
+    if (!taken)
+        return;  // (workgroup-uniform)
     const ts_wg_entry *list = p.lists + (size_t)me * TS_PIDS;
-    const uint32_t n = p.list_counts[me];
+    const uint32_t n = s_recs[me].nlist;
     for (uint32_t k = t; k < n; k += kMergeBlock) {
         const ts_wg_entry e = list[k];
         atomicAdd(&g_count[e.pid], e.count);
-        atomicMin(&g_first[e.pid], packet_base + e.first + 1);
-        atomicMax(&g_last[e.pid], packet_base + e.last + 1);
+        atomicMin(&g_first[e.pid], base + e.first + 1);
+        atomicMax(&g_last[e.pid], base + e.last + 1);
     }
 }
 
@@ -264,52 +541,45 @@ __global__ __launch_bounds__(256) void ts_generate_kernel(unsigned char *__restr
     }
 }
 
-// the (packets per lane, workgroup size, aggregated update) forms that are built: the default and the measurement knobs
-// TS_SCAN_UNROLL / TS_SCAN_BLOCK / TS_SCAN_AGG of ts_runtime.cpp
-// (measured, tools/gpu_session45.sh: 1.213-1.233 ms for every non-aggregated form, 1.22-1.31 for the aggregated ones —
-// neither the LDS atomics nor the geometry is what holds the scan at 0.77-0.78 of peak on its header lines; the default
-// stays <1, 1024, false> and the rest is built by `make MEASURE=1` only)
-#ifdef PAPR_MEASURE
-#define TS_FOR_EACH_SCAN_FORM(X) \
-    X(1, 1024, false) X(2, 1024, false) X(4, 1024, false) X(1, 1024, true) X(2, 1024, true) X(4, 1024, true) \
-    X(2, 512, false) X(4, 512, false) X(8, 512, false) X(2, 512, true) X(4, 512, true) X(8, 512, true)
-#else
-#define TS_FOR_EACH_SCAN_FORM(X) X(1, 1024, false) X(2, 1024, false) X(4, 1024, false)
-#endif
+__global__ __launch_bounds__(256) void ts_generate_damaged_kernel(unsigned char *__restrict__ out, uint64_t nbytes, uint64_t period,
+                                                                   uint64_t seed)
+{
+    const uint64_t words = (nbytes + 3) / 4;  // (the buffer has slack behind nbytes)
+    for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (uint64_t)gridDim.x * 256) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            v |= (uint32_t)(4 * w + b < nbytes ? ts_synth_damaged_byte(seed, period, 4 * w + b) : 0) << (8 * b);
+        reinterpret_cast<uint32_t *>(out)[w] = v;
+    }
+}
+
+void ts_launch_generate_damaged(hipStream_t st, void *out, uint64_t nbytes, uint64_t period, uint64_t seed)
+{
+    const uint64_t words = (nbytes + 3) / 4;
+    const int blocks = (int)((words + 255) / 256 < 16384 ? (words + 255) / 256 : 16384);
+    if (blocks > 0)
+        hipLaunchKernelGGL(ts_generate_damaged_kernel, dim3(blocks), dim3(256), 0, st, (unsigned char *)out, nbytes, period, seed);
+}
 
 void ts_kernels_prepare_device(void)  // function attributes belong to the current device
 {
     const int lds = 3 * TS_PIDS * (int)sizeof(uint32_t);
-#define X(U, B, A) (void)hipFuncSetAttribute((const void *)ts_scan_kernel<U, B, A>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    TS_FOR_EACH_SCAN_FORM(X)
-#undef X
+    (void)hipFuncSetAttribute((const void *)ts_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
-int ts_scan_form_exists(int unroll, int block, int agg)
-{
-#define X(U, B, A) if (unroll == U && block == B && (agg != 0) == A) return 1;
-    TS_FOR_EACH_SCAN_FORM(X)
-#undef X
-    return 0;
-}
-
-void ts_launch_scan(hipStream_t st, int blocks, int unroll, int block, int agg, const ts_scan_params &p)
+void ts_launch_scan(hipStream_t st, int blocks, const ts_scan_params &p)
 {
     const size_t lds = 3 * TS_PIDS * sizeof(uint32_t);
-#define X(U, B, A)                                                                                   \
-    if (unroll == U && block == B && (agg != 0) == A) {                                               \
-        hipLaunchKernelGGL((ts_scan_kernel<U, B, A>), dim3(blocks), dim3(B), lds, st, p);             \
-        return;                                                                                       \
-    }
-    TS_FOR_EACH_SCAN_FORM(X)
-#undef X
+    hipLaunchKernelGGL(ts_scan_kernel, dim3(blocks), dim3(kScanBlock), lds, st, p);
 }
 
-void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t nspans, uint64_t packet_base, uint32_t *g_count,
-                     unsigned long long *g_first, unsigned long long *g_last, unsigned long long *taken_out)
+void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t from_span, uint64_t packet_base, const ts_walk_state &cur,
+                     uint32_t *g_count, unsigned long long *g_first, unsigned long long *g_last, unsigned long long *span_base,
+                     uint32_t *span_attempt, ts_merge_out *out)
 {
-    hipLaunchKernelGGL(ts_merge_kernel, dim3(nspans), dim3(kMergeBlock), 0, st, p, nspans, packet_base, g_count, g_first,
-                       g_last, taken_out);
+    hipLaunchKernelGGL(ts_merge_kernel, dim3(p.nspans_total - from_span), dim3(kMergeBlock), 0, st, p, from_span, packet_base, cur,
+                       g_count, g_first, g_last, span_base, span_attempt, out);
 }
 
 void ts_launch_generate(hipStream_t st, void *out, uint64_t nunits, uint32_t unit, uint64_t seed, int hdmv)

@@ -1,11 +1,12 @@
-// ts_runtime.cpp — host runtime behind include/ts_hip.h: the stream's residency in HBM and the scan loop that
-// alternates GPU launches over stretches of regular packets (ts_kernels.hip) with the closed-form host walker
-// (ts_host.c) across the irregular ones.  No CPU compute path for the bulk: the walker sees a few hundred bytes per
-// irregular packet, copied back from the device.
+// ts_runtime.cpp — host runtime behind include/ts_hip.h: the stream's residency in HBM and the scan: ONE launch over
+// all spans (regular packets in one-lane-per-packet blocks, everything else by the packet walker on the device,
+// ts_kernels.hip), the chain check + merge, and — only where a span's speculated entry was not where the chain
+// arrived — one more launch of that span from the true state.  The host never looks at stream bytes.
 
 #include "ts_hip.h"
 #include "papr_hip.h"  // the PAPR_E_* codes (one error vocabulary for the library)
 #include "ts_kernels.h"
+#include "ts_synth.h"
 
 #include <hip/hip_runtime.h>
 
@@ -31,27 +32,26 @@ struct ts_hip_ctx {
     uint64_t cap = 0, n = 0;
     bool loaded = false;
     // scan work buffers
-    ts_wg_entry *d_lists = nullptr;
-    uint32_t *d_list_counts = nullptr, *d_span_stopped = nullptr, *d_count = nullptr;
-    unsigned long long *d_span_done = nullptr, *d_first = nullptr, *d_last = nullptr, *d_taken = nullptr;
-    uint32_t *d_events = nullptr, *d_event_counts = nullptr, *d_merged_events = nullptr;
-    uint32_t *h_events = nullptr;                           // pinned
-    unsigned long long *h_taken = nullptr;                  // pinned: [0] units taken, [1] quirk events
-    unsigned char *h_window = nullptr;                      // pinned: what the walker looks at
+    ts_wg_entry *d_lists = nullptr;                         // per span: its PIDs
+    ts_span_rec *d_recs = nullptr;                          // per span: where it started, where it ended, what it counted
+    uint32_t *d_count = nullptr;                            // stream-wide tables: count | first | last
+    unsigned long long *d_first = nullptr, *d_last = nullptr;
+    unsigned long long *d_span_base = nullptr;              // per span: stream-wide number of its first packet
+    uint32_t *d_span_attempt = nullptr;                     // per span: the attempt whose record the chain took (0: none)
+    ts_event *d_events = nullptr;                           // `Transport Sync Error` events of the scan's launches
+    uint32_t event_cap = 0;
+    unsigned int *d_event_count = nullptr;
+    ts_merge_out *h_out = nullptr, *h_out_dev = nullptr;    // mapped: what the merge kernel reports
     void *h_tables = nullptr;                               // pinned: count / first / last read back at the end
+    std::vector<ts_sync_error> errors;                      // every sync error of the last scan, in stream order
     int spans = 0;
-    int unroll = 1;  // TS_SCAN_UNROLL (measurement knob): packets per lane between two barriers of the scan kernel
-    int block = 1024, agg = 0;  // TS_SCAN_BLOCK / TS_SCAN_AGG: threads per workgroup; per-(wave, PID) table updates
     hipEvent_t ev_a = nullptr, ev_m = nullptr, ev_b = nullptr;
 };
 
 namespace {
 
 char g_ts_open_error[256] = "";
-constexpr size_t kWindow = 1 << 16;       // bytes the walker gets per hand-over
-constexpr uint64_t kMaxUnitsPerLaunch = 1ull << 31;
-constexpr uint32_t kEventCap = 1024;             // per workgroup: harmless read-boundary events (one packet in 4096 at most)
-constexpr uint32_t kMergedEventCap = 1u << 20;
+constexpr uint32_t kEventCapInitial = 1u << 16;  // events the first scan has room for (a scan that needs more is repeated)
 
 int ts_fail(ts_hip_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -136,33 +136,22 @@ int ts_hip_open(ts_hip_ctx **out, int device)
     hipDeviceProp_t prop;
     OPENCHK(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    ctx->spans = ctx->num_cus;  // one 1024-thread workgroup (96 KiB of LDS) per CU
-    {   // measurement knobs: packets per lane between barriers, workgroup size, aggregated table update
-        int u = ctx->unroll, b = ctx->block, a = ctx->agg;
-        if (const char *e = getenv("TS_SCAN_UNROLL")) u = atoi(e);
-        if (const char *e = getenv("TS_SCAN_BLOCK")) b = atoi(e);
-        if (const char *e = getenv("TS_SCAN_AGG")) a = atoi(e) != 0;
-        if (ts_scan_form_exists(u, b, a)) {
-            ctx->unroll = u;
-            ctx->block = b;
-            ctx->agg = a;
-        }
-    }
+    ctx->spans = std::min(ctx->num_cus, TS_MAX_SPANS);  // one 1024-thread workgroup (96 KiB of LDS) per CU
+    if (const char *e = getenv("TS_SCAN_SPANS"))  // (tests: many small spans exercise the chain check on small streams)
+        ctx->spans = std::max(1, std::min(atoi(e), TS_MAX_SPANS));
     OPENCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    OPENCHK(hipMalloc((void **)&ctx->d_lists, (size_t)ctx->spans * TS_PIDS * sizeof(ts_wg_entry)));
-    OPENCHK(hipMalloc((void **)&ctx->d_list_counts, ctx->spans * sizeof(uint32_t)));
-    OPENCHK(hipMalloc((void **)&ctx->d_span_stopped, ctx->spans * sizeof(uint32_t)));
-    OPENCHK(hipMalloc((void **)&ctx->d_span_done, ctx->spans * sizeof(unsigned long long)));
+    OPENCHK(hipMalloc((void **)&ctx->d_lists, (size_t)TS_MAX_SPANS * TS_PIDS * sizeof(ts_wg_entry)));
+    OPENCHK(hipMalloc((void **)&ctx->d_recs, TS_MAX_SPANS * sizeof(ts_span_rec)));
+    OPENCHK(hipMalloc((void **)&ctx->d_span_base, TS_MAX_SPANS * sizeof(unsigned long long)));
+    OPENCHK(hipMalloc((void **)&ctx->d_span_attempt, TS_MAX_SPANS * sizeof(uint32_t)));
     OPENCHK(hipMalloc((void **)&ctx->d_count, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long))));
     ctx->d_first = reinterpret_cast<unsigned long long *>(ctx->d_count + TS_PIDS);
     ctx->d_last = ctx->d_first + TS_PIDS;
-    OPENCHK(hipMalloc((void **)&ctx->d_taken, 2 * sizeof(unsigned long long)));
-    OPENCHK(hipHostMalloc((void **)&ctx->h_taken, 2 * sizeof(unsigned long long), hipHostMallocDefault));
-    OPENCHK(hipMalloc((void **)&ctx->d_events, (size_t)ctx->spans * kEventCap * sizeof(uint32_t)));
-    OPENCHK(hipMalloc((void **)&ctx->d_event_counts, ctx->spans * sizeof(uint32_t)));
-    OPENCHK(hipMalloc((void **)&ctx->d_merged_events, (size_t)kMergedEventCap * sizeof(uint32_t)));
-    OPENCHK(hipHostMalloc((void **)&ctx->h_events, (size_t)kMergedEventCap * sizeof(uint32_t), hipHostMallocDefault));
-    OPENCHK(hipHostMalloc((void **)&ctx->h_window, kWindow, hipHostMallocDefault));
+    OPENCHK(hipMalloc((void **)&ctx->d_event_count, sizeof(unsigned int)));
+    OPENCHK(hipMalloc((void **)&ctx->d_events, (size_t)kEventCapInitial * sizeof(ts_event)));
+    ctx->event_cap = kEventCapInitial;
+    OPENCHK(hipHostMalloc((void **)&ctx->h_out, sizeof(ts_merge_out), hipHostMallocMapped));
+    OPENCHK(hipHostGetDevicePointer((void **)&ctx->h_out_dev, ctx->h_out, 0));
     OPENCHK(hipHostMalloc(&ctx->h_tables, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long)), hipHostMallocDefault));
     OPENCHK(hipEventCreate(&ctx->ev_a));
     OPENCHK(hipEventCreate(&ctx->ev_b));
@@ -183,17 +172,13 @@ void ts_hip_close(ts_hip_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
     release(ctx);
     if (ctx->d_lists) (void)hipFree(ctx->d_lists);
-    if (ctx->d_list_counts) (void)hipFree(ctx->d_list_counts);
-    if (ctx->d_span_stopped) (void)hipFree(ctx->d_span_stopped);
-    if (ctx->d_span_done) (void)hipFree(ctx->d_span_done);
+    if (ctx->d_recs) (void)hipFree(ctx->d_recs);
+    if (ctx->d_span_base) (void)hipFree(ctx->d_span_base);
+    if (ctx->d_span_attempt) (void)hipFree(ctx->d_span_attempt);
     if (ctx->d_count) (void)hipFree(ctx->d_count);
-    if (ctx->d_taken) (void)hipFree(ctx->d_taken);
     if (ctx->d_events) (void)hipFree(ctx->d_events);
-    if (ctx->d_event_counts) (void)hipFree(ctx->d_event_counts);
-    if (ctx->d_merged_events) (void)hipFree(ctx->d_merged_events);
-    if (ctx->h_events) (void)hipHostFree(ctx->h_events);
-    if (ctx->h_taken) (void)hipHostFree(ctx->h_taken);
-    if (ctx->h_window) (void)hipHostFree(ctx->h_window);
+    if (ctx->d_event_count) (void)hipFree(ctx->d_event_count);
+    if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     if (ctx->h_tables) (void)hipHostFree(ctx->h_tables);
     if (ctx->ev_a) (void)hipEventDestroy(ctx->ev_a);
     if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
@@ -311,6 +296,27 @@ int ts_hip_generate(ts_hip_ctx *ctx, uint64_t seed, uint64_t npackets, int hdmv)
     return PAPR_OK;
 }
 
+int ts_hip_generate_damaged(ts_hip_ctx *ctx, uint64_t seed, uint64_t npackets, uint64_t period)
+{
+    if (!ctx)
+        return PAPR_E_ARG;
+    if (period == 0 || npackets % (4 * period) != 0)
+        return ts_fail(ctx, PAPR_E_ARG, "npackets must be a multiple of 4 * period");
+    TSCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t nbytes = ts_synth_damaged_size(npackets, period);
+    if (!(ctx->d_data && ctx->cap >= nbytes)) {
+        int rc = ensure_capacity(ctx, nbytes);
+        if (rc)
+            return rc;
+    }
+    ts_launch_generate_damaged(ctx->stream, ctx->d_data, nbytes, period, seed);
+    TSCHK(ctx, hipGetLastError());
+    TSCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n = nbytes;
+    ctx->loaded = true;
+    return PAPR_OK;
+}
+
 int ts_hip_download(ts_hip_ctx *ctx, void *bytes, uint64_t first, uint64_t nbytes)
 {
     if (!ctx || (!bytes && nbytes))
@@ -323,100 +329,130 @@ int ts_hip_download(ts_hip_ctx *ctx, void *bytes, uint64_t first, uint64_t nbyte
     return PAPR_OK;
 }
 
-int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
+static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
 {
-    if (!ctx || !out)
-        return PAPR_E_ARG;
-    if (!ctx->loaded)
-        return ts_fail(ctx, PAPR_E_STATE, "ts_hip_scan called before a stream was loaded");
-    TSCHK(ctx, hipSetDevice(ctx->device));
     memset(out, 0, sizeof(*out));
     out->bytes = ctx->n;
+    ctx->errors.clear();
+    if (ctx->n == 0)
+        return PAPR_OK;
     const uint32_t stride = hdmv ? 192u : 188u, sync_offset = hdmv ? 4u : 0u;
-    TSCHK(ctx, hipMemsetAsync(ctx->d_count, 0, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long)), ctx->stream));
-    TSCHK(ctx, hipMemsetAsync(ctx->d_first, 0xFF, TS_PIDS * sizeof(unsigned long long), ctx->stream));  // min table
-    ts_walk_state st;
-    ts_walk_init(&st, hdmv);
+    // one span per CU, at least 64 KiB each (a span must hold a few packets for its entry to be found)
+    uint64_t span_bytes = (ctx->n + (uint64_t)ctx->spans - 1) / (uint64_t)ctx->spans;
+    const uint64_t min_span = (uint64_t)std::max(4096, atoi(getenv("TS_SCAN_MIN_SPAN") ? getenv("TS_SCAN_MIN_SPAN") : "65536"));
+    span_bytes = std::max<uint64_t>((span_bytes + 4095) & ~4095ull, min_span);
+    const uint32_t nspans = (uint32_t)((ctx->n + span_bytes - 1) / span_bytes);
+    std::vector<ts_span_rec> recs(nspans);
+    std::vector<unsigned long long> base(nspans);
+    std::vector<uint32_t> taken(nspans);
     float ms_total = 0.f, ms_merge = 0.f;
-    for (;;) {
-        // ---- GPU: every regular unit from a clean position on ----
-        if (ts_walk_is_clean(&st) && st.pos + sync_offset + 188 <= ctx->n) {
-            const uint64_t units = std::min<uint64_t>((ctx->n - st.pos + stride - 1) / stride, kMaxUnitsPerLaunch);
-            ts_scan_params p{};
-            p.data = ctx->d_data;
-            p.nbytes = ctx->n;
-            p.first_unit = st.pos;
-            p.nunits = units;
-            p.stride = stride;
-            p.sync_offset = sync_offset;
-            p.lists = ctx->d_lists;
-            p.list_counts = ctx->d_list_counts;
-            p.span_done = ctx->d_span_done;
-            p.span_stopped = ctx->d_span_stopped;
-            p.events = ctx->d_events;
-            p.event_counts = ctx->d_event_counts;
-            p.event_cap = kEventCap;
-            p.merged_events = ctx->d_merged_events;
-            p.merged_event_cap = kMergedEventCap;
-            const int blocks = (int)std::min<uint64_t>((uint64_t)ctx->spans, (units + 1023) / 1024);
+    for (int round = 0;; round++) {  // (a second round only when the event list turned out too small)
+        TSCHK(ctx, hipMemsetAsync(ctx->d_count, 0, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long)), ctx->stream));
+        TSCHK(ctx, hipMemsetAsync(ctx->d_first, 0xFF, TS_PIDS * sizeof(unsigned long long), ctx->stream));  // min table
+        TSCHK(ctx, hipMemsetAsync(ctx->d_event_count, 0, sizeof(unsigned int), ctx->stream));
+        TSCHK(ctx, hipMemsetAsync(ctx->d_span_attempt, 0, nspans * sizeof(uint32_t), ctx->stream));
+        ts_scan_params p{};
+        p.data = ctx->d_data;
+        p.nbytes = ctx->n;
+        p.span_bytes = span_bytes;
+        p.first_span = 0;
+        p.nspans_total = nspans;
+        p.stride = stride;
+        p.sync_offset = sync_offset;
+        p.hdmv = hdmv ? 1u : 0u;
+        p.attempt = 1;
+        p.explicit_entry = 0;
+        p.quirk_events = getenv("TS_SCAN_QUIRK_EVENTS") ? (uint32_t)atoi(getenv("TS_SCAN_QUIRK_EVENTS")) : 1u;
+        ts_walk_init(&p.entry, hdmv);
+        p.lists = ctx->d_lists;
+        p.recs = ctx->d_recs;
+        p.events = ctx->d_events;
+        p.event_cap = ctx->event_cap;
+        p.event_count = ctx->d_event_count;
+        ts_walk_state cur;
+        ts_walk_init(&cur, hdmv);
+        uint64_t packets = 0;
+        uint32_t from = 0;
+        out->launches = 0;
+        for (;;) {
+            // ---- scan (every span from its speculated entry; or ONE span again, from the state the chain arrived with) ...
             TSCHK(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
-            ts_launch_scan(ctx->stream, blocks, ctx->unroll, ctx->block, ctx->agg, p);
+            ts_launch_scan(ctx->stream, p.explicit_entry ? 1 : (int)nspans, p);
             TSCHK(ctx, hipEventRecord(ctx->ev_m, ctx->stream));
-            ts_launch_merge(ctx->stream, p, (uint32_t)blocks, out->packets, ctx->d_count, ctx->d_first, ctx->d_last, ctx->d_taken);
+            // ---- ... and the chain check + merge from there on
+            ts_launch_merge(ctx->stream, p, from, packets, cur, ctx->d_count, ctx->d_first, ctx->d_last, ctx->d_span_base,
+                            ctx->d_span_attempt, ctx->h_out_dev);
             TSCHK(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
             TSCHK(ctx, hipGetLastError());
-            TSCHK(ctx, hipMemcpyAsync(ctx->h_taken, ctx->d_taken, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
             TSCHK(ctx, hipStreamSynchronize(ctx->stream));
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_m) == hipSuccess)
                 ms_total += ms;
             if (hipEventElapsedTime(&ms, ctx->ev_m, ctx->ev_b) == hipSuccess)
                 ms_merge += ms;
-            const uint64_t taken = ctx->h_taken[0];
-            uint64_t nev = ctx->h_taken[1];
-            if (nev > kMergedEventCap)
-                return ts_fail(ctx, PAPR_E_LIMIT, "more than %u read-boundary events in one launch", kMergedEventCap);
-            if (nev) {
-                // packets that ended one byte past a 16384-byte read of the reference: each is one `skipped 1 bytes`
-                // line, reported when the stream locks again, i.e. with that packet's own number
-                TSCHK(ctx, hipMemcpyAsync(ctx->h_events, ctx->d_merged_events, nev * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-                TSCHK(ctx, hipStreamSynchronize(ctx->stream));
-                std::sort(ctx->h_events, ctx->h_events + nev);
-                for (uint64_t k = 0; k < nev; k++) {
-                    if (ctx->h_events[k] >= taken)
-                        continue;  // (cannot happen: events come from the spans in front of the stop)
-                    if (out->nsync_errors < TS_MAX_SYNC_ERRORS) {
-                        out->sync_errors[out->nsync_errors].skipped = 1;
-                        out->sync_errors[out->nsync_errors].at_packet = out->packets + ctx->h_events[k] + 1;
-                    }
-                    out->nsync_errors++;
-                }
-            }
             out->launches++;
-            out->packets += taken;
-            out->gpu_packets += taken;
-            st.pos += taken * stride;
-            if (taken == units && st.pos >= ctx->n)
-                break;  // the stream ended on a packet boundary
-            if (taken == units)
-                continue;  // (a launch-size limit: go on from here)
+            const ts_merge_out mo = *ctx->h_out;
+            out->gpu_packets += mo.block_packets;
+            out->walks += (uint32_t)std::min<uint64_t>(mo.walks, 0xFFFFFFFFull);
+            packets = mo.packets;
+            cur = mo.cur;
+            if (mo.valid_upto >= nspans)
+                break;
+            if (out->launches > 2 * nspans + 4)
+                return ts_fail(ctx, PAPR_E_INTERNAL, "the span chain does not converge (span %u)", mo.valid_upto);
+            // the chain arrived in front of span `valid_upto` somewhere else (or in another state) than the span assumed:
+            // that span once more, from the true state
+            from = mo.valid_upto;
+            p.first_span = from;
+            p.explicit_entry = 1;
+            p.entry = cur;
+            p.attempt++;
         }
-        if (st.pos >= ctx->n)
-            break;
-        // ---- host walker: across the irregular packet(s), on a window copied back from the device ----
-        const uint64_t want = std::min<uint64_t>(kWindow, ctx->n - st.pos);
-        const int eof = st.pos + want >= ctx->n;
-        TSCHK(ctx, hipMemcpyAsync(ctx->h_window, ctx->d_data + st.pos, want, hipMemcpyDeviceToHost, ctx->stream));
+        out->packets = packets;
+        unsigned int nev = 0;
+        TSCHK(ctx, hipMemcpyAsync(&nev, ctx->d_event_count, sizeof(nev), hipMemcpyDeviceToHost, ctx->stream));
         TSCHK(ctx, hipStreamSynchronize(ctx->stream));
-        const uint64_t before = st.pos;
-        const uint64_t walked = ts_walk(&st, ctx->h_window, before, want, eof, 2, out);
-        out->walks++;
-        if (eof && (st.pos >= ctx->n || (walked == 0 && st.pos == before)))
-            break;  // the walker consumed the tail
-        if (!eof && walked == 0 && st.pos == before && want < 189)
-            return ts_fail(ctx, PAPR_E_INTERNAL, "the packet walker made no progress at offset %llu", (unsigned long long)before);
+        if (nev > ctx->event_cap) {  // more sync errors than the list held: make room for all of them and scan again
+            if (round > 0)
+                return ts_fail(ctx, PAPR_E_INTERNAL, "the sync-error list overflowed twice (%u events)", nev);
+            (void)hipFree(ctx->d_events);
+            ctx->d_events = nullptr;
+            ctx->event_cap = 0;
+            const size_t want = (size_t)nev + (size_t)nev / 4 + 1024;
+            if (hipMalloc((void **)&ctx->d_events, want * sizeof(ts_event)) != hipSuccess) {
+                (void)hipGetLastError();
+                return ts_fail(ctx, PAPR_E_NOMEM, "cannot allocate the sync-error list (%zu events)", want);
+            }
+            ctx->event_cap = (uint32_t)std::min<size_t>(want, 0xFFFFFFFFu);
+            out->gpu_packets = 0;
+            out->walks = 0;
+            continue;
+        }
+        // ---- the sync errors: the events of the attempts the chain took, with stream-wide packet numbers, in order ----
+        if (nev) {
+            std::vector<ts_event> ev(nev);
+            TSCHK(ctx, hipMemcpyAsync(ev.data(), ctx->d_events, (size_t)nev * sizeof(ts_event), hipMemcpyDeviceToHost, ctx->stream));
+            TSCHK(ctx, hipMemcpyAsync(base.data(), ctx->d_span_base, nspans * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            TSCHK(ctx, hipMemcpyAsync(taken.data(), ctx->d_span_attempt, nspans * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            TSCHK(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->errors.reserve(nev);
+            for (const ts_event &e : ev) {
+                if (e.span >= nspans || taken[e.span] == 0 || taken[e.span] != e.attempt)
+                    continue;  // (an attempt the chain did not take)
+                ts_sync_error se;
+                se.skipped = e.skipped;
+                se.at_packet = base[e.span] + e.at_rel;
+                ctx->errors.push_back(se);
+            }
+            std::sort(ctx->errors.begin(), ctx->errors.end(),
+                      [](const ts_sync_error &a, const ts_sync_error &b) { return a.at_packet < b.at_packet; });
+        }
+        break;
     }
-    // fold the device-side tables into the result (absolute packet numbers: min / max are order-independent)
+    out->nsync_errors = ctx->errors.size();
+    for (size_t k = 0; k < ctx->errors.size() && k < TS_MAX_SYNC_ERRORS; k++)
+        out->sync_errors[k] = ctx->errors[k];
+    // the stream-wide tables (absolute packet numbers: min / max are order-independent)
     TSCHK(ctx, hipMemcpyAsync(ctx->h_tables, ctx->d_count, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long)),
                               hipMemcpyDeviceToHost, ctx->stream));
     TSCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -424,15 +460,41 @@ int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
     const unsigned long long *gf = (const unsigned long long *)(gc + TS_PIDS), *gl = gf + TS_PIDS;
     for (int pid = 0; pid < TS_PIDS; pid++) {
         if (gf[pid] == ~0ull)
-            continue;  // never seen by a launch
-        out->count[pid] += gc[pid];
-        if (out->first[pid] == 0 || gf[pid] < out->first[pid])
-            out->first[pid] = gf[pid];
-        if (gl[pid] > out->last[pid])
-            out->last[pid] = gl[pid];
+            continue;  // never seen
+        out->count[pid] = gc[pid];
+        out->first[pid] = gf[pid];
+        out->last[pid] = gl[pid];
     }
     out->kernel_ms = ms_total;
     out->merge_ms = ms_merge;
+    return PAPR_OK;
+}
+
+int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
+{
+    if (!ctx || !out)
+        return PAPR_E_ARG;
+    if (!ctx->loaded)
+        return ts_fail(ctx, PAPR_E_STATE, "ts_hip_scan called before a stream was loaded");
+    TSCHK(ctx, hipSetDevice(ctx->device));
+    try {
+        return ts_hip_scan_impl(ctx, hdmv, out);
+    } catch (const std::bad_alloc &) {
+        return ts_fail(ctx, PAPR_E_NOMEM, "out of host memory");
+    }
+}
+
+uint64_t ts_hip_sync_error_count(const ts_hip_ctx *ctx)
+{
+    return ctx ? (uint64_t)ctx->errors.size() : 0;
+}
+
+int ts_hip_get_sync_errors(const ts_hip_ctx *ctx, uint64_t first, uint64_t n, ts_sync_error *out)
+{
+    if (!ctx || (n && !out) || first > ctx->errors.size() || n > ctx->errors.size() - first)
+        return PAPR_E_ARG;
+    if (n)
+        memcpy(out, ctx->errors.data() + first, (size_t)n * sizeof(ts_sync_error));
     return PAPR_OK;
 }
 

@@ -35,6 +35,8 @@
 #include <time.h>
 
 #include "papr_hip.h"
+#include "papr_exchange.h"
+#include "papr_hip_measure.h" /* (PAPR_STATS=1: the ingest and sweep read-outs) */
 
 #define MAX_GPUS 64
 #define SHARD_ALIGN 8192ull /* samples: one reference fread chunk (papr.c:30), a multiple of the kernel tile */

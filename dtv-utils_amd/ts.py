@@ -16,8 +16,8 @@ PIDS = 0x2000
 MAX_SYNC_ERRORS = 4096
 
 ABI_SYMBOLS = ("ts_walk_init", "ts_walk_is_clean", "ts_walk", "ts_format_report", "ts_format_report_all", "ts_hip_open", "ts_hip_close",
-               "ts_hip_last_error", "ts_hip_upload", "ts_hip_load_file", "ts_hip_adopt", "ts_hip_generate",
-               "ts_hip_download", "ts_hip_scan")
+               "ts_hip_last_error", "ts_hip_upload", "ts_hip_load_file", "ts_hip_adopt", "ts_hip_generate", "ts_hip_generate_damaged",
+               "ts_hip_download", "ts_hip_scan", "ts_hip_sync_error_count", "ts_hip_get_sync_errors")
 
 
 class SyncError(C.Structure):
@@ -31,10 +31,19 @@ class ScanResult(C.Structure):
                 ("bytes", C.c_uint64), ("gpu_packets", C.c_uint64), ("launches", C.c_uint32), ("walks", C.c_uint32),
                 ("kernel_ms", C.c_double), ("merge_ms", C.c_double)]
 
+    _all_errors = None   # every sync error of the scan (TsHip.scan attaches them when the inline list is not all of them)
+
     def report(self) -> bytes:
-        """The reference's report lines (ts_format_report)."""
-        buf = C.create_string_buffer(1 << 20)
-        n = _lib().ts_format_report(C.byref(self), buf, len(buf))
+        """The reference's report lines (ts_format_report / ts_format_report_all): every sync error, then the PIDs."""
+        errs = self._all_errors
+        n = len(errs) if errs is not None else min(int(self.nsync_errors), MAX_SYNC_ERRORS)
+        if errs is None and int(self.nsync_errors) > MAX_SYNC_ERRORS:
+            raise PaprError(-7, "ts_format_report", "the result holds only the first %d of %d sync errors" % (MAX_SYNC_ERRORS, self.nsync_errors))
+        buf = C.create_string_buffer((1 << 20) + 64 * n)
+        if errs is not None:
+            n = _lib().ts_format_report_all(C.byref(self), errs, len(errs), buf, len(buf))
+        else:
+            n = _lib().ts_format_report(C.byref(self), buf, len(buf))
         return buf.raw[:n]
 
     def tables(self):
@@ -42,8 +51,9 @@ class ScanResult(C.Structure):
                 np.ctypeslib.as_array(self.last).copy())
 
     def sync_error_list(self):
-        return [(int(self.sync_errors[k].skipped), int(self.sync_errors[k].at_packet))
-                for k in range(min(int(self.nsync_errors), MAX_SYNC_ERRORS))]
+        src = self._all_errors if self._all_errors is not None else self.sync_errors
+        n = len(self._all_errors) if self._all_errors is not None else min(int(self.nsync_errors), MAX_SYNC_ERRORS)
+        return [(int(src[k].skipped), int(src[k].at_packet)) for k in range(n)]
 
 
 class WalkState(C.Structure):
@@ -67,6 +77,12 @@ def _lib():
         L.ts_walk.restype = u64
         L.ts_format_report.argtypes = [C.POINTER(ScanResult), C.c_char_p, C.c_size_t]
         L.ts_format_report.restype = C.c_size_t
+        L.ts_format_report_all.argtypes = [C.POINTER(ScanResult), vp, u64, C.c_char_p, C.c_size_t]
+        L.ts_format_report_all.restype = C.c_size_t
+        L.ts_hip_sync_error_count.argtypes = [vp]
+        L.ts_hip_sync_error_count.restype = u64
+        L.ts_hip_get_sync_errors.argtypes = [vp, u64, u64, vp]
+        L.ts_hip_get_sync_errors.restype = i32
         L.ts_hip_open.argtypes = [C.POINTER(vp), i32]
         L.ts_hip_close.argtypes = [vp]
         L.ts_hip_close.restype = None
@@ -76,10 +92,12 @@ def _lib():
         L.ts_hip_load_file.argtypes = [vp, C.c_char_p]
         L.ts_hip_adopt.argtypes = [vp, vp, u64]
         L.ts_hip_generate.argtypes = [vp, u64, u64, i32]
+        L.ts_hip_generate_damaged.argtypes = [vp, u64, u64, u64]
+        L.ts_hip_generate_damaged.restype = i32
         L.ts_hip_download.argtypes = [vp, vp, u64, u64]
         L.ts_hip_scan.argtypes = [vp, i32, C.POINTER(ScanResult)]
         for name in ("ts_hip_open", "ts_hip_upload", "ts_hip_load_file", "ts_hip_adopt", "ts_hip_generate",
-                     "ts_hip_download", "ts_hip_scan"):
+                     "ts_hip_download", "ts_hip_scan", "ts_hip_sync_error_count", "ts_hip_get_sync_errors"):
             getattr(L, name).restype = i32
         _bound = True
     return L
@@ -157,6 +175,11 @@ class TsHip:
     def generate(self, npackets: int, seed: int = 0x7500001, hdmv: bool = False):
         self._chk(self._L.ts_hip_generate(self._ctx, seed, npackets, int(hdmv)), "ts_hip_generate")
 
+    def generate_damaged(self, npackets: int, period: int, seed: int = 0x7500001) -> int:
+        """npackets of the synthetic stream with one damaged spot every `period` packets; returns the stream's size."""
+        self._chk(self._L.ts_hip_generate_damaged(self._ctx, seed, npackets, period), "ts_hip_generate_damaged")
+        return npackets * 188 - npackets // (4 * period)
+
     def download(self, first: int, nbytes: int) -> bytes:
         out = np.empty(nbytes, dtype=np.uint8)
         self._chk(self._L.ts_hip_download(self._ctx, out.ctypes.data if nbytes else None, first, nbytes), "ts_hip_download")
@@ -165,4 +188,10 @@ class TsHip:
     def scan(self, hdmv: bool = False) -> ScanResult:
         res = ScanResult()
         self._chk(self._L.ts_hip_scan(self._ctx, int(hdmv), C.byref(res)), "ts_hip_scan")
+        n = int(self._L.ts_hip_sync_error_count(self._ctx))
+        assert n == int(res.nsync_errors)
+        if n > MAX_SYNC_ERRORS:   # the result holds the first 4096 inline; the reference prints every one
+            errs = (SyncError * n)()
+            self._chk(self._L.ts_hip_get_sync_errors(self._ctx, 0, n, errs), "ts_hip_get_sync_errors")
+            res._all_errors = errs
         return res

@@ -1,0 +1,54 @@
+/*
+ * papr_exchange.h — the exchange between the shards of one file (one process, or one thread, per GPU): part of
+ * libpaprhip.so's C ABI, used together with include/papr_hip.h (papr_hip_analyze takes a papr_exchange).
+ */
+#ifndef PAPR_EXCHANGE_H
+#define PAPR_EXCHANGE_H
+
+#include "papr_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- the exchange between shards: one process per GPU ---------------------------------
+ * The sample axis shards with no bulk exchange; what crosses GPUs is three tiny, latency-bound messages:
+ *   papr_exchange_stats     after pass 1 / the sweep (also for the mean estimate before it): all-gather of one
+ *                           96-byte papr_stats per rank, folded in rank (= file) order with papr_stats_merge on
+ *                           every rank — first-index extrema are not a reduction op RCCL has, and a fixed order
+ *                           keeps the double sum identical everywhere.  Also returns the sum of the ranks in
+ *                           front of this one (what the exact-sum path and its hint want).
+ *   papr_exchange_counts    after pass 2: all-reduce (sum) of the per-level counters, as 64-bit integers
+ *   papr_exchange_exact_sum exact-sum mode: all-gather of the shards' sum programs (<= ~1 MB), chained in rank
+ *                           order with papr_exact_chain -> the reference's sequential sum on every rank
+ * Transports: RCCL over xGMI (papr_exchange_open_rccl: ncclAllGather / ncclAllReduce on the context's stream,
+ * device staging buffers, one stream synchronisation per exchange; the 128-byte ncclUniqueId from
+ * papr_exchange_unique_id on rank 0 is handed to the other ranks by whatever launched them), or any pair of
+ * collectives the caller supplies (papr_exchange_open_ops: the tests run the same code over gloo on CPUs). */
+typedef struct papr_exchange_ops {
+    void *user;
+    int (*allgather)(void *user, const void *send, void *recv, size_t bytes_per_rank); /* recv: world x bytes_per_rank */
+    int (*allreduce_sum_u64)(void *user, uint64_t *buf, size_t count);                 /* in place */
+} papr_exchange_ops;
+#define PAPR_EXCHANGE_ID_BYTES 128
+int papr_exchange_unique_id(void *id /* PAPR_EXCHANGE_ID_BYTES */);
+int papr_exchange_open_rccl(papr_exchange **x, papr_hip_ctx *ctx, const void *id, int rank, int world);
+int papr_exchange_open_ops(papr_exchange **x, const papr_exchange_ops *ops, int rank, int world);
+void papr_exchange_close(papr_exchange *x);
+const char *papr_exchange_last_error(const papr_exchange *x); /* x may be NULL: last open error */
+int papr_exchange_stats(papr_exchange *x, const papr_stats *local, papr_stats *total, double *sum_before,
+                        papr_stats *all /* world records in rank order, or NULL */);
+int papr_exchange_counts(papr_exchange *x, uint64_t *counts, int n);
+int papr_exchange_exact_sum(papr_exchange *x, const void *program, size_t bytes, double *sum);
+
+/* An in-process transport for papr_exchange: n handles for n threads of ONE process that each drive one GPU (what
+ * bin/papr does): the same exchange calls, met at a barrier instead of on a wire. xs receives n handles. */
+int papr_exchange_open_local(papr_exchange **xs, int n);
+/* a thread that cannot go on (its GPU failed) cancels the in-process exchange: the other threads' pending and future
+ * exchange calls return PAPR_E_STATE instead of waiting for it (no-op for the other transports) */
+void papr_exchange_abort(papr_exchange *x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAPR_EXCHANGE_H */

@@ -37,8 +37,6 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#include "papr_synth.h"
-
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -80,73 +78,14 @@ typedef struct papr_stats {
 #define PAPR_FLAG_NAN 1u      /* some power value was NaN */
 #define PAPR_FLAG_ODD_TAIL 2u /* the shard ends with the reference's phantom sample */
 
-/* Kernel timing accumulated since the last reset (HIP events on the context's
- * stream, kernel launches only). */
-typedef struct papr_hip_timing {
-    double stats_ms;  uint64_t stats_launches;  uint64_t stats_bytes;
-    double ccdf_ms;   uint64_t ccdf_launches;   uint64_t ccdf_bytes;
-    double exact_ms;  uint64_t exact_launches;  uint64_t exact_bytes; /* exact-sum kernels (classify + segments + groups) */
-    double sweep_ms;  uint64_t sweep_launches;  uint64_t sweep_bytes; /* one-sweep kernel (pass 1 + banded pass 2) */
-    double aux_ms;    uint64_t aux_launches;    uint64_t aux_bytes;   /* mean-estimate and stash-recount kernels */
-} papr_hip_timing;
-
-/* Where the wall time of the last papr_hip_load_file went (seconds). */
-typedef struct papr_hip_ingest_timing {
-    double total_s;       /* whole call */
-    double setup_s;       /* staging buffers, shard allocation, reader threads */
-    double read_s;        /* main thread blocked on the file readers */
-    double buffer_wait_s; /* main thread blocked on a pinned buffer still being copied */
-    double issue_s;       /* hipMemcpyAsync / kernel launch calls */
-    double drain_s;       /* final wait for copies + pass-1 kernels + finalize */
-    uint64_t bytes, chunks;
-    int reader_threads;
-    int resident;         /* 1 = shard kept in HBM, 0 = will be re-streamed for pass 2 */
-    int o_direct;         /* 1 = the file was read with O_DIRECT (not in the page cache, or PAPR_O_DIRECT=1) */
-    int numa_bound;       /* 1 = reader threads and pinned staging buffers sit on the GPU's NUMA node (PAPR_NUMA=0 disables) */
-    int io_uring;         /* 1 = the O_DIRECT reads went through one io_uring instead of the reader threads (PAPR_IO_URING=0 disables) */
-    int file_passes;      /* whole passes over the shard's file range so far: 1 after the ingest, more when later calls had to re-stream it */
-} papr_hip_ingest_timing;
-
-/* Launch geometry knobs.  0 always means "built-in default" (chosen from the
- * 10 GiB sweeps in DESIGN.md section 6); variant and map fields therefore hold
- * id + 1.  Also settable with the PAPR_HIP_TUNE environment variable, e.g.
- * "sblocks=512,svariant=1,smap=0,cblocks=512,cvariant=13,cmap=0,nt=1" (= the defaults on a 256-CU device)
- * ("blocks=" / "variant=" / "map=" set both passes; "wblocks=" / "wvariant=" / "wmap=" / "band=" / "ratio="
- * the one-sweep kernel). */
-typedef struct papr_hip_tuning {
-    int stats_blocks;   /* pass 1: workgroups per launch */
-    int stats_variant;  /* pass 1: kernel geometry variant id + 1 (block x unroll x prefetch form, papr_kernels.hip) */
-    int stats_map;      /* pass 1: tile mapping id + 1 (ids: 0 grid-stride, 1 span per workgroup, 2 span per XCD) */
-    int ccdf_blocks;    /* pass 2: workgroups per launch */
-    int ccdf_variant;   /* pass 2: kernel geometry variant id + 1 */
-    int ccdf_map;       /* pass 2: tile mapping id + 1 */
-    int nontemporal;    /* 0/1 = default (nontemporal loads), 2 = plain loads */
-    int hist_copies;    /* LDS histogram copies per workgroup (1..waves) */
-    int flags;          /* bit 0: force the binary-search form of pass 2 (tests) */
-    int sweep_blocks;   /* one-sweep kernel: workgroups per launch */
-    int sweep_variant;  /* one-sweep kernel: geometry variant id + 1 */
-    int sweep_map;      /* one-sweep kernel: tile mapping id + 1 */
-    int sweep_band_log2;/* half-width of a threshold band in float bit patterns, log2 (default 14; 8..20) */
-    int estimate_ratio; /* papr_hip_estimate reads one 2048-sample tile out of this many (default 64) */
-    int reserved;
-} papr_hip_tuning;
 
 typedef struct papr_hip_ctx papr_hip_ctx;
 
 /* ---- context ------------------------------------------------------------ */
-int papr_hip_abi_version(void);
 int papr_hip_device_count(void);                       /* >= 0, or a PAPR_E_* code */
 int papr_hip_open(papr_hip_ctx **ctx, int device);
 void papr_hip_close(papr_hip_ctx *ctx);
 const char *papr_hip_last_error(const papr_hip_ctx *ctx); /* ctx may be NULL: last open error */
-int papr_hip_device_name(const papr_hip_ctx *ctx, char *buf, int buflen);
-int papr_hip_set_tuning(papr_hip_ctx *ctx, const papr_hip_tuning *t);
-/* Kernel timing (papr_hip_get_timing): 0 off, 1 every timed kernel, 2 only the kernels that read the shard (pass 1,
- * pass 2, the sweep, the exact-sum pass) — a timed kernel carries a completion signal of its own, which costs the stream
- * ~5 us on either side of it (profiles/r02_step_timeline.txt), so a benchmark times the small estimate / recount
- * kernels in separate steps.  Also resets the counters. */
-int papr_hip_set_timing(papr_hip_ctx *ctx, int enabled);
-int papr_hip_get_timing(papr_hip_ctx *ctx, papr_hip_timing *out);
 
 /* ---- shard residency (replaces the fread ingest, papr.c:100-101,143-144) -- */
 
@@ -164,23 +103,7 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
  * budget: 90 % of the free memory at open, or PAPR_HBM_BUDGET_MB), 0 if it would be re-streamed from the file
  * for every further pass. */
 int papr_hip_shard_fits(const papr_hip_ctx *ctx, uint64_t nsamples);
-int papr_hip_get_ingest_timing(const papr_hip_ctx *ctx, papr_hip_ingest_timing *out);
 
-/* Copy nsamples IQ pairs from host memory into the shard. */
-int papr_hip_upload(papr_hip_ctx *ctx, const float *iq, uint64_t nsamples, uint64_t base_index);
-
-/* Use caller-owned device memory (16-byte aligned, on this context's GPU) as
- * the shard, without copying.  The memory must stay valid until the next
- * load/upload/adopt/close. */
-int papr_hip_adopt(papr_hip_ctx *ctx, void *device_iq, uint64_t nsamples, uint64_t base_index);
-
-/* Fill the shard with synthetic samples [first_index, first_index+nsamples)
- * of the stream defined by include/papr_synth.h.  If a buffer of at least that
- * size was adopted it is filled in place, otherwise the context allocates. */
-int papr_hip_generate(papr_hip_ctx *ctx, const papr_synth_spec *spec, uint64_t first_index, uint64_t nsamples);
-
-/* Copy shard samples [first, first+nsamples) (shard-relative) back to the host (tests). */
-int papr_hip_download(papr_hip_ctx *ctx, float *iq, uint64_t first, uint64_t nsamples);
 
 /* ---- pass 1 (papr.c:102-128) -------------------------------------------- */
 int papr_hip_stats(papr_hip_ctx *ctx, papr_stats *out);
@@ -247,7 +170,8 @@ int papr_exact_chain(const void *const *programs, const size_t *bytes, int nprog
  *                                     the shard is read again as before.  Same counts either way.
  *
  * papr_hip_stats_sweep falls back to plain papr_hip_stats by itself (exact-sum mode, shards that are
- * not resident, guess tables without a band form); papr_hip_get_sweep_info tells what happened. */
+ * not resident, guess tables without a band form); papr_hip_get_sweep_info (papr_hip_measure.h) tells what
+ * happened. */
 enum {
     PAPR_SWEEP_OK = 0,
     PAPR_SWEEP_NONE = 1,        /* no sweep was made for the current shard */
@@ -256,22 +180,6 @@ enum {
     PAPR_SWEEP_OUT_OF_BAND = 4, /* a true threshold fell outside every band of the guess */
     PAPR_SWEEP_STASH_FULL = 5   /* more in-band samples than the stash holds (1/8 of the shard) */
 };
-typedef struct papr_hip_sweep_info {
-    uint64_t stash_samples;  /* in-band samples the last sweep produced */
-    uint64_t stash_capacity;
-    uint64_t estimate_samples; /* samples the last papr_hip_estimate read */
-    int swept;               /* last papr_hip_stats_sweep: 1 = banded + stashed, 0 = plain pass 1 */
-    int resolved;            /* last papr_hip_ccdf: 1 = answered from the sweep, 0 = read the shard again */
-    int reason;              /* PAPR_SWEEP_*: why not */
-    int band_log2;
-    uint32_t exact_redo_tiles; /* exact-sum mode, last papr_hip_ccdf_exact / _exact_program after a sweep: 2048-sample tiles whose
-                                * speculated running-sum binade was wrong and whose rounding functions were rebuilt */
-    uint32_t gave_up;        /* waves that gave the sweep up for their workgroup because most of what it folded was in band
-                              * (constant-envelope captures); any > 0 shows as PAPR_SWEEP_STASH_FULL */
-    int kernel_variant;      /* id of the kernel form the last sweep was launched as (papr_sweep.hip's tables); measurements
-                              * quote it so that numbers taken with another form are recognised as stale */
-    int reserved;
-} papr_hip_sweep_info;
 int papr_hip_estimate(papr_hip_ctx *ctx, papr_stats *est);
 /* Exact-sum mode (papr_hip_set_exact(ctx, 1)) is served by the same single read: papr_hip_estimate then also keeps
  * one sampled sum per 1 MiB group on the device, papr_hip_stats_sweep speculates from them in which binade the
@@ -312,68 +220,9 @@ int papr_hip_stats_sweep(papr_hip_ctx *ctx, const float *guess_levels, int nleve
  * tells which.  Without a matching estimate the ingest in exact-sum mode is the plain one (pass 1 only). */
 int papr_hip_load_file_sweep(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples,
                              const float *guess_levels, int nlevels);
-int papr_hip_get_sweep_info(const papr_hip_ctx *ctx, papr_hip_sweep_info *out);
 
-/* The GPU-free halves of the one-sweep bookkeeping — what the runtime itself calls, exported so that the
- * speculation's logic can be checked without a GPU (tests/test_sweep_host.py):
- *   papr_level_key      smallest bit pattern of a non-negative float that is > level (the integer compare
- *                       `bits(v) >= key` is the reference's float compare `v > level`); 0 for negative levels,
- *                       UINT32_MAX when nothing can exceed the level (NaN, +Inf)
- *   papr_sweep_bands    guessed levels -> unique ascending keys and the band edges key -+ 2^band_log2
- *                       (edges[2j], edges[2j+1]); returns the number of keys, or 0 when the guess has no band
- *                       form (no usable level, denormal/huge thresholds, bands that touch)
- *   papr_sweep_resolve  counts_above[l] for the true levels from what a sweep left behind: above_band[j] =
- *                       samples at or above band j's upper edge, stash_above[l] = stash powers > levels[l].
- *                       Returns 1, or 0 if some true level lies in no band (then nothing is written). */
-uint32_t papr_level_key(float level);
-int papr_sweep_bands(const float *guess_levels, int nlevels, int band_log2, uint32_t *keys, uint32_t *edges);
-int papr_sweep_resolve(const uint32_t *guess_keys, int nguess, int band_log2, const uint64_t *above_band,
-                       const float *levels, int nlevels, const uint64_t *stash_above, uint64_t *counts_above);
 
-/* ---- the exchange between shards: one process per GPU ---------------------------------
- * The sample axis shards with no bulk exchange; what crosses GPUs is three tiny, latency-bound messages:
- *   papr_exchange_stats     after pass 1 / the sweep (also for the mean estimate before it): all-gather of one
- *                           96-byte papr_stats per rank, folded in rank (= file) order with papr_stats_merge on
- *                           every rank — first-index extrema are not a reduction op RCCL has, and a fixed order
- *                           keeps the double sum identical everywhere.  Also returns the sum of the ranks in
- *                           front of this one (what the exact-sum path and its hint want).
- *   papr_exchange_counts    after pass 2: all-reduce (sum) of the per-level counters, as 64-bit integers
- *   papr_exchange_exact_sum exact-sum mode: all-gather of the shards' sum programs (<= ~1 MB), chained in rank
- *                           order with papr_exact_chain -> the reference's sequential sum on every rank
- * Transports: RCCL over xGMI (papr_exchange_open_rccl: ncclAllGather / ncclAllReduce on the context's stream,
- * device staging buffers, one stream synchronisation per exchange; the 128-byte ncclUniqueId from
- * papr_exchange_unique_id on rank 0 is handed to the other ranks by whatever launched them), or any pair of
- * collectives the caller supplies (papr_exchange_open_ops: the tests run the same code over gloo on CPUs). */
-typedef struct papr_exchange papr_exchange;
-typedef struct papr_exchange_ops {
-    void *user;
-    int (*allgather)(void *user, const void *send, void *recv, size_t bytes_per_rank); /* recv: world x bytes_per_rank */
-    int (*allreduce_sum_u64)(void *user, uint64_t *buf, size_t count);                 /* in place */
-} papr_exchange_ops;
-typedef struct papr_exchange_timing { /* host wall time spent inside the exchanges since open / the last reset */
-    uint64_t stats_calls, counts_calls, exact_calls;
-    double stats_us, counts_us, exact_us;
-    uint64_t in_stream_calls; /* collectives queued on the context's stream between kernels (RCCL transport, papr_hip_analyze's
-                               * single-wait step): no host staging and no wait of their own, so no time to report */
-} papr_exchange_timing;
-#define PAPR_EXCHANGE_ID_BYTES 128
-int papr_exchange_unique_id(void *id /* PAPR_EXCHANGE_ID_BYTES */);
-int papr_exchange_open_rccl(papr_exchange **x, papr_hip_ctx *ctx, const void *id, int rank, int world);
-int papr_exchange_open_ops(papr_exchange **x, const papr_exchange_ops *ops, int rank, int world);
-void papr_exchange_close(papr_exchange *x);
-const char *papr_exchange_last_error(const papr_exchange *x); /* x may be NULL: last open error */
-int papr_exchange_stats(papr_exchange *x, const papr_stats *local, papr_stats *total, double *sum_before,
-                        papr_stats *all /* world records in rank order, or NULL */);
-int papr_exchange_counts(papr_exchange *x, uint64_t *counts, int n);
-int papr_exchange_exact_sum(papr_exchange *x, const void *program, size_t bytes, double *sum);
-int papr_exchange_get_timing(papr_exchange *x, papr_exchange_timing *out, int reset);
-
-/* An in-process transport for papr_exchange: n handles for n threads of ONE process that each drive one GPU (what
- * bin/papr does): the same exchange calls, met at a barrier instead of on a wire. xs receives n handles. */
-int papr_exchange_open_local(papr_exchange **xs, int n);
-/* a thread that cannot go on (its GPU failed) cancels the in-process exchange: the other threads' pending and future
- * exchange calls return PAPR_E_STATE instead of waiting for it (no-op for the other transports) */
-void papr_exchange_abort(papr_exchange *x);
+typedef struct papr_exchange papr_exchange; /* include/papr_exchange.h: the exchange between the shards of one file */
 
 /* ---- the whole result in one call --------------------------------------------------------------------
  * papr_hip_analyze runs, for the shard loaded in `ctx` and — through `x` — together with the other shards'

@@ -21,13 +21,16 @@
  * Streams that carry a complete ATSC Master Guide Table on PID 0x1ffb are outside the domain (the reference starts
  * parsing further PIDs then).
  *
- * How: packets at a fixed stride from a known sync position are independent, so the GPU takes every stretch of
- * "regular" packets (sync byte in place, whole, legal adaptation field, not on the read-boundary quirk) in one launch
- * — each lane one packet header; per-workgroup LDS tables of count / first / last, committed only for the workgroups
- * in front of the first irregular packet — and a closed-form host walker (ts_walk, plain C, exported and tested
- * without a GPU) carries the scan across the irregular ones: sync loss, false sync bytes, malformed adaptation
- * fields, the truncated tail, the read-boundary quirk.  Speculation decides how many launches are made, never a
- * number in the result.
+ * How: packets at a fixed stride from a known sync position are independent, so the stream is cut into one byte range
+ * per CU and every range is scanned in parallel: stretches of "regular" packets (sync byte in place, whole, legal
+ * adaptation field, not on the read-boundary quirk) one lane per packet header into per-workgroup LDS tables of count /
+ * first / last; everything else — sync loss, false sync bytes, malformed adaptation fields, the truncated tail, the
+ * read-boundary quirk — by the closed-form packet walker, ON THE DEVICE (ts_walk_core.h: the same step this library
+ * exports as ts_walk, GPU-free, for the tests).  A range cannot know where the chain of packets enters it, so it
+ * speculates (eight sync bytes in a row at the stride); a merge kernel checks that every range started exactly where
+ * the one in front of it ended and folds the tables with stream-wide packet numbers; a range that guessed wrong is
+ * scanned once more from the true state.  Speculation decides how many launches are made, never a number in the
+ * result; damage costs its own bytes, once.
  *
  * Conventions as in papr_hip.h: plain C types, 0 or a negative PAPR_E_* code, no CPU fallback.
  */
@@ -59,9 +62,9 @@ typedef struct ts_scan_result {
     ts_sync_error sync_errors[TS_MAX_SYNC_ERRORS];
     /* how the scan went (not part of the reference's output) */
     uint64_t bytes;            /* stream length */
-    uint64_t gpu_packets;      /* packets counted by the GPU launches (the rest: the host walker) */
-    uint32_t launches;         /* scan-kernel launches */
-    uint32_t walks;            /* hand-overs to the host walker */
+    uint64_t gpu_packets;      /* packets counted one lane per packet (the rest: the device-side walker) */
+    uint32_t launches;         /* scan-kernel launches (1 + the ranges that had to be scanned again) */
+    uint32_t walks;            /* times the device-side walker took over from the one-lane-per-packet blocks */
     double kernel_ms;          /* sum of the scan kernels' durations (HIP events) */
     double merge_ms;           /* sum of the merge kernels' durations */
 } ts_scan_result;
@@ -103,8 +106,16 @@ int ts_hip_load_file(ts_hip_ctx *ctx, const char *path);
 int ts_hip_adopt(ts_hip_ctx *ctx, void *device_bytes, uint64_t nbytes);
 /* fill the stream with `npackets` synthetic packets of include/ts_synth.h (hdmv != 0: 192-byte units) */
 int ts_hip_generate(ts_hip_ctx *ctx, uint64_t seed, uint64_t npackets, int hdmv);
+/* the same stream with one damaged spot every `period` packets (include/ts_synth.h: ts_synth_damaged_byte — inserted
+ * and missing bytes, an overwritten sync byte; npackets a multiple of 4 * period): the scan's unfriendly case */
+int ts_hip_generate_damaged(ts_hip_ctx *ctx, uint64_t seed, uint64_t npackets, uint64_t period);
 int ts_hip_download(ts_hip_ctx *ctx, void *bytes, uint64_t first, uint64_t nbytes);
 int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out);
+/* EVERY sync error of the last ts_hip_scan, in the order the reference prints them (ts_scan_result holds the first
+ * TS_MAX_SYNC_ERRORS inline; a stream that locks one byte off a 4-byte grid yields one `skipped 1 bytes` line per 4096
+ * packets, i.e. more than that from ~3 GB on): their number, and a copy of entries [first, first + n) */
+uint64_t ts_hip_sync_error_count(const ts_hip_ctx *ctx);
+int ts_hip_get_sync_errors(const ts_hip_ctx *ctx, uint64_t first, uint64_t n, ts_sync_error *out);
 
 #ifdef __cplusplus
 }

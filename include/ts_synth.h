@@ -75,4 +75,44 @@ TS_SYNTH_FN unsigned char ts_synth_byte(uint64_t seed, uint64_t k, uint32_t i, i
     return (unsigned char)(ts_synth_mix(h + (i >> 3)) >> (8 * (i & 7u)));
 }
 
+/* ---- the same stream with damage at a fixed period (the scan's unfriendly bench case) --------------------------
+ * Every `period` packets something is wrong with the stream, in a cycle of four kinds: three garbage bytes inserted in
+ * front of a packet (the stream leaves its grid), a sync byte overwritten (0x46), the first five bytes of a packet
+ * missing (off the grid again), one byte inserted.  Four periods are 4 * period * 188 - 1 bytes, so byte `pos` of the
+ * damaged stream is index-addressable like the clean one.  npackets must be a multiple of 4 * period. */
+TS_SYNTH_FN uint64_t ts_synth_damaged_size(uint64_t npackets, uint64_t period)
+{
+    return npackets * 188u - npackets / (4u * period);
+}
+
+TS_SYNTH_FN unsigned char ts_synth_damaged_byte(uint64_t seed, uint64_t period, uint64_t pos)
+{
+    const uint64_t plain = period * 188u, block = 4u * plain - 1u;
+    const uint64_t b = pos / block;
+    uint64_t off = pos % block;
+    /* group lengths within a block: +3 (insert), +0 (sync overwritten), -5 (bytes missing), +1 (insert) */
+    const uint64_t len[4] = {plain + 3u, plain, plain - 5u, plain + 1u};
+    uint32_t g = 0;
+    while (off >= len[g]) {
+        off -= len[g];
+        g++;
+    }
+    const uint64_t k0 = (4u * b + g) * period; /* the group's first packet */
+    if (g == 0 || g == 3) {
+        const uint64_t ins = g == 0 ? 3u : 1u;
+        if (off < ins) /* garbage; never a sync byte */
+            return (unsigned char)((ts_synth_mix(seed ^ (pos * 0xD1B54A32D192ED03ull)) & 0xffu) == 0x47u
+                                       ? 0x48u
+                                       : (ts_synth_mix(seed ^ (pos * 0xD1B54A32D192ED03ull)) & 0xffu));
+        off -= ins;
+    } else if (g == 2) {
+        off += 5u; /* packet k0 starts at its sixth byte */
+    }
+    const uint64_t k = k0 + off / 188u;
+    const uint32_t i = (uint32_t)(off % 188u);
+    if (g == 1 && k == k0 && i == 0)
+        return 0x46;
+    return ts_synth_byte(seed, k, i, 0);
+}
+
 #endif

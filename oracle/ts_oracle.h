@@ -6,7 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
-#define TS_ORACLE_MAX_SYNC_ERRORS 4096
+#define TS_ORACLE_MAX_SYNC_ERRORS (1u << 20) /* room for every line of any stream the tests build (the reference prints them all) */
 
 typedef struct ts_oracle_sync_error {
     uint64_t skipped;   /* bytes passed over before the next sync byte (printed with %d) */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libts_oracle.so")
 CLI_PATH = os.path.join(_HERE, "ts_oracle")
 REF_CLI = os.path.join(_HERE, "_ref", "xport")   # the real reference, when it was built
-MAX_SYNC_ERRORS = 4096
+MAX_SYNC_ERRORS = 1 << 20
 REF_PROGRAM = "70000"   # a program number no 16-bit PAT entry can carry: the reference then demultiplexes nothing
 
 

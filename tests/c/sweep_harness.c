@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "papr_hip.h"
+#include "papr_hip_measure.h"
 
 static uint64_t state;
 static uint32_t rnd(void)

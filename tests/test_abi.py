@@ -19,10 +19,26 @@ except Exception:  # pragma: no cover
     HAVE_GPU = False
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "papr_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(papr_[a-z_]+)\s*\(", text)))
+HEADERS = ("papr_hip.h", "papr_exchange.h", "papr_hip_measure.h")   # the papr path; the exchange between shards; measurement
+
+
+def declared_functions(headers=HEADERS):
+    out = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(papr_[a-z_]+)\s*\(", text))
+    return sorted(out)
+
+
+def test_the_product_header_is_the_papr_path_only():
+    """include/papr_hip.h is what a caller of the papr path binds: no tuning, timing or probe entry
+    points — those live in papr_hip_measure.h."""
+    product = declared_functions(("papr_hip.h",))
+    assert len(product) <= 25, product
+    for name in ("papr_hip_set_tuning", "papr_hip_set_timing", "papr_hip_get_timing", "papr_hip_generate", "papr_hip_adopt",
+                 "papr_sweep_bands", "papr_hip_get_sweep_info"):
+        assert name not in product and name in declared_functions(("papr_hip_measure.h",))
 
 
 def test_header_and_binding_list_agree(pkg):
@@ -41,9 +57,10 @@ def test_library_exports_every_declared_symbol(pkg):
 
 
 def test_no_torch_or_hip_types_in_the_abi():
-    text = open(os.path.join(ROOT, "include", "papr_hip.h")).read()
-    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    assert "hip/" not in code and "torch" not in code and "hipStream" not in code
+    for h in HEADERS + ("ts_hip.h",):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        assert "hip/" not in code and "torch" not in code and "hipStream" not in code, h
 
 
 def test_library_does_not_link_the_oracle(pkg):

@@ -86,7 +86,7 @@ def test_torchrun_single_rank_uses_rccl(extra):
             assert 0 <= d["config"]["one_sweep"]["exact_redo_tiles_per_step"] <= d["config"]["samples_per_gpu"] / 2048 / 20
         assert d["config"]["one_sweep"]["steps_resolved_from_the_sweep"] == 3
         assert d["config"]["reads_of_the_shard_per_step"] == 1
-        assert d["roofline"]["kernel"] == ("papr_sweep2_kernel<EXACT>" if "--exact" in extra else "papr_sweep_kernel")
+        assert d["roofline"]["kernel"] == ("papr_sweep3_kernel" if "--exact" in extra else "papr_sweep_kernel")
         assert 0 < d["config"]["one_sweep"]["stash_samples"] < d["config"]["samples_per_gpu"] // 8
 
 

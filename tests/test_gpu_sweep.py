@@ -68,7 +68,9 @@ def test_sweep_equals_oracle_sizes(pkg, orc, gpu, n, graph):
 
 
 @pytest.mark.parametrize("tune", [dict(sweep_variant=v, sweep_blocks=b, sweep_map=m)
-                                  for v, b, m in [(40, 0, 0), (40, 7, 0), (40, 1, 0), (40, 700, 2), (40, 300, 1),
+                                  for v, b, m in [(111, 0, 0), (111, 7, 0), (111, 1, 0), (111, 700, 2), (111, 300, 1),
+                                                  # (the laboratory's forms, `make MEASURE=1` + PAPR_LIB_PATH: skipped otherwise)
+                                                  (40, 0, 0), (40, 7, 0), (40, 1, 0), (40, 700, 2), (40, 300, 1),
                                                   (1, 96, 1), (1, 1000, 2), (4, 7, 0), (4, 1, 0), (4, 0, 2), (4, 0, 0), (8, 0, 0),
                                                   (8, 64, 2), (13, 0, 0), (13, 1536, 2), (13, 300, 1), (14, 0, 0),
                                                   (14, 8, 2), (20, 0, 0), (20, 96, 1), (24, 0, 0), (24, 7, 2),
@@ -77,6 +79,8 @@ def test_sweep_equals_oracle_sizes(pkg, orc, gpu, n, graph):
                          [dict(estimate_ratio=r) for r in (1, 7, 1000)] + [dict(hist_copies=1), dict(hist_copies=8)],
                          ids=str)
 def test_sweep_geometries_agree(pkg, orc, gpu, tune):
+    if "sweep_variant" in tune and not pkg.sweep_variant_built(tune["sweep_variant"]):
+        pytest.skip("a laboratory kernel form: built by `make MEASURE=1` only")
     n = 3 * 1048576 + 4099
     gpu.generate(pkg.SynthSpec.spike(n, seed=78), 0, n)
     iq = gpu.download(0, n)
@@ -87,7 +91,7 @@ def test_sweep_geometries_agree(pkg, orc, gpu, tune):
             st, table, counts, info = one_sweep(pkg, gpu, graph)
             check_stats(st, ref)
             assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
-            if tune.get("sweep_band_log2", 14) >= 14 or 20 <= tune.get("sweep_variant", 40) < 40 or tune.get("sweep_variant", 40) == 41:   # (narrower bands need a finer one-edge LUT than fits: plain pass 1)
+            if tune.get("sweep_band_log2", 14) >= 14 or 20 <= tune.get("sweep_variant", 111) < 40 or tune.get("sweep_variant", 111) == 41:   # (narrower bands need a finer one-edge LUT than fits: plain pass 1)
                 assert info.swept == 1 and info.resolved == 1, info.as_dict()
     finally:
         gpu.set_tuning()
@@ -104,9 +108,11 @@ def test_sweep_first_index_wins(pkg, orc, gpu):
         iq[2 * s] = 9.5
         iq[2 * s + 1] = -9.5
     gpu.upload(iq)
-    for tune in (dict(), dict(sweep_variant=40, sweep_blocks=3), dict(sweep_variant=4), dict(sweep_variant=1, sweep_blocks=3),
-                 dict(sweep_variant=8, sweep_map=2), dict(sweep_variant=20),
+    for tune in (dict(), dict(sweep_variant=111, sweep_blocks=3), dict(sweep_variant=40, sweep_blocks=3), dict(sweep_variant=4),
+                 dict(sweep_variant=1, sweep_blocks=3), dict(sweep_variant=8, sweep_map=2), dict(sweep_variant=20),
                  dict(sweep_variant=32), dict(sweep_variant=41, sweep_blocks=5)):
+        if "sweep_variant" in tune and not pkg.sweep_variant_built(tune["sweep_variant"]):
+            continue   # (a laboratory form: `make MEASURE=1` builds)
         gpu.set_tuning(**tune)
         st, table, counts, info = one_sweep(pkg, gpu, False)
         gpu.set_tuning()
@@ -584,9 +590,12 @@ def test_analyze_constant_envelope_gives_up_the_sweep(pkg, orc, exact):
                 assert np.array_equal(counts.astype(np.int64), orc.count_mem(iq, table))
 
 
-@pytest.mark.parametrize("variant", [48, 56])
+@pytest.mark.parametrize("variant", [131, 48, 56])
 def test_exact_sweep_variants_agree_with_the_reference(pkg, orc, variant):
-    """the exact-sum forms of the sweep kernel (returning-atomic and ballot ring stash), whole result against the oracle"""
+    """the exact-sum forms of the sweep kernel (the product's papr_sweep3_kernel; from the laboratory its predecessor with
+    the returning-atomic and the ballot ring stash), whole result against the oracle"""
+    if not pkg.sweep_variant_built(variant):
+        pytest.skip("a laboratory kernel form: built by `make MEASURE=1` only")
     n = 7 * 1048576 + 2049
     with pkg.PaprHip(0) as g:
         g.set_exact(True)
