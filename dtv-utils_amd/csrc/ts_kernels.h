@@ -64,6 +64,8 @@ struct ts_merge_out {
     ts_walk_state cur;          // the walker state the chain arrived with in front of span `valid_upto`
     uint64_t block_packets;
     uint64_t walks;
+    uint32_t events;            // sync-error events the scan's launches have wanted so far (> event_cap: the list overflowed)
+    uint32_t pad2;
 };
 
 void ts_kernels_prepare_device(void);

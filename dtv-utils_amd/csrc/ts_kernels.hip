@@ -463,6 +463,8 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
                 out->cur = cur;
                 out->block_packets = s_sum_block;
                 out->walks = s_sum_walks;
+                out->events = *p.event_count;
+                out->pad2 = 0;
             }
         }
     } else if (t == 0) {
@@ -504,6 +506,8 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
             out->cur = cur;
             out->block_packets = blockp;
             out->walks = walks;
+            out->events = *p.event_count;
+            out->pad2 = 0;
         }
     }
     __syncthreads();

@@ -384,6 +384,10 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
                             ctx->d_span_attempt, ctx->h_out_dev);
             TSCHK(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
             TSCHK(ctx, hipGetLastError());
+            // (the stream-wide tables as they stand behind this merge: final if the chain turns out complete — the usual
+            // case — so that a scan is ONE wait)
+            TSCHK(ctx, hipMemcpyAsync(ctx->h_tables, ctx->d_count, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long)),
+                                      hipMemcpyDeviceToHost, ctx->stream));
             TSCHK(ctx, hipStreamSynchronize(ctx->stream));
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_m) == hipSuccess)
@@ -409,9 +413,7 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
             p.attempt++;
         }
         out->packets = packets;
-        unsigned int nev = 0;
-        TSCHK(ctx, hipMemcpyAsync(&nev, ctx->d_event_count, sizeof(nev), hipMemcpyDeviceToHost, ctx->stream));
-        TSCHK(ctx, hipStreamSynchronize(ctx->stream));
+        const unsigned int nev = ctx->h_out->events;  // (what the last merge saw: every scan launch of this round is behind it)
         if (nev > ctx->event_cap) {  // more sync errors than the list held: make room for all of them and scan again
             if (round > 0)
                 return ts_fail(ctx, PAPR_E_INTERNAL, "the sync-error list overflowed twice (%u events)", nev);
@@ -452,10 +454,7 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
     out->nsync_errors = ctx->errors.size();
     for (size_t k = 0; k < ctx->errors.size() && k < TS_MAX_SYNC_ERRORS; k++)
         out->sync_errors[k] = ctx->errors[k];
-    // the stream-wide tables (absolute packet numbers: min / max are order-independent)
-    TSCHK(ctx, hipMemcpyAsync(ctx->h_tables, ctx->d_count, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long)),
-                              hipMemcpyDeviceToHost, ctx->stream));
-    TSCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // the stream-wide tables (absolute packet numbers: min / max are order-independent; copied behind the last merge)
     const uint32_t *gc = (const uint32_t *)ctx->h_tables;
     const unsigned long long *gf = (const unsigned long long *)(gc + TS_PIDS), *gl = gf + TS_PIDS;
     for (int pid = 0; pid < TS_PIDS; pid++) {
