@@ -175,6 +175,13 @@ def lib() -> C.CDLL:
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: build it with `make lib` or __graft_entry__.build(); "
             "there is no fallback implementation")
+    # One process, one ROCm runtime: PyTorch brings its own libamdhip64 / libhsa-runtime64, and the copy that is mapped
+    # first is the one both sides end up sharing — a second HSA runtime in the process finds no GPU ("No HIP GPUs are
+    # available" from whoever came second).  So torch, where it is installed, goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     L.papr_hip_abi_version.restype = i32

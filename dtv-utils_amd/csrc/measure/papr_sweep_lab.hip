@@ -110,8 +110,14 @@ struct WaveStashT {
                 v.y = i + 1 < n ? v.y : pad;
                 v.z = i + 2 < n ? v.z : pad;
                 v.w = i + 3 < n ? v.w : pad;
-                if (pos + i + 4 <= seg_cap)
-                    store16<(MODE & 16) ? 0 : 2>(seg + pos + i, v);
+                // (MODE bit 7: the stores left out; bit 8: every spill over the segment's first bytes — both measurement
+                // only, to tell what of a spill's cost is the HBM write)
+                if constexpr ((MODE & 128) != 0)
+                    asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                else if constexpr ((MODE & 256) != 0)
+                    store16<(MODE & 16) ? 0 : 2>(seg + i, v);
+                else if (pos + i + 4 <= seg_cap)
+                    store16<(MODE & 16) ? 0 : (MODE & 512) ? 1 : 2>(seg + pos + i, v);  // (bit 9: nontemporal)
             }
         } else {
             for (uint32_t i = lane; i < n; i += kWave)
@@ -228,6 +234,7 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_lab_kernel(const float4 *__r
     double sum = 0.0;
     TileTrack tr = {{0.f, 0.f, 0.f, 0.f, 0.f}, {0, 0, 0, 0, 0}};
     const TileWalk w = tile_walk(blockIdx.x, gridDim.x, ntiles, map);
+    uint32_t last_epoch = 0;
     auto fold = [&](const float4(&x)[U], uint32_t it) {
         float pw[2 * U];
 #pragma unroll
@@ -259,8 +266,21 @@ __global__ __launch_bounds__(BLOCK) void papr_sweep_lab_kernel(const float4 *__r
 #pragma unroll
         for (int u = 0; u < 2 * U; u++)
             count_and_stash(pw[u], k[u]);
-        if constexpr (!(ABL & 32) && !(SMODE & 64))
-            ws.spill_if_above(SLICE - 2 * U * kWave - ((SMODE & 8) ? kWave : 0), (it + 1) * (uint32_t)(2 * TILE_F4));  // the next tile might not fit
+        if constexpr (!(ABL & 32) && !(SMODE & 64)) {
+            uint32_t limit = SLICE - 2 * U * kWave - ((SMODE & 8) ? kWave : 0);  // the next tile might not fit
+            // SMODE bit 10 / 11: every wave of the chip spills at the same moment — every 32nd tile / whenever the 100 MHz
+            // clock enters a new 82 us epoch — so that the memory side sees the stash as a few large bursts of writes
+            // between long stretches of pure reads instead of a trickle that turns its buses around all the time
+            if constexpr ((SMODE & 1024) != 0)
+                limit = (it & 31u) == 31u ? kWave : limit;
+            if constexpr ((SMODE & 2048) != 0) {
+                constexpr int EP_SHIFT = ((SMODE >> 12) & 3) == 0 ? 13 : ((SMODE >> 12) & 3) == 1 ? 12 : ((SMODE >> 12) & 3) == 2 ? 14 : 11;  // (bits 12-13: the epoch)
+                const uint32_t ep = (uint32_t)(__builtin_amdgcn_s_memrealtime() >> EP_SHIFT);
+                limit = ep != last_epoch ? kWave : limit;
+                last_epoch = ep;
+            }
+            ws.spill_if_above(limit, (it + 1) * (uint32_t)(2 * TILE_F4));
+        }
     };
 
     const float4 *p = data + w.first * TILE_F4 + t;
@@ -1011,7 +1031,10 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
     X(102, 512, 4, 0, false, 10) X(103, 1024, 8, 0, false, 10) X(104, 512, 8, 0, false, 11) X(105, 512, 8, 0, false, 26)   \
     X(106, 512, 8, 0, false, 27) X(107, 512, 8, 0, false, 42) X(109, 512, 8, 0, false, 59)   \
     X(110, 512, 8, 1, false, 11) X(112, 256, 8, 0, false, 43) X(113, 1024, 4, 0, false, 43) \
-    X(114, 512, 8, 1, false, 107)
+    X(114, 512, 8, 1, false, 107) X(140, 512, 8, 1, false, 43) X(141, 512, 8, 1, false, 171) X(142, 512, 8, 1, false, 299) \
+    X(143, 512, 8, 1, false, 315) X(144, 512, 8, 1, false, 555) X(145, 512, 8, 2, false, 43) X(146, 512, 8, 1, false, 1067) \
+    X(147, 512, 8, 1, false, 2091) X(148, 512, 8, 1, false, 6187) X(149, 512, 8, 1, false, 10283) X(153, 512, 8, 1, false, 14379) \
+    X(154, 512, 8, 0, false, 2091)
 
 // loader / binner split (papr_sweep_split_kernel): id, loader waves, binners per loader, loads per lane per tile, ring depth
 // (measured slower than papr_sweep_kernel in every shape — DESIGN.md section 4b — so only `make MEASURE=1` builds it)
@@ -1020,7 +1043,7 @@ __global__ __launch_bounds__(WAVES *kWave) void papr_sweep2_kernel(const papr_sw
 int papr_lab_sweep_variant(int variant)
 {
     if ((variant >= 60 && variant <= 69) || (variant >= 90 && variant <= 99 && variant != 93 && variant != 96) ||
-        (variant >= 120 && variant <= 129 && variant != 123 && variant != 126))
+        (variant >= 120 && variant <= 129 && variant != 123 && variant != 126) || (variant >= 150 && variant <= 152))
         return variant;  // ablations of <1024, 4> / <256, 8> (measurement only)
     switch (variant) {
 #define X(V, PW, NB, LU, D) case V: return V;
@@ -1045,7 +1068,7 @@ int papr_lab_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, s
         variant = 4;
     if (variant >= 90 && variant <= 99)
         variant = 0;
-    if (variant >= 120 && variant <= 129)
+    if ((variant >= 120 && variant <= 129) || (variant >= 150 && variant <= 152))
         variant = 40;
     switch (variant) {
 #define X(V, PW, NB, LU, D)                                                                                      \
@@ -1090,6 +1113,8 @@ int papr_lab_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, s
 #define PAPR_FOR_EACH_ABLATION2(X) X(90, 1) X(91, 2) X(92, 3) X(94, 8) X(95, 16) X(97, 32) X(98, 7) X(99, 24)
 // (and of the default, <512, 8> with the branch-free stash)
 #define PAPR_FOR_EACH_ABLATION3(X) X(120, 1) X(121, 2) X(122, 3) X(124, 8) X(125, 16) X(127, 32) X(128, 7) X(129, 24)
+// (and of the product form: the same with the next tile's loads in flight)
+#define PAPR_FOR_EACH_ABLATION4(X) X(150, 1) X(151, 2) X(152, 3)
 
 void papr_lab_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,
                        uint64_t base_index, int map, papr_partial *out, const void *tail, uint32_t tail_samples,
@@ -1137,6 +1162,14 @@ void papr_lab_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_b
                            table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                     \
         break;
         PAPR_FOR_EACH_ABLATION3(X)
+#undef X
+#define X(V, A)                                                                                                      \
+    case V:                                                                                                           \
+        launch_maybe_timed((papr_sweep_lab_kernel<512, 8, true, 1, A, false, 43>), dim3(blocks), dim3(512), lds_bytes, st, \
+                           (const float4 *)data, ntiles, base_index, map, out, (const float2 *)tail, tail_samples,    \
+                           table, P, ghist, stash, seg_counts, seg_cap, gave_up, seg_real, Pdev);                     \
+        break;
+        PAPR_FOR_EACH_ABLATION4(X)
 #undef X
 #define X(V, B, U, PP)                                                                                               \
     case V:                                                                                                           \

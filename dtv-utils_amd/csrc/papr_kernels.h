@@ -204,7 +204,7 @@ void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, c
 #define PAPR_SWEEP3_VARIANT 131
 int papr_sweep_variant(int variant); /* the sweep geometry used for a variant id, or -1 */
 #define PAPR_SWEEP_VARIANT_IS_LUT2(v) (((v) >= 20 && (v) <= 29) || ((v) >= 70 && (v) <= 79) || (v) == 18 || (v) == 38) /* compact table: papr_sweep_kernel<LUT2>, papr_sweep_split_kernel */
-#define PAPR_SWEEP_VARIANT_IS_PERSISTENT(v) ((v) == PAPR_SWEEP_VARIANT || (v) == 40 || (v) == 114) /* launched as ONE workgroup per CU (512 threads x 8 loads per lane) */
+#define PAPR_SWEEP_VARIANT_IS_PERSISTENT(v) ((v) == PAPR_SWEEP_VARIANT || (v) == 40 || (v) == 114 || ((v) >= 120 && (v) <= 129) || ((v) >= 140 && (v) <= 154)) /* launched as ONE workgroup per CU (512 threads x 8 loads per lane) */
 #define PAPR_SWEEP_VARIANT_HAS_HIST_SETS(v) (((v) >= 84 && (v) <= 85) || ((v) >= 87 && (v) <= 89)) /* SMODE bit 2 (measurement variants) */
 int papr_sweep_geometry(int variant, int *threads, uint64_t *tile_samples, size_t *stash_lds); /* 0, or -1 */
 void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes, const void *data, uint64_t ntiles,

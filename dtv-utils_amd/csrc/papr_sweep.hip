@@ -728,6 +728,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep_kernel(const fl
     TileTrack tr = {{0.f, 0.f, 0.f, 0.f, 0.f}, {0, 0, 0, 0, 0}};
     const TileWalk w = tile_walk(blockIdx.x, gridDim.x, ntiles, map);
     auto fold = [&](const float4(&x)[U], uint32_t it) {
+        const uint64_t now = __builtin_amdgcn_s_memrealtime();  // (for the spill check at the end)
         float pw[2 * U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep_kernel(const fl
 #pragma unroll
         for (int u = 0; u < 2 * U; u++)
             count_and_stash(pw[u], k[u]);
-        ws.spill_if_above(SLICE - (2 * U + 1) * kWave, (it + 1) * (uint32_t)(2 * TILE_F4));  // the next tile might not fit
+        ws.spill_in_step(now, SLICE - (2 * U + 1) * kWave, (it + 1) * (uint32_t)(2 * TILE_F4));  // the next tile might not fit
     };
 
     const float4 *p = data + w.first * TILE_F4 + t;
@@ -897,6 +898,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         load_seg(x, seg0);
     for (uint32_t it = 0; it < count; it++) {
         const uint64_t seg = seg0 + (uint64_t)it * seg_stride;
+        const uint64_t now = __builtin_amdgcn_s_memrealtime();  // (for the spill check)
         const int E = __builtin_amdgcn_readfirstlane(tile_E[(p.seg_offset + seg) >> 1]);
 #pragma unroll
         for (int r = 0; r < U; r++) {
@@ -915,7 +917,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         // room for the segment's 16 samples of every lane (and the trash words)?  Checked IN FRONT of the fold, behind the
         // next segment's loads: a spill's stores then have the fold's duration to drain before this wave waits for memory
         // again (vmcnt is in order and counts stores too)
-        ws.spill_if_above(SLICE - (2 * U + 1) * kWave, (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
+        ws.spill_in_step(now, SLICE - (2 * U + 1) * kWave, (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
         float4 y[U];
 #pragma unroll
         for (int j = 0; j < U; j++)

@@ -113,6 +113,9 @@ __device__ __forceinline__ void store16_wt(float *p, f32x4s v) { store16<2>(p, v
 // cannot be answered from the stash, and must not cost more than the pass it replaces: each spill compares what the
 // workgroup stashed in this launch with what it folded, and once more than half of it was in band — or the segment is
 // full — the wave GIVES UP for the whole workgroup (sweep_give_up).
+constexpr int kSpillEpochShift = 10;  // 1024 ticks of the 100 MHz real-time clock
+constexpr uint32_t kSpillUnarmed = 0xFFFFFFFFu;
+
 struct WaveStash {
     float *buf;                         // this wave's slice of LDS
     float *__restrict__ seg;            // this workgroup's stash segment
@@ -125,6 +128,9 @@ struct WaveStash {
     unsigned long long *gave_up;        // device counter of give-ups
     uint32_t trash;                     // this lane's own word at the end of the slice, where what is not in band goes
     uint32_t sbase, sbytes;             // LDS byte address of the slice, and of its next free slot (wave-uniform)
+    uint32_t epoch, epochs, n_ref;      // spill_in_step: the clock epoch last seen; whole epochs since the fill was n_ref
+    uint32_t rate;                      // ... powers per epoch, times 9/8
+    bool in_step;
 
     __device__ __forceinline__ void init(float *slice, uint32_t slice_floats, float *segment, unsigned long long *fill,
                                          unsigned long long *real, uint64_t cap, uint32_t *table, uint32_t words,
@@ -141,6 +147,11 @@ struct WaveStash {
         gave_up = gave_up_counter;
         trash = slice_floats - kWave + (threadIdx.x & (kWave - 1));
         sbase = sbytes = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u32 *)slice);
+        epoch = (uint32_t)(__builtin_amdgcn_s_memrealtime() >> kSpillEpochShift);
+        epochs = kSpillUnarmed;
+        n_ref = 0;
+        rate = 0;
+        in_step = false;
     }
     __device__ __forceinline__ void put(float pw, bool take)
     {
@@ -158,6 +169,40 @@ struct WaveStash {
         // (s_lshl2_add_u32 writes SCC: said, so that the compiler never schedules it between a compare and its consumer)
         asm("s_lshl2_add_u32 %0, %1, %2" : "=s"(sbytes) : "s"((uint32_t)__popcll(m)), "s"(__builtin_amdgcn_readfirstlane(sbytes)) : "scc");
     }
+    // The per-tile spill check.  When every wave spills as its own slice fills up the memory side sees the stash as a
+    // trickle of small writes from 2048 waves at 2048 different moments, and each of them turns a channel's bus around
+    // under the read stream: measured on the 0.1 dB table, 250 MB of stash cost as much time as 1.3 GB of reads
+    // (spills with the stores left out cost nothing).  So the waves of the whole chip spill IN STEP, at the ticks of a
+    // clock they all see — the 100 MHz real-time counter, in epochs of 10.24 us: the writes then arrive as bursts of up
+    // to 12 MB between long stretches of pure reads.  At the beginning of epoch number e a wave asks whether its slice
+    // lasts until the next epoch whose number has MORE trailing zeros than e — 2^ctz(e) epochs from now — at the rate it
+    // has been filling, an eighth to spare, and spills if not: epochs with many trailing zeros are where everybody
+    // meets, and a wave only spills on the way there if it must.  All waves see the same stream statistics, so they
+    // take the same decisions; the ones that do not still spill on a common tick.  A slice that fills up in between is
+    // spilled at once, as before.
+    // `now`: __builtin_amdgcn_s_memrealtime() read at the START of the tile (its latency then hides under the fold);
+    // `limit`: what may wait (the next tile must fit behind it).
+    __device__ __forceinline__ void spill_in_step(uint64_t now, uint32_t limit, uint32_t folded)
+    {
+        const uint32_t ep = (uint32_t)(now >> kSpillEpochShift);
+        if (ep != epoch) {  // (wave-uniform)
+            epoch = ep;
+            const uint32_t n = (sbytes - sbase) >> 2;
+            if (epochs == kSpillUnarmed) {  // the first whole epoch since the start / since the slice ran over begins here
+                epochs = 0;
+                n_ref = n;
+            } else if (++epochs >= 2u || rate == 0u) {  // (one epoch alone is a noisy measure: the last spill's rate stands)
+                rate = ((n - n_ref) * 9u) / epochs;     // per epoch, times 9/8 (n < 2^12)
+            }
+            const uint32_t zeros = ep ? min((uint32_t)__builtin_ctz(ep), 12u) : 12u;
+            if (n + ((rate << zeros) >> 3) + kWave > limit) {
+                limit = 0;
+                in_step = true;
+            }
+        }
+        spill_if_above(limit, folded);
+        in_step = false;
+    }
     // spill if more than `limit` entries are waiting (wave-uniform decision); `folded` = samples this workgroup has
     // folded in this launch, about
     __device__ __forceinline__ void spill_if_above(uint32_t limit, uint32_t folded)
@@ -166,6 +211,8 @@ struct WaveStash {
         if (n <= limit)
             return;
         sbytes = sbase;
+        epochs = in_step ? 0u : kSpillUnarmed;  // (a spill in step starts whole epochs; one out of step does not)
+        n_ref = 0;
         __builtin_amdgcn_wave_barrier();  // LDS is in-order per wave; this pins the compiler's order too
         const uint32_t lane = threadIdx.x & (kWave - 1);
         const uint32_t nres = (n + 3u) & ~3u;  // floats reserved in the segment
