@@ -321,6 +321,12 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
                 });
         }
     };
+    bool two_copy_streams = env_int("PAPR_COPY_STREAMS", 1) >= 2;
+    if (two_copy_streams && !ctx->copy_stream2 &&
+        hipStreamCreateWithFlags(&ctx->copy_stream2, hipStreamNonBlocking) != hipSuccess) {
+        ctx->copy_stream2 = nullptr;
+        two_copy_streams = false;  // (one stream it is)
+    }
     // copy chunk c (already read into its pinned buffer) to the device and run the pass kernel on it
     auto process_chunk = [&](uint64_t c) -> int {
         const int b = (int)(c % kNumBuf);
@@ -328,10 +334,11 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
         const uint64_t cnt = std::min(chunk_samples, ctx->n - s0);
         unsigned char *hbuf = (unsigned char *)ctx->h_stage[b];
         float *dst = to_resident ? ctx->d_iq + 2 * s0 : (float *)ctx->d_stage[b];
+        hipStream_t cs = two_copy_streams && (c & 1) ? ctx->copy_stream2 : ctx->copy_stream;
         if (!to_resident && c >= (uint64_t)kNumBuf)
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_kernel[b], 0));
-        HIPCHK(ctx, hipMemcpyAsync(dst, hbuf, cnt * 8, hipMemcpyHostToDevice, ctx->copy_stream));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_copy[b], ctx->copy_stream));
+            HIPCHK(ctx, hipStreamWaitEvent(cs, ctx->ev_kernel[b], 0));
+        HIPCHK(ctx, hipMemcpyAsync(dst, hbuf, cnt * 8, hipMemcpyHostToDevice, cs));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_copy[b], cs));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copy[b], 0));
         const bool last = (c + 1 == nchunks);
         int prc = PAPR_OK;

@@ -627,6 +627,7 @@ void papr_hip_close(papr_hip_ctx *ctx)
         (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->copy_stream2) (void)hipStreamSynchronize(ctx->copy_stream2);
     delete ctx->pool;
     delete ctx->uring;
     release_shard(ctx);
@@ -677,6 +678,7 @@ void papr_hip_close(papr_hip_ctx *ctx)
     if (ctx->d_nan_key) (void)hipFree(ctx->d_nan_key);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->copy_stream2) (void)hipStreamDestroy(ctx->copy_stream2);
     delete ctx;
 }
 

@@ -146,6 +146,7 @@ struct papr_hip_ctx {
     int device = -1;
     hipStream_t stream = nullptr;     // compute
     hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream2 = nullptr;  // chunks alternate between the two: two DMA engines on the link (PAPR_COPY_STREAMS)
     char name[128] = "";
     char err[256] = "";
     int num_cus = 256;
