@@ -278,6 +278,7 @@ struct papr_sweep2_params {
     void *seg_D;                  // per segment: double2 (D0, D1); D0 doubles as the segment's sum
     uint64_t seg_offset;          // index of the launch's first segment within the shard (chunked launches)
     uint32_t lds_bytes;           // papr_sweep3_kernel: the launch's dynamic LDS (set by its launch wrapper)
+    uint32_t fine_table;          // papr_sweep3_kernel: more than 64 bands (the 0.1 dB table) — selects the kernel form
 };
 int papr_sweep2_geometry(int variant, int *threads, uint64_t *seg_samples, size_t *lds_fixed, int *exact);
 // ---- the exact-sum sweep, third form (papr_sweep.hip: papr_sweep3_kernel) ----------------------------------------

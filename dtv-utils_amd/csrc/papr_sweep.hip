@@ -817,6 +817,8 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep_kernel(const fl
 // Its predecessor papr_sweep2_kernel<EXACT> (12 waves, compact table, ring stash, ordered 64-lane composition: 37 VALU +
 // 18 SALU per sample against 26 + 12 here) and the forms of this kernel that lost (two batches per segment, the powers
 // instead of the samples through LDS, 12 waves) are measure/papr_sweep_lab.hip's and DESIGN.md section 5's.
+// FINE: the 0.1 dB table's form (a kernel of its own: as one wave-uniform branch the second path costs the first 0.05 ms)
+template <bool FINE>
 __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const papr_sweep2_params p)
 {
     constexpr int U = 8, WAVES = PAPR_SWEEP_THREADS / kWave;
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         const uint2 e = lut_biased[clamp_cell(cell, cell_first, cell_last)];
         return e.x + (__float_as_uint(pw) >= e.y ? 1u : 0u);
     };
-    auto count_and_stash = [&](float pw, uint32_t k) {
+    auto count_and_stash_masked = [&](float pw, uint32_t k, unsigned long long in_band) {
         // bin 0 (below every band: not counted) adds to this lane's trash word instead of being skipped
         const unsigned long long nz = __ballot(k != 0u);
         const uint32_t a_bin = (uint32_t)(uintptr_t)(lds_u32 *)&my[k];
@@ -874,8 +876,11 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         uint32_t a;
         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a) : "v"(a_trash), "v"(a_bin), "s"(nz));
         (void)__hip_atomic_fetch_add((lds_u32 *)(uintptr_t)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        ws.put(pw, (k & 1u) != 0u);
+        ws.put_masked(pw, in_band);
     };
+    auto count_and_stash = [&](float pw, uint32_t k) { count_and_stash_masked(pw, k, __ballot((k & 1u) != 0u)); };
+
+    constexpr bool fine = FINE;
 
     const float4 *data = reinterpret_cast<const float4 *>(p.data);
     const uint64_t seg_stride = (uint64_t)gridDim.x * WAVES;
@@ -917,7 +922,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         // room for the segment's 16 samples of every lane (and the trash words)?  Checked IN FRONT of the fold, behind the
         // next segment's loads: a spill's stores then have the fold's duration to drain before this wave waits for memory
         // again (vmcnt is in order and counts stores too)
-        ws.spill_in_step(now, SLICE - (2 * U + 1) * kWave, (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
+        ws.spill_in_step(now, fine ? SLICE - kWave : SLICE - (2 * U + 1) * kWave, (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
         float4 y[U];
 #pragma unroll
         for (int j = 0; j < U; j++)
@@ -943,9 +948,28 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
 #pragma unroll
         for (int u = 0; u < 2 * U; u++)
             k[u] = bin_of(pw[u]);  // the LUT reads in flight together
+        if constexpr (FINE) {
+            // A fine table stashes ten times what the 1 dB one does, out of a slice that is half as large (the table takes
+            // the rest): keeping the segment's worst case free — every sample of every lane in band, 4 KiB — would leave a
+            // quarter of the slice to collect in, and the waves would spill every 40 us instead of every 80.  So the
+            // segment's ballots are taken first and room is made for what it WILL put.  (Not for the coarse table: all
+            // sixteen lookups then have to be back before the first count, 0.05 ms per launch.)
+            unsigned long long in_band[2 * U];
+            uint32_t need = 0;
 #pragma unroll
-        for (int u = 0; u < 2 * U; u++)
-            count_and_stash(pw[u], k[u]);
+            for (int u = 0; u < 2 * U; u++) {
+                in_band[u] = __ballot((k[u] & 1u) != 0u);
+                need += (uint32_t)__popcll(in_band[u]);
+            }
+            ws.reserve(need, SLICE, (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
+#pragma unroll
+            for (int u = 0; u < 2 * U; u++)
+                count_and_stash_masked(pw[u], k[u], in_band[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2 * U; u++)
+                count_and_stash(pw[u], k[u]);
+        }
         segmax_commit(tr, m, it);
         // ---- the segment's pair ----
         const double d0 = x0 - m0, d1 = x1 - m1;  // exact: multiples of the ulp inside the binade (plain sums when no binade was given)
@@ -1156,7 +1180,11 @@ void papr_launch_sweep3(hipStream_t st, int variant, int blocks, size_t lds_byte
         return;
     papr_sweep2_params q = p;
     q.lds_bytes = (uint32_t)lds_bytes;
-    launch_maybe_timed(papr_sweep3_kernel, dim3(blocks), dim3(PAPR_SWEEP_THREADS), lds_bytes, st, q);
+    // (which form: the table's size is known to whoever planned it — the host, or papr_guess_bands_kernel through p.fine_hint)
+    if (q.fine_table)
+        launch_maybe_timed(papr_sweep3_kernel<true>, dim3(blocks), dim3(PAPR_SWEEP_THREADS), lds_bytes, st, q);
+    else
+        launch_maybe_timed(papr_sweep3_kernel<false>, dim3(blocks), dim3(PAPR_SWEEP_THREADS), lds_bytes, st, q);
 }
 
 void papr_launch_ccdf_power(hipStream_t st, int num_cus, bool lut, size_t lds_bytes, const float *stash,
@@ -1180,7 +1208,8 @@ void papr_sweep_prepare_device(void)
 {
     const int want = papr_ccdf_max_dynamic_lds();
     (void)hipFuncSetAttribute((const void *)papr_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want);
-    (void)hipFuncSetAttribute((const void *)papr_sweep3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    (void)hipFuncSetAttribute((const void *)papr_sweep3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    (void)hipFuncSetAttribute((const void *)papr_sweep3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
     (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
     (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
 #ifdef PAPR_MEASURE

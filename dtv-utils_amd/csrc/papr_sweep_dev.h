@@ -153,12 +153,13 @@ struct WaveStash {
         rate = 0;
         in_step = false;
     }
-    __device__ __forceinline__ void put(float pw, bool take)
+    __device__ __forceinline__ void put(float pw, bool take) { put_masked(pw, __ballot(take)); }
+    // the same with the takers' ballot handed in (a tile's ballots are taken first, to know what the tile needs: reserve)
+    __device__ __forceinline__ void put_masked(float pw, unsigned long long m)
     {
         // (the select is written out: from `take ? at : trash` hipcc makes an exec-masked region per sample)
         // Addresses in bytes: slot = rank among the takers * 4 + the next free slot's address, the latter wave-uniform
         // (one scalar operand of the v_lshl_add) — no copy of the fill count into a vector register per sample.
-        const unsigned long long m = __ballot(take);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         uint32_t a_slot;
         asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(a_slot) : "v"(rank), "s"(__builtin_amdgcn_readfirstlane(sbytes)));
@@ -202,6 +203,15 @@ struct WaveStash {
         }
         spill_if_above(limit, folded);
         in_step = false;
+    }
+    // room for `want` more powers (what the tile at hand will put: the popcounts of its ballots)?  If not, the slice goes
+    // out now, out of step.  Reserving the tile's ACTUAL need instead of its worst case (every sample of every lane in
+    // band: a third of a 12 KiB slice, most of a 6 KiB one) is what lets a slice collect for 80 us between two ticks.
+    __device__ __forceinline__ void reserve(uint32_t want, uint32_t slice_floats, uint32_t folded)
+    {
+        const uint32_t n = (sbytes - sbase) >> 2;
+        if (n + want > slice_floats - kWave)  // (the last kWave words are the lanes' trash words)
+            spill_if_above(0, folded);
     }
     // spill if more than `limit` entries are waiting (wave-uniform decision); `folded` = samples this workgroup has
     // folded in this launch, about

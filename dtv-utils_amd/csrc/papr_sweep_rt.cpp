@@ -267,6 +267,7 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
         p.tile_E_spec = ctx->d_tile_E_spec;
         p.seg_D = ctx->d_seg_D;
         p.seg_offset = (base_index - ctx->base) / PAPR_EXACT_SEG_SAMPLES;
+        p.fine_table = run.bands.P.nkeys > 128u ? 1u : 0u;
         time_begin_kernel(ctx, 3, n * 8);
         if (run.v3)  // (a persistent workgroup: all of the CU's LDS — what the table leaves goes to the stash slices)
             papr_launch_sweep3(ctx->stream, run.variant, blocks,
@@ -616,6 +617,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
         p.tile_E_spec = ctx->d_tile_E_spec;
         p.seg_D = ctx->d_seg_D;
         p.seg_offset = 0;
+        p.fine_table = graph ? 1u : 0u;  // (the table is planned on the device: 301 bands for -g, 31 otherwise)
         time_begin_kernel(ctx, 3, ctx->n * 8);
         if (run.v3)
             papr_launch_sweep3(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, p);
