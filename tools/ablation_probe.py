@@ -39,7 +39,7 @@ def main():
             ids = ((4, 60, 61, 62, 63, 64, 65, 67, 68, 69, 66) if args.family == 0 else
                    (0, 90, 91, 92, 94, 95, 97, 98, 99, 80, 81, 82, 2) if args.family == 30 else
                    (40, 120, 121, 122, 124, 125, 128, 129) if args.family == 60 else
-                   (111, 147, 140, 150))
+                   (111, 140, 150, 151, 152, 141, 142, 143, 110, 144, 145, 147, 148, 153, 149, 146, 154))
             for v in ids:
                 g.set_tuning(sweep_variant=v, sweep_blocks=blocks)
                 g.set_timing(True)
@@ -51,7 +51,7 @@ def main():
                 tm = g.timing()
                 g.set_timing(False)
                 ms = tm.sweep_ms / max(tm.sweep_launches, 1)
-                name = NAMES.get(v) or NAMES.get(v - args.family) or {111: "product (512 x 8, prefetch)", 140: "its lab twin", 145: "true double buffer", 146: "spills every 32nd tile, chip-wide", 147: "spills every 82 us, chip-wide", 148: "every 41 us", 149: "every 164 us", 153: "every 20 us", 154: "every 82 us, no prefetch", 110: "half the slice per wave (6 KiB)", 144: "nontemporal spill stores", 150: "no stash", 151: "no histogram", 152: "no stash, no histogram", 141: "spill without the stores", 142: "spills over the same 12 KiB, write-through", 143: "spills over the same 12 KiB, plain stores", 40: "full <512, 8> (default)", 0: "full <256, 8>", 2: "<256, 8> next-tile prefetch", 80: "<256, 8> ballot stash", 81: "<256, 8> ballot + 16-byte spills", 82: "<256, 8> prefetch + ballot"}.get(v, "?")
+                name = NAMES.get(v) or NAMES.get(v - args.family) or {111: "product (spills in step)", 140: "the same, every wave spills when ITS slice is full (round 3 start)", 145: "true double buffer", 146: "spills every 32nd tile, chip-wide", 147: "spills every 82 us, chip-wide", 148: "every 41 us", 149: "every 164 us", 153: "every 20 us", 154: "every 82 us, no prefetch", 110: "half the slice per wave (6 KiB)", 144: "nontemporal spill stores", 150: "no stash", 151: "no histogram", 152: "no stash, no histogram", 141: "spill without the stores", 142: "spills over the same 12 KiB, write-through", 143: "spills over the same 12 KiB, plain stores", 40: "full <512, 8> (default)", 0: "full <256, 8>", 2: "<256, 8> next-tile prefetch", 80: "<256, 8> ballot stash", 81: "<256, 8> ballot + 16-byte spills", 82: "<256, 8> prefetch + ballot"}.get(v, "?")
                 print(f"mode={'graph' if graph else 'default'} round {rnd} blocks {blocks} v={v:2d} {name:34s} {ms:.3f} ms  {n * 8 / ms / 1e6:.0f} GB/s", flush=True)
     g.close()
 
