@@ -9,9 +9,15 @@ the guessed thresholds — the stats exchange, the host scalar stage (mean, PAPR
 the true level table), the recount of the few in-band samples and the count
 exchange.  `--two-pass` runs the classic pass 1 / pass 2 kernels instead (two
 reads; also what a step falls back to if the speculation misses), `--exact`
-the two-read path that reproduces the reference's sequential double sum.
+the same single read with the reference's sequential double sum reproduced
+bit for bit (bin/papr's default; `--exact --exact-two-pass`: in two reads).
 Every step recomputes everything from the samples; nothing carries over
-between steps.  Workload at N=1 is BASELINE.json configs[1]: 10 GiB of
+between steps.  The plain invocation — what the driver runs — prints the
+configs[1] line with the other legs as members: `graph` (configs[2]), `exact`
+(both tables), `ts` (the transport-stream packet scan of `--workload ts`),
+`cpu_baseline` / `cpu_baseline_graph` (the reference binary on one host core)
+and `e2e` (bin/papr on the same workload from /dev/shm, PCIe-inclusive);
+`--headline-only` leaves the members out.  Workload at N=1 is BASELINE.json configs[1]: 10 GiB of
 synthetic gr_complex IQ, default mode ("peak+mean+1 dB histogram"); `--mode
 graph` gives configs[2] (0.1 dB CCDF, ~301 bins).  With N ranks every rank owns
 its own 10 GiB shard of an N x 10 GiB stream (weak scaling; N=8 is configs[3]).
