@@ -285,22 +285,64 @@ bool papr_exchange_is_identity(const papr_exchange *x)
 // and consume its buffers — no host staging, no wait.  The caller-callback and in-process transports move host memory.
 namespace papr_rt {
 
+// PAPR_XCH_IN_STREAM=2 lets the host transports (caller callbacks, threads) STAND IN for them — the device buffer is
+// brought to the host behind a wait, crosses the transport, and goes back — so that the sharded step's device side (the
+// record kernels, the guess from all ranks' records, the ordered merge, the packed counters) can be run with real worlds
+// of 2-8 ranks on a box with one GPU (tests/test_exchange_gloo.py, bench.py --backend gloo).  Not a fast path.
 bool xch_in_stream(const papr_exchange *x, const papr_hip_ctx *ctx)
 {
-    return x && x->comm && x->ctx == ctx && env_int("PAPR_XCH_IN_STREAM", 1) != 0;
+    if (!x)
+        return false;
+    const int mode = env_int("PAPR_XCH_IN_STREAM", 1);
+    if (x->comm)
+        return x->ctx == ctx && mode != 0;
+    return mode == 2 && (x->hub || x->use_ops) && !(x->world == 1 && x->use_ops);
 }
 int xch_rank(const papr_exchange *x) { return x ? x->rank : 0; }
 int xch_world(const papr_exchange *x) { return x ? x->world : 1; }
 
-int xch_allgather_dev(papr_exchange *x, const void *send_dev, void *recv_dev, size_t bytes_per_rank)
+namespace {
+// the stand-in: device -> host, the transport's own collective, host -> device (the stream is idle in between)
+int through_the_host(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev, void *recv_dev, size_t send_bytes,
+                     size_t recv_bytes, bool reduce_u64)
 {
+    try {
+        x->scratch.resize(send_bytes + recv_bytes);
+    } catch (...) {
+        return xfail(x, PAPR_E_NOMEM, "out of host memory");
+    }
+    unsigned char *hs = x->scratch.data(), *hr = hs + send_bytes;
+    XHIP(x, hipMemcpyAsync(hs, send_dev, send_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    XHIP(x, hipStreamSynchronize(ctx->stream));
+    int rc;
+    if (reduce_u64) {
+        memcpy(hr, hs, send_bytes);
+        rc = allreduce_u64(x, reinterpret_cast<uint64_t *>(hr), send_bytes / sizeof(uint64_t));
+    } else {
+        rc = allgather_bytes(x, hs, hr, send_bytes);
+    }
+    if (rc)
+        return rc;
+    XHIP(x, hipMemcpyAsync(recv_dev, hr, recv_bytes, hipMemcpyHostToDevice, ctx->stream));
+    XHIP(x, hipStreamSynchronize(ctx->stream));  // (`scratch` is reused by the next call)
+    x->timing.in_stream_calls++;
+    return PAPR_OK;
+}
+}  // namespace
+
+int xch_allgather_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev, void *recv_dev, size_t bytes_per_rank)
+{
+    if (!x->comm)
+        return through_the_host(x, ctx, send_dev, recv_dev, bytes_per_rank, bytes_per_rank * (size_t)x->world, false);
     XNCCL(x, rccl()->AllGather(send_dev, recv_dev, bytes_per_rank, ncclUint8, x->comm, x->ctx->stream));
     x->timing.in_stream_calls++;
     return PAPR_OK;
 }
 
-int xch_allreduce_u64_dev(papr_exchange *x, const void *send_dev, void *recv_dev, size_t count)
+int xch_allreduce_u64_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev, void *recv_dev, size_t count)
 {
+    if (!x->comm)
+        return through_the_host(x, ctx, send_dev, recv_dev, count * sizeof(uint64_t), count * sizeof(uint64_t), true);
     XNCCL(x, rccl()->AllReduce(send_dev, recv_dev, count, ncclUint64, ncclSum, x->comm, x->ctx->stream));
     x->timing.in_stream_calls++;
     return PAPR_OK;

@@ -403,8 +403,8 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
 bool xch_in_stream(const papr_exchange *x, const papr_hip_ctx *ctx);
 int xch_rank(const papr_exchange *x);
 int xch_world(const papr_exchange *x);
-int xch_allgather_dev(papr_exchange *x, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
-int xch_allreduce_u64_dev(papr_exchange *x, const void *send_dev, void *recv_dev, size_t count);
+int xch_allgather_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
+int xch_allreduce_u64_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev, void *recv_dev, size_t count);
 int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total);
 void run_overlap_work(papr_hip_ctx *ctx);  // (see papr_hip_ctx::overlap_work)
 int launch_stats_range(papr_hip_ctx *ctx, const float *data, uint64_t n, uint64_t base_index, size_t slot,

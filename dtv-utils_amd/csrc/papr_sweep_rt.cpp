@@ -575,7 +575,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
         papr_launch_est_record(ctx->stream, est_partials, ctx->d_est_sq, (uint32_t)est_blocks, ngroups,
                                ngroups * PAPR_ESTIMATE_TILE_SAMPLES, ctx->n, (uint32_t)ratio, ctx->shard_flags, d_est_mine);
         HIPCHK(ctx, hipGetLastError());
-        rc = xch_allgather_dev(x, d_est_mine, d_est_all, sizeof(papr_est_record));
+        rc = xch_allgather_dev(x, ctx, d_est_mine, d_est_all, sizeof(papr_est_record));
         if (rc)
             return fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x));
     }
@@ -660,7 +660,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
     constexpr uint32_t true_soft = 20 * 1024;  // LDS the recount is launched with (as the host path: table + histogram copies)
     ctx->h_true->ok = 0;
     if (peers) {  // exchange 1b, in the stream: the shards' pass-1 records, folded in rank (= file) order on every rank
-        rc = xch_allgather_dev(x, ctx->d_result_copy, d_recs_all, sizeof(papr_partial));
+        rc = xch_allgather_dev(x, ctx, ctx->d_result_copy, d_recs_all, sizeof(papr_partial));
         if (rc)
             return fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x));
         papr_launch_record_merge(ctx->stream, d_recs_all, d_est_all, world, my_rank, d_total, d_n_total, ctx->h_peer_dev);
@@ -685,7 +685,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
                           ctx->d_sweep_hist + kBinsMax + 2 * run.blocks, ctx->d_hist, PAPR_TRUE_MAX_LEVELS + 1, ctx->d_guess,
                           ctx->d_true, d_xvec);
         HIPCHK(ctx, hipGetLastError());
-        rc = xch_allreduce_u64_dev(x, d_xvec, d_xvec_sum, kXvecWords);
+        rc = xch_allreduce_u64_dev(x, ctx, d_xvec, d_xvec_sum, kXvecWords);
         if (rc)
             return fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x));
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_xvec, d_xvec_sum, (size_t)kXvecWords * 8, hipMemcpyDeviceToHost, ctx->stream));

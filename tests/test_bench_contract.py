@@ -90,14 +90,14 @@ def test_torchrun_single_rank_uses_rccl(extra):
         assert 0 < d["config"]["one_sweep"]["stash_samples"] < d["config"]["samples_per_gpu"] // 8
 
 
-def _run_bench(nproc, gib, extra):
+def _run_bench(nproc, gib, extra, env=None):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
     if nproc > 1:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
                "--backend", "gloo"]
     cmd += ["--gpus", str(nproc), "--gib", str(gib), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *extra]
-    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout
@@ -132,6 +132,26 @@ def test_one_sweep_equals_two_pass_at_every_rank_count(mode):
             assert got["config"][key] == ref["config"][key], (ranks, key)
         assert abs(float.fromhex(got["config"]["sum_hex"]) - float.fromhex(ref["config"]["sum_hex"])) <= \
             1e-12 * float.fromhex(ref["config"]["sum_hex"])
+
+
+@pytest.mark.parametrize("mode", ["default", "graph"])
+def test_sharded_step_as_one_sequence_of_launches_with_real_worlds(mode):
+    """What an N-GPU run over RCCL executes — estimate records, pass-1 records and counters crossing the exchange as
+    collectives on DEVICE buffers between the kernels that produce and consume them (papr_est_record_kernel, the guess
+    from all ranks' records, papr_record_merge_kernel, papr_xpack_kernel) — with worlds of 2, 4 and 8 ranks on the one
+    GPU: PAPR_XCH_IN_STREAM=2 lets the gloo callbacks stand in for ncclAllGather / ncclAllReduce.  Table and counts must
+    be the 1-rank two-pass run's, the sum the tree sum's to 1e-12, and every step must have taken that path."""
+    ref = _run_bench(1, 0.5, ["--mode", mode, "--two-pass"])
+    for ranks in (2, 4, 8):
+        got = _run_bench(ranks, 0.5 / ranks, ["--mode", mode], env={"PAPR_XCH_IN_STREAM": "2"})
+        assert got["config"]["one_sweep"]["steps_resolved_from_the_sweep"] == 2, got["config"]["one_sweep"]
+        for key in ("papr_db", "levels", "counts_crc32", "samples_total"):
+            assert got["config"][key] == ref["config"][key], (ranks, key)
+        assert abs(float.fromhex(got["config"]["sum_hex"]) - float.fromhex(ref["config"]["sum_hex"])) <= \
+            1e-12 * float.fromhex(ref["config"]["sum_hex"])
+        # three collectives per step, none of the host exchanges
+        assert got["exchange"]["in_stream_collectives"] >= 3 * 2, got["exchange"]
+        assert got["exchange"]["stats"]["calls"] == 0 and got["exchange"]["counts"]["calls"] == 0, got["exchange"]
 
 
 @pytest.mark.parametrize("extra", [[], ["--exact"]], ids=["tree", "exact"])

@@ -35,19 +35,29 @@ def _golden(name):
         return f.read()
 
 
-@pytest.mark.parametrize("extra", [[], ["--exact"]], ids=["tree", "exact"])
+@pytest.mark.parametrize("extra", [[], ["--exact"], ["--collectives-on-device-buffers"]],
+                         ids=["tree", "exact", "tree, exchanges between the kernels"])
 def test_eight_rank_bench_line_proves_itself_at_full_size(extra, manifest):
+    """BASELINE configs[3] on the one GPU: 8 ranks x 10 GiB over gloo.  The third form takes the way an 8-GPU run over RCCL
+    takes — the three exchanges as collectives on device buffers inside the step's sequence of launches — with the gloo
+    callbacks standing in for ncclAllGather / ncclAllReduce (PAPR_XCH_IN_STREAM=2)."""
     import torch
+    env = dict(os.environ)
+    if "--collectives-on-device-buffers" in extra:
+        extra = []
+        env["PAPR_XCH_IN_STREAM"] = "2"
     free, total = torch.cuda.mem_get_info(0)
     if free < 110 * (1 << 30):
         pytest.skip(f"8 x 10 GiB shards + stashes need ~100 GiB of HBM; {free >> 30} GiB free")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo",
            "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", *extra]
-    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
     assert d["n_gpus"] == 8 and d["config"]["samples_total"] == 8 * 1342177280 == manifest["big_spike80g"]["nsamples"]
+    if env.get("PAPR_XCH_IN_STREAM") == "2":
+        assert d["exchange"]["in_stream_collectives"] >= 6 and d["exchange"]["stats"]["calls"] == 0, d["exchange"]
     assert d["parity_in_run"] is True and d["parity_golden"] == "big_spike80g.default.txt"
     assert d["graph"]["parity_in_run"] is True and d["graph"]["parity_golden"] == "big_spike80g.graph.txt"
     assert d["report_sha256"] == manifest["big_spike80g"]["default"]["sha256"]
