@@ -28,6 +28,7 @@ struct ts_span_rec {
     uint32_t explicit_entry; // 1: started from a walker state handed in by the host, clean or not
 };
 #define TS_NO_ENTRY 0xFFFFFFFFFFFFFFFFull
+#define TS_EVENT_BRIDGE 0x80000000u /* ts_event::attempt: written by a bridge of ts_merge_kernel */
 #define TS_MAX_SPANS 512 /* spans per scan (one per CU; ts_merge_kernel keeps their records in LDS) */
 
 // a `Transport Sync Error` line, before the span's packets have their stream-wide numbers
@@ -72,10 +73,11 @@ void ts_kernels_prepare_device(void);
 void ts_launch_scan(hipStream_t st, int blocks, const ts_scan_params &p);
 // folds spans [from_span, ...) as far as the chain holds, starting from state `cur` with `packet_base` packets counted;
 // span_base / span_attempt (nspans_total each): per span its first packet's stream-wide number and the attempt whose
-// record was taken (0: the span was not taken)
+// record was taken (0: the span was not taken); span_bridge_base: the number of the first packet of the bridge the merge
+// walked in front of it (== span_base where there was none) — events with TS_EVENT_BRIDGE in `attempt` count from there
 void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t from_span, uint64_t packet_base, const ts_walk_state &cur,
                      uint32_t *g_count, unsigned long long *g_first, unsigned long long *g_last, unsigned long long *span_base,
-                     uint32_t *span_attempt, ts_merge_out *out);
+                     unsigned long long *span_bridge_base, uint32_t *span_attempt, ts_merge_out *out);
 void ts_launch_generate(hipStream_t st, void *out, uint64_t nunits, uint32_t unit, uint64_t seed, int hdmv);
 void ts_launch_generate_damaged(hipStream_t st, void *out, uint64_t nbytes, uint64_t period, uint64_t seed);
 

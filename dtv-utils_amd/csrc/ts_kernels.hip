@@ -33,8 +33,18 @@ constexpr int kScanBlock = 1024;
 constexpr int kMergeBlock = 256;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kEntrySyncs = 8;  // sync bytes in a row, at the stride, that make a position a span's speculated entry
+constexpr uint32_t kEntryRounds = 16;  // ... looked for in the span's first 16 KiB
 
 // ---- the walker on the device: ts_walk_core.h with these hooks, run by wave 0 with all 64 lanes in step ----
+// The walker reads the stream through a WINDOW in LDS: 4 KiB brought in by one cooperative load (four 16-byte loads per
+// lane in flight: one trip to memory), from which its header bytes and its sync searches are served.  Read straight from
+// global memory every byte the walker step looks at was a dependent trip of its own, 1-2 us each, and a damaged spot —
+// a burst of garbage with a false sync byte every few hundred bytes — cost ~30 us of its span's time.
+constexpr uint32_t kWalkWindow = 4096;
+constexpr uint64_t kBridgeMax = 1u << 20;   // a bridge longer than this is the host's (a launch of the span from the true state)
+constexpr uint32_t kBridgeSteps = 8192;     // ... or one of more packets than this
+constexpr uint32_t kBridgeEvent = 0x80000000u;  // ts_event::attempt of a bridge's events (numbered from the bridge's first packet)
+
 struct DevWalk {
     const unsigned char *data;
     uint32_t *s_count, *s_first, *s_last;  // the workgroup's tables (LDS); the other waves wait at a barrier meanwhile
@@ -42,6 +52,15 @@ struct DevWalk {
     ts_event *events;
     unsigned int *event_count;
     uint32_t event_cap, span, attempt, lane;
+    unsigned char *win;                    // LDS, 16-byte aligned
+    uint64_t nbytes, win_base;             // the window holds the stream's bytes [win_base, win_base + win_len)
+    uint32_t win_len;
+    // the merge kernel's bridges (below) count into the STREAM-WIDE tables, or not at all (a dry run):
+    uint32_t *g_count;                     // null: the workgroup's LDS tables above
+    unsigned long long *g_first, *g_last;
+    uint64_t abs0;                         // stream-wide number of the walk's first packet
+    uint64_t stop_at;                      // the sync byte in front of which the walk is to stop (TS_NO_ENTRY: nowhere)
+    uint32_t quiet;                        // 1: count packets only — no table, no event
 };
 
 __device__ __forceinline__ bool walk_is_clean(const ts_walk_state &st)
@@ -49,40 +68,70 @@ __device__ __forceinline__ bool walk_is_clean(const ts_walk_state &st)
     return st.skipped == 0 && st.stale_af == 0 && (!st.hdmv || st.extra_pending == 4u);
 }
 
-// first offset in [from, end) that holds 0x47, or end: 1 KiB per step (16 bytes per lane) where the address allows,
-// single bytes up to the next 16-byte boundary and at the end
-__device__ __forceinline__ uint64_t dev_find_sync(const DevWalk *w, uint64_t from, uint64_t end)
+// bring the window to `off` (wave-uniform; off < nbytes).  Its base is `off` rounded down to a 16-byte boundary OF THE
+// BUFFER, so that whole 16-byte loads can be used (an adopted buffer need not be aligned: then it is bytes)
+__device__ __forceinline__ void win_fill(DevWalk *w, uint64_t off)
 {
-    const unsigned char *d = w->data;
+    const uint32_t lane = w->lane;
+    const uint32_t mis = (uint32_t)(((uintptr_t)w->data + off) & 15u);
+    const bool aligned = off >= mis;
+    const uint64_t base = aligned ? off - mis : off;
+    const uint64_t room = w->nbytes - base;
+    const uint32_t len = room < kWalkWindow ? (uint32_t)room : kWalkWindow;
+    __builtin_amdgcn_wave_barrier();  // (earlier reads of the window are done: same wave, in order — this is for the compiler)
+    const uint32_t quads = aligned ? len / 16u : 0u;
+    for (uint32_t q = lane; q < quads; q += 64u)  // (kWalkWindow / 16 / 64 = 4 loads per lane, issued back to back)
+        *reinterpret_cast<uint4 *>(w->win + 16u * q) = *reinterpret_cast<const uint4 *>(w->data + base + 16u * q);
+    for (uint32_t b = 16u * quads + lane; b < len; b += 64u)
+        w->win[b] = w->data[base + b];
+    __builtin_amdgcn_wave_barrier();
+    w->win_base = base;
+    w->win_len = len;
+}
+
+__device__ __forceinline__ unsigned dev_byte(DevWalk *w, uint64_t off)
+{
+    if (off - w->win_base >= (uint64_t)w->win_len)  // (also when off lies in front of the window)
+        win_fill(w, off);
+    return w->win[off - w->win_base];
+}
+
+// first offset in [from, end) that holds 0x47, or end: 1 KiB of the window per step (16 bytes per lane)
+__device__ __forceinline__ uint64_t dev_find_sync(DevWalk *w, uint64_t from, uint64_t end)
+{
     const uint32_t lane = w->lane;
     uint64_t pos = from;
     while (pos < end) {  // (wave-uniform)
-        if ((((uintptr_t)d + pos) & 15u) == 0 && pos + 1024 <= end) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(d + pos + 16u * lane);
+        if (pos - w->win_base >= (uint64_t)w->win_len)
+            win_fill(w, pos);
+        const uint32_t rel = (uint32_t)(pos - w->win_base);  // < win_len
+        const uint64_t left = end - w->win_base;
+        const uint32_t lim = left < (uint64_t)w->win_len ? (uint32_t)left : w->win_len;  // bytes of the window that may be looked at
+        const uint32_t c0 = (rel & ~15u) + 16u * lane;  // this lane's 16 bytes
+        uint32_t idx = 16;
+        if (c0 < lim) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(w->win + c0);  // (bytes behind win_len: stale, masked off below)
             const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
-            uint32_t idx = 16;
+            uint32_t bits = 0;  // bit i: byte i of the 16 is 0x47 (exact: no borrow tricks, every flagged byte is a match)
 #pragma unroll
-            for (int k = 3; k >= 0; k--) {
+            for (int k = 0; k < 4; k++) {
                 const uint32_t x = wd[k] ^ 0x47474747u;
-                const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;  // (the LOWEST flagged byte is always a true match)
-                if (z)
-                    idx = 4u * (uint32_t)k + ((uint32_t)__ffs((int)z) - 1u) / 8u;
+                const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 in every zero byte of x
+                bits |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * k);
             }
-            const unsigned long long m = __ballot(idx < 16u);
-            if (m) {
-                const int l = __ffsll((long long)m) - 1;
-                return pos + 16u * (uint32_t)l + (uint32_t)__builtin_amdgcn_readlane((int)idx, l);
-            }
-            pos += 1024;
-        } else {
-            uint64_t n = (((uintptr_t)d + pos) & 15u) ? 16u - (((uintptr_t)d + pos) & 15u) : 64u;
-            n = n < end - pos ? n : end - pos;
-            const bool hit = lane < n && d[pos + lane] == 0x47u;
-            const unsigned long long m = __ballot(hit);
-            if (m)
-                return pos + (uint64_t)(__ffsll((long long)m) - 1);
-            pos += n;
+            const uint32_t lo = rel > c0 ? rel - c0 : 0u;                    // (only the first lane's chunk starts in front of pos)
+            const uint32_t hi = lim - c0 < 16u ? lim - c0 : 16u;
+            bits &= ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+            if (bits)
+                idx = (uint32_t)__ffs((int)bits) - 1u;
         }
+        const unsigned long long m = __ballot(idx < 16u);
+        if (m) {
+            const int l = __ffsll((long long)m) - 1;
+            return w->win_base + (rel & ~15u) + 16u * (uint32_t)l + (uint32_t)__builtin_amdgcn_readlane((int)idx, l);
+        }
+        const uint32_t next = (rel & ~15u) + 1024u;
+        pos = w->win_base + (next < lim ? next : lim);
     }
     return end;
 }
@@ -91,6 +140,17 @@ __device__ __forceinline__ void dev_count(DevWalk *w, unsigned h1, unsigned h2)
 {
     const uint32_t rel = (uint32_t)w->packets;  // (a span counts < 2^32 packets)
     w->packets++;
+    if (w->quiet)
+        return;
+    if (w->g_count) {
+        if (w->lane == 0 && (h1 & 0x80u) == 0) {
+            const uint32_t pid = ((h1 & 0x1fu) << 8) | h2;
+            atomicAdd(&w->g_count[pid], 1u);
+            atomicMin(&w->g_first[pid], w->abs0 + rel + 1);
+            atomicMax(&w->g_last[pid], w->abs0 + rel + 1);
+        }
+        return;
+    }
     if (w->lane == 0 && (h1 & 0x80u) == 0) {  // transport_error_indicator clear, xport.c:2861-2867
         const uint32_t pid = ((h1 & 0x1fu) << 8) | h2;
         w->s_count[pid]++;
@@ -103,7 +163,7 @@ __device__ __forceinline__ void dev_count(DevWalk *w, unsigned h1, unsigned h2)
 
 __device__ __forceinline__ void dev_event(const DevWalk *w, uint64_t skipped, uint64_t at_rel)
 {
-    if (w->lane == 0) {
+    if (w->lane == 0 && !w->quiet) {
         const unsigned int slot = atomicAdd(w->event_count, 1u);  // (counts what no longer fits: the host sees the overflow)
         if (slot < w->event_cap) {
             ts_event e;
@@ -119,10 +179,11 @@ __device__ __forceinline__ void dev_event(const DevWalk *w, uint64_t skipped, ui
 #define TS_CORE_QUAL __device__ __forceinline__
 #define TS_CORE_NAME dev_walk_step
 #define TS_CORE_CTX DevWalk *
-#define TS_CORE_BYTE(ctx, off) ((unsigned)(ctx)->data[(off)])
+#define TS_CORE_BYTE(ctx, off) dev_byte(ctx, off)
 #define TS_CORE_FIND_SYNC(ctx, from, end) dev_find_sync(ctx, from, end)
 #define TS_CORE_COUNT(ctx, h1, h2) dev_count(ctx, h1, h2)
 #define TS_CORE_SYNC_ERROR(ctx, skipped) dev_event(ctx, skipped, (ctx)->packets)
+#define TS_CORE_STOP_AT(ctx, s) ((ctx)->stop_at == (s))
 #include "ts_walk_core.h"
 
 }  // namespace
@@ -161,6 +222,7 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
     __shared__ ts_walk_state s_st;
     __shared__ unsigned long long s_packets, s_block_packets;
     __shared__ uint32_t s_stop, s_walks, s_entries, s_cand;
+    __shared__ __attribute__((aligned(16))) unsigned char s_window[kWalkWindow];  // the walker's view of the stream (wave 0)
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t span = p.first_span + blockIdx.x;
     const uint64_t B0 = (uint64_t)span * p.span_bytes;
@@ -196,9 +258,12 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
     // from a state the host hands in: there; otherwise speculated — the first unit start in the span's first stride-ful
     // of bytes behind which the sync bytes sit on the grid) ----
     if (!p.explicit_entry && span != 0) {
-        if (t < p.stride) {
-            const uint64_t sy = B0 + t + p.sync_offset;
-            bool ok = sy < p.nbytes;
+        // (the first offset of the span behind which the sync bytes sit on the grid — normally within its first stride-ful of
+        // bytes; with damage right there, further in: the merge's bridge walks what lies in front, so the span is not lost)
+        for (uint32_t round = 0; round < kEntryRounds; round++) {
+            const uint64_t c = (uint64_t)round * kScanBlock + t;
+            const uint64_t sy = B0 + c + p.sync_offset;
+            bool ok = B0 + c < B1 && sy < p.nbytes;
             for (int i = 0; ok && i < kEntrySyncs; i++) {
                 const uint64_t at = sy + (uint64_t)i * p.stride;
                 if (at >= p.nbytes)
@@ -206,9 +271,12 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
                 ok = p.data[at] == 0x47u;
             }
             if (ok)
-                atomicMin(&s_cand, t);
+                atomicMin(&s_cand, (uint32_t)c);
+            __syncthreads();
+            if (s_cand != kNone || (uint64_t)(round + 1) * kScanBlock >= B1 - B0)  // (workgroup-uniform)
+                break;
+            __syncthreads();  // (everyone has read s_cand before the next round's candidates go in)
         }
-        __syncthreads();
         if (s_cand == kNone) {  // (workgroup-uniform) nothing regular here: the span in front carries the chain across
             if (t == 0) {
                 ts_span_rec r;
@@ -293,6 +361,7 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
                 }
                 if (quirk) {  // (about one packet in 4096 of a stream whose packets sit at odd offsets): the line is
                     DevWalk w;  // printed when the stream locks again, i.e. with this packet counted
+                    w.quiet = 0;
                     w.events = p.events;
                     w.event_count = p.event_count;
                     w.event_cap = p.event_cap;
@@ -327,13 +396,22 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
             w.span = span;
             w.attempt = p.attempt;
             w.lane = lane;
+            w.win = s_window;
+            w.nbytes = p.nbytes;
+            w.win_base = 0;
+            w.win_len = 0;  // (nothing in the window yet: the first byte asked for brings it in)
+            w.g_count = nullptr;
+            w.g_first = w.g_last = nullptr;
+            w.abs0 = 0;
+            w.stop_at = TS_NO_ENTRY;
+            w.quiet = 0;
             ts_walk_state s2 = st;
             for (;;) {
                 if (!dev_walk_step(&s2, &w, p.nbytes, 1))
                     break;  // the stream ended in front of the next packet (s2.pos == nbytes)
                 if (s2.pos >= p.nbytes)
                     break;
-                if (walk_is_clean(s2) && (s2.pos >= B1 || s2.pos + p.sync_offset >= p.nbytes || p.data[s2.pos + p.sync_offset] == 0x47u))
+                if (walk_is_clean(s2) && (s2.pos >= B1 || s2.pos + p.sync_offset >= p.nbytes || dev_byte(&w, s2.pos + p.sync_offset) == 0x47u))
                     break;  // (behind the span's end the next span takes over, grid or not: the merge sorts that out)
             }
             if (lane == 0) {
@@ -396,11 +474,13 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
                                                                unsigned long long *__restrict__ g_first,
                                                                unsigned long long *__restrict__ g_last,
                                                                unsigned long long *__restrict__ span_base,
+                                                               unsigned long long *__restrict__ span_bridge_base,
                                                                uint32_t *__restrict__ span_attempt,
                                                                ts_merge_out *__restrict__ out)
 {
     __shared__ uint32_t s_taken;
-    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_base, s_bridge_base;
+    __shared__ __attribute__((aligned(16))) unsigned char s_window[kWalkWindow];  // (the bridges' view of the stream)
     __shared__ ts_span_rec s_recs[TS_MAX_SPANS];  // (the chain walk is a serial loop: out of LDS, not out of HBM)
     const uint32_t t = threadIdx.x;
     const uint32_t me = from_span + blockIdx.x;
@@ -449,7 +529,7 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
     if (!s_broken) {
         if (t == 0) {
             s_taken = s_recs[me].attempt;
-            s_base = packet_base + s_sum_before;
+            s_base = s_bridge_base = packet_base + s_sum_before;
             if (blockIdx.x == 0) {
                 const ts_span_rec last = s_recs[p.nspans_total - 1];
                 out->valid_upto = p.nspans_total;
@@ -467,11 +547,18 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
                 out->pad2 = 0;
             }
         }
-    } else if (t == 0) {
+    } else if (t < 64u) {
+        // The chain does not hold everywhere: wave 0 goes along it, all lanes in step.  Where it arrives IN FRONT of the
+        // place a span assumed — damage at the span's beginning, which its speculated entry skipped — the walker BRIDGES
+        // the gap: from the chain's state up to the span's entry; if it gets there clean, the span's own findings stand,
+        // numbered behind the bridge's packets, and only the bridge was walked (a dry run first: what a bridge counts and
+        // reports must not be applied unless it arrives).  Every workgroup walks the bridges in front of its span (it
+        // needs its base); the one that owns the span applies them.  Only where that fails too (the chain arrives BEHIND
+        // the span's entry, or dirty, or nowhere near) does the host launch the span again.
         ts_walk_state cur = cur0;
         uint64_t base = packet_base, blockp = 0, walks = 0;
         uint32_t k = from_span, taken_me = 0;
-        uint64_t base_me = 0;
+        uint64_t base_me = 0, bridge_me = 0;
         for (; k < p.nspans_total; k++) {
             const uint64_t B1 = (k + 1 == p.nspans_total || (uint64_t)(k + 1) * p.span_bytes > p.nbytes) ? p.nbytes
                                                                                                         : (uint64_t)(k + 1) * p.span_bytes;
@@ -482,12 +569,63 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
             }
             const ts_span_rec r = s_recs[k];
             const bool clean = cur.skipped == 0 && cur.stale_af == 0 && (!cur.hdmv || cur.extra_pending == 4u);
-            const bool fits = r.entry == cur.pos && (clean || (r.explicit_entry && k == from_span));
+            bool fits = r.entry == cur.pos && (clean || (r.explicit_entry && k == from_span));
+            uint64_t bridge_base = base;
+            if (!fits && !r.explicit_entry && r.entry != TS_NO_ENTRY && cur.pos <= r.entry && r.entry - cur.pos <= kBridgeMax) {
+                DevWalk w;
+                w.data = p.data;
+                w.s_count = w.s_first = w.s_last = nullptr;
+                w.events = p.events;
+                w.event_count = p.event_count;
+                w.event_cap = p.event_cap;
+                w.span = k;
+                w.attempt = r.attempt | kBridgeEvent;
+                w.lane = t;
+                w.win = s_window;
+                w.nbytes = p.nbytes;
+                w.g_count = g_count;
+                w.g_first = g_first;
+                w.g_last = g_last;
+                w.abs0 = base;
+                w.stop_at = r.entry + p.sync_offset;  // the span's first sync byte: where its own findings begin
+                ts_walk_state s2 = cur;
+                for (int run = 0; run < 2; run++) {  // dry, then — if it arrives and the span is this workgroup's — for real
+                    w.quiet = run == 0 ? 1u : 0u;
+                    w.packets = 0;
+                    w.win_base = 0;
+                    w.win_len = 0;
+                    s2 = cur;
+                    bool arrived = false;
+                    for (uint32_t steps = 0; steps < kBridgeSteps; steps++) {
+                        const int rc = dev_walk_step(&s2, &w, p.nbytes, 1);
+                        if (rc == 2) {  // the search ended on that very byte; what an earlier packet still owed would
+                            arrived = s2.stale_af == 0;  // change how the span's first packet is taken: not the same stream
+                            break;
+                        }
+                        if (rc == 0 || s2.pos > w.stop_at)
+                            break;
+                    }
+                    if (!arrived)
+                        break;
+                    fits = true;
+                    // the line the reference prints when it locks there (xport.c:4324-4327): the span, which started
+                    // clean, did not know of the bytes skipped in front of it
+                    if (run == 1 && s2.skipped)
+                        dev_event(&w, s2.skipped, w.packets);
+                    if (k != me)
+                        break;
+                }
+                if (fits) {
+                    base += w.packets;
+                    walks++;
+                }
+            }
             if (!fits)
                 break;
             if (k == me) {
                 taken_me = r.attempt;
                 base_me = base;
+                bridge_me = bridge_base;
             }
             base += r.packets;
             blockp += r.block_packets;
@@ -497,17 +635,19 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
             cur.stale_af = r.exit_stale_af;
             cur.extra_pending = r.exit_extra;
         }
-        s_taken = k > me ? taken_me : 0u;  // (k <= me: the chain broke in front of this span)
-        s_base = base_me;
-        if (blockIdx.x == 0) {
-            out->valid_upto = k;
-            out->pad = 0;
-            out->packets = base;
-            out->cur = cur;
-            out->block_packets = blockp;
-            out->walks = walks;
-            out->events = *p.event_count;
-            out->pad2 = 0;
+        if (t == 0) {
+            s_taken = k > me ? taken_me : 0u;  // (k <= me: the chain broke in front of this span)
+            s_base = base_me;
+            s_bridge_base = bridge_me;
+            if (blockIdx.x == 0) {
+                out->valid_upto = k;
+                out->pad = 0;
+                out->packets = base;
+                out->cur = cur;
+                out->block_packets = blockp;
+                out->walks = walks;
+                out->pad2 = 0;
+            }
         }
     }
     __syncthreads();
@@ -516,6 +656,7 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
     if (t == 0) {
         span_attempt[me] = taken;
         span_base[me] = base;
+        span_bridge_base[me] = s_bridge_base;
     }
     if (!taken)
         return;  // (workgroup-uniform)
@@ -580,10 +721,10 @@ void ts_launch_scan(hipStream_t st, int blocks, const ts_scan_params &p)
 
 void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t from_span, uint64_t packet_base, const ts_walk_state &cur,
                      uint32_t *g_count, unsigned long long *g_first, unsigned long long *g_last, unsigned long long *span_base,
-                     uint32_t *span_attempt, ts_merge_out *out)
+                     unsigned long long *span_bridge_base, uint32_t *span_attempt, ts_merge_out *out)
 {
     hipLaunchKernelGGL(ts_merge_kernel, dim3(p.nspans_total - from_span), dim3(kMergeBlock), 0, st, p, from_span, packet_base, cur,
-                       g_count, g_first, g_last, span_base, span_attempt, out);
+                       g_count, g_first, g_last, span_base, span_bridge_base, span_attempt, out);
 }
 
 void ts_launch_generate(hipStream_t st, void *out, uint64_t nunits, uint32_t unit, uint64_t seed, int hdmv)

@@ -16,6 +16,9 @@
  *   TS_CORE_FIND_SYNC(ctx, from, end) first offset in [from, end) whose byte is 0x47, or `end`
  *   TS_CORE_COUNT(ctx, h1, h2)        a packet: header bytes 1 and 2 (xport.c:2860-2867)
  *   TS_CORE_SYNC_ERROR(ctx, skipped)  the stream locked again after `skipped` bytes (xport.c:4324-4327)
+ *   TS_CORE_STOP_AT(ctx, s)           optional: the search has ended on the sync byte at `s` — stop in front of that packet
+ *                                     (nothing reported, nothing consumed; st->pos == s, st->skipped as it stands)?
+ *                                     Then the step returns 2.  (The scan's merge walks up to a place it knows.)
  *
  *   sync search   (xport.c:4317-4373)  bytes that are not 0x47 are skipped and counted; HDMV mode swallows four
  *                                      bytes of tp_extra_header unconditionally in front of every search
@@ -33,6 +36,9 @@
  * packet was counted, 0 if the step stopped in front of one (the data ran out, or — eof == 0 — the packet and the byte
  * behind it are not all there yet: st->pos then says from where a later window must go on).
  */
+#ifndef TS_CORE_STOP_AT
+#define TS_CORE_STOP_AT(ctx, s) 0
+#endif
 TS_CORE_QUAL int TS_CORE_NAME(ts_walk_state *st, TS_CORE_CTX ctx, uint64_t end, int eof)
 {
     uint64_t p = st->pos;
@@ -53,6 +59,8 @@ TS_CORE_QUAL int TS_CORE_NAME(ts_walk_state *st, TS_CORE_CTX ctx, uint64_t end, 
     if (!eof && end - p < 189)
         return 0; /* the packet — and the byte behind it — must be in the window: ask for a later one */
     const uint64_t s = p, avail = end - s;
+    if (TS_CORE_STOP_AT(ctx, s))
+        return 2;
     if (st->skipped) { /* xport.c:4324-4327 */
         TS_CORE_SYNC_ERROR(ctx, st->skipped);
         st->skipped = 0;

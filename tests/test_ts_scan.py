@@ -224,9 +224,10 @@ def test_more_sync_errors_than_the_result_holds_inline(ts, gpu, tmp_path):
     assert res.report() == ts_oracle.report_lines(ref)
     if os.path.exists(ts_oracle.REF_CLI):
         assert res.report() == ts_oracle.reference_lines(path)
-    # damage costs walks on the device; a launch more only where it sits right behind a span boundary (here, with a
-    # damaged spot every 40 packets, that is one span in five)
-    assert res.walks >= n // period and res.launches <= 1 + 128
+    # damage costs walks on the device — in the span it sits in, or, right behind a span boundary, in the merge's bridge
+    # up to the span's speculated entry; a launch more only where the chain arrives BEHIND the place a span assumed
+    # (measured on this stream: 18 launches; before the bridges: one per damaged boundary, 50+)
+    assert res.walks >= n // period and res.launches <= 1 + 40
 
 
 @pytest.mark.gpu
