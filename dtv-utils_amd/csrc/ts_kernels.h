@@ -78,6 +78,8 @@ void ts_launch_scan(hipStream_t st, int blocks, const ts_scan_params &p);
 void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t from_span, uint64_t packet_base, const ts_walk_state &cur,
                      uint32_t *g_count, unsigned long long *g_first, unsigned long long *g_last, unsigned long long *span_base,
                      unsigned long long *span_bridge_base, uint32_t *span_attempt, ts_merge_out *out);
+void ts_launch_reset(hipStream_t st, uint32_t *g_count, unsigned long long *g_first, unsigned long long *g_last,
+                     unsigned int *event_count, uint32_t *span_attempt, uint32_t nspans);
 void ts_launch_generate(hipStream_t st, void *out, uint64_t nunits, uint32_t unit, uint64_t seed, int hdmv);
 void ts_launch_generate_damaged(hipStream_t st, void *out, uint64_t nbytes, uint64_t period, uint64_t seed);
 

@@ -707,6 +707,32 @@ void ts_launch_generate_damaged(hipStream_t st, void *out, uint64_t nbytes, uint
         hipLaunchKernelGGL(ts_generate_damaged_kernel, dim3(blocks), dim3(256), 0, st, (unsigned char *)out, nbytes, period, seed);
 }
 
+// what a scan starts from, in ONE launch (four memsets were four dispatches): empty tables — `first` is a min table and
+// starts at all-ones — no events, no span taken
+__global__ __launch_bounds__(256) void ts_reset_kernel(uint32_t *__restrict__ g_count, unsigned long long *__restrict__ g_first,
+                                                        unsigned long long *__restrict__ g_last, unsigned int *__restrict__ event_count,
+                                                        uint32_t *__restrict__ span_attempt, uint32_t nspans)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < TS_PIDS) {
+        g_count[i] = 0;
+        g_first[i] = ~0ull;
+        g_last[i] = 0;
+    }
+    if (i < nspans)
+        span_attempt[i] = 0;
+    if (i == 0)
+        *event_count = 0;
+}
+
+void ts_launch_reset(hipStream_t st, uint32_t *g_count, unsigned long long *g_first, unsigned long long *g_last,
+                     unsigned int *event_count, uint32_t *span_attempt, uint32_t nspans)
+{
+    const uint32_t n = nspans > TS_PIDS ? nspans : TS_PIDS;
+    hipLaunchKernelGGL(ts_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g_count, g_first, g_last, event_count, span_attempt,
+                       nspans);
+}
+
 void ts_kernels_prepare_device(void)  // function attributes belong to the current device
 {
     const int lds = 3 * TS_PIDS * (int)sizeof(uint32_t);

@@ -350,10 +350,7 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
     std::vector<uint32_t> taken(nspans);
     float ms_total = 0.f, ms_merge = 0.f;
     for (int round = 0;; round++) {  // (a second round only when the event list turned out too small)
-        TSCHK(ctx, hipMemsetAsync(ctx->d_count, 0, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long)), ctx->stream));
-        TSCHK(ctx, hipMemsetAsync(ctx->d_first, 0xFF, TS_PIDS * sizeof(unsigned long long), ctx->stream));  // min table
-        TSCHK(ctx, hipMemsetAsync(ctx->d_event_count, 0, sizeof(unsigned int), ctx->stream));
-        TSCHK(ctx, hipMemsetAsync(ctx->d_span_attempt, 0, nspans * sizeof(uint32_t), ctx->stream));
+        ts_launch_reset(ctx->stream, ctx->d_count, ctx->d_first, ctx->d_last, ctx->d_event_count, ctx->d_span_attempt, nspans);
         ts_scan_params p{};
         p.data = ctx->d_data;
         p.nbytes = ctx->n;
