@@ -24,7 +24,10 @@ its own 10 GiB shard of an N x 10 GiB stream (weak scaling; N=8 is configs[3]).
 
 Launched by the driver as
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
-Rank 0 prints ONE JSON line.  Inputs are already resident in HBM when the timed
+one rank per GPU; the step's exchanges between the ranks are RCCL collectives on device buffers, queued by libpaprhip on
+its own communicator and stream (--backend nccl, the default).  The bench's own bookkeeping — the barrier around the
+timed steps, the max of the ranks' times, handing the RCCL id round — goes over gloo (--control), because a second RCCL
+communicator (torch's) in the process costs the sweep kernel 1.3 % and the step 10 us.  Rank 0 prints ONE JSON line.  Inputs are already resident in HBM when the timed
 region starts (generated on the device by the shared counter-hash generator).
 """
 from __future__ import annotations
@@ -237,7 +240,7 @@ def run_mode(args, mode, env):
     result.clear()
     result.update(kept)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.control == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -342,7 +345,7 @@ def run_mode(args, mode, env):
                         "papr_exact_kernels": {"avg_ms": k_exact, "GB/s": gbs_exact, "launches": int(tm_x.exact_launches)},
                         "host_and_exchange_ms_per_step": ms_per_step - kernel_ms_per_step},
             # host wall time inside the C-ABI exchanges (H2D + collective + D2H + one stream sync each), rank 0
-            "exchange": {"transport": xch.transport, "world": world, **xt},
+            "exchange": {"transport": xch.transport, "world": world, "bench_bookkeeping_over": args.control if use_dist else None, **xt},
             "device": gpu.name,
         }
         return line
@@ -380,7 +383,7 @@ def run_ts(args, rank, world, local_rank, use_dist):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank) if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank) if args.control == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank != 0:
@@ -504,6 +507,11 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend; gloo (+ ranks sharing GPUs round-robin) exists so the N>1 "
                          "code path can be exercised on a box with fewer GPUs than ranks")
+    ap.add_argument("--control", choices=["gloo", "nccl"], default="gloo",
+                    help="what carries the bench's OWN bookkeeping between the ranks (the barrier around the timed steps, the "
+                         "max of the ranks' times, the RCCL id): gloo by default — the data path's collectives are RCCL either "
+                         "way (--backend nccl), but a second RCCL communicator, torch's, beside the one the step uses costs "
+                         "the sweep kernel 1.3 %% and the step 10 us (measured at world size 1)")
     ap.add_argument("--cpu-sample-gib", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
@@ -531,6 +539,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the papr product has no CPU path")
     if args.backend == "gloo":
+        args.control = "gloo"
+    if args.backend == "gloo":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -538,7 +548,7 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if args.backend == "nccl":
+        if args.control == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)

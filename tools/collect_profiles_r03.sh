@@ -19,6 +19,8 @@ $B --workload ts                     > $O/bench_ts.json 2> $O/bench_ts.err
 $B --workload ts --damage 1e-4       > $O/bench_ts_damage.json 2> $O/bench_ts_damage.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
     $R/bench.py --gpus 1 $H > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29535 \
+    $R/bench.py --gpus 1 $H --control nccl > $O/bench_torchrun1_nccl_control.json 2> $O/bench_torchrun1_nccl_control.err
 PAPR_XCH_IN_STREAM=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 \
     $R/bench.py --gpus 1 $H > $O/bench_torchrun1_hostpath.json 2> $O/bench_torchrun1_hostpath.err
 for SIG in bursty constant; do $B $H --signal $SIG > $O/bench_$SIG.json 2> $O/bench_$SIG.err; done
