@@ -65,7 +65,7 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_estimate_kernel(const float4 
         for (int u = 0; u < U; u++) {
             const uint64_t row = g * kRows + (uint64_t)u * (PAPR_BLOCK / kWave) + wave;
             const uint64_t tile = g * ratio + papr_estimate_pick(row, ratio);
-            x[u] = load16<false>(data + tile * TILE_F4 + (uint64_t)u * PAPR_BLOCK + threadIdx.x);
+            x[u] = load16<true>(data + tile * TILE_F4 + (uint64_t)u * PAPR_BLOCK + threadIdx.x);
         }
         double gsum = 0.0;
 #pragma unroll
