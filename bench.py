@@ -33,6 +33,7 @@ region starts (generated on the device by the shared counter-hash generator).
 from __future__ import annotations
 
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -49,6 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
+E2E_RUNS = 5         # timed runs of bin/papr per table in the e2e leg: the median is reported
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -137,25 +139,27 @@ def e2e_block(pkg, gib: float):
         for _ in range(2):
             subprocess.run([pkg.CLI_PATH, path], capture_output=True)
         for graph, tag in ((False, "default"), (True, "graph")):
-            best = None
-            for _ in range(2):   # the first run of a session also pays for loading the GPU runtime
+            runs = []
+            for _ in range(E2E_RUNS):
                 # (a process that has just exited is still being taken down by the driver — 10 GiB of HBM to unmap — and a
                 # runtime that starts during that takes 0.2 s instead of 0.08 to come up: every run starts on a quiet GPU)
                 time.sleep(0.75)
                 t0 = time.perf_counter()
                 p = subprocess.run([pkg.CLI_PATH] + (["-g"] if graph else []) + [path], capture_output=True,
                                    env=dict(os.environ, PAPR_STATS="1"))
-                dt = time.perf_counter() - t0
-                if best is None or dt < best[0]:
-                    best = (dt, p)
-            dt, p = best
+                runs.append((time.perf_counter() - t0, p))
+            runs.sort(key=lambda r: r[0])
+            dt, p = runs[len(runs) // 2]   # the MEDIAN run, and its own PAPR_STATS line
             golden, name = golden_report(1, gib, graph)
             info = {}
             try:
                 info = json.loads(p.stderr.decode().splitlines()[-1])
             except Exception:
                 pass
-            out[tag] = {"seconds": dt, "msamples_per_s": n / dt / 1e6, "rc": p.returncode,
+            out[tag] = {"seconds": dt, "seconds_is": f"median of {E2E_RUNS} runs (after 2 untimed ones)",
+                        "seconds_all": [round(r[0], 4) for r in runs],
+                        "all_stdout_identical": None if golden is None else all(r[1].stdout == golden for r in runs),
+                        "msamples_per_s": n / dt / 1e6, "rc": p.returncode,
                         "stdout_identical_to_reference": None if golden is None else p.stdout == golden,
                         "ingest_GBps": info.get("ingest_GBps"),
                         "ingest_frac_of_h2d_ceiling": (round(info["ingest_GBps"] / ceiling, 3)
@@ -167,6 +171,32 @@ def e2e_block(pkg, gib: float):
         if os.path.exists(path):
             os.unlink(path)
     return out
+
+
+def step_summary(step_s):
+    """min / median / p90 / max of the timed steps in ms, and which step was the slowest."""
+    ms = np.asarray(step_s, dtype=np.float64) * 1e3
+    if ms.size == 0:
+        return None
+    return {"min": round(float(ms.min()), 4), "median": round(float(np.median(ms)), 4),
+            "p90": round(float(np.percentile(ms, 90)), 4), "max": round(float(ms.max()), 4),
+            "slowest": int(ms.argmax()), "n": int(ms.size),
+            "all": [round(float(v), 3) for v in ms[:64]]}
+
+
+def brief(summary):
+    """A step summary without its list (the legs' one-liners inside the headline's roofline)."""
+    return None if summary is None else {k: v for k, v in summary.items() if k != "all"}
+
+
+def leg_summary(line):
+    """What the driver's record needs of a member leg (it keeps `roofline` and `config` whole, nothing else of a member)."""
+    r = line["roofline"]
+    return {"ms_per_step": round(line["ms_per_step"], 4), "value": round(line["value"], 1), "kernel": r["kernel"],
+            "kernel_ms": round(r["kernel_ms"], 4), "frac": round(r["frac"], 4), "step_ms": brief(r.get("step_ms")), "kernel_launch_ms": brief(r.get("kernel_launch_ms")),
+            "host_and_exchange_ms_per_step": round(r["host_and_exchange_ms_per_step"], 4),
+            "all_kernels_frac_of_peak": round(line["kernels"]["all_kernels_frac_of_peak"], 4),
+            "parity_in_run": line["parity_in_run"], "steps": line["steps"], "warmup": line["warmup"]}
 
 
 def golden_report(world: int, gib: float, graph: bool):
@@ -211,22 +241,39 @@ def run_mode(args, mode, env):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The timing mode of the timed steps is on BEFORE the warm-up: a kernel launch with a pair of events bound to it
+    # (hipExtLaunchKernelGGL) is its own path through the runtime — its first use, like every other first use of the step,
+    # belongs to the warm-up, and the event pairs exist before the first of them is queued (papr_hip_set_timing).
+    # HIP events on the kernels that read the shard (the roofline's kernel among them), bound to their dispatches; the
+    # small estimate / recount kernels are timed in extra steps behind the timed region — a timed kernel carries a
+    # completion signal of its own, which costs the stream ~5 us on either side (profiles/r02_step_timeline.txt)
+    gc_was_on = gc.isenabled()
+    gc.collect()   # (before the warm-up: nothing may leave the GPU idle between the warm-up and the timed steps)
+    gc.disable()
+    gpu.set_timing(2)
     for _ in range(args.warmup):
         step()
     for k in ("resolved", "redo_tiles", "reruns", "exact_done"):
         result.pop(k, None)
     xch.timing(reset=True)
-    # HIP events on the kernels that read the shard (the roofline's kernel among them), bound to their dispatches; the
-    # small estimate / recount kernels are timed in extra steps behind the timed region — a timed kernel carries a
-    # completion signal of its own, which costs the stream ~5 us on either side (profiles/r02_step_timeline.txt)
     gpu.set_timing(2)
+    # Every step ends in its one wait, so the host clock around a step is that step's time: kept per step, so that the
+    # line can say whether `value` (total / elapsed, below) is twenty equal steps or nineteen and a stall.
+    step_s = [0.0] * args.steps
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    t_prev = t0
+    for i in range(args.steps):
         step()
+        t_now = time.perf_counter()
+        step_s[i] = t_now - t_prev
+        t_prev = t_now
     fence()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     tm = gpu.timing()
+    launch_ms = {kind: gpu.timing_launches(kind) for kind in (0, 1, 2, 3)}   # per launch, in dispatch order
     xt = xch.timing().as_dict()
     if one_sweep:
         result["sweep_info"] = gpu.sweep_info().as_dict()
@@ -323,6 +370,15 @@ def run_mode(args, mode, env):
                          "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                          "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": per_gpu * 8,
                          "kernel_variant": kernel_variant, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                         # the timed region step by step (host clock around each papr_hip_analyze, which ends in the step's
+                         # one wait): `value` = total / elapsed, i.e. the MEAN — a stall shows as max >> median here
+                         "step_ms": step_summary(step_s),
+                         # the dominant kernel launch by launch (HIP events bound to the dispatches): is it the kernel or
+                         # the host that makes a slow step slow
+                         "kernel_launch_ms": step_summary(launch_ms[{"papr_stats_kernel": 0, "papr_ccdf_kernel": 1,
+                                                                     "papr_exact_seg_kernel<CCDF>": 2}.get(dom, 3)] / 1e3),
+                         "kernels_ms_per_step": kernel_ms_per_step,
+                         "host_and_exchange_ms_per_step": ms_per_step - kernel_ms_per_step,
                          # SURVEY.md 8(d) prices a papr result at 16 B/sample (two reads: 500 000 Msamples/s = 100 %).  The
                          # sweep kernel does the work of both passes in ONE read, so `frac` above is priced on the 8 B/sample
                          # it actually moves; on the survey's two-pass convention the same launch retires 16 B/sample:
@@ -372,13 +428,21 @@ def run_ts(args, rank, world, local_rank, use_dist):
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
+    step_s = [0.0] * args.steps
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
+    t_prev = t0
     kernel_ms = merge_ms = 0.0
-    for _ in range(args.steps):
+    for i in range(args.steps):
         res = gpu.scan()
         kernel_ms += res.kernel_ms
         merge_ms += res.merge_ms
+        t_now = time.perf_counter()
+        step_s[i] = t_now - t_prev
+        t_prev = t_now
     torch.cuda.synchronize()
+    gc.enable()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -423,6 +487,7 @@ def run_ts(args, rank, world, local_rank, use_dist):
                      "unit": "GB/s", "frac": (line_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms else 0.0,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "ts_scan_kernel", "kernel_ms": k_ms, "merge_kernel_ms": merge_ms / args.steps,
+                     "step_ms": step_summary(step_s),
                      "algorithmic_bytes_per_launch": line_bytes,
                      "algorithmic_bytes_note": f"{lines_per_packet:.4f} 128-byte lines per packet (the header's); the stream "
                                                f"itself is {nbytes} bytes"},
@@ -609,8 +674,10 @@ def main():
         ts_line = run_ts(ts_args, rank, world, local_rank, use_dist)
     if rank == 0:
         line = lines[0]
+        legs = {}
         if len(lines) > 1:   # configs[2] rides along: same shard, same code path, the 0.1 dB table
             line["graph"] = {k: lines[1][k] for k in GRAPH_KEYS}
+            legs["graph"] = leg_summary(lines[1])
         if exact_lines:
             want_sum = None
             try:
@@ -628,8 +695,13 @@ def main():
             ex["what"] = ("the same step with the reference's sequential double sum (papr.c:104) reproduced bit for bit in "
                           "the same single read: bin/papr's default arithmetic")
             line["exact"] = ex
+            legs["exact"] = dict(leg_summary(exact_lines[0]), sum_is_the_reference_s=ex["sum_is_the_reference_s"])
+            legs["exact_graph"] = dict(leg_summary(exact_lines[1]), sum_is_the_reference_s=ex["graph"]["sum_is_the_reference_s"])
         if ts_line:
             line["ts"] = ts_line
+            legs["ts"] = {"ms_per_step": round(ts_line["ms_per_step"], 4), "value": round(ts_line["value"], 1),
+                          "unit": ts_line["unit"], "kernel_ms": round(ts_line["roofline"]["kernel_ms"], 4),
+                          "frac": round(ts_line["roofline"]["frac"], 4), "step_ms": brief(ts_line["roofline"].get("step_ms"))}
         if world == 1 and not args.no_cpu_baseline:
             mode0 = modes[0]
             sample = args.cpu_sample_gib if args.cpu_sample_gib else (1.0 if mode0 == "graph" else 4.0)   # ~10-15 s of reference CPU time
@@ -649,6 +721,13 @@ def main():
                 line["e2e"] = e2e_block(pkg, args.gib)
             except Exception as e:
                 line["e2e"] = {"error": repr(e)}
+            for tag in ("default", "graph"):
+                if isinstance(line["e2e"].get(tag), dict):
+                    legs["e2e_" + tag] = {k: line["e2e"][tag].get(k) for k in
+                                          ("seconds", "seconds_is", "open_s", "ingest_GBps", "ingest_frac_of_h2d_ceiling",
+                                           "all_stdout_identical")}
+        if legs:   # the driver's record keeps `roofline` whole and drops the members: their one-line summaries live here
+            line["roofline"]["legs"] = legs
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)

@@ -31,7 +31,7 @@ MAX_LEVELS = 16384
 ABI_SYMBOLS = (
     "papr_hip_abi_version", "papr_hip_device_count", "papr_hip_open", "papr_hip_close",
     "papr_hip_last_error", "papr_hip_device_name", "papr_hip_set_tuning", "papr_hip_set_timing",
-    "papr_hip_get_timing", "papr_file_samples", "papr_hip_load_file", "papr_hip_get_ingest_timing", "papr_hip_upload",
+    "papr_hip_get_timing", "papr_hip_get_timing_launches", "papr_file_samples", "papr_hip_load_file", "papr_hip_get_ingest_timing", "papr_hip_upload",
     "papr_hip_adopt", "papr_hip_generate", "papr_hip_download", "papr_hip_stats",
     "papr_stats_init", "papr_stats_merge", "papr_levels", "papr_hip_ccdf",
     "papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
@@ -197,6 +197,8 @@ def lib() -> C.CDLL:
     L.papr_hip_sweep_variant_built.argtypes = [i32]
     L.papr_hip_sweep_variant_built.restype = i32
     L.papr_hip_get_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.papr_hip_get_timing_launches.argtypes = [vp, i32, vp, i32]
+    L.papr_hip_get_timing_launches.restype = i32
     L.papr_file_samples.argtypes = [C.c_char_p, C.POINTER(u64)]
     L.papr_hip_load_file.argtypes = [vp, C.c_char_p, u64, u64]
     L.papr_hip_get_ingest_timing.argtypes = [vp, C.POINTER(IngestTiming)]
@@ -405,6 +407,14 @@ class PaprHip:
     def set_timing(self, enabled):
         """False / 0 off, True / 1 every timed kernel, 2 only the kernels that read the shard (include/papr_hip.h)."""
         self._chk(self._L.papr_hip_set_timing(self._ctx, int(enabled)), "papr_hip_set_timing")
+
+    def timing_launches(self, kind: int, cap: int = 4096) -> np.ndarray:
+        """Durations (ms) of the timed launches of one class, in dispatch order (3 = the sweep kernel)."""
+        buf = np.zeros(cap, dtype=np.float32)
+        n = self._L.papr_hip_get_timing_launches(self._ctx, int(kind), buf.ctypes.data_as(C.c_void_p), cap)
+        if n < 0:
+            self._chk(n, "papr_hip_get_timing_launches")
+        return buf[:min(n, cap)].copy()
 
     def timing(self) -> Timing:
         t = Timing()

@@ -732,6 +732,18 @@ int papr_hip_set_timing(papr_hip_ctx *ctx, int enabled)
     ctx->timing = enabled != 0;
     ctx->timing_aux = enabled == 1;
     ctx->timed_used = 0;
+    // the event pairs of the first few hundred timed launches exist before the first of them is queued: creating
+    // them on demand put the runtime's signal-pool growth inside a benchmark's timed region
+    while (enabled && ctx->timed.size() < 256) {
+        TimedLaunch t{};
+        if (hipEventCreate(&t.a) != hipSuccess)
+            break;
+        if (hipEventCreate(&t.b) != hipSuccess) {
+            (void)hipEventDestroy(t.a);
+            break;
+        }
+        ctx->timed.push_back(t);
+    }
     return PAPR_OK;
 }
 
@@ -768,6 +780,27 @@ int papr_hip_get_timing(papr_hip_ctx *ctx, papr_hip_timing *out)
         }
     }
     return PAPR_OK;
+}
+
+int papr_hip_get_timing_launches(papr_hip_ctx *ctx, int kind, float *ms, int cap)
+{
+    if (!ctx || cap < 0 || (cap && !ms))
+        return PAPR_E_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return fail(ctx, PAPR_E_HIP, "stream synchronisation failed");
+    int n = 0;
+    for (size_t k = 0; k < ctx->timed_used; k++) {
+        const int cls = ctx->timed[k].kind == 5 ? 2 : ctx->timed[k].kind;
+        if (cls != kind)
+            continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, ctx->timed[k].a, ctx->timed[k].b) != hipSuccess)
+            return fail(ctx, PAPR_E_HIP, "hipEventElapsedTime failed");
+        if (n < cap)
+            ms[n] = t;
+        n++;
+    }
+    return n;
 }
 
 // ---- shard residency ------------------------------------------------------------

@@ -79,6 +79,10 @@ int papr_hip_sweep_variant_built(int variant);
  * kernels in separate steps.  Also resets the counters. */
 int papr_hip_set_timing(papr_hip_ctx *ctx, int enabled);
 int papr_hip_get_timing(papr_hip_ctx *ctx, papr_hip_timing *out);
+/* The same launches one by one, in dispatch order: durations (ms) of the timed launches of one class (0 pass 1, 1 pass 2,
+ * 2 exact-sum kernels, 3 the sweep, 4 estimate / recount) into ms[0 .. cap); returns how many there were (may exceed cap),
+ * or a negative PAPR_E_* code.  A benchmark reports min / median / max of its dominant kernel from this. */
+int papr_hip_get_timing_launches(papr_hip_ctx *ctx, int kind, float *ms, int cap);
 
 int papr_hip_get_ingest_timing(const papr_hip_ctx *ctx, papr_hip_ingest_timing *out);
 
