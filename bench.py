@@ -50,6 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
+PREHEAT_STEPS = 32   # untimed steps (~50-70 ms) in front of every leg's warm-up (see run_mode)
 E2E_RUNS = 5         # timed runs of bin/papr per table in the e2e leg: the median is reported
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
@@ -251,6 +252,16 @@ def run_mode(args, mode, env):
     gc.collect()   # (before the warm-up: nothing may leave the GPU idle between the warm-up and the timed steps)
     gc.disable()
     gpu.set_timing(2)
+    # Pre-heat, in front of the W warm-up steps and like them untimed: an idle MI355X needs ~15-20 ms of load before its
+    # kernels run at their steady speed (profiles/r04_driver_command_repeat.txt: with five 1.6 ms warm-up steps alone, the
+    # first six TIMED sweeps took 1.64, 1.64, 1.62, 1.60, 1.57, 1.55 ms before settling at 1.53), and every leg of this
+    # script starts on a GPU that has been idle while the host set the leg up.  Disclosed in config.preheat.
+    preheat_steps = PREHEAT_STEPS   # (a COUNT, not a duration: with peers every step holds collectives all ranks must enter)
+    t_heat = time.perf_counter()
+    for _ in range(preheat_steps):
+        step()
+    result["preheat"] = {"steps": preheat_steps, "seconds": round(time.perf_counter() - t_heat, 4),
+                         "what": "untimed steps in front of the warm-up steps: the idle GPU reaches its steady speed after ~20 ms of load"}
     for _ in range(args.warmup):
         step()
     for k in ("resolved", "redo_tiles", "reruns", "exact_done"):
@@ -349,6 +360,7 @@ def run_mode(args, mode, env):
                                    f"({'0.1 dB CCDF' if graph else 'peak+mean+1 dB histogram'}), HBM-resident, "
                                    f"{world}xMI355X",
                        "mode": args.mode, "signal": args.signal, "forced_miss": bool(args.force_miss),
+                       "preheat": result.get("preheat"),
                        "samples_per_gpu": per_gpu, "samples_total": total,
                        "levels": int(result["table"].size), "papr_db": round(float(result["papr"]), 6),
                        "reads_of_the_shard_per_step": 1 if one_sweep and result.get("resolved", 0) == args.steps else 2,
@@ -423,6 +435,9 @@ def run_ts(args, rank, world, local_rank, use_dist):
     else:
         gpu.generate(npackets, seed=0x7500001 + rank)
     res = None
+    preheat_steps = PREHEAT_STEPS
+    for _ in range(preheat_steps):   # (as run_mode: the idle GPU's first ~20 ms of load are slower)
+        res = gpu.scan()
     for _ in range(args.warmup):
         res = gpu.scan()
     torch.cuda.synchronize()
@@ -479,6 +494,7 @@ def run_ts(args, rank, world, local_rank, use_dist):
                                f"MPEG-2 TS per GPU, HBM-resident, {world}xMI355X", "packets_per_gpu": npackets,
                    "bytes_per_gpu": nbytes, "launches_per_scan": int(res.launches), "walks_per_scan": int(res.walks),
                    "damage": (f"one damaged spot every {period} packets (include/ts_synth.h: ts_synth_damaged_byte)" if period else None),
+                   "preheat": {"steps": preheat_steps, "what": "untimed scans in front of the warm-up"},
                    "sync_error_lines": int(res.nsync_errors), "packets_counted": int(res.packets),
                    "pids_seen": int(np.count_nonzero(res.tables()[0])), "sharding": "independent streams, no exchange",
                    "report_sha256": hashlib.sha256(res.report()).hexdigest(),

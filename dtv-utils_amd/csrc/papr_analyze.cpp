@@ -43,6 +43,31 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
         }
     };
     auto replay_when_ready = [&] {
+        if (ctx->xprog_ready) {
+            // peers, single-wait step: every rank's program crossed the exchange in the stream and lies in its slot of
+            // h_xprog_all (papr_sweep_rt.cpp) — replayed here in rank (= file) order, on every rank alike.  A slot that is
+            // marked (a program that outgrew it, or is not final) or is no program: nothing is replayed, and every rank —
+            // they all see the same slots — exchanges the programs on the host further down.
+            ctx->xprog_ready = false;
+            const int world = ctx->xprog_world;
+            std::vector<const void *> progs((size_t)world);
+            std::vector<size_t> sizes((size_t)world);
+            for (int r = 0; r < world; r++) {
+                const unsigned char *slot = ctx->h_xprog_all + (size_t)r * ctx->xprog_slot;
+                papr_exact_header h;
+                memcpy(&h, slot, sizeof(h));
+                const size_t want = sizeof(h) + (size_t)h.ngroups * sizeof(papr_exact_group_rec) +
+                                    (size_t)h.nmixed * sizeof(papr_exact_mixed_rec) + (size_t)h.nraw * sizeof(papr_exact_raw_rec) +
+                                    (size_t)h.tail_samples * 8;
+                if (h.magic != PAPR_EXACT_MAGIC || h.reserved != 0 || want > ctx->xprog_slot || env_int("PAPR_EXACT_HOST_ASSEMBLY", 0))
+                    return;
+                progs[(size_t)r] = slot;
+                sizes[(size_t)r] = want;
+            }
+            crc = papr_exact_chain(progs.data(), sizes.data(), world, &seq);
+            replayed = true;
+            return;
+        }
         if (*ctx->h_redo_count > kCapRedo)
             return;  // too many tiles to rebuild: the program is not final yet
         const size_t nbytes = swept_program_bytes(ctx);
@@ -55,7 +80,7 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
     PeerStep peer;
     if (!(flags & PAPR_ANALYZE_TWO_PASS)) {
         const bool alone = papr_exchange_is_identity(x);
-        if (ctx->exact && alone)
+        if (ctx->exact)  // (with peers: only the single-wait step over an in-stream exchange leaves work for it)
             ctx->overlap_work = replay_when_ready;
         // estimate, guess (on the device) and sweep in one sequence of launches, one wait (papr_sweep_rt.cpp) — alone, or
         // with the exchanges as collectives on the stream when the transport has them (RCCL)

@@ -187,8 +187,11 @@ __global__ __launch_bounds__(256) void papr_exact_block_sums(const double *__res
 // in-place exclusive scan of the block sums, starting from `before` (the accurate
 // sum of everything that precedes this shard in the file)
 __global__ __launch_bounds__(256) void papr_exact_scan_blocks(double *__restrict__ block_sums, uint32_t nblocks,
-                                                               double before, uint32_t *__restrict__ zero_word)
+                                                               double before, uint32_t *__restrict__ zero_word,
+                                                               const double *__restrict__ before_dev)
 {
+    if (before_dev)
+        before = *before_dev;  // (peers, single-wait step: the merged records' sum in front of this shard is on the device)
     if (zero_word && threadIdx.x == 0)
         *zero_word = 0;  // (the redo list's counter, for the classification that follows: saves a memset in the stream)
     __shared__ double sh[256];
@@ -226,8 +229,15 @@ __global__ __launch_bounds__(256) void papr_exact_classify(const double *__restr
                                                             uint32_t *__restrict__ ambig_count,
                                                             const int32_t *__restrict__ spec,
                                                             uint32_t *__restrict__ redo_list, uint32_t redo_cap,
-                                                            uint32_t *__restrict__ redo_count)
+                                                            uint32_t *__restrict__ redo_count,
+                                                            const unsigned long long *__restrict__ n_total_dev,
+                                                            unsigned long long n_shard)
 {
+    if (n_total_dev) {  // (peers: the file's length is known on the device only — the margin as the host computes it)
+        const unsigned long long nt = *n_total_dev;
+        const double d = 8.0 * (double)(nt > n_shard ? nt : n_shard) * 1.1102230246251565e-16;
+        delta = d > 1.0e-6 ? d : 1.0e-6;
+    }
     __shared__ double sh[256];
     const uint64_t t0 = (uint64_t)blockIdx.x * kTilesPerBlock + (uint64_t)threadIdx.x * 4;
     double s[4], tot = 0.0;
@@ -567,13 +577,19 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(const papr_exact_p
                                                                uint32_t cap_mixed, uint32_t cap_raw,
                                                                unsigned char *__restrict__ out,
                                                                const uint32_t *__restrict__ count_src,
-                                                               uint32_t *__restrict__ count_dst)
+                                                               uint32_t *__restrict__ count_dst, uint64_t out_cap,
+                                                               uint32_t redo_cap)
 {
     const uint32_t nmixed = plan->nmixed, nraw = plan->nraw;
     const size_t off_groups = 48;  // sizeof(papr_exact_header)
     const size_t off_mixed = off_groups + ngroups * 24;
     const size_t off_raw = off_mixed + (size_t)nmixed * 4616;
     const size_t off_tail = off_raw + (size_t)nraw * 16392;
+    // a bounded destination (the slot of the in-stream program exchange): a program that does not fit leaves only its
+    // header, marked — every rank sees that and all of them take the host path
+    const bool fits = out_cap == 0 || off_tail + (size_t)tail_samples * 8 <= out_cap;
+    if (!fits && blockIdx.x + 1 != gridDim.x)
+        return;
     uint32_t b = blockIdx.x;
     if (b < group_blocks) {  // group table, 8 bytes per thread per step
         const uint64_t words = ngroups * 3;
@@ -618,7 +634,7 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(const papr_exact_p
     // last workgroup: the tail samples and the header (layout of papr_exact_header)
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(tail_src);
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(out + off_tail);
-    for (uint32_t k = threadIdx.x; k < tail_samples; k += 256)
+    for (uint32_t k = threadIdx.x; fits && k < tail_samples; k += 256)
         dst[k] = src[k];
     if (threadIdx.x == 0) {
         uint32_t *h32 = reinterpret_cast<uint32_t *>(out);
@@ -631,7 +647,9 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(const papr_exact_p
         h32[8] = tail_samples;
         h32[9] = nmixed;
         h32[10] = nraw;
-        h32[11] = plan->overflow;  // reserved word: non-zero = lists were truncated, do not use this program
+        // reserved word: non-zero = do not use this program (1: the lists were truncated; 2: it did not fit its slot;
+        // 4: more tiles to redo than the list holds — the pairs are not final)
+        h32[11] = plan->overflow | (fits ? 0u : 2u) | ((redo_cap && count_src && *count_src > redo_cap) ? 4u : 0u);
         if (count_dst)
             *count_dst = *count_src;  // (the redo count, to mapped host memory with the program: saves a D2H copy)
     }
@@ -647,10 +665,11 @@ void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, ui
     if (nb == 0)
         return;
     hipLaunchKernelGGL(papr_exact_block_sums<false>, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums);
-    hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before, (uint32_t *)nullptr,
+                       (const double *)nullptr);
     hipLaunchKernelGGL(papr_exact_classify<false>, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums, delta,
                        tile_E, ambig_list, ambig_cap, ambig_count, (const int32_t *)nullptr, (uint32_t *)nullptr, 0u,
-                       (uint32_t *)nullptr);
+                       (uint32_t *)nullptr, (const unsigned long long *)nullptr, 0ull);
     if (ambig_list)
         hipLaunchKernelGGL(papr_exact_sort_list_kernel, dim3(1), dim3(512), 0, st, ambig_list, ambig_count, ambig_cap,
                            ambig_sorted);
@@ -661,16 +680,18 @@ void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, ui
 void papr_launch_exact_classify_swept(hipStream_t st, const void *seg_D, uint64_t ntiles, double *block_sums, double before,
                                       double delta, int32_t *tile_E, const int32_t *spec, uint32_t *redo_list,
                                       uint32_t redo_cap, uint32_t *redo_count, uint32_t *ambig_list, uint32_t ambig_cap,
-                                      uint32_t *ambig_count, uint32_t *ambig_sorted)
+                                      uint32_t *ambig_count, uint32_t *ambig_sorted, const double *before_dev,
+                                      const unsigned long long *n_total_dev, uint64_t n_shard)
 {
     const uint32_t nb = (uint32_t)((ntiles + kTilesPerBlock - 1) / kTilesPerBlock);
     if (nb == 0)
         return;
     const double *sums = (const double *)seg_D;
     hipLaunchKernelGGL(papr_exact_block_sums<true>, dim3(nb), dim3(256), 0, st, sums, ntiles, block_sums);
-    hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before, redo_count);
+    hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before, redo_count, before_dev);
     hipLaunchKernelGGL(papr_exact_classify<true>, dim3(nb), dim3(256), 0, st, sums, ntiles, block_sums, delta, tile_E,
-                       ambig_list, ambig_cap, ambig_count, spec, redo_list, redo_cap, redo_count);
+                       ambig_list, ambig_cap, ambig_count, spec, redo_list, redo_cap, redo_count, n_total_dev,
+                       (unsigned long long)n_shard);
     if (ambig_list)  // a streamed shard: the unprovable tiles, ascending (they are read back from the file for the program)
         hipLaunchKernelGGL(papr_exact_sort_list_kernel, dim3(1), dim3(512), 0, st, ambig_list, ambig_count, ambig_cap,
                            ambig_sorted);
@@ -756,8 +777,11 @@ void papr_launch_exact_redo(hipStream_t st, int blocks, const void *data, const 
 // the group's sum.  Exclusive scan over the groups (one workgroup) ...
 __global__ __launch_bounds__(1024) void papr_exact_spec_scan_kernel(const double *__restrict__ group_sums, uint64_t ngroups,
                                                                     double scale, double before,
-                                                                    double *__restrict__ group_prefix)
+                                                                    double *__restrict__ group_prefix,
+                                                                    const double *__restrict__ before_dev)
 {
+    if (before_dev)
+        before = *before_dev;  // (peers: the estimated sum in front of this shard, from every shard's estimate record)
     __shared__ double sh[1024 / kWave];
     const uint64_t per = (ngroups + 1023) / 1024;
     const uint64_t a = threadIdx.x * per, e = min(a + per, ngroups);
@@ -826,7 +850,7 @@ __global__ __launch_bounds__(256) void papr_exact_fill_spec_kernel(int32_t *__re
 }
 
 void papr_launch_exact_spec(hipStream_t st, const double *group_sums, uint64_t ngroups, uint32_t ratio, double scale,
-                            double before, double *group_prefix, uint64_t ntiles, int32_t *spec)
+                            double before, double *group_prefix, uint64_t ntiles, int32_t *spec, const double *before_dev)
 {
     if (ntiles == 0)
         return;
@@ -837,7 +861,7 @@ void papr_launch_exact_spec(hipStream_t st, const double *group_sums, uint64_t n
         return;
     }
     hipLaunchKernelGGL(papr_exact_spec_scan_kernel, dim3(1), dim3(1024), 0, st, group_sums, ngroups, scale, before,
-                       group_prefix);
+                       group_prefix, before_dev);
     hipLaunchKernelGGL(papr_exact_spec_tiles_kernel, dim3(blocks), dim3(256), 0, st, group_sums, group_prefix, ngroups,
                        ratio, scale, ntiles, spec);
 }
@@ -876,7 +900,8 @@ void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint
                             uint64_t ntiles, const void *seg_D, const void *data, const void *raw_store,
                             const void *tail_src, uint64_t nsamples, uint32_t tail_samples, uint32_t *mixed_list,
                             uint32_t cap_mixed, uint32_t *raw_list, uint32_t cap_raw, papr_exact_plan *plan,
-                            unsigned char *out_mapped, const uint32_t *count_src, uint32_t *count_dst)
+                            unsigned char *out_mapped, const uint32_t *count_src, uint32_t *count_dst, uint64_t out_cap,
+                            uint32_t redo_cap)
 {
     hipLaunchKernelGGL(papr_exact_plan_kernel, dim3(1), dim3(256), 0, st, groups, ngroups, tile_E, ntiles, mixed_list,
                        cap_mixed, raw_list, cap_raw, plan);
@@ -884,5 +909,34 @@ void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint
     hipLaunchKernelGGL(papr_exact_pack_kernel, dim3(group_blocks + cap_mixed + cap_raw + 1), dim3(256), 0, st, plan,
                        mixed_list, raw_list, groups, ngroups, tile_E, ntiles, (const double *)seg_D, (const float *)data,
                        (const float *)raw_store, (const float *)tail_src, nsamples, tail_samples, group_blocks, cap_mixed,
-                       cap_raw, out_mapped, count_src, count_dst);
+                       cap_raw, out_mapped, count_src, count_dst, out_cap, redo_cap);
+}
+
+// ---- the in-stream exchange of the sum programs (peers, single-wait step) ------------------------------------------
+// After the all-gather of the ranks' fixed-size slots: one workgroup per rank copies the USED bytes of that rank's slot
+// into the same slot of a mapped host buffer (the host replays all programs in rank order while the stream goes on with
+// the recount).  A slot whose header is marked (or is no header at all) travels as its 48 header bytes.
+__global__ __launch_bounds__(1024) void papr_exact_programs_to_host_kernel(const unsigned char *__restrict__ slots, uint64_t slot_bytes,
+                                                                           unsigned char *__restrict__ host)
+{
+    const unsigned char *src = slots + (uint64_t)blockIdx.x * slot_bytes;
+    unsigned char *dst = host + (uint64_t)blockIdx.x * slot_bytes;
+    const uint32_t *h32 = reinterpret_cast<const uint32_t *>(src);
+    const unsigned long long *h64 = reinterpret_cast<const unsigned long long *>(src);
+    uint64_t used = 48;
+    if (h32[0] == 0x31535850u && h32[11] == 0) {
+        const uint64_t want = 48 + h64[3] * 24 + (uint64_t)h32[9] * 4616 + (uint64_t)h32[10] * 16392 + (uint64_t)h32[8] * 8;
+        if (want <= slot_bytes)
+            used = want;
+    }
+    const unsigned long long *s8 = reinterpret_cast<const unsigned long long *>(src);
+    unsigned long long *d8 = reinterpret_cast<unsigned long long *>(dst);
+    for (uint64_t k = threadIdx.x; k < used / 8; k += 1024)
+        d8[k] = s8[k];
+}
+
+void papr_launch_exact_programs_to_host(hipStream_t st, const void *slots, uint64_t slot_bytes, uint32_t world, void *host_mapped)
+{
+    hipLaunchKernelGGL(papr_exact_programs_to_host_kernel, dim3(world), dim3(1024), 0, st, (const unsigned char *)slots, slot_bytes,
+                       (unsigned char *)host_mapped);
 }

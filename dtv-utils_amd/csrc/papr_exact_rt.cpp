@@ -73,6 +73,7 @@ int papr_hip_set_exact(papr_hip_ctx *ctx, int enabled)
     if ((enabled != 0) != ctx->exact) {
         ctx->exact = enabled != 0;
         ctx->exact_valid = false;
+        ctx->peer_epoch += 0x9E3779B97F4A7C15ull;  // (the ranks agree again on the single-wait step: stats_sweep_fused)
         ctx->exact_swept = ctx->est_groups_valid = ctx->exact_program_launched = false;
         if (ctx->resident)
             ctx->have_file_stats = false;  // pass 1 is re-run over the resident shard in the other mode
@@ -195,21 +196,11 @@ int run_exact_device(papr_hip_ctx *ctx, double before, uint64_t n_total, const C
     return PAPR_OK;
 }
 
-// The one-read form: papr_hip_stats_sweep already left every segment's sum and its pair for a SPECULATED binade in
-// d_seg_D.  What is left to do needs no sweep over the samples: true prefix sums from the segment sums, the true
-// classification, the pairs of the tiles whose speculated binade was wrong rebuilt from the resident samples
-// (normally a fraction of a per cent of them), group composition and the program gather.  Everything is queued on
-// the stream; the caller synchronises.  *redo_overflow (valid after that synchronisation) != 0: more tiles to redo
-// than the list holds — the caller then runs the full rounding-function sweep (run_exact_full_redo).
-int run_exact_swept_streamed(papr_hip_ctx *ctx, double before, double delta, uint64_t ntiles, uint64_t ngroups, uint32_t tail,
-                             unsigned char *program_dev);
-
-int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total)
+int reserve_exact_lists(papr_hip_ctx *ctx)
 {
     const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
     const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
     const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
-    const double delta = std::max(1.0e-6, 8.0 * (double)std::max<uint64_t>(n_total, ctx->n) * 1.1102230246251565e-16);
     if (!ctx->d_plan) {
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_mixed_list, kCapMixed * sizeof(uint32_t)));
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_raw_list, kCapRaw * sizeof(uint32_t)));
@@ -220,9 +211,54 @@ int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total)
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_redo_count, sizeof(uint32_t), hipHostMallocDefault));
         HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_redo_count_dev, ctx->h_redo_count, 0));
     }
-    int rc = reserve_program(ctx, sizeof(papr_exact_header) + ngroups * sizeof(papr_exact_group_rec) +
-                                      (size_t)kCapMixed * sizeof(papr_exact_mixed_rec) +
-                                      (size_t)kCapRaw * sizeof(papr_exact_raw_rec) + (size_t)tail * 8);
+    return reserve_program(ctx, sizeof(papr_exact_header) + ngroups * sizeof(papr_exact_group_rec) +
+                                    (size_t)kCapMixed * sizeof(papr_exact_mixed_rec) +
+                                    (size_t)kCapRaw * sizeof(papr_exact_raw_rec) + (size_t)tail * 8);
+}
+
+// Slot of the in-stream program exchange: the group table of the largest shard, room for 16 mixed groups and 32 raw
+// tiles (the 10 GiB bench shard that starts the file: 13 and 23; shards further in: 1-2 and 2-4) and a whole tail, in
+// units of 64 KiB.  A program that outgrows its slot is marked and the ranks exchange on the host (nothing is lost).
+size_t exact_program_slot_bytes(uint64_t nsamples)
+{
+    const uint64_t ntiles = nsamples / PAPR_EXACT_TILE_SAMPLES;
+    const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
+    const size_t want = sizeof(papr_exact_header) + ngroups * sizeof(papr_exact_group_rec) + 16 * sizeof(papr_exact_mixed_rec) +
+                        32 * sizeof(papr_exact_raw_rec) + (size_t)PAPR_EXACT_TILE_SAMPLES * 8;
+    const size_t forced = (size_t)std::max(0, env_int("PAPR_XPROG_SLOT_KB", 0)) * 1024;  // (tests: a slot too small on purpose)
+    return forced ? forced : (want + 65535) & ~(size_t)65535;
+}
+
+// from here on the program(s) in mapped host memory and the redo count are complete: whoever waits for this event may use
+// them while the stream goes on with the recount (run_overlap_work)
+int mark_program_ready(papr_hip_ctx *ctx)
+{
+    if (!ctx->ev_program)
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_program, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_program, ctx->stream));
+    ctx->program_pending = true;
+    return PAPR_OK;
+}
+
+// The one-read form: papr_hip_stats_sweep already left every segment's sum and its pair for a SPECULATED binade in
+// d_seg_D.  What is left to do needs no sweep over the samples: true prefix sums from the segment sums, the true
+// classification, the pairs of the tiles whose speculated binade was wrong rebuilt from the resident samples
+// (normally a fraction of a per cent of them), group composition and the program gather.  Everything is queued on
+// the stream; the caller synchronises.  *redo_overflow (valid after that synchronisation) != 0: more tiles to redo
+// than the list holds — the caller then runs the full rounding-function sweep (run_exact_full_redo).
+int run_exact_swept_streamed(papr_hip_ctx *ctx, double before, double delta, uint64_t ntiles, uint64_t ngroups, uint32_t tail,
+                             unsigned char *program_dev);
+
+// before_dev / n_total_dev (peers, single-wait step): the same two numbers where only the device knows them yet;
+// slot_dev / slot_cap: the program goes into that device buffer (a slot of the in-stream exchange) instead of h_program.
+int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total, const double *before_dev,
+                    const unsigned long long *n_total_dev, unsigned char *slot_dev, uint64_t slot_cap)
+{
+    const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
+    const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
+    const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
+    const double delta = std::max(1.0e-6, 8.0 * (double)std::max<uint64_t>(n_total, ctx->n) * 1.1102230246251565e-16);
+    int rc = reserve_exact_lists(ctx);
     if (rc)
         return rc;
     unsigned char *program_dev = nullptr;
@@ -230,25 +266,26 @@ int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total)
     // (the redo counter is zeroed by papr_launch_exact_classify_swept)
     if (!ctx->resident)
         return run_exact_swept_streamed(ctx, before, delta, ntiles, ngroups, tail, program_dev);
+    if (slot_dev)
+        program_dev = slot_dev;
+    ctx->program_view = nullptr;
+    ctx->xprog_ready = false;
     time_begin(ctx, 5, 0);  // (helper kernels: timed like the estimate / recount kernels, reported with kind 2)
     papr_launch_exact_classify_swept(ctx->stream, ctx->d_seg_D, ntiles, ctx->d_block_sums, before, delta, ctx->d_tile_E,
                                      ctx->d_tile_E_spec, ctx->d_redo, kCapRedo, ctx->d_redo + kCapRedo, nullptr, 0, nullptr,
-                                     nullptr);
+                                     nullptr, before_dev, n_total_dev, ctx->n);
     papr_launch_exact_redo(ctx->stream, ctx->num_cus, ctx->d_iq, ctx->d_tile_E, ctx->d_seg_D, ctx->d_redo,
                            ctx->d_redo + kCapRedo, kCapRedo, 0);
     papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
     time_end(ctx);
     papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, ctx->d_iq, nullptr,
                            ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, ctx->n, tail, ctx->d_mixed_list, kCapMixed,
-                           ctx->d_raw_list, kCapRaw, ctx->d_plan, program_dev, ctx->d_redo + kCapRedo, ctx->h_redo_count_dev);
+                           ctx->d_raw_list, kCapRaw, ctx->d_plan, program_dev, ctx->d_redo + kCapRedo, ctx->h_redo_count_dev,
+                           slot_dev ? slot_cap : 0, kCapRedo);
     HIPCHK(ctx, hipGetLastError());
-    // from here on the program (mapped host memory) and the redo count are complete: whoever waits for this event
-    // may use them while the stream goes on with the recount (run_overlap_work)
-    if (!ctx->ev_program)
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_program, hipEventDisableTiming));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_program, ctx->stream));
-    ctx->program_pending = true;
-    return PAPR_OK;
+    if (slot_dev)
+        return PAPR_OK;  // (the caller gathers the ranks' slots and records the event behind that)
+    return mark_program_ready(ctx);
 }
 
 // The same for a shard that STREAMED through the sweep (papr_hip_load_file_sweep in exact-sum mode) and is gone: the
@@ -346,6 +383,7 @@ int run_exact_full_redo(papr_hip_ctx *ctx)
     const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
     unsigned char *program_dev = nullptr;
     HIPCHK(ctx, hipHostGetDevicePointer((void **)&program_dev, ctx->h_program, 0));
+    ctx->program_view = nullptr;  // (the program is rebuilt into h_program)
     const uint64_t nsegs = 2 * ntiles;
     const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((nsegs + 3) / 4, (uint64_t)ctx->num_cus * 2));
     time_begin(ctx, 2, ctx->n * 8);
@@ -367,12 +405,18 @@ size_t swept_program_bytes(papr_hip_ctx *ctx)
     const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
     const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
     papr_exact_header h;
-    memcpy(&h, ctx->h_program, sizeof(h));
+    memcpy(&h, current_program(ctx), sizeof(h));
     if (h.magic == PAPR_EXACT_MAGIC && h.reserved == 0 && h.ngroups == ngroups && h.nsamples == ctx->n &&
         !env_int("PAPR_EXACT_HOST_ASSEMBLY", 0))
         return sizeof(h) + ngroups * sizeof(papr_exact_group_rec) + (size_t)h.nmixed * sizeof(papr_exact_mixed_rec) +
                (size_t)h.nraw * sizeof(papr_exact_raw_rec) + (size_t)tail * 8;
     return 0;
+}
+
+// where the current step's program was gathered: h_program, or this rank's slot of the in-stream exchange
+const unsigned char *current_program(const papr_hip_ctx *ctx)
+{
+    return ctx->program_view ? ctx->program_view : ctx->h_program;
 }
 
 // Host-driven assembly, for the (never yet seen) case that a shard has more mixed groups / raw tiles
@@ -474,7 +518,7 @@ static int papr_hip_exact_program_impl(papr_hip_ctx *ctx, double before, uint64_
         return rc;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (ctx->exact_swept) {
-        const bool launched = ctx->exact_program_launched && before == 0.0;  // (stats_sweep_fused did it, for before = 0)
+        const bool launched = ctx->exact_program_launched && before == ctx->exact_program_before;  // (stats_sweep_fused did it)
         ctx->exact_program_launched = false;
         rc = launched ? PAPR_OK : run_exact_swept(ctx, before, n_total);
         if (rc)
@@ -490,7 +534,9 @@ static int papr_hip_exact_program_impl(papr_hip_ctx *ctx, double before, uint64_
                 return rc;
         }
         *bytes = swept_program_bytes(ctx);
-        *program = ctx->h_program;
+        *program = current_program(ctx);
+        if (!*bytes)
+            ctx->program_view = nullptr;  // (assembled into h_program)
         return *bytes ? PAPR_OK : assemble_program_on_host(ctx, program, bytes);
     }
     rc = run_exact_device(ctx, before, n_total, nullptr, bytes);
@@ -515,7 +561,7 @@ static int papr_hip_ccdf_exact_impl(papr_hip_ctx *ctx, const float *levels, int 
     if (swept_form) {
         // one-read form: the sweep already holds what both results need (papr_hip_stats_sweep, or a one-sweep ingest,
         // in exact-sum mode)
-        const bool launched = ctx->exact_program_launched && before == 0.0;  // (stats_sweep_fused did it, for before = 0)
+        const bool launched = ctx->exact_program_launched && before == ctx->exact_program_before;  // (stats_sweep_fused did it)
         ctx->exact_program_launched = false;
         rc = launched ? PAPR_OK : run_exact_swept(ctx, before, n_total);
         if (rc)
@@ -547,7 +593,9 @@ static int papr_hip_ccdf_exact_impl(papr_hip_ctx *ctx, const float *levels, int 
                 return rc;
         }
         *bytes = swept_program_bytes(ctx);
-        *program = ctx->h_program;
+        *program = current_program(ctx);
+        if (!*bytes)
+            ctx->program_view = nullptr;  // (assembled into h_program)
         return *bytes ? PAPR_OK : assemble_program_on_host(ctx, program, bytes);
     }
     CcdfPlan plan;

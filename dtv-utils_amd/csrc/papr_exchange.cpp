@@ -6,6 +6,7 @@
 
 #include "papr_runtime_internal.h"
 
+#include <atomic>
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and enums only: the functions are looked up with dlsym
 
@@ -20,6 +21,7 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -46,6 +48,7 @@ RcclApi *rccl()
         SYM(GetUniqueId);
         SYM(CommInitRank);
         SYM(CommDestroy);
+        SYM(CommAbort);
         SYM(AllGather);
         SYM(AllReduce);
         SYM(GetErrorString);
@@ -72,6 +75,10 @@ struct LocalHub {
     std::vector<unsigned char> slots;  // world x bytes of the collective in flight
     size_t slot_bytes = 0;
     bool failed = false;  // a participant gave up (papr_exchange_abort): every collective fails from then on
+    // papr_exchange_open_rccl_local: the id every thread's ncclCommInitRank joins with (papr_exchange_bind)
+    bool want_rccl = false;
+    ncclUniqueId uid{};
+    std::vector<papr_exchange *> members;  // (for papr_exchange_abort: every member's communicator is aborted)
     bool barrier(std::unique_lock<std::mutex> &lk)
     {
         if (failed)
@@ -98,6 +105,9 @@ struct papr_exchange {
     // RCCL transport
     papr_hip_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
+    bool want_rccl = false;        // papr_exchange_open_rccl_local: papr_exchange_bind still has to create `comm`
+    ncclUniqueId solo_uid{};       // ... for a world of one (no hub)
+    std::atomic<bool> aborted{false};
     unsigned char *d_send = nullptr, *d_recv = nullptr;  // device staging
     unsigned char *h_send = nullptr, *h_recv = nullptr;  // pinned mirrors
     size_t cap_send = 0, cap_recv = 0;
@@ -159,8 +169,8 @@ int ensure_staging(papr_exchange *x, size_t send_bytes, size_t recv_bytes)
 // recv = world x bytes_per_rank, in rank order
 int allgather_bytes(papr_exchange *x, const void *send, void *recv, size_t bytes_per_rank)
 {
-    if (x->world == 1 && x->use_ops) {  // (an RCCL communicator of one rank still runs its collectives: that is
-        memcpy(recv, send, bytes_per_rank);  // what `torchrun --nproc-per-node 1` measures)
+    if (x->world == 1 && (x->use_ops || !x->comm)) {  // (an RCCL communicator of one rank still runs its collectives:
+        memcpy(recv, send, bytes_per_rank);            // that is what `torchrun --nproc-per-node 1` measures)
         return PAPR_OK;
     }
     if (x->hub) {
@@ -209,7 +219,7 @@ int allgather_bytes(papr_exchange *x, const void *send, void *recv, size_t bytes
 
 int allreduce_u64(papr_exchange *x, uint64_t *buf, size_t count)
 {
-    if ((x->world == 1 && x->use_ops) || count == 0)
+    if ((x->world == 1 && (x->use_ops || !x->comm)) || count == 0)
         return PAPR_OK;
     if (x->hub) {  // gather, then every thread adds the slots in rank order
         std::vector<uint64_t> all;
@@ -297,6 +307,10 @@ bool xch_in_stream(const papr_exchange *x, const papr_hip_ctx *ctx)
     if (x->comm)
         return x->ctx == ctx && mode != 0;
     return mode == 2 && (x->hub || x->use_ops) && !(x->world == 1 && x->use_ops);
+}
+int xch_allgather_host(papr_exchange *x, const void *send, void *recv, size_t bytes_per_rank)
+{
+    return allgather_bytes(x, send, recv, bytes_per_rank);
 }
 int xch_rank(const papr_exchange *x) { return x ? x->rank : 0; }
 int xch_world(const papr_exchange *x) { return x ? x->world : 1; }
@@ -427,13 +441,90 @@ int papr_exchange_open_local(papr_exchange **xs, int n)
     return PAPR_OK;
 }
 
+int papr_exchange_open_rccl_local(papr_exchange **xs, int n)
+{
+    if (!xs || n < 1)
+        return PAPR_E_ARG;
+    if (!rccl())
+        return xfail(nullptr, PAPR_E_NO_DEVICE, "RCCL (librccl.so) could not be loaded");
+    ncclUniqueId uid;
+    if (rccl()->GetUniqueId(&uid) != ncclSuccess)
+        return xfail(nullptr, PAPR_E_HIP, "ncclGetUniqueId failed");
+    int rc = papr_exchange_open_local(xs, n);
+    if (rc)
+        return rc;
+    for (int r = 0; r < n; r++) {
+        xs[r]->want_rccl = true;
+        xs[r]->solo_uid = uid;
+        xs[r]->use_ops = n > 1;  // (a world of one still runs its collectives through RCCL: no identity short cut)
+    }
+    if (n > 1) {
+        LocalHub *hub = xs[0]->hub;
+        hub->want_rccl = true;
+        hub->uid = uid;
+        hub->members.assign(xs, xs + n);
+    }
+    return PAPR_OK;
+}
+
+int papr_exchange_bind(papr_exchange *x, papr_hip_ctx *ctx)
+{
+    if (!x || !ctx)
+        return PAPR_E_ARG;
+    if (!x->want_rccl)
+        return PAPR_OK;  // (the other transports have nothing to bind)
+    x->want_rccl = false;
+    // One communicator cannot hold two ranks of one device (bin/papr with PAPR_OVERSUBSCRIBE): the threads settle
+    // through the hub whether every shard has a GPU of its own; if not, the handles stay what papr_exchange_open_local
+    // made them.
+    if (x->hub) {
+        std::vector<uint64_t> devs((size_t)x->world);
+        const uint64_t mine = (uint64_t)ctx->device;
+        int rc = allgather_bytes(x, &mine, devs.data(), sizeof(uint64_t));
+        if (rc)
+            return rc;
+        std::sort(devs.begin(), devs.end());
+        if (std::adjacent_find(devs.begin(), devs.end()) != devs.end())
+            return PAPR_OK;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess)
+        return xfail(x, PAPR_E_HIP, "hipSetDevice(%d) failed", ctx->device);
+    const ncclUniqueId uid = x->hub ? x->hub->uid : x->solo_uid;
+    const ncclResult_t r = rccl()->CommInitRank(&x->comm, x->world, uid, x->rank);  // (every thread is in here at once)
+    if (r != ncclSuccess) {
+        x->comm = nullptr;
+        return xfail(x, PAPR_E_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", x->rank, x->world,
+                     rccl()->GetErrorString ? rccl()->GetErrorString(r) : "RCCL error");
+    }
+    x->ctx = ctx;
+    return PAPR_OK;
+}
+
+int papr_exchange_is_rccl(const papr_exchange *x)
+{
+    return x && x->comm ? 1 : 0;
+}
+
 void papr_exchange_abort(papr_exchange *x)
 {
-    if (!x || !x->hub)
+    if (!x)
         return;
-    std::lock_guard<std::mutex> g(x->hub->m);
-    x->hub->failed = true;
-    x->hub->cv.notify_all();
+    if (x->hub) {
+        std::vector<papr_exchange *> members;
+        {
+            std::lock_guard<std::mutex> g(x->hub->m);
+            x->hub->failed = true;
+            x->hub->cv.notify_all();
+            members = x->hub->members;
+        }
+        // peers that wait inside (or for) an RCCL collective are released by aborting the communicators
+        for (papr_exchange *m : members)
+            if (m && m->comm && rccl() && rccl()->CommAbort && !m->aborted.exchange(true))
+                (void)rccl()->CommAbort(m->comm);
+        return;
+    }
+    if (x->comm && rccl() && rccl()->CommAbort && !x->aborted.exchange(true))
+        (void)rccl()->CommAbort(x->comm);  // (one process per GPU: the peers' collectives fail instead of waiting)
 }
 
 void papr_exchange_close(papr_exchange *x)
@@ -444,6 +535,9 @@ void papr_exchange_close(papr_exchange *x)
         bool last;
         {
             std::lock_guard<std::mutex> g(x->hub->m);
+            for (papr_exchange *&m : x->hub->members)
+                if (m == x)
+                    m = nullptr;
             last = --x->hub->refs == 0;
         }
         if (last)
@@ -452,7 +546,7 @@ void papr_exchange_close(papr_exchange *x)
     }
     if (x->ctx)
         (void)hipSetDevice(x->ctx->device);
-    if (x->comm && rccl())
+    if (x->comm && rccl() && !x->aborted.load())
         (void)rccl()->CommDestroy(x->comm);
     if (x->d_send) (void)hipFree(x->d_send);
     if (x->d_recv) (void)hipFree(x->d_recv);

@@ -468,6 +468,7 @@ int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, u
     ctx->loaded = true;
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
+    ctx->peer_epoch += 0x9E3779B97F4A7C15ull;  // (the ranks agree again on the single-wait step: stats_sweep_fused)
     ctx->sweep_valid = false;
     ctx->est_groups_valid = ctx->exact_swept = ctx->exact_program_launched = false;
     ctx->shard_flags = (fs.odd && first_sample + nsamples == fs.nsamples && nsamples > 0) ? PAPR_FLAG_ODD_TAIL : 0;

@@ -210,6 +210,7 @@ void release_shard(papr_hip_ctx *ctx)
     ctx->loaded = ctx->resident = false;
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
+    ctx->peer_epoch += 0x9E3779B97F4A7C15ull;  // (the ranks agree again on the single-wait step: stats_sweep_fused)
     ctx->sweep_valid = false;
     ctx->est_groups_valid = ctx->exact_swept = ctx->exact_program_launched = false;
     ctx->shard_flags = 0;
@@ -668,6 +669,12 @@ void papr_hip_close(papr_hip_ctx *ctx)
     if (ctx->h_true) (void)hipHostFree(ctx->h_true);
     if (ctx->d_guess) (void)hipFree(ctx->d_guess);
     if (ctx->h_guess) (void)hipHostFree(ctx->h_guess);
+    if (ctx->d_peer) (void)hipFree(ctx->d_peer);
+    if (ctx->h_peer) (void)hipHostFree(ctx->h_peer);
+    if (ctx->h_xvec) (void)hipHostFree(ctx->h_xvec);
+    if (ctx->d_xprog) (void)hipFree(ctx->d_xprog);
+    if (ctx->d_xprog_all) (void)hipFree(ctx->d_xprog_all);
+    if (ctx->h_xprog_all) (void)hipHostFree(ctx->h_xprog_all);
     if (ctx->ev_program) (void)hipEventDestroy(ctx->ev_program);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
@@ -709,6 +716,7 @@ int papr_hip_set_tuning(papr_hip_ctx *ctx, const papr_hip_tuning *t)
         t->estimate_ratio > 65536)
         return fail(ctx, PAPR_E_ARG, "bad tuning values");
     ctx->tune = *t;
+    ctx->peer_epoch += 0x9E3779B97F4A7C15ull;
     return PAPR_OK;
 }
 
@@ -838,6 +846,7 @@ int papr_hip_upload(papr_hip_ctx *ctx, const float *iq, uint64_t nsamples, uint6
     ctx->loaded = ctx->resident = true;
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
+    ctx->peer_epoch += 0x9E3779B97F4A7C15ull;  // (the ranks agree again on the single-wait step: stats_sweep_fused)
     ctx->sweep_valid = false;
     ctx->est_groups_valid = ctx->exact_swept = ctx->exact_program_launched = false;
     ctx->shard_flags = 0;
@@ -866,6 +875,7 @@ int papr_hip_generate(papr_hip_ctx *ctx, const papr_synth_spec *spec, uint64_t f
     ctx->loaded = ctx->resident = true;
     ctx->have_file_stats = false;
     ctx->exact_valid = false;
+    ctx->peer_epoch += 0x9E3779B97F4A7C15ull;  // (the ranks agree again on the single-wait step: stats_sweep_fused)
     ctx->sweep_valid = false;
     ctx->est_groups_valid = ctx->exact_swept = ctx->exact_program_launched = false;
     ctx->shard_flags = 0;

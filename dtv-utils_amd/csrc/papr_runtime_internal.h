@@ -191,7 +191,14 @@ struct papr_hip_ctx {
     // that is about to wait for the stream (run_overlap_work), then cleared
     hipEvent_t ev_program = nullptr;
     bool program_pending = false;        // ev_program was recorded for the current step
-    bool exact_program_launched = false; // stats_sweep_fused already ran run_exact_swept for the current sweep (before = 0)
+    bool exact_program_launched = false; // stats_sweep_fused already ran run_exact_swept for the current sweep ...
+    double exact_program_before = 0.0;   // ... with this sum in front of the shard (0 without peers)
+    // peers, single-wait step: every rank's program slot after the in-stream all-gather (device; mapped host)
+    unsigned char *d_xprog = nullptr, *d_xprog_all = nullptr, *h_xprog_all = nullptr, *h_xprog_all_dev = nullptr;
+    size_t xprog_slot = 0;               // bytes per slot (every rank sizes it from the same numbers)
+    int xprog_world = 0;                 // slots in d_xprog_all / h_xprog_all
+    bool xprog_ready = false;            // h_xprog_all holds the current step's programs (behind ev_program)
+    const unsigned char *program_view = nullptr;  // where the current step's own program is, if not in h_program
     std::function<void()> overlap_work;
     size_t stage_bytes = 0;
     papr_rt::ReaderPool *pool = nullptr;
@@ -243,6 +250,7 @@ struct papr_hip_ctx {
     bool counts_global = false;                  // the last papr_hip_ccdf answered with the file's counts (no exchange needed)
     std::vector<uint64_t> sweep_even_above_global;
     std::vector<unsigned long long> recount_global;
+    uint64_t peer_epoch = 0;                     // bumped by every call that changes shard state or mode (see stats_sweep_fused)
     uint64_t peer_agreed_key = 0;                // the shard state for which the ranks agreed ...
     bool peer_agreed_ok = false;                 // ... that every one of them can take the single-wait step
     papr_hip_sweep_info sweep_info{};
@@ -401,11 +409,17 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
                       PeerStep *peer);
 // papr_exchange.cpp: collectives queued on the context's stream (RCCL transport only)
 bool xch_in_stream(const papr_exchange *x, const papr_hip_ctx *ctx);
+int xch_allgather_host(papr_exchange *x, const void *send, void *recv, size_t bytes_per_rank);  // (host memory; one wait)
 int xch_rank(const papr_exchange *x);
 int xch_world(const papr_exchange *x);
 int xch_allgather_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
 int xch_allreduce_u64_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev, void *recv_dev, size_t count);
-int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total);
+int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total, const double *before_dev = nullptr,
+                    const unsigned long long *n_total_dev = nullptr, unsigned char *slot_dev = nullptr, uint64_t slot_cap = 0);
+int mark_program_ready(papr_hip_ctx *ctx);
+int reserve_exact_lists(papr_hip_ctx *ctx);            // the small device lists / pinned words run_exact_swept needs
+size_t exact_program_slot_bytes(uint64_t nsamples);   // slot of the in-stream program exchange for shards of up to nsamples
+const unsigned char *current_program(const papr_hip_ctx *ctx);
 void run_overlap_work(papr_hip_ctx *ctx);  // (see papr_hip_ctx::overlap_work)
 int launch_stats_range(papr_hip_ctx *ctx, const float *data, uint64_t n, uint64_t base_index, size_t slot,
                        int *nrecords);
@@ -438,7 +452,6 @@ int exact_preconditions(papr_hip_ctx *ctx, double before, bool allow_restreamed)
 int reserve_program(papr_hip_ctx *ctx, size_t want);  // grow the pinned program buffer, keeping its contents
 int run_exact_device(papr_hip_ctx *ctx, double before, uint64_t n_total, const CcdfPlan *fused, size_t *bytes);
 int assemble_program_on_host(papr_hip_ctx *ctx, const void **program, size_t *bytes);
-int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total);
 int run_exact_full_redo(papr_hip_ctx *ctx);
 size_t swept_program_bytes(papr_hip_ctx *ctx);
 void counts_from_histogram(const papr_hip_ctx *ctx, const CcdfPlan &plan, int nlevels, uint64_t *counts_above);

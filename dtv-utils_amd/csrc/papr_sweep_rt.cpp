@@ -372,7 +372,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
     ctx->peer_global = false;
     const bool exact = ctx->exact;
     const bool peers = x && !papr_exchange_is_identity(x);
-    if (peers && (!xch_in_stream(x, ctx) || exact || !peer))
+    if (peers && (!xch_in_stream(x, ctx) || !peer))
         return PAPR_OK;
     // (a chosen kernel form goes through the host path, except the forms that share the default's launch shape: one
     // persistent workgroup per CU)
@@ -389,174 +389,249 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
                           ctx->tune.sweep_blocks <= 0 && env_int(exact ? "PAPR_FUSED_EXACT" : "PAPR_FUSED_GUESS", 1) &&
                           ntiles_est != 0 && nl <= PAPR_GUESS_MAX_BANDS && max_db >= 0 &&
                           ctx->n / (exact ? (uint64_t)PAPR_EXACT_TILE_SAMPLES : 8192ull) != 0;
-    if (peers) {
-        // a rank that left this path while the others queue their collectives would hang them: the ranks agree ONCE per
-        // shard state (one host all-reduce, in the first step) that every one of them takes it
-        const uint64_t key = ((uint64_t)(uintptr_t)ctx->d_iq * 0x9E3779B97F4A7C15ull) ^ (ctx->n * 0xC2B2AE3D27D4EB4Full) ^ ctx->base ^
-                             ((uint64_t)graph << 62) ^ ((uint64_t)ctx->tune.sweep_variant << 40) ^ ((uint64_t)ctx->tune.estimate_ratio << 20) ^
-                             (uint64_t)ctx->tune.sweep_band_log2 ^ 1ull;
-        if (ctx->peer_agreed_key != key) {
-            uint64_t ok = eligible ? 1u : 0u;
-            const int xrc = papr_exchange_counts(x, &ok, 1);
-            if (xrc)
-                return fail(ctx, xrc, "exchange: %s", papr_exchange_last_error(x));
-            ctx->peer_agreed_key = key;
-            ctx->peer_agreed_ok = ok == (uint64_t)xch_world(x);
-        }
-        if (!ctx->peer_agreed_ok)
-            return PAPR_OK;
-    } else if (!eligible) {
+    if (!peers && !eligible)
         return PAPR_OK;
-    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // With peers the rest of this function queues collectives every rank must enter, so the ranks AGREE first that all of
+    // them take this path (one host all-reduce) — and everything that can fail for a local reason (the buffers, the
+    // stash) is allocated in front of that agreement and folded into it: behind it a rank leaves only with an error, and
+    // then cancels the exchange so that nobody waits for it (papr_exchange_abort).  The agreement is repeated whenever
+    // the exchange, the mode or the shard state may have changed: the key holds the exchange and what the step depends
+    // on, and every call that changes shard state (load / upload / adopt / generate / set_tuning / set_exact) clears it —
+    // on every rank of an SPMD caller alike, whether or not the values changed on that rank.
+    const uint64_t agree_key = ((uint64_t)(uintptr_t)x * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(peers ? xch_world(x) : 1) << 48) ^
+                               ((uint64_t)graph << 62) ^ ((uint64_t)exact << 61) ^ ctx->peer_epoch ^ 1ull;
+    const bool agreed = peers && ctx->peer_agreed_key == agree_key;
+    if (agreed && !ctx->peer_agreed_ok)
+        return PAPR_OK;
+    bool local_ok = eligible;  // (folded into the agreement; a rank that is not eligible still takes part in it)
+    auto leave = [&](int rc) {  // behind the agreement: no rank-local way out but with an error, and the peers are released
+        if (peers && rc != PAPR_OK)
+            papr_exchange_abort(x);
+        return rc;
+    };
     papr_hip_sweep_info &info = ctx->sweep_info;
     // ---- geometry: the default kernel of the mode; its table is what the device builds ----
     SweepRun run;
     int vblock = 0;
-    if (exact) {
-        int v2_exact = 0;
-        run.variant = chosen >= 0 ? chosen : kSweepExactVariant;
-        if (papr_sweep3_geometry(run.variant, &vblock, &run.stash_lds) == 0) {
-            run.v3 = run.exact = true;  // papr_sweep_kernel's one-edge table, papr_sweep2_kernel's segments and launch
-        } else {
-            if (papr_sweep2_geometry(run.variant, &vblock, &run.tile, &run.stash_lds, &v2_exact) != 0 || !v2_exact)
-                return PAPR_OK;
-            run.v2 = run.lut2 = run.exact = true;
-        }
-        run.tile = PAPR_EXACT_TILE_SAMPLES;  // the launch covers whole 2048-sample tiles (two segments each)
-    } else {
-        run.variant = chosen >= 0 ? chosen : kSweepVariant;
-        run.lut2 = PAPR_SWEEP_VARIANT_IS_LUT2(run.variant);
-        if (papr_sweep3_geometry(run.variant, &vblock, &run.stash_lds) == 0) {
-            run.v3 = true;  // the plain form of papr_sweep3_kernel: wave-private 1024-sample segments
-            run.tile = PAPR_EXACT_SEG_SAMPLES;
-        } else if (papr_sweep_geometry(run.variant, &vblock, &run.tile, &run.stash_lds) != 0) {
-            return PAPR_OK;
-        }
-    }
-    run.threads = vblock;
-    const uint64_t ntiles = ctx->n / run.tile;
-    if (ntiles == 0)
-        return PAPR_OK;
-    const int waves = vblock / 64;
-    const bool by_segments = exact || run.v3;  // launched through papr_sweep2_params: one persistent workgroup per CU
-    const uint64_t nsegs_launch = exact ? 2 * ntiles : ntiles;
-    if (by_segments)
-        run.blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus, (nsegs_launch + waves - 1) / waves));
-    else
-        run.blocks = pick_blocks(ctx, SWEEP, ntiles);
+    uint64_t ntiles = 0, nsegs_launch = 0, ratio = 1, ngroups = 0;
+    int waves = 0, est_blocks = 0;
+    bool by_segments = false;
     constexpr uint32_t kBinsMax = 2 * PAPR_GUESS_MAX_BANDS + 2;
     constexpr uint32_t kCopies = 4;
-    const size_t lds_cap = (size_t)papr_ccdf_max_dynamic_lds();
-    // LDS for table + histogram copies: what the launch is given, and what the device-side plan has to fit into
-    const size_t table_lds = by_segments ? (lds_cap - 2048 > run.stash_lds ? lds_cap - 2048 - run.stash_lds : 0)
-                                   : (size_t)((PAPR_SWEEP_VARIANT_IS_LUT2(run.variant) ? 48 : 40) * 1024 + 32) +
-                                         (((size_t)kCopies * kBinsMax + 3) & ~(size_t)3) * 4;  // (one-edge table: <= 40 KiB)
-    if (table_lds < 16 * 1024 || table_lds + run.stash_lds > lds_cap)
-        return PAPR_OK;
-    const uint32_t table_cap_words = by_segments ? (uint32_t)(table_lds / 4) : 48 * 1024 / 4 + 8;
-    // (the workgroup's share of the CU's LDS: 80 bytes per thread where several are resident, everything for a persistent one)
-    const uint32_t soft_lds = by_segments ? (uint32_t)table_lds
-                              : PAPR_SWEEP_VARIANT_IS_PERSISTENT(run.variant)
-                                  ? (uint32_t)(lds_cap - 2048 - run.stash_lds)
-                                  : (uint32_t)std::max<long long>(0, (long long)vblock * 80 - (long long)run.stash_lds);
-    run.seg_off = kBinsMax;
-    // ---- estimate geometry (as papr_hip_estimate) ----
-    uint64_t ratio = ctx->tune.estimate_ratio > 0 ? (uint64_t)ctx->tune.estimate_ratio : (uint64_t)kEstimateRatio;
-    ratio = std::max<uint64_t>(1, std::min<uint64_t>(ratio, ntiles_est / kEstimateMinTiles));
-    const uint64_t ngroups = ntiles_est / ratio;
-    const int est_blocks = (int)std::min<uint64_t>(ngroups, (uint64_t)ctx->num_cus * 8);
-    // ---- buffers ----
-    int rc = ensure_partials(ctx, (size_t)run.blocks + 1 + (size_t)est_blocks + 1);
-    if (rc)
-        return rc;
-    papr_partial *est_partials = ctx->d_partials + run.blocks + 1;
-    if (!ctx->d_est_sq) {
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double)));
-        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double), hipHostMallocDefault));
-    }
-    if (!ctx->d_result_copy) {
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_result_copy, sizeof(papr_partial)));
-    }
-    if (!ctx->d_true) {
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_true, sizeof(papr_true_out)));
-        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_true, sizeof(papr_true_out), hipHostMallocMapped));
-        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_true_dev, ctx->h_true, 0));
-    }
-    if (!ctx->d_guess) {
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_guess, sizeof(papr_guess_out)));
-        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_guess, sizeof(papr_guess_out), hipHostMallocMapped));
-        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_guess_dev, ctx->h_guess, 0));
-    }
-    // peers: device scratch [my estimate record | all of them | all pass-1 records | the merged one | n | vector | reduced vector]
     constexpr uint32_t kXvecWords = kBinsMax + (PAPR_TRUE_MAX_LEVELS + 1) + PAPR_XVEC_FLAGS;
+    size_t table_lds = 0;
+    uint32_t table_cap_words = 0, soft_lds = 0;
+    papr_partial *est_partials = nullptr;
     const uint32_t world = peers ? (uint32_t)xch_world(x) : 1u, my_rank = peers ? (uint32_t)xch_rank(x) : 0u;
     papr_est_record *d_est_mine = nullptr, *d_est_all = nullptr;
     papr_partial *d_recs_all = nullptr, *d_total = nullptr;
     unsigned long long *d_n_total = nullptr, *d_xvec = nullptr, *d_xvec_sum = nullptr;
-    if (peers) {
-        const size_t a_est = 64, a_all = (size_t)world * sizeof(papr_est_record), a_recs = (size_t)world * sizeof(papr_partial);
-        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-        const size_t need = up(a_est) + up(a_all) + up(a_recs) + up(sizeof(papr_partial)) + 256 + 2 * up((size_t)kXvecWords * 8);
-        if (ctx->peer_cap < need) {
-            if (ctx->d_peer) HIPCHK(ctx, hipFree(ctx->d_peer));
-            ctx->d_peer = nullptr;
-            ctx->peer_cap = 0;
-            HIPCHK(ctx, hipMalloc((void **)&ctx->d_peer, need));
-            ctx->peer_cap = need;
-        }
-        if (!ctx->h_peer) {
-            HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_peer, sizeof(papr_peer_out), hipHostMallocMapped));
-            HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_peer_dev, ctx->h_peer, 0));
-            HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_xvec, (size_t)kXvecWords * 8, hipHostMallocDefault));
-        }
-        unsigned char *q = ctx->d_peer;
-        d_est_mine = (papr_est_record *)q;          q += up(a_est);
-        d_est_all = (papr_est_record *)q;           q += up(a_all);
-        d_recs_all = (papr_partial *)q;             q += up(a_recs);
-        d_total = (papr_partial *)q;                q += up(sizeof(papr_partial));
-        d_n_total = (unsigned long long *)q;        q += 256;
-        d_xvec = (unsigned long long *)q;           q += up((size_t)kXvecWords * 8);
-        d_xvec_sum = (unsigned long long *)q;
-    }
-    constexpr size_t kMaxSweepBlocks = 65536;
-    if (!ctx->d_sweep_hist) {
-        const size_t bytes = (2 * (size_t)PAPR_HIP_MAX_LEVELS + 2 + 2 * kMaxSweepBlocks + 1) * sizeof(unsigned long long);
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_sweep_hist, bytes));
-        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_sweep_hist, bytes, hipHostMallocDefault));
-    }
-    if (!ctx->h_sweep_hist_dev)
-        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_sweep_hist_dev, ctx->h_sweep_hist, 0));
-    run.seg_cap = stash_segment_floats(ctx->n, run.blocks);
-    const uint64_t want_stash = run.seg_cap * (uint64_t)run.blocks;
-    if (ctx->stash_cap < want_stash) {
-        if (ctx->d_stash) HIPCHK(ctx, hipFree(ctx->d_stash));
-        ctx->d_stash = nullptr;
-        ctx->stash_cap = 0;
-        if (hipMalloc((void **)&ctx->d_stash, want_stash * sizeof(float)) != hipSuccess) {
-            (void)hipGetLastError();
-            ctx->d_stash = nullptr;
-            return PAPR_OK;  // (no room for the stash: the host path reports it)
-        }
-        ctx->stash_cap = want_stash;
-    }
-    rc = ensure_table(ctx, std::max<uint32_t>(table_cap_words, 48 * 1024 / 4 + 8));
-    if (rc)
-        return rc;
     double *group_sums = nullptr;
-    if (exact) {
-        rc = ensure_exact_buffers(ctx);
+    // everything that can say "not this way" or fail for a reason of this rank's own; `local_ok` = this rank can go on
+    auto prepare = [&]() -> int {
+        if (!local_ok)
+            return PAPR_OK;
+        local_ok = false;
+        if (exact) {
+            int v2_exact = 0;
+            run.variant = chosen >= 0 ? chosen : kSweepExactVariant;
+            if (papr_sweep3_geometry(run.variant, &vblock, &run.stash_lds) == 0) {
+                run.v3 = run.exact = true;  // papr_sweep_kernel's one-edge table, papr_sweep2_kernel's segments and launch
+            } else {
+                if (papr_sweep2_geometry(run.variant, &vblock, &run.tile, &run.stash_lds, &v2_exact) != 0 || !v2_exact)
+                    return PAPR_OK;
+                run.v2 = run.lut2 = run.exact = true;
+            }
+            run.tile = PAPR_EXACT_TILE_SAMPLES;  // the launch covers whole 2048-sample tiles (two segments each)
+        } else {
+            run.variant = chosen >= 0 ? chosen : kSweepVariant;
+            run.lut2 = PAPR_SWEEP_VARIANT_IS_LUT2(run.variant);
+            if (papr_sweep3_geometry(run.variant, &vblock, &run.stash_lds) == 0) {
+                run.v3 = true;  // the plain form of papr_sweep3_kernel: wave-private 1024-sample segments
+                run.tile = PAPR_EXACT_SEG_SAMPLES;
+            } else if (papr_sweep_geometry(run.variant, &vblock, &run.tile, &run.stash_lds) != 0) {
+                return PAPR_OK;
+            }
+        }
+        run.threads = vblock;
+        ntiles = ctx->n / run.tile;
+        if (ntiles == 0)
+            return PAPR_OK;
+        waves = vblock / 64;
+        by_segments = exact || run.v3;  // launched through papr_sweep2_params: one persistent workgroup per CU
+        nsegs_launch = exact ? 2 * ntiles : ntiles;
+        if (by_segments)
+            run.blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ctx->num_cus, (nsegs_launch + waves - 1) / waves));
+        else
+            run.blocks = pick_blocks(ctx, SWEEP, ntiles);
+        const size_t lds_cap = (size_t)papr_ccdf_max_dynamic_lds();
+        // LDS for table + histogram copies: what the launch is given, and what the device-side plan has to fit into
+        table_lds = by_segments ? (lds_cap - 2048 > run.stash_lds ? lds_cap - 2048 - run.stash_lds : 0)
+                                : (size_t)((PAPR_SWEEP_VARIANT_IS_LUT2(run.variant) ? 48 : 40) * 1024 + 32) +
+                                      (((size_t)kCopies * kBinsMax + 3) & ~(size_t)3) * 4;  // (one-edge table: <= 40 KiB)
+        if (table_lds < 16 * 1024 || table_lds + run.stash_lds > lds_cap)
+            return PAPR_OK;
+        table_cap_words = by_segments ? (uint32_t)(table_lds / 4) : 48 * 1024 / 4 + 8;
+        // (the workgroup's share of the CU's LDS: 80 bytes per thread where several are resident, everything for a persistent one)
+        soft_lds = by_segments ? (uint32_t)table_lds
+                   : PAPR_SWEEP_VARIANT_IS_PERSISTENT(run.variant)
+                       ? (uint32_t)(lds_cap - 2048 - run.stash_lds)
+                       : (uint32_t)std::max<long long>(0, (long long)vblock * 80 - (long long)run.stash_lds);
+        run.seg_off = kBinsMax;
+        // ---- estimate geometry (as papr_hip_estimate) ----
+        ratio = ctx->tune.estimate_ratio > 0 ? (uint64_t)ctx->tune.estimate_ratio : (uint64_t)kEstimateRatio;
+        ratio = std::max<uint64_t>(1, std::min<uint64_t>(ratio, ntiles_est / kEstimateMinTiles));
+        ngroups = ntiles_est / ratio;
+        est_blocks = (int)std::min<uint64_t>(ngroups, (uint64_t)ctx->num_cus * 8);
+        // ---- buffers ----
+        int rc = ensure_partials(ctx, (size_t)run.blocks + 1 + (size_t)est_blocks + 1);
         if (rc)
             return rc;
-        if (ctx->est_groups_cap < ngroups) {
-            if (ctx->d_est_groups) HIPCHK(ctx, hipFree(ctx->d_est_groups));
-            ctx->d_est_groups = nullptr;
-            ctx->est_groups_cap = 0;
-            const uint64_t cap = std::max<uint64_t>(ngroups, 4096);
-            HIPCHK(ctx, hipMalloc((void **)&ctx->d_est_groups, cap * 5 * sizeof(double)));  // 4 wave sums + 1 prefix per group
-            ctx->est_groups_cap = cap;
+        est_partials = ctx->d_partials + run.blocks + 1;
+        if (!ctx->d_est_sq) {
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double)));
+            HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_est_sq, (size_t)ctx->num_cus * 8 * sizeof(double), hipHostMallocDefault));
         }
-        group_sums = ctx->d_est_groups;
+        if (!ctx->d_result_copy) {
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_result_copy, sizeof(papr_partial)));
+        }
+        if (!ctx->d_true) {
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_true, sizeof(papr_true_out)));
+            HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_true, sizeof(papr_true_out), hipHostMallocMapped));
+            HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_true_dev, ctx->h_true, 0));
+        }
+        if (!ctx->d_guess) {
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_guess, sizeof(papr_guess_out)));
+            HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_guess, sizeof(papr_guess_out), hipHostMallocMapped));
+            HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_guess_dev, ctx->h_guess, 0));
+        }
+        // peers: device scratch [my estimate record | all of them | all pass-1 records | the merged one | n, before | vector | reduced vector]
+        if (peers) {
+            const size_t a_est = 64, a_all = (size_t)world * sizeof(papr_est_record), a_recs = (size_t)world * sizeof(papr_partial);
+            auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            const size_t need = up(a_est) + up(a_all) + up(a_recs) + up(sizeof(papr_partial)) + 256 + 2 * up((size_t)kXvecWords * 8);
+            if (ctx->peer_cap < need) {
+                if (ctx->d_peer) HIPCHK(ctx, hipFree(ctx->d_peer));
+                ctx->d_peer = nullptr;
+                ctx->peer_cap = 0;
+                HIPCHK(ctx, hipMalloc((void **)&ctx->d_peer, need));
+                ctx->peer_cap = need;
+            }
+            if (!ctx->h_peer) {
+                HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_peer, sizeof(papr_peer_out), hipHostMallocMapped));
+                HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_peer_dev, ctx->h_peer, 0));
+                HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_xvec, (size_t)kXvecWords * 8, hipHostMallocDefault));
+            }
+            unsigned char *q = ctx->d_peer;
+            d_est_mine = (papr_est_record *)q;          q += up(a_est);
+            d_est_all = (papr_est_record *)q;           q += up(a_all);
+            d_recs_all = (papr_partial *)q;             q += up(a_recs);
+            d_total = (papr_partial *)q;                q += up(sizeof(papr_partial));
+            d_n_total = (unsigned long long *)q;        q += 256;   // [0] the file's length, [1] (a double) the sum in front of this shard
+            d_xvec = (unsigned long long *)q;           q += up((size_t)kXvecWords * 8);
+            d_xvec_sum = (unsigned long long *)q;
+            if (exact) {
+                // the in-stream exchange of the sum programs: one slot per rank, sized from the LARGEST shard the ranks
+                // could hold under this geometry — every rank computes the same number from ctx->xprog_slot_samples,
+                // which the agreement settles (the maximum of the ranks' shard sizes)
+                const size_t slot = ctx->xprog_slot;
+                if (slot == 0 || ctx->xprog_world != (int)world || !ctx->d_xprog) {
+                    if (ctx->d_xprog) HIPCHK(ctx, hipFree(ctx->d_xprog));
+                    if (ctx->d_xprog_all) HIPCHK(ctx, hipFree(ctx->d_xprog_all));
+                    if (ctx->h_xprog_all) HIPCHK(ctx, hipHostFree(ctx->h_xprog_all));
+                    ctx->d_xprog = ctx->d_xprog_all = ctx->h_xprog_all = ctx->h_xprog_all_dev = nullptr;
+                    ctx->xprog_world = 0;
+                    if (slot) {
+                        HIPCHK(ctx, hipMalloc((void **)&ctx->d_xprog, slot));
+                        HIPCHK(ctx, hipMalloc((void **)&ctx->d_xprog_all, slot * world));
+                        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_xprog_all, slot * world, hipHostMallocMapped));
+                        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_xprog_all_dev, ctx->h_xprog_all, 0));
+                        ctx->xprog_world = (int)world;
+                    }
+                }
+            }
+        }
+        constexpr size_t kMaxSweepBlocks = 65536;
+        if (!ctx->d_sweep_hist) {
+            const size_t bytes = (2 * (size_t)PAPR_HIP_MAX_LEVELS + 2 + 2 * kMaxSweepBlocks + 1) * sizeof(unsigned long long);
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_sweep_hist, bytes));
+            HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_sweep_hist, bytes, hipHostMallocDefault));
+        }
+        if (!ctx->h_sweep_hist_dev)
+            HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_sweep_hist_dev, ctx->h_sweep_hist, 0));
+        run.seg_cap = stash_segment_floats(ctx->n, run.blocks);
+        const uint64_t want_stash = run.seg_cap * (uint64_t)run.blocks;
+        if (ctx->stash_cap < want_stash) {
+            if (ctx->d_stash) HIPCHK(ctx, hipFree(ctx->d_stash));
+            ctx->d_stash = nullptr;
+            ctx->stash_cap = 0;
+            if (hipMalloc((void **)&ctx->d_stash, want_stash * sizeof(float)) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->d_stash = nullptr;
+                return PAPR_OK;  // (no room for the stash: the host path reports it)
+            }
+            ctx->stash_cap = want_stash;
+        }
+        rc = ensure_table(ctx, std::max<uint32_t>(table_cap_words, 48 * 1024 / 4 + 8));
+        if (rc)
+            return rc;
+        if (exact) {
+            rc = ensure_exact_buffers(ctx);
+            if (rc)
+                return rc;
+            if (ctx->est_groups_cap < ngroups) {
+                if (ctx->d_est_groups) HIPCHK(ctx, hipFree(ctx->d_est_groups));
+                ctx->d_est_groups = nullptr;
+                ctx->est_groups_cap = 0;
+                const uint64_t cap = std::max<uint64_t>(ngroups, 4096);
+                HIPCHK(ctx, hipMalloc((void **)&ctx->d_est_groups, cap * 5 * sizeof(double)));  // 4 wave sums + 1 prefix per group
+                ctx->est_groups_cap = cap;
+            }
+            group_sums = ctx->d_est_groups;
+            if (peers) {
+                rc = reserve_exact_lists(ctx);
+                if (rc)
+                    return rc;
+            }
+        }
+        local_ok = true;
+        return PAPR_OK;
+    };
+    if (peers && !agreed) {
+        // the agreement (and, exact-sum mode, the slot size of the program exchange: from the LARGEST shard, so that every
+        // rank allocates the same): [ranks that can, largest shard]
+        uint64_t nmax = ctx->n;
+        if (exact) {
+            std::vector<uint64_t> all((size_t)world);
+            const uint64_t mine = ctx->n;
+            const int xrc = xch_allgather_host(x, &mine, all.data(), sizeof(uint64_t));
+            if (xrc)
+                return fail(ctx, xrc, "exchange: %s", papr_exchange_last_error(x));
+            nmax = *std::max_element(all.begin(), all.end());
+        }
+        ctx->xprog_slot = exact ? exact_program_slot_bytes(nmax) : 0;
+        int prc = prepare();
+        uint64_t ok = (prc == PAPR_OK && local_ok) ? 1u : 0u;
+        const int xrc = papr_exchange_counts(x, &ok, 1);
+        if (xrc)
+            return fail(ctx, xrc, "exchange: %s", papr_exchange_last_error(x));
+        ctx->peer_agreed_key = agree_key;
+        ctx->peer_agreed_ok = ok == (uint64_t)world;
+        if (prc)
+            return prc;  // (an allocation failed here; the peers heard "no" and take the host path without this rank)
+        if (!ctx->peer_agreed_ok)
+            return PAPR_OK;
+    } else {
+        const int prc = prepare();
+        if (prc)
+            return leave(prc);
+        if (!local_ok) {
+            if (!peers)
+                return PAPR_OK;
+            // (agreed earlier, and now this rank cannot: its state changed behind the agreement's back)
+            return leave(fail(ctx, PAPR_E_STATE, "the shard's state changed since the ranks agreed on the single-wait step"));
+        }
     }
     info.swept = info.resolved = 0;
     info.stash_samples = 0;
@@ -566,18 +641,26 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
     ctx->est_groups_valid = false;
     ctx->exact_program_launched = false;
     // ---- the launches ----
+    // (from here on a failure of this rank's own must release the peers: leave())
+#define XCHK(call)                                                                                  \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return leave(fail(ctx, PAPR_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)));   \
+    } while (0)
+    int rc = PAPR_OK;
     time_begin_kernel(ctx, 4, ngroups * PAPR_ESTIMATE_TILE_SAMPLES * 8);
     papr_launch_estimate(ctx->stream, est_blocks, ctx->d_iq, ngroups, (uint32_t)ratio, est_partials, group_sums, ctx->d_est_sq);
     time_end_kernel(ctx);
-    HIPCHK(ctx, hipGetLastError());
+    XCHK(hipGetLastError());
     const int band_override = ctx->tune.sweep_band_log2 > 0 ? ctx->tune.sweep_band_log2 : 0;
     if (peers) {  // exchange 1a, in the stream: every shard's estimate record
         papr_launch_est_record(ctx->stream, est_partials, ctx->d_est_sq, (uint32_t)est_blocks, ngroups,
                                ngroups * PAPR_ESTIMATE_TILE_SAMPLES, ctx->n, (uint32_t)ratio, ctx->shard_flags, d_est_mine);
-        HIPCHK(ctx, hipGetLastError());
+        XCHK(hipGetLastError());
         rc = xch_allgather_dev(x, ctx, d_est_mine, d_est_all, sizeof(papr_est_record));
         if (rc)
-            return fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x));
+            return leave(fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x)));
     }
     papr_launch_guess_bands(ctx->stream, est_partials, ctx->d_est_sq, (uint32_t)est_blocks, ngroups,
                             ngroups * PAPR_ESTIMATE_TILE_SAMPLES, ctx->n, (uint32_t)ratio, graph, (float)max_db, spoil,
@@ -585,7 +668,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
                             ctx->h_guess_dev, ctx->d_sweep_hist,
                             kBinsMax + 2u * (uint32_t)run.blocks + 1u,  // (also clears the sweep's bins and segment counters)
                             d_est_all, peers ? world : 0u, my_rank);
-    HIPCHK(ctx, hipGetLastError());
+    XCHK(hipGetLastError());
     const uint32_t tail = (uint32_t)(ctx->n - ntiles * run.tile);
     papr_ccdf_params none{};
     if (by_segments) {
@@ -594,9 +677,11 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
             ctx->est_ngroups = ngroups;
             ctx->est_ratio = ratio;
             ctx->est_groups_valid = true;
+            // (peers: ... what papr_guess_bands_kernel made of the shards' estimate records in front of this one)
             papr_launch_exact_spec(ctx->stream, ctx->d_est_groups, ngroups, (uint32_t)ratio, (double)ratio, 0.0,
-                                   ctx->d_est_groups + 4 * ctx->est_groups_cap, ctx->n / PAPR_EXACT_TILE_SAMPLES, ctx->d_tile_E_spec);
-            HIPCHK(ctx, hipGetLastError());
+                                   ctx->d_est_groups + 4 * ctx->est_groups_cap, ctx->n / PAPR_EXACT_TILE_SAMPLES, ctx->d_tile_E_spec,
+                                   peers ? &ctx->d_guess->est_before : nullptr);
+            XCHK(hipGetLastError());
         }
         papr_sweep2_params p{};
         p.data = ctx->d_iq;
@@ -633,25 +718,26 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
                           ctx->d_sweep_hist + kBinsMax + run.blocks, &ctx->d_guess->P);
         time_end_kernel(ctx);
     }
-    HIPCHK(ctx, hipGetLastError());
+    XCHK(hipGetLastError());
     // pass 1's record (tail + merge of the workgroups' records) — and, on the way, the sweep's bins and segment counters
     // into mapped host memory (sweep_fetch without a copy in the stream; PAPR_FUSED_COPIES=1 keeps the copies) ...
     const bool by_kernel = env_int("PAPR_FUSED_COPIES", 0) == 0;
     if (!by_kernel) {
         rc = sweep_fetch(ctx, run);
         if (rc)
-            return rc;
+            return leave(rc);
     }
     papr_launch_stats_finalize(ctx->stream, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->base + ctx->n - tail, ctx->d_partials,
                                (uint32_t)run.blocks, ctx->h_result_dev, ctx->d_result_copy, ctx->d_sweep_hist,
                                ctx->h_sweep_hist_dev, by_kernel ? kBinsMax + 2u * (uint32_t)run.blocks + 1u : 0u);
-    HIPCHK(ctx, hipGetLastError());
-    if (exact) {
+    XCHK(hipGetLastError());
+    if (exact && !peers) {
         // ... the sum program from the pairs the sweep built (true prefix, the refuted tiles rebuilt, groups, gather) ...
         rc = run_exact_swept(ctx, 0.0, ctx->n);
         if (rc)
-            return rc;
+            return leave(rc);
         ctx->exact_program_launched = true;
+        ctx->exact_program_before = 0.0;
     }
     // ... and, speculatively, what follows from the record: the reference's level table with the device's libm, the
     // recount LUT for it, and the recount of the stash — so that the step's second half needs no launch + wait round
@@ -662,37 +748,62 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
     if (peers) {  // exchange 1b, in the stream: the shards' pass-1 records, folded in rank (= file) order on every rank
         rc = xch_allgather_dev(x, ctx, ctx->d_result_copy, d_recs_all, sizeof(papr_partial));
         if (rc)
-            return fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x));
+            return leave(fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x)));
         papr_launch_record_merge(ctx->stream, d_recs_all, d_est_all, world, my_rank, d_total, d_n_total, ctx->h_peer_dev);
-        HIPCHK(ctx, hipGetLastError());
+        XCHK(hipGetLastError());
+        if (exact) {
+            // exact-sum mode: this shard's sum program from the pairs the sweep built, classified against the TRUE prefix —
+            // which starts at the merged records' sum in front of this shard, known on the device only (d_n_total[1]) —
+            // into this rank's slot; exchange 1c, in the stream: every rank's slot; then the used bytes of all of them into
+            // mapped host memory, where the host replays them in rank (= file) order while the stream goes on
+            // (papr_hip_analyze: overlap_work).  A program that outgrew its slot, or is not final, is marked: every rank
+            // sees that and all of them exchange on the host afterwards.
+            rc = run_exact_swept(ctx, 0.0, 0, reinterpret_cast<const double *>(d_n_total) + 1, d_n_total, ctx->d_xprog, ctx->xprog_slot);
+            if (rc)
+                return leave(rc);
+            rc = xch_allgather_dev(x, ctx, ctx->d_xprog, ctx->d_xprog_all, ctx->xprog_slot);
+            if (rc)
+                return leave(fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x)));
+            papr_launch_exact_programs_to_host(ctx->stream, ctx->d_xprog_all, ctx->xprog_slot, world, ctx->h_xprog_all_dev);
+            XCHK(hipGetLastError());
+            rc = mark_program_ready(ctx);
+            if (rc)
+                return leave(rc);
+            ctx->xprog_ready = true;
+            ctx->program_view = ctx->h_xprog_all + (size_t)my_rank * ctx->xprog_slot;
+            ctx->exact_program_launched = true;  // (exact_program_before: known after the wait)
+        }
     }
     papr_launch_true_table(ctx->stream, peers ? d_total : ctx->d_result_copy, ctx->n, graph, kTrueCopies, true_soft, ctx->d_table,
                            std::max<uint32_t>(table_cap_words, 48 * 1024 / 4 + 8), ctx->d_true, ctx->h_true_dev, ctx->d_hist,
                            PAPR_TRUE_MAX_LEVELS + 1,  // (also clears the recount's bins)
                            ctx->d_sweep_hist + kBinsMax + 2 * run.blocks, peers ? d_n_total : nullptr);
-    HIPCHK(ctx, hipGetLastError());
+    XCHK(hipGetLastError());
     {
         time_begin_kernel(ctx, 4, 0);
         papr_launch_ccdf_power(ctx->stream, ctx->num_cus, true, true_soft, ctx->d_stash, ctx->d_sweep_hist + kBinsMax,
                                run.seg_cap, (uint32_t)run.blocks, ctx->d_table, none, ctx->d_hist, &ctx->d_true->P);
         time_end_kernel(ctx);
-        HIPCHK(ctx, hipGetLastError());
+        XCHK(hipGetLastError());
     }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(PAPR_TRUE_MAX_LEVELS + 1) * sizeof(unsigned long long),
+    XCHK(hipMemcpyAsync(ctx->h_hist, ctx->d_hist, (size_t)(PAPR_TRUE_MAX_LEVELS + 1) * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost, ctx->stream));
     if (peers) {  // exchange 2, in the stream: what the sweep decided, what the recount found, and whether either may be used
         papr_launch_xpack(ctx->stream, ctx->d_sweep_hist, kBinsMax, ctx->d_sweep_hist + kBinsMax, (uint32_t)run.blocks, run.seg_cap,
                           ctx->d_sweep_hist + kBinsMax + 2 * run.blocks, ctx->d_hist, PAPR_TRUE_MAX_LEVELS + 1, ctx->d_guess,
                           ctx->d_true, d_xvec);
-        HIPCHK(ctx, hipGetLastError());
+        XCHK(hipGetLastError());
         rc = xch_allreduce_u64_dev(x, ctx, d_xvec, d_xvec_sum, kXvecWords);
         if (rc)
-            return fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_xvec, d_xvec_sum, (size_t)kXvecWords * 8, hipMemcpyDeviceToHost, ctx->stream));
+            return leave(fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x)));
+        XCHK(hipMemcpyAsync(ctx->h_xvec, d_xvec_sum, (size_t)kXvecWords * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     run_overlap_work(ctx);  // (exact-sum mode: the program's replay, while the recount runs)
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    XCHK(hipStreamSynchronize(ctx->stream));
+#undef XCHK
     ctx->program_pending = false;
+    if (peers && exact)
+        ctx->exact_program_before = ctx->h_peer->before;
     partial_to_stats(*ctx->h_result, ctx->n, out);
     out->flags |= ctx->shard_flags;
     if (peers) {
@@ -701,6 +812,9 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
         const unsigned long long *flags = ctx->h_xvec + kBinsMax + (PAPR_TRUE_MAX_LEVELS + 1);
         if (ctx->h_peer->nan_ranks != 0 || flags[1] != 0) {
             ctx->sweep_info.reason = PAPR_SWEEP_NO_BANDS;
+            ctx->xprog_ready = ctx->exact_program_launched = false;  // (whatever was gathered belongs to no usable step)
+            ctx->program_view = nullptr;
+            ctx->overlap_work = nullptr;
             return PAPR_OK;  // (*done stays false)
         }
     }
@@ -715,6 +829,8 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
         // was a plain pass 1): the plain pass of the mode takes over (exact-sum mode: with its per-tile sums)
         info.reason = PAPR_SWEEP_NO_BANDS;
         ctx->exact_program_launched = false;
+        ctx->xprog_ready = false;
+        ctx->program_view = nullptr;
         ctx->est_groups_valid = false;
         if (exact || std::isnan(out->sum))
             return papr_hip_stats(ctx, out);
@@ -743,6 +859,10 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
         peer->before = ctx->h_peer->before;
         peer->global = true;
         ctx->spec_recount_valid = ctx->h_true->ok != 0 && flags[2] == 0;
+        if (exact) {
+            ctx->exact_swept = true;  // d_seg_D holds every segment's sum and its pair (speculated, or rebuilt)
+            ctx->exact_valid = true;
+        }
     } else if (rc == PAPR_OK) {
         ctx->spec_recount_valid = ctx->h_true->ok != 0;  // (whether it is the RIGHT table is for resolve_from_sweep to say)
         if (exact) {

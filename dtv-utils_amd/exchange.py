@@ -58,6 +58,12 @@ def _lib():
         L.papr_exchange_open_ops.argtypes = [C.POINTER(vp), C.POINTER(_Ops), i32, i32]
         L.papr_exchange_open_local.argtypes = [C.POINTER(vp), i32]
         L.papr_exchange_open_local.restype = i32
+        L.papr_exchange_open_rccl_local.argtypes = [C.POINTER(vp), i32]
+        L.papr_exchange_open_rccl_local.restype = i32
+        L.papr_exchange_bind.argtypes = [vp, vp]
+        L.papr_exchange_bind.restype = i32
+        L.papr_exchange_is_rccl.argtypes = [vp]
+        L.papr_exchange_is_rccl.restype = i32
         L.papr_exchange_abort.argtypes = [vp]
         L.papr_exchange_abort.restype = None
         L.papr_exchange_close.argtypes = [vp]
@@ -77,7 +83,8 @@ def _lib():
 
 ABI_SYMBOLS = ("papr_exchange_unique_id", "papr_exchange_open_rccl", "papr_exchange_open_ops", "papr_exchange_close",
                "papr_exchange_last_error", "papr_exchange_stats", "papr_exchange_counts", "papr_exchange_exact_sum",
-               "papr_exchange_get_timing", "papr_exchange_open_local", "papr_exchange_abort")
+               "papr_exchange_get_timing", "papr_exchange_open_local", "papr_exchange_abort",
+               "papr_exchange_open_rccl_local", "papr_exchange_bind", "papr_exchange_is_rccl")
 
 
 class Exchange:
@@ -109,6 +116,30 @@ class Exchange:
         if rc:
             raise PaprError(rc, "papr_exchange_open_local", L.papr_exchange_last_error(None).decode())
         return [cls(C.c_void_p(xs[r]), r, n, "threads") for r in range(n)]
+
+    @classmethod
+    def rccl_local(cls, n: int) -> List["Exchange"]:
+        """n linked handles for n threads of this process with RCCL underneath (papr_exchange_open_rccl_local); every
+        thread calls bind(gpu) once its context is open."""
+        L = _lib()
+        xs = (C.c_void_p * n)()
+        rc = L.papr_exchange_open_rccl_local(xs, n)
+        if rc:
+            raise PaprError(rc, "papr_exchange_open_rccl_local", L.papr_exchange_last_error(None).decode())
+        return [cls(C.c_void_p(xs[r]), r, n, "threads+RCCL") for r in range(n)]
+
+    def bind(self, gpu):
+        """papr_exchange_bind: ncclCommInitRank on gpu's device (all ranks at once); no-op for the other transports."""
+        self._chk(self._L.papr_exchange_bind(self._x, gpu._ctx), "papr_exchange_bind")
+        self._keep = gpu
+        return self
+
+    @property
+    def is_rccl(self) -> bool:
+        return bool(self._L.papr_exchange_is_rccl(self._x))
+
+    def abort(self):
+        self._L.papr_exchange_abort(self._x)
 
     @classmethod
     def rccl(cls, gpu, rank: int, world: int, group=None) -> "Exchange":

@@ -13,6 +13,9 @@
  *   PAPR_GPUS=N        use N GPUs (default: one per 2 GiB of input, at most all visible)
  *   PAPR_OVERSUBSCRIBE=1  let PAPR_GPUS exceed the visible GPUs (shard g runs on GPU g mod visible);
  *                      for exercising the multi-shard path on a small machine
+ *   PAPR_XCH=rccl|threads  how the shards' partial results meet: RCCL collectives on device buffers over xGMI, queued
+ *                      on each GPU's stream (the default with more than one GPU, when librccl loads and every shard has
+ *                      a GPU of its own; =rccl also runs them for a single shard), or the plain in-process hub
  *   PAPR_STATS=1       one JSON line with sizes and timings on stderr
  *   PAPR_TEARDOWN=1    close the contexts and let the runtime's exit handlers run (default: _exit once the answer
  *                      is printed — the orderly way costs ~90 ms for a 10 GiB shard)
@@ -92,6 +95,13 @@ static void *shard_thread(void *arg)
         return NULL;
     }
     papr_hip_set_exact(s->ctx, s->exact);
+    rc = papr_exchange_bind(s->xch, s->ctx); /* RCCL transport: ncclCommInitRank, every shard's thread at once */
+    if (rc != PAPR_OK) {
+        s->rc = rc;
+        snprintf(s->err, sizeof(s->err), "exchange: %s (code %d)", papr_exchange_last_error(s->xch), rc);
+        papr_exchange_abort(s->xch);
+        return NULL;
+    }
     s->t_open = now_s();
     if (s->ingest_sweep == 1) {
         /* "when the file is streamed": does any shard exceed its GPU's HBM budget?  (decided together: every thread
@@ -240,7 +250,17 @@ int main(int argc, char **argv)
     env = getenv("PAPR_ONE_SWEEP");
     const int one_sweep = env && env[0] != '\0' ? (atoi(env) > 0 ? 2 : 0) : 1; /* 2 = always, 1 = when the file is streamed */
     papr_exchange *xs[MAX_GPUS];
-    if (papr_exchange_open_local(xs, ngpu) != PAPR_OK) {
+    /* the shards' partial peak / mean / histogram meet over RCCL (collectives on device buffers, on each GPU's stream) when
+     * there is more than one GPU — or when asked to; otherwise, or when librccl cannot be loaded, at the in-process hub */
+    env = getenv("PAPR_XCH");
+    const int rccl_forced = env && strcmp(env, "rccl") == 0;
+    const int rccl_wanted = rccl_forced || (ngpu > 1 && !(env && strcmp(env, "threads") == 0));
+    int xrc = rccl_wanted ? papr_exchange_open_rccl_local(xs, ngpu) : PAPR_E_STATE;
+    if (rccl_forced && xrc != PAPR_OK) {
+        fprintf(stderr, "papr: PAPR_XCH=rccl: %s\n", papr_exchange_last_error(NULL));
+        return 253;
+    }
+    if (xrc != PAPR_OK && papr_exchange_open_local(xs, ngpu) != PAPR_OK) {
         fprintf(stderr, "papr: out of memory\n");
         return 253;
     }
@@ -333,13 +353,14 @@ int main(int argc, char **argv)
         }
         const papr_hip_ingest_timing *it = &sh[0].ingest;
         fprintf(stderr,
-                "{\"samples\": %llu, \"bytes\": %llu, \"gpus\": %d, \"levels\": %d, \"open_s\": %.6f, "
+                "{\"samples\": %llu, \"bytes\": %llu, \"gpus\": %d, \"exchange\": \"%s\", \"levels\": %d, \"open_s\": %.6f, "
                 "\"shards_swept\": %d, \"shards_resolved_from_sweep\": %d, "
                 "\"ingest_pass1_s\": %.6f, \"exact_sum\": %d, \"exact_redo_tiles\": %u, \"analysis_s\": %.6f, \"total_s\": %.6f, "
                 "\"msamples_per_s\": %.3f, \"ingest_GBps\": %.2f, \"gpu0_ingest\": {\"setup_s\": %.4f, \"read_s\": %.4f, "
                 "\"buffer_wait_s\": %.4f, \"issue_s\": %.4f, \"drain_s\": %.4f, \"chunks\": %llu, \"reader_threads\": %d, "
                 "\"resident\": %d, \"o_direct\": %d, \"numa_bound\": %d, \"io_uring\": %d, \"file_passes\": %d}}\n",
-                (unsigned long long)nsamples, (unsigned long long)nsamples * 8, ngpu, nlevels, t_open - t0, swept, resolved,
+                (unsigned long long)nsamples, (unsigned long long)nsamples * 8, ngpu,
+                papr_exchange_is_rccl(xs[0]) ? "rccl" : (ngpu > 1 ? "threads" : "none"), nlevels, t_open - t0, swept, resolved,
                 t_loaded - t_open, r->exact_sum, r->exact_redo_tiles, t2 - t_loaded, t3 - t0, (double)nsamples / (t3 - t0) / 1e6,
                 (double)nsamples * 8 / (t_loaded - t_open) / 1e9, it->setup_s, it->read_s, it->buffer_wait_s, it->issue_s,
                 it->drain_s, (unsigned long long)it->chunks, it->reader_threads, it->resident, it->o_direct, it->numa_bound, it->io_uring, it->file_passes);

@@ -44,8 +44,23 @@ int papr_exchange_exact_sum(papr_exchange *x, const void *program, size_t bytes,
 /* An in-process transport for papr_exchange: n handles for n threads of ONE process that each drive one GPU (what
  * bin/papr does): the same exchange calls, met at a barrier instead of on a wire. xs receives n handles. */
 int papr_exchange_open_local(papr_exchange **xs, int n);
-/* a thread that cannot go on (its GPU failed) cancels the in-process exchange: the other threads' pending and future
- * exchange calls return PAPR_E_STATE instead of waiting for it (no-op for the other transports) */
+/* The same n handles for n threads of one process, with RCCL underneath ("partial peak / mean / histogram
+ * reduced over RCCL / xGMI"; what bin/papr uses when it drives more than one GPU, PAPR_XCH=threads keeps the plain hub):
+ * every thread, once it has opened its context, calls papr_exchange_bind(x, ctx) — all n of them, at about the same time:
+ * it is ncclCommInitRank on the thread's own device, which returns when every rank has joined.  From then on the step's
+ * exchanges are ncclAllGather / ncclAllReduce on device buffers, queued on each context's stream between the kernels that
+ * produce and consume them (papr_hip_analyze: one wait per step); the few host-level exchanges that remain (agreeing on a
+ * path, programs that outgrew their slot) still meet at the in-process hub.  If two shards share a device (one
+ * communicator cannot hold two ranks of one GPU) bind leaves the handles as papr_exchange_open_local made them.
+ * papr_exchange_bind is a no-op for handles of the other transports; papr_exchange_is_rccl tells what a handle became. */
+int papr_exchange_open_rccl_local(papr_exchange **xs, int n);
+int papr_exchange_bind(papr_exchange *x, papr_hip_ctx *ctx);
+int papr_exchange_is_rccl(const papr_exchange *x);
+/* A rank that cannot go on cancels the exchange so that its peers are released instead of waiting for it: the threads of
+ * the in-process transports get PAPR_E_STATE from their pending and future exchange calls, and RCCL communicators — this
+ * rank's, and with papr_exchange_open_rccl_local every thread's — are aborted (ncclCommAbort), which ends collectives that
+ * are already queued on the peers' streams.  No-op for caller-supplied collectives.  libpaprhip calls it itself when a
+ * step fails locally after its collectives have begun (papr_hip_analyze: FAILURE WITH PEERS). */
 void papr_exchange_abort(papr_exchange *x);
 
 #ifdef __cplusplus
