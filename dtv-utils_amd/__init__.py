@@ -156,7 +156,7 @@ class PaprError(RuntimeError):
 
 
 _lib: Optional[C.CDLL] = None
-SWEEP_VARIANT, SWEEP_EXACT_VARIANT = 111, 135   # the product's one-sweep kernel forms (csrc/papr_kernels.h)
+SWEEP_VARIANT, SWEEP_EXACT_VARIANT = 111, 131   # the product's one-sweep kernel forms (csrc/papr_kernels.h)
 
 
 def sweep_variant_built(variant: int) -> bool:

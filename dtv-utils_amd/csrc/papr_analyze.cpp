@@ -52,18 +52,30 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
             const int world = ctx->xprog_world;
             std::vector<const void *> progs((size_t)world);
             std::vector<size_t> sizes((size_t)world);
+            bool usable = !env_int("PAPR_EXACT_HOST_ASSEMBLY", 0);
             for (int r = 0; r < world; r++) {
-                const unsigned char *slot = ctx->h_xprog_all + (size_t)r * ctx->xprog_slot;
+                const unsigned char *slot = ctx->h_xprog_all + ctx->xprog_offs[(size_t)r];
+                const size_t room = ctx->xprog_sizes[(size_t)r];
                 papr_exact_header h;
                 memcpy(&h, slot, sizeof(h));
+                if (h.magic != PAPR_EXACT_MAGIC) {
+                    usable = false;
+                    continue;
+                }
                 const size_t want = sizeof(h) + (size_t)h.ngroups * sizeof(papr_exact_group_rec) +
                                     (size_t)h.nmixed * sizeof(papr_exact_mixed_rec) + (size_t)h.nraw * sizeof(papr_exact_raw_rec) +
                                     (size_t)h.tail_samples * 8;
-                if (h.magic != PAPR_EXACT_MAGIC || h.reserved != 0 || want > ctx->xprog_slot || env_int("PAPR_EXACT_HOST_ASSEMBLY", 0))
-                    return;
+                // a program that outgrew its slot: the slot grows to what it needed and a quarter (from the next step on;
+                // every rank reads the same header and does the same)
+                if (want > room && !env_int("PAPR_XPROG_SLOT_KB", 0))
+                    ctx->xprog_sizes[(size_t)r] = std::min<size_t>((want + want / 4 + 65535) & ~(size_t)65535, (size_t)64 << 20);
+                if (h.reserved != 0 || want > room)
+                    usable = false;
                 progs[(size_t)r] = slot;
                 sizes[(size_t)r] = want;
             }
+            if (!usable)
+                return;
             crc = papr_exact_chain(progs.data(), sizes.data(), world, &seq);
             replayed = true;
             return;

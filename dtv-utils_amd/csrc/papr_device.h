@@ -104,6 +104,81 @@ __device__ __forceinline__ uint32_t search_bin(uint32_t bits, const uint32_t *ke
     return lo;
 }
 
+
+// ---- shared by papr_exact.hip and papr_sweep.hip ---------------------------------------------------------------------
+// exclusive scan of one value per thread over the workgroup, in thread order (wave shuffles, then the wave totals):
+// what a single thread walking an LDS array did in 256 / 1024 dependent steps (17 us / 37 us per kernel,
+// profiles/r02_step_timeline.txt).  `wave_tot`: BLOCK / 64 entries of LDS; `total` (optional): the sum of all values.
+template <typename T, int BLOCK>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *wave_tot, T *total)
+{
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    T inc = v;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const T o = __shfl_up(inc, d);
+        if (lane >= d)
+            inc += o;
+    }
+    T ex = __shfl_up(inc, 1);
+    if (lane == 0)
+        ex = T(0);
+    __syncthreads();  // (wave_tot may still be read from a previous call)
+    if (lane == kWave - 1)
+        wave_tot[w] = inc;
+    __syncthreads();
+    T base = T(0), all = T(0);
+#pragma unroll
+    for (int k = 0; k < BLOCK / kWave; k++) {
+        const T x = wave_tot[k];
+        if (k < w)
+            base += x;
+        all += x;
+    }
+    if (total)
+        *total = all;
+    return base + ex;
+}
+
+
+// The exact one-read sweep's binade speculation, first half: group g of the estimate = tiles [g * ratio, (g + 1) * ratio);
+// group_sums[4 g .. 4 g + 3] (one per wave of the estimate kernel) add up to the sum of ONE tile's worth of its rows, so
+// `scale` (= ratio) times that estimates the group's sum.  Exclusive scan over the groups by one workgroup of 1024
+// (papr_exact_spec_scan_kernel — or, without peers, the second workgroup of papr_guess_bands_kernel, beside the guess).
+__device__ __forceinline__ void papr_exact_spec_scan_body(const double *__restrict__ group_sums, uint64_t ngroups, double scale,
+                                                          double before, double *__restrict__ group_prefix, double *sh /* 16 */)
+{
+    const uint64_t per = (ngroups + 1023) / 1024;
+    const uint64_t a = threadIdx.x * per, e = a + per < ngroups ? a + per : ngroups;
+    auto gsum = [&](uint64_t k) { return (((group_sums[4 * k] + group_sums[4 * k + 1]) + group_sums[4 * k + 2]) + group_sums[4 * k + 3]) * scale; };
+    // (eight groups' loads in flight at a time: one group after the other was 20 dependent trips to the L2)
+    constexpr int CH = 8;
+    double s = 0.0;
+    for (uint64_t k0 = a; k0 < e; k0 += CH) {
+        double g[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            g[j] = k0 + j < e ? gsum(k0 + j) : 0.0;
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            s += g[j];
+    }
+    // (an estimate: the order of these additions decides nothing but which tiles get redone)
+    double run = before + block_exclusive_scan<double, 1024>(s, sh, (double *)nullptr);
+    for (uint64_t k0 = a; k0 < e; k0 += CH) {
+        double g[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            g[j] = k0 + j < e ? gsum(k0 + j) : 0.0;
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            if (k0 + j < e) {
+                group_prefix[k0 + j] = run;
+                run += g[j];
+            }
+    }
+}
+
 }  // namespace
 
 #endif

@@ -26,7 +26,7 @@
 // shipped raw and added one by one on the host, which also chains everything
 // (papr_exact_chain in papr_host.c) — a few thousand dependent operations.
 //
-// Kernels:  papr_exact_block_sums -> papr_exact_scan_blocks -> papr_exact_classify
+// Kernels:  papr_exact_block_sums -> papr_exact_classify (each block adds up the block sums in front of it)
 //           papr_exact_seg_kernel   (8 B/sample HBM read; LDS transpose so that each
 //                                    lane owns 16 CONSECUTIVE samples)
 //           papr_exact_group_kernel (pre-composes 128-tile groups)
@@ -128,46 +128,14 @@ __device__ __forceinline__ Pair wave_compose(Pair f, double m0)
 
 }  // namespace
 
-// exclusive scan of one value per thread over the workgroup, in thread order (wave shuffles, then the wave totals):
-// what a single thread walking an LDS array did in 256 / 1024 dependent steps (17 us / 37 us per kernel,
-// profiles/r02_step_timeline.txt).  `wave_tot`: BLOCK / 64 entries of LDS; `total` (optional): the sum of all values.
-template <typename T, int BLOCK>
-__device__ __forceinline__ T block_exclusive_scan(T v, T *wave_tot, T *total)
-{
-    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-    T inc = v;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const T o = __shfl_up(inc, d);
-        if (lane >= d)
-            inc += o;
-    }
-    T ex = __shfl_up(inc, 1);
-    if (lane == 0)
-        ex = T(0);
-    __syncthreads();  // (wave_tot may still be read from a previous call)
-    if (lane == kWave - 1)
-        wave_tot[w] = inc;
-    __syncthreads();
-    T base = T(0), all = T(0);
-#pragma unroll
-    for (int k = 0; k < BLOCK / kWave; k++) {
-        const T x = wave_tot[k];
-        if (k < w)
-            base += x;
-        all += x;
-    }
-    if (total)
-        *total = all;
-    return base + ex;
-}
-
 // ---- tile prefix sums and classification ------------------------------------------
 
 template <bool SEGD>
 __global__ __launch_bounds__(256) void papr_exact_block_sums(const double *__restrict__ tws, uint64_t ntiles,
-                                                              double *__restrict__ block_sums)
+                                                              double *__restrict__ block_sums, uint32_t *__restrict__ zero_word)
 {
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0)
+        *zero_word = 0;  // (the redo list's counter, for the classification that follows: saves a memset in the stream)
     __shared__ double sh[256];
     const uint64_t t0 = (uint64_t)blockIdx.x * kTilesPerBlock + (uint64_t)threadIdx.x * 4;
     double s = 0.0;
@@ -184,41 +152,6 @@ __global__ __launch_bounds__(256) void papr_exact_block_sums(const double *__res
     }
 }
 
-// in-place exclusive scan of the block sums, starting from `before` (the accurate
-// sum of everything that precedes this shard in the file)
-__global__ __launch_bounds__(256) void papr_exact_scan_blocks(double *__restrict__ block_sums, uint32_t nblocks,
-                                                               double before, uint32_t *__restrict__ zero_word,
-                                                               const double *__restrict__ before_dev)
-{
-    if (before_dev)
-        before = *before_dev;  // (peers, single-wait step: the merged records' sum in front of this shard is on the device)
-    if (zero_word && threadIdx.x == 0)
-        *zero_word = 0;  // (the redo list's counter, for the classification that follows: saves a memset in the stream)
-    __shared__ double sh[256];
-    const uint32_t per = (nblocks + 255) / 256;
-    const uint32_t a = threadIdx.x * per, e = min(a + per, nblocks);
-    double s = 0.0;
-    for (uint32_t k = a; k < e; k++)
-        s += block_sums[k];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double run = before;
-        for (int k = 0; k < 256; k++) {
-            const double v = sh[k];
-            sh[k] = run;
-            run += v;
-        }
-    }
-    __syncthreads();
-    double run = sh[threadIdx.x];
-    for (uint32_t k = a; k < e; k++) {
-        const double v = block_sums[k];
-        block_sums[k] = run;
-        run += v;
-    }
-}
-
 // `spec` (one-read sweep): the binade each tile's pairs were built for; a tile that is provably inside ANOTHER binade
 // (or had none) goes on the redo list — its two segments are recomputed by papr_exact_seg_kernel's list form
 template <bool SEGD>
@@ -231,7 +164,8 @@ __global__ __launch_bounds__(256) void papr_exact_classify(const double *__restr
                                                             uint32_t *__restrict__ redo_list, uint32_t redo_cap,
                                                             uint32_t *__restrict__ redo_count,
                                                             const unsigned long long *__restrict__ n_total_dev,
-                                                            unsigned long long n_shard)
+                                                            unsigned long long n_shard, double before,
+                                                            const double *__restrict__ before_dev)
 {
     if (n_total_dev) {  // (peers: the file's length is known on the device only — the margin as the host computes it)
         const unsigned long long nt = *n_total_dev;
@@ -247,8 +181,21 @@ __global__ __launch_bounds__(256) void papr_exact_classify(const double *__restr
     }
     sh[threadIdx.x] = tot;
     __syncthreads();
+    // this block's prefix: `before` + the sums of the blocks in front of it, added up here (a few hundred values out of the
+    // L2 — a scan kernel of its own between the block sums and this one was a launch and 5 us of one workgroup).  Any
+    // order will do: the prefix only has to be good to `delta`.
+    __shared__ double sh_pre[256];
+    {
+        double a = 0.0;
+        for (uint32_t k = threadIdx.x; k < blockIdx.x; k += 256)
+            a += block_prefix[k];
+        sh_pre[threadIdx.x] = a;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        double run = block_prefix[blockIdx.x];
+        double run = before_dev ? *before_dev : before;
+        for (int k = 0; k < 256; k++)
+            run += sh_pre[k];
         for (int k = 0; k < 256; k++) {
             const double v = sh[k];
             sh[k] = run;
@@ -506,11 +453,11 @@ __global__ __launch_bounds__(256) void papr_exact_capture_kernel(const float *__
 // pinned host memory, so the host does one stream synchronisation instead of ~50 small copies.
 
 // ordered lists of the mixed groups and of their unprovable tiles
-__global__ __launch_bounds__(256) void papr_exact_plan_kernel(const papr_exact_group *__restrict__ groups, uint64_t ngroups,
-                                                               const int32_t *__restrict__ tile_E, uint64_t ntiles,
-                                                               uint32_t *__restrict__ mixed_list, uint32_t cap_mixed,
-                                                               uint32_t *__restrict__ raw_list, uint32_t cap_raw,
-                                                               papr_exact_plan *__restrict__ out)
+// (a device function: every workgroup of papr_exact_pack_kernel makes the plan for itself, into LDS — a kernel of its own
+// for it was 13 us of one workgroup's dependent loops plus a launch in the exact-sum step's chain of small kernels)
+__device__ __forceinline__ void exact_plan(const papr_exact_group *__restrict__ groups, uint64_t ngroups,
+                                           const int32_t *__restrict__ tile_E, uint64_t ntiles, uint32_t *mixed_list,
+                                           uint32_t cap_mixed, uint32_t *raw_list, uint32_t cap_raw, papr_exact_plan *out)
 {
     __shared__ uint32_t sh[256 / kWave];
     uint32_t sh_total = 0;
@@ -561,12 +508,13 @@ __global__ __launch_bounds__(256) void papr_exact_plan_kernel(const papr_exact_g
         out->overflow = (nmixed_all > cap_mixed || nraw_all > cap_raw) ? 1u : 0u;
         out->pad = 0;
     }
+    __syncthreads();
 }
 
 // one workgroup per piece of the program: group-table chunks, mixed records, raw tiles, header + tail
-__global__ __launch_bounds__(256) void papr_exact_pack_kernel(const papr_exact_plan *__restrict__ plan,
-                                                               const uint32_t *__restrict__ mixed_list,
-                                                               const uint32_t *__restrict__ raw_list,
+__global__ __launch_bounds__(256) void papr_exact_pack_kernel(papr_exact_plan *__restrict__ plan_out,
+                                                               uint32_t *__restrict__ mixed_list_out,
+                                                               uint32_t *__restrict__ raw_list_out,
                                                                const papr_exact_group *__restrict__ groups,
                                                                uint64_t ngroups, const int32_t *__restrict__ tile_E,
                                                                uint64_t ntiles, const double *__restrict__ seg_D,
@@ -580,6 +528,19 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(const papr_exact_p
                                                                uint32_t *__restrict__ count_dst, uint64_t out_cap,
                                                                uint32_t redo_cap)
 {
+    __shared__ uint32_t mixed_list[256], raw_list[512];  // (kCapMixed, kCapRaw)
+    __shared__ papr_exact_plan plan_sh;
+    papr_exact_plan *plan = &plan_sh;
+    exact_plan(groups, ngroups, tile_E, ntiles, mixed_list, cap_mixed < 256u ? cap_mixed : 256u, raw_list,
+               cap_raw < 512u ? cap_raw : 512u, plan);
+    if (blockIdx.x + 1 == gridDim.x) {  // (the plan also goes where the host-side fallbacks look for it)
+        for (uint32_t k = threadIdx.x; k < plan->nmixed; k += 256)
+            mixed_list_out[k] = mixed_list[k];
+        for (uint32_t k = threadIdx.x; k < plan->nraw; k += 256)
+            raw_list_out[k] = raw_list[k];
+        if (threadIdx.x == 0)
+            *plan_out = plan_sh;
+    }
     const uint32_t nmixed = plan->nmixed, nraw = plan->nraw;
     const size_t off_groups = 48;  // sizeof(papr_exact_header)
     const size_t off_mixed = off_groups + ngroups * 24;
@@ -664,12 +625,11 @@ void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, ui
     const uint32_t nb = (uint32_t)((ntiles + kTilesPerBlock - 1) / kTilesPerBlock);
     if (nb == 0)
         return;
-    hipLaunchKernelGGL(papr_exact_block_sums<false>, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums);
-    hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before, (uint32_t *)nullptr,
-                       (const double *)nullptr);
+    hipLaunchKernelGGL(papr_exact_block_sums<false>, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums,
+                       (uint32_t *)nullptr);
     hipLaunchKernelGGL(papr_exact_classify<false>, dim3(nb), dim3(256), 0, st, tile_wave_sums, ntiles, block_sums, delta,
                        tile_E, ambig_list, ambig_cap, ambig_count, (const int32_t *)nullptr, (uint32_t *)nullptr, 0u,
-                       (uint32_t *)nullptr, (const unsigned long long *)nullptr, 0ull);
+                       (uint32_t *)nullptr, (const unsigned long long *)nullptr, 0ull, before, (const double *)nullptr);
     if (ambig_list)
         hipLaunchKernelGGL(papr_exact_sort_list_kernel, dim3(1), dim3(512), 0, st, ambig_list, ambig_count, ambig_cap,
                            ambig_sorted);
@@ -687,11 +647,10 @@ void papr_launch_exact_classify_swept(hipStream_t st, const void *seg_D, uint64_
     if (nb == 0)
         return;
     const double *sums = (const double *)seg_D;
-    hipLaunchKernelGGL(papr_exact_block_sums<true>, dim3(nb), dim3(256), 0, st, sums, ntiles, block_sums);
-    hipLaunchKernelGGL(papr_exact_scan_blocks, dim3(1), dim3(256), 0, st, block_sums, nb, before, redo_count, before_dev);
+    hipLaunchKernelGGL(papr_exact_block_sums<true>, dim3(nb), dim3(256), 0, st, sums, ntiles, block_sums, redo_count);
     hipLaunchKernelGGL(papr_exact_classify<true>, dim3(nb), dim3(256), 0, st, sums, ntiles, block_sums, delta, tile_E,
                        ambig_list, ambig_cap, ambig_count, spec, redo_list, redo_cap, redo_count, n_total_dev,
-                       (unsigned long long)n_shard);
+                       (unsigned long long)n_shard, before, before_dev);
     if (ambig_list)  // a streamed shard: the unprovable tiles, ascending (they are read back from the file for the program)
         hipLaunchKernelGGL(papr_exact_sort_list_kernel, dim3(1), dim3(512), 0, st, ambig_list, ambig_count, ambig_cap,
                            ambig_sorted);
@@ -783,35 +742,7 @@ __global__ __launch_bounds__(1024) void papr_exact_spec_scan_kernel(const double
     if (before_dev)
         before = *before_dev;  // (peers: the estimated sum in front of this shard, from every shard's estimate record)
     __shared__ double sh[1024 / kWave];
-    const uint64_t per = (ngroups + 1023) / 1024;
-    const uint64_t a = threadIdx.x * per, e = min(a + per, ngroups);
-    auto gsum = [&](uint64_t k) { return (((group_sums[4 * k] + group_sums[4 * k + 1]) + group_sums[4 * k + 2]) + group_sums[4 * k + 3]) * scale; };
-    // (eight groups' loads in flight at a time: one group after the other was 20 dependent trips to the L2)
-    constexpr int CH = 8;
-    double s = 0.0;
-    for (uint64_t k0 = a; k0 < e; k0 += CH) {
-        double g[CH];
-#pragma unroll
-        for (int j = 0; j < CH; j++)
-            g[j] = k0 + j < e ? gsum(k0 + j) : 0.0;
-#pragma unroll
-        for (int j = 0; j < CH; j++)
-            s += g[j];
-    }
-    // (an estimate: the order of these additions decides nothing but which tiles get redone)
-    double run = before + block_exclusive_scan<double, 1024>(s, sh, (double *)nullptr);
-    for (uint64_t k0 = a; k0 < e; k0 += CH) {
-        double g[CH];
-#pragma unroll
-        for (int j = 0; j < CH; j++)
-            g[j] = k0 + j < e ? gsum(k0 + j) : 0.0;
-#pragma unroll
-        for (int j = 0; j < CH; j++)
-            if (k0 + j < e) {
-                group_prefix[k0 + j] = run;
-                run += g[j];
-            }
-    }
+    papr_exact_spec_scan_body(group_sums, ngroups, scale, before, group_prefix, sh);
 }
 
 // ... then per tile: the binade of the estimated prefix if the estimated tile lies well inside it, else none.
@@ -850,7 +781,8 @@ __global__ __launch_bounds__(256) void papr_exact_fill_spec_kernel(int32_t *__re
 }
 
 void papr_launch_exact_spec(hipStream_t st, const double *group_sums, uint64_t ngroups, uint32_t ratio, double scale,
-                            double before, double *group_prefix, uint64_t ntiles, int32_t *spec, const double *before_dev)
+                            double before, double *group_prefix, uint64_t ntiles, int32_t *spec, const double *before_dev,
+                            bool scan_done)
 {
     if (ntiles == 0)
         return;
@@ -860,8 +792,9 @@ void papr_launch_exact_spec(hipStream_t st, const double *group_sums, uint64_t n
                            (int32_t)PAPR_EXACT_AMBIG);
         return;
     }
-    hipLaunchKernelGGL(papr_exact_spec_scan_kernel, dim3(1), dim3(1024), 0, st, group_sums, ngroups, scale, before,
-                       group_prefix, before_dev);
+    if (!scan_done)  // (else papr_guess_bands_kernel's second workgroup did it, beside the guess)
+        hipLaunchKernelGGL(papr_exact_spec_scan_kernel, dim3(1), dim3(1024), 0, st, group_sums, ngroups, scale, before,
+                           group_prefix, before_dev);
     hipLaunchKernelGGL(papr_exact_spec_tiles_kernel, dim3(blocks), dim3(256), 0, st, group_sums, group_prefix, ngroups,
                        ratio, scale, ntiles, spec);
 }
@@ -903,8 +836,6 @@ void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint
                             unsigned char *out_mapped, const uint32_t *count_src, uint32_t *count_dst, uint64_t out_cap,
                             uint32_t redo_cap)
 {
-    hipLaunchKernelGGL(papr_exact_plan_kernel, dim3(1), dim3(256), 0, st, groups, ngroups, tile_E, ntiles, mixed_list,
-                       cap_mixed, raw_list, cap_raw, plan);
     const uint32_t group_blocks = (uint32_t)std::min<uint64_t>(64, (ngroups * 3 + 255) / 256 + 1);
     hipLaunchKernelGGL(papr_exact_pack_kernel, dim3(group_blocks + cap_mixed + cap_raw + 1), dim3(256), 0, st, plan,
                        mixed_list, raw_list, groups, ngroups, tile_E, ntiles, (const double *)seg_D, (const float *)data,
@@ -916,11 +847,12 @@ void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint
 // After the all-gather of the ranks' fixed-size slots: one workgroup per rank copies the USED bytes of that rank's slot
 // into the same slot of a mapped host buffer (the host replays all programs in rank order while the stream goes on with
 // the recount).  A slot whose header is marked (or is no header at all) travels as its 48 header bytes.
-__global__ __launch_bounds__(1024) void papr_exact_programs_to_host_kernel(const unsigned char *__restrict__ slots, uint64_t slot_bytes,
+__global__ __launch_bounds__(1024) void papr_exact_programs_to_host_kernel(const unsigned char *__restrict__ slots, const papr_xprog_layout lay,
                                                                            unsigned char *__restrict__ host)
 {
-    const unsigned char *src = slots + (uint64_t)blockIdx.x * slot_bytes;
-    unsigned char *dst = host + (uint64_t)blockIdx.x * slot_bytes;
+    const uint64_t off = lay.offs[blockIdx.x], slot_bytes = lay.offs[blockIdx.x + 1] - off;
+    const unsigned char *src = slots + off;
+    unsigned char *dst = host + off;
     const uint32_t *h32 = reinterpret_cast<const uint32_t *>(src);
     const unsigned long long *h64 = reinterpret_cast<const unsigned long long *>(src);
     uint64_t used = 48;
@@ -935,8 +867,8 @@ __global__ __launch_bounds__(1024) void papr_exact_programs_to_host_kernel(const
         d8[k] = s8[k];
 }
 
-void papr_launch_exact_programs_to_host(hipStream_t st, const void *slots, uint64_t slot_bytes, uint32_t world, void *host_mapped)
+void papr_launch_exact_programs_to_host(hipStream_t st, const void *slots, const papr_xprog_layout &lay, void *host_mapped)
 {
-    hipLaunchKernelGGL(papr_exact_programs_to_host_kernel, dim3(world), dim3(1024), 0, st, (const unsigned char *)slots, slot_bytes,
+    hipLaunchKernelGGL(papr_exact_programs_to_host_kernel, dim3(lay.world), dim3(1024), 0, st, (const unsigned char *)slots, lay,
                        (unsigned char *)host_mapped);
 }

@@ -216,15 +216,17 @@ int reserve_exact_lists(papr_hip_ctx *ctx)
                                     (size_t)kCapRaw * sizeof(papr_exact_raw_rec) + (size_t)tail * 8);
 }
 
-// Slot of the in-stream program exchange: the group table of the largest shard, room for 16 mixed groups and 32 raw
-// tiles (the 10 GiB bench shard that starts the file: 13 and 23; shards further in: 1-2 and 2-4) and a whole tail, in
-// units of 64 KiB.  A program that outgrows its slot is marked and the ranks exchange on the host (nothing is lost).
+// Slot of the in-stream program exchange, to begin with: the group table of the largest shard, room for 4 mixed groups and
+// 8 raw tiles (shards inside a file: 1-2 and 2-4; the shard that STARTS the file crosses the binades of the small sums: 13
+// and 23 for the 10 GiB bench shard, more when the file is longer) and a whole tail, in units of 64 KiB.  A program that
+// outgrows its slot is marked, that step's programs cross on the host (nothing is lost), and the slot of THAT rank grows
+// to what it needed (papr_hip_analyze: every rank sees the same headers).
 size_t exact_program_slot_bytes(uint64_t nsamples)
 {
     const uint64_t ntiles = nsamples / PAPR_EXACT_TILE_SAMPLES;
     const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
-    const size_t want = sizeof(papr_exact_header) + ngroups * sizeof(papr_exact_group_rec) + 16 * sizeof(papr_exact_mixed_rec) +
-                        32 * sizeof(papr_exact_raw_rec) + (size_t)PAPR_EXACT_TILE_SAMPLES * 8;
+    const size_t want = sizeof(papr_exact_header) + ngroups * sizeof(papr_exact_group_rec) + 4 * sizeof(papr_exact_mixed_rec) +
+                        8 * sizeof(papr_exact_raw_rec) + (size_t)PAPR_EXACT_TILE_SAMPLES * 8;
     const size_t forced = (size_t)std::max(0, env_int("PAPR_XPROG_SLOT_KB", 0)) * 1024;  // (tests: a slot too small on purpose)
     return forced ? forced : (want + 65535) & ~(size_t)65535;
 }

@@ -24,6 +24,9 @@ struct RcclApi {
     decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
@@ -51,6 +54,9 @@ RcclApi *rccl()
         SYM(CommAbort);
         SYM(AllGather);
         SYM(AllReduce);
+        SYM(Broadcast);
+        SYM(GroupStart);
+        SYM(GroupEnd);
         SYM(GetErrorString);
 #undef SYM
         if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.AllReduce)
@@ -349,6 +355,51 @@ int xch_allgather_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev,
     if (!x->comm)
         return through_the_host(x, ctx, send_dev, recv_dev, bytes_per_rank, bytes_per_rank * (size_t)x->world, false);
     XNCCL(x, rccl()->AllGather(send_dev, recv_dev, bytes_per_rank, ncclUint8, x->comm, x->ctx->stream));
+    x->timing.in_stream_calls++;
+    return PAPR_OK;
+}
+
+// every rank's block of its own size: recv_dev + offs[r] receives rank r's sizes[r] bytes (sizes / offs: the same on every
+// rank).  RCCL: one broadcast per rank inside a group call — one launch; the stand-in pads to the largest.
+int xch_allgatherv_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev, void *recv_dev, const size_t *sizes,
+                       const size_t *offs)
+{
+    const int world = x->world, me = x->rank;
+    if (!x->comm) {
+        size_t big = 0;
+        for (int r = 0; r < world; r++)
+            big = std::max(big, sizes[r]);
+        try {
+            x->scratch.resize(big * (size_t)(world + 1));
+        } catch (...) {
+            return xfail(x, PAPR_E_NOMEM, "out of host memory");
+        }
+        unsigned char *hs = x->scratch.data(), *hr = hs + big;
+        memset(hs, 0, big);
+        XHIP(x, hipMemcpyAsync(hs, send_dev, sizes[me], hipMemcpyDeviceToHost, ctx->stream));
+        XHIP(x, hipStreamSynchronize(ctx->stream));
+        std::vector<unsigned char> mine(hs, hs + big);  // (allgather_bytes may use x->scratch itself: not here, but keep the send apart)
+        int rc = allgather_bytes(x, mine.data(), hr, big);
+        if (rc)
+            return rc;
+        for (int r = 0; r < world; r++)
+            XHIP(x, hipMemcpyAsync((unsigned char *)recv_dev + offs[r], hr + (size_t)r * big, sizes[r], hipMemcpyHostToDevice, ctx->stream));
+        XHIP(x, hipStreamSynchronize(ctx->stream));
+        x->timing.in_stream_calls++;
+        return PAPR_OK;
+    }
+    if (!rccl()->Broadcast || !rccl()->GroupStart || !rccl()->GroupEnd)
+        return xfail(x, PAPR_E_NO_DEVICE, "this RCCL has no ncclBroadcast / group calls");
+    XNCCL(x, rccl()->GroupStart());
+    for (int r = 0; r < world; r++) {
+        unsigned char *dst = (unsigned char *)recv_dev + offs[r];
+        const ncclResult_t rr = rccl()->Broadcast(r == me ? send_dev : (const void *)dst, dst, sizes[r], ncclUint8, r, x->comm, x->ctx->stream);
+        if (rr != ncclSuccess) {
+            (void)rccl()->GroupEnd();
+            return xfail(x, PAPR_E_HIP, "ncclBroadcast failed: %s", rccl()->GetErrorString ? rccl()->GetErrorString(rr) : "RCCL error");
+        }
+    }
+    XNCCL(x, rccl()->GroupEnd());
     x->timing.in_stream_calls++;
     return PAPR_OK;
 }

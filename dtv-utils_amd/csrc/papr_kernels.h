@@ -85,7 +85,11 @@ void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint
                             uint64_t out_cap = 0 /* bytes `out` can hold (0: as much as any program needs) */,
                             uint32_t redo_cap = 0 /* with count_src: a larger count marks the program as not final */);
 /* peers: the used bytes of every rank's program slot (device, after the all-gather) into the same slot of mapped host memory */
-void papr_launch_exact_programs_to_host(hipStream_t st, const void *slots, uint64_t slot_bytes, uint32_t world, void *host_mapped);
+struct papr_xprog_layout {
+    uint32_t world, pad;
+    uint64_t offs[65];  /* slot r = bytes [offs[r], offs[r + 1]) (8-byte aligned; at most 64 ranks) */
+};
+void papr_launch_exact_programs_to_host(hipStream_t st, const void *slots, const papr_xprog_layout &lay, void *host_mapped);
 /* ambig_* may be null (resident shards); otherwise the unprovable tiles are also listed, ascending, in ambig_sorted */
 void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, uint64_t ntiles, double *block_sums,
                                 double before, double delta, int32_t *tile_E, uint32_t *ambig_list, uint32_t ambig_cap,
@@ -93,7 +97,8 @@ void papr_launch_exact_classify(hipStream_t st, const double *tile_wave_sums, ui
 /* one-read sweep (papr_sweep2_kernel<EXACT>): speculated binades before it, true classification + redo after it */
 void papr_launch_exact_spec(hipStream_t st, const double *group_sums, uint64_t ngroups, uint32_t ratio, double scale,
                             double before, double *group_prefix, uint64_t ntiles, int32_t *spec,
-                            const double *before_dev = nullptr /* overrides `before` (peers: known on the device only) */);
+                            const double *before_dev = nullptr /* overrides `before` (peers: known on the device only) */,
+                            bool scan_done = false /* papr_launch_guess_bands already made group_prefix (its spec_* arguments) */);
 void papr_launch_exact_fill_spec(hipStream_t st, int32_t *spec, uint64_t ntiles, int32_t E);
 /* ambig_* may be null (resident shards); otherwise the unprovable tiles are also listed, ascending, in ambig_sorted */
 void papr_launch_exact_classify_swept(hipStream_t st, const void *seg_D, uint64_t ntiles, double *block_sums, double before,
@@ -202,15 +207,17 @@ void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, c
                              uint32_t table_cap_words, papr_guess_out *out_dev, papr_guess_out *out_host,
                              unsigned long long *zero /* words the kernel clears on its way */, uint32_t zero_words,
                              const papr_est_record *recs = nullptr /* all shards' estimate records, rank order (peers) */,
-                             uint32_t nrecs = 0, uint32_t my_rank = 0);
+                             uint32_t nrecs = 0, uint32_t my_rank = 0,
+                             const double *spec_group_sums = nullptr /* exact-sum mode without peers: a SECOND workgroup scans the */,
+                             uint64_t spec_ngroups = 0 /* estimate's per-group sums for the binade speculation meanwhile */,
+                             double spec_scale = 0.0, double *spec_group_prefix = nullptr);
 /* the product form of the sweep: papr_sweep_kernel = 512 threads x 8 loads per lane (64 KiB tiles), one persistent
  * workgroup per CU, 12 KiB of stash slice per wave; its variant id, and papr_sweep3_kernel's (exact-sum mode) */
 #define PAPR_SWEEP_THREADS 512
 #define PAPR_SWEEP_LOADS 8
 #define PAPR_SWEEP_SLICE_FLOATS 3072u
 #define PAPR_SWEEP_VARIANT 111
-#define PAPR_SWEEP3_VARIANT 135          /* papr_sweep3_kernel<.., POW>: the powers cross the LDS */
-#define PAPR_SWEEP3_SAMPLES_VARIANT 131  /* ... its predecessor: the samples do (kept for the A/B of profiles/r04_*) */
+#define PAPR_SWEEP3_VARIANT 131
 int papr_sweep_variant(int variant); /* the sweep geometry used for a variant id, or -1 */
 #define PAPR_SWEEP_VARIANT_IS_LUT2(v) (((v) >= 20 && (v) <= 29) || ((v) >= 70 && (v) <= 79) || (v) == 18 || (v) == 38) /* compact table: papr_sweep_kernel<LUT2>, papr_sweep_split_kernel */
 #define PAPR_SWEEP_VARIANT_IS_PERSISTENT(v) ((v) == PAPR_SWEEP_VARIANT || (v) == 40 || (v) == 114 || ((v) >= 120 && (v) <= 129) || ((v) >= 140 && (v) <= 154)) /* launched as ONE workgroup per CU (512 threads x 8 loads per lane) */
@@ -288,7 +295,6 @@ struct papr_sweep2_params {
     uint64_t seg_offset;          // index of the launch's first segment within the shard (chunked launches)
     uint32_t lds_bytes;           // papr_sweep3_kernel: the launch's dynamic LDS (set by its launch wrapper)
     uint32_t fine_table;          // papr_sweep3_kernel: more than 64 bands (the 0.1 dB table) — selects the kernel form
-    uint32_t slice_cap;           // papr_sweep3_kernel: 0, or an upper limit for the per-wave stash slice (words)
 };
 int papr_sweep2_geometry(int variant, int *threads, uint64_t *seg_samples, size_t *lds_fixed, int *exact);
 // ---- the exact-sum sweep, third form (papr_sweep.hip: papr_sweep3_kernel) ----------------------------------------

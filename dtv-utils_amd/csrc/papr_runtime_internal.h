@@ -195,7 +195,10 @@ struct papr_hip_ctx {
     double exact_program_before = 0.0;   // ... with this sum in front of the shard (0 without peers)
     // peers, single-wait step: every rank's program slot after the in-stream all-gather (device; mapped host)
     unsigned char *d_xprog = nullptr, *d_xprog_all = nullptr, *h_xprog_all = nullptr, *h_xprog_all_dev = nullptr;
-    size_t xprog_slot = 0;               // bytes per slot (every rank sizes it from the same numbers)
+    size_t xprog_slot = 0;               // bytes of a slot to begin with (every rank sizes it from the same numbers)
+    std::vector<size_t> xprog_sizes, xprog_offs;  // per rank: its slot and where it starts — the same on every rank: a rank
+                                         // whose program outgrew its slot is seen by all (the headers), and all enlarge it
+    size_t xprog_cap_mine = 0, xprog_cap_all = 0;  // what d_xprog / d_xprog_all, h_xprog_all hold
     int xprog_world = 0;                 // slots in d_xprog_all / h_xprog_all
     bool xprog_ready = false;            // h_xprog_all holds the current step's programs (behind ev_program)
     const unsigned char *program_view = nullptr;  // where the current step's own program is, if not in h_program
@@ -413,6 +416,8 @@ int xch_allgather_host(papr_exchange *x, const void *send, void *recv, size_t by
 int xch_rank(const papr_exchange *x);
 int xch_world(const papr_exchange *x);
 int xch_allgather_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
+int xch_allgatherv_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev, void *recv_dev, const size_t *sizes,
+                       const size_t *offs);
 int xch_allreduce_u64_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev, void *recv_dev, size_t count);
 int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total, const double *before_dev = nullptr,
                     const unsigned long long *n_total_dev = nullptr, unsigned char *slot_dev = nullptr, uint64_t slot_cap = 0);

@@ -271,8 +271,16 @@ __global__ __launch_bounds__(1024) void papr_guess_bands_kernel(
     uint64_t sampled, uint64_t nsamples, uint32_t ratio, int graph, float max_db, float spoil, int band_override,
     uint32_t copies, int compact, uint32_t soft_lds, uint32_t *__restrict__ table, uint32_t table_cap_words,
     papr_guess_out *__restrict__ out_dev, papr_guess_out *__restrict__ out_host, unsigned long long *__restrict__ zero,
-    uint32_t zero_words, const papr_est_record *__restrict__ recs, uint32_t nrecs, uint32_t my_rank)
+    uint32_t zero_words, const papr_est_record *__restrict__ recs, uint32_t nrecs, uint32_t my_rank,
+    const double *__restrict__ spec_group_sums, uint64_t spec_ngroups, double spec_scale, double *__restrict__ spec_group_prefix)
 {
+    if (blockIdx.x == 1) {
+        // exact-sum mode without peers: the scan of the estimate's per-group sums (first half of the binade speculation,
+        // papr_exact.hip) has nothing to do with the guess — it runs beside it instead of behind it
+        __shared__ double sh_scan[1024 / kWave];
+        papr_exact_spec_scan_body(spec_group_sums, spec_ngroups, spec_scale, 0.0, spec_group_prefix, sh_scan);
+        return;
+    }
     constexpr uint32_t kNeverHi = 0xFFFFFFFFu;
     for (uint32_t w = threadIdx.x; w < zero_words; w += 1024)
         zero[w] = 0;  // (the sweep's histogram and segment counters: saves a memset between the launches)
@@ -478,11 +486,14 @@ void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, c
                              float spoil, int band_override, uint32_t copies, int compact, uint32_t soft_lds, uint32_t *table,
                              uint32_t table_cap_words, papr_guess_out *out_dev, papr_guess_out *out_host,
                              unsigned long long *zero, uint32_t zero_words, const papr_est_record *recs, uint32_t nrecs,
-                             uint32_t my_rank)
+                             uint32_t my_rank, const double *spec_group_sums, uint64_t spec_ngroups, double spec_scale,
+                             double *spec_group_prefix)
 {
-    hipLaunchKernelGGL(papr_guess_bands_kernel, dim3(1), dim3(1024), 0, st, est_partials, est_sq, est_blocks, ngroups, sampled,
-                       nsamples, ratio, graph, max_db, spoil, band_override, copies, compact, soft_lds, table, table_cap_words,
-                       out_dev, out_host, zero, zero_words, recs, nrecs, my_rank);
+    const bool with_scan = spec_group_sums && spec_group_prefix && spec_ngroups;
+    hipLaunchKernelGGL(papr_guess_bands_kernel, dim3(with_scan ? 2 : 1), dim3(1024), 0, st, est_partials, est_sq, est_blocks, ngroups,
+                       sampled, nsamples, ratio, graph, max_db, spoil, band_override, copies, compact, soft_lds, table,
+                       table_cap_words, out_dev, out_host, zero, zero_words, recs, nrecs, my_rank, spec_group_sums, spec_ngroups,
+                       spec_scale, spec_group_prefix);
 }
 
 // =============================================================================
@@ -819,15 +830,9 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep_kernel(const fl
 // 18 SALU per sample against 26 + 12 here) and the forms of this kernel that lost (two batches per segment, the powers
 // instead of the samples through LDS, 12 waves) are measure/papr_sweep_lab.hip's and DESIGN.md section 5's.
 // FINE: the 0.1 dB table's form (a kernel of its own: as one wave-uniform branch the second path costs the first 0.05 ms)
-// POW: only the POWERS cross the LDS (4 bytes per sample instead of 8).  Everything but the two chains of the sequential
-// sum is indifferent to which lane holds which sample — trackers, table lookups, histogram and stash are — so all of it runs
-// on the registers AS LOADED (lane l: 16-byte words u * 64 + l of the segment, papr_sweep_kernel's layout) and only the 16
-// powers of a lane are written out (eight 8-byte writes) and read back as the lane's run of 16 consecutive samples (four
-// 16-byte reads): half the LDS traffic of the transposition, half its buffer — which the stash slices get.
-template <bool FINE, int MODE>
+template <bool FINE>
 __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const papr_sweep2_params p)
 {
-    constexpr bool POW = MODE != 0, EARLY = MODE == 2;  // (EARLY: the run's reads and chains in front of the table lookups' use)
     constexpr int U = 8, WAVES = PAPR_SWEEP_THREADS / kWave;
     constexpr int BLOCK = PAPR_SWEEP_THREADS;
     constexpr uint64_t SEG_F4 = 64ull * U;
@@ -841,14 +846,12 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
     // the stash slices take what table and histogram leave of the launch's LDS (p.lds_bytes): a small table (the 1 dB
     // one) means rare, wide spills; at least PAPR_SWEEP3_SLICE_FLOATS (what the geometry function promises), at most 4096
     const uint32_t used_words = (uint32_t)(slices - reinterpret_cast<float *>(smem));
-    constexpr uint32_t kXposeWords = WAVES * (POW ? 1024u : 2048u);
+    constexpr uint32_t kXposeWords = WAVES * 2048u;
     const uint32_t free_words = p.lds_bytes / 4u > used_words + kXposeWords ? p.lds_bytes / 4u - used_words - kXposeWords : 0u;
     uint32_t slice_words = (free_words / WAVES) & ~63u;
     slice_words = slice_words < PAPR_SWEEP3_SLICE_FLOATS ? PAPR_SWEEP3_SLICE_FLOATS : (slice_words > 4096u ? 4096u : slice_words);
-    if (p.slice_cap && slice_words > p.slice_cap)
-        slice_words = p.slice_cap;  // (experiment knob: PAPR_S3_SLICE_CAP)
     const uint32_t SLICE = __builtin_amdgcn_readfirstlane(slice_words);
-    float4 *xpose = reinterpret_cast<float4 *>(slices + WAVES * SLICE);  // WAVES x 8 KiB (POW: x 4 KiB)
+    float4 *xpose = reinterpret_cast<float4 *>(slices + WAVES * SLICE);  // WAVES x 8 KiB
 
     const uint32_t t = threadIdx.x;
     const uint32_t lane = t & (kWave - 1);
@@ -904,7 +907,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
 
     double sum = 0.0;
     TileTrack tr = {{0.f, 0.f, 0.f, 0.f, 0.f}, {0, 0, 0, 0, 0}};
-    float4 *mine = xpose + wave * (kWave * (POW ? 4 : 8));
+    float4 *mine = xpose + wave * (kWave * 8);
     const int32_t *__restrict__ tile_E = p.tile_E_spec;
     double2 *__restrict__ seg_D = reinterpret_cast<double2 *>(p.seg_D);
     float4 x[U];
@@ -914,30 +917,10 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         const uint64_t seg = seg0 + (uint64_t)it * seg_stride;
         const uint64_t now = __builtin_amdgcn_s_memrealtime();  // (for the spill check)
         const int E = __builtin_amdgcn_readfirstlane(tile_E[(p.seg_offset + seg) >> 1]);
-        SegMax m = {0u, 0u, 0u, INT32_MIN, INT32_MIN};
-        float pw[2 * U];
-        if constexpr (POW) {
-            // powers and trackers from the registers as loaded; the lane's two powers of word f = u * 64 + lane go to run
-            // f >> 3 (16 samples = 4 quads of powers), quad (f & 7) >> 1, half f & 1 — quads XOR-swizzled by the run so
-            // that the 8-byte writes and the 16-byte reads are both conflict-free
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                typedef float f32x2v __attribute__((ext_vector_type(2)));
-                const f32x2v a = {x[u].x, x[u].y}, b = {x[u].z, x[u].w};
-                const f32x2v aa = a * a, bb = b * b;
-                asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u]) : "v"(aa.x), "v"(aa.y));
-                asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u + 1]) : "v"(bb.x), "v"(bb.y));
-                segmax_fold(m, x[u], pw[2 * u], pw[2 * u + 1]);
-                const int f = u * kWave + (int)lane, run = f >> 3;
-                float2 *dst = reinterpret_cast<float2 *>(mine + xpose_pow_slot(run, (f & 7) >> 1)) + (f & 1);
-                *dst = make_float2(pw[2 * u], pw[2 * u + 1]);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < U; r++) {
-                const int f = r * kWave + (int)lane;  // float4 slot within the segment, file order
-                mine[xpose_slot(f >> 3, f & 7)] = x[r];
-            }
+        for (int r = 0; r < U; r++) {
+            const int f = r * kWave + (int)lane;  // float4 slot within the segment, file order
+            mine[xpose_slot(f >> 3, f & 7)] = x[r];
         }
         // the registers are free again: the next segment's loads fly while this one is folded out of LDS — in front of
         // any spill store of this segment, so that a spill never stands between the wave and its next data
@@ -947,73 +930,36 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         const bool valid = E != PAPR_EXACT_AMBIG;
         const double m0 = valid ? pow2_f64(E) : 0.0, ulp = valid ? pow2_f64(E - 52) : 0.0, m1 = m0 + ulp;
         double x0 = m0, x1 = m1;
+        SegMax m = {0u, 0u, 0u, INT32_MIN, INT32_MIN};
         // room for the segment's 16 samples of every lane (and the trash words)?  Checked IN FRONT of the fold, behind the
         // next segment's loads: a spill's stores then have the fold's duration to drain before this wave waits for memory
         // again (vmcnt is in order and counts stores too)
         ws.spill_in_step(now, fine ? SLICE - kWave : SLICE - (2 * U + 1) * kWave, (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
-        if constexpr (!POW) {
-            float4 y[U];
+        float4 y[U];
 #pragma unroll
-            for (int j = 0; j < U; j++)
-                y[j] = mine[xpose_slot((int)lane, j)];
+        for (int j = 0; j < U; j++)
+            y[j] = mine[xpose_slot((int)lane, j)];
+        float pw[2 * U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                // (power_of with the squares as one packed multiplication and the additions written out: see papr_sweep_kernel)
-                typedef float f32x2v __attribute__((ext_vector_type(2)));
-                const f32x2v a = {y[u].x, y[u].y}, b = {y[u].z, y[u].w};
-                const f32x2v aa = a * a, bb = b * b;
-                asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u]) : "v"(aa.x), "v"(aa.y));
-                asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u + 1]) : "v"(bb.x), "v"(bb.y));
-                segmax_fold(m, y[u], pw[2 * u], pw[2 * u + 1]);
-            }
-#pragma unroll
-            for (int u = 0; u < 2 * U; u++) {
-                const double v = (double)pw[u];
-                x0 += v;  // the reference's additions themselves (papr.c:104), from the two canonical entry states
-                x1 += v;
-            }
+        for (int u = 0; u < U; u++) {
+            // (power_of with the squares as one packed multiplication and the additions written out: see papr_sweep_kernel)
+            typedef float f32x2v __attribute__((ext_vector_type(2)));
+            const f32x2v a = {y[u].x, y[u].y}, b = {y[u].z, y[u].w};
+            const f32x2v aa = a * a, bb = b * b;
+            asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u]) : "v"(aa.x), "v"(aa.y));
+            asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u + 1]) : "v"(bb.x), "v"(bb.y));
+            segmax_fold(m, y[u], pw[2 * u], pw[2 * u + 1]);
         }
-        auto run_chains = [&] {
-            // the lane's run: 16 consecutive powers, the order the reference adds them in (papr.c:104)
-            float4 q[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                q[j] = mine[xpose_pow_slot((int)lane, j)];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float r4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const double v = (double)r4[c];
-                    x0 += v;  // the reference's additions themselves, from the two canonical entry states
-                    x1 += v;
-                }
-            }
-        };
+        for (int u = 0; u < 2 * U; u++) {
+            const double v = (double)pw[u];
+            x0 += v;  // the reference's additions themselves (papr.c:104), from the two canonical entry states
+            x1 += v;
+        }
         uint32_t k[2 * U];
-        if constexpr (POW && EARLY) {
-            float4 q[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                q[j] = mine[xpose_pow_slot((int)lane, j)];
-#pragma unroll
-            for (int u = 0; u < 2 * U; u++)
-                k[u] = bin_of(pw[u]);  // the LUT reads in flight behind the run's reads; the chains run under them
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float r4[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const double v = (double)r4[c];
-                    x0 += v;
-                    x1 += v;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 2 * U; u++)
-                k[u] = bin_of(pw[u]);  // the LUT reads in flight together
-        }
+        for (int u = 0; u < 2 * U; u++)
+            k[u] = bin_of(pw[u]);  // the LUT reads in flight together
         if constexpr (FINE) {
             // A fine table stashes ten times what the 1 dB one does, out of a slice that is half as large (the table takes
             // the rest): keeping the segment's worst case free — every sample of every lane in band, 4 KiB — would leave a
@@ -1036,8 +982,6 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
             for (int u = 0; u < 2 * U; u++)
                 count_and_stash(pw[u], k[u]);
         }
-        if constexpr (POW && !EARLY)
-            run_chains();
         segmax_commit(tr, m, it);
         // ---- the segment's pair ----
         const double d0 = x0 - m0, d1 = x1 - m1;  // exact: multiples of the ulp inside the binade (plain sums when no binade was given)
@@ -1060,7 +1004,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
     }
     ws.spill_if_above(0, ~0u);
 
-    sweep2_record<WAVES, U, !POW>(sum, tr, seg0, seg_stride, data, p.base_index, p.out);  // (POW: trackers saw the words as loaded)
+    sweep2_record<WAVES, U, true>(sum, tr, seg0, seg_stride, data, p.base_index, p.out);
     hist_flush<BLOCK>(hist, nbins, P.copies, p.ghist);  // (starts with a barrier: every wave has spilled)
     if (t == 0) {
         p.seg_slots[blockIdx.x] = seg_fill;
@@ -1233,11 +1177,10 @@ void papr_launch_sweep2(hipStream_t st, int variant, int blocks, size_t lds_byte
 
 int papr_sweep3_geometry(int variant, int *threads, size_t *lds_fixed, int *exact)
 {
-    if (variant != PAPR_SWEEP3_VARIANT && variant != PAPR_SWEEP3_SAMPLES_VARIANT && variant != 136)
+    if (variant != PAPR_SWEEP3_VARIANT)
         return -1;
     *threads = PAPR_SWEEP_THREADS;
-    *lds_fixed = (size_t)(PAPR_SWEEP_THREADS / kWave) *
-                     (PAPR_SWEEP3_SLICE_FLOATS * sizeof(float) + (variant != PAPR_SWEEP3_SAMPLES_VARIANT ? 4096u : 8192u)) + 16;
+    *lds_fixed = (size_t)(PAPR_SWEEP_THREADS / kWave) * (PAPR_SWEEP3_SLICE_FLOATS * sizeof(float) + 8192u) + 16;
     if (exact)
         *exact = 1;
     return 0;
@@ -1245,25 +1188,15 @@ int papr_sweep3_geometry(int variant, int *threads, size_t *lds_fixed, int *exac
 
 void papr_launch_sweep3(hipStream_t st, int variant, int blocks, size_t lds_bytes, const papr_sweep2_params &p)
 {
-    if (variant != PAPR_SWEEP3_VARIANT && variant != PAPR_SWEEP3_SAMPLES_VARIANT && variant != 136)
+    if (variant != PAPR_SWEEP3_VARIANT)
         return;
     papr_sweep2_params q = p;
     q.lds_bytes = (uint32_t)lds_bytes;
     // (which form: the table's size is known to whoever planned it — the host, or papr_guess_bands_kernel through p.fine_hint)
-    const int mode = variant == PAPR_SWEEP3_SAMPLES_VARIANT ? 0 : (variant == 136 ? 2 : 1);
-    const char *cap = getenv("PAPR_S3_SLICE_CAP");
-    q.slice_cap = cap ? (uint32_t)atoi(cap) : 0u;
-#define S3_LAUNCH(F, M) launch_maybe_timed((papr_sweep3_kernel<F, M>), dim3(blocks), dim3(PAPR_SWEEP_THREADS), lds_bytes, st, q)
-    if (q.fine_table) {
-        if (mode == 0) S3_LAUNCH(true, 0);
-        else if (mode == 1) S3_LAUNCH(true, 1);
-        else S3_LAUNCH(true, 2);
-    } else {
-        if (mode == 0) S3_LAUNCH(false, 0);
-        else if (mode == 1) S3_LAUNCH(false, 1);
-        else S3_LAUNCH(false, 2);
-    }
-#undef S3_LAUNCH
+    if (q.fine_table)
+        launch_maybe_timed(papr_sweep3_kernel<true>, dim3(blocks), dim3(PAPR_SWEEP_THREADS), lds_bytes, st, q);
+    else
+        launch_maybe_timed(papr_sweep3_kernel<false>, dim3(blocks), dim3(PAPR_SWEEP_THREADS), lds_bytes, st, q);
 }
 
 void papr_launch_ccdf_power(hipStream_t st, int num_cus, bool lut, size_t lds_bytes, const float *stash,
@@ -1287,12 +1220,8 @@ void papr_sweep_prepare_device(void)
 {
     const int want = papr_ccdf_max_dynamic_lds();
     (void)hipFuncSetAttribute((const void *)papr_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, want);
-    (void)hipFuncSetAttribute((const void *)papr_sweep3_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
-    (void)hipFuncSetAttribute((const void *)papr_sweep3_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
-    (void)hipFuncSetAttribute((const void *)papr_sweep3_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
-    (void)hipFuncSetAttribute((const void *)papr_sweep3_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
-    (void)hipFuncSetAttribute((const void *)papr_sweep3_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
-    (void)hipFuncSetAttribute((const void *)papr_sweep3_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    (void)hipFuncSetAttribute((const void *)papr_sweep3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
+    (void)hipFuncSetAttribute((const void *)papr_sweep3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
     (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
     (void)hipFuncSetAttribute((const void *)papr_ccdf_power_kernel<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, want);
 #ifdef PAPR_MEASURE

@@ -407,11 +407,6 @@ __device__ __forceinline__ double pow2_f64(int e) { return __longlong_as_double(
 // slot of float4 w of run r in the wave's transpose buffer (conflict-free both ways; papr_exact.hip)
 __device__ __forceinline__ int xpose_slot(int run, int w) { return run * 8 + (w ^ ((run >> 1) & 7)); }
 
-// slot of quad q (4 powers) of run r (16 consecutive samples) when only the POWERS are transposed (papr_sweep3_kernel<POW>):
-// the 8-byte writes of 32 lanes fill four whole runs, the 16-byte reads of 16 lanes (one run each) hit 16 different quads
-// of banks
-__device__ __forceinline__ int xpose_pow_slot(int run, int q) { return run * 4 + (q ^ ((run >> 2) & 3)); }
-
 // Workgroup record of the v2 kernel: as sweep_record, for wave-private segments.  LANE_MAJOR: lane l owns float4
 // l*U .. l*U+U-1 of its segment (exact mode); otherwise float4 u*64 + l.
 template <int WAVES, int U, bool LANE_MAJOR>

@@ -535,21 +535,34 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
                 // the in-stream exchange of the sum programs: one slot per rank, sized from the LARGEST shard the ranks
                 // could hold under this geometry — every rank computes the same number from ctx->xprog_slot_samples,
                 // which the agreement settles (the maximum of the ranks' shard sizes)
-                const size_t slot = ctx->xprog_slot;
-                if (slot == 0 || ctx->xprog_world != (int)world || !ctx->d_xprog) {
+                if ((int)ctx->xprog_sizes.size() != (int)world || ctx->xprog_slot == 0) {
+                    ctx->xprog_sizes.assign(world, ctx->xprog_slot);
+                    ctx->xprog_world = 0;
+                }
+                ctx->xprog_offs.assign(world + 1, 0);
+                for (uint32_t r = 0; r < world; r++)
+                    ctx->xprog_offs[r + 1] = ctx->xprog_offs[r] + ctx->xprog_sizes[r];
+                const size_t mine = ctx->xprog_sizes[my_rank], all = ctx->xprog_offs[world];
+                if (mine == 0)
+                    return PAPR_OK;  // (no slot size agreed yet: not this way)
+                if (ctx->xprog_cap_mine < mine) {
                     if (ctx->d_xprog) HIPCHK(ctx, hipFree(ctx->d_xprog));
+                    ctx->d_xprog = nullptr;
+                    ctx->xprog_cap_mine = 0;
+                    HIPCHK(ctx, hipMalloc((void **)&ctx->d_xprog, mine));
+                    ctx->xprog_cap_mine = mine;
+                }
+                if (ctx->xprog_cap_all < all) {
                     if (ctx->d_xprog_all) HIPCHK(ctx, hipFree(ctx->d_xprog_all));
                     if (ctx->h_xprog_all) HIPCHK(ctx, hipHostFree(ctx->h_xprog_all));
-                    ctx->d_xprog = ctx->d_xprog_all = ctx->h_xprog_all = ctx->h_xprog_all_dev = nullptr;
-                    ctx->xprog_world = 0;
-                    if (slot) {
-                        HIPCHK(ctx, hipMalloc((void **)&ctx->d_xprog, slot));
-                        HIPCHK(ctx, hipMalloc((void **)&ctx->d_xprog_all, slot * world));
-                        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_xprog_all, slot * world, hipHostMallocMapped));
-                        HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_xprog_all_dev, ctx->h_xprog_all, 0));
-                        ctx->xprog_world = (int)world;
-                    }
+                    ctx->d_xprog_all = ctx->h_xprog_all = ctx->h_xprog_all_dev = nullptr;
+                    ctx->xprog_cap_all = 0;
+                    HIPCHK(ctx, hipMalloc((void **)&ctx->d_xprog_all, all));
+                    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_xprog_all, all, hipHostMallocMapped));
+                    HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_xprog_all_dev, ctx->h_xprog_all, 0));
+                    ctx->xprog_cap_all = all;
                 }
+                ctx->xprog_world = (int)world;
             }
         }
         constexpr size_t kMaxSweepBlocks = 65536;
@@ -667,7 +680,10 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
                             band_override, kCopies, run.lut2 ? 1 : 0, soft_lds, ctx->d_table, table_cap_words, ctx->d_guess,
                             ctx->h_guess_dev, ctx->d_sweep_hist,
                             kBinsMax + 2u * (uint32_t)run.blocks + 1u,  // (also clears the sweep's bins and segment counters)
-                            d_est_all, peers ? world : 0u, my_rank);
+                            d_est_all, peers ? world : 0u, my_rank,
+                            // (exact-sum mode, no peers: the scan half of the binade speculation runs beside the guess)
+                            exact && !peers ? ctx->d_est_groups : nullptr, exact && !peers ? ngroups : 0, (double)ratio,
+                            exact && !peers ? ctx->d_est_groups + 4 * ctx->est_groups_cap : nullptr);
     XCHK(hipGetLastError());
     const uint32_t tail = (uint32_t)(ctx->n - ntiles * run.tile);
     papr_ccdf_params none{};
@@ -680,7 +696,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
             // (peers: ... what papr_guess_bands_kernel made of the shards' estimate records in front of this one)
             papr_launch_exact_spec(ctx->stream, ctx->d_est_groups, ngroups, (uint32_t)ratio, (double)ratio, 0.0,
                                    ctx->d_est_groups + 4 * ctx->est_groups_cap, ctx->n / PAPR_EXACT_TILE_SAMPLES, ctx->d_tile_E_spec,
-                                   peers ? &ctx->d_guess->est_before : nullptr);
+                                   peers ? &ctx->d_guess->est_before : nullptr, /*scan_done=*/!peers && ngroups != 0);
             XCHK(hipGetLastError());
         }
         papr_sweep2_params p{};
@@ -758,19 +774,24 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
             // mapped host memory, where the host replays them in rank (= file) order while the stream goes on
             // (papr_hip_analyze: overlap_work).  A program that outgrew its slot, or is not final, is marked: every rank
             // sees that and all of them exchange on the host afterwards.
-            rc = run_exact_swept(ctx, 0.0, 0, reinterpret_cast<const double *>(d_n_total) + 1, d_n_total, ctx->d_xprog, ctx->xprog_slot);
+            rc = run_exact_swept(ctx, 0.0, 0, reinterpret_cast<const double *>(d_n_total) + 1, d_n_total, ctx->d_xprog,
+                                 ctx->xprog_sizes[my_rank]);
             if (rc)
                 return leave(rc);
-            rc = xch_allgather_dev(x, ctx, ctx->d_xprog, ctx->d_xprog_all, ctx->xprog_slot);
+            rc = xch_allgatherv_dev(x, ctx, ctx->d_xprog, ctx->d_xprog_all, ctx->xprog_sizes.data(), ctx->xprog_offs.data());
             if (rc)
                 return leave(fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x)));
-            papr_launch_exact_programs_to_host(ctx->stream, ctx->d_xprog_all, ctx->xprog_slot, world, ctx->h_xprog_all_dev);
+            papr_xprog_layout lay{};
+            lay.world = world;
+            for (uint32_t r = 0; r <= world; r++)
+                lay.offs[r] = ctx->xprog_offs[r];
+            papr_launch_exact_programs_to_host(ctx->stream, ctx->d_xprog_all, lay, ctx->h_xprog_all_dev);
             XCHK(hipGetLastError());
             rc = mark_program_ready(ctx);
             if (rc)
                 return leave(rc);
             ctx->xprog_ready = true;
-            ctx->program_view = ctx->h_xprog_all + (size_t)my_rank * ctx->xprog_slot;
+            ctx->program_view = ctx->h_xprog_all + ctx->xprog_offs[my_rank];
             ctx->exact_program_launched = true;  // (exact_program_before: known after the wait)
         }
     }

@@ -125,13 +125,32 @@ class UringReader {
             delete r;
         }
         backlog_.clear();
-        for (int spin = 0; spin < 50000 && !live_.empty(); spin++) {
+        // entries that sit in the submission ring but were never handed to the kernel (exactly the state a failed
+        // io_uring_enter leaves behind) can never complete: they are the LAST `unsubmitted_` of live_ — taken back at once
+        while (unsubmitted_ && !live_.empty()) {
+            Req *r = live_.back();
+            live_.pop_back();
+            unsubmitted_--;
+            inflight_--;
+            sq_tail_->store(sq_tail_->load(std::memory_order_relaxed) - 1, std::memory_order_release);
+            if (r->batch->pending > 0)
+                r->batch->pending--;
+            delete r;
+        }
+        unsubmitted_ = 0;
+        for (int spin = 0; spin < 50000 && !live_.empty(); spin++) {  // only what the kernel really has is waited for
             if (!reap())
                 usleep(100);
         }
         for (Req *r : live_)
             r->batch = &orphans_;
         live_.clear();
+        // closing the ring cancels (or waits for) whatever is still in flight: nothing writes into the staging buffers
+        // the reader threads take over from here
+        if (fd_ >= 0) {
+            close(fd_);
+            fd_ = -1;
+        }
     }
 
     bool init(unsigned entries)

@@ -49,6 +49,29 @@ static void host_count(const host_walk *w, unsigned h1, unsigned h2)
     }
 }
 
+/* xport.c:2872-2889: the packet's counter against the PID's last one (ts_scan_result.cc_state: last counter + 1, 0 = none) */
+static void host_cc(const host_walk *w, unsigned pid, unsigned h3)
+{
+    ts_scan_result *res = w->res;
+    const unsigned cc = h3 & 0xfu, last = res->cc_state[pid];
+    if ((h3 & 0x10u) == 0)
+        return; /* no payload: neither checked nor remembered */
+    if (last != 0 && pid != 0x1fffu && (last & 0xfu) != cc) { /* (last = counter + 1, so last & 15 is the successor) */
+        if (res->ndiscontinuities < TS_MAX_DISCONTINUITIES) {
+            ts_discontinuity *d = &res->discontinuities[res->ndiscontinuities];
+            d->at_packet = res->packets;
+            d->after_sync_errors = res->nsync_errors;
+            d->pid = pid;
+            d->received = (uint8_t)cc;
+            d->expected = (uint8_t)(last & 0xfu);
+            d->pad[0] = d->pad[1] = 0;
+        }
+        res->ndiscontinuities++;
+    }
+    if (pid != 0)
+        res->cc_state[pid] = (uint8_t)(cc + 1u);
+}
+
 static void host_sync_error(const host_walk *w, uint64_t skipped)
 {
     ts_scan_result *res = w->res;
@@ -65,6 +88,7 @@ static void host_sync_error(const host_walk *w, uint64_t skipped)
 #define TS_CORE_BYTE(ctx, off) ((unsigned)(ctx)->data[(off) - (ctx)->base])
 #define TS_CORE_FIND_SYNC(ctx, from, end) host_find_sync(ctx, from, end)
 #define TS_CORE_COUNT(ctx, h1, h2) host_count(ctx, h1, h2)
+#define TS_CORE_CC(ctx, pid, h3) host_cc(ctx, pid, h3)
 #define TS_CORE_SYNC_ERROR(ctx, skipped) host_sync_error(ctx, skipped)
 #include "ts_walk_core.h"
 
@@ -87,13 +111,25 @@ uint64_t ts_walk(ts_walk_state *st, const unsigned char *data, uint64_t base, ui
     }
 }
 
-static size_t format_lines(const ts_scan_result *res, const ts_sync_error *errs, uint64_t nerrs, char *buf, size_t cap)
+static size_t format_lines(const ts_scan_result *res, const ts_sync_error *errs, uint64_t nerrs, const ts_discontinuity *discs,
+                           uint64_t ndiscs, char *buf, size_t cap)
 {
     size_t used = 0;
     if (!buf || cap == 0)
         return 0;
     buf[0] = 0;
-    for (uint64_t k = 0; k < nerrs && used + 1 < cap; k++) {
+    uint64_t d = 0;
+    for (uint64_t k = 0; used + 1 < cap; k++) { /* the two kinds of line in the order the reference printed them */
+        for (; d < ndiscs && discs[d].after_sync_errors <= k && used + 1 < cap; d++) {
+            const int w = snprintf(buf + used, cap - used, "Discontinuity!, pid = %d <0x%04x>, received = %2d, expected = %2d, at %lld\n",
+                                   (int)discs[d].pid, (unsigned)discs[d].pid, (int)discs[d].received, (int)discs[d].expected,
+                                   (long long)discs[d].at_packet);
+            if (w < 0 || (size_t)w >= cap - used)
+                return used;
+            used += (size_t)w;
+        }
+        if (k >= nerrs)
+            break;
         const int w = snprintf(buf + used, cap - used, "Transport Sync Error, skipped %d bytes, at %lld\n",
                                (int)errs[k].skipped, (long long)errs[k].at_packet);
         if (w < 0 || (size_t)w >= cap - used)
@@ -114,11 +150,16 @@ static size_t format_lines(const ts_scan_result *res, const ts_sync_error *errs,
 
 size_t ts_format_report(const ts_scan_result *res, char *buf, size_t cap)
 {
-    const uint64_t n = res->nsync_errors < TS_MAX_SYNC_ERRORS ? res->nsync_errors : TS_MAX_SYNC_ERRORS;
-    return format_lines(res, res->sync_errors, n, buf, cap);
+    if (res->nsync_errors > TS_MAX_SYNC_ERRORS || res->ndiscontinuities > TS_MAX_DISCONTINUITIES) { /* not all inline: no truncated report */
+        if (buf && cap)
+            buf[0] = 0;
+        return 0;
+    }
+    return format_lines(res, res->sync_errors, res->nsync_errors, res->discontinuities, res->ndiscontinuities, buf, cap);
 }
 
-size_t ts_format_report_all(const ts_scan_result *res, const ts_sync_error *errors, uint64_t nerrors, char *buf, size_t cap)
+size_t ts_format_report_all(const ts_scan_result *res, const ts_sync_error *errors, uint64_t nerrors,
+                            const ts_discontinuity *discs, uint64_t ndiscs, char *buf, size_t cap)
 {
-    return format_lines(res, errors, nerrors, buf, cap);
+    return format_lines(res, errors, nerrors, discs, ndiscs, buf, cap);
 }

@@ -26,16 +26,42 @@ struct ts_span_rec {
     uint32_t nlist;          // PIDs in its list
     uint32_t attempt;        // id of the launch that wrote this record (its events carry the same)
     uint32_t explicit_entry; // 1: started from a walker state handed in by the host, clean or not
+    uint32_t ncc, pad;       // entries in its continuity list
 };
 #define TS_NO_ENTRY 0xFFFFFFFFFFFFFFFFull
 #define TS_EVENT_BRIDGE 0x80000000u /* ts_event::attempt: written by a bridge of ts_merge_kernel */
 #define TS_MAX_SPANS 512 /* spans per scan (one per CU; ts_merge_kernel keeps their records in LDS) */
 
-// a `Transport Sync Error` line, before the span's packets have their stream-wide numbers
+// a line of the report, before the span's packets have their stream-wide numbers
+//   kind 0  `Transport Sync Error`: at_rel = packets the span had counted at that moment
+//   kind 1  `Discontinuity!` found inside a span: at_rel = the packet's own number within the span (1-based); info = pid << 8 |
+//           received << 4 | expected
+//   kind 2  a payload-carrying packet a BRIDGE of the merge kernel walked (info = pid << 8 | counter << 4): its continuity is
+//           the host's to check, which links the spans' first and last counters in stream order anyway (ts_runtime.cpp)
 struct ts_event {
     uint64_t skipped;
-    uint64_t at_rel;   // packets the span had counted at that moment
+    uint64_t at_rel;
     uint32_t span, attempt;
+    uint32_t kind, info;
+};
+#define TS_EV_SYNC 0u
+#define TS_EV_DISC 1u
+#define TS_EV_BRIDGE_CC 2u
+
+// continuity counters (xport.c:2872-2889) per span: one entry per PID that had a payload-carrying packet in the span
+struct ts_cc_entry {
+    uint16_t pid;
+    uint8_t first_cc, last_cc;  // counter of the PID's first / last such packet in the span
+    uint32_t first_rel;         // the first one's number within the span (0-based)
+};
+#define TS_CC_OUT 32u /* entries per span that travel to the host with the scan's one wait (more: a second copy) */
+
+// what the host needs of every span once the chain is merged, in one block of memory (one D2H copy)
+struct ts_span_out {
+    unsigned long long base, bridge_base;  // stream-wide number of the span's (of its bridge's) first packet - 1
+    uint32_t attempt;                      // the attempt whose record was taken (0: the span was not taken)
+    uint32_t ncc;                          // entries in its continuity list
+    ts_cc_entry cc[TS_CC_OUT];
 };
 
 struct ts_scan_params {
@@ -52,6 +78,7 @@ struct ts_scan_params {
     ts_walk_state entry;
     ts_wg_entry *lists;         // per span: up to TS_PIDS entries
     ts_span_rec *recs;          // per span
+    ts_cc_entry *cc_lists;      // per span: up to TS_PIDS entries
     ts_event *events;           // one list for the launch(es) of a scan, slots handed out by an atomic counter
     uint32_t event_cap;
     unsigned int *event_count;  // events wanted so far (may run past event_cap: the host then repeats the scan with more room)
@@ -65,7 +92,7 @@ struct ts_merge_out {
     ts_walk_state cur;          // the walker state the chain arrived with in front of span `valid_upto`
     uint64_t block_packets;
     uint64_t walks;
-    uint32_t events;            // sync-error events the scan's launches have wanted so far (> event_cap: the list overflowed)
+    uint32_t events;            // events the scan's launches have wanted so far (> event_cap: the list overflowed)
     uint32_t pad2;
 };
 
@@ -77,7 +104,7 @@ void ts_launch_scan(hipStream_t st, int blocks, const ts_scan_params &p);
 // walked in front of it (== span_base where there was none) — events with TS_EVENT_BRIDGE in `attempt` count from there
 void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t from_span, uint64_t packet_base, const ts_walk_state &cur,
                      uint32_t *g_count, unsigned long long *g_first, unsigned long long *g_last, unsigned long long *span_base,
-                     unsigned long long *span_bridge_base, uint32_t *span_attempt, ts_merge_out *out);
+                     unsigned long long *span_bridge_base, uint32_t *span_attempt, ts_merge_out *out, ts_span_out *span_out);
 void ts_launch_reset(hipStream_t st, uint32_t *g_count, unsigned long long *g_first, unsigned long long *g_last,
                      unsigned int *event_count, uint32_t *span_attempt, uint32_t nspans);
 void ts_launch_generate(hipStream_t st, void *out, uint64_t nunits, uint32_t unit, uint64_t seed, int hdmv);

@@ -61,6 +61,12 @@ struct DevWalk {
     uint64_t abs0;                         // stream-wide number of the walk's first packet
     uint64_t stop_at;                      // the sync byte in front of which the walk is to stop (TS_NO_ENTRY: nowhere)
     uint32_t quiet;                        // 1: count packets only — no table, no event
+    // continuity counters (xport.c:2872-2889): a span's walker keeps them in the workgroup's table; a bridge's packets
+    // are reported one by one for the host to check (s_cc == nullptr)
+    unsigned char *s_cc;                   // LDS, per PID: last counter + 1, 0 = no payload packet of the PID in this span yet
+    uint32_t *s_ncc;                       // LDS: entries in the span's continuity list
+    ts_cc_entry *cc_list;
+    uint32_t *s_ev;                        // LDS, two words: next reserved slot of the event list, slots left (null: none kept)
 };
 
 __device__ __forceinline__ bool walk_is_clean(const ts_walk_state &st)
@@ -161,19 +167,89 @@ __device__ __forceinline__ void dev_count(DevWalk *w, unsigned h1, unsigned h2)
     }
 }
 
+__device__ __forceinline__ void put_event(ts_event *events, unsigned int *event_count, uint32_t event_cap, uint32_t span,
+                                          uint32_t attempt, uint32_t kind, uint64_t skipped, uint64_t at_rel, uint32_t info)
+{
+    const unsigned int slot = atomicAdd(event_count, 1u);  // (counts what no longer fits: the host sees the overflow)
+    if (slot < event_cap) {
+        ts_event e;
+        e.skipped = skipped;
+        e.at_rel = at_rel;
+        e.span = span;
+        e.attempt = attempt;
+        e.kind = kind;
+        e.info = info;
+        events[slot] = e;
+    }
+}
+
+// The span walker's lines come one at a time, each behind a returning atomic on the list's counter (~2 us of the one wave
+// that walks): it reserves kWalkBatch slots at once instead, marks them empty (a span number no span has: the host skips
+// them) and fills them as lines come.  Slots still grow with the stream within a span — the blocks between two walks
+// drop what is left of a batch before they reserve their own (ts_scan_kernel).
+constexpr uint32_t kWalkBatch = 8;
+__device__ __forceinline__ void walk_event(const DevWalk *w, uint32_t kind, uint64_t skipped, uint64_t at_rel, uint32_t info)
+{
+    if (w->lane != 0 || w->quiet)
+        return;
+    if (!w->s_ev) {
+        put_event(w->events, w->event_count, w->event_cap, w->span, w->attempt, kind, skipped, at_rel, info);
+        return;
+    }
+    if (w->s_ev[1] == 0) {
+        const unsigned int base = atomicAdd(w->event_count, kWalkBatch);
+        for (uint32_t k = 0; k < kWalkBatch; k++)
+            if (base + k < w->event_cap) {
+                ts_event e;
+                e.skipped = e.at_rel = 0;
+                e.span = 0xFFFFFFFFu;
+                e.attempt = e.kind = e.info = 0;
+                w->events[base + k] = e;
+            }
+        w->s_ev[0] = base;
+        w->s_ev[1] = kWalkBatch;
+    }
+    const unsigned int slot = w->s_ev[0]++;
+    w->s_ev[1]--;
+    if (slot < w->event_cap) {
+        ts_event e;
+        e.skipped = skipped;
+        e.at_rel = at_rel;
+        e.span = w->span;
+        e.attempt = w->attempt;
+        e.kind = kind;
+        e.info = info;
+        w->events[slot] = e;
+    }
+}
+
 __device__ __forceinline__ void dev_event(const DevWalk *w, uint64_t skipped, uint64_t at_rel)
 {
-    if (w->lane == 0 && !w->quiet) {
-        const unsigned int slot = atomicAdd(w->event_count, 1u);  // (counts what no longer fits: the host sees the overflow)
-        if (slot < w->event_cap) {
-            ts_event e;
-            e.skipped = skipped;
-            e.at_rel = at_rel;
-            e.span = w->span;
-            e.attempt = w->attempt;
-            w->events[slot] = e;
-        }
+    walk_event(w, TS_EV_SYNC, skipped, at_rel, 0u);
+}
+
+// header byte 3 of the packet the walker has just counted (w->packets is its number within the walk, 1-based)
+__device__ __forceinline__ void dev_cc(DevWalk *w, unsigned pid, unsigned h3)
+{
+    if (w->lane != 0 || w->quiet || (h3 & 0x10u) == 0 || pid == 0)
+        return;  // no payload: neither checked nor remembered; PID 0 is never remembered, hence never reported
+    const uint32_t cc = h3 & 0xfu;
+    if (!w->s_cc) {  // a bridge: the host checks it between the spans it links
+        walk_event(w, TS_EV_BRIDGE_CC, 0, w->packets, (pid << 8) | (cc << 4));
+        return;
     }
+    const uint32_t last = w->s_cc[pid];
+    if (last == 0) {
+        ts_cc_entry e;
+        e.pid = (uint16_t)pid;
+        e.first_cc = (uint8_t)cc;
+        e.last_cc = 0;
+        e.first_rel = (uint32_t)(w->packets - 1);
+        w->cc_list[(*w->s_ncc)++] = e;
+    } else if (pid != 0x1fffu && (last & 0xfu) != cc) {
+        walk_event(w, TS_EV_DISC, 0, w->packets, (pid << 8) | (cc << 4) | (last & 0xfu));
+    }
+    w->s_cc[pid] = (unsigned char)(cc + 1u);
 }
 
 #define TS_CORE_QUAL __device__ __forceinline__
@@ -182,6 +258,7 @@ __device__ __forceinline__ void dev_event(const DevWalk *w, uint64_t skipped, ui
 #define TS_CORE_BYTE(ctx, off) dev_byte(ctx, off)
 #define TS_CORE_FIND_SYNC(ctx, from, end) dev_find_sync(ctx, from, end)
 #define TS_CORE_COUNT(ctx, h1, h2) dev_count(ctx, h1, h2)
+#define TS_CORE_CC(ctx, pid, h3) dev_cc(ctx, pid, h3)
 #define TS_CORE_SYNC_ERROR(ctx, skipped) dev_event(ctx, skipped, (ctx)->packets)
 #define TS_CORE_STOP_AT(ctx, s) ((ctx)->stop_at == (s))
 #include "ts_walk_core.h"
@@ -198,6 +275,7 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
         uint32_t first_span, nspans_total, stride, sync_offset, hdmv, attempt, explicit_entry, quirk_events, event_cap;
         ts_wg_entry *lists;
         ts_span_rec *recs;
+        ts_cc_entry *cc_lists;
         ts_event *events;
         unsigned int *event_count;
     } p;
@@ -215,13 +293,15 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
     p.event_cap = prm.event_cap;
     p.lists = prm.lists;
     p.recs = prm.recs;
+    p.cc_lists = prm.cc_lists;
     p.events = prm.events;
     p.event_count = prm.event_count;
     extern __shared__ __attribute__((aligned(16))) uint32_t ts_smem[];  // 3 x TS_PIDS words = 96 KiB (one workgroup per CU)
     uint32_t *s_count = ts_smem, *s_first = ts_smem + TS_PIDS, *s_last = ts_smem + 2 * TS_PIDS;
     __shared__ ts_walk_state s_st;
     __shared__ unsigned long long s_packets, s_block_packets;
-    __shared__ uint32_t s_stop, s_walks, s_entries, s_cand;
+    __shared__ uint32_t s_stop, s_walks, s_entries, s_cand, s_ticket, s_ncc, s_ev[2];
+    __shared__ unsigned char s_cc[TS_PIDS];  // per PID: last continuity counter + 1 (0: no payload packet in this span yet)
     __shared__ __attribute__((aligned(16))) unsigned char s_window[kWalkWindow];  // the walker's view of the stream (wave 0)
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t span = p.first_span + blockIdx.x;
@@ -231,8 +311,13 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
         s_count[k] = 0;
         s_first[k] = kNone;
         s_last[k] = 0;
+        s_cc[k] = 0;
     }
+    ts_cc_entry *cc_list = p.cc_lists + (size_t)span * TS_PIDS;
     if (t == 0) {
+        s_ticket = 0;
+        s_ncc = 0;
+        s_ev[0] = s_ev[1] = 0;
         s_stop = kNone;
         s_walks = 0;
         s_entries = 0;
@@ -287,6 +372,7 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
                 r.walks = r.nlist = 0;
                 r.attempt = p.attempt;
                 r.explicit_entry = 0;
+                r.ncc = r.pad = 0;
                 p.recs[span] = r;
             }
             return;
@@ -303,6 +389,9 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
     uint64_t packets = 0, block_packets = 0;
     uint32_t units_seen = 0;  // units the blocks of this span have looked at so far: block-independent indices for s_stop
     uint32_t walks = 0;
+    uint32_t ticket_base = 0;  // the continuity check's turn counter (below): 16 turns per block
+    uint64_t pre_pos = TS_NO_ENTRY;  // the position whose block's header words are in pre_w0 / pre_w1 already
+    uint32_t pre_w0 = 0, pre_w1 = 0;
     bool walk_next = false;
     for (;;) {
         const bool clean = walk_is_clean(st);
@@ -317,10 +406,16 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
             const uint64_t sy = st.pos + (uint64_t)t * p.stride + p.sync_offset;  // file offset of this lane's sync byte
             const bool mine = t < nblk, whole = mine && sy + 188 <= p.nbytes;
             // the five bytes that matter — sync, two PID bytes, adaptation_field_control, adaptation_field_length — out of
-            // two aligned dwords
-            const uint64_t a = whole ? (sy & ~3ull) : 0ull;
-            const uint32_t w0 = *reinterpret_cast<const uint32_t *>(p.data + a);
-            const uint32_t w1 = *reinterpret_cast<const uint32_t *>(p.data + a + 4);
+            // two aligned dwords (already on their way if the block in front of this one was a whole one: below)
+            uint32_t w0, w1;
+            if (pre_pos == st.pos) {
+                w0 = pre_w0;
+                w1 = pre_w1;
+            } else {
+                const uint64_t a = whole ? (sy & ~3ull) : 0ull;
+                w0 = *reinterpret_cast<const uint32_t *>(p.data + a);
+                w1 = *reinterpret_cast<const uint32_t *>(p.data + a + 4);
+            }
             const uint32_t sh = (uint32_t)(sy & 3u);
             const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh);  // bytes sy .. sy+3
             const uint32_t b4 = (w1 >> (8 * sh)) & 0xffu;                // byte sy+4 (sh <= 3: inside w1)
@@ -352,6 +447,20 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
             __syncthreads();
             const uint32_t stop = s_stop - units_seen;  // (kNone - units_seen >= nblk: a span looks at < 2^32 - 1024 units)
             const uint32_t take = stop < nblk ? stop : nblk;  // units in front of the first irregular one
+            // A whole block taken: the next block's header words are asked for NOW — they fly while this block's packets are
+            // committed and its continuity counters go through the workgroup's table in turn (below), which is then not
+            // on the scan's critical path
+            if (take == (uint32_t)kScanBlock) {
+                const uint64_t npos = st.pos + (uint64_t)kScanBlock * p.stride;
+                const uint64_t nroom = npos < B1 ? B1 - npos : 0;
+                const uint32_t nn = nroom > (uint64_t)(kScanBlock - 1) * p.stride ? (uint32_t)kScanBlock
+                                                                                 : (uint32_t)((nroom + p.stride - 1) / p.stride);
+                const uint64_t nsy = npos + (uint64_t)t * p.stride + p.sync_offset;
+                const uint64_t na = (t < nn && nsy + 188 <= p.nbytes) ? (nsy & ~3ull) : 0ull;
+                pre_w0 = *reinterpret_cast<const uint32_t *>(p.data + na);
+                pre_w1 = *reinterpret_cast<const uint32_t *>(p.data + na + 4);
+                pre_pos = npos;
+            }
             if (t < take) {
                 const uint32_t rel = (uint32_t)packets + t;  // packet number within the span (a span counts < 2^32)
                 if (tei == 0) {
@@ -359,17 +468,97 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
                     atomicMin(&s_first[pid], rel);
                     atomicMax(&s_last[pid], rel);
                 }
-                if (quirk) {  // (about one packet in 4096 of a stream whose packets sit at odd offsets): the line is
-                    DevWalk w;  // printed when the stream locks again, i.e. with this packet counted
-                    w.quiet = 0;
-                    w.events = p.events;
-                    w.event_count = p.event_count;
-                    w.event_cap = p.event_cap;
-                    w.span = span;
-                    w.attempt = p.attempt;
-                    w.lane = 0;
-                    dev_event(&w, 1, (uint64_t)rel + 1);
+            }
+            // ---- continuity counters (xport.c:2872-2889) of the block's committed packets: header byte 3 is loaded already ----
+            // A payload-carrying packet (adaptation_field_control & 1) of a PID other than 0 is compared with the PID's previous
+            // such packet.  Inside a wave the previous one is found with ballots (one round per PID the wave holds: a handful);
+            // across waves and blocks it is the workgroup's table s_cc, which the waves go through IN TURN (a ticket: wave w of
+            // this block after wave w - 1) — each reads it for the PIDs whose first packet it holds and writes it for those
+            // whose last: a few LDS operations per wave and block.  A PID's first such packet in the SPAN has nothing to be
+            // compared with here: it goes on the span's list, and the host links the spans (ts_runtime.cpp).
+            {
+                const uint32_t cc4 = b3 & 0xfu;
+                const bool ccv = t < take && (b3 & 0x10u) != 0 && pid != 0u;
+                uint32_t prev = 0;  // the previous packet's counter + 1; 0: not known (yet)
+                bool first_in_wave = ccv, last_in_wave = false;
+                unsigned long long todo = __ballot(ccv);
+                while (todo) {  // (wave-uniform)
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const uint32_t lp = (uint32_t)__builtin_amdgcn_readlane((int)pid, leader);
+                    const bool in = ccv && pid == lp;
+                    const unsigned long long m = __ballot(in);
+                    const unsigned long long below = m & ((1ull << lane) - 1ull);
+                    const int src = below ? 63 - __clzll((long long)below) : (int)lane;
+                    const uint32_t pc = (uint32_t)__shfl((int)cc4, src);
+                    if (in) {
+                        if (below) {
+                            prev = pc + 1u;
+                            first_in_wave = false;
+                        }
+                        last_in_wave = ((m >> lane) >> 1) == 0;
+                    }
+                    todo &= ~m;
                 }
+                const uint32_t turn = ticket_base + wave;
+                if (lane == 0)  // (no s_sleep: sixteen waves polling one LDS word cost nothing, a late wake-up costs the chain)
+                    while (__hip_atomic_load(&s_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != turn) {
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (ccv && first_in_wave) {
+                    const uint32_t last = s_cc[pid];
+                    if (last == 0) {
+                        ts_cc_entry e;
+                        e.pid = (uint16_t)pid;
+                        e.first_cc = (uint8_t)cc4;
+                        e.last_cc = 0;
+                        e.first_rel = (uint32_t)packets + t;
+                        cc_list[atomicAdd(&s_ncc, 1u)] = e;
+                    } else {
+                        prev = last;
+                    }
+                }
+                if (ccv && last_in_wave)
+                    s_cc[pid] = (unsigned char)(cc4 + 1u);
+                // The block's lines — a discontinuity, and behind it the `skipped 1 bytes` of a read-boundary quirk (about one
+                // packet in 4096 of a stream whose packets sit at odd offsets; printed when the stream locks again, i.e. with
+                // this packet counted) — get their slots of the event list HERE, inside the turn: the waves reserve in order
+                // and the lanes of a wave take theirs in lane order, so a span's lines sit in the list in the order the
+                // reference prints them and the host has nothing to sort.
+                const bool ev_disc = ccv && prev != 0 && pid != 0x1fffu && (prev & 0xfu) != cc4;
+                const bool ev_quirk = t < take && quirk;
+                const unsigned long long md = __ballot(ev_disc), mq = __ballot(ev_quirk);
+                if (md | mq) {  // (wave-uniform; rare)
+                    unsigned int base = 0;
+                    if (lane == 0) {
+                        s_ev[1] = 0;  // (what the walker had left of its batch lies in FRONT of these slots: dropped)
+                        base = atomicAdd(p.event_count, (unsigned int)(__popcll(md) + __popcll(mq)));
+                    }
+                    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                    const unsigned long long lt = (1ull << lane) - 1ull;
+                    unsigned int slot = base + (unsigned int)(__popcll(md & lt) + __popcll(mq & lt));
+                    const uint64_t number = (uint64_t)((uint32_t)packets + t) + 1;
+                    auto put = [&](uint32_t kind, uint64_t skipped, uint32_t info) {
+                        if (slot < p.event_cap) {
+                            ts_event e;
+                            e.skipped = skipped;
+                            e.at_rel = number;
+                            e.span = span;
+                            e.attempt = p.attempt;
+                            e.kind = kind;
+                            e.info = info;
+                            p.events[slot] = e;
+                        }
+                        slot++;
+                    };
+                    if (ev_disc)
+                        put(TS_EV_DISC, 0, (pid << 8) | (cc4 << 4) | (prev & 0xfu));
+                    if (ev_quirk)
+                        put(TS_EV_SYNC, 1, 0u);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0)
+                    __hip_atomic_store(&s_ticket, turn + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ticket_base += kScanBlock / 64;
             }
             packets += take;
             block_packets += take;
@@ -405,6 +594,10 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
             w.abs0 = 0;
             w.stop_at = TS_NO_ENTRY;
             w.quiet = 0;
+            w.s_cc = s_cc;
+            w.s_ncc = &s_ncc;
+            w.cc_list = cc_list;
+            w.s_ev = s_ev;
             ts_walk_state s2 = st;
             for (;;) {
                 if (!dev_walk_step(&s2, &w, p.nbytes, 1))
@@ -445,9 +638,13 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
             list[at] = e;
         }
     }
+    for (uint32_t k = t; k < s_ncc; k += kScanBlock)  // the list's PIDs: their last counter in this span
+        cc_list[k].last_cc = (uint8_t)(s_cc[cc_list[k].pid] - 1u);
     __syncthreads();
     if (t == 0) {
         ts_span_rec r;
+        r.ncc = s_ncc;
+        r.pad = 0;
         r.entry = entry_pos;
         r.exit_pos = s_st.pos;
         r.exit_skipped = s_st.skipped;
@@ -476,7 +673,7 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
                                                                unsigned long long *__restrict__ span_base,
                                                                unsigned long long *__restrict__ span_bridge_base,
                                                                uint32_t *__restrict__ span_attempt,
-                                                               ts_merge_out *__restrict__ out)
+                                                               ts_merge_out *__restrict__ out, ts_span_out *__restrict__ span_out)
 {
     __shared__ uint32_t s_taken;
     __shared__ unsigned long long s_base, s_bridge_base;
@@ -587,6 +784,10 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
                 w.g_first = g_first;
                 w.g_last = g_last;
                 w.abs0 = base;
+                w.s_cc = nullptr;  // (a bridge's packets are reported one by one: the host checks their continuity)
+                w.s_ncc = nullptr;
+                w.cc_list = nullptr;
+                w.s_ev = nullptr;
                 w.stop_at = r.entry + p.sync_offset;  // the span's first sync byte: where its own findings begin
                 ts_walk_state s2 = cur;
                 for (int run = 0; run < 2; run++) {  // dry, then — if it arrives and the span is this workgroup's — for real
@@ -657,6 +858,21 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
         span_attempt[me] = taken;
         span_base[me] = base;
         span_bridge_base[me] = s_bridge_base;
+    }
+    // what the host needs of this span — where its packets are numbered from, and the head of its continuity list — in
+    // the one block the scan's single wait brings over
+    {
+        const uint32_t ncc = taken ? s_recs[me].ncc : 0u;
+        ts_span_out *so = span_out + me;
+        if (t == 0) {
+            so->base = base;
+            so->bridge_base = s_bridge_base;
+            so->attempt = taken;
+            so->ncc = ncc;
+        }
+        const ts_cc_entry *cl = p.cc_lists + (size_t)me * TS_PIDS;
+        for (uint32_t k = t; k < ncc && k < TS_CC_OUT; k += kMergeBlock)
+            so->cc[k] = cl[k];
     }
     if (!taken)
         return;  // (workgroup-uniform)
@@ -747,10 +963,10 @@ void ts_launch_scan(hipStream_t st, int blocks, const ts_scan_params &p)
 
 void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t from_span, uint64_t packet_base, const ts_walk_state &cur,
                      uint32_t *g_count, unsigned long long *g_first, unsigned long long *g_last, unsigned long long *span_base,
-                     unsigned long long *span_bridge_base, uint32_t *span_attempt, ts_merge_out *out)
+                     unsigned long long *span_bridge_base, uint32_t *span_attempt, ts_merge_out *out, ts_span_out *span_out)
 {
     hipLaunchKernelGGL(ts_merge_kernel, dim3(p.nspans_total - from_span), dim3(kMergeBlock), 0, st, p, from_span, packet_base, cur,
-                       g_count, g_first, g_last, span_base, span_bridge_base, span_attempt, out);
+                       g_count, g_first, g_last, span_base, span_bridge_base, span_attempt, out, span_out);
 }
 
 void ts_launch_generate(hipStream_t st, void *out, uint64_t nunits, uint32_t unit, uint64_t seed, int hdmv)

@@ -39,12 +39,18 @@ struct ts_hip_ctx {
     unsigned long long *d_span_base = nullptr;              // per span: stream-wide number of its first packet
     unsigned long long *d_span_bridge_base = nullptr;       // ... and of the first packet of the bridge in front of it
     uint32_t *d_span_attempt = nullptr;                     // per span: the attempt whose record the chain took (0: none)
-    ts_event *d_events = nullptr;                           // `Transport Sync Error` events of the scan's launches
+    ts_cc_entry *d_cc_lists = nullptr;                      // per span: its PIDs' first / last continuity counter
+    ts_span_out *d_span_out = nullptr, *h_span_out = nullptr;  // per span: what the host needs of it (one D2H copy; pinned)
+    ts_event *d_events = nullptr;                           // events (report lines) of the scan's launches
     uint32_t event_cap = 0;
     unsigned int *d_event_count = nullptr;
     ts_merge_out *h_out = nullptr, *h_out_dev = nullptr;    // mapped: what the merge kernel reports
     void *h_tables = nullptr;                               // pinned: count / first / last read back at the end
     std::vector<ts_sync_error> errors;                      // every sync error of the last scan, in stream order
+    std::vector<ts_discontinuity> discs;                    // every discontinuity of the last scan, in stream order
+    ts_event *h_events = nullptr;                           // pinned mirror of the event list (grows with it)
+    size_t h_events_cap = 0;
+    std::vector<unsigned char> line_scratch;                // the host's working copy of the lines, reused from scan to scan
     int spans = 0;
     hipEvent_t ev_a = nullptr, ev_m = nullptr, ev_b = nullptr;
 };
@@ -143,6 +149,9 @@ int ts_hip_open(ts_hip_ctx **out, int device)
     OPENCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     OPENCHK(hipMalloc((void **)&ctx->d_lists, (size_t)TS_MAX_SPANS * TS_PIDS * sizeof(ts_wg_entry)));
     OPENCHK(hipMalloc((void **)&ctx->d_recs, TS_MAX_SPANS * sizeof(ts_span_rec)));
+    OPENCHK(hipMalloc((void **)&ctx->d_cc_lists, (size_t)TS_MAX_SPANS * TS_PIDS * sizeof(ts_cc_entry)));
+    OPENCHK(hipMalloc((void **)&ctx->d_span_out, TS_MAX_SPANS * sizeof(ts_span_out)));
+    OPENCHK(hipHostMalloc((void **)&ctx->h_span_out, TS_MAX_SPANS * sizeof(ts_span_out), hipHostMallocDefault));
     OPENCHK(hipMalloc((void **)&ctx->d_span_base, TS_MAX_SPANS * sizeof(unsigned long long)));
     OPENCHK(hipMalloc((void **)&ctx->d_span_bridge_base, TS_MAX_SPANS * sizeof(unsigned long long)));
     OPENCHK(hipMalloc((void **)&ctx->d_span_attempt, TS_MAX_SPANS * sizeof(uint32_t)));
@@ -175,6 +184,10 @@ void ts_hip_close(ts_hip_ctx *ctx)
     release(ctx);
     if (ctx->d_lists) (void)hipFree(ctx->d_lists);
     if (ctx->d_recs) (void)hipFree(ctx->d_recs);
+    if (ctx->d_cc_lists) (void)hipFree(ctx->d_cc_lists);
+    if (ctx->d_span_out) (void)hipFree(ctx->d_span_out);
+    if (ctx->h_span_out) (void)hipHostFree(ctx->h_span_out);
+    if (ctx->h_events) (void)hipHostFree(ctx->h_events);
     if (ctx->d_span_base) (void)hipFree(ctx->d_span_base);
     if (ctx->d_span_bridge_base) (void)hipFree(ctx->d_span_bridge_base);
     if (ctx->d_span_attempt) (void)hipFree(ctx->d_span_attempt);
@@ -307,7 +320,9 @@ int ts_hip_generate_damaged(ts_hip_ctx *ctx, uint64_t seed, uint64_t npackets, u
         return ts_fail(ctx, PAPR_E_ARG, "npackets must be a multiple of 4 * period");
     TSCHK(ctx, hipSetDevice(ctx->device));
     const uint64_t nbytes = ts_synth_damaged_size(npackets, period);
-    if (!(ctx->d_data && ctx->cap >= nbytes)) {
+    // (the generator writes whole dwords — up to three bytes behind an nbytes that is no multiple of 4: only the context's
+    // own buffers have that slack; an adopted one of exactly nbytes is replaced)
+    if (!(ctx->d_data && ctx->owns && ctx->cap >= nbytes)) {
         int rc = ensure_capacity(ctx, nbytes);
         if (rc)
             return rc;
@@ -337,6 +352,7 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
     memset(out, 0, sizeof(*out));
     out->bytes = ctx->n;
     ctx->errors.clear();
+    ctx->discs.clear();
     if (ctx->n == 0)
         return PAPR_OK;
     const uint32_t stride = hdmv ? 192u : 188u, sync_offset = hdmv ? 4u : 0u;
@@ -366,6 +382,7 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
         ts_walk_init(&p.entry, hdmv);
         p.lists = ctx->d_lists;
         p.recs = ctx->d_recs;
+        p.cc_lists = ctx->d_cc_lists;
         p.events = ctx->d_events;
         p.event_cap = ctx->event_cap;
         p.event_count = ctx->d_event_count;
@@ -381,7 +398,7 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
             TSCHK(ctx, hipEventRecord(ctx->ev_m, ctx->stream));
             // ---- ... and the chain check + merge from there on
             ts_launch_merge(ctx->stream, p, from, packets, cur, ctx->d_count, ctx->d_first, ctx->d_last, ctx->d_span_base,
-                            ctx->d_span_bridge_base, ctx->d_span_attempt, ctx->h_out_dev);
+                            ctx->d_span_bridge_base, ctx->d_span_attempt, ctx->h_out_dev, ctx->d_span_out);
             TSCHK(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
             TSCHK(ctx, hipGetLastError());
             // (the event counter behind the merge — its bridges write events too, in every workgroup: only now is it final)
@@ -391,6 +408,9 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
             // case — so that a scan is ONE wait)
             TSCHK(ctx, hipMemcpyAsync(ctx->h_tables, ctx->d_count, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long)),
                                       hipMemcpyDeviceToHost, ctx->stream));
+            // (... and every span's numbering base and the head of its continuity list: the host links the spans)
+            TSCHK(ctx, hipMemcpyAsync(ctx->h_span_out, ctx->d_span_out, (size_t)nspans * sizeof(ts_span_out), hipMemcpyDeviceToHost,
+                                      ctx->stream));
             TSCHK(ctx, hipStreamSynchronize(ctx->stream));
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_m) == hipSuccess)
@@ -433,48 +453,133 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
             out->walks = 0;
             continue;
         }
-        // ---- the sync errors: the events of the attempts the chain took, with stream-wide packet numbers, in order ----
-        if (nev) {
-            std::vector<ts_event> ev(nev);
-            TSCHK(ctx, hipMemcpyAsync(ev.data(), ctx->d_events, (size_t)nev * sizeof(ts_event), hipMemcpyDeviceToHost, ctx->stream));
-            TSCHK(ctx, hipMemcpyAsync(base.data(), ctx->d_span_base, nspans * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-            TSCHK(ctx, hipMemcpyAsync(taken.data(), ctx->d_span_attempt, nspans * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            TSCHK(ctx, hipMemcpyAsync(bridge_base.data(), ctx->d_span_bridge_base, nspans * sizeof(unsigned long long),
-                                      hipMemcpyDeviceToHost, ctx->stream));
-            TSCHK(ctx, hipStreamSynchronize(ctx->stream));
-            // Spans are in stream order and a span's walker hands its events out in order, so the list is sorted by a
-            // counting sort over the spans (stable: slots of one span keep their order) plus a look at each span's few
-            // events for the ones the block lanes put in between (read-boundary quirks: slots in any order) — instead of
-            // one sort of everything, which for the 11 000 lines of a stream damaged every 10 000th packet took longer
-            // than a third of the scan.
-            std::vector<uint32_t> first(nspans + 1, 0);
-            // (an event of a bridge carries TS_EVENT_BRIDGE and counts from the bridge's first packet)
-            auto takes = [&](const ts_event &e) {
-                return e.span < nspans && taken[e.span] != 0 && taken[e.span] == (e.attempt & ~TS_EVENT_BRIDGE);
-            };
-            for (const ts_event &e : ev)
-                if (takes(e))  // (else: an attempt the chain did not take)
-                    first[e.span + 1]++;
-            for (uint32_t k = 0; k < nspans; k++)
-                first[k + 1] += first[k];
-            ctx->errors.resize(first[nspans]);
-            std::vector<uint32_t> at(first.begin(), first.end() - 1);
-            for (const ts_event &e : ev)
-                if (takes(e)) {
-                    ts_sync_error &se = ctx->errors[at[e.span]++];
-                    se.skipped = e.skipped;
-                    se.at_packet = ((e.attempt & TS_EVENT_BRIDGE) ? bridge_base[e.span] : base[e.span]) + e.at_rel;
-                }
-            auto by_packet = [](const ts_sync_error &a, const ts_sync_error &b) { return a.at_packet < b.at_packet; };
-            for (uint32_t k = 0; k < nspans; k++)
-                if (!std::is_sorted(ctx->errors.begin() + first[k], ctx->errors.begin() + first[k + 1], by_packet))
-                    std::stable_sort(ctx->errors.begin() + first[k], ctx->errors.begin() + first[k + 1], by_packet);
+        // ---- the report's lines: the events of the attempts the chain took, with stream-wide packet numbers, in the order
+        // the reference prints them — and the continuity of every PID ACROSS the spans, which no span could check: a span
+        // lists, per PID, the counter of its first and of its last payload-carrying packet; the spans are linked here, in
+        // stream order, through the table the reference keeps (xport.c:2659), together with the packets the merge kernel's
+        // bridges walked between them ----
+        struct Line {
+            uint64_t key;      // 2 * packet number (+ 1 for a sync error, which is printed behind that packet's own lines)
+            uint64_t skipped;
+            uint32_t kind, info;
+        };
+        if (nev > ctx->h_events_cap) {  // (pinned: a pageable destination made this copy the longest part of a damaged scan)
+            if (ctx->h_events) (void)hipHostFree(ctx->h_events);
+            ctx->h_events = nullptr;
+            ctx->h_events_cap = 0;
+            const size_t want = std::max<size_t>((size_t)nev + nev / 4, 1u << 16);
+            TSCHK(ctx, hipHostMalloc((void **)&ctx->h_events, want * sizeof(ts_event), hipHostMallocDefault));
+            ctx->h_events_cap = want;
         }
+        if (nev) {
+            TSCHK(ctx, hipMemcpyAsync(ctx->h_events, ctx->d_events, (size_t)nev * sizeof(ts_event), hipMemcpyDeviceToHost, ctx->stream));
+            TSCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        const ts_event *ev_begin = ctx->h_events, *ev_end = ctx->h_events + nev;
+        const ts_span_out *so = ctx->h_span_out;
+        auto takes = [&](const ts_event &e) {  // (else: an attempt the chain did not take)
+            return e.span < nspans && so[e.span].attempt != 0 && so[e.span].attempt == (e.attempt & ~TS_EVENT_BRIDGE);
+        };
+        // Every span's lines come in three runs, each in the reference's order already: what the merge kernel's bridge in
+        // front of it reported, what the span itself reported (the event list's slots are handed out in stream order
+        // within a span: ts_kernels.hip), and the few the linking below adds.  A counting sort over (span, run) — stable —
+        // lays them out; the runs are then merged.  Nothing is sorted unless a run turns out not to be in order.
+        auto run_of = [](const ts_event &e) { return (e.attempt & TS_EVENT_BRIDGE) ? (e.kind == TS_EV_BRIDGE_CC ? 0u : 1u) : 2u; };
+        std::vector<uint32_t> first(3 * (size_t)nspans + 1, 0);
+        for (const ts_event *pe = ev_begin; pe != ev_end; pe++)
+            if (takes(*pe))
+                first[3 * (size_t)pe->span + run_of(*pe) + 1]++;
+        for (size_t k = 0; k < 3 * (size_t)nspans; k++)
+            first[k + 1] += first[k];
+        const size_t nlines = first[3 * (size_t)nspans];
+        if (ctx->line_scratch.size() < nlines * sizeof(Line))
+            ctx->line_scratch.resize(nlines * sizeof(Line) + (nlines * sizeof(Line)) / 4);
+        Line *lines = reinterpret_cast<Line *>(ctx->line_scratch.data());
+        {
+            std::vector<uint32_t> at(first.begin(), first.end() - 1);
+            for (const ts_event *pe = ev_begin; pe != ev_end; pe++)
+                if (takes(*pe)) {
+                    const ts_event &e = *pe;
+                    // (an event of a bridge carries TS_EVENT_BRIDGE and counts from the bridge's first packet)
+                    const uint64_t num = ((e.attempt & TS_EVENT_BRIDGE) ? so[e.span].bridge_base : so[e.span].base) + e.at_rel;
+                    lines[at[3 * (size_t)e.span + run_of(e)]++] = Line{2 * num + (e.kind == TS_EV_SYNC ? 1u : 0u), e.skipped, e.kind, e.info};
+                }
+        }
+        auto by_key = [](const Line &a, const Line &b) { return a.key < b.key; };
+        auto in_order = [&](Line *b, Line *e) {
+            if (!std::is_sorted(b, e, by_key))
+                std::sort(b, e, by_key);  // (keys are unique: a packet has one line of each kind at most)
+        };
+        // link the spans: continuity_counter[] as the reference would hold it at each span's start
+        std::vector<uint8_t> cc_state(TS_PIDS, 0);  // last counter + 1, 0 = none yet
+        std::vector<Line> linked;
+        std::vector<ts_cc_entry> big;
+        ctx->errors.reserve(nlines);
+        for (uint32_t k = 0; k < nspans; k++) {
+            if (so[k].attempt == 0)
+                continue;
+            Line *r0 = lines + first[3 * (size_t)k], *r1 = lines + first[3 * (size_t)k + 1], *r2 = lines + first[3 * (size_t)k + 2],
+                 *r3 = lines + first[3 * (size_t)k + 3];
+            in_order(r0, r1);
+            in_order(r1, r2);
+            in_order(r2, r3);
+            linked.clear();
+            auto check = [&](uint32_t pid, uint32_t cc, uint64_t num) {
+                const uint32_t last = cc_state[pid];
+                if (last != 0 && pid != 0x1fffu && (last & 0xfu) != cc)
+                    linked.push_back(Line{2 * num, 0, TS_EV_DISC, (pid << 8) | (cc << 4) | (last & 0xfu)});
+            };
+            for (Line *l = r0; l != r1; l++) {  // the bridge's payload-carrying packets, in front of the span, one by one
+                const uint32_t pid = l->info >> 8, cc = (l->info >> 4) & 0xfu;
+                check(pid, cc, l->key / 2);
+                cc_state[pid] = (uint8_t)(cc + 1u);
+            }
+            const ts_cc_entry *list = so[k].cc;
+            if (so[k].ncc > TS_CC_OUT) {  // (more PIDs than travel with the scan's one wait: this span's list itself)
+                big.resize(so[k].ncc);
+                TSCHK(ctx, hipMemcpy(big.data(), ctx->d_cc_lists + (size_t)k * TS_PIDS, (size_t)so[k].ncc * sizeof(ts_cc_entry),
+                                     hipMemcpyDeviceToHost));
+                list = big.data();
+            }
+            for (uint32_t j = 0; j < so[k].ncc; j++)
+                check(list[j].pid, list[j].first_cc, so[k].base + list[j].first_rel + 1);
+            for (uint32_t j = 0; j < so[k].ncc; j++)
+                cc_state[list[j].pid] = (uint8_t)(list[j].last_cc + 1u);
+            in_order(linked.data(), linked.data() + linked.size());
+            // three-way merge of the bridge's lines, the span's lines and the linked ones
+            Line *a = r1, *b = r2;
+            const Line *c = linked.data(), *ce = c + linked.size();
+            for (;;) {
+                const Line *pick = nullptr;
+                int which = -1;
+                if (a != r2) { pick = a; which = 0; }
+                if (b != r3 && (!pick || b->key < pick->key)) { pick = b; which = 1; }
+                if (c != ce && (!pick || c->key < pick->key)) { pick = c; which = 2; }
+                if (!pick)
+                    break;
+                if (pick->kind == TS_EV_SYNC) {
+                    ctx->errors.push_back(ts_sync_error{pick->skipped, pick->key / 2});
+                } else {
+                    ts_discontinuity d{};
+                    d.at_packet = pick->key / 2;
+                    d.after_sync_errors = ctx->errors.size();
+                    d.pid = pick->info >> 8;
+                    d.received = (uint8_t)((pick->info >> 4) & 0xfu);
+                    d.expected = (uint8_t)(pick->info & 0xfu);
+                    ctx->discs.push_back(d);
+                }
+                if (which == 0) a++; else if (which == 1) b++; else c++;
+            }
+        }
+        memcpy(out->cc_state, cc_state.data(), TS_PIDS);
         break;
     }
     out->nsync_errors = ctx->errors.size();
     for (size_t k = 0; k < ctx->errors.size() && k < TS_MAX_SYNC_ERRORS; k++)
         out->sync_errors[k] = ctx->errors[k];
+    out->ndiscontinuities = ctx->discs.size();
+    for (size_t k = 0; k < ctx->discs.size() && k < TS_MAX_DISCONTINUITIES; k++)
+        out->discontinuities[k] = ctx->discs[k];
     // the stream-wide tables (absolute packet numbers: min / max are order-independent; copied behind the last merge)
     const uint32_t *gc = (const uint32_t *)ctx->h_tables;
     const unsigned long long *gf = (const unsigned long long *)(gc + TS_PIDS), *gl = gf + TS_PIDS;
@@ -507,6 +612,20 @@ int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
 uint64_t ts_hip_sync_error_count(const ts_hip_ctx *ctx)
 {
     return ctx ? (uint64_t)ctx->errors.size() : 0;
+}
+
+uint64_t ts_hip_discontinuity_count(const ts_hip_ctx *ctx)
+{
+    return ctx ? (uint64_t)ctx->discs.size() : 0;
+}
+
+int ts_hip_get_discontinuities(const ts_hip_ctx *ctx, uint64_t first, uint64_t n, ts_discontinuity *out)
+{
+    if (!ctx || (n && !out) || first > ctx->discs.size() || n > ctx->discs.size() - first)
+        return PAPR_E_ARG;
+    if (n)
+        memcpy(out, ctx->discs.data() + first, (size_t)n * sizeof(ts_discontinuity));
+    return PAPR_OK;
 }
 
 int ts_hip_get_sync_errors(const ts_hip_ctx *ctx, uint64_t first, uint64_t n, ts_sync_error *out)

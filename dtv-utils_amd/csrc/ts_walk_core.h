@@ -15,6 +15,7 @@
  *   TS_CORE_BYTE(ctx, off)            the stream's byte at file offset `off`
  *   TS_CORE_FIND_SYNC(ctx, from, end) first offset in [from, end) whose byte is 0x47, or `end`
  *   TS_CORE_COUNT(ctx, h1, h2)        a packet: header bytes 1 and 2 (xport.c:2860-2867)
+ *   TS_CORE_CC(ctx, pid, b3)          header byte 3 of the packet just counted: its continuity counter (xport.c:2872-2889)
  *   TS_CORE_SYNC_ERROR(ctx, skipped)  the stream locked again after `skipped` bytes (xport.c:4324-4327)
  *   TS_CORE_STOP_AT(ctx, s)           optional: the search has ended on the sync byte at `s` — stop in front of that packet
  *                                     (nothing reported, nothing consumed; st->pos == s, st->skipped as it stands)?
@@ -82,7 +83,9 @@ TS_CORE_QUAL int TS_CORE_NAME(ts_walk_state *st, TS_CORE_CTX ctx, uint64_t end, 
     uint64_t q = s + 4;  /* next unconsumed byte */
     uint32_t left = 184; /* bytes of this packet still to consume */
     uint32_t af = st->stale_af;
-    if (TS_CORE_BYTE(ctx, s + 3) & 0x20u) { /* adaptation_field_control & 2: a length byte follows (and replaces what was owed) */
+    const unsigned h3 = TS_CORE_BYTE(ctx, s + 3);
+    TS_CORE_CC(ctx, pid, h3);
+    if (h3 & 0x20u) { /* adaptation_field_control & 2: a length byte follows (and replaces what was owed) */
         if (q >= end) {
             st->pos = end;
             return 1;

@@ -32,6 +32,7 @@
  * There is no CPU fallback: without a usable GPU the program exits 254.
  */
 #define _FILE_OFFSET_BITS 64
+#include <fcntl.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -275,6 +276,19 @@ int main(int argc, char **argv)
         }
     }
 
+    /* stdout carries the reference's text and nothing else: RCCL prints a version banner there when a communicator is
+     * created, so while the shards work (nothing of ours is printed before they are done) fd 1 points at /dev/null */
+    int saved_stdout = -1;
+    if (xrc == PAPR_OK) {
+        fflush(stdout);
+        saved_stdout = dup(1);
+        const int nul = open("/dev/null", O_WRONLY);
+        if (saved_stdout >= 0 && nul >= 0)
+            dup2(nul, 1);
+        if (nul >= 0)
+            close(nul);
+    }
+
     /* ---- one thread per shard (a shard whose thread cannot be created runs inline, last) ---- */
     pthread_t th[MAX_GPUS];
     int started[MAX_GPUS];
@@ -295,6 +309,11 @@ int main(int argc, char **argv)
     shard_thread(&sh[0]);
     for (int g = 1; g < ngpu; g++)
         pthread_join(th[g], NULL);
+    if (saved_stdout >= 0) {
+        fflush(stdout);
+        dup2(saved_stdout, 1);
+        close(saved_stdout);
+    }
     for (int g = 0; g < ngpu; g++)
         if (sh[g].rc != PAPR_OK && sh[g].rc != PAPR_E_STATE) { /* (E_STATE: cancelled because another shard failed) */
             fprintf(stderr, "papr: GPU %d: %s\n", sh[g].device, sh[g].err);

@@ -14,37 +14,59 @@ from . import PaprError, lib
 
 PIDS = 0x2000
 MAX_SYNC_ERRORS = 4096
+MAX_DISCONTINUITIES = 4096
 
 ABI_SYMBOLS = ("ts_walk_init", "ts_walk_is_clean", "ts_walk", "ts_format_report", "ts_format_report_all", "ts_hip_open", "ts_hip_close",
                "ts_hip_last_error", "ts_hip_upload", "ts_hip_load_file", "ts_hip_adopt", "ts_hip_generate", "ts_hip_generate_damaged",
-               "ts_hip_download", "ts_hip_scan", "ts_hip_sync_error_count", "ts_hip_get_sync_errors")
+               "ts_hip_download", "ts_hip_scan", "ts_hip_sync_error_count", "ts_hip_get_sync_errors", "ts_hip_discontinuity_count",
+               "ts_hip_get_discontinuities")
 
 
 class SyncError(C.Structure):
     _fields_ = [("skipped", C.c_uint64), ("at_packet", C.c_uint64)]
 
 
+class Discontinuity(C.Structure):
+    _fields_ = [("at_packet", C.c_uint64), ("after_sync_errors", C.c_uint64), ("pid", C.c_uint32), ("received", C.c_uint8),
+                ("expected", C.c_uint8), ("pad", C.c_uint8 * 2)]
+
+
 class ScanResult(C.Structure):
     """ts_scan_result (include/ts_hip.h)."""
     _fields_ = [("packets", C.c_uint64), ("count", C.c_uint32 * PIDS), ("first", C.c_uint64 * PIDS),
                 ("last", C.c_uint64 * PIDS), ("nsync_errors", C.c_uint64), ("sync_errors", SyncError * MAX_SYNC_ERRORS),
+                ("ndiscontinuities", C.c_uint64), ("discontinuities", Discontinuity * MAX_DISCONTINUITIES),
+                ("cc_state", C.c_uint8 * PIDS),
                 ("bytes", C.c_uint64), ("gpu_packets", C.c_uint64), ("launches", C.c_uint32), ("walks", C.c_uint32),
                 ("kernel_ms", C.c_double), ("merge_ms", C.c_double)]
 
     _all_errors = None   # every sync error of the scan (TsHip.scan attaches them when the inline list is not all of them)
+    _all_discs = None    # ... and every discontinuity
 
     def report(self) -> bytes:
-        """The reference's report lines (ts_format_report / ts_format_report_all): every sync error, then the PIDs."""
-        errs = self._all_errors
-        n = len(errs) if errs is not None else min(int(self.nsync_errors), MAX_SYNC_ERRORS)
-        if errs is None and int(self.nsync_errors) > MAX_SYNC_ERRORS:
-            raise PaprError(-7, "ts_format_report", "the result holds only the first %d of %d sync errors" % (MAX_SYNC_ERRORS, self.nsync_errors))
-        buf = C.create_string_buffer((1 << 20) + 64 * n)
-        if errs is not None:
-            n = _lib().ts_format_report_all(C.byref(self), errs, len(errs), buf, len(buf))
-        else:
+        """The reference's report lines (ts_format_report / ts_format_report_all): every sync error and discontinuity in
+        the order they were printed, then the PIDs."""
+        if self._all_errors is None and self._all_discs is None:
+            if int(self.nsync_errors) > MAX_SYNC_ERRORS or int(self.ndiscontinuities) > MAX_DISCONTINUITIES:
+                raise PaprError(-7, "ts_format_report", "the result holds only the first %d / %d of %d sync errors / %d discontinuities"
+                                % (MAX_SYNC_ERRORS, MAX_DISCONTINUITIES, self.nsync_errors, self.ndiscontinuities))
+            buf = C.create_string_buffer((1 << 20) + 96 * (int(self.nsync_errors) + int(self.ndiscontinuities)))
             n = _lib().ts_format_report(C.byref(self), buf, len(buf))
+            return buf.raw[:n]
+        errs = self._all_errors if self._all_errors is not None else self.sync_errors
+        ne = len(self._all_errors) if self._all_errors is not None else int(self.nsync_errors)
+        discs = self._all_discs if self._all_discs is not None else self.discontinuities
+        nd = len(self._all_discs) if self._all_discs is not None else int(self.ndiscontinuities)
+        buf = C.create_string_buffer((1 << 20) + 96 * (ne + nd))
+        n = _lib().ts_format_report_all(C.byref(self), errs, ne, discs, nd, buf, len(buf))
         return buf.raw[:n]
+
+    def discontinuity_list(self):
+        """(at_packet, sync-error lines printed before it, pid, received, expected) — the oracle's tuples."""
+        src = self._all_discs if self._all_discs is not None else self.discontinuities
+        n = len(self._all_discs) if self._all_discs is not None else min(int(self.ndiscontinuities), MAX_DISCONTINUITIES)
+        return [(int(src[k].at_packet), int(src[k].after_sync_errors), int(src[k].pid), int(src[k].received), int(src[k].expected))
+                for k in range(n)]
 
     def tables(self):
         return (np.ctypeslib.as_array(self.count).copy(), np.ctypeslib.as_array(self.first).copy(),
@@ -77,12 +99,16 @@ def _lib():
         L.ts_walk.restype = u64
         L.ts_format_report.argtypes = [C.POINTER(ScanResult), C.c_char_p, C.c_size_t]
         L.ts_format_report.restype = C.c_size_t
-        L.ts_format_report_all.argtypes = [C.POINTER(ScanResult), vp, u64, C.c_char_p, C.c_size_t]
+        L.ts_format_report_all.argtypes = [C.POINTER(ScanResult), vp, u64, vp, u64, C.c_char_p, C.c_size_t]
         L.ts_format_report_all.restype = C.c_size_t
         L.ts_hip_sync_error_count.argtypes = [vp]
         L.ts_hip_sync_error_count.restype = u64
         L.ts_hip_get_sync_errors.argtypes = [vp, u64, u64, vp]
         L.ts_hip_get_sync_errors.restype = i32
+        L.ts_hip_discontinuity_count.argtypes = [vp]
+        L.ts_hip_discontinuity_count.restype = u64
+        L.ts_hip_get_discontinuities.argtypes = [vp, u64, u64, vp]
+        L.ts_hip_get_discontinuities.restype = i32
         L.ts_hip_open.argtypes = [C.POINTER(vp), i32]
         L.ts_hip_close.argtypes = [vp]
         L.ts_hip_close.restype = None
@@ -97,7 +123,7 @@ def _lib():
         L.ts_hip_download.argtypes = [vp, vp, u64, u64]
         L.ts_hip_scan.argtypes = [vp, i32, C.POINTER(ScanResult)]
         for name in ("ts_hip_open", "ts_hip_upload", "ts_hip_load_file", "ts_hip_adopt", "ts_hip_generate",
-                     "ts_hip_download", "ts_hip_scan", "ts_hip_sync_error_count", "ts_hip_get_sync_errors"):
+                     "ts_hip_download", "ts_hip_scan", "ts_hip_get_sync_errors"):   # (ts_hip_sync_error_count returns a count: u64)
             getattr(L, name).restype = i32
         _bound = True
     return L
@@ -194,4 +220,10 @@ class TsHip:
             errs = (SyncError * n)()
             self._chk(self._L.ts_hip_get_sync_errors(self._ctx, 0, n, errs), "ts_hip_get_sync_errors")
             res._all_errors = errs
+        nd = int(self._L.ts_hip_discontinuity_count(self._ctx))
+        assert nd == int(res.ndiscontinuities)
+        if nd > MAX_DISCONTINUITIES:
+            discs = (Discontinuity * nd)()
+            self._chk(self._L.ts_hip_get_discontinuities(self._ctx, 0, nd, discs), "ts_hip_get_discontinuities")
+            res._all_discs = discs
         return res

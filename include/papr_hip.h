@@ -234,14 +234,20 @@ typedef struct papr_exchange papr_exchange; /* include/papr_exchange.h: the exch
  * bin/papr prints from; every step is one of the calls above and can be made separately.  `x` may be NULL for a
  * single shard.  levels / counts_above: caller's arrays of `cap` entries (PAPR_HIP_MAX_LEVELS always suffices);
  * all ranks receive the same result.
- * With the RCCL transport the three exchanges are collectives queued on the context's stream between the kernels that
- * produce and consume them (no host staging; the whole step is one wait); with the callback and in-process transports
- * they are host calls between three waits.
- * FAILURE WITH PEERS: a rank whose call fails locally (a HIP error, out of memory, a shard that cannot be read) returns
- * at once and does not enter the collectives that were still to come — the other ranks would wait in them for ever.
- * Whoever gets a non-zero return must therefore tear the exchange down so that its peers are released: the in-process
- * transport has papr_exchange_abort for that (bin/papr calls it); with RCCL or caller-supplied collectives destroy the
- * communicator / leave the process group (ncclCommAbort, or exit), as with any collective program. */
+ * With the RCCL transports (papr_exchange_open_rccl, papr_exchange_open_rccl_local + papr_exchange_bind) the step's exchanges
+ * are collectives queued on the context's stream between the kernels that produce and consume them — the estimate records,
+ * the pass-1 records, in exact-sum mode every rank's sum program (a slot per rank, enlarged when a program outgrows it), the
+ * counters — with no host staging: the whole step is one wait.  With the callback and in-process transports they are host
+ * calls between three waits.
+ * FAILURE WITH PEERS: the ranks first AGREE (a host all-reduce, repeated whenever a shard, a mode or the exchange changed)
+ * that every one of them can take the single-wait step — buffers are allocated in front of that agreement and a rank that
+ * cannot says so there, and all of them take the host path.  A rank whose call fails locally BEHIND the agreement, or
+ * anywhere on the host path (a HIP error, out of memory, a shard that cannot be read), returns its error at once and does
+ * NOT enter the collectives that were still to come; so that the other ranks do not wait in them for ever, the library
+ * cancels the exchange on its way out of the single-wait step (papr_exchange_abort: the in-process hub's waiters return
+ * PAPR_E_STATE, RCCL communicators are aborted with ncclCommAbort), and on the host path whoever gets a non-zero return
+ * must do the same: papr_exchange_abort(x) (bin/papr does), or — with caller-supplied collectives — leave the process
+ * group, as with any collective program. */
 #define PAPR_ANALYZE_TWO_PASS 1u /* no speculation: pass 1, then pass 2 (two reads of the shard) */
 #define PAPR_ANALYZE_SPOIL_GUESS 2u /* diagnostics: feed the sweep a guess that is 3 % off (what a missed speculation costs) */
 typedef struct papr_result {

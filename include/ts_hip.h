@@ -1,6 +1,7 @@
 /*
  * ts_hip.h — C ABI of the MI355X (gfx950) transport-stream packet scan in libpaprhip.so: sync lock, per-PID packet
- * count and first / last packet number of an MPEG-2 transport stream (188-byte packets, or 192-byte HDMV packets).
+ * count and first / last packet number, and the continuity-counter check of an MPEG-2 transport stream (188-byte packets,
+ * or 192-byte HDMV packets).
  *
  * It replaces the scan inside drmpeg/dtv-utils xport.c — which, like papr.c, has no library surface: the scan is
  * inline in main() and demux_mpeg2_transport() — for the report `xport -p` ends with:
@@ -11,11 +12,13 @@
  *   :4317-4373 sync acquisition, `Transport Sync Error` events     ts_hip_scan -> ts_scan_result.sync_errors
  *   :2844-2867 header parse, packet_counter, pid_counter[pid]++,   ts_hip_scan -> .packets, .count, .first, .last
  *              pid_first_packet / pid_last_packet
+ *   :2872-2889 header byte 3: the continuity counter against the   ts_hip_scan -> .discontinuities
+ *              PID's last one, `Discontinuity!` lines
  *   :245-250   printf("packets for pid ...")                       stays in the caller (ts_format_report is the
  *                                                                  reference's format, for tests and tools)
  *
  * Scope: the lines above as `xport -ps[h] <file> <program no PAT announces> <v> <a>` prints them — no demultiplexing,
- * no PSI / PES parsing, no continuity-counter or PCR output.  Within that scope the result is the reference's bit for
+ * no PSI / PES parsing, no PCR output.  Within that scope the result is the reference's bit for
  * bit, including what its 16384-byte read loop does to a packet that ends exactly one byte past a read
  * (xport.c:4302 `>=`): positions are therefore FILE offsets, and a stream must be scanned from its first byte.
  * Streams that carry a complete ATSC Master Guide Table on PID 0x1ffb are outside the domain (the reference starts
@@ -46,12 +49,23 @@ extern "C" {
 
 #define TS_PIDS 0x2000
 #define TS_MAX_SYNC_ERRORS 4096
+#define TS_MAX_DISCONTINUITIES 4096
 #define TS_READ_CHUNK 16384u /* xport.c:70 `static unsigned char buffer[16384]` */
 
 typedef struct ts_sync_error {
     uint64_t skipped;   /* bytes passed over before the stream locked again (xport.c prints it with %d) */
     uint64_t at_packet; /* packet_counter at that moment */
 } ts_sync_error;
+
+/* a `Discontinuity!` line (xport.c:2876-2884): header byte 3 of a payload-carrying packet (adaptation_field_control & 1) of
+ * a PID other than the null PID does not continue that PID's last counter.  The two kinds of line interleave in the
+ * reference's output: after_sync_errors = `Transport Sync Error` lines printed before this one. */
+typedef struct ts_discontinuity {
+    uint64_t at_packet;         /* packet_counter: the packet's own number */
+    uint64_t after_sync_errors;
+    uint32_t pid;
+    uint8_t received, expected, pad[2];
+} ts_discontinuity;
 
 typedef struct ts_scan_result {
     uint64_t packets;          /* packet_counter (xport.c:34) */
@@ -60,6 +74,10 @@ typedef struct ts_scan_result {
     uint64_t last[TS_PIDS];    /* pid_last_packet */
     uint64_t nsync_errors;     /* `Transport Sync Error` lines the reference prints; the first TS_MAX_SYNC_ERRORS are kept */
     ts_sync_error sync_errors[TS_MAX_SYNC_ERRORS];
+    uint64_t ndiscontinuities; /* `Discontinuity!` lines the reference prints; the first TS_MAX_DISCONTINUITIES are kept */
+    ts_discontinuity discontinuities[TS_MAX_DISCONTINUITIES];
+    uint8_t cc_state[TS_PIDS]; /* continuity_counter[] as it stands (xport.c:2659): 0 = no payload packet of the PID yet,
+                                  else its last counter + 1 (ts_walk keeps its state here between calls) */
     /* how the scan went (not part of the reference's output) */
     uint64_t bytes;            /* stream length */
     uint64_t gpu_packets;      /* packets counted one lane per packet (the rest: the device-side walker) */
@@ -87,12 +105,16 @@ int ts_walk_is_clean(const ts_walk_state *st);
  * reach past the window and eof == 0: the caller then supplies a window further on.  Returns the packets taken. */
 uint64_t ts_walk(ts_walk_state *st, const unsigned char *data, uint64_t base, uint64_t n, int eof, uint64_t min_packets,
                  ts_scan_result *res);
-/* the report lines of the reference for a result (xport.c:245-250 and :4326 / :4364); returns the bytes written
- * (excluding the terminating NUL), at most cap - 1 */
+/* the report lines of the reference for a result (xport.c:245-250, :4326 / :4364 and :2876-2884: sync errors and
+ * discontinuities in the order they were printed, then the PIDs); returns the bytes written (excluding the terminating
+ * NUL), at most cap - 1 — or 0, with an empty string in buf, when the result does not hold all of its lines inline
+ * (res->nsync_errors > TS_MAX_SYNC_ERRORS or res->ndiscontinuities > TS_MAX_DISCONTINUITIES: the reference prints every one
+ * of them, so a report from the inline lists would not be its report): fetch the lists with ts_hip_get_sync_errors /
+ * ts_hip_get_discontinuities and use ts_format_report_all */
 size_t ts_format_report(const ts_scan_result *res, char *buf, size_t cap);
-/* the same with a complete list of sync errors (ts_hip_get_sync_errors) when res->nsync_errors exceeds what the result
- * holds inline: the reference prints every one of them (xport.c:4325-4327) */
-size_t ts_format_report_all(const ts_scan_result *res, const ts_sync_error *errors, uint64_t nerrors, char *buf, size_t cap);
+/* the same with complete lists */
+size_t ts_format_report_all(const ts_scan_result *res, const ts_sync_error *errors, uint64_t nerrors,
+                            const ts_discontinuity *discs, uint64_t ndiscs, char *buf, size_t cap);
 
 /* ---- GPU scan -------------------------------------------------------------------------------------------------- */
 typedef struct ts_hip_ctx ts_hip_ctx;
@@ -116,6 +138,9 @@ int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out);
  * packets, i.e. more than that from ~3 GB on): their number, and a copy of entries [first, first + n) */
 uint64_t ts_hip_sync_error_count(const ts_hip_ctx *ctx);
 int ts_hip_get_sync_errors(const ts_hip_ctx *ctx, uint64_t first, uint64_t n, ts_sync_error *out);
+/* ... and every discontinuity */
+uint64_t ts_hip_discontinuity_count(const ts_hip_ctx *ctx);
+int ts_hip_get_discontinuities(const ts_hip_ctx *ctx, uint64_t first, uint64_t n, ts_discontinuity *out);
 
 #ifdef __cplusplus
 }

@@ -4,8 +4,9 @@
  *
  *     xport -ps <file> <program that is in no PAT> <v> <a>        (add -h for 192-byte HDMV packets)
  *
- * i.e. the lines `packets for pid %4d <0x%04x> = %d, first = %lld, last = %lld` (xport.c:245-250) and
- * `Transport Sync Error, skipped %d bytes, at %lld` (xport.c:4325-4327 / 4363-4365).  Only tests/, smoke() and the
+ * i.e. the lines `packets for pid %4d <0x%04x> = %d, first = %lld, last = %lld` (xport.c:245-250),
+ * `Transport Sync Error, skipped %d bytes, at %lld` (xport.c:4325-4327 / 4363-4365) and
+ * `Discontinuity!, pid = %d <0x%04x>, received = %2d, expected = %2d, at %lld` (xport.c:2876-2884).  Only tests/, smoke() and the
  * cpu_baseline leg of bench.py may use it, and only as the checker; nothing here is linked into the product.
  *
  * What is restated, byte for byte as the reference walks it:
@@ -29,7 +30,11 @@
  *                      exactly ONE byte past a 16384-byte read is declared finished one byte early and its last byte
  *                      goes to the sync search (skipped as a 1-byte sync error, or taken for a sync byte if it is 0x47)
  *
- * Not restated (does not touch the lines above): PAT contents, continuity-counter messages, PCR / rate output.
+ *   xport.c:2872-2889  the continuity counter of header byte 3 against the PID's last one (0xff = none yet): a line when
+ *                      it is not the successor, the packet carries a payload and the PID is not the null PID; the
+ *                      counter is remembered for every payload-carrying packet of a PID other than 0
+ *
+ * Not restated (does not touch the lines above): PAT contents, PCR / rate output.
  */
 #define _FILE_OFFSET_BITS 64
 #include "ts_oracle.h"
@@ -43,6 +48,7 @@ void ts_oracle_init(ts_oracle_state *s, int hdmv)
     memset(s, 0, sizeof(*s));
     s->hdmv = hdmv != 0;
     s->tp_extra_header_parse = 4; /* xport.c:2662, 2726 */
+    memset(s->continuity_counter, 0xff, sizeof(s->continuity_counter)); /* xport.c:2720-2721 */
 }
 
 /* demux_mpeg2_transport(length, buffer) for one fread chunk (xport.c:2729-4378) */
@@ -68,10 +74,31 @@ void ts_oracle_feed(ts_oracle_state *s, const unsigned char *buffer, unsigned in
                         s->result.last[s->pid] = s->result.packets;
                     }
                     break;
-                case 0:
-                    if (((buffer[i] >> 4) & 0x2) == 0x2)
+                case 0: { /* xport.c:2872-2892 */
+                    const unsigned temp = buffer[i];
+                    const unsigned adaptation_field_control = (temp >> 4) & 0x3;
+                    if (((s->continuity_counter[s->pid] + 1u) & 0xf) != (temp & 0xf)) {
+                        if ((adaptation_field_control & 0x1) && s->pid != 0x1fff) {
+                            if (s->continuity_counter[s->pid] != 0xff) {
+                                if (s->result.ndiscontinuities < TS_ORACLE_MAX_SYNC_ERRORS) {
+                                    ts_oracle_discontinuity *d = &s->result.discontinuities[s->result.ndiscontinuities];
+                                    d->at_packet = s->result.packets;
+                                    d->after_sync_errors = s->result.nsync_errors;
+                                    d->pid = s->pid;
+                                    d->received = temp & 0xf;
+                                    d->expected = (s->continuity_counter[s->pid] + 1u) & 0xf;
+                                    d->pad = 0;
+                                }
+                                s->result.ndiscontinuities++;
+                            }
+                        }
+                    }
+                    if ((adaptation_field_control & 0x1) && s->pid)
+                        s->continuity_counter[s->pid] = (unsigned char)(temp & 0xf);
+                    if ((adaptation_field_control & 0x2) == 0x2)
                         s->af_state = 1;
                     break;
+                }
                 }
             } else if (s->af_state) { /* xport.c:2908-2917 */
                 --s->packet_length;
@@ -156,9 +183,18 @@ int ts_oracle_scan_file(const char *path, int hdmv, ts_oracle_result *out)
 /* the report lines this oracle is pinned on, in the reference's order and format */
 void ts_oracle_print(const ts_oracle_result *r, FILE *fp)
 {
-    for (unsigned k = 0; k < r->nsync_errors && k < TS_ORACLE_MAX_SYNC_ERRORS; k++)
+    uint64_t d = 0;
+    const uint64_t nd = r->ndiscontinuities < TS_ORACLE_MAX_SYNC_ERRORS ? r->ndiscontinuities : TS_ORACLE_MAX_SYNC_ERRORS;
+    for (uint64_t k = 0;; k++) { /* the two kinds of line, in the order the reference prints them */
+        for (; d < nd && r->discontinuities[d].after_sync_errors <= k; d++)
+            fprintf(fp, "Discontinuity!, pid = %d <0x%04x>, received = %2d, expected = %2d, at %lld\n",
+                    (int)r->discontinuities[d].pid, r->discontinuities[d].pid, (int)r->discontinuities[d].received,
+                    (int)r->discontinuities[d].expected, (long long)r->discontinuities[d].at_packet);
+        if (k >= r->nsync_errors || k >= TS_ORACLE_MAX_SYNC_ERRORS)
+            break;
         fprintf(fp, "Transport Sync Error, skipped %d bytes, at %lld\n", (int)r->sync_errors[k].skipped,
                 (long long)r->sync_errors[k].at_packet);
+    }
     for (int i = 0; i < 0x2000; i++)
         if (r->count[i] != 0)
             fprintf(fp, "packets for pid %4d <0x%04x> = %d, first = %lld, last = %lld\n", i, i, (int)r->count[i],

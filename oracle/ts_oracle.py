@@ -23,9 +23,15 @@ class SyncError(C.Structure):
     _fields_ = [("skipped", C.c_uint64), ("at_packet", C.c_uint64)]
 
 
+class Discontinuity(C.Structure):
+    _fields_ = [("at_packet", C.c_uint64), ("after_sync_errors", C.c_uint64), ("pid", C.c_uint32), ("received", C.c_uint32),
+                ("expected", C.c_uint32), ("pad", C.c_uint32)]
+
+
 class Result(C.Structure):
     _fields_ = [("packets", C.c_uint64), ("count", C.c_uint32 * 0x2000), ("first", C.c_uint64 * 0x2000),
-                ("last", C.c_uint64 * 0x2000), ("nsync_errors", C.c_uint64), ("sync_errors", SyncError * MAX_SYNC_ERRORS)]
+                ("last", C.c_uint64 * 0x2000), ("nsync_errors", C.c_uint64), ("sync_errors", SyncError * MAX_SYNC_ERRORS),
+                ("ndiscontinuities", C.c_uint64), ("discontinuities", Discontinuity * MAX_SYNC_ERRORS)]
 
 
 _lib = None
@@ -49,7 +55,11 @@ def _unpack(r: Result) -> dict:
     return {"packets": int(r.packets), "count": np.ctypeslib.as_array(r.count).copy(),
             "first": np.ctypeslib.as_array(r.first).copy(), "last": np.ctypeslib.as_array(r.last).copy(),
             "nsync_errors": int(r.nsync_errors),
-            "sync_errors": [(int(r.sync_errors[k].skipped), int(r.sync_errors[k].at_packet)) for k in range(n)]}
+            "sync_errors": [(int(r.sync_errors[k].skipped), int(r.sync_errors[k].at_packet)) for k in range(n)],
+            "ndiscontinuities": int(r.ndiscontinuities),
+            # (at_packet, sync-error lines printed before it, pid, received, expected)
+            "discontinuities": [(int(d.at_packet), int(d.after_sync_errors), int(d.pid), int(d.received), int(d.expected))
+                                for d in r.discontinuities[:min(int(r.ndiscontinuities), MAX_SYNC_ERRORS)]]}
 
 
 def scan_mem(data: bytes, hdmv: bool = False) -> dict:
@@ -67,8 +77,17 @@ def scan_file(path: str, hdmv: bool = False) -> dict:
 
 
 def report_lines(res: dict) -> bytes:
-    """The reference's lines this scan is pinned on: sync errors in order of occurrence, then the per-PID report."""
-    out = [b"Transport Sync Error, skipped %d bytes, at %d\n" % (_i32(s), a) for s, a in res["sync_errors"]]
+    """The reference's lines this scan is pinned on: sync errors and discontinuities in order of occurrence, then the
+    per-PID report."""
+    out, d, discs = [], 0, res.get("discontinuities", [])
+    for k in range(len(res["sync_errors"]) + 1):   # the two kinds of line interleave, in stream order
+        while d < len(discs) and discs[d][1] <= k:
+            at, _, pid, got, want = discs[d]
+            out.append(b"Discontinuity!, pid = %d <0x%04x>, received = %2d, expected = %2d, at %d\n" % (pid, pid, got, want, at))
+            d += 1
+        if k < len(res["sync_errors"]):
+            s, a = res["sync_errors"][k]
+            out.append(b"Transport Sync Error, skipped %d bytes, at %d\n" % (_i32(s), a))
     for pid in np.nonzero(res["count"])[0]:
         out.append(b"packets for pid %4d <0x%04x> = %d, first = %d, last = %d\n" %
                    (pid, pid, _i32(int(res["count"][pid])), int(res["first"][pid]), int(res["last"][pid])))
@@ -89,6 +108,6 @@ def reference_lines(path: str, hdmv: bool = False) -> bytes:
 
 
 def filter_lines(stdout: bytes) -> bytes:
-    sync = [l for l in stdout.split(b"\n") if l.startswith(b"Transport Sync Error")]
+    sync = [l for l in stdout.split(b"\n") if l.startswith(b"Transport Sync Error") or l.startswith(b"Discontinuity!")]
     pids = [l for l in stdout.split(b"\n") if l.startswith(b"packets for pid")]
     return b"".join(l + b"\n" for l in sync + pids)

@@ -6,7 +6,7 @@ README's own gcc line), generates every stream of tests/ts_streams.py:FIXTURES, 
 
     oracle/_ref/xport -ps[h] <stream> 70000 1 1
 
-(parse only, no rate output, a program number no PAT can carry) and stores the `Transport Sync Error` and
+(parse only, no rate output, a program number no PAT can carry) and stores the `Transport Sync Error`, `Discontinuity!` and
 `packets for pid` lines of its stdout as tests/golden/ts/<name>.txt, plus the stream's size and sha256 in
 tests/golden/ts/manifest.json — the streams themselves are regenerated from the seeded generator by the tests,
 which check that hash first.  Only data (expected outputs) is stored.
@@ -44,7 +44,8 @@ def main():
                 f.write(lines)
             manifest[name] = {"bytes": len(data), "sha256": hashlib.sha256(data).hexdigest(),
                               "hdmv": ts_streams.is_hdmv(name), "lines": lines.count(b"\n"),
-                              "sync_error_lines": lines.count(b"Transport Sync Error")}
+                              "sync_error_lines": lines.count(b"Transport Sync Error"),
+                              "discontinuity_lines": lines.count(b"Discontinuity!")}
     json.dump(manifest, open(os.path.join(out_dir, "manifest.json"), "w"), indent=1, sort_keys=True)
     print(f"recorded {len(manifest)} TS fixtures")
 

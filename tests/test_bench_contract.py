@@ -88,6 +88,10 @@ def test_torchrun_single_rank_uses_rccl(extra):
         assert d["config"]["reads_of_the_shard_per_step"] == 1
         assert d["roofline"]["kernel"] == ("papr_sweep3_kernel" if "--exact" in extra else "papr_sweep_kernel")
         assert 0 < d["config"]["one_sweep"]["stash_samples"] < d["config"]["samples_per_gpu"] // 8
+        # every exchange of the step was a collective in the stream (exact-sum steps: the programs too)
+        per_step = 4 if "--exact" in extra else 3
+        assert d["exchange"]["in_stream_collectives"] >= per_step * 3, d["exchange"]
+        assert d["exchange"]["stats"]["calls"] == 0 and d["exchange"]["exact"]["calls"] == 0, d["exchange"]
 
 
 def _run_bench(nproc, gib, extra, env=None):
@@ -132,6 +136,32 @@ def test_one_sweep_equals_two_pass_at_every_rank_count(mode):
             assert got["config"][key] == ref["config"][key], (ranks, key)
         assert abs(float.fromhex(got["config"]["sum_hex"]) - float.fromhex(ref["config"]["sum_hex"])) <= \
             1e-12 * float.fromhex(ref["config"]["sum_hex"])
+
+
+@pytest.mark.parametrize("slot_kb", [None, "64"], ids=["programs cross in the stream", "a slot too small: host exchange"])
+def test_exact_sum_sharded_step_as_one_sequence_of_launches_with_real_worlds(slot_kb):
+    """The same for exact-sum steps (bin/papr's default arithmetic): the sum programs' classification starts from the
+    merged records' sum in front of the shard, read from DEVICE memory, every rank's program crosses the exchange in the
+    stream in a fixed-size slot and all of them are replayed in file order while the GPU does the recount.  The chained
+    sum must be the 1-rank run's bit for bit at 2, 4 and 8 ranks, both tables, with no host exchange of programs — and, with
+    a slot made too small on purpose (PAPR_XPROG_SLOT_KB), the same result through the host exchange every rank falls
+    back to together."""
+    env = {"PAPR_XCH_IN_STREAM": "2"}
+    if slot_kb:
+        env["PAPR_XPROG_SLOT_KB"] = slot_kb
+    for mode in ("default", "graph"):
+        one = _run_bench(1, 0.5, ["--mode", mode, "--exact"])
+        for ranks in (2, 4, 8):
+            got = _run_bench(ranks, 0.5 / ranks, ["--mode", mode, "--exact"], env=env)
+            assert got["config"]["exact_sequential_sum"] is True
+            assert got["config"]["one_sweep"]["steps_resolved_from_the_sweep"] == 2, got["config"]["one_sweep"]
+            for key in ("sum_hex", "papr_db", "levels", "counts_crc32", "samples_total"):
+                assert got["config"][key] == one["config"][key], (ranks, key)
+            assert got["exchange"]["stats"]["calls"] == 0, got["exchange"]
+            if slot_kb:
+                assert got["exchange"]["exact"]["calls"] == 2, got["exchange"]
+            else:   # four collectives per step (estimate records, pass-1 records, programs, counters), no host exchange
+                assert got["exchange"]["in_stream_collectives"] >= 4 * 2 and got["exchange"]["exact"]["calls"] == 0, got["exchange"]
 
 
 @pytest.mark.parametrize("mode", ["default", "graph"])

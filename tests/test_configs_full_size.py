@@ -35,8 +35,8 @@ def _golden(name):
         return f.read()
 
 
-@pytest.mark.parametrize("extra", [[], ["--exact"], ["--collectives-on-device-buffers"]],
-                         ids=["tree", "exact", "tree, exchanges between the kernels"])
+@pytest.mark.parametrize("extra", [[], ["--exact"], ["--collectives-on-device-buffers"], ["--exact", "--collectives-on-device-buffers"]],
+                         ids=["tree", "exact", "tree, exchanges between the kernels", "exact, exchanges between the kernels"])
 def test_eight_rank_bench_line_proves_itself_at_full_size(extra, manifest):
     """BASELINE configs[3] on the one GPU: 8 ranks x 10 GiB over gloo.  The third form takes the way an 8-GPU run over RCCL
     takes — the three exchanges as collectives on device buffers inside the step's sequence of launches — with the gloo
@@ -44,7 +44,7 @@ def test_eight_rank_bench_line_proves_itself_at_full_size(extra, manifest):
     import torch
     env = dict(os.environ)
     if "--collectives-on-device-buffers" in extra:
-        extra = []
+        extra = [e for e in extra if e != "--collectives-on-device-buffers"]
         env["PAPR_XCH_IN_STREAM"] = "2"
     free, total = torch.cuda.mem_get_info(0)
     if free < 110 * (1 << 30):
@@ -58,6 +58,7 @@ def test_eight_rank_bench_line_proves_itself_at_full_size(extra, manifest):
     assert d["n_gpus"] == 8 and d["config"]["samples_total"] == 8 * 1342177280 == manifest["big_spike80g"]["nsamples"]
     if env.get("PAPR_XCH_IN_STREAM") == "2":
         assert d["exchange"]["in_stream_collectives"] >= 6 and d["exchange"]["stats"]["calls"] == 0, d["exchange"]
+        assert d["exchange"]["exact"]["calls"] == 0, d["exchange"]   # (exact-sum steps: the programs crossed in the stream too)
     assert d["parity_in_run"] is True and d["parity_golden"] == "big_spike80g.default.txt"
     assert d["graph"]["parity_in_run"] is True and d["graph"]["parity_golden"] == "big_spike80g.graph.txt"
     assert d["report_sha256"] == manifest["big_spike80g"]["default"]["sha256"]

@@ -6,6 +6,7 @@ size-independent properties.  Integer/index results must be bit-exact; the
 double sum is order-dependent in the reference (serial `sum +=`, papr.c:104)
 and is held to 1e-12 relative here (north_star: dB values within 1e-5)."""
 import ctypes as C
+import json
 import os
 import subprocess
 
@@ -72,6 +73,26 @@ def test_cli_reproduces_reference_stdout(pkg, manifest, name, graph):
     assert p.returncode == want["rc"], p.stderr
     assert p.stderr.decode() == want["stderr"]
     assert p.stdout == golden_text(name, graph)
+
+
+@pytest.mark.parametrize("exact", ["1", "0"], ids=["exact sum (the default)", "tree sum"])
+def test_cli_over_rccl_reproduces_reference_stdout(pkg, manifest, exact):
+    """bin/papr with its shard's exchanges as RCCL collectives on device buffers, queued on the GPU's stream (PAPR_XCH=rccl:
+    papr_exchange_open_rccl_local + papr_exchange_bind — what it uses by default on a multi-GPU node; here a communicator
+    of ONE rank, which still executes every collective): every fixture, both tables, stdout / stderr / exit status the
+    reference's; and the step did cross RCCL (PAPR_STATS says which transport carried it)."""
+    env = dict(os.environ, PAPR_GPUS="1", PAPR_XCH="rccl", PAPR_EXACT_SUM=exact, PAPR_STATS="1")
+    for name in golden_names():
+        for graph in (False, True):
+            args = [pkg.CLI_PATH] + (["-g"] if graph else []) + [golden_path(name)]
+            p = subprocess.run(args, capture_output=True, env=env)
+            want = manifest[name]["graph" if graph else "default"]
+            assert p.returncode == want["rc"], (name, graph, p.stderr)
+            assert p.stdout == golden_text(name, graph), (name, graph, p.stderr)
+            lines = p.stderr.decode().splitlines()
+            stats = json.loads(lines[-1])
+            assert "\n".join(lines[:-1]) + ("\n" if len(lines) > 1 else "") == want["stderr"]
+            assert stats["exchange"] == "rccl" and stats["gpus"] == 1
 
 
 @pytest.mark.parametrize("shards", [2, 3, 8])

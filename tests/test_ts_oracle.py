@@ -34,6 +34,7 @@ def test_oracle_reproduces_reference_lines(name):
     res = ts_oracle.scan_mem(data, ts_streams.is_hdmv(name))
     assert ts_oracle.report_lines(res) == golden_lines(name)
     assert res["nsync_errors"] == MANIFEST[name]["sync_error_lines"]
+    assert res["ndiscontinuities"] == MANIFEST[name]["discontinuity_lines"]
 
 
 def test_oracle_cli_and_file_path(tmp_path):
@@ -63,6 +64,10 @@ def random_stream_kwargs(t, rng):
                        int(rng.integers(1, 188 if rng.integers(0, 2) else 3000))))
     dm = [d for d in dm if not (d[1] == "delete" and d[2] > 187)]
     kw["damage"] = list({d[0]: d for d in dm}.values())
+    if n > 4 and rng.integers(0, 2):   # continuity counters: jumps, lost and repeated packets, packets without a payload
+        pick = lambda m: tuple(int(v) for v in rng.integers(0, n, int(rng.integers(0, m))))
+        kw["cc_jump_at"] = {k: int(rng.integers(1, 16)) for k in pick(12)}
+        kw["drop_at"], kw["repeat_at"], kw["no_payload_at"] = pick(6), pick(6), pick(20)
     if rng.integers(0, 3) == 0 and n > 130:   # a packet that ends one byte past a 16384-byte read (the reference's quirk)
         k = int(rng.integers(88, 130))
         kw["offset_garbage"] = ts_streams.quirk_offset(k, 192 if kw["hdmv"] else 188)

@@ -111,6 +111,7 @@ def test_scan_equals_oracle_on_random_damaged_streams(ts, gpu):
         assert res.packets == ref["packets"] and np.array_equal(cnt, ref["count"]) and \
             np.array_equal(first, ref["first"]) and np.array_equal(last, ref["last"]), kw
         assert res.sync_error_list() == ref["sync_errors"]
+        assert res.discontinuity_list() == ref["discontinuities"], kw
 
 
 @pytest.mark.gpu
@@ -221,6 +222,8 @@ def test_more_sync_errors_than_the_result_holds_inline(ts, gpu, tmp_path):
     ref = ts_oracle.scan_mem(host)
     assert ref["nsync_errors"] > ts.MAX_SYNC_ERRORS and res.nsync_errors == ref["nsync_errors"]
     assert res.sync_error_list() == ref["sync_errors"]
+    # ... and every `Discontinuity!` line (xport.c:2876-2884): each lost packet leaves its PID's counter one short
+    assert res.ndiscontinuities == ref["ndiscontinuities"] > 1000 and res.discontinuity_list() == ref["discontinuities"]
     assert res.report() == ts_oracle.report_lines(ref)
     if os.path.exists(ts_oracle.REF_CLI):
         assert res.report() == ts_oracle.reference_lines(path)

@@ -32,8 +32,11 @@ def pat_payload() -> bytes:
     return bytes([0x00]) + bytes(sec)                            # pointer_field 0
 
 
-def packet(rng, pid: int, cc: int, *, tei=0, pusi=0, af_len=None, payload: bytes = None, no_sync_in_payload=False) -> bytes:
+def packet(rng, pid: int, cc: int, *, tei=0, pusi=0, af_len=None, payload: bytes = None, no_sync_in_payload=False,
+           no_payload=False) -> bytes:
     afc = 1 if af_len is None else 3
+    if no_payload:   # adaptation field only (adaptation_field_control = 2): its continuity counter is neither checked nor kept
+        afc, af_len = 2, 183
     head = bytes([0x47, (tei << 7) | (pusi << 6) | ((pid >> 8) & 0x1F), pid & 0xFF, (afc << 4) | (cc & 0xF)])
     body = bytearray()
     if af_len is not None:
@@ -57,12 +60,16 @@ def packet(rng, pid: int, cc: int, *, tei=0, pusi=0, af_len=None, payload: bytes
 
 def make_stream(seed: int, npackets: int, *, hdmv=False, pat=True, pids=(0x100, 0x101, 0x102, 0x1FFB, 0x1FFF, 0x31),
                 af_rate=0.2, bad_af_rate=0.0, tei_rate=0.01, offset_garbage=0, garbage_has_sync=False, damage=(),
-                truncate=0, last_byte_sync_at=None, plain_at=(), extra_header_at=None) -> bytes:
+                truncate=0, last_byte_sync_at=None, plain_at=(), extra_header_at=None, cc_jump_at=None, drop_at=(),
+                no_payload_at=(), repeat_at=()) -> bytes:
     """damage: list of (packet_index, kind, amount): kind 'insert' (amount garbage bytes before that packet),
     'delete' (drop `amount` bytes from the start of that packet).  last_byte_sync_at: packet index whose last
     payload byte is forced to 0x47 (a false sync byte for the chunk-boundary quirk).  plain_at: packet indices that are
     forced to be an ordinary payload-only packet on PID 0x100 (what the quirk needs).  extra_header_at: {packet index: the
-    four tp_extra_header bytes of that HDMV unit}."""
+    four tp_extra_header bytes of that HDMV unit}.  Continuity counters (xport.c:2872-2889): cc_jump_at {packet index: what
+    is added to that packet's counter, and to its PID's from there on}; drop_at: packets that are left out of the stream (their
+    PID's counter still advances: a lost packet); no_payload_at: packets that carry an adaptation field only; repeat_at:
+    packets that are sent twice (the copy repeats the counter)."""
     rng = np.random.default_rng(seed)
     cc = {}
     out = bytearray()
@@ -82,7 +89,11 @@ def make_stream(seed: int, npackets: int, *, hdmv=False, pat=True, pids=(0x100, 
             pid, payload, pusi = int(pids[int(rng.integers(0, len(pids)))]), None, int(rng.integers(0, 8) == 0)
             if pid == 0x1FFB:
                 pusi = 0    # no PSIP section ever starts: the reference would parse it (and act on a Master Guide Table)
+        if k in plain_at:   # (decided before the counter is taken: the packet counts for the PID it ends up on)
+            pid = 0x100
         c = cc.get(pid, 0)
+        if cc_jump_at and k in cc_jump_at:
+            c = (c + cc_jump_at[k]) & 15
         cc[pid] = (c + 1) & 15
         af_len = None
         if pid != 0 and rng.random() < af_rate:
@@ -92,7 +103,9 @@ def make_stream(seed: int, npackets: int, *, hdmv=False, pat=True, pids=(0x100, 
         tei = int(rng.random() < tei_rate)
         if k in plain_at:
             pid, payload, pusi, af_len, tei = 0x100, None, 0, None, 0
-        p = bytearray(packet(rng, pid, c, tei=tei, pusi=pusi, af_len=af_len, payload=payload))
+        p = bytearray(packet(rng, pid, c, tei=tei, pusi=pusi, af_len=af_len, payload=payload, no_payload=k in no_payload_at))
+        if k in drop_at:
+            continue
         if last_byte_sync_at is not None and k == last_byte_sync_at:
             p[187] = 0x47
         if hdmv:
@@ -107,6 +120,8 @@ def make_stream(seed: int, npackets: int, *, hdmv=False, pat=True, pids=(0x100, 
             elif kind == "delete":
                 p = p[amount:]
         out += p
+        if k in repeat_at:
+            out += p
     if truncate:
         out = out[:len(out) - truncate]
     return bytes(out)
@@ -154,6 +169,17 @@ FIXTURES = {
     "ts_hdmv_quirk_false_sync": dict(seed=125, npackets=500, hdmv=True, pat=False, offset_garbage=quirk_offset(85, 192),
                                      plain_at=(85,), extra_header_at={86: b"\x11\x22\x33\x47"}),
     "ts_hdmv_quirk_last": dict(seed=126, npackets=86, hdmv=True, pat=False, offset_garbage=quirk_offset(85, 192), plain_at=(85,)),
+    # continuity counters (xport.c:2872-2889): jumps on every kind of PID (the null PID and PID 0 stay silent), lost and
+    # repeated packets, packets without a payload (neither checked nor remembered), error-indicator packets (checked all
+    # the same), and discontinuities between sync errors
+    "ts_cc_jumps": dict(seed=127, npackets=3000, tei_rate=0.05, cc_jump_at={k: 1 + k % 14 for k in range(50, 3000, 97)}),
+    "ts_cc_lost_and_repeated": dict(seed=128, npackets=2500, drop_at=tuple(range(30, 2500, 171)), repeat_at=tuple(range(77, 2500, 233)),
+                                    no_payload_at=tuple(range(5, 2500, 41))),
+    "ts_cc_between_sync_errors": dict(seed=129, npackets=2000, garbage_has_sync=True, cc_jump_at={k: 3 for k in range(10, 2000, 53)},
+                                      damage=[(100, "insert", 700), (101, "delete", 9), (102, "insert", 2), (900, "delete", 100),
+                                              (1500, "insert", 5000)], drop_at=(103, 104, 901)),
+    "ts_cc_hdmv": dict(seed=130, npackets=1500, hdmv=True, cc_jump_at={k: 7 for k in range(20, 1500, 61)}, drop_at=(700, 701),
+                       damage=[(400, "insert", 33)]),
 }
 
 

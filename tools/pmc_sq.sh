@@ -1,8 +1,8 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): SQ counters of the two product sweep kernels, both tables, one --pmc set per
 # rocprofv3 pass (with --kernel-trace only).  tools/pmc_summarize.py prints the per-kernel averages into
-# gpurun_out/<tag>/summary.txt; copy that to profiles/r03_pmc_sq_product_kernels.txt.
-#   gpurun -- 'bash tools/pmc_sq_r03.sh pmc_r03'
+# gpurun_out/<tag>/summary.txt; copy that to profiles/<tag>_pmc_sq_product_kernels.txt.
+#   gpurun -- 'bash tools/pmc_sq.sh pmc_r03'
 set -u
 TAG=${1:-pmc_r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
