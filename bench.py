@@ -490,12 +490,13 @@ def run_ts(args, rank, world, local_rank, use_dist):
         "value": npackets * world * args.steps / elapsed / 1e6, "unit": "Mpackets/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"xport -p packet scan (sync lock, per-PID count/first/last) on {args.gib:g} GiB synthetic "
+        "config": {"workload": f"xport -p packet scan (sync lock, per-PID count/first/last, continuity counters) on {args.gib:g} GiB synthetic "
                                f"MPEG-2 TS per GPU, HBM-resident, {world}xMI355X", "packets_per_gpu": npackets,
                    "bytes_per_gpu": nbytes, "launches_per_scan": int(res.launches), "walks_per_scan": int(res.walks),
                    "damage": (f"one damaged spot every {period} packets (include/ts_synth.h: ts_synth_damaged_byte)" if period else None),
                    "preheat": {"steps": preheat_steps, "what": "untimed scans in front of the warm-up"},
-                   "sync_error_lines": int(res.nsync_errors), "packets_counted": int(res.packets),
+                   "sync_error_lines": int(res.nsync_errors), "discontinuity_lines": int(res.ndiscontinuities),
+                   "packets_counted": int(res.packets),
                    "pids_seen": int(np.count_nonzero(res.tables()[0])), "sharding": "independent streams, no exchange",
                    "report_sha256": hashlib.sha256(res.report()).hexdigest(),
                    "stream_GBps": nbytes * world * args.steps / elapsed / 1e9},

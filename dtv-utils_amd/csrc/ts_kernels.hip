@@ -183,35 +183,55 @@ __device__ __forceinline__ void put_event(ts_event *events, unsigned int *event_
     }
 }
 
-// The span walker's lines come one at a time, each behind a returning atomic on the list's counter (~2 us of the one wave
-// that walks): it reserves kWalkBatch slots at once instead, marks them empty (a span number no span has: the host skips
-// them) and fills them as lines come.  Slots still grow with the stream within a span — the blocks between two walks
-// drop what is left of a batch before they reserve their own (ts_scan_kernel).
-constexpr uint32_t kWalkBatch = 8;
-__device__ __forceinline__ void walk_event(const DevWalk *w, uint32_t kind, uint64_t skipped, uint64_t at_rel, uint32_t info)
+// A span's lines get their slots of the event list out of a POOL the workgroup keeps in LDS (s_ev: next slot, slots left),
+// refilled kEvBatch slots at a time with one returning atomic on the list's counter: the walker's lines come one at a time,
+// and an atomic each (~2 us of the one wave that walks) was a third of a damaged stream's scan.  A refill marks its slots
+// empty (a span number no span has: the host skips them) before any is used.  All of a span's slots come out of the pool
+// one after the other, so they grow with the stream: the host finds a span's lines in the reference's order.
+// Called by ALL lanes of one wave with the same arguments; returns the first of the n slots.
+constexpr uint32_t kEvBatch = 64;
+__device__ __forceinline__ unsigned int ev_take(uint32_t *s_ev, uint32_t n, uint32_t lane, ts_event *events, unsigned int *event_count,
+                                                uint32_t event_cap)
 {
-    if (w->lane != 0 || w->quiet)
-        return;
-    if (!w->s_ev) {
-        put_event(w->events, w->event_count, w->event_cap, w->span, w->attempt, kind, skipped, at_rel, info);
-        return;
-    }
-    if (w->s_ev[1] == 0) {
-        const unsigned int base = atomicAdd(w->event_count, kWalkBatch);
-        for (uint32_t k = 0; k < kWalkBatch; k++)
-            if (base + k < w->event_cap) {
+    uint32_t next = s_ev[0], left = s_ev[1];
+    __builtin_amdgcn_wave_barrier();
+    if (left < n) {  // (wave-uniform) what is left of the old batch is dropped: it lies in front of these slots
+        const uint32_t want = n > kEvBatch ? n : kEvBatch;
+        unsigned int base = 0;
+        if (lane == 0)
+            base = atomicAdd(event_count, want);  // (counts what no longer fits: the host sees the overflow)
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        for (uint32_t k = lane; k < want; k += 64u)
+            if (base + k < event_cap) {
                 ts_event e;
                 e.skipped = e.at_rel = 0;
                 e.span = 0xFFFFFFFFu;
                 e.attempt = e.kind = e.info = 0;
-                w->events[base + k] = e;
+                events[base + k] = e;
             }
-        w->s_ev[0] = base;
-        w->s_ev[1] = kWalkBatch;
+        next = base;
+        left = want;
     }
-    const unsigned int slot = w->s_ev[0]++;
-    w->s_ev[1]--;
-    if (slot < w->event_cap) {
+    if (lane == 0) {
+        s_ev[0] = next + n;
+        s_ev[1] = left - n;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return next;
+}
+
+// a line of the walker (all 64 lanes of the walking wave are here, in step)
+__device__ __forceinline__ void walk_event(const DevWalk *w, uint32_t kind, uint64_t skipped, uint64_t at_rel, uint32_t info)
+{
+    if (w->quiet)
+        return;
+    if (!w->s_ev) {  // a bridge of the merge kernel: no pool (its lines are few)
+        if (w->lane == 0)
+            put_event(w->events, w->event_count, w->event_cap, w->span, w->attempt, kind, skipped, at_rel, info);
+        return;
+    }
+    const unsigned int slot = ev_take(w->s_ev, 1u, w->lane, w->events, w->event_count, w->event_cap);
+    if (w->lane == 0 && slot < w->event_cap) {
         ts_event e;
         e.skipped = skipped;
         e.at_rel = at_rel;
@@ -228,28 +248,34 @@ __device__ __forceinline__ void dev_event(const DevWalk *w, uint64_t skipped, ui
     walk_event(w, TS_EV_SYNC, skipped, at_rel, 0u);
 }
 
-// header byte 3 of the packet the walker has just counted (w->packets is its number within the walk, 1-based)
+// header byte 3 of the packet the walker has just counted (w->packets is its number within the walk, 1-based); all lanes
+// of the walking wave are here with the same arguments
 __device__ __forceinline__ void dev_cc(DevWalk *w, unsigned pid, unsigned h3)
 {
-    if (w->lane != 0 || w->quiet || (h3 & 0x10u) == 0 || pid == 0)
+    if (w->quiet || (h3 & 0x10u) == 0 || pid == 0)
         return;  // no payload: neither checked nor remembered; PID 0 is never remembered, hence never reported
     const uint32_t cc = h3 & 0xfu;
     if (!w->s_cc) {  // a bridge: the host checks it between the spans it links
         walk_event(w, TS_EV_BRIDGE_CC, 0, w->packets, (pid << 8) | (cc << 4));
         return;
     }
-    const uint32_t last = w->s_cc[pid];
+    const uint32_t last = w->s_cc[pid];  // (every lane reads the same byte)
+    __builtin_amdgcn_wave_barrier();
     if (last == 0) {
-        ts_cc_entry e;
-        e.pid = (uint16_t)pid;
-        e.first_cc = (uint8_t)cc;
-        e.last_cc = 0;
-        e.first_rel = (uint32_t)(w->packets - 1);
-        w->cc_list[(*w->s_ncc)++] = e;
+        if (w->lane == 0) {
+            ts_cc_entry e;
+            e.pid = (uint16_t)pid;
+            e.first_cc = (uint8_t)cc;
+            e.last_cc = 0;
+            e.first_rel = (uint32_t)(w->packets - 1);
+            w->cc_list[(*w->s_ncc)++] = e;
+        }
     } else if (pid != 0x1fffu && (last & 0xfu) != cc) {
         walk_event(w, TS_EV_DISC, 0, w->packets, (pid << 8) | (cc << 4) | (last & 0xfu));
     }
-    w->s_cc[pid] = (unsigned char)(cc + 1u);
+    if (w->lane == 0)
+        w->s_cc[pid] = (unsigned char)(cc + 1u);
+    __builtin_amdgcn_wave_barrier();
 }
 
 #define TS_CORE_QUAL __device__ __forceinline__
@@ -300,8 +326,13 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
     uint32_t *s_count = ts_smem, *s_first = ts_smem + TS_PIDS, *s_last = ts_smem + 2 * TS_PIDS;
     __shared__ ts_walk_state s_st;
     __shared__ unsigned long long s_packets, s_block_packets;
-    __shared__ uint32_t s_stop, s_walks, s_entries, s_cand, s_ticket, s_ncc, s_ev[2];
+    __shared__ uint32_t s_stop, s_walks, s_entries, s_cand, s_ncc, s_ev[2], s_evbase, s_nid, s_evn[kScanBlock / 64];
     __shared__ unsigned char s_cc[TS_PIDS];  // per PID: last continuity counter + 1 (0: no payload packet in this span yet)
+    // the continuity check across the waves of ONE block (below): per PID the number of its pair of words for this block,
+    // the waves that hold the PID, and each such wave's last counter of it (a nibble per wave)
+    __shared__ uint32_t s_bid[TS_PIDS];
+    __shared__ uint32_t s_waves[kScanBlock + 1];
+    __shared__ unsigned long long s_lastcc[kScanBlock + 1];
     __shared__ __attribute__((aligned(16))) unsigned char s_window[kWalkWindow];  // the walker's view of the stream (wave 0)
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t span = p.first_span + blockIdx.x;
@@ -312,10 +343,15 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
         s_first[k] = kNone;
         s_last[k] = 0;
         s_cc[k] = 0;
+        s_bid[k] = 0;
+    }
+    for (uint32_t k = t; k < kScanBlock + 1; k += kScanBlock) {
+        s_waves[k] = 0;
+        s_lastcc[k] = 0;
     }
     ts_cc_entry *cc_list = p.cc_lists + (size_t)span * TS_PIDS;
     if (t == 0) {
-        s_ticket = 0;
+        s_nid = 0;
         s_ncc = 0;
         s_ev[0] = s_ev[1] = 0;
         s_stop = kNone;
@@ -389,7 +425,6 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
     uint64_t packets = 0, block_packets = 0;
     uint32_t units_seen = 0;  // units the blocks of this span have looked at so far: block-independent indices for s_stop
     uint32_t walks = 0;
-    uint32_t ticket_base = 0;  // the continuity check's turn counter (below): 16 turns per block
     uint64_t pre_pos = TS_NO_ENTRY;  // the position whose block's header words are in pre_w0 / pre_w1 already
     uint32_t pre_w0 = 0, pre_w1 = 0;
     bool walk_next = false;
@@ -471,11 +506,15 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
             }
             // ---- continuity counters (xport.c:2872-2889) of the block's committed packets: header byte 3 is loaded already ----
             // A payload-carrying packet (adaptation_field_control & 1) of a PID other than 0 is compared with the PID's previous
-            // such packet.  Inside a wave the previous one is found with ballots (one round per PID the wave holds: a handful);
-            // across waves and blocks it is the workgroup's table s_cc, which the waves go through IN TURN (a ticket: wave w of
-            // this block after wave w - 1) — each reads it for the PIDs whose first packet it holds and writes it for those
-            // whose last: a few LDS operations per wave and block.  A PID's first such packet in the SPAN has nothing to be
-            // compared with here: it goes on the span's list, and the host links the spans (ts_runtime.cpp).
+            // such packet.  Inside a wave the previous one is found with ballots (one round per PID the wave holds: a handful).
+            // Across the waves of the block nothing is serial either: every wave PUBLISHES, per PID it holds, that it does
+            // and the counter of its last packet of it (one bit and one nibble per wave in two words the PID gets for the
+            // length of this block); behind a barrier the first packet of a PID in a wave finds the nearest earlier wave
+            // that holds the PID in those words — or, if there is none, the workgroup's table s_cc (the state at the block's
+            // start) — and behind a second barrier the block's last packet of every PID writes the table and gives the
+            // words back.  (A first form passed a ticket from wave to wave: 16 dependent LDS round trips per block, which
+            // the damaged stream's many short blocks paid in full.)  A PID's first such packet in the SPAN has nothing to
+            // be compared with here: it goes on the span's list, and the host links the spans (ts_runtime.cpp).
             {
                 const uint32_t cc4 = b3 & 0xfu;
                 const bool ccv = t < take && (b3 & 0x10u) != 0 && pid != 0u;
@@ -499,43 +538,78 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
                     }
                     todo &= ~m;
                 }
-                const uint32_t turn = ticket_base + wave;
-                if (lane == 0)  // (no s_sleep: sixteen waves polling one LDS word cost nothing, a late wake-up costs the chain)
-                    while (__hip_atomic_load(&s_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != turn) {
+                // publish (one lane per wave and PID): the PID's words for this block are found through s_bid
+                uint32_t bid = 0;
+                if (ccv && last_in_wave) {
+                    bid = s_bid[pid];
+                    if (!bid) {
+                        const uint32_t n = atomicAdd(&s_nid, 1u) + 1u;  // (at most one per publishing lane: <= 1024 a block)
+                        const uint32_t old = atomicCAS(&s_bid[pid], 0u, n);
+                        bid = old ? old : n;
                     }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    atomicOr(&s_waves[bid], 1u << wave);
+                    atomicOr(&s_lastcc[bid], (unsigned long long)cc4 << (4u * wave));
+                }
+                __syncthreads();
+                bool block_last = false;
                 if (ccv && first_in_wave) {
-                    const uint32_t last = s_cc[pid];
-                    if (last == 0) {
-                        ts_cc_entry e;
-                        e.pid = (uint16_t)pid;
-                        e.first_cc = (uint8_t)cc4;
-                        e.last_cc = 0;
-                        e.first_rel = (uint32_t)packets + t;
-                        cc_list[atomicAdd(&s_ncc, 1u)] = e;
+                    const uint32_t id = s_bid[pid];
+                    const uint32_t earlier = s_waves[id] & ((1u << wave) - 1u);
+                    if (earlier) {
+                        const uint32_t wp = 31u - (uint32_t)__clz((int)earlier);
+                        prev = (uint32_t)((s_lastcc[id] >> (4u * wp)) & 0xfull) + 1u;
                     } else {
-                        prev = last;
+                        const uint32_t last = s_cc[pid];
+                        if (last == 0) {
+                            ts_cc_entry e;
+                            e.pid = (uint16_t)pid;
+                            e.first_cc = (uint8_t)cc4;
+                            e.last_cc = 0;
+                            e.first_rel = (uint32_t)packets + t;
+                            cc_list[atomicAdd(&s_ncc, 1u)] = e;
+                        } else {
+                            prev = last;
+                        }
                     }
                 }
                 if (ccv && last_in_wave)
-                    s_cc[pid] = (unsigned char)(cc4 + 1u);
+                    block_last = (s_waves[bid] >> (wave + 1u)) == 0;
                 // The block's lines — a discontinuity, and behind it the `skipped 1 bytes` of a read-boundary quirk (about one
                 // packet in 4096 of a stream whose packets sit at odd offsets; printed when the stream locks again, i.e. with
-                // this packet counted) — get their slots of the event list HERE, inside the turn: the waves reserve in order
-                // and the lanes of a wave take theirs in lane order, so a span's lines sit in the list in the order the
-                // reference prints them and the host has nothing to sort.
+                // this packet counted) — take their slots of the event list in stream order: the waves' line counts meet in
+                // LDS, ONE atomic reserves the block's slots, every wave starts behind the waves in front of it and its
+                // lanes follow in lane order.  A span's lines then sit in the list in the order the reference prints them
+                // and the host has nothing to sort.
                 const bool ev_disc = ccv && prev != 0 && pid != 0x1fffu && (prev & 0xfu) != cc4;
                 const bool ev_quirk = t < take && quirk;
                 const unsigned long long md = __ballot(ev_disc), mq = __ballot(ev_quirk);
-                if (md | mq) {  // (wave-uniform; rare)
-                    unsigned int base = 0;
-                    if (lane == 0) {
-                        s_ev[1] = 0;  // (what the walker had left of its batch lies in FRONT of these slots: dropped)
-                        base = atomicAdd(p.event_count, (unsigned int)(__popcll(md) + __popcll(mq)));
+                if (lane == 0)
+                    s_evn[wave] = (uint32_t)(__popcll(md) + __popcll(mq));
+                __syncthreads();
+                if (block_last) {  // the table moves on; the PID's words are free again
+                    s_cc[pid] = (unsigned char)(cc4 + 1u);
+                    s_bid[pid] = 0;
+                    s_waves[bid] = 0;
+                    s_lastcc[bid] = 0;
+                }
+                if (t == 0)
+                    s_nid = 0;
+                uint32_t ev_before = 0, ev_total = 0;
+#pragma unroll
+                for (uint32_t wq = 0; wq < kScanBlock / 64; wq++) {
+                    const uint32_t n = s_evn[wq];
+                    ev_before += wq < wave ? n : 0u;
+                    ev_total += n;
+                }
+                if (ev_total) {  // (workgroup-uniform; rare)
+                    if (wave == 0) {
+                        const unsigned int base = ev_take(s_ev, ev_total, lane, p.events, p.event_count, p.event_cap);
+                        if (lane == 0)
+                            s_evbase = base;
                     }
-                    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                    __syncthreads();
                     const unsigned long long lt = (1ull << lane) - 1ull;
-                    unsigned int slot = base + (unsigned int)(__popcll(md & lt) + __popcll(mq & lt));
+                    unsigned int slot = s_evbase + ev_before + (unsigned int)(__popcll(md & lt) + __popcll(mq & lt));
                     const uint64_t number = (uint64_t)((uint32_t)packets + t) + 1;
                     auto put = [&](uint32_t kind, uint64_t skipped, uint32_t info) {
                         if (slot < p.event_cap) {
@@ -555,10 +629,6 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
                     if (ev_quirk)
                         put(TS_EV_SYNC, 1, 0u);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0)
-                    __hip_atomic_store(&s_ticket, turn + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                ticket_base += kScanBlock / 64;
             }
             packets += take;
             block_packets += take;

@@ -513,7 +513,18 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
         // link the spans: continuity_counter[] as the reference would hold it at each span's start
         std::vector<uint8_t> cc_state(TS_PIDS, 0);  // last counter + 1, 0 = none yet
         std::vector<Line> linked;
+        // (spans with more PIDs than travel with the scan's one wait — garbage read as packets carries any PID —: the heads
+        // of ALL lists once more, as long as the longest, in one copy)
         std::vector<ts_cc_entry> big;
+        uint32_t max_ncc = 0;
+        for (uint32_t k = 0; k < nspans; k++)
+            if (so[k].attempt)
+                max_ncc = std::max(max_ncc, so[k].ncc);
+        if (max_ncc > TS_CC_OUT) {
+            big.resize((size_t)nspans * max_ncc);
+            TSCHK(ctx, hipMemcpy2D(big.data(), (size_t)max_ncc * sizeof(ts_cc_entry), ctx->d_cc_lists, (size_t)TS_PIDS * sizeof(ts_cc_entry),
+                                   (size_t)max_ncc * sizeof(ts_cc_entry), nspans, hipMemcpyDeviceToHost));
+        }
         ctx->errors.reserve(nlines);
         for (uint32_t k = 0; k < nspans; k++) {
             if (so[k].attempt == 0)
@@ -534,13 +545,7 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
                 check(pid, cc, l->key / 2);
                 cc_state[pid] = (uint8_t)(cc + 1u);
             }
-            const ts_cc_entry *list = so[k].cc;
-            if (so[k].ncc > TS_CC_OUT) {  // (more PIDs than travel with the scan's one wait: this span's list itself)
-                big.resize(so[k].ncc);
-                TSCHK(ctx, hipMemcpy(big.data(), ctx->d_cc_lists + (size_t)k * TS_PIDS, (size_t)so[k].ncc * sizeof(ts_cc_entry),
-                                     hipMemcpyDeviceToHost));
-                list = big.data();
-            }
+            const ts_cc_entry *list = so[k].ncc > TS_CC_OUT ? big.data() + (size_t)k * max_ncc : so[k].cc;
             for (uint32_t j = 0; j < so[k].ncc; j++)
                 check(list[j].pid, list[j].first_cc, so[k].base + list[j].first_rel + 1);
             for (uint32_t j = 0; j < so[k].ncc; j++)
