@@ -911,22 +911,38 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
     const int32_t *__restrict__ tile_E = p.tile_E_spec;
     double2 *__restrict__ seg_D = reinterpret_cast<double2 *>(p.seg_D);
     float4 x[U];
-    if (count)
+    // Everything this wave has in the vector-memory queue is IN ORDER (vmcnt), so the order of issue decides what a wait
+    // costs: the segment's speculated binade is requested IN FRONT of the segment's samples (it is there when they are),
+    // and the previous segment's pair is stored in front of both (a store behind the loads would have every wait for
+    // the samples wait for the store's acknowledgement as well; a binade requested at the top of the loop would have the
+    // wave stand still for a whole memory round trip with nothing of its own in flight).
+    int E_next = PAPR_EXACT_AMBIG;
+    if (count) {
+        E_next = tile_E[(p.seg_offset + seg0) >> 1];
+        asm volatile("" ::: "memory");
         load_seg(x, seg0);
+    }
+    double2 D_prev = make_double2(0.0, 0.0);
     for (uint32_t it = 0; it < count; it++) {
         const uint64_t seg = seg0 + (uint64_t)it * seg_stride;
         const uint64_t now = __builtin_amdgcn_s_memrealtime();  // (for the spill check)
-        const int E = __builtin_amdgcn_readfirstlane(tile_E[(p.seg_offset + seg) >> 1]);
+        const int E = __builtin_amdgcn_readfirstlane(E_next);
 #pragma unroll
         for (int r = 0; r < U; r++) {
             const int f = r * kWave + (int)lane;  // float4 slot within the segment, file order
             mine[xpose_slot(f >> 3, f & 7)] = x[r];
         }
+        if (it && lane == kWave - 1)
+            seg_D[p.seg_offset + seg - seg_stride] = D_prev;
+        asm volatile("" ::: "memory");
         // the registers are free again: the next segment's loads fly while this one is folded out of LDS — in front of
         // any spill store of this segment, so that a spill never stands between the wave and its next data
         // (same wave wrote and reads the buffer: LDS operations of one wave complete in order)
-        if (it + 1 < count)
+        if (it + 1 < count) {
+            E_next = tile_E[(p.seg_offset + seg + seg_stride) >> 1];
+            asm volatile("" ::: "memory");
             load_seg(x, seg + seg_stride);
+        }
         const bool valid = E != PAPR_EXACT_AMBIG;
         const double m0 = valid ? pow2_f64(E) : 0.0, ulp = valid ? pow2_f64(E - 52) : 0.0, m1 = m0 + ulp;
         double x0 = m0, x1 = m1;
@@ -986,10 +1002,10 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         // ---- the segment's pair ----
         const double d0 = x0 - m0, d1 = x1 - m1;  // exact: multiples of the ulp inside the binade (plain sums when no binade was given)
         sum += d0;
-        const double2 D = segment_pair(x0, x1, d0, d1, ulp);
-        if (lane == kWave - 1)
-            seg_D[p.seg_offset + seg] = D;
+        D_prev = segment_pair(x0, x1, d0, d1, ulp);
     }
+    if (count && lane == kWave - 1)
+        seg_D[p.seg_offset + seg0 + (uint64_t)(count - 1) * seg_stride] = D_prev;
     // remainder of the launch: binned here (its pass-1 part is folded in by papr_stats_finalize, its exact-sum part
     // travels raw in the sum program)
     if (blockIdx.x == gridDim.x - 1) {
