@@ -16,6 +16,7 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
     if (!ctx->loaded)
         return fail(ctx, PAPR_E_STATE, "papr_hip_analyze called before a shard was loaded");
     memset(res, 0, sizeof(*res));
+    ctx->trace.mark("enter");
     auto xfail = [&](int rc) {  // an exchange failed: its text is the detail
         if (x)
             snprintf(ctx->err, sizeof(ctx->err), "exchange: %s", papr_exchange_last_error(x));
@@ -85,7 +86,9 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
         const size_t nbytes = swept_program_bytes(ctx);
         if (!nbytes)
             return;  // the device-side gather overflowed its lists: assembled by the host afterwards
+        ctx->trace.mark("program_here");
         replay(ctx->h_program, nbytes, true);
+        ctx->trace.mark("replayed");
         replayed = true;
     };
     bool fused = false;
@@ -136,6 +139,7 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
     }
     if (rc)
         return rc;
+    ctx->trace.mark("stats_done");
     // ---- exchange 1 + host scalars ----
     papr_stats total = local;
     double before = 0.0;
@@ -151,6 +155,7 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
     if (L > cap || L > PAPR_HIP_MAX_LEVELS)
         return fail(ctx, PAPR_E_LIMIT, "%d levels exceed the caller's capacity (%d)", L, std::min(cap, PAPR_HIP_MAX_LEVELS));
     (void)papr_levels(&total, graph, nullptr, nullptr, levels, L);
+    ctx->trace.mark("levels");
     // ---- pass 2 (the stash recount when the sweep resolves) and, in exact-sum mode, the sequential sum ----
     bool counted = false;
     if (ctx->exact && std::isfinite(total.sum)) {
@@ -162,6 +167,7 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
             ctx->overlap_work = replay_when_ready;
         const int xrc = papr_hip_ccdf_exact(ctx, levels, L, counts_above, before, total.n, &program, &bytes);
         ctx->overlap_work = nullptr;
+        ctx->trace.mark("ccdf_exact");
         counted = xrc == PAPR_OK;
         if (!replayed) {
             if (x || xrc == PAPR_OK)
@@ -174,13 +180,13 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
             res->exact_sum = 1;
             std::vector<float> again;
             try {
-                again.resize((size_t)PAPR_HIP_MAX_LEVELS);
+                again.resize((size_t)std::min(std::max(papr_levels(&total, graph, nullptr, nullptr, nullptr, 0), 1), PAPR_HIP_MAX_LEVELS));
             } catch (...) {
                 return fail(ctx, PAPR_E_NOMEM, "out of host memory");
             }
-            const int L2 = papr_levels(&total, graph, &mean, &papr, again.data(), PAPR_HIP_MAX_LEVELS);
-            if (L2 > cap)
-                return fail(ctx, PAPR_E_LIMIT, "%d levels exceed the caller's capacity (%d)", L2, cap);
+            const int L2 = papr_levels(&total, graph, &mean, &papr, again.data(), (int)again.size());
+            if (L2 > cap || L2 > PAPR_HIP_MAX_LEVELS)
+                return fail(ctx, PAPR_E_LIMIT, "%d levels exceed the caller's capacity (%d)", L2, std::min(cap, PAPR_HIP_MAX_LEVELS));
             if (L2 != L || memcmp(again.data(), levels, (size_t)L * sizeof(float)) != 0) {
                 // the exact sum moved a float threshold (rare): count again — from the stash if the sweep holds
                 L = L2;
@@ -208,6 +214,8 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
     res->reason = swept_path ? ctx->sweep_info.reason : PAPR_SWEEP_NONE;
     res->exact_redo_tiles = ctx->sweep_info.exact_redo_tiles;
     res->band_log2 = ctx->sweep_info.band_log2;
+    ctx->trace.mark("leave");
+    ctx->trace.dump();
     return PAPR_OK;
 }
 

@@ -39,6 +39,7 @@
 
 #include "papr_kernels.h"
 #include "papr_device.h"
+#include "papr_stream.h"
 
 namespace {
 
@@ -142,14 +143,13 @@ __global__ __launch_bounds__(256) void papr_exact_block_sums(const double *__res
     for (int k = 0; k < 4; k++)
         if (t0 + k < ntiles)
             s += tile_sum_of<SEGD>(tws, t0 + k);
-    sh[threadIdx.x] = s;
+    // (any order will do: the prefixes only have to be good to `delta`)
+    const double w = wave_reduce_sum(s);
+    if ((threadIdx.x & (kWave - 1)) == 0)
+        sh[threadIdx.x / kWave] = w;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int k = 0; k < 256; k++)
-            tot += sh[k];
-        block_sums[blockIdx.x] = tot;
-    }
+    if (threadIdx.x == 0)
+        block_sums[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 // `spec` (one-read sweep): the binade each tile's pairs were built for; a tile that is provably inside ANOTHER binade
@@ -179,31 +179,21 @@ __global__ __launch_bounds__(256) void papr_exact_classify(const double *__restr
         s[k] = t0 + k < ntiles ? tile_sum_of<SEGD>(tws, t0 + k) : 0.0;
         tot += s[k];
     }
-    sh[threadIdx.x] = tot;
-    __syncthreads();
     // this block's prefix: `before` + the sums of the blocks in front of it, added up here (a few hundred values out of the
     // L2 — a scan kernel of its own between the block sums and this one was a launch and 5 us of one workgroup).  Any
-    // order will do: the prefix only has to be good to `delta`.
-    __shared__ double sh_pre[256];
+    // order will do: the prefix only has to be good to `delta` — wave reductions and a wave-level scan (one thread
+    // walking 512 LDS words was 8 of this kernel's 13 us).
+    __shared__ double sh_pre[256 / kWave];
     {
         double a = 0.0;
         for (uint32_t k = threadIdx.x; k < blockIdx.x; k += 256)
             a += block_prefix[k];
-        sh_pre[threadIdx.x] = a;
+        a = wave_reduce_sum(a);
+        if ((threadIdx.x & (kWave - 1)) == 0)
+            sh_pre[threadIdx.x / kWave] = a;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double run = before_dev ? *before_dev : before;
-        for (int k = 0; k < 256; k++)
-            run += sh_pre[k];
-        for (int k = 0; k < 256; k++) {
-            const double v = sh[k];
-            sh[k] = run;
-            run += v;
-        }
-    }
-    __syncthreads();
-    double P = sh[threadIdx.x];
+    const double ex = block_exclusive_scan<double, 256>(tot, sh, (double *)nullptr);  // (its barriers also publish sh_pre)
+    double P = ((before_dev ? *before_dev : before) + ((sh_pre[0] + sh_pre[1]) + (sh_pre[2] + sh_pre[3]))) + ex;
     for (int k = 0; k < 4; k++) {
         if (t0 + k >= ntiles)
             break;
@@ -455,57 +445,94 @@ __global__ __launch_bounds__(256) void papr_exact_capture_kernel(const float *__
 // ordered lists of the mixed groups and of their unprovable tiles
 // (a device function: every workgroup of papr_exact_pack_kernel makes the plan for itself, into LDS — a kernel of its own
 // for it was 13 us of one workgroup's dependent loops plus a launch in the exact-sum step's chain of small kernels)
+// Ordered compaction through a bit map in LDS: the flags are gathered with coalesced loads, several in flight per thread
+// (one thread walking its own range of the group table was twenty dependent trips to the L2 per pass, 25 us of the
+// kernel's 35), then every thread owns a few words of the map, counts them, and — behind one exclusive scan — writes out
+// the positions of its set bits in ascending order.
+constexpr uint32_t kPlanWords = 8192;  // 262 144 groups: a 512 GiB shard
+template <typename F>
+__device__ __forceinline__ uint32_t plan_compact(const uint32_t *bits, uint32_t nwords, uint32_t *sh_scan, uint32_t cap, F emit)
+{
+    const uint32_t per = (nwords + 255u) / 256u;
+    const uint32_t w0 = threadIdx.x * per, w1 = min(w0 + per, nwords);
+    uint32_t cnt = 0;
+    for (uint32_t w = w0; w < w1; w++)
+        cnt += (uint32_t)__popc(bits[w]);
+    uint32_t total = 0;
+    uint32_t pos = block_exclusive_scan<uint32_t, 256>(cnt, sh_scan, &total);
+    for (uint32_t w = w0; w < w1; w++) {
+        uint32_t m = bits[w];
+        while (m) {
+            const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
+            m &= m - 1u;
+            if (pos < cap)
+                emit(pos, w * 32u + b);
+            pos++;
+        }
+    }
+    return total;
+}
+
 __device__ __forceinline__ void exact_plan(const papr_exact_group *__restrict__ groups, uint64_t ngroups,
                                            const int32_t *__restrict__ tile_E, uint64_t ntiles, uint32_t *mixed_list,
                                            uint32_t cap_mixed, uint32_t *raw_list, uint32_t cap_raw, papr_exact_plan *out)
 {
     __shared__ uint32_t sh[256 / kWave];
-    uint32_t sh_total = 0;
-    auto ordered_offsets = [&](uint32_t mine) -> uint32_t {  // exclusive scan over the 256 threads, in order
-        return block_exclusive_scan<uint32_t, 256>(mine, sh, &sh_total);
-    };
-    // mixed groups
-    const uint64_t per_g = (ngroups + 255) / 256;
-    const uint64_t g0 = threadIdx.x * per_g, g1 = min(g0 + per_g, ngroups);
-    uint32_t cnt = 0;
-    for (uint64_t g = g0; g < g1; g++)
-        cnt += groups[g].E == PAPR_EXACT_AMBIG;
-    uint32_t pos = ordered_offsets(cnt);
-    const uint32_t nmixed_all = sh_total;
-    for (uint64_t g = g0; g < g1; g++)
-        if (groups[g].E == PAPR_EXACT_AMBIG) {
-            if (pos < cap_mixed)
-                mixed_list[pos] = (uint32_t)g;
-            pos++;
-        }
+    __shared__ uint32_t bits[kPlanWords];
+    const uint32_t t = threadIdx.x;
+    constexpr int CH = 8;
+    // ---- mixed groups ----
+    const uint64_t ng = min(ngroups, (uint64_t)kPlanWords * 32u);  // (beyond that: reported as overflow below)
+    const uint32_t gwords = (uint32_t)((ng + 31) / 32);
+    for (uint32_t w = t; w < gwords; w += 256)
+        bits[w] = 0;
+    __syncthreads();
+    for (uint64_t g0 = t; g0 < ng; g0 += 256ull * CH) {
+        int32_t e[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+            e[k] = g0 + 256ull * k < ng ? groups[g0 + 256ull * k].E : PAPR_EXACT_ZERO;
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+            if (e[k] == PAPR_EXACT_AMBIG) {
+                const uint64_t g = g0 + 256ull * k;
+                atomicOr(&bits[g >> 5], 1u << (g & 31));
+            }
+    }
+    __syncthreads();
+    const uint32_t nmixed_all = plan_compact(bits, gwords, sh, cap_mixed, [&](uint32_t pos, uint32_t g) { mixed_list[pos] = g; });
     const uint32_t nmixed = min(nmixed_all, cap_mixed);
     __syncthreads();
-    // their tiles that have to travel raw
-    const uint64_t items = (uint64_t)nmixed * PAPR_EXACT_GROUP_TILES;
-    const uint64_t per_t = (items + 255) / 256;
-    const uint64_t i0 = threadIdx.x * per_t, i1 = min(i0 + per_t, items);
-    auto tile_of = [&](uint64_t item) -> uint64_t {
+    // ---- their tiles that have to travel raw ----
+    const uint32_t items = nmixed * PAPR_EXACT_GROUP_TILES;  // (<= 256 * 128 bits: 1024 words)
+    const uint32_t iwords = (items + 31) / 32;
+    for (uint32_t w = t; w < iwords; w += 256)
+        bits[w] = 0;
+    __syncthreads();
+    auto tile_of = [&](uint32_t item) -> uint64_t {
         return (uint64_t)mixed_list[item / PAPR_EXACT_GROUP_TILES] * PAPR_EXACT_GROUP_TILES + item % PAPR_EXACT_GROUP_TILES;
     };
-    cnt = 0;
-    for (uint64_t it = i0; it < i1; it++) {
-        const uint64_t t = tile_of(it);
-        cnt += t < ntiles && tile_E[t] == PAPR_EXACT_AMBIG;
-    }
-    pos = ordered_offsets(cnt);
-    const uint32_t nraw_all = sh_total;
-    for (uint64_t it = i0; it < i1; it++) {
-        const uint64_t t = tile_of(it);
-        if (t < ntiles && tile_E[t] == PAPR_EXACT_AMBIG) {
-            if (pos < cap_raw)
-                raw_list[pos] = (uint32_t)t;
-            pos++;
+    for (uint32_t i0 = t; i0 < items; i0 += 256u * CH) {
+        int32_t e[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const uint32_t it = i0 + 256u * k;
+            const uint64_t tile = it < items ? tile_of(it) : ntiles;
+            e[k] = tile < ntiles ? tile_E[tile] : PAPR_EXACT_ZERO;
         }
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+            if (e[k] == PAPR_EXACT_AMBIG) {
+                const uint32_t it = i0 + 256u * k;
+                atomicOr(&bits[it >> 5], 1u << (it & 31));
+            }
     }
-    if (threadIdx.x == 0) {
+    __syncthreads();
+    const uint32_t nraw_all = plan_compact(bits, iwords, sh, cap_raw, [&](uint32_t pos, uint32_t it) { raw_list[pos] = (uint32_t)tile_of(it); });
+    if (t == 0) {
         out->nmixed = nmixed;
         out->nraw = min(nraw_all, cap_raw);
-        out->overflow = (nmixed_all > cap_mixed || nraw_all > cap_raw) ? 1u : 0u;
+        out->overflow = (nmixed_all > cap_mixed || nraw_all > cap_raw || ngroups > ng) ? 1u : 0u;
         out->pad = 0;
     }
     __syncthreads();

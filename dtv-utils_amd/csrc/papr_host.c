@@ -10,6 +10,7 @@
 #define _FILE_OFFSET_BITS 64
 #include <limits.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
@@ -77,6 +78,33 @@ static int to_int_x86(float x)
     return (int)x;
 }
 
+/* pow(10, x_j) of the level tables: the argument of level j depends on j and the mode alone (papr.c:138-141: (float)j / 10;
+ * papr.c:168-173: the float that accumulated j times 0.1), so the libm call is made once per j and process — the SAME
+ * call with the same argument the reference makes, its result kept; what changes from file to file is `* mean` and the
+ * rounding to float.  (301 pow() calls were 10 us of every -g step, made three times.) */
+#define PAPR_POW_CACHE 2048
+static double pow_cache[2][PAPR_POW_CACHE];
+static pthread_once_t pow_once = PTHREAD_ONCE_INIT;
+static void pow_fill(void)
+{
+    float tenth_db = 0.0f;
+    for (int j = 0; j < PAPR_POW_CACHE; j++) {
+        pow_cache[0][j] = pow(10, (double)((float)j / 10));
+        pow_cache[1][j] = pow(10, (double)(tenth_db / 10));
+        tenth_db = (float)(tenth_db + 0.1);
+    }
+}
+
+/* (internal: the runtime copies the tables to the device, where the kernels that speculate the level tables use the very
+ * same values — their tables then ARE the host's, given the same sum) */
+const double *papr_level_pow_table(int graph, int *count)
+{
+    pthread_once(&pow_once, pow_fill);
+    if (count)
+        *count = PAPR_POW_CACHE;
+    return pow_cache[graph ? 1 : 0];
+}
+
 int papr_levels(const papr_stats *total, int graph, double *mean_out, float *papr_out, float *levels, int cap)
 {
     const double mean = total->sum / (double)(long long)total->n;       /* papr.c:131 / 164 */
@@ -89,15 +117,16 @@ int papr_levels(const papr_stats *total, int graph, double *mean_out, float *pap
     const int nl = top < 0 ? 0 : top + 1;
     if (!levels)
         return nl;
+    pthread_once(&pow_once, pow_fill);
     if (graph) {
         float tenth_db = 0.0f;                                          /* papr.c:168-173 */
         for (int j = 0; j < nl && j < cap; j++) {
-            levels[j] = (float)(pow(10, (double)(tenth_db / 10)) * mean);
+            levels[j] = (float)((j < PAPR_POW_CACHE ? pow_cache[1][j] : pow(10, (double)(tenth_db / 10))) * mean);
             tenth_db = (float)(tenth_db + 0.1);
         }
     } else {
         for (int j = 0; j < nl && j < cap; j++)                         /* papr.c:138-141 */
-            levels[j] = (float)(pow(10, (double)((float)j / 10)) * mean);
+            levels[j] = (float)((j < PAPR_POW_CACHE ? pow_cache[0][j] : pow(10, (double)((float)j / 10))) * mean);
     }
     return nl;
 }
@@ -112,15 +141,17 @@ int papr_guess_levels(const papr_stats *est_total, int graph, double max_db, flo
     if (!(mean > 0) || mean > 3e38)
         return 0;
     int nl = 0;
+    pthread_once(&pow_once, pow_fill);
     if (graph) {
         float tenth_db = 0.0f;
         while (nl < cap && (double)tenth_db <= max_db) {
-            levels[nl++] = (float)(pow(10, (double)(tenth_db / 10)) * mean);
+            levels[nl] = (float)((nl < PAPR_POW_CACHE ? pow_cache[1][nl] : pow(10, (double)(tenth_db / 10))) * mean);
+            nl++;
             tenth_db = (float)(tenth_db + 0.1);
         }
     } else {
         while (nl < cap && (double)nl <= max_db) {
-            levels[nl] = (float)(pow(10, (double)((float)nl / 10)) * mean);
+            levels[nl] = (float)((nl < PAPR_POW_CACHE ? pow_cache[0][nl] : pow(10, (double)((float)nl / 10))) * mean);
             nl++;
         }
     }

@@ -200,6 +200,7 @@ void papr_launch_xpack(hipStream_t st, const unsigned long long *sweep_hist, uin
                        uint32_t nsegs, uint64_t seg_cap, const unsigned long long *gave_up, const unsigned long long *recount_hist,
                        uint32_t recount_words, const struct papr_guess_out *guess, const struct papr_true_out *tru,
                        unsigned long long *vec);
+#define PAPR_POW_TABLE 2048 /* entries per mode of the pow(10, x_j) table (papr_host.c: PAPR_POW_CACHE) */
 void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, const double *est_sq, uint32_t est_blocks,
                              uint64_t ngroups, uint64_t sampled, uint64_t nsamples, uint32_t ratio, int graph, float max_db,
                              float spoil, int band_override, uint32_t copies, int compact /* LUT form: two edges per cell */,
@@ -210,7 +211,8 @@ void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, c
                              uint32_t nrecs = 0, uint32_t my_rank = 0,
                              const double *spec_group_sums = nullptr /* exact-sum mode without peers: a SECOND workgroup scans the */,
                              uint64_t spec_ngroups = 0 /* estimate's per-group sums for the binade speculation meanwhile */,
-                             double spec_scale = 0.0, double *spec_group_prefix = nullptr);
+                             double spec_scale = 0.0, double *spec_group_prefix = nullptr,
+                             const double *pow_tab = nullptr /* [2][PAPR_POW_TABLE]: the host libm's pow(10, x_j) (papr_host.c) */);
 /* the product form of the sweep: papr_sweep_kernel = 512 threads x 8 loads per lane (64 KiB tiles), one persistent
  * workgroup per CU, 12 KiB of stash slice per wave; its variant id, and papr_sweep3_kernel's (exact-sum mode) */
 #define PAPR_SWEEP_THREADS 512
@@ -248,7 +250,8 @@ void papr_launch_true_table(hipStream_t st, const papr_partial *result, uint64_t
                             uint32_t soft_lds, uint32_t *table, uint32_t table_cap_words, papr_true_out *out_dev,
                             papr_true_out *out_host, unsigned long long *zero, uint32_t zero_words,
                             const unsigned long long *gave_up /* the sweep's give-up counter: non-zero = nothing to recount */,
-                            const unsigned long long *nsamples_dev = nullptr /* peers: the file's length, in device memory */);
+                            const unsigned long long *nsamples_dev = nullptr /* peers: the file's length, in device memory */,
+                            const double *pow_tab = nullptr /* as papr_launch_guess_bands */);
 void papr_sweep_prepare_device(void);
 #ifdef PAPR_MEASURE /* measure/papr_sweep_lab.hip: every other kernel form, behind the same variant ids */
 int papr_lab_sweep_variant(int variant);

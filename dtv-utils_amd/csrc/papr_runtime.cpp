@@ -664,6 +664,7 @@ void papr_hip_close(papr_hip_ctx *ctx)
     if (ctx->d_ambig) (void)hipFree(ctx->d_ambig);
     if (ctx->d_raw_store) (void)hipFree(ctx->d_raw_store);
     if (ctx->d_redo_store) (void)hipFree(ctx->d_redo_store);
+    if (ctx->d_pow_tab) (void)hipFree(ctx->d_pow_tab);
     if (ctx->d_true) (void)hipFree(ctx->d_true);
     if (ctx->d_result_copy) (void)hipFree(ctx->d_result_copy);
     if (ctx->h_true) (void)hipHostFree(ctx->h_true);

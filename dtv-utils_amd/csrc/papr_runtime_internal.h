@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <deque>
 #include <functional>
 #include <mutex>
@@ -142,7 +143,40 @@ struct SweepRun;
 
 }  // namespace papr_rt
 
+// PAPR_HOST_TRACE=1: wall-clock marks of one papr_hip_analyze call, printed to stderr when it returns (where the host's
+// share of a step goes; a measurement aid, off by default)
+struct HostTrace {
+    int on = -1, n = 0;
+    const char *what[32];
+    double t[32];
+    void mark(const char *w)
+    {
+        if (on < 0)
+            on = getenv("PAPR_HOST_TRACE") && atoi(getenv("PAPR_HOST_TRACE")) ? 1 : 0;
+        if (!on || n >= 32)
+            return;
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        what[n] = w;
+        t[n++] = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+    }
+    void dump()
+    {
+        if (on == 1 && n) {
+            char line[2048];
+            int k = snprintf(line, sizeof(line), "papr host trace (us since entry):");
+            for (int i = 0; i < n && k < (int)sizeof(line) - 64; i++)
+                k += snprintf(line + k, sizeof(line) - k, " %s %.1f", what[i], t[i] - t[0]);
+            fprintf(stderr, "%s\n", line);
+        }
+        n = 0;
+    }
+};
+
+extern "C" const double *papr_level_pow_table(int graph, int *count);
+
 struct papr_hip_ctx {
+    HostTrace trace;
     int device = -1;
     hipStream_t stream = nullptr;     // compute
     hipStream_t copy_stream = nullptr;
@@ -239,6 +273,7 @@ struct papr_hip_ctx {
     uint64_t sweep_seg_cap = 0;                  // floats per stash segment
     uint32_t sweep_nsegs = 0, sweep_nbins = 0, sweep_seg_off = 0;
     papr_guess_out *d_guess = nullptr, *h_guess = nullptr, *h_guess_dev = nullptr;  // papr_guess_bands_kernel's output (device; mapped host)
+    double *d_pow_tab = nullptr;  // [2][PAPR_POW_TABLE]: the host libm's pow(10, x_j) of the two level tables (papr_host.c)
     papr_true_out *d_true = nullptr, *h_true = nullptr, *h_true_dev = nullptr;     // papr_true_table_kernel's output
     papr_partial *d_result_copy = nullptr;  // the finalize kernel's record once more, for papr_true_table_kernel
     unsigned long long *h_sweep_hist_dev = nullptr;  // device address of h_sweep_hist

@@ -272,7 +272,8 @@ __global__ __launch_bounds__(1024) void papr_guess_bands_kernel(
     uint32_t copies, int compact, uint32_t soft_lds, uint32_t *__restrict__ table, uint32_t table_cap_words,
     papr_guess_out *__restrict__ out_dev, papr_guess_out *__restrict__ out_host, unsigned long long *__restrict__ zero,
     uint32_t zero_words, const papr_est_record *__restrict__ recs, uint32_t nrecs, uint32_t my_rank,
-    const double *__restrict__ spec_group_sums, uint64_t spec_ngroups, double spec_scale, double *__restrict__ spec_group_prefix)
+    const double *__restrict__ spec_group_sums, uint64_t spec_ngroups, double spec_scale, double *__restrict__ spec_group_prefix,
+    const double *__restrict__ pow_tab)
 {
     if (blockIdx.x == 1) {
         // exact-sum mode without peers: the scan of the estimate's per-group sums (first half of the binade speculation,
@@ -344,8 +345,10 @@ __global__ __launch_bounds__(1024) void papr_guess_bands_kernel(
     __syncthreads();
     uint32_t key = kNeverHi;
     if (t < nl && have) {
+        // (the host libm's pow(10, x_t), computed once per process, where the runtime has uploaded it: no pow() here)
         const float db = graph ? (float)t * 0.1f : (float)t;
-        const float lv = (float)(pow(10.0, (double)(db / 10.0f)) * mean) * spoil;
+        const double p10 = pow_tab && t < PAPR_POW_TABLE ? pow_tab[(graph ? PAPR_POW_TABLE : 0) + t] : pow(10.0, (double)(db / 10.0f));
+        const float lv = (float)(p10 * mean) * spoil;
         const uint32_t bits = __float_as_uint(lv);
         key = (lv != lv || bits >= 0x7F800000u) ? kNeverHi : (lv <= 0.0f ? (lv < 0.0f ? 0u : 1u) : bits + 1u);
         keys[t] = key;
@@ -487,13 +490,13 @@ void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, c
                              uint32_t table_cap_words, papr_guess_out *out_dev, papr_guess_out *out_host,
                              unsigned long long *zero, uint32_t zero_words, const papr_est_record *recs, uint32_t nrecs,
                              uint32_t my_rank, const double *spec_group_sums, uint64_t spec_ngroups, double spec_scale,
-                             double *spec_group_prefix)
+                             double *spec_group_prefix, const double *pow_tab)
 {
     const bool with_scan = spec_group_sums && spec_group_prefix && spec_ngroups;
     hipLaunchKernelGGL(papr_guess_bands_kernel, dim3(with_scan ? 2 : 1), dim3(1024), 0, st, est_partials, est_sq, est_blocks, ngroups,
                        sampled, nsamples, ratio, graph, max_db, spoil, band_override, copies, compact, soft_lds, table,
                        table_cap_words, out_dev, out_host, zero, zero_words, recs, nrecs, my_rank, spec_group_sums, spec_ngroups,
-                       spec_scale, spec_group_prefix);
+                       spec_scale, spec_group_prefix, pow_tab);
 }
 
 // =============================================================================
@@ -512,7 +515,8 @@ __global__ __launch_bounds__(1024) void papr_true_table_kernel(const papr_partia
                                                                 papr_true_out *__restrict__ out_host,
                                                                 unsigned long long *__restrict__ zero, uint32_t zero_words,
                                                                 const unsigned long long *__restrict__ gave_up,
-                                                                const unsigned long long *__restrict__ nsamples_dev)
+                                                                const unsigned long long *__restrict__ nsamples_dev,
+                                                                const double *__restrict__ pow_tab)
 {
     if (nsamples_dev)
         nsamples = *nsamples_dev;  // (peers: the file's length, known once the shards' records have been gathered)
@@ -537,7 +541,10 @@ __global__ __launch_bounds__(1024) void papr_true_table_kernel(const papr_partia
     float level = 0.f;
     uint32_t key = 0;
     if (ok && t < nl) {
-        if (graph) {
+        if (pow_tab && t < PAPR_POW_TABLE) {
+            // the host libm's own pow(10, x_t) (papr_host.c, uploaded once): this level IS papr_levels' level
+            level = (float)(pow_tab[(graph ? PAPR_POW_TABLE : 0) + t] * mean);
+        } else if (graph) {
             float tenth_db = 0.0f;  // papr.c:168-173: the float accumulation, step by step
             for (uint32_t j = 0; j < t; j++)
                 tenth_db = (float)(tenth_db + 0.1);
@@ -639,10 +646,10 @@ __global__ __launch_bounds__(1024) void papr_true_table_kernel(const papr_partia
 void papr_launch_true_table(hipStream_t st, const papr_partial *result, uint64_t nsamples, int graph, uint32_t copies,
                             uint32_t soft_lds, uint32_t *table, uint32_t table_cap_words, papr_true_out *out_dev,
                             papr_true_out *out_host, unsigned long long *zero, uint32_t zero_words,
-                            const unsigned long long *gave_up, const unsigned long long *nsamples_dev)
+                            const unsigned long long *gave_up, const unsigned long long *nsamples_dev, const double *pow_tab)
 {
     hipLaunchKernelGGL(papr_true_table_kernel, dim3(1), dim3(1024), 0, st, result, nsamples, graph, copies, soft_lds, table,
-                       table_cap_words, out_dev, out_host, zero, zero_words, gave_up, nsamples_dev);
+                       table_cap_words, out_dev, out_host, zero, zero_words, gave_up, nsamples_dev, pow_tab);
 }
 
 // =============================================================================

@@ -501,6 +501,16 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
             HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_true, sizeof(papr_true_out), hipHostMallocMapped));
             HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->h_true_dev, ctx->h_true, 0));
         }
+        if (!ctx->d_pow_tab) {  // the host libm's pow(10, x_j) of both level tables, for the two table-building kernels
+            int cnt = 0;
+            const double *t0 = papr_level_pow_table(0, &cnt), *t1 = papr_level_pow_table(1, &cnt);
+            static_assert(PAPR_POW_TABLE == 2048, "papr_host.c: PAPR_POW_CACHE");
+            if (cnt == PAPR_POW_TABLE) {
+                HIPCHK(ctx, hipMalloc((void **)&ctx->d_pow_tab, 2 * (size_t)PAPR_POW_TABLE * sizeof(double)));
+                HIPCHK(ctx, hipMemcpy(ctx->d_pow_tab, t0, (size_t)PAPR_POW_TABLE * sizeof(double), hipMemcpyHostToDevice));
+                HIPCHK(ctx, hipMemcpy(ctx->d_pow_tab + PAPR_POW_TABLE, t1, (size_t)PAPR_POW_TABLE * sizeof(double), hipMemcpyHostToDevice));
+            }
+        }
         if (!ctx->d_guess) {
             HIPCHK(ctx, hipMalloc((void **)&ctx->d_guess, sizeof(papr_guess_out)));
             HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_guess, sizeof(papr_guess_out), hipHostMallocMapped));
@@ -662,6 +672,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
             return leave(fail(ctx, PAPR_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)));   \
     } while (0)
     int rc = PAPR_OK;
+    ctx->trace.mark("prepared");
     time_begin_kernel(ctx, 4, ngroups * PAPR_ESTIMATE_TILE_SAMPLES * 8);
     papr_launch_estimate(ctx->stream, est_blocks, ctx->d_iq, ngroups, (uint32_t)ratio, est_partials, group_sums, ctx->d_est_sq);
     time_end_kernel(ctx);
@@ -683,7 +694,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
                             d_est_all, peers ? world : 0u, my_rank,
                             // (exact-sum mode, no peers: the scan half of the binade speculation runs beside the guess)
                             exact && !peers ? ctx->d_est_groups : nullptr, exact && !peers ? ngroups : 0, (double)ratio,
-                            exact && !peers ? ctx->d_est_groups + 4 * ctx->est_groups_cap : nullptr);
+                            exact && !peers ? ctx->d_est_groups + 4 * ctx->est_groups_cap : nullptr, ctx->d_pow_tab);
     XCHK(hipGetLastError());
     const uint32_t tail = (uint32_t)(ctx->n - ntiles * run.tile);
     papr_ccdf_params none{};
@@ -798,7 +809,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
     papr_launch_true_table(ctx->stream, peers ? d_total : ctx->d_result_copy, ctx->n, graph, kTrueCopies, true_soft, ctx->d_table,
                            std::max<uint32_t>(table_cap_words, 48 * 1024 / 4 + 8), ctx->d_true, ctx->h_true_dev, ctx->d_hist,
                            PAPR_TRUE_MAX_LEVELS + 1,  // (also clears the recount's bins)
-                           ctx->d_sweep_hist + kBinsMax + 2 * run.blocks, peers ? d_n_total : nullptr);
+                           ctx->d_sweep_hist + kBinsMax + 2 * run.blocks, peers ? d_n_total : nullptr, ctx->d_pow_tab);
     XCHK(hipGetLastError());
     {
         time_begin_kernel(ctx, 4, 0);
@@ -819,8 +830,11 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
             return leave(fail(ctx, rc, "exchange: %s", papr_exchange_last_error(x)));
         XCHK(hipMemcpyAsync(ctx->h_xvec, d_xvec_sum, (size_t)kXvecWords * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
+    ctx->trace.mark("queued");
     run_overlap_work(ctx);  // (exact-sum mode: the program's replay, while the recount runs)
+    ctx->trace.mark("overlap_done");
     XCHK(hipStreamSynchronize(ctx->stream));
+    ctx->trace.mark("synced");
 #undef XCHK
     ctx->program_pending = false;
     if (peers && exact)
