@@ -39,7 +39,7 @@ $(CSRC)/papr_sweep$(X): $(CSRC)/papr_sweep.hip $(CSRC)/papr_sweep_dev.h $(CSRC)/
 $(CSRC)/measure/papr_sweep_lab$(X): $(CSRC)/measure/papr_sweep_lab.hip $(CSRC)/papr_sweep_dev.h $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h $(CSRC)/papr_stream.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/papr_exact$(X): $(CSRC)/papr_exact.hip $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h $(CSRC)/papr_stream.h
+$(CSRC)/papr_exact$(X): $(CSRC)/papr_exact.hip $(CSRC)/papr_exact_format.h $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h $(CSRC)/papr_stream.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 RT_HDRS := $(CSRC)/papr_runtime_internal.h $(CSRC)/papr_kernels.h $(CSRC)/papr_exact_format.h include/papr_hip.h include/papr_exchange.h include/papr_hip_measure.h include/papr_synth.h

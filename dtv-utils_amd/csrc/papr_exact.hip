@@ -39,6 +39,7 @@
 
 #include "papr_kernels.h"
 #include "papr_device.h"
+#include "papr_exact_format.h"
 #include "papr_stream.h"
 
 namespace {
@@ -46,6 +47,10 @@ namespace {
 constexpr int kTilesPerBlock = 1024;  // classification workgroup: 256 threads x 4 tiles
 constexpr int kSegF4 = PAPR_EXACT_SEG_SAMPLES / 2;  // float4 slots per segment (512)
 constexpr int kRows = kSegF4 / kWave;               // 16-byte loads per lane per segment (8)
+constexpr int kRunSamples = 16, kTileRuns = PAPR_EXACT_TILE_SAMPLES / kRunSamples;  // (papr_exact_format.h: PAPR_XF_RUN_SAMPLES)
+constexpr size_t kRawRecBytes = 8 + 8 * (size_t)PAPR_EXACT_TILE_SAMPLES + 4 * kTileRuns + 16 * kTileRuns;  // sizeof(papr_exact_raw_rec)
+static_assert(kRawRecBytes == sizeof(papr_exact_raw_rec) && kRunSamples == PAPR_XF_RUN_SAMPLES && PAPR_EXACT_TILE_SAMPLES == PAPR_XF_TILE_SAMPLES,
+              "papr_exact_format.h");
 
 // LDS transpose without padding: the lane that owns run r (8 consecutive float4 = 16 samples)
 // finds its w-th float4 at slot r*8 + (w ^ ((r >> 1) & 7)).  Writers (8 consecutive lanes fill one
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(papr_exact_plan *_
                                                                unsigned char *__restrict__ out,
                                                                const uint32_t *__restrict__ count_src,
                                                                uint32_t *__restrict__ count_dst, uint64_t out_cap,
-                                                               uint32_t redo_cap)
+                                                               uint32_t redo_cap, const papr_exact_prefix_src prefix)
 {
     __shared__ uint32_t mixed_list[256], raw_list[512];  // (kCapMixed, kCapRaw)
     __shared__ papr_exact_plan plan_sh;
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(papr_exact_plan *_
     const size_t off_groups = 48;  // sizeof(papr_exact_header)
     const size_t off_mixed = off_groups + ngroups * 24;
     const size_t off_raw = off_mixed + (size_t)nmixed * 4616;
-    const size_t off_tail = off_raw + (size_t)nraw * 16392;
+    const size_t off_tail = off_raw + (size_t)nraw * kRawRecBytes;
     // a bounded destination (the slot of the in-stream program exchange): a program that does not fit leaves only its
     // header, marked — every rank sees that and all of them take the host path
     const bool fits = out_cap == 0 || off_tail + (size_t)tail_samples * 8 <= out_cap;
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(papr_exact_plan *_
         if (b >= nraw)
             return;
         const uint64_t t = raw_list[b];
-        unsigned char *rec = out + off_raw + (size_t)b * 16392;
+        unsigned char *rec = out + off_raw + (size_t)b * kRawRecBytes;
         if (threadIdx.x == 0)
             *reinterpret_cast<unsigned long long *>(rec) = t;
         // resident shard: the tile itself; re-streamed shard: the copy captured while its chunk was staged
@@ -617,6 +622,70 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(papr_exact_plan *_
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(rec + 8);
         for (uint32_t k = threadIdx.x; k < PAPR_EXACT_TILE_SAMPLES; k += 256)
             dst[k] = src[k];  // one IQ pair per 8-byte word
+        // ---- the tile's 16-sample runs, each with the pair of the binade the running sum is in when it gets there ----
+        // The sum changes binade somewhere in this tile (or may), so the tile as a whole has no pair — but 127 of its 128
+        // runs do, and an approximate prefix says for which binade: the host applies a run's pair when the sum is in
+        // that binade before and after it and adds the run sample by sample when not, so nothing here has to be
+        // exact but the pair itself (the additions themselves, from the binade's two canonical entry states).
+        int32_t *run_E = reinterpret_cast<int32_t *>(rec + 8 + 8 * PAPR_EXACT_TILE_SAMPLES);
+        double *run_D = reinterpret_cast<double *>(rec + 8 + 8 * PAPR_EXACT_TILE_SAMPLES + 4 * kTileRuns);
+        __shared__ double sh_red[256 / kWave];
+        double P_tile = 0.0;
+        if (prefix.kind) {
+            const uint64_t blk = t / kTilesPerBlock;
+            double a = 0.0;
+            for (uint64_t k = threadIdx.x; k < blk; k += 256)
+                a += prefix.block_sums[k];
+            for (uint64_t k = blk * kTilesPerBlock + threadIdx.x; k < t; k += 256)
+                a += prefix.kind == 1 ? tile_sum_of<true>(prefix.sums, k) : tile_sum_of<false>(prefix.sums, k);
+            a = wave_reduce_sum(a);
+            if ((threadIdx.x & (kWave - 1)) == 0)
+                sh_red[threadIdx.x / kWave] = a;
+            __syncthreads();
+            P_tile = (prefix.before_dev ? *prefix.before_dev : prefix.before) + ((sh_red[0] + sh_red[1]) + (sh_red[2] + sh_red[3]));
+        }
+        const uint32_t r = threadIdx.x;  // (threads 128 .. 255 only take part in the scan)
+        float pw[kRunSamples];
+        double s = 0.0;
+        if (r < kTileRuns) {
+            const float2 *q = reinterpret_cast<const float2 *>(src) + (size_t)r * kRunSamples;
+#pragma unroll
+            for (int k = 0; k < kRunSamples; k++) {
+                const float2 v = q[k];
+                pw[k] = power_of(v.x, v.y);
+                s += (double)pw[k];
+            }
+        }
+        __shared__ double sh_scan[256 / kWave];
+        const double P = P_tile + block_exclusive_scan<double, 256>(s, sh_scan, (double *)nullptr);
+        if (r < kTileRuns) {
+            int32_t cls = PAPR_EXACT_AMBIG;
+            double d0 = 0.0, d1 = 0.0;
+            if (s == 0.0) {
+                cls = PAPR_EXACT_ZERO;  // (sixteen + 0.0)
+            } else if (prefix.kind && s > 0.0 && s < 1.0e300 && P > 0.0 && P < 1.0e300) {
+                const int biased = (int)((__double_as_longlong(P) >> 52) & 0x7ff);
+                const int E = biased - 1023;
+                if (biased != 0 && E >= -960) {
+                    const double m0 = two_pow(E), m1 = m0 + two_pow(E - 52);
+                    double x0 = m0, x1 = m1;
+#pragma unroll
+                    for (int k = 0; k < kRunSamples; k++) {
+                        const double v = (double)pw[k];
+                        x0 += v;
+                        x1 += v;
+                    }
+                    if (x1 < 2.0 * m0) {  // both chains stayed inside the binade: one ulp throughout
+                        cls = E;
+                        d0 = x0 - m0;
+                        d1 = x1 - m1;
+                    }
+                }
+            }
+            run_E[r] = cls;
+            run_D[2 * r] = d0;
+            run_D[2 * r + 1] = d1;
+        }
         return;
     }
     // last workgroup: the tail samples and the header (layout of papr_exact_header)
@@ -628,7 +697,7 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(papr_exact_plan *_
         uint32_t *h32 = reinterpret_cast<uint32_t *>(out);
         unsigned long long *h64 = reinterpret_cast<unsigned long long *>(out);
         h32[0] = 0x31535850u;  // PAPR_EXACT_MAGIC
-        h32[1] = 1u;           // PAPR_EXACT_VERSION
+        h32[1] = 2u;           // PAPR_EXACT_VERSION
         h64[1] = nsamples;
         h64[2] = ntiles;
         h64[3] = ngroups;
@@ -861,13 +930,13 @@ void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint
                             const void *tail_src, uint64_t nsamples, uint32_t tail_samples, uint32_t *mixed_list,
                             uint32_t cap_mixed, uint32_t *raw_list, uint32_t cap_raw, papr_exact_plan *plan,
                             unsigned char *out_mapped, const uint32_t *count_src, uint32_t *count_dst, uint64_t out_cap,
-                            uint32_t redo_cap)
+                            uint32_t redo_cap, papr_exact_prefix_src prefix)
 {
     const uint32_t group_blocks = (uint32_t)std::min<uint64_t>(64, (ngroups * 3 + 255) / 256 + 1);
     hipLaunchKernelGGL(papr_exact_pack_kernel, dim3(group_blocks + cap_mixed + cap_raw + 1), dim3(256), 0, st, plan,
                        mixed_list, raw_list, groups, ngroups, tile_E, ntiles, (const double *)seg_D, (const float *)data,
                        (const float *)raw_store, (const float *)tail_src, nsamples, tail_samples, group_blocks, cap_mixed,
-                       cap_raw, out_mapped, count_src, count_dst, out_cap, redo_cap);
+                       cap_raw, out_mapped, count_src, count_dst, out_cap, redo_cap, prefix);
 }
 
 // ---- the in-stream exchange of the sum programs (peers, single-wait step) ------------------------------------------
@@ -884,7 +953,7 @@ __global__ __launch_bounds__(1024) void papr_exact_programs_to_host_kernel(const
     const unsigned long long *h64 = reinterpret_cast<const unsigned long long *>(src);
     uint64_t used = 48;
     if (h32[0] == 0x31535850u && h32[11] == 0) {
-        const uint64_t want = 48 + h64[3] * 24 + (uint64_t)h32[9] * 4616 + (uint64_t)h32[10] * 16392 + (uint64_t)h32[8] * 8;
+        const uint64_t want = 48 + h64[3] * 24 + (uint64_t)h32[9] * 4616 + (uint64_t)h32[10] * kRawRecBytes + (uint64_t)h32[8] * 8;
         if (want <= slot_bytes)
             used = want;
     }

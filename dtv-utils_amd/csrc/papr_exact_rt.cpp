@@ -283,7 +283,8 @@ int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total, const do
     papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, ctx->d_iq, nullptr,
                            ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, ctx->n, tail, ctx->d_mixed_list, kCapMixed,
                            ctx->d_raw_list, kCapRaw, ctx->d_plan, program_dev, ctx->d_redo + kCapRedo, ctx->h_redo_count_dev,
-                           slot_dev ? slot_cap : 0, kCapRedo);
+                           slot_dev ? slot_cap : 0, kCapRedo,
+                           papr_exact_prefix_src{(const double *)ctx->d_seg_D, ctx->d_block_sums, before_dev, before, 1});
     HIPCHK(ctx, hipGetLastError());
     if (slot_dev)
         return PAPR_OK;  // (the caller gathers the ranks' slots and records the event behind that)
@@ -483,6 +484,9 @@ int assemble_program_on_host(papr_hip_ctx *ctx, const void **program, size_t *by
     for (size_t k = 0; k < raw.size(); k++) {
         papr_exact_raw_rec *r = (papr_exact_raw_rec *)(ctx->h_program + off_raw + k * sizeof(papr_exact_raw_rec));
         r->tile = raw[k];
+        for (int q = 0; q < PAPR_XF_TILE_RUNS; q++)  // (no pairs for the runs: the host adds the whole tile sample by sample)
+            r->run_E[q] = PAPR_XF_AMBIG;
+        memset(r->run_D, 0, sizeof(r->run_D));
         HIPCHK(ctx, hipMemcpyAsync(r->iq, ctx->d_iq + 2 * raw[k] * PAPR_EXACT_TILE_SAMPLES, PAPR_EXACT_TILE_SAMPLES * 8,
                                    hipMemcpyDeviceToHost, ctx->stream));
     }

@@ -75,6 +75,16 @@ struct papr_exact_plan {
     uint32_t nmixed, nraw, overflow, pad;
 };
 
+/* what the pack kernel needs to place a raw tile's 16-sample runs in their binades (an approximate prefix at the tile):
+ * the sums papr_exact_classify scanned — kind 1: seg_D (two (D0, D1) per tile), kind 2: pass 1's four wave sums per tile,
+ * 0: none (the runs then travel without pairs) — its block sums, and what lies in front of the shard */
+struct papr_exact_prefix_src {
+    const double *sums;
+    const double *block_sums;
+    const double *before_dev;
+    double before;
+    int kind;
+};
 void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint64_t ngroups, const int32_t *tile_E,
                             uint64_t ntiles, const void *seg_D, const void *data, const void *raw_store,
                             const void *tail_src, uint64_t nsamples, uint32_t tail_samples, uint32_t *mixed_list,
@@ -83,7 +93,8 @@ void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint
                             const uint32_t *count_src = nullptr /* one word (the redo count) copied along ... */,
                             uint32_t *count_dst = nullptr /* ... to mapped host memory */,
                             uint64_t out_cap = 0 /* bytes `out` can hold (0: as much as any program needs) */,
-                            uint32_t redo_cap = 0 /* with count_src: a larger count marks the program as not final */);
+                            uint32_t redo_cap = 0 /* with count_src: a larger count marks the program as not final */,
+                            papr_exact_prefix_src prefix = papr_exact_prefix_src{nullptr, nullptr, nullptr, 0.0, 0});
 /* peers: the used bytes of every rank's program slot (device, after the all-gather) into the same slot of mapped host memory */
 struct papr_xprog_layout {
     uint32_t world, pad;

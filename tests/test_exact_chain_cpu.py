@@ -10,7 +10,8 @@ import pytest
 
 TILE, SEG, GROUP = 2048, 1024, 128
 AMBIG, ZERO = -(2 ** 31), -(2 ** 31) + 1
-MAGIC, VERSION = 0x31535850, 1
+MAGIC, VERSION = 0x31535850, 2
+RUN = 16
 
 
 def powers(iq):
@@ -43,7 +44,36 @@ def classify(P, s, delta):
     return AMBIG
 
 
-def build_program(iq, before=0.0, force_mixed=True):
+def run_records(pw_tile, P_tile, runs):
+    """What the pack kernel appends to a raw tile: per 16-sample run the binade of an APPROXIMATE prefix and the pair for
+    it (none where the canonical chains leave the binade).  runs: "model" as the device does it, "none" no pairs at all,
+    "wrong" every pair's binade off by one (the host must notice and add those runs sample by sample)."""
+    es, ds = [], []
+    P = P_tile
+    for r in range(TILE // RUN):
+        pw = pw_tile[r * RUN:(r + 1) * RUN]
+        s = float(np.sum(pw.astype(np.float64)))
+        e, d = AMBIG, (0.0, 0.0)
+        if s == 0.0:
+            e = ZERO
+        elif runs != "none" and s > 0 and np.isfinite(s) and P > 0 and np.isfinite(P):
+            E = int(np.floor(np.log2(P)))
+            if 2.0 ** E > P:
+                E -= 1
+            if E >= -960:
+                if runs == "wrong":
+                    E += 1
+                m0 = np.float64(2.0) ** E
+                d0, d1 = seg_pair(pw, E)
+                if (m0 + np.float64(2.0) ** (E - 52)) + d1 < 2 * m0:
+                    e, d = E, (d0, d1)
+        es.append(e)
+        ds.append(d)
+        P += s
+    return struct.pack(f"<{TILE // RUN}i", *es) + b"".join(struct.pack("<dd", *d) for d in ds)
+
+
+def build_program(iq, before=0.0, force_mixed=True, runs="model"):
     """Every group is emitted as 'mixed' (per-tile classes + per-segment pairs), unsafe tiles raw."""
     pw = powers(iq)
     n = pw.size
@@ -51,9 +81,10 @@ def build_program(iq, before=0.0, force_mixed=True):
     ngroups = (ntiles + GROUP - 1) // GROUP
     delta = max(1e-6, 8 * n * 2.0 ** -53)
     tile_sums = [float(np.sum(pw[t * TILE:(t + 1) * TILE].astype(np.float64))) for t in range(ntiles)]
-    P, cls = before, []
+    P, cls, prefix = before, [], []
     for s in tile_sums:
         cls.append(classify(P, s, delta))
+        prefix.append(P * (1 + 3e-7))    # (the device's prefix is only good to `delta`)
         P += s
     groups = b"".join(struct.pack("<iidd", AMBIG, 0, 0.0, 0.0) for _ in range(ngroups))
     mixed, raw = b"", b""
@@ -69,7 +100,8 @@ def build_program(iq, before=0.0, force_mixed=True):
                 else:
                     pairs.append((0.0, 0.0))
             if t < ntiles and te[j] == AMBIG:
-                raw += struct.pack("<Q", t) + iq[2 * t * TILE:2 * (t + 1) * TILE].tobytes()
+                raw += (struct.pack("<Q", t) + iq[2 * t * TILE:2 * (t + 1) * TILE].tobytes() +
+                        run_records(pw[t * TILE:(t + 1) * TILE], prefix[t], runs))
                 nraw += 1
         mixed += struct.pack("<Q", g) + struct.pack(f"<{GROUP}i", *te) + b"".join(struct.pack("<dd", *p) for p in pairs)
     header = struct.pack("<IIQQQIIII", MAGIC, VERSION, n, ntiles, ngroups, tail, ngroups, nraw, 0)
@@ -92,6 +124,9 @@ def test_chain_replays_the_sequential_sum(pkg, orc, case):
     prog, nraw = build_program(iq)
     want = orc.run_mem(iq, False)["sum"]
     assert pkg.exact_chain([prog]) == want
+    # raw tiles without run pairs, and with pairs built for the wrong binade: the same sum, sample by sample
+    assert pkg.exact_chain([build_program(iq, runs="none")[0]]) == want
+    assert pkg.exact_chain([build_program(iq, runs="wrong")[0]]) == want
     if case not in ("short", "growing"):        # (a sum that doubles every few tiles is mostly binade crossings)
         assert nraw < (n // TILE) // 2          # most tiles really go through the pair path
     # two shards: the second program is built knowing only the accurate sum of the first
