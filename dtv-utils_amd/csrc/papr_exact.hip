@@ -48,7 +48,7 @@ constexpr int kTilesPerBlock = 1024;  // classification workgroup: 256 threads x
 constexpr int kSegF4 = PAPR_EXACT_SEG_SAMPLES / 2;  // float4 slots per segment (512)
 constexpr int kRows = kSegF4 / kWave;               // 16-byte loads per lane per segment (8)
 constexpr int kRunSamples = 16, kTileRuns = PAPR_EXACT_TILE_SAMPLES / kRunSamples;  // (papr_exact_format.h: PAPR_XF_RUN_SAMPLES)
-constexpr size_t kRawRecBytes = 8 + 8 * (size_t)PAPR_EXACT_TILE_SAMPLES + 4 * kTileRuns + 16 * kTileRuns;  // sizeof(papr_exact_raw_rec)
+constexpr size_t kRawRecBytes = 8 + 4 * (size_t)PAPR_EXACT_TILE_SAMPLES + 4 * kTileRuns + 16 * kTileRuns;  // sizeof(papr_exact_raw_rec)
 static_assert(kRawRecBytes == sizeof(papr_exact_raw_rec) && kRunSamples == PAPR_XF_RUN_SAMPLES && PAPR_EXACT_TILE_SAMPLES == PAPR_XF_TILE_SAMPLES,
               "papr_exact_format.h");
 
@@ -362,7 +362,8 @@ __global__ __launch_bounds__(BLOCK) void papr_exact_seg_kernel(const float4 *__r
 // group collapses to one pair, otherwise it is flagged for tile-by-tile handling on the host.
 __global__ __launch_bounds__(256) void papr_exact_group_kernel(const int32_t *__restrict__ tile_E, uint64_t ntiles,
                                                                 const double2 *__restrict__ seg_D, uint64_t ngroups,
-                                                                papr_exact_group *__restrict__ out)
+                                                                papr_exact_group *__restrict__ out,
+                                                                papr_exact_group *__restrict__ program_table)
 {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const uint64_t g = (uint64_t)blockIdx.x * (256 / kWave) + wave;
@@ -402,8 +403,11 @@ __global__ __launch_bounds__(256) void papr_exact_group_kernel(const int32_t *__
             rec.D1 = f.d1;
         }
     }
-    if (lane == 0)
+    if (lane == 0) {
         out[g] = rec;
+        if (program_table)  // (the sum program's group table, where the program is gathered: 24 bytes the pack kernel need not copy)
+            program_table[g] = rec;
+    }
 }
 
 // ---- re-streamed shards: keep the unprovable tiles while their chunk is on the device ------------
@@ -619,16 +623,14 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(papr_exact_plan *_
         // resident shard: the tile itself; re-streamed shard: the copy captured while its chunk was staged
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(
             raw_store ? raw_store + 2 * (uint64_t)b * PAPR_EXACT_TILE_SAMPLES : data + 2 * t * PAPR_EXACT_TILE_SAMPLES);
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(rec + 8);
-        for (uint32_t k = threadIdx.x; k < PAPR_EXACT_TILE_SAMPLES; k += 256)
-            dst[k] = src[k];  // one IQ pair per 8-byte word
+        float *dst_pw = reinterpret_cast<float *>(rec + 8);  // (the powers travel, not the samples: half the bytes)
         // ---- the tile's 16-sample runs, each with the pair of the binade the running sum is in when it gets there ----
         // The sum changes binade somewhere in this tile (or may), so the tile as a whole has no pair — but 127 of its 128
         // runs do, and an approximate prefix says for which binade: the host applies a run's pair when the sum is in
         // that binade before and after it and adds the run sample by sample when not, so nothing here has to be
         // exact but the pair itself (the additions themselves, from the binade's two canonical entry states).
-        int32_t *run_E = reinterpret_cast<int32_t *>(rec + 8 + 8 * PAPR_EXACT_TILE_SAMPLES);
-        double *run_D = reinterpret_cast<double *>(rec + 8 + 8 * PAPR_EXACT_TILE_SAMPLES + 4 * kTileRuns);
+        int32_t *run_E = reinterpret_cast<int32_t *>(rec + 8 + 4 * PAPR_EXACT_TILE_SAMPLES);
+        double *run_D = reinterpret_cast<double *>(rec + 8 + 4 * PAPR_EXACT_TILE_SAMPLES + 4 * kTileRuns);
         __shared__ double sh_red[256 / kWave];
         double P_tile = 0.0;
         if (prefix.kind) {
@@ -644,15 +646,22 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(papr_exact_plan *_
             __syncthreads();
             P_tile = (prefix.before_dev ? *prefix.before_dev : prefix.before) + ((sh_red[0] + sh_red[1]) + (sh_red[2] + sh_red[3]));
         }
+        // (coalesced: thread t takes samples t, t + 256, ...; the run's owner reads its sixteen powers back out of LDS)
+        __shared__ float sh_pw[PAPR_EXACT_TILE_SAMPLES];
+        for (uint32_t k = threadIdx.x; k < PAPR_EXACT_TILE_SAMPLES; k += 256) {
+            const float2 v = reinterpret_cast<const float2 *>(src)[k];
+            const float p = power_of(v.x, v.y);
+            sh_pw[k] = p;
+            dst_pw[k] = p;
+        }
+        __syncthreads();
         const uint32_t r = threadIdx.x;  // (threads 128 .. 255 only take part in the scan)
         float pw[kRunSamples];
         double s = 0.0;
         if (r < kTileRuns) {
-            const float2 *q = reinterpret_cast<const float2 *>(src) + (size_t)r * kRunSamples;
 #pragma unroll
             for (int k = 0; k < kRunSamples; k++) {
-                const float2 v = q[k];
-                pw[k] = power_of(v.x, v.y);
+                pw[k] = sh_pw[r * kRunSamples + k];
                 s += (double)pw[k];
             }
         }
@@ -697,7 +706,7 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(papr_exact_plan *_
         uint32_t *h32 = reinterpret_cast<uint32_t *>(out);
         unsigned long long *h64 = reinterpret_cast<unsigned long long *>(out);
         h32[0] = 0x31535850u;  // PAPR_EXACT_MAGIC
-        h32[1] = 2u;           // PAPR_EXACT_VERSION
+        h32[1] = 3u;           // PAPR_EXACT_VERSION
         h64[1] = nsamples;
         h64[2] = ntiles;
         h64[3] = ngroups;
@@ -916,13 +925,13 @@ void papr_launch_exact_segments_ccdf(hipStream_t st, int blocks, const void *dat
 }
 
 void papr_launch_exact_groups(hipStream_t st, const int32_t *tile_E, uint64_t ntiles, const void *seg_D,
-                              uint64_t ngroups, papr_exact_group *out)
+                              uint64_t ngroups, papr_exact_group *out, unsigned char *program)
 {
     if (ngroups == 0)
         return;
     const uint32_t nb = (uint32_t)((ngroups + 3) / 4);
     hipLaunchKernelGGL(papr_exact_group_kernel, dim3(nb), dim3(256), 0, st, tile_E, ntiles, (const double2 *)seg_D,
-                       ngroups, out);
+                       ngroups, out, program ? reinterpret_cast<papr_exact_group *>(program + 48) : nullptr);
 }
 
 void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint64_t ngroups, const int32_t *tile_E,
@@ -932,7 +941,8 @@ void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint
                             unsigned char *out_mapped, const uint32_t *count_src, uint32_t *count_dst, uint64_t out_cap,
                             uint32_t redo_cap, papr_exact_prefix_src prefix)
 {
-    const uint32_t group_blocks = (uint32_t)std::min<uint64_t>(64, (ngroups * 3 + 255) / 256 + 1);
+    // (groups_in_place: papr_launch_exact_groups already wrote the group table into this program)
+    const uint32_t group_blocks = prefix.groups_in_place ? 0u : (uint32_t)std::min<uint64_t>(64, (ngroups * 3 + 255) / 256 + 1);
     hipLaunchKernelGGL(papr_exact_pack_kernel, dim3(group_blocks + cap_mixed + cap_raw + 1), dim3(256), 0, st, plan,
                        mixed_list, raw_list, groups, ngroups, tile_E, ntiles, (const double *)seg_D, (const float *)data,
                        (const float *)raw_store, (const float *)tail_src, nsamples, tail_samples, group_blocks, cap_mixed,

@@ -5,7 +5,7 @@
  *   papr_exact_header
  *   ngroups x { int32 E; int32 pad; double D0, D1 }          group table
  *   nmixed  x { uint64 group; int32 tile_E[128]; double seg_D[256][2] }
- *   nraw    x { uint64 tile; float iq[2 * 2048];              tiles the running sum changes binade in (or may):
+ *   nraw    x { uint64 tile; float pw[2048];                  tiles the running sum changes binade in (or may): the powers,
  *               int32 run_E[128]; double run_D[128][2] }      every 16-sample run with the pair of ITS binade — the host
  *                                                             applies it when the sum is in that binade before and after,
  *                                                             and adds the run sample by sample otherwise
@@ -17,7 +17,7 @@
 #include <stdint.h>
 
 #define PAPR_EXACT_MAGIC 0x31535850u /* "PXS1" */
-#define PAPR_EXACT_VERSION 2u
+#define PAPR_EXACT_VERSION 3u
 
 #define PAPR_XF_TILE_SAMPLES 2048
 #define PAPR_XF_GROUP_TILES 128
@@ -50,7 +50,7 @@ typedef struct papr_exact_mixed_rec {
 
 typedef struct papr_exact_raw_rec {
     uint64_t tile;
-    float iq[2 * PAPR_XF_TILE_SAMPLES];
+    float pw[PAPR_XF_TILE_SAMPLES];      /* fl(fl(I*I) + fl(Q*Q)) of every sample, as the device (and papr.c:103) forms it */
     int32_t run_E[PAPR_XF_TILE_RUNS];    /* the binade run_D was built for; PAPR_XF_AMBIG: none; PAPR_XF_ZERO: sixteen +0 powers */
     double run_D[PAPR_XF_TILE_RUNS][2];
 } papr_exact_raw_rec;

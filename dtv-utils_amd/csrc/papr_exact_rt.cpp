@@ -278,13 +278,17 @@ int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total, const do
                                      nullptr, before_dev, n_total_dev, ctx->n);
     papr_launch_exact_redo(ctx->stream, ctx->num_cus, ctx->d_iq, ctx->d_tile_E, ctx->d_seg_D, ctx->d_redo,
                            ctx->d_redo + kCapRedo, kCapRedo, 0);
-    papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups);
+    // (the group table goes straight into the program — unless the program's destination is a bounded slot it might not fit)
+    const bool table_fits = !slot_dev || 48 + ngroups * sizeof(papr_exact_group_rec) <= slot_cap;
+    papr_launch_exact_groups(ctx->stream, ctx->d_tile_E, ntiles, ctx->d_seg_D, ngroups, ctx->d_groups,
+                             table_fits ? program_dev : nullptr);
     time_end(ctx);
     papr_launch_exact_pack(ctx->stream, ctx->d_groups, ngroups, ctx->d_tile_E, ntiles, ctx->d_seg_D, ctx->d_iq, nullptr,
                            ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES, ctx->n, tail, ctx->d_mixed_list, kCapMixed,
                            ctx->d_raw_list, kCapRaw, ctx->d_plan, program_dev, ctx->d_redo + kCapRedo, ctx->h_redo_count_dev,
                            slot_dev ? slot_cap : 0, kCapRedo,
-                           papr_exact_prefix_src{(const double *)ctx->d_seg_D, ctx->d_block_sums, before_dev, before, 1});
+                           papr_exact_prefix_src{(const double *)ctx->d_seg_D, ctx->d_block_sums, before_dev, before, 1,
+                                                 table_fits ? 1 : 0});
     HIPCHK(ctx, hipGetLastError());
     if (slot_dev)
         return PAPR_OK;  // (the caller gathers the ranks' slots and records the event behind that)
@@ -487,14 +491,31 @@ int assemble_program_on_host(papr_hip_ctx *ctx, const void **program, size_t *by
         for (int q = 0; q < PAPR_XF_TILE_RUNS; q++)  // (no pairs for the runs: the host adds the whole tile sample by sample)
             r->run_E[q] = PAPR_XF_AMBIG;
         memset(r->run_D, 0, sizeof(r->run_D));
-        HIPCHK(ctx, hipMemcpyAsync(r->iq, ctx->d_iq + 2 * raw[k] * PAPR_EXACT_TILE_SAMPLES, PAPR_EXACT_TILE_SAMPLES * 8,
-                                   hipMemcpyDeviceToHost, ctx->stream));
     }
+    // (the samples of those tiles, then their powers as the device forms them: separate roundings, no FMA — this file is
+    // compiled with -ffp-contract=off)
+    std::vector<float> iq;
+    try {
+        iq.resize(raw.size() * 2 * (size_t)PAPR_EXACT_TILE_SAMPLES);
+    } catch (...) {
+        return fail(ctx, PAPR_E_NOMEM, "out of host memory");
+    }
+    for (size_t k = 0; k < raw.size(); k++)
+        HIPCHK(ctx, hipMemcpyAsync(iq.data() + k * 2 * (size_t)PAPR_EXACT_TILE_SAMPLES, ctx->d_iq + 2 * raw[k] * PAPR_EXACT_TILE_SAMPLES,
+                                   PAPR_EXACT_TILE_SAMPLES * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (tail)
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_program + off_tail, ctx->d_iq + 2 * ntiles * PAPR_EXACT_TILE_SAMPLES,
                                    (size_t)tail * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (!raw.empty() || tail)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k < raw.size(); k++) {
+        papr_exact_raw_rec *r = (papr_exact_raw_rec *)(ctx->h_program + off_raw + k * sizeof(papr_exact_raw_rec));
+        const float *q = iq.data() + k * 2 * (size_t)PAPR_EXACT_TILE_SAMPLES;
+        for (int j = 0; j < PAPR_EXACT_TILE_SAMPLES; j++) {
+            const volatile float re2 = q[2 * j] * q[2 * j], im2 = q[2 * j + 1] * q[2 * j + 1];
+            r->pw[j] = re2 + im2;
+        }
+    }
     papr_exact_header h;
     memset(&h, 0, sizeof(h));
     h.magic = PAPR_EXACT_MAGIC;

@@ -315,6 +315,25 @@ static void add_raw(double *S, const float *iq, uint64_t nsamples)
  * (all terms are >= 0: every intermediate sum then is, too), sample by sample where it is not (the run the sum crosses
  * in, a run the device's approximate prefix placed in the wrong binade, a run with no pair at all): ~128 steps and one
  * or two 16-sample runs per tile instead of 2048 dependent additions. */
+/* The program was written by the GPU: none of it is in this core's caches, and a raw record's run table (2.5 KB, 11 KB
+ * from the next one) is too short a stream for the hardware prefetcher — walked cold it cost 40 dependent trips to
+ * memory per tile, more than its arithmetic.  So the table of the NEXT raw record is requested, all lines at once, while
+ * the chain is busy in front of it. */
+static void prefetch_run_table(const papr_exact_raw_rec *r)
+{
+    const char *p = (const char *)r->run_E, *e = (const char *)(r->run_D + PAPR_XF_TILE_RUNS);
+    for (; p < e; p += 64)
+        __builtin_prefetch(p, 0, 3);
+}
+
+static void add_raw_powers(double *S, const float *pw, uint64_t nsamples)
+{
+    double acc = *S;
+    for (uint64_t k = 0; k < nsamples; k++)
+        acc += pw[k]; /* the device's fl(fl(I*I) + fl(Q*Q)), as papr.c:103 forms it */
+    *S = acc;
+}
+
 static void add_raw_tile(double *S, const papr_exact_raw_rec *r)
 {
     for (int k = 0; k < PAPR_XF_TILE_RUNS; k++) {
@@ -330,7 +349,7 @@ static void add_raw_tile(double *S, const papr_exact_raw_rec *r)
                 continue;
             }
         }
-        add_raw(S, r->iq + 2 * PAPR_XF_RUN_SAMPLES * k, PAPR_XF_RUN_SAMPLES);
+        add_raw_powers(S, r->pw + PAPR_XF_RUN_SAMPLES * k, PAPR_XF_RUN_SAMPLES);
     }
 }
 
@@ -368,6 +387,8 @@ int papr_exact_chain(const void *const *programs, const size_t *bytes, int nprog
         const papr_exact_raw_rec *raw = (const papr_exact_raw_rec *)(mixed + h.nmixed);
         const float *tail = (const float *)(raw + h.nraw);
         uint32_t mi = 0, ri = 0;
+        if (h.nraw)
+            prefetch_run_table(&raw[0]);
         for (uint64_t g = 0; g < h.ngroups; g++) {
             const papr_exact_group_rec *gr = &groups[g];
             if (gr->E == PAPR_XF_ZERO)
@@ -390,6 +411,8 @@ int papr_exact_chain(const void *const *programs, const size_t *bytes, int nprog
                 if (e == PAPR_XF_AMBIG) {
                     if (ri >= h.nraw || raw[ri].tile != tile)
                         return PAPR_E_ARG;
+                    if (ri + 1 < h.nraw)
+                        prefetch_run_table(&raw[ri + 1]);
                     add_raw_tile(&S, &raw[ri++]);
                 } else if (apply_pair(&S, e, m->seg_D[2 * j][0], m->seg_D[2 * j][1]) ||
                            apply_pair(&S, e, m->seg_D[2 * j + 1][0], m->seg_D[2 * j + 1][1])) {

@@ -84,6 +84,7 @@ struct papr_exact_prefix_src {
     const double *before_dev;
     double before;
     int kind;
+    int groups_in_place; /* the program's group table was written by papr_launch_exact_groups (its `program` argument) */
 };
 void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint64_t ngroups, const int32_t *tile_E,
                             uint64_t ntiles, const void *seg_D, const void *data, const void *raw_store,
@@ -94,7 +95,7 @@ void papr_launch_exact_pack(hipStream_t st, const papr_exact_group *groups, uint
                             uint32_t *count_dst = nullptr /* ... to mapped host memory */,
                             uint64_t out_cap = 0 /* bytes `out` can hold (0: as much as any program needs) */,
                             uint32_t redo_cap = 0 /* with count_src: a larger count marks the program as not final */,
-                            papr_exact_prefix_src prefix = papr_exact_prefix_src{nullptr, nullptr, nullptr, 0.0, 0});
+                            papr_exact_prefix_src prefix = papr_exact_prefix_src{nullptr, nullptr, nullptr, 0.0, 0, 0});
 /* peers: the used bytes of every rank's program slot (device, after the all-gather) into the same slot of mapped host memory */
 struct papr_xprog_layout {
     uint32_t world, pad;
@@ -134,7 +135,8 @@ void papr_launch_exact_segments_ccdf(hipStream_t st, int blocks, const void *dat
                                      const uint32_t *table, const papr_ccdf_params &P, size_t lds_table_bytes,
                                      unsigned long long *ghist);
 void papr_launch_exact_groups(hipStream_t st, const int32_t *tile_E, uint64_t ntiles, const void *seg_D,
-                              uint64_t ngroups, papr_exact_group *out);
+                              uint64_t ngroups, papr_exact_group *out,
+                              unsigned char *program = nullptr /* also into this sum program's group table */);
 
 int papr_variant_geometry(int variant, int *block, int *unroll); /* 0, or -1 for an unknown variant */
 void papr_launch_stats(hipStream_t st, int variant, int blocks, bool nt, const void *data, uint64_t ntiles,

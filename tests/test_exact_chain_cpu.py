@@ -10,7 +10,7 @@ import pytest
 
 TILE, SEG, GROUP = 2048, 1024, 128
 AMBIG, ZERO = -(2 ** 31), -(2 ** 31) + 1
-MAGIC, VERSION = 0x31535850, 2
+MAGIC, VERSION = 0x31535850, 3
 RUN = 16
 
 
@@ -100,7 +100,7 @@ def build_program(iq, before=0.0, force_mixed=True, runs="model"):
                 else:
                     pairs.append((0.0, 0.0))
             if t < ntiles and te[j] == AMBIG:
-                raw += (struct.pack("<Q", t) + iq[2 * t * TILE:2 * (t + 1) * TILE].tobytes() +
+                raw += (struct.pack("<Q", t) + pw[t * TILE:(t + 1) * TILE].tobytes() +
                         run_records(pw[t * TILE:(t + 1) * TILE], prefix[t], runs))
                 nraw += 1
         mixed += struct.pack("<Q", g) + struct.pack(f"<{GROUP}i", *te) + b"".join(struct.pack("<dd", *p) for p in pairs)

@@ -29,7 +29,7 @@ def _raw_program(floats: np.ndarray) -> bytes:
     header + zero groups + the samples, added one by one by papr_exact_chain exactly as papr.c:104 adds them."""
     n = floats.size // 2
     assert n < 2048, "helper for small shards: everything travels as the < 1 tile tail"
-    header = struct.pack("<IIQQQIIII", 0x31535850, 1, n, 0, 0, n, 0, 0, 0)
+    header = struct.pack("<IIQQQIIII", 0x31535850, 3, n, 0, 0, n, 0, 0, 0)
     return header + floats.astype(np.float32).tobytes()
 
 
