@@ -200,7 +200,9 @@ int read_samples(const FileSrc &fs, uint64_t s0, uint64_t cnt, unsigned char *ds
     return PAPR_OK;
 }
 
-int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage)
+// The pinned staging buffers of the ingest (and the pipeline's depth).  Touches nothing else of the context: papr_hip_open_ex
+// runs it beside the creation of the streams when the caller says a file load follows.
+hipError_t make_staging(papr_hip_ctx *ctx)
 {
     if (!ctx->stage_bytes) {
         size_t mb = (size_t)std::max(1, env_int("PAPR_CHUNK_MB", 16));
@@ -208,20 +210,40 @@ int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage)
         if (!ctx->stage_bytes)
             ctx->stage_bytes = kChunkAlign * 8;
     }
+    if (!ctx->num_buf) {
+        // the depth of the pipeline: num_buf pinned buffers, read_ahead of them being filled by the readers while the
+        // others' copies are queued on the engine
+        ctx->num_buf = std::min(kMaxBuf, std::max(2, env_int("PAPR_STAGE_BUFS", kNumBufDefault)));
+        ctx->read_ahead = std::min(ctx->num_buf - 1, std::max(1, env_int("PAPR_READ_AHEAD", std::max(kReadAheadDefault, ctx->num_buf / 2))));
+    }
     const CpuSet near_gpu = numa_cpus_of_device(ctx->device);
-    for (int b = 0; b < kNumBuf; b++) {
-        if (!ctx->h_stage[b]) {
-            // pinned pages are placed where they are first touched: do that on the GPU's NUMA node
-            cpu_set_t before;
-            const bool moved = near_gpu.valid && sched_getaffinity(0, sizeof(before), &before) == 0 &&
-                               sched_setaffinity(0, sizeof(near_gpu.set), &near_gpu.set) == 0;
-            const hipError_t e = hipHostMalloc(&ctx->h_stage[b], ctx->stage_bytes, hipHostMallocDefault);
-            if (e == hipSuccess && moved)
-                memset(ctx->h_stage[b], 0, ctx->stage_bytes);
-            if (moved)
-                (void)sched_setaffinity(0, sizeof(before), &before);
-            HIPCHK(ctx, e);
+    // pinned pages are placed where they are first touched: do that on the GPU's NUMA node.  (Pinning 16 MiB takes ~3 ms
+    // and the driver takes the buffers one at a time: four threads making one each were no faster.)
+    cpu_set_t before;
+    const bool moved = near_gpu.valid && sched_getaffinity(0, sizeof(before), &before) == 0 &&
+                       sched_setaffinity(0, sizeof(near_gpu.set), &near_gpu.set) == 0;
+    hipError_t e = hipSuccess;
+    for (int b = 0; b < ctx->num_buf && e == hipSuccess; b++) {
+        if (ctx->h_stage[b])
+            continue;
+        e = hipHostMalloc(&ctx->h_stage[b], ctx->stage_bytes, hipHostMallocDefault);
+        if (e == hipSuccess && moved)
+            memset(ctx->h_stage[b], 0, ctx->stage_bytes);
+        if (e == hipSuccess && hipHostGetDevicePointer(&ctx->h_stage_dev[b], ctx->h_stage[b], 0) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->h_stage_dev[b] = nullptr;  // (not mapped: this buffer goes through the copy engine)
         }
+    }
+    if (moved)
+        (void)sched_setaffinity(0, sizeof(before), &before);
+    return e;
+}
+
+int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage)
+{
+    HIPCHK(ctx, make_staging(ctx));
+    const CpuSet near_gpu = numa_cpus_of_device(ctx->device);
+    for (int b = 0; b < ctx->num_buf; b++) {
         if (!ctx->ev_copy[b])
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_copy[b], hipEventDisableTiming));
         if (!ctx->ev_kernel[b])
@@ -231,6 +253,7 @@ int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage)
     }
     if (need_device_stage && !ctx->d_tail)
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_tail, PAPR_TILE_SAMPLES_MAX * 8));
+    ctx->trace.mark("ei_bufs");
     if (!ctx->pool) {
         int n = env_int("PAPR_READ_THREADS", 0);
         if (n <= 0)
@@ -239,6 +262,7 @@ int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage)
         ctx->pool = new ReaderPool(n, near_gpu);
         ctx->ingest_numa = near_gpu.valid;
     }
+    ctx->trace.mark("ei_pool");
     return PAPR_OK;
 }
 
@@ -256,6 +280,7 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
     const bool to_resident = (pass == PASS_LOAD_STATS);
     const bool timed = (pass == PASS_LOAD_STATS || pass == PASS_STREAM_STATS);
     double t_mark = now_s();
+    ctx->trace.mark("sf_opened");
     rc = ensure_ingest(ctx, !to_resident);
     if (rc) {
         close_file_src(&fs);
@@ -289,12 +314,12 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
     UringReader *ring = fs.fd_direct >= 0 && ctx->uring && !ctx->uring->dead() ? ctx->uring : nullptr;  // (a ring that failed once: threads)
     if (timed)
         ctx->ingest.io_uring = ring ? 1 : 0;
-    // queue the slices of chunk c for the reader threads (buffer c % kNumBuf must be free)
+    // queue the slices of chunk c for the reader threads (buffer c % num_buf must be free)
     std::vector<ReadBatch> batches(nchunks);
     const FileSrc *fsp = &fs;
     const uint64_t file_first = ctx->file_first, shard_n = ctx->n;
     auto submit_chunk = [&](uint64_t c) {
-        const int b = (int)(c % kNumBuf);
+        const int b = (int)(c % ctx->num_buf);
         const uint64_t s0 = c * chunk_samples;
         const uint64_t cnt = std::min(chunk_samples, shard_n - s0);
         unsigned char *hbuf = (unsigned char *)ctx->h_stage[b];
@@ -329,17 +354,31 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
     }
     // copy chunk c (already read into its pinned buffer) to the device and run the pass kernel on it
     auto process_chunk = [&](uint64_t c) -> int {
-        const int b = (int)(c % kNumBuf);
+        const int b = (int)(c % ctx->num_buf);
         const uint64_t s0 = c * chunk_samples;
         const uint64_t cnt = std::min(chunk_samples, ctx->n - s0);
         unsigned char *hbuf = (unsigned char *)ctx->h_stage[b];
         float *dst = to_resident ? ctx->d_iq + 2 * s0 : (float *)ctx->d_stage[b];
         hipStream_t cs = two_copy_streams && (c & 1) ? ctx->copy_stream2 : ctx->copy_stream;
-        if (!to_resident && c >= (uint64_t)kNumBuf)
+        if (!to_resident && c >= (uint64_t)ctx->num_buf)
             HIPCHK(ctx, hipStreamWaitEvent(cs, ctx->ev_kernel[b], 0));
-        HIPCHK(ctx, hipMemcpyAsync(dst, hbuf, cnt * 8, hipMemcpyHostToDevice, cs));
+        // the H2D leg: a kernel pulls the staging buffer over the link (PAPR_H2D=copy: the copy engine does)
+        if (ctx->h2d_pull < 0) {
+            const char *form = getenv("PAPR_H2D");
+            ctx->h2d_pull = form && !strcmp(form, "copy") ? 0 : 1;
+        }
+        if (ctx->h2d_pull && ctx->h_stage_dev[b] && (cnt * 8) % 8 == 0 && ((uintptr_t)dst & 15) == 0) {
+            papr_launch_pull(cs, ctx->h_stage_dev[b], dst, cnt * 8);
+            HIPCHK(ctx, hipGetLastError());
+        } else {
+            HIPCHK(ctx, hipMemcpyAsync(dst, hbuf, cnt * 8, hipMemcpyHostToDevice, cs));
+        }
+        if (c == 0)
+            ctx->trace.mark("c0_copy_queued");
         HIPCHK(ctx, hipEventRecord(ctx->ev_copy[b], cs));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copy[b], 0));
+        if (c == 0)
+            ctx->trace.mark("c0_events");
         const bool last = (c + 1 == nchunks);
         int prc = PAPR_OK;
         switch (pass) {
@@ -378,7 +417,8 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
     };
 
     uint64_t submitted = 0;
-    for (; submitted < std::min<uint64_t>(kReadAhead, nchunks); submitted++)
+    ctx->trace.mark("sf_loop");
+    for (; submitted < std::min<uint64_t>((uint64_t)ctx->read_ahead, nchunks); submitted++)
         submit_chunk(submitted);
     for (uint64_t c = 0; c < nchunks && rc == PAPR_OK; c++) {
         t_mark = now_s();
@@ -388,7 +428,7 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
             // (the reader threads patch the phantom sample's partner in read_samples: here it is done once per chunk)
             const uint64_t s0 = c * chunk_samples, cnt = std::min(chunk_samples, shard_n - s0);
             if (!rc && fs.odd && file_first + s0 + cnt == fs.nsamples && cnt > 0)
-                memcpy((unsigned char *)ctx->h_stage[c % kNumBuf] + cnt * 8 - 4, &fs.partner, 4);
+                memcpy((unsigned char *)ctx->h_stage[c % ctx->num_buf] + cnt * 8 - 4, &fs.partner, 4);
         } else if (ctx->pool->wait(&batches[c])) {
             rc = fail(ctx, PAPR_E_IO, "read error in %s", ctx->path.c_str());
         }
@@ -396,16 +436,20 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
             ctx->ingest.read_s += now_s() - t_mark;
         if (rc)
             break;
+        if (c == 0)
+            ctx->trace.mark("sf_chunk0_read");
         t_mark = now_s();
         rc = process_chunk(c);
         if (timed)
             ctx->ingest.issue_s += now_s() - t_mark;
-        // read ahead: the next unread chunk goes into the buffer used kNumBuf chunks earlier, which is
+        if (c < 2)
+            ctx->trace.mark(c ? "sf_chunk1_issued" : "sf_chunk0_issued");
+        // read ahead: the next unread chunk goes into the buffer used num_buf chunks earlier, which is
         // free once that chunk's H2D copy has completed
         if (rc == PAPR_OK && submitted < nchunks) {
             t_mark = now_s();
-            if (submitted >= (uint64_t)kNumBuf &&
-                hipEventSynchronize(ctx->ev_copy[submitted % kNumBuf]) != hipSuccess)
+            if (submitted >= (uint64_t)ctx->num_buf &&
+                hipEventSynchronize(ctx->ev_copy[submitted % ctx->num_buf]) != hipSuccess)
                 rc = fail(ctx, PAPR_E_HIP, "hipEventSynchronize failed while recycling a staging buffer");
             if (timed)
                 ctx->ingest.buffer_wait_s += now_s() - t_mark;
@@ -413,6 +457,7 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
                 submit_chunk(submitted++);
         }
     }
+    ctx->trace.mark("sf_loop_end");
     // on any failure let the reads already queued finish before `fs` and the batches go away
     for (uint64_t k = 0; k < submitted; k++) {
         if (ring)
@@ -435,6 +480,7 @@ int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, u
         return PAPR_E_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const double t_begin = now_s();
+    ctx->trace.mark("load_enter");
     memset(&ctx->ingest, 0, sizeof(ctx->ingest));
     papr_hip_sweep_info &info = ctx->sweep_info;
     info.swept = info.resolved = 0;
@@ -460,6 +506,7 @@ int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, u
         if (rc)
             return rc;
     }
+    ctx->trace.mark("shard_alloc");
     ctx->path = path;
     ctx->file_first = first_sample;
     ctx->n = nsamples;
@@ -511,6 +558,7 @@ int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, u
     // pass 1 (or the whole sweep) rides along with the ingest
     size_t records = 0;
     rc = stream_file(ctx, fits ? PASS_LOAD_STATS : PASS_STREAM_STATS, nullptr, &records);
+    ctx->trace.mark("streamed");
     const bool swept = ctx->ingest_run != nullptr;
     ctx->ingest_run = nullptr;
     if (rc) {
@@ -572,6 +620,8 @@ int load_file_impl(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, u
     ctx->have_file_stats = true;
     ctx->exact_valid = ctx->exact;  // the per-tile sums are on the device, resident shard or not
     ctx->ingest.total_s = now_s() - t_begin;
+    ctx->trace.mark("load_leave");
+    ctx->trace.dump();
     return PAPR_OK;
 }
 
@@ -672,7 +722,7 @@ static int papr_hip_estimate_file_impl(papr_hip_ctx *ctx, const char *path, uint
     const FileSrc *fsp = &fs;
     auto submit = [&](uint64_t bi) {
         const uint64_t g0 = bi * per_batch, g1 = std::min(ngroups, g0 + per_batch);
-        unsigned char *hbuf = (unsigned char *)ctx->h_stage[bi % kNumBuf];
+        unsigned char *hbuf = (unsigned char *)ctx->h_stage[bi % ctx->num_buf];
         const int nthr = ctx->reader_threads;
         const uint64_t per = (g1 - g0 + nthr - 1) / nthr;
         for (int t = 0; t < nthr; t++) {
@@ -700,7 +750,7 @@ static int papr_hip_estimate_file_impl(papr_hip_ctx *ctx, const char *path, uint
             rc = fail(ctx, PAPR_E_IO, "read error in %s", path);
             break;
         }
-        const int b = (int)(bi % kNumBuf);
+        const int b = (int)(bi % ctx->num_buf);
         const uint64_t cnt = std::min(ngroups, (bi + 1) * per_batch) - bi * per_batch;
         if (hipMemcpyAsync(ctx->d_stage[b], ctx->h_stage[b], cnt * kTileBytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
             rc = fail(ctx, PAPR_E_HIP, "hipMemcpyAsync of the estimate sample failed");
@@ -715,8 +765,8 @@ static int papr_hip_estimate_file_impl(papr_hip_ctx *ctx, const char *path, uint
         if (hipEventRecord(ctx->ev_copy[b], ctx->stream) != hipSuccess)
             rc = fail(ctx, PAPR_E_HIP, "hipEventRecord failed");
         if (rc == PAPR_OK && submitted < nbatches) {
-            // the buffer about to be refilled was consumed kNumBuf batches ago
-            if (submitted >= (uint64_t)kNumBuf && hipEventSynchronize(ctx->ev_copy[submitted % kNumBuf]) != hipSuccess)
+            // the buffer about to be refilled was consumed num_buf batches ago
+            if (submitted >= (uint64_t)ctx->num_buf && hipEventSynchronize(ctx->ev_copy[submitted % ctx->num_buf]) != hipSuccess)
                 rc = fail(ctx, PAPR_E_HIP, "hipEventSynchronize failed while recycling a staging buffer");
             if (rc == PAPR_OK)
                 submit(submitted++);

@@ -151,6 +151,8 @@ void papr_launch_stats_finalize(hipStream_t st, const void *tail, uint32_t tail_
                                 uint32_t copy_words = 0);
 void papr_launch_first_nan(hipStream_t st, int blocks, const void *data, uint64_t nsamples, uint64_t base_index,
                            unsigned long long *key);
+// bytes (a multiple of 8) from mapped pinned host memory to device memory, by a kernel (the ingest's H2D leg)
+void papr_launch_pull(hipStream_t st, const void *src_mapped, void *dst, uint64_t bytes);
 void papr_launch_ccdf(hipStream_t st, int variant, int blocks, bool nt, bool lut, size_t lds_bytes, const void *data,
                       uint64_t ntiles, int map, const void *tail, uint32_t tail_samples, const uint32_t *table,
                       const papr_ccdf_params &P, unsigned long long *ghist);

@@ -362,6 +362,40 @@ void papr_launch_stats_finalize(hipStream_t st, const void *tail, uint32_t tail_
                        tail_base_index, partials, npartials, result, result_dev, copy_src, copy_dst, copy_words);
 }
 
+// The ingest's H2D leg as a kernel: a few workgroups pull a pinned staging buffer (mapped host memory) over the link with
+// 16-byte nontemporal loads, four in flight per lane, and store it where the copy engine would have put it.  48 workgroups
+// move 16 MiB chunks at 55-56 GB/s where hipMemcpyAsync gives 52-54 (17 us between two of its copies, 7 ms for its queue
+// at the first one: tools/zero_copy_probe.hip); more workgroups are SLOWER (256: 50 GB/s) — the link wants few, long streams.
+typedef unsigned int papr_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void papr_pull_kernel(const papr_u32x4 *__restrict__ src, papr_u32x4 *__restrict__ dst, uint64_t n16,
+                                                        const unsigned long long *__restrict__ src8, unsigned long long *__restrict__ dst8,
+                                                        uint32_t has_word)
+{
+    constexpr int U = 4;
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * U;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 * U + threadIdx.x; i < n16; i += stride) {
+        papr_u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            v[u] = i + u * 256 < n16 ? __builtin_nontemporal_load(src + i + u * 256) : papr_u32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (i + u * 256 < n16)
+                __builtin_nontemporal_store(v[u], dst + i + u * 256);
+    }
+    if (has_word && blockIdx.x == 0 && threadIdx.x == 0)
+        *dst8 = *src8;  // (an odd number of samples: the last 8 bytes)
+}
+
+void papr_launch_pull(hipStream_t st, const void *src_mapped, void *dst, uint64_t bytes)
+{
+    const uint64_t n16 = bytes / 16;
+    const uint32_t has_word = (bytes & 8) ? 1u : 0u;
+    hipLaunchKernelGGL(papr_pull_kernel, dim3(48), dim3(256), 0, st, (const papr_u32x4 *)src_mapped, (papr_u32x4 *)dst, n16,
+                       (const unsigned long long *)((const char *)src_mapped + n16 * 16),
+                       (unsigned long long *)((char *)dst + n16 * 16), has_word);
+}
+
 void papr_launch_first_nan(hipStream_t st, int blocks, const void *data, uint64_t nsamples, uint64_t base_index,
                            unsigned long long *key)
 {

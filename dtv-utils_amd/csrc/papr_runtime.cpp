@@ -636,7 +636,7 @@ void papr_hip_close(papr_hip_ctx *ctx)
         (void)hipEventDestroy(t.a);
         (void)hipEventDestroy(t.b);
     }
-    for (int b = 0; b < kNumBuf; b++) {
+    for (int b = 0; b < kMaxBuf; b++) {
         if (ctx->h_stage[b]) (void)hipHostFree(ctx->h_stage[b]);
         if (ctx->d_stage[b]) (void)hipFree(ctx->d_stage[b]);
         if (ctx->ev_copy[b]) (void)hipEventDestroy(ctx->ev_copy[b]);

@@ -40,8 +40,9 @@
 namespace papr_rt {
 
 constexpr uint64_t kChunkAlign = PAPR_TILE_SAMPLES_MAX;  // chunk boundaries stay tile aligned for every variant
-constexpr int kNumBuf = 4;      // pinned staging buffers
-constexpr int kReadAhead = 2;   // chunks being read ahead of the one being copied
+constexpr int kMaxBuf = 16;     // pinned staging buffers: capacity (ctx->num_buf of them are used: PAPR_STAGE_BUFS)
+constexpr int kNumBufDefault = 4;
+constexpr int kReadAheadDefault = 2;   // chunks being read ahead of the one being copied (ctx->read_ahead: PAPR_READ_AHEAD)
 constexpr int kMaxTimed = 4096;
 
 // ---- a tiny pool of file-reader threads -------------------------------------
@@ -216,10 +217,13 @@ struct papr_hip_ctx {
     float *d_tail = nullptr;               // streaming mode: the last chunk's sub-tile tail
 
     // ingest
-    void *h_stage[papr_rt::kNumBuf] = {};
-    void *d_stage[papr_rt::kNumBuf] = {};
-    hipEvent_t ev_copy[papr_rt::kNumBuf] = {};
-    hipEvent_t ev_kernel[papr_rt::kNumBuf] = {};
+    int num_buf = 0, read_ahead = 0;       // (set by ensure_ingest)
+    void *h_stage[papr_rt::kMaxBuf] = {};
+    void *h_stage_dev[papr_rt::kMaxBuf] = {};  // the same buffers as the device sees them (mapped); null: not mapped
+    int h2d_pull = -1;                         // the H2D leg by papr_pull_kernel (1) or by hipMemcpyAsync (0): PAPR_H2D
+    void *d_stage[papr_rt::kMaxBuf] = {};
+    hipEvent_t ev_copy[papr_rt::kMaxBuf] = {};
+    hipEvent_t ev_kernel[papr_rt::kMaxBuf] = {};
     // exact-sum one-read step: the sum program is complete (ev_program) before the stash recount has run; work the caller
     // wants done in that window (papr_hip_analyze: the exchange / replay of the programs) — run once, by the next call
     // that is about to wait for the stream (run_overlap_work), then cleared
@@ -474,6 +478,7 @@ void close_file_src(FileSrc *fs);
 int open_file_src(papr_hip_ctx *ctx, const char *path, FileSrc *fs);
 int read_samples(const FileSrc &fs, uint64_t s0, uint64_t cnt, unsigned char *dst);
 int ensure_ingest(papr_hip_ctx *ctx, bool need_device_stage);
+hipError_t make_staging(papr_hip_ctx *ctx);
 int launch_fused_chunk(papr_hip_ctx *ctx, const CcdfPlan &plan, const float *chunk, uint64_t s0, uint64_t cnt, bool last);
 int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uint64_t n_shard, uint64_t n_launch,
                   SweepRun *run, int *reason);
