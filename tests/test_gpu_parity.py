@@ -82,17 +82,24 @@ def test_cli_over_rccl_reproduces_reference_stdout(pkg, manifest, exact):
     of ONE rank, which still executes every collective): every fixture, both tables, stdout / stderr / exit status the
     reference's; and the step did cross RCCL (PAPR_STATS says which transport carried it)."""
     env = dict(os.environ, PAPR_GPUS="1", PAPR_XCH="rccl", PAPR_EXACT_SUM=exact, PAPR_STATS="1")
-    for name in golden_names():
-        for graph in (False, True):
-            args = [pkg.CLI_PATH] + (["-g"] if graph else []) + [golden_path(name)]
-            p = subprocess.run(args, capture_output=True, env=env)
-            want = manifest[name]["graph" if graph else "default"]
-            assert p.returncode == want["rc"], (name, graph, p.stderr)
-            assert p.stdout == golden_text(name, graph), (name, graph, p.stderr)
-            lines = p.stderr.decode().splitlines()
-            stats = json.loads(lines[-1])
-            assert "\n".join(lines[:-1]) + ("\n" if len(lines) > 1 else "") == want["stderr"]
-            assert stats["exchange"] == "rccl" and stats["gpus"] == 1
+
+    def one(case):
+        name, graph = case
+        args = [pkg.CLI_PATH] + (["-g"] if graph else []) + [golden_path(name)]
+        return case, subprocess.run(args, capture_output=True, env=env)
+
+    # (a run is ~2 s of communicator set-up around milliseconds of work: six of them side by side on the one GPU)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        results = list(pool.map(one, [(name, graph) for name in golden_names() for graph in (False, True)]))
+    for (name, graph), p in results:
+        want = manifest[name]["graph" if graph else "default"]
+        assert p.returncode == want["rc"], (name, graph, p.stderr)
+        assert p.stdout == golden_text(name, graph), (name, graph, p.stderr)
+        lines = p.stderr.decode().splitlines()
+        stats = json.loads(lines[-1])
+        assert "\n".join(lines[:-1]) + ("\n" if len(lines) > 1 else "") == want["stderr"]
+        assert stats["exchange"] == "rccl" and stats["gpus"] == 1
 
 
 @pytest.mark.parametrize("shards", [2, 3, 8])
