@@ -75,25 +75,31 @@ struct ts_scan_params {
     uint32_t attempt;
     uint32_t explicit_entry;    // 1: a launch of ONE span from `entry` (the state the chain arrived with)
     uint32_t quirk_events;      // 0: every read-boundary quirk goes to the walker (tests)
+    uint32_t slots;             // 1: the slot form of the scan kernel (512 threads, per-slot tables: two spans per CU); 0: full tables
+    uint32_t slot_limit;        // slots a span may hand out (0: all it has; tests: few, to force the full-table scan)
+    uint32_t abort_walks;       // full-table form: a span that has walked this often, more than once per 3072 packets, stops the
+                                // scan (every span) — the stream is damaged and the slot form's (0: never)
     ts_walk_state entry;
     ts_wg_entry *lists;         // per span: up to TS_PIDS entries
     ts_span_rec *recs;          // per span
     ts_cc_entry *cc_lists;      // per span: up to TS_PIDS entries
     ts_event *events;           // one list for the launch(es) of a scan, slots handed out by an atomic counter
     uint32_t event_cap;
-    unsigned int *event_count;  // events wanted so far (may run past event_cap: the host then repeats the scan with more room)
+    unsigned int *event_count;  // [0] events wanted so far (may run past event_cap: the host then repeats the scan with more room);
+                                // [1] a span of the slot form met more PIDs than it has slots (the host scans again, full tables)
+                                // [2] the full-table form gave a damaged stream up (the host scans again, slot form)
 };
 
 // what ts_merge_kernel tells the host
 struct ts_merge_out {
     uint32_t valid_upto;        // first span the chain did NOT reach validly (== nspans_total: done)
-    uint32_t pad;
+    uint32_t pad;               // != 0: the full-table form gave the (damaged) stream up — nothing of this scan is to be used
     uint64_t packets;           // packets of the valid chain (stream-wide packet_counter so far)
     ts_walk_state cur;          // the walker state the chain arrived with in front of span `valid_upto`
     uint64_t block_packets;
     uint64_t walks;
     uint32_t events;            // events the scan's launches have wanted so far (> event_cap: the list overflowed)
-    uint32_t pad2;
+    uint32_t pad2;              // != 0: a span overflowed its PID slots — nothing of this scan is to be used
 };
 
 void ts_kernels_prepare_device(void);

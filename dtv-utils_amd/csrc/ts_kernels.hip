@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ts_hip.h"
 #include "ts_kernels.h"
@@ -29,17 +30,53 @@
 
 namespace {
 
-constexpr int kScanBlock = 1024;
+constexpr int kScanBlock = 1024;   // the full-table form: one workgroup per CU
+constexpr int kSlotBlock = 512;    // the slot-table form: two workgroups per CU
 constexpr int kMergeBlock = 256;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kEntrySyncs = 8;  // sync bytes in a row, at the stride, that make a position a span's speculated entry
-constexpr uint32_t kEntryRounds = 16;  // ... looked for in the span's first 16 KiB
+constexpr uint32_t kEntryBytes = 16384;  // ... looked for in the span's first 16 KiB
 
 // ---- the walker on the device: ts_walk_core.h with these hooks, run by wave 0 with all 64 lanes in step ----
 // The walker reads the stream through a WINDOW in LDS: 4 KiB brought in by one cooperative load (four 16-byte loads per
 // lane in flight: one trip to memory), from which its header bytes and its sync searches are served.  Read straight from
 // global memory every byte the walker step looks at was a dependent trip of its own, 1-2 us each, and a damaged spot —
 // a burst of garbage with a false sync byte every few hundred bytes — cost ~30 us of its span's time.
+// ---- PID slots (the scan's second form) ----
+// 96 KiB of per-PID tables allow ONE workgroup per CU, and everything a span does at a damaged spot — a partial block, the
+// walker's window, the next block's headers: three dependent trips to memory with nothing else to run — is then the CU's
+// time.  A stream uses a few dozen PIDs, not 8192: the slot form keeps count / first / last / continuity state per SLOT
+// (kSlots of them), a PID gets its slot at its first packet in the span (s_slot: PID -> slot + 1), the workgroup needs
+// 62 KiB and 512 threads, and TWO spans share a CU: one's stalls are the other's time.  A span that meets more PIDs than
+// it has slots (garbage read as packets carries any PID) says so; the host then scans again with the full tables.
+constexpr uint32_t kSlots = 1024;
+constexpr uint32_t kSlotClaim = 0xFFFFFFFFu;  // s_slot[pid] while the lane that saw the PID first takes a slot for it
+
+// slot of `pid` (slot_limit: what a dummy slot is handed out beyond — its numbers are never used)
+__device__ __forceinline__ uint32_t slot_of(uint32_t *s_slot, uint32_t *s_nslots, uint16_t *s_slot_pid, uint32_t *s_over, uint32_t slot_limit,
+                                            uint32_t pid)
+{
+    uint32_t v = __hip_atomic_load(&s_slot[pid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (v == 0u || v == kSlotClaim) {
+        if (v == 0u && atomicCAS(&s_slot[pid], 0u, kSlotClaim) == 0u) {  // this lane assigns it
+            const uint32_t n = atomicAdd(s_nslots, 1u);
+            if (n < slot_limit) {
+                s_slot_pid[n] = (uint16_t)pid;
+                v = n + 1u;
+            } else {
+                *s_over = 1u;
+                v = kSlots + 1u;  // the dummy slot
+            }
+            __hip_atomic_store(&s_slot[pid], v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // (another lane does — of this wave: it has, the branch above lies in front of this loop — or of another wave)
+        do {
+            v = __hip_atomic_load(&s_slot[pid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } while (v == kSlotClaim);
+    }
+    return v - 1u;
+}
+
 constexpr uint32_t kWalkWindow = 4096;
 constexpr uint64_t kBridgeMax = 1u << 20;   // a bridge longer than this is the host's (a launch of the span from the true state)
 constexpr uint32_t kBridgeSteps = 8192;     // ... or one of more packets than this
@@ -67,7 +104,17 @@ struct DevWalk {
     uint32_t *s_ncc;                       // LDS: entries in the span's continuity list
     ts_cc_entry *cc_list;
     uint32_t *s_ev;                        // LDS, two words: next reserved slot of the event list, slots left (null: none kept)
+    // the slot form of the tables (null: they are indexed by the PID itself)
+    uint32_t *s_slot, *s_nslots, *s_over;
+    uint16_t *s_slot_pid;
+    uint32_t slot_limit;
 };
+
+// where the walker's tables keep `pid` (called by ONE lane)
+__device__ __forceinline__ uint32_t walk_idx(const DevWalk *w, uint32_t pid)
+{
+    return w->s_slot ? slot_of(w->s_slot, w->s_nslots, w->s_slot_pid, w->s_over, w->slot_limit, pid) : pid;
+}
 
 __device__ __forceinline__ bool walk_is_clean(const ts_walk_state &st)
 {
@@ -158,12 +205,12 @@ __device__ __forceinline__ void dev_count(DevWalk *w, unsigned h1, unsigned h2)
         return;
     }
     if (w->lane == 0 && (h1 & 0x80u) == 0) {  // transport_error_indicator clear, xport.c:2861-2867
-        const uint32_t pid = ((h1 & 0x1fu) << 8) | h2;
-        w->s_count[pid]++;
-        if (rel < w->s_first[pid])
-            w->s_first[pid] = rel;
-        if (rel > w->s_last[pid])
-            w->s_last[pid] = rel;
+        const uint32_t ix = walk_idx(w, ((h1 & 0x1fu) << 8) | h2);
+        w->s_count[ix]++;
+        if (rel < w->s_first[ix])
+            w->s_first[ix] = rel;
+        if (rel > w->s_last[ix])
+            w->s_last[ix] = rel;
     }
 }
 
@@ -259,7 +306,11 @@ __device__ __forceinline__ void dev_cc(DevWalk *w, unsigned pid, unsigned h3)
         walk_event(w, TS_EV_BRIDGE_CC, 0, w->packets, (pid << 8) | (cc << 4));
         return;
     }
-    const uint32_t last = w->s_cc[pid];  // (every lane reads the same byte)
+    uint32_t ix = 0;
+    if (w->lane == 0)
+        ix = walk_idx(w, pid);
+    ix = (uint32_t)__builtin_amdgcn_readfirstlane((int)ix);
+    const uint32_t last = w->s_cc[ix];  // (every lane reads the same byte)
     __builtin_amdgcn_wave_barrier();
     if (last == 0) {
         if (w->lane == 0) {
@@ -274,7 +325,7 @@ __device__ __forceinline__ void dev_cc(DevWalk *w, unsigned pid, unsigned h3)
         walk_event(w, TS_EV_DISC, 0, w->packets, (pid << 8) | (cc << 4) | (last & 0xfu));
     }
     if (w->lane == 0)
-        w->s_cc[pid] = (unsigned char)(cc + 1u);
+        w->s_cc[ix] = (unsigned char)(cc + 1u);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -291,14 +342,17 @@ __device__ __forceinline__ void dev_cc(DevWalk *w, unsigned pid, unsigned h3)
 
 }  // namespace
 
-__global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_params prm)
+template <int BLOCK, bool SLOTS>
+__global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm)
 {
+    constexpr int kScanBlock = BLOCK;               // (the workgroup's size: a block of the scan is one packet per thread)
+    constexpr uint32_t NT = SLOTS ? kSlots + 1u : (uint32_t)TS_PIDS;  // entries of the per-PID (per-slot) tables
     // (the fields the loop needs, as values: taken out of the by-value argument block once — left inside the struct the
     // compiler re-reads them from its stack copy in every iteration)
     struct {
         const unsigned char *data;
         uint64_t nbytes, span_bytes;
-        uint32_t first_span, nspans_total, stride, sync_offset, hdmv, attempt, explicit_entry, quirk_events, event_cap;
+        uint32_t first_span, nspans_total, stride, sync_offset, hdmv, attempt, explicit_entry, quirk_events, event_cap, slot_limit, abort_walks;
         ts_wg_entry *lists;
         ts_span_rec *recs;
         ts_cc_entry *cc_lists;
@@ -317,20 +371,26 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
     p.explicit_entry = prm.explicit_entry;
     p.quirk_events = prm.quirk_events;
     p.event_cap = prm.event_cap;
+    p.slot_limit = prm.slot_limit && prm.slot_limit < kSlots ? prm.slot_limit : kSlots;
+    p.abort_walks = SLOTS ? 0u : prm.abort_walks;
     p.lists = prm.lists;
     p.recs = prm.recs;
     p.cc_lists = prm.cc_lists;
     p.events = prm.events;
     p.event_count = prm.event_count;
-    extern __shared__ __attribute__((aligned(16))) uint32_t ts_smem[];  // 3 x TS_PIDS words = 96 KiB (one workgroup per CU)
-    uint32_t *s_count = ts_smem, *s_first = ts_smem + TS_PIDS, *s_last = ts_smem + 2 * TS_PIDS;
+    extern __shared__ __attribute__((aligned(16))) uint32_t ts_smem[];  // 3 x NT words (full tables: 96 KiB, one workgroup per CU)
+    uint32_t *s_count = ts_smem, *s_first = ts_smem + NT, *s_last = ts_smem + 2 * NT;
     __shared__ ts_walk_state s_st;
     __shared__ unsigned long long s_packets, s_block_packets;
     __shared__ uint32_t s_stop, s_walks, s_entries, s_cand, s_ncc, s_ev[2], s_evbase, s_nid, s_evn[kScanBlock / 64];
-    __shared__ unsigned char s_cc[TS_PIDS];  // per PID: last continuity counter + 1 (0: no payload packet in this span yet)
+    __shared__ unsigned char s_cc[NT];  // per PID: last continuity counter + 1 (0: no payload packet in this span yet)
+    // the slot form: PID -> slot + 1 (0: none yet), the slots' PIDs, slots handed out, "more PIDs than slots"
+    __shared__ uint32_t s_slot[SLOTS ? TS_PIDS : 1];
+    __shared__ uint16_t s_slot_pid[SLOTS ? kSlots : 1];
+    __shared__ uint32_t s_nslots, s_over, s_abort;
     // the continuity check across the waves of ONE block (below): per PID the number of its pair of words for this block,
     // the waves that hold the PID, and each such wave's last counter of it (a nibble per wave)
-    __shared__ uint32_t s_bid[TS_PIDS];
+    __shared__ uint32_t s_bid[NT];
     __shared__ uint32_t s_waves[kScanBlock + 1];
     __shared__ unsigned long long s_lastcc[kScanBlock + 1];
     __shared__ __attribute__((aligned(16))) unsigned char s_window[kWalkWindow];  // the walker's view of the stream (wave 0)
@@ -338,19 +398,32 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
     const uint32_t span = p.first_span + blockIdx.x;
     const uint64_t B0 = (uint64_t)span * p.span_bytes;
     const uint64_t B1 = (span + 1 == p.nspans_total || B0 + p.span_bytes > p.nbytes) ? p.nbytes : B0 + p.span_bytes;
-    for (uint32_t k = t; k < TS_PIDS; k += kScanBlock) {
+    for (uint32_t k = t; k < NT; k += kScanBlock) {
         s_count[k] = 0;
         s_first[k] = kNone;
         s_last[k] = 0;
         s_cc[k] = 0;
         s_bid[k] = 0;
     }
+    if constexpr (SLOTS)
+        for (uint32_t k = t; k < TS_PIDS; k += kScanBlock)
+            s_slot[k] = 0;
+    // where the tables keep a PID
+    auto idx = [&](uint32_t pid) -> uint32_t {
+        if constexpr (SLOTS)
+            return slot_of(s_slot, &s_nslots, s_slot_pid, &s_over, p.slot_limit, pid);
+        else
+            return pid;
+    };
     for (uint32_t k = t; k < kScanBlock + 1; k += kScanBlock) {
         s_waves[k] = 0;
         s_lastcc[k] = 0;
     }
     ts_cc_entry *cc_list = p.cc_lists + (size_t)span * TS_PIDS;
     if (t == 0) {
+        s_nslots = 0;
+        s_over = 0;
+        s_abort = 0;
         s_nid = 0;
         s_ncc = 0;
         s_ev[0] = s_ev[1] = 0;
@@ -381,7 +454,7 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
     if (!p.explicit_entry && span != 0) {
         // (the first offset of the span behind which the sync bytes sit on the grid — normally within its first stride-ful of
         // bytes; with damage right there, further in: the merge's bridge walks what lies in front, so the span is not lost)
-        for (uint32_t round = 0; round < kEntryRounds; round++) {
+        for (uint32_t round = 0; round < kEntryBytes / (uint32_t)kScanBlock; round++) {
             const uint64_t c = (uint64_t)round * kScanBlock + t;
             const uint64_t sy = B0 + c + p.sync_offset;
             bool ok = B0 + c < B1 && sy < p.nbytes;
@@ -479,7 +552,12 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
             // disturb what a slower one still reads of this block — the one barrier per block is enough)
             if (mine && !regular)
                 atomicMin(&s_stop, units_seen + t);
+            // (a damaged stream is the slot form's: some span has said so — seen by ONE thread, published in front of the barrier)
+            if (p.abort_walks && t == 0 && __hip_atomic_load(p.event_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                s_abort = 1;
             __syncthreads();
+            if (p.abort_walks && s_abort)
+                break;  // (workgroup-uniform; nothing of this scan will be used)
             const uint32_t stop = s_stop - units_seen;  // (kNone - units_seen >= nblk: a span looks at < 2^32 - 1024 units)
             const uint32_t take = stop < nblk ? stop : nblk;  // units in front of the first irregular one
             // A whole block taken: the next block's header words are asked for NOW — they fly while this block's packets are
@@ -496,12 +574,14 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
                 pre_w1 = *reinterpret_cast<const uint32_t *>(p.data + na + 4);
                 pre_pos = npos;
             }
+            // (the tables' entry of this lane's PID — a slot, in the slot form — wanted by the count and by the continuity check)
+            const uint32_t ix = (t < take && (tei == 0 || ((b3 & 0x10u) != 0 && pid != 0u))) ? idx(pid) : 0u;
             if (t < take) {
                 const uint32_t rel = (uint32_t)packets + t;  // packet number within the span (a span counts < 2^32)
                 if (tei == 0) {
-                    atomicAdd(&s_count[pid], 1u);
-                    atomicMin(&s_first[pid], rel);
-                    atomicMax(&s_last[pid], rel);
+                    atomicAdd(&s_count[ix], 1u);
+                    atomicMin(&s_first[ix], rel);
+                    atomicMax(&s_last[ix], rel);
                 }
             }
             // ---- continuity counters (xport.c:2872-2889) of the block's committed packets: header byte 3 is loaded already ----
@@ -541,10 +621,10 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
                 // publish (one lane per wave and PID): the PID's words for this block are found through s_bid
                 uint32_t bid = 0;
                 if (ccv && last_in_wave) {
-                    bid = s_bid[pid];
+                    bid = s_bid[ix];
                     if (!bid) {
                         const uint32_t n = atomicAdd(&s_nid, 1u) + 1u;  // (at most one per publishing lane: <= 1024 a block)
-                        const uint32_t old = atomicCAS(&s_bid[pid], 0u, n);
+                        const uint32_t old = atomicCAS(&s_bid[ix], 0u, n);
                         bid = old ? old : n;
                     }
                     atomicOr(&s_waves[bid], 1u << wave);
@@ -553,13 +633,13 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
                 __syncthreads();
                 bool block_last = false;
                 if (ccv && first_in_wave) {
-                    const uint32_t id = s_bid[pid];
+                    const uint32_t id = s_bid[ix];
                     const uint32_t earlier = s_waves[id] & ((1u << wave) - 1u);
                     if (earlier) {
                         const uint32_t wp = 31u - (uint32_t)__clz((int)earlier);
                         prev = (uint32_t)((s_lastcc[id] >> (4u * wp)) & 0xfull) + 1u;
                     } else {
-                        const uint32_t last = s_cc[pid];
+                        const uint32_t last = s_cc[ix];
                         if (last == 0) {
                             ts_cc_entry e;
                             e.pid = (uint16_t)pid;
@@ -587,8 +667,8 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
                     s_evn[wave] = (uint32_t)(__popcll(md) + __popcll(mq));
                 __syncthreads();
                 if (block_last) {  // the table moves on; the PID's words are free again
-                    s_cc[pid] = (unsigned char)(cc4 + 1u);
-                    s_bid[pid] = 0;
+                    s_cc[ix] = (unsigned char)(cc4 + 1u);
+                    s_bid[ix] = 0;
                     s_waves[bid] = 0;
                     s_lastcc[bid] = 0;
                 }
@@ -641,6 +721,14 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
         // where the next sync is due is one (else the next block would only find that out) ----
         walk_next = false;
         walks++;
+        // The full-table form gives a damaged stream up: one workgroup per CU has nothing to run while a damaged spot's three
+        // dependent trips to memory are under way; the slot form (two spans per CU) has.  More than one walk in 3072
+        // packets, abort_walks walks into the span: every span stops, the host scans again in the slot form.
+        if (p.abort_walks && walks >= p.abort_walks && (uint64_t)walks * 3072u > packets) {  // (workgroup-uniform)
+            if (t == 0)
+                atomicOr(p.event_count + 2, 1u);
+            break;
+        }
         __syncthreads();  // every thread has committed its packets and read s_stop
         if (wave == 0) {
             DevWalk w;
@@ -668,6 +756,11 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
             w.s_ncc = &s_ncc;
             w.cc_list = cc_list;
             w.s_ev = s_ev;
+            w.s_slot = SLOTS ? s_slot : nullptr;
+            w.s_nslots = &s_nslots;
+            w.s_over = &s_over;
+            w.s_slot_pid = s_slot_pid;
+            w.slot_limit = p.slot_limit;
             ts_walk_state s2 = st;
             for (;;) {
                 if (!dev_walk_step(&s2, &w, p.nbytes, 1))
@@ -697,11 +790,12 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
     __syncthreads();
     // ---- what the span leaves behind: its PIDs as a list, and its record ----
     ts_wg_entry *list = p.lists + (size_t)span * TS_PIDS;
-    for (uint32_t k = t; k < TS_PIDS; k += kScanBlock) {
+    const uint32_t nused = SLOTS ? (s_nslots < p.slot_limit ? s_nslots : p.slot_limit) : (uint32_t)TS_PIDS;
+    for (uint32_t k = t; k < nused; k += kScanBlock) {
         if (s_count[k]) {
             const uint32_t at = atomicAdd(&s_entries, 1u);
             ts_wg_entry e;
-            e.pid = k;
+            e.pid = SLOTS ? (uint32_t)s_slot_pid[k] : k;
             e.count = s_count[k];
             e.first = s_first[k];
             e.last = s_last[k];
@@ -709,12 +803,14 @@ __global__ __launch_bounds__(kScanBlock) void ts_scan_kernel(const ts_scan_param
         }
     }
     for (uint32_t k = t; k < s_ncc; k += kScanBlock)  // the list's PIDs: their last counter in this span
-        cc_list[k].last_cc = (uint8_t)(s_cc[cc_list[k].pid] - 1u);
+        cc_list[k].last_cc = (uint8_t)(s_cc[SLOTS ? s_slot[cc_list[k].pid] - 1u : (uint32_t)cc_list[k].pid] - 1u);
     __syncthreads();
     if (t == 0) {
         ts_span_rec r;
         r.ncc = s_ncc;
-        r.pad = 0;
+        r.pad = SLOTS ? s_over : 0u;  // 1: more PIDs than slots — this span's numbers are not to be used
+        if (SLOTS && s_over)
+            atomicOr(p.event_count + 1, 1u);  // (the word behind the event counter: the scan's "a span overflowed")
         r.entry = entry_pos;
         r.exit_pos = s_st.pos;
         r.exit_skipped = s_st.skipped;
@@ -800,7 +896,7 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
             if (blockIdx.x == 0) {
                 const ts_span_rec last = s_recs[p.nspans_total - 1];
                 out->valid_upto = p.nspans_total;
-                out->pad = 0;
+                out->pad = p.event_count[2];  // the full-table form gave a damaged stream up (ts_scan_params::abort_walks)
                 out->packets = packet_base + s_sum_all;
                 ts_walk_state cur = cur0;
                 cur.pos = last.exit_pos;
@@ -811,7 +907,7 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
                 out->block_packets = s_sum_block;
                 out->walks = s_sum_walks;
                 out->events = *p.event_count;
-                out->pad2 = 0;
+                out->pad2 = p.event_count[1];  // a span of the slot form met more PIDs than it has slots
             }
         }
     } else if (t < 64u) {
@@ -858,6 +954,10 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
                 w.s_ncc = nullptr;
                 w.cc_list = nullptr;
                 w.s_ev = nullptr;
+                w.s_slot = nullptr;
+                w.s_nslots = w.s_over = nullptr;
+                w.s_slot_pid = nullptr;
+                w.slot_limit = 0;
                 w.stop_at = r.entry + p.sync_offset;  // the span's first sync byte: where its own findings begin
                 ts_walk_state s2 = cur;
                 for (int run = 0; run < 2; run++) {  // dry, then — if it arrives and the span is this workgroup's — for real
@@ -912,12 +1012,12 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
             s_bridge_base = bridge_me;
             if (blockIdx.x == 0) {
                 out->valid_upto = k;
-                out->pad = 0;
+                out->pad = p.event_count[2];
                 out->packets = base;
                 out->cur = cur;
                 out->block_packets = blockp;
                 out->walks = walks;
-                out->pad2 = 0;
+                out->pad2 = p.event_count[1];
             }
         }
     }
@@ -1008,7 +1108,7 @@ __global__ __launch_bounds__(256) void ts_reset_kernel(uint32_t *__restrict__ g_
     if (i < nspans)
         span_attempt[i] = 0;
     if (i == 0)
-        *event_count = 0;
+        event_count[0] = event_count[1] = event_count[2] = 0;  // (events wanted; "a span overflowed its PID slots"; "a damaged stream")
 }
 
 void ts_launch_reset(hipStream_t st, uint32_t *g_count, unsigned long long *g_first, unsigned long long *g_last,
@@ -1019,16 +1119,23 @@ void ts_launch_reset(hipStream_t st, uint32_t *g_count, unsigned long long *g_fi
                        nspans);
 }
 
+static size_t scan_lds(bool slots)
+{
+    return 3 * (slots ? (size_t)kSlots + 1 : (size_t)TS_PIDS) * sizeof(uint32_t);
+}
+
 void ts_kernels_prepare_device(void)  // function attributes belong to the current device
 {
-    const int lds = 3 * TS_PIDS * (int)sizeof(uint32_t);
-    (void)hipFuncSetAttribute((const void *)ts_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)ts_scan_kernel<kScanBlock, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds(false));
+    (void)hipFuncSetAttribute((const void *)ts_scan_kernel<kSlotBlock, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds(true));
 }
 
 void ts_launch_scan(hipStream_t st, int blocks, const ts_scan_params &p)
 {
-    const size_t lds = 3 * TS_PIDS * sizeof(uint32_t);
-    hipLaunchKernelGGL(ts_scan_kernel, dim3(blocks), dim3(kScanBlock), lds, st, p);
+    if (p.slots)
+        hipLaunchKernelGGL((ts_scan_kernel<kSlotBlock, true>), dim3(blocks), dim3(kSlotBlock), scan_lds(true), st, p);
+    else
+        hipLaunchKernelGGL((ts_scan_kernel<kScanBlock, false>), dim3(blocks), dim3(kScanBlock), scan_lds(false), st, p);
 }
 
 void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t from_span, uint64_t packet_base, const ts_walk_state &cur,

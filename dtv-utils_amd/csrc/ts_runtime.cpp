@@ -51,7 +51,11 @@ struct ts_hip_ctx {
     ts_event *h_events = nullptr;                           // pinned mirror of the event list (grows with it)
     size_t h_events_cap = 0;
     std::vector<unsigned char> line_scratch;                // the host's working copy of the lines, reused from scan to scan
-    int spans = 0;
+    int spans = 0;                                          // spans of a scan with the full tables (one workgroup per CU)
+    int spans_slots = 0;                                    // ... of the slot form (two per CU)
+    int form = 0;                                           // 0: full tables, given up for the slot form when the stream is damaged;
+                                                            // 1: full tables only; 2: slot form first (TS_SCAN_FORM=auto|full|slots)
+    uint32_t slot_limit = 0;                                // (tests: TS_SCAN_SLOT_LIMIT)
     hipEvent_t ev_a = nullptr, ev_m = nullptr, ev_b = nullptr;
 };
 
@@ -143,9 +147,14 @@ int ts_hip_open(ts_hip_ctx **out, int device)
     hipDeviceProp_t prop;
     OPENCHK(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    ctx->spans = std::min(ctx->num_cus, TS_MAX_SPANS);  // one 1024-thread workgroup (96 KiB of LDS) per CU
+    ctx->spans = std::min(ctx->num_cus, TS_MAX_SPANS);            // one 1024-thread workgroup (96 KiB of LDS) per CU
+    ctx->spans_slots = std::min(2 * ctx->num_cus, TS_MAX_SPANS);  // two 512-thread workgroups with per-slot tables (62 KiB)
     if (const char *e = getenv("TS_SCAN_SPANS"))  // (tests: many small spans exercise the chain check on small streams)
-        ctx->spans = std::max(1, std::min(atoi(e), TS_MAX_SPANS));
+        ctx->spans = ctx->spans_slots = std::max(1, std::min(atoi(e), TS_MAX_SPANS));
+    if (const char *e = getenv("TS_SCAN_FORM"))
+        ctx->form = !strcmp(e, "full") ? 1 : !strcmp(e, "slots") ? 2 : 0;
+    if (const char *e = getenv("TS_SCAN_SLOT_LIMIT"))
+        ctx->slot_limit = (uint32_t)std::max(0, atoi(e));
     OPENCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     OPENCHK(hipMalloc((void **)&ctx->d_lists, (size_t)TS_MAX_SPANS * TS_PIDS * sizeof(ts_wg_entry)));
     OPENCHK(hipMalloc((void **)&ctx->d_recs, TS_MAX_SPANS * sizeof(ts_span_rec)));
@@ -158,7 +167,7 @@ int ts_hip_open(ts_hip_ctx **out, int device)
     OPENCHK(hipMalloc((void **)&ctx->d_count, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long))));
     ctx->d_first = reinterpret_cast<unsigned long long *>(ctx->d_count + TS_PIDS);
     ctx->d_last = ctx->d_first + TS_PIDS;
-    OPENCHK(hipMalloc((void **)&ctx->d_event_count, sizeof(unsigned int)));
+    OPENCHK(hipMalloc((void **)&ctx->d_event_count, 4 * sizeof(unsigned int)));  // [0] events wanted, [1] a span overflowed its PID slots, [2] damaged: the slot form's
     OPENCHK(hipMalloc((void **)&ctx->d_events, (size_t)kEventCapInitial * sizeof(ts_event)));
     ctx->event_cap = kEventCapInitial;
     OPENCHK(hipHostMalloc((void **)&ctx->h_out, sizeof(ts_merge_out), hipHostMallocMapped));
@@ -347,7 +356,14 @@ int ts_hip_download(ts_hip_ctx *ctx, void *bytes, uint64_t first, uint64_t nbyte
     return PAPR_OK;
 }
 
-static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
+// scan_with: nothing of the scan stands —
+constexpr int kSlotsOverflowed = 1;  // a span met more PIDs than the slot form has slots
+constexpr int kGaveUp = 2;           // the full-table form met a damaged stream (abort_walks)
+constexpr uint32_t kAbortWalks = 4;
+
+// one scan in one form; what the forms tried before it cost goes into the result's `launches` and `kernel_ms`
+static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots, uint32_t abort_walks, uint32_t launches_before,
+                     double ms_before, double merge_ms_before)
 {
     memset(out, 0, sizeof(*out));
     out->bytes = ctx->n;
@@ -357,7 +373,8 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
         return PAPR_OK;
     const uint32_t stride = hdmv ? 192u : 188u, sync_offset = hdmv ? 4u : 0u;
     // one span per CU, at least 64 KiB each (a span must hold a few packets for its entry to be found)
-    uint64_t span_bytes = (ctx->n + (uint64_t)ctx->spans - 1) / (uint64_t)ctx->spans;
+    const int spans_wanted = slots ? ctx->spans_slots : ctx->spans;
+    uint64_t span_bytes = (ctx->n + (uint64_t)spans_wanted - 1) / (uint64_t)spans_wanted;
     const uint64_t min_span = (uint64_t)std::max(4096, atoi(getenv("TS_SCAN_MIN_SPAN") ? getenv("TS_SCAN_MIN_SPAN") : "65536"));
     span_bytes = std::max<uint64_t>((span_bytes + 4095) & ~4095ull, min_span);
     const uint32_t nspans = (uint32_t)((ctx->n + span_bytes - 1) / span_bytes);
@@ -379,6 +396,9 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
         p.attempt = 1;
         p.explicit_entry = 0;
         p.quirk_events = getenv("TS_SCAN_QUIRK_EVENTS") ? (uint32_t)atoi(getenv("TS_SCAN_QUIRK_EVENTS")) : 1u;
+        p.slots = slots ? 1u : 0u;
+        p.slot_limit = ctx->slot_limit;
+        p.abort_walks = abort_walks;
         ts_walk_init(&p.entry, hdmv);
         p.lists = ctx->d_lists;
         p.recs = ctx->d_recs;
@@ -390,7 +410,7 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
         ts_walk_init(&cur, hdmv);
         uint64_t packets = 0;
         uint32_t from = 0;
-        out->launches = 0;
+        out->launches = launches_before;
         for (;;) {
             // ---- scan (every span from its speculated entry; or ONE span again, from the state the chain arrived with) ...
             TSCHK(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
@@ -419,13 +439,18 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
                 ms_merge += ms;
             out->launches++;
             const ts_merge_out mo = *ctx->h_out;
+            if ((slots && mo.pad2) || (abort_walks && mo.pad)) {
+                out->kernel_ms = ms_before + ms_total;  // (what the dropped scan cost is part of the answer's cost)
+                out->merge_ms = merge_ms_before + ms_merge;
+                return slots ? kSlotsOverflowed : kGaveUp;  // (garbage read as packets carries any PID: the full tables take it)
+            }
             out->gpu_packets += mo.block_packets;
             out->walks += (uint32_t)std::min<uint64_t>(mo.walks, 0xFFFFFFFFull);
             packets = mo.packets;
             cur = mo.cur;
             if (mo.valid_upto >= nspans)
                 break;
-            if (out->launches > 2 * nspans + 4)
+            if (out->launches - launches_before > 2 * nspans + 4)
                 return ts_fail(ctx, PAPR_E_INTERNAL, "the span chain does not converge (span %u)", mo.valid_upto);
             // the chain arrived in front of span `valid_upto` somewhere else (or in another state) than the span assumed:
             // that span once more, from the true state
@@ -595,9 +620,32 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
         out->first[pid] = gf[pid];
         out->last[pid] = gl[pid];
     }
-    out->kernel_ms = ms_total;
-    out->merge_ms = ms_merge;
+    out->kernel_ms = ms_before + ms_total;
+    out->merge_ms = merge_ms_before + ms_merge;
     return PAPR_OK;
+}
+
+static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
+{
+    // The full-table form (one 1024-thread workgroup per CU) is the faster one on a stream that is in order (by 4 %), the
+    // slot form (two spans per CU) on a damaged one (one damaged packet in 10000: even; in 3000: by a quarter; in 1000: by
+    // half): the scan starts in the first and, if a span meets damage more often than once in 3072 packets (four
+    // walks in: the first twentieth of a span or less), is done again in the second — which itself hands a stream with more PIDs
+    // in a span than it has slots back to the first.
+    int rc = PAPR_OK;
+    out->launches = 0;
+    out->kernel_ms = out->merge_ms = 0.0;
+    if (ctx->form == 0) {
+        rc = scan_with(ctx, hdmv, out, false, kAbortWalks, 0, 0.0, 0.0);
+        if (rc != kGaveUp)
+            return rc;
+    }
+    if (ctx->form != 1) {
+        rc = scan_with(ctx, hdmv, out, true, 0, out->launches, out->kernel_ms, out->merge_ms);
+        if (rc != kSlotsOverflowed)
+            return rc;
+    }
+    return scan_with(ctx, hdmv, out, false, 0, out->launches, out->kernel_ms, out->merge_ms);
 }
 
 int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)

@@ -79,9 +79,26 @@ def test_synthetic_stream_is_pinned_and_regular(tmp_path):
 
 # ---- GPU ------------------------------------------------------------------------------------------------
 
-@pytest.fixture(scope="module")
-def gpu(ts):
-    g = ts.TsHip(0)
+def _with_env(ts, env):
+    """a context opened under `env` (the scan's geometry and form are fixed when it is opened)"""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return ts.TsHip(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+# Every GPU test runs the scan three ways: "auto" (the default: the full-table form — 1024 threads, 8192-entry tables, one span
+# per CU — which gives a damaged stream up for the slot form), "slots" (512 threads, per-slot tables, two spans per CU; hands a
+# stream with more PIDs in a span than it has slots back to the full tables) and "full" (the full-table form, whatever comes)
+@pytest.fixture(scope="module", params=["auto", "slots", "full"])
+def gpu(ts, request):
+    g = _with_env(ts, {"TS_SCAN_FORM": request.param})
     yield g
     g.close()
 
@@ -149,20 +166,12 @@ def test_scan_of_the_synthetic_stream_and_handover_counts(ts, gpu, tmp_path):
         gpu.load_file(str(tmp_path / "missing.ts"))
 
 
-@pytest.fixture(scope="module")
-def gpu_small_spans(ts):
+@pytest.fixture(scope="module", params=["auto", "slots", "full"])
+def gpu_small_spans(ts, request):
     """a context that cuts even the small fixtures into many spans (4 KiB each: 21 packets)"""
-    old = {k: os.environ.get(k) for k in ("TS_SCAN_SPANS", "TS_SCAN_MIN_SPAN")}
-    os.environ["TS_SCAN_SPANS"] = "256"
-    os.environ["TS_SCAN_MIN_SPAN"] = "4096"
-    g = ts.TsHip(0)
+    g = _with_env(ts, {"TS_SCAN_SPANS": "256", "TS_SCAN_MIN_SPAN": "4096", "TS_SCAN_FORM": request.param})
     yield g
     g.close()
-    for k, v in old.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
 
 
 @pytest.mark.gpu
@@ -197,6 +206,59 @@ def test_scan_in_small_spans_equals_oracle_on_random_damaged_streams(ts, gpu_sma
             np.array_equal(first, ref["first"]) and np.array_equal(last, ref["last"]), kw
         relaunched += res.launches > 1
     assert relaunched > 0   # (some span did guess wrong: the re-launch path was taken)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,many", [({"TS_SCAN_SLOT_LIMIT": "3"}, False),
+                                      ({"TS_SCAN_SLOT_LIMIT": "3", "TS_SCAN_SPANS": "64", "TS_SCAN_MIN_SPAN": "4096"}, False),
+                                      ({"TS_SCAN_SPANS": "4"}, True)],
+                         ids=["three slots", "three slots, small spans", "3000 PIDs in a span"])
+def test_more_pids_than_slots_falls_back_to_the_full_tables(ts, env, many):
+    """The slot form keeps per-PID state for the PIDs a span actually meets (1024 slots).  A span that meets more — garbage
+    read as packets carries any PID — says so, and the scan is done again with the 8192-entry tables: same report, same
+    tables, at the price of the launches that were dropped."""
+    rng = np.random.default_rng(99)
+    with _with_env(ts, dict(env, TS_SCAN_FORM="slots")) as g:  # (the slot form first: the default would not take it for these)
+        fell_back = 0
+        for t in range(12):
+            if not many:
+                kw = random_stream_kwargs(t, rng)
+                kw["npackets"] = int(kw["npackets"] * rng.choice([1, 8]))
+            else:  # 20000 packets in four spans, 3000 PIDs among them
+                kw = dict(seed=int(rng.integers(1, 1 << 30)), npackets=20000, hdmv=bool(t & 1),
+                          pids=tuple(int(v) for v in rng.choice(np.arange(1, 0x1FFF), size=3000, replace=False)))
+            data = ts_streams.make_stream(**kw)
+            ref = ts_oracle.scan_mem(data, kw["hdmv"])
+            g.upload(data)
+            res = g.scan(kw["hdmv"])
+            assert res.report() == ts_oracle.report_lines(ref), kw
+            cnt, first, last = res.tables()
+            assert res.packets == ref["packets"] and np.array_equal(cnt, ref["count"]) and \
+                np.array_equal(first, ref["first"]) and np.array_equal(last, ref["last"]), kw
+            assert res.discontinuity_list() == ref["discontinuities"], kw
+            fell_back += res.launches >= 2
+        assert fell_back >= (12 if many else 4)
+
+
+@pytest.mark.gpu
+def test_a_damaged_stream_is_given_up_for_the_slot_form(ts, tmp_path):
+    """The default scan starts in the full-table form; spans that meet damage more often than once in 3072 packets stop it
+    and the slot form does the stream (one launch more, the same report); an occasional damaged spot does not."""
+    with _with_env(ts, {"TS_SCAN_FORM": "auto"}) as g, _with_env(ts, {"TS_SCAN_FORM": "full"}) as f:
+        for n, period, gives_up in ((2_000_000, 500, True), (2_000_000, 50000, False)):
+            size = g.generate_damaged(n, period)
+            assert f.generate_damaged(n, period) == size
+            a, b = g.scan(), f.scan()
+            assert a.report() == b.report() and a.packets == b.packets
+            assert a.sync_error_list() == b.sync_error_list() and a.discontinuity_list() == b.discontinuity_list()
+            ca, cb = a.tables(), b.tables()
+            assert all(np.array_equal(x, y) for x, y in zip(ca, cb))
+            assert (a.launches > b.launches) == gives_up, (period, a.launches, b.launches)
+        path = str(tmp_path / "d.ts")
+        subprocess.check_call([os.path.join(ROOT, "oracle", "mkts"), path, "400000", "--damage", "500"])
+        host = open(path, "rb").read()
+        g.upload(host)
+        assert g.scan().report() == ts_oracle.report_lines(ts_oracle.scan_mem(host))
 
 
 @pytest.mark.gpu

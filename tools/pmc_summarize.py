@@ -26,7 +26,7 @@ def main():
                 a[0] += float(row["Counter_Value"])
                 a[1] += 1
     for k in sorted(acc):
-        if not any(t in k for t in ("papr_sweep", "papr_stats_kernel", "papr_ccdf_kernel", "papr_exact_seg")):
+        if not any(t in k for t in ("papr_sweep", "papr_stats_kernel", "papr_ccdf_kernel", "papr_exact_seg", "ts_scan_kernel")):
             continue
         print(k)
         c = {n: v[0] / max(v[1], 1) for n, v in acc[k].items()}
