@@ -14,7 +14,8 @@ bit for bit (bin/papr's default; `--exact --exact-two-pass`: in two reads).
 Every step recomputes everything from the samples; nothing carries over
 between steps.  The plain invocation — what the driver runs — prints the
 configs[1] line with the other legs as members: `graph` (configs[2]), `exact`
-(both tables), `ts` (the transport-stream packet scan of `--workload ts`),
+(both tables), `ts` / `ts_damaged` (the transport-stream packet scan of `--workload ts`, clean and with one damaged
+spot per 1000 packets),
 `cpu_baseline` / `cpu_baseline_graph` (the reference binary on one host core)
 and `e2e` (bin/papr on the same workload from /dev/shm, PCIe-inclusive);
 `--headline-only` leaves the members out.  Workload at N=1 is BASELINE.json configs[1]: 10 GiB of
@@ -684,11 +685,14 @@ def main():
     gpu.close()
     del shard
     torch.cuda.empty_cache()
-    ts_line = None
+    ts_line = ts_damaged_line = None
     if full and not args.no_ts:
         ts_args = argparse.Namespace(**{**vars(args), "steps": max(1, min(args.steps, args.member_steps)),
                                         "warmup": min(args.warmup, 2)})
         ts_line = run_ts(ts_args, rank, world, local_rank, use_dist)
+        # ... and the scan's unfriendly case: one damaged spot per 1000 packets (no CPU member: the clean leg has it)
+        ts_damaged_line = run_ts(argparse.Namespace(**{**vars(ts_args), "damage": 1e-3, "no_cpu_baseline": True}),
+                                 rank, world, local_rank, use_dist)
     if rank == 0:
         line = lines[0]
         legs = {}
@@ -719,6 +723,13 @@ def main():
             legs["ts"] = {"ms_per_step": round(ts_line["ms_per_step"], 4), "value": round(ts_line["value"], 1),
                           "unit": ts_line["unit"], "kernel_ms": round(ts_line["roofline"]["kernel_ms"], 4),
                           "frac": round(ts_line["roofline"]["frac"], 4), "step_ms": brief(ts_line["roofline"].get("step_ms"))}
+        if ts_damaged_line:
+            line["ts_damaged"] = ts_damaged_line
+            legs["ts_damage_1e-3"] = {"ms_per_step": round(ts_damaged_line["ms_per_step"], 4), "value": round(ts_damaged_line["value"], 1),
+                                      "unit": ts_damaged_line["unit"], "kernel_ms": round(ts_damaged_line["roofline"]["kernel_ms"], 4),
+                                      "frac": round(ts_damaged_line["roofline"]["frac"], 4),
+                                      "launches_per_scan": ts_damaged_line["config"]["launches_per_scan"],
+                                      "lines": ts_damaged_line["config"]["sync_error_lines"] + ts_damaged_line["config"]["discontinuity_lines"]}
         if world == 1 and not args.no_cpu_baseline:
             mode0 = modes[0]
             sample = args.cpu_sample_gib if args.cpu_sample_gib else (1.0 if mode0 == "graph" else 4.0)   # ~10-15 s of reference CPU time
