@@ -30,7 +30,7 @@ struct ts_span_rec {
 };
 #define TS_NO_ENTRY 0xFFFFFFFFFFFFFFFFull
 #define TS_EVENT_BRIDGE 0x80000000u /* ts_event::attempt: written by a bridge of ts_merge_kernel */
-#define TS_MAX_SPANS 512 /* spans per scan (one per CU; ts_merge_kernel keeps their records in LDS) */
+#define TS_MAX_SPANS 1024 /* spans per scan (one to three per CU; ts_merge_kernel keeps their records in LDS) */
 
 // a line of the report, before the span's packets have their stream-wide numbers
 //   kind 0  `Transport Sync Error`: at_rel = packets the span had counted at that moment

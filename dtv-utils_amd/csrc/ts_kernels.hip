@@ -47,18 +47,36 @@ constexpr uint32_t kEntryBytes = 16384;  // ... looked for in the span's first 1
 // walker's window, the next block's headers: three dependent trips to memory with nothing else to run — is then the CU's
 // time.  A stream uses a few dozen PIDs, not 8192: the slot form keeps count / first / last / continuity state per SLOT
 // (kSlots of them), a PID gets its slot at its first packet in the span (s_slot: PID -> slot + 1), the workgroup needs
-// 62 KiB and 512 threads, and TWO spans share a CU: one's stalls are the other's time.  A span that meets more PIDs than
+// 46 KiB and 512 threads, and TWO spans share a CU: one's stalls are the other's time.  A span that meets more PIDs than
 // it has slots (garbage read as packets carries any PID) says so; the host then scans again with the full tables.
 constexpr uint32_t kSlots = 1024;
-constexpr uint32_t kSlotClaim = 0xFFFFFFFFu;  // s_slot[pid] while the lane that saw the PID first takes a slot for it
+constexpr uint32_t kSlotClaim = 0xFFFFu;  // a PID's half word of s_slot while the lane that saw the PID first takes a slot for it
+
+// s_slot packs two PIDs into a word (16 KiB for the 8192 of them): 0 = no slot yet, kSlotClaim, or slot + 1
+__device__ __forceinline__ uint32_t slot_peek(const uint32_t *s_slot, uint32_t pid)
+{
+    return (__hip_atomic_load(&s_slot[pid >> 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> ((pid & 1u) * 16u)) & 0xFFFFu;
+}
 
 // slot of `pid` (slot_limit: what a dummy slot is handed out beyond — its numbers are never used)
 __device__ __forceinline__ uint32_t slot_of(uint32_t *s_slot, uint32_t *s_nslots, uint16_t *s_slot_pid, uint32_t *s_over, uint32_t slot_limit,
                                             uint32_t pid)
 {
-    uint32_t v = __hip_atomic_load(&s_slot[pid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t sh = (pid & 1u) * 16u;
+    uint32_t *wp = &s_slot[pid >> 1];
+    uint32_t w = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t v = (w >> sh) & 0xFFFFu;
     if (v == 0u || v == kSlotClaim) {
-        if (v == 0u && atomicCAS(&s_slot[pid], 0u, kSlotClaim) == 0u) {  // this lane assigns it
+        bool mine = false;
+        while (((w >> sh) & 0xFFFFu) == 0u) {  // claim the half word if it is still empty (the other half may change meanwhile)
+            const uint32_t seen = atomicCAS(wp, w, w | (kSlotClaim << sh));
+            if (seen == w) {
+                mine = true;
+                break;
+            }
+            w = seen;
+        }
+        if (mine) {  // this lane assigns it
             const uint32_t n = atomicAdd(s_nslots, 1u);
             if (n < slot_limit) {
                 s_slot_pid[n] = (uint16_t)pid;
@@ -67,11 +85,12 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t *s_slot, uint32_t *s_nslots
                 *s_over = 1u;
                 v = kSlots + 1u;  // the dummy slot
             }
-            __hip_atomic_store(&s_slot[pid], v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __threadfence_block();
+            atomicXor(wp, (kSlotClaim ^ v) << sh);  // claim -> slot + 1, the other half untouched
         }
         // (another lane does — of this wave: it has, the branch above lies in front of this loop — or of another wave)
         do {
-            v = __hip_atomic_load(&s_slot[pid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            v = slot_peek(s_slot, pid);
         } while (v == kSlotClaim);
     }
     return v - 1u;
@@ -385,7 +404,7 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
     __shared__ uint32_t s_stop, s_walks, s_entries, s_cand, s_ncc, s_ev[2], s_evbase, s_nid, s_evn[kScanBlock / 64];
     __shared__ unsigned char s_cc[NT];  // per PID: last continuity counter + 1 (0: no payload packet in this span yet)
     // the slot form: PID -> slot + 1 (0: none yet), the slots' PIDs, slots handed out, "more PIDs than slots"
-    __shared__ uint32_t s_slot[SLOTS ? TS_PIDS : 1];
+    __shared__ uint32_t s_slot[SLOTS ? TS_PIDS / 2 : 1];  // (two PIDs a word)
     __shared__ uint16_t s_slot_pid[SLOTS ? kSlots : 1];
     __shared__ uint32_t s_nslots, s_over, s_abort;
     // the continuity check across the waves of ONE block (below): per PID the number of its pair of words for this block,
@@ -406,7 +425,7 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
         s_bid[k] = 0;
     }
     if constexpr (SLOTS)
-        for (uint32_t k = t; k < TS_PIDS; k += kScanBlock)
+        for (uint32_t k = t; k < TS_PIDS / 2; k += kScanBlock)
             s_slot[k] = 0;
     // where the tables keep a PID
     auto idx = [&](uint32_t pid) -> uint32_t {
@@ -803,7 +822,7 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
         }
     }
     for (uint32_t k = t; k < s_ncc; k += kScanBlock)  // the list's PIDs: their last counter in this span
-        cc_list[k].last_cc = (uint8_t)(s_cc[SLOTS ? s_slot[cc_list[k].pid] - 1u : (uint32_t)cc_list[k].pid] - 1u);
+        cc_list[k].last_cc = (uint8_t)(s_cc[SLOTS ? slot_peek(s_slot, cc_list[k].pid) - 1u : (uint32_t)cc_list[k].pid] - 1u);
     __syncthreads();
     if (t == 0) {
         ts_span_rec r;

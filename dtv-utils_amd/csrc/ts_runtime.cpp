@@ -64,6 +64,15 @@ namespace {
 char g_ts_open_error[256] = "";
 constexpr uint32_t kEventCapInitial = 1u << 16;  // events the first scan has room for (a scan that needs more is repeated)
 
+// spans of the slot form per CU.  (Three fit once the kernel is held to 80 VGPRs and are no faster: 1.246 against 1.242 ms at
+// --damage 3e-4; more spans are more span boundaries for damage to sit on, and a span the chain reaches behind its assumed
+// entry is scanned again by ONE workgroup: 768 spans took three launches and 3.08 ms at 1e-3 where 512 take one and 1.65.)
+int env_spans_per_cu()
+{
+    const char *e = getenv("TS_SCAN_SLOT_SPANS_PER_CU");
+    return e ? std::max(1, std::min(atoi(e), 4)) : 2;
+}
+
 int ts_fail(ts_hip_ctx *ctx, int code, const char *fmt, ...)
 {
     char *dst = ctx ? ctx->err : g_ts_open_error;
@@ -148,7 +157,7 @@ int ts_hip_open(ts_hip_ctx **out, int device)
     OPENCHK(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->spans = std::min(ctx->num_cus, TS_MAX_SPANS);            // one 1024-thread workgroup (96 KiB of LDS) per CU
-    ctx->spans_slots = std::min(2 * ctx->num_cus, TS_MAX_SPANS);  // two 512-thread workgroups with per-slot tables (62 KiB)
+    ctx->spans_slots = std::min(env_spans_per_cu() * ctx->num_cus, TS_MAX_SPANS);  // 512-thread workgroups with per-slot tables (46 KiB)
     if (const char *e = getenv("TS_SCAN_SPANS"))  // (tests: many small spans exercise the chain check on small streams)
         ctx->spans = ctx->spans_slots = std::max(1, std::min(atoi(e), TS_MAX_SPANS));
     if (const char *e = getenv("TS_SCAN_FORM"))
