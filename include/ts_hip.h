@@ -132,6 +132,11 @@ int ts_hip_generate(ts_hip_ctx *ctx, uint64_t seed, uint64_t npackets, int hdmv)
  * and missing bytes, an overwritten sync byte; npackets a multiple of 4 * period): the scan's unfriendly case */
 int ts_hip_generate_damaged(ts_hip_ctx *ctx, uint64_t seed, uint64_t npackets, uint64_t period);
 int ts_hip_download(ts_hip_ctx *ctx, void *bytes, uint64_t first, uint64_t nbytes);
+/* One complete scan of the resident stream (what `xport -p[h]` reports: xport.c:241-250, 2842-2889, 4317-4373).  The kernel has
+ * two forms with the same result: full per-PID tables, one span of the stream per CU — the faster one on a stream that is in
+ * order — and per-slot tables, two spans per CU, for damaged streams; a scan starts in the first and is done again in the
+ * second when its spans meet damage more than once per 3072 packets (out->launches and out->kernel_ms count both attempts;
+ * TS_SCAN_FORM=auto|full|slots chooses, a context reads it when it is opened). */
 int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out);
 /* EVERY sync error of the last ts_hip_scan, in the order the reference prints them (ts_scan_result holds the first
  * TS_MAX_SYNC_ERRORS inline; a stream that locks one byte off a 4-byte grid yields one `skipped 1 bytes` line per 4096
