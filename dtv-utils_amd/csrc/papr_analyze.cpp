@@ -175,6 +175,8 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
             else
                 crc = xrc;
         }
+        if (crc != PAPR_OK && env_int("PAPR_EXACT_DEBUG", 0))  // (the tree sum stands in; why, for whoever asks)
+            fprintf(stderr, "papr: the sequential sum was not reproduced (code %d): %s\n", crc, ctx->err);
         if (crc == PAPR_OK) {
             total.sum = seq;
             res->exact_sum = 1;

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void papr_exact_classify(const double *__restr
 {
     if (n_total_dev) {  // (peers: the file's length is known on the device only — the margin as the host computes it)
         const unsigned long long nt = *n_total_dev;
-        const double d = 8.0 * (double)(nt > n_shard ? nt : n_shard) * 1.1102230246251565e-16;
+        const double d = 4.0 * (double)(nt > n_shard ? nt : n_shard) * 1.1102230246251565e-16;  // (papr_exact_rt.cpp: kDeltaPerSample)
         delta = d > 1.0e-6 ? d : 1.0e-6;
     }
     __shared__ double sh[256];
@@ -564,11 +564,11 @@ __global__ __launch_bounds__(256) void papr_exact_pack_kernel(papr_exact_plan *_
                                                                uint32_t *__restrict__ count_dst, uint64_t out_cap,
                                                                uint32_t redo_cap, const papr_exact_prefix_src prefix)
 {
-    __shared__ uint32_t mixed_list[256], raw_list[512];  // (kCapMixed, kCapRaw)
+    __shared__ uint32_t mixed_list[256], raw_list[1024];  // (kCapMixed, kCapRaw)
     __shared__ papr_exact_plan plan_sh;
     papr_exact_plan *plan = &plan_sh;
     exact_plan(groups, ngroups, tile_E, ntiles, mixed_list, cap_mixed < 256u ? cap_mixed : 256u, raw_list,
-               cap_raw < 512u ? cap_raw : 512u, plan);
+               cap_raw < 1024u ? cap_raw : 1024u, plan);
     if (blockIdx.x + 1 == gridDim.x) {  // (the plan also goes where the host-side fallbacks look for it)
         for (uint32_t k = threadIdx.x; k < plan->nmixed; k += 256)
             mixed_list_out[k] = mixed_list[k];

@@ -7,6 +7,18 @@ using namespace papr_rt;
 
 namespace papr_rt {
 
+// How far the prefix sums the tiles are classified with may be from the reference's running sum, relative: the reference's
+// own recursive sum is within n * 2^-53 of the real sum of non-negative terms, the prefixes here — tile sums out of pairs
+// built for a binade that is at most one too high, i.e. additions rounded to at most twice the true ulp, then a tree — within
+// 2 n * 2^-53; 4 n * 2^-53 covers both with a third to spare.  (It was 8 n: a tile counts as undecided within that
+// distance of a power of two and travels raw, and the distance grows with n * the sum, i.e. with n squared — a single
+// shard of 192 GiB had more undecided tiles around 2^34 and 2^35 than the program's raw list holds, and lost its
+// sequential sum to the tree sum.)
+static inline double exact_delta(uint64_t n)
+{
+    return std::max(1.0e-6, 4.0 * (double)n * 1.1102230246251565e-16);
+}
+
 // exact-sum mode: device buffers sized for the current shard
 int ensure_exact_buffers(papr_hip_ctx *ctx)
 {
@@ -123,7 +135,7 @@ int run_exact_device(papr_hip_ctx *ctx, double before, uint64_t n_total, const C
     const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
     const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
     // margin >= the worst-case relative drift of a sequential double sum of n_total non-negative terms
-    const double delta = std::max(1.0e-6, 8.0 * (double)std::max<uint64_t>(n_total, ctx->n) * 1.1102230246251565e-16);
+    const double delta = exact_delta(std::max<uint64_t>(n_total, ctx->n));
     *bytes = 0;
     int rc = ensure_exact_buffers(ctx);
     if (rc)
@@ -259,7 +271,7 @@ int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total, const do
     const uint64_t ntiles = ctx->n / PAPR_EXACT_TILE_SAMPLES;
     const uint64_t ngroups = (ntiles + PAPR_EXACT_GROUP_TILES - 1) / PAPR_EXACT_GROUP_TILES;
     const uint32_t tail = (uint32_t)(ctx->n - ntiles * PAPR_EXACT_TILE_SAMPLES);
-    const double delta = std::max(1.0e-6, 8.0 * (double)std::max<uint64_t>(n_total, ctx->n) * 1.1102230246251565e-16);
+    const double delta = exact_delta(std::max<uint64_t>(n_total, ctx->n));
     int rc = reserve_exact_lists(ctx);
     if (rc)
         return rc;

@@ -379,7 +379,7 @@ struct FileSrc {
     float partner = 0.0f;  // Q of the phantom sample
 };
 
-constexpr uint32_t kCapMixed = 256, kCapRaw = 512;
+constexpr uint32_t kCapMixed = 256, kCapRaw = 1024;  // (papr_exact.hip sizes its lists by the same numbers: PAPR_EXACT_CAP_*)
 constexpr uint32_t kCapRedo = 65536;  // tiles (of 16 KiB) the one-read sweep may have to redo before a full second read is cheaper  // beyond this the program is assembled by the host path
 
 // ---- one-sweep mode: set-up, launch and bookkeeping shared by resident shards and file ingest -------------------

@@ -10,6 +10,7 @@ GPU's 32 GiB share of the 256 GiB config; the reference streams any size, papr.c
 `bin/papr [-g]` under a 4 GiB budget, as one shard and as eight, and stdout must be the reference's recording
 (big_spike40g.*.txt) after ONE pass over the file.
 """
+import hashlib
 import json
 import os
 import shutil
@@ -132,4 +133,50 @@ def test_40_gib_file_streams_once_under_a_4_gib_budget(pkg, file40g, manifest, g
     assert info["exact_sum"] == 1                       # the CLI's default arithmetic: the reference's sequential sum
     assert info["gpu0_ingest"]["resident"] == 0         # 40 GiB (5 GiB per shard at eight) against a 4 GiB budget
     assert info["gpu0_ingest"]["file_passes"] == 1      # ... and still ONE pass over the file
+    assert info["shards_swept"] == gpus and info["shards_resolved_from_sweep"] == gpus
+
+
+# ---- configs[4] at its own size: 256 GiB (opt-in: PAPR_TEST_256G=1; ~2 min on a box with 300 GiB of /dev/shm) ----------
+
+@pytest.fixture(scope="module")
+def file256g(orc):
+    if os.environ.get("PAPR_TEST_256G", "0") != "1":
+        pytest.skip("the 256 GiB file is opt-in (PAPR_TEST_256G=1): 260 GiB of /dev/shm, two minutes")
+    n = 34359738368   # 256 GiB = eight shards of 2^32 samples
+    need = n * 8
+    try:
+        with open("/proc/meminfo") as f:
+            avail = next(int(l.split()[1]) for l in f if l.startswith("MemAvailable")) * 1024
+        if shutil.disk_usage("/dev/shm").free < need + (16 << 30) or avail < need + (64 << 30):
+            pytest.skip("this box cannot hold a 256 GiB file in /dev/shm")
+    except OSError:
+        pytest.skip("no /dev/shm")
+    path = f"/dev/shm/papr_big_spike256g_{os.getpid()}.cfile"
+    workers = 64
+    per = n // workers
+    try:
+        procs = [subprocess.Popen([orc.MKCFILE, path, str(n), "--spike", "--part", str(w * per), str(per)]) for w in range(workers)]
+        assert all(p.wait() == 0 for p in procs)
+        assert os.path.getsize(path) == need
+        yield path
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["default", "graph"])
+@pytest.mark.parametrize("gpus", [8, 1], ids=["eight-shards", "one-shard"])
+def test_256_gib_file_streams_once_under_a_4_gib_budget(pkg, file256g, manifest, gpus, graph):
+    """BASELINE configs[4] as it stands: 256 GiB, every shard 2^32 samples (beyond the budget and beyond 32-bit indices at
+    once), streamed through the sweep once; stdout = what the reference program printed for this very file on the GPU box's
+    host (tests/golden/big_spike256g.*.txt, recorded by tools/config4_full_size.sh)."""
+    env = dict(os.environ, PAPR_STATS="1", PAPR_HBM_BUDGET_MB="4096", PAPR_GPUS=str(gpus), PAPR_OVERSUBSCRIBE="1")
+    p = subprocess.run([pkg.CLI_PATH] + (["-g"] if graph else []) + [file256g], capture_output=True, env=env, timeout=1800)
+    assert p.returncode == 0, p.stderr[-2000:]
+    tag = "graph" if graph else "default"
+    assert p.stdout == _golden(f"big_spike256g.{tag}.txt")
+    assert hashlib.sha256(p.stdout).hexdigest() == manifest["big_spike256g"][tag]["sha256"]
+    info = json.loads(p.stderr.decode().splitlines()[-1])
+    assert info["samples"] == manifest["big_spike256g"]["nsamples"] == 34359738368 and info["gpus"] == gpus
+    assert info["exact_sum"] == 1 and info["gpu0_ingest"]["resident"] == 0 and info["gpu0_ingest"]["file_passes"] == 1
     assert info["shards_swept"] == gpus and info["shards_resolved_from_sweep"] == gpus
