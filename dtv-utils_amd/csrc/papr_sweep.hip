@@ -818,8 +818,9 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep_kernel(const fl
 // that the bit-exact sequential sum costs one read as well.
 //   * a wave owns whole segments (wave w of workgroup b: segment (it * gridDim + b) * 8 + w); its 64 lanes own 16
 //     CONSECUTIVE samples each — the order the reference adds them in — through an XOR-swizzled LDS transposition
-//     (conflict-free both ways), and the next segment's loads are issued as soon as the registers are in LDS: they fly
-//     while this segment is folded, in front of any spill store
+//     (conflict-free both ways), and the next segment's loads are issued as soon as the buffer is free again: they fly
+//     while this segment is folded, in front of any spill store.  The 1 dB form loads the segment from memory straight
+//     into that buffer (LDS-direct loads, the swizzle in the source address); the 0.1 dB form through registers
 //   * the whole segment is ONE batch: its eight LDS reads, then its sixteen table lookups, are in flight together and
 //     the double-precision chains run under them (with two waves per SIMD it is the LDS round trips per segment that
 //     decide how long a wave is stalled)
@@ -911,6 +912,23 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         for (int u = 0; u < U; u++)
             x[u] = load16_nt_at(base, lane + u * kWave);
     };
+    // The 1 dB table's form takes the segment from memory STRAIGHT into the transpose buffer (gfx950's 16-byte LDS-direct
+    // loads, global_load_lds_dwordx4): lane l of row r lands in slot r * 64 + l whatever it asks for, so it asks for the
+    // float4 that belongs there — the swizzle of xpose_slot sits in the source address, inside the same 128-byte line, and
+    // the wave's eight 16-byte LDS writes, 32 VGPRs and the wake-up per arriving row are gone: 1.705 -> 1.652 ms.  (The
+    // 0.1 dB form keeps the registers: with its spills in the same queue the direct form is 4 % SLOWER.)
+    constexpr bool DIRECT = !FINE;
+    typedef __attribute__((address_space(1))) const void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    auto load_seg_lds = [&](float4 *dst, uint64_t seg) {
+        const float4 *base = data + seg * SEG_F4;
+#pragma unroll
+        for (int r = 0; r < U; r++) {
+            const uint32_t slot = (uint32_t)r * kWave + lane;                         // where the hardware puts this lane's 16 bytes
+            const uint32_t f = (slot & ~7u) | ((slot & 7u) ^ ((slot >> 4) & 7u));   // xpose_slot's inverse: the float4 that lives there
+            __builtin_amdgcn_global_load_lds((gvoid *)(base + f), (lvoid *)(dst + r * kWave), 16, 0, 2 /* nt */);
+        }
+    };
 
     double sum = 0.0;
     TileTrack tr = {{0.f, 0.f, 0.f, 0.f, 0.f}, {0, 0, 0, 0, 0}};
@@ -927,17 +945,31 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
     if (count) {
         E_next = tile_E[(p.seg_offset + seg0) >> 1];
         asm volatile("" ::: "memory");
-        load_seg(x, seg0);
+        if constexpr (DIRECT)
+            load_seg_lds(mine, seg0);
+        else
+            load_seg(x, seg0);
     }
     double2 D_prev = make_double2(0.0, 0.0);
     for (uint32_t it = 0; it < count; it++) {
         const uint64_t seg = seg0 + (uint64_t)it * seg_stride;
         const uint64_t now = __builtin_amdgcn_s_memrealtime();  // (for the spill check)
         const int E = __builtin_amdgcn_readfirstlane(E_next);
+        float4 y[U];
+        if constexpr (DIRECT) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the segment is in LDS ...
+            asm volatile("" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < U; r++) {
-            const int f = r * kWave + (int)lane;  // float4 slot within the segment, file order
-            mine[xpose_slot(f >> 3, f & 7)] = x[r];
+            for (int j = 0; j < U; j++)
+                y[j] = mine[xpose_slot((int)lane, j)];
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): ... and in registers: the buffer may be written again
+            asm volatile("" ::: "memory");
+        } else {
+#pragma unroll
+            for (int r = 0; r < U; r++) {
+                const int f = r * kWave + (int)lane;  // float4 slot within the segment, file order
+                mine[xpose_slot(f >> 3, f & 7)] = x[r];
+            }
         }
         if (it && lane == kWave - 1)
             seg_D[p.seg_offset + seg - seg_stride] = D_prev;
@@ -948,7 +980,10 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         if (it + 1 < count) {
             E_next = tile_E[(p.seg_offset + seg + seg_stride) >> 1];
             asm volatile("" ::: "memory");
-            load_seg(x, seg + seg_stride);
+            if constexpr (DIRECT)
+                load_seg_lds(mine, seg + seg_stride);
+            else
+                load_seg(x, seg + seg_stride);
         }
         const bool valid = E != PAPR_EXACT_AMBIG;
         const double m0 = valid ? pow2_f64(E) : 0.0, ulp = valid ? pow2_f64(E - 52) : 0.0, m1 = m0 + ulp;
@@ -958,10 +993,11 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         // next segment's loads: a spill's stores then have the fold's duration to drain before this wave waits for memory
         // again (vmcnt is in order and counts stores too)
         ws.spill_in_step(now, fine ? SLICE - kWave : SLICE - (2 * U + 1) * kWave, (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
-        float4 y[U];
+        if constexpr (!DIRECT) {
 #pragma unroll
-        for (int j = 0; j < U; j++)
-            y[j] = mine[xpose_slot((int)lane, j)];
+            for (int j = 0; j < U; j++)
+                y[j] = mine[xpose_slot((int)lane, j)];
+        }
         float pw[2 * U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
