@@ -22,7 +22,6 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "ts_hip.h"
 #include "ts_kernels.h"
