@@ -819,8 +819,8 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep_kernel(const fl
 //   * a wave owns whole segments (wave w of workgroup b: segment (it * gridDim + b) * 8 + w); its 64 lanes own 16
 //     CONSECUTIVE samples each — the order the reference adds them in — through an XOR-swizzled LDS transposition
 //     (conflict-free both ways), and the next segment's loads are issued as soon as the buffer is free again: they fly
-//     while this segment is folded, in front of any spill store.  The 1 dB form loads the segment from memory straight
-//     into that buffer (LDS-direct loads, the swizzle in the source address); the 0.1 dB form through registers
+//     while this segment is folded, in front of any spill store.  The segment goes from memory straight into that
+//     buffer (gfx950's LDS-direct loads, the swizzle in the source address)
 //   * the whole segment is ONE batch: its eight LDS reads, then its sixteen table lookups, are in flight together and
 //     the double-precision chains run under them (with two waves per SIMD it is the LDS round trips per segment that
 //     decide how long a wave is stalled)
@@ -915,9 +915,14 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
     // The 1 dB table's form takes the segment from memory STRAIGHT into the transpose buffer (gfx950's 16-byte LDS-direct
     // loads, global_load_lds_dwordx4): lane l of row r lands in slot r * 64 + l whatever it asks for, so it asks for the
     // float4 that belongs there — the swizzle of xpose_slot sits in the source address, inside the same 128-byte line, and
-    // the wave's eight 16-byte LDS writes, 32 VGPRs and the wake-up per arriving row are gone: 1.705 -> 1.652 ms.  (The
-    // 0.1 dB form keeps the registers: with its spills in the same queue the direct form is 4 % SLOWER.)
-    constexpr bool DIRECT = !FINE;
+    // the wave's eight 16-byte LDS writes, 32 VGPRs and the wake-up per arriving row are gone: 1.705 -> 1.652 ms ...
+    constexpr bool DIRECT = true;
+    // ... and the 0.1 dB form, whose stash logic reads LDS all along the fold, sends its powers' table lookups off IN FRONT
+    // of those loads: the compiler cannot tell that an LDS-direct load does not touch the table or the slices (everything is
+    // carved out of one dynamic array) and puts s_waitcnt vmcnt(0) in front of every LDS READ that follows one — with the
+    // lookups behind the loads that form was 4 % slower than through registers, with them in front it is 2.7 % faster
+    // (1.816 -> 1.767 ms).  The 1 dB form has one such wait and is better off with its loads out first.
+    constexpr bool EARLY = DIRECT && FINE;
     typedef __attribute__((address_space(1))) const void gvoid;
     typedef __attribute__((address_space(3))) void lvoid;
     auto load_seg_lds = [&](float4 *dst, uint64_t seg) {
@@ -971,6 +976,25 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
                 mine[xpose_slot(f >> 3, f & 7)] = x[r];
             }
         }
+        float pw[2 * U];
+        uint2 e_lut[2 * U];
+        SegMax m = {0u, 0u, 0u, INT32_MIN, INT32_MIN};
+        if constexpr (EARLY) {
+            // (the powers and all sixteen table lookups, in front of the next segment's LDS-direct loads: see EARLY)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                typedef float f32x2v __attribute__((ext_vector_type(2)));
+                const f32x2v a = {y[u].x, y[u].y}, b = {y[u].z, y[u].w};
+                const f32x2v aa = a * a, bb = b * b;
+                asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u]) : "v"(aa.x), "v"(aa.y));
+                asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u + 1]) : "v"(bb.x), "v"(bb.y));
+                segmax_fold(m, y[u], pw[2 * u], pw[2 * u + 1]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * U; u++)
+                e_lut[u] = lut_biased[clamp_cell(__float_as_int(pw[u]) >> shift, cell_first, cell_last)];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (it && lane == kWave - 1)
             seg_D[p.seg_offset + seg - seg_stride] = D_prev;
         asm volatile("" ::: "memory");
@@ -988,7 +1012,6 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         const bool valid = E != PAPR_EXACT_AMBIG;
         const double m0 = valid ? pow2_f64(E) : 0.0, ulp = valid ? pow2_f64(E - 52) : 0.0, m1 = m0 + ulp;
         double x0 = m0, x1 = m1;
-        SegMax m = {0u, 0u, 0u, INT32_MIN, INT32_MIN};
         // room for the segment's 16 samples of every lane (and the trash words)?  Checked IN FRONT of the fold, behind the
         // next segment's loads: a spill's stores then have the fold's duration to drain before this wave waits for memory
         // again (vmcnt is in order and counts stores too)
@@ -998,16 +1021,17 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
             for (int j = 0; j < U; j++)
                 y[j] = mine[xpose_slot((int)lane, j)];
         }
-        float pw[2 * U];
+        if constexpr (!EARLY) {
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            // (power_of with the squares as one packed multiplication and the additions written out: see papr_sweep_kernel)
-            typedef float f32x2v __attribute__((ext_vector_type(2)));
-            const f32x2v a = {y[u].x, y[u].y}, b = {y[u].z, y[u].w};
-            const f32x2v aa = a * a, bb = b * b;
-            asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u]) : "v"(aa.x), "v"(aa.y));
-            asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u + 1]) : "v"(bb.x), "v"(bb.y));
-            segmax_fold(m, y[u], pw[2 * u], pw[2 * u + 1]);
+            for (int u = 0; u < U; u++) {
+                // (power_of with the squares as one packed multiplication and the additions written out: see papr_sweep_kernel)
+                typedef float f32x2v __attribute__((ext_vector_type(2)));
+                const f32x2v a = {y[u].x, y[u].y}, b = {y[u].z, y[u].w};
+                const f32x2v aa = a * a, bb = b * b;
+                asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u]) : "v"(aa.x), "v"(aa.y));
+                asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u + 1]) : "v"(bb.x), "v"(bb.y));
+                segmax_fold(m, y[u], pw[2 * u], pw[2 * u + 1]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 2 * U; u++) {
@@ -1017,8 +1041,12 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         }
         uint32_t k[2 * U];
 #pragma unroll
-        for (int u = 0; u < 2 * U; u++)
-            k[u] = bin_of(pw[u]);  // the LUT reads in flight together
+        for (int u = 0; u < 2 * U; u++) {
+            if constexpr (EARLY)
+                k[u] = e_lut[u].x + (__float_as_uint(pw[u]) >= e_lut[u].y ? 1u : 0u);
+            else
+                k[u] = bin_of(pw[u]);  // the LUT reads in flight together
+        }
         if constexpr (FINE) {
             // A fine table stashes ten times what the 1 dB one does, out of a slice that is half as large (the table takes
             // the rest): keeping the segment's worst case free — every sample of every lane in band, 4 KiB — would leave a
