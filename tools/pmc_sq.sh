@@ -23,7 +23,7 @@ for RUN in ${PMC_RUNS:-"sweep_default:default:" "sweep_graph:graph:" "sweep3_def
   python $R/tools/pmc_summarize.py $O/$NAME 2>&1 | awk '/^papr_sweep/{p=1} /^papr_(stats|ccdf|exact|est|guess|true)/{p=0} p' >> $O/summary.txt
 done
 # the transport-stream scan (clean stream, and damaged at 1e-3)
-for RUN in "ts_clean:" "ts_damage_1e-3:--damage 1e-3"; do
+for RUN in ${PMC_TS_RUNS-"ts_clean:" "ts_damage_1e-3:--damage 1e-3"}; do
   IFS=: read NAME EXTRA <<< "$RUN"
   mkdir -p $O/$NAME
   for s in a b c; do
