@@ -1,0 +1,29 @@
+"""The measurement helpers under tools/ are run by hand on the GPU box: here only that they still parse (bash -n, py_compile)
+and that tools/README.md names every one of them — a helper that rots is worse than none."""
+import glob
+import os
+import py_compile
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+TOOLS = os.path.join(ROOT, "tools")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(TOOLS, "*.sh"))), ids=os.path.basename)
+def test_shell_tools_parse(path):
+    subprocess.check_call(["bash", "-n", path])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(TOOLS, "*.py"))), ids=os.path.basename)
+def test_python_tools_compile(path, tmp_path):
+    py_compile.compile(path, cfile=str(tmp_path / "x.pyc"), doraise=True)
+
+
+def test_readme_names_every_tool():
+    text = open(os.path.join(TOOLS, "README.md")).read()
+    missing = [os.path.basename(p) for p in sorted(glob.glob(os.path.join(TOOLS, "*")))
+               if os.path.basename(p) != "README.md" and os.path.basename(p) not in text]
+    assert not missing, missing
