@@ -51,7 +51,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-PREHEAT_STEPS = 32   # untimed steps (~50-70 ms) in front of every leg's warm-up (see run_mode)
+PREHEAT_STEPS = 32   # default of --preheat: untimed steps (~50-70 ms) in front of every leg's warm-up (see run_mode)
+LINE_LIMIT = 6000    # bytes of the ONE stdout line (the driver keeps the last 8000 characters of stdout + stderr)
 E2E_RUNS = 5         # timed runs of bin/papr per table in the e2e leg: the median is reported
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
@@ -104,6 +105,8 @@ def cpu_baseline(pkg, mode: str, sample_gib: float):
         return {"value": n / cpu_s / 1e6, "unit": "Msamples/s", "cores": 1, "kind": kind, "best_effort_build": best,
                 "sample": f"{sample_gib:g} GiB ({n} samples) of the same spike workload, mode={mode}, "
                           f"levels={int(table.size)}, file in {tmpdir} (page cache warm), {cpu_s:.2f} s wall",
+                "sample_short": f"{sample_gib:g} GiB ({n} samples) of the same stream, mode={mode}, {int(table.size)} levels, "
+                                f"page cache warm, {cpu_s:.2f} s wall",
                 "nproc": os.cpu_count(), "gpu_stdout_identical": text == p.stdout, "mkcfile_s": round(gen_s, 2)}
     finally:
         if os.path.exists(path):
@@ -191,14 +194,128 @@ def brief(summary):
     return None if summary is None else {k: v for k, v in summary.items() if k != "all"}
 
 
+def mmm(summary):
+    """[min, median, max] of a step summary: the legs' one-liners."""
+    return None if summary is None else [summary["min"], summary["median"], summary["max"]]
+
+
 def leg_summary(line):
     """What the driver's record needs of a member leg (it keeps `roofline` and `config` whole, nothing else of a member)."""
     r = line["roofline"]
     return {"ms_per_step": round(line["ms_per_step"], 4), "value": round(line["value"], 1), "kernel": r["kernel"],
-            "kernel_ms": round(r["kernel_ms"], 4), "frac": round(r["frac"], 4), "step_ms": brief(r.get("step_ms")), "kernel_launch_ms": brief(r.get("kernel_launch_ms")),
+            "kernel_ms": round(r["kernel_ms"], 4), "frac": round(r["frac"], 4), "step_ms": mmm(r.get("step_ms")), "kernel_launch_ms": mmm(r.get("kernel_launch_ms")),
             "host_and_exchange_ms_per_step": round(r["host_and_exchange_ms_per_step"], 4),
             "all_kernels_frac_of_peak": round(line["kernels"]["all_kernels_frac_of_peak"], 4),
             "parity_in_run": line["parity_in_run"], "steps": line["steps"], "warmup": line["warmup"]}
+
+
+def _r(v, nd=4):
+    """Round floats for the compact line (the full record keeps every digit)."""
+    return round(float(v), nd) if isinstance(v, (float, np.floating)) else v
+
+
+def compact_line(full, full_path):
+    """The ONE stdout line: the contract keys, `config`, `roofline` (with every other leg as a one-liner under
+    `roofline.legs`, and the fractions the verdicts ask about repeated as plain numbers so that a record which keeps only
+    the scalars of `roofline` still has them), `cpu_baseline[_graph]`, the parity flags — and, LAST, `headline`: the four
+    numbers of the run again, so that the final characters of stdout carry them whatever is cut off in front.  Everything
+    else (member legs whole, per-step arrays, kernel tables, the exchange's timing) is in the file `full` names."""
+    c, r = full["config"], full["roofline"]
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _r(full["value"], 1), _r(full["ms_per_step"], 5)
+    pre = c.get("preheat") or {}
+    sw = c.get("one_sweep") or None
+    line["config"] = {
+        "workload": c["workload"], "mode": c.get("mode"), "signal": c.get("signal"), "forced_miss": c.get("forced_miss"),
+        "samples_per_gpu": c.get("samples_per_gpu"), "samples_total": c.get("samples_total"), "levels": c.get("levels"),
+        "papr_db": c.get("papr_db"), "reads_of_the_shard_per_step": c.get("reads_of_the_shard_per_step"),
+        "exact_sequential_sum": c.get("exact_sequential_sum"), "sum_hex": c.get("sum_hex"),
+        "counts_crc32": c.get("counts_crc32"), "sharding": c.get("sharding"), "exchange": c.get("exchange"),
+        # untimed steps in front of the --warmup steps (an idle MI355X runs its first ~10 launches 5-7 % slow), and what the
+        # first five untimed steps cost on the host clock: the price of a FIRST papr_hip_analyze on an idle GPU
+        "preheat_steps": pre.get("steps"), "cold_first_steps_ms": pre.get("cold_first_steps_ms"),
+        "one_sweep": (None if sw is None else {"resolved": sw.get("steps_resolved_from_the_sweep"), "stash": sw.get("stash_samples"),
+                                               "band_log2": sw.get("band_log2"), "gave_up": sw.get("gave_up")}),
+    }
+    legs = r.get("legs") or {}
+    k = full.get("kernels") or {}
+    line["roofline"] = {
+        "bound": r["bound"], "achieved": _r(r["achieved"], 2), "peak": r["peak"], "unit": r["unit"],
+        "frac": _r(r["achieved"], 2) / r["peak"],   # (of the rounded figure beside it, exactly)
+        "traffic": _r(r.get("traffic"), 0), "kernel": r["kernel"], "kernel_ms": _r(r["kernel_ms"], 5),
+        "algorithmic_bytes_per_launch": r.get("algorithmic_bytes_per_launch"), "kernel_variant": r.get("kernel_variant"),
+        "traffic_source": (r.get("traffic_source") or "")[:60] or None, "traffic_stale": r.get("traffic_stale"),
+        "step_ms": brief(r.get("step_ms")), "kernel_launch_ms": brief(r.get("kernel_launch_ms")),
+        "step_ms_median": (r.get("step_ms") or {}).get("median"), "step_ms_max": (r.get("step_ms") or {}).get("max"),
+        "kernels_ms_per_step": _r(r.get("kernels_ms_per_step"), 5),
+        "host_and_exchange_ms_per_step": _r(r.get("host_and_exchange_ms_per_step"), 5),
+        "all_kernels_frac_of_peak": _r(k.get("all_kernels_frac_of_peak"), 4),
+        "two_pass_equiv_frac": _r((r.get("survey_two_pass_equiv") or {}).get("frac"), 4),
+        # the member legs' fractions of peak as plain numbers ...
+        **{f"{name}_frac": leg.get("frac") for name, leg in legs.items() if leg.get("frac") is not None},
+        **{f"{name}_ms_per_step": leg.get("ms_per_step") for name, leg in legs.items() if leg.get("ms_per_step") is not None},
+        # ... and their one-liners
+        "legs": legs,
+    }
+    for key in ("cpu_baseline", "cpu_baseline_graph"):
+        cb = full.get(key)
+        if isinstance(cb, dict):
+            if "error" in cb:
+                line[key] = {"error": str(cb["error"])[:200]}
+                continue
+            best = cb.get("best_effort_build") or {}
+            line[key] = {"value": _r(cb["value"], 3), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                         "nproc": cb.get("nproc"), "sample": cb.get("sample_short") or cb["sample"][:120],
+                         "gpu_stdout_identical": cb.get("gpu_stdout_identical"),
+                         "O3_avx2_value": _r(best.get("value"), 3) if best else None}
+    for key in ("parity_in_run", "parity_golden", "report_sha256", "device"):
+        line[key] = full.get(key)
+    line["full"] = full_path
+    cb = line.get("cpu_baseline") or {}
+    line["headline"] = {"value": line["value"], "ms_per_step": line["ms_per_step"], "roofline_frac": line["roofline"]["frac"],
+                        "cpu_baseline_value": cb.get("value"), "parity_in_run": line["parity_in_run"]}
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:   # never again a line the driver cannot keep: drop the nested summaries first
+        for leg in legs.values():
+            for key in ("step_ms", "kernel_launch_ms"):
+                leg.pop(key, None)
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:
+        line["roofline"].pop("legs", None)
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def emit(full, full_path, real_stdout):
+    """Rank 0: the full record to `full_path` (a file: the driver keeps the last 8000 characters of stdout AND stderr
+    together, so nothing long may follow the line on either), the compact line — ONE line, <= LINE_LIMIT bytes — to stdout."""
+    shown = None
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(full_path)), exist_ok=True)
+        with open(full_path, "w") as f:
+            json.dump(full, f)
+            f.write("\n")
+        shown = os.path.relpath(full_path, ROOT) if os.path.abspath(full_path).startswith(ROOT + os.sep) else full_path
+    except OSError as e:
+        print(f"bench.py: full record not written ({e})", file=sys.stderr)
+    text = compact_line(full, shown) if full["unit"] == "Msamples/s" else compact_ts_line(full, shown)
+    assert len(text) <= LINE_LIMIT and "\n" not in text, len(text)
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(text, flush=True)
+    os.dup2(2, 1)
+
+
+def compact_ts_line(full, full_path):
+    """--workload ts: the scan's own line without its per-step array."""
+    line = json.loads(json.dumps(full))
+    line["roofline"]["step_ms"] = brief(line["roofline"].get("step_ms"))
+    line["full"] = full_path
+    cb = line.get("cpu_baseline") or {}
+    line["headline"] = {"value": round(line["value"], 1), "ms_per_step": round(line["ms_per_step"], 5),
+                        "roofline_frac": round(line["roofline"]["frac"], 5), "cpu_baseline_value": cb.get("value")}
+    return json.dumps(line, separators=(",", ":"))
 
 
 def golden_report(world: int, gib: float, graph: bool):
@@ -257,14 +374,19 @@ def run_mode(args, mode, env):
     # kernels run at their steady speed (profiles/r04_driver_command_repeat.txt: with five 1.6 ms warm-up steps alone, the
     # first six TIMED sweeps took 1.64, 1.64, 1.62, 1.60, 1.57, 1.55 ms before settling at 1.53), and every leg of this
     # script starts on a GPU that has been idle while the host set the leg up.  Disclosed in config.preheat.
-    preheat_steps = PREHEAT_STEPS   # (a COUNT, not a duration: with peers every step holds collectives all ranks must enter)
+    preheat_steps = args.preheat   # (a COUNT, not a duration: with peers every step holds collectives all ranks must enter)
+    cold = []                      # the first untimed steps on the idle GPU, each on the host clock: what a FIRST papr_hip_analyze costs
     t_heat = time.perf_counter()
-    for _ in range(preheat_steps):
+    heat_s = 0.0
+    for i in range(preheat_steps + args.warmup):
+        t_c = time.perf_counter()
         step()
-    result["preheat"] = {"steps": preheat_steps, "seconds": round(time.perf_counter() - t_heat, 4),
+        if i < 5:
+            cold.append(round((time.perf_counter() - t_c) * 1e3, 3))
+        if i + 1 == preheat_steps:
+            heat_s = time.perf_counter() - t_heat
+    result["preheat"] = {"steps": preheat_steps, "seconds": round(heat_s, 4), "cold_first_steps_ms": cold,
                          "what": "untimed steps in front of the warm-up steps: the idle GPU reaches its steady speed after ~20 ms of load"}
-    for _ in range(args.warmup):
-        step()
     for k in ("resolved", "redo_tiles", "reruns", "exact_done"):
         result.pop(k, None)
     xch.timing(reset=True)
@@ -436,15 +558,18 @@ def run_ts(args, rank, world, local_rank, use_dist):
     else:
         gpu.generate(npackets, seed=0x7500001 + rank)
     res = None
-    preheat_steps = PREHEAT_STEPS
-    for _ in range(preheat_steps):   # (as run_mode: the idle GPU's first ~20 ms of load are slower)
+    preheat_steps = args.preheat
+    cold = []
+    for i in range(preheat_steps + args.warmup):   # (as run_mode: the idle GPU's first ~20 ms of load are slower)
+        t_c = time.perf_counter()
         res = gpu.scan()
-    for _ in range(args.warmup):
-        res = gpu.scan()
+        if i < 5:
+            cold.append(round((time.perf_counter() - t_c) * 1e3, 3))
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     step_s = [0.0] * args.steps
+    gc_was_on = gc.isenabled()
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
@@ -458,10 +583,11 @@ def run_ts(args, rank, world, local_rank, use_dist):
         step_s[i] = t_now - t_prev
         t_prev = t_now
     torch.cuda.synchronize()
-    gc.enable()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank) if args.control == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -495,7 +621,7 @@ def run_ts(args, rank, world, local_rank, use_dist):
                                f"MPEG-2 TS per GPU, HBM-resident, {world}xMI355X", "packets_per_gpu": npackets,
                    "bytes_per_gpu": nbytes, "launches_per_scan": int(res.launches), "walks_per_scan": int(res.walks),
                    "damage": (f"one damaged spot every {period} packets (include/ts_synth.h: ts_synth_damaged_byte)" if period else None),
-                   "preheat": {"steps": preheat_steps, "what": "untimed scans in front of the warm-up"},
+                   "preheat": {"steps": preheat_steps, "cold_first_steps_ms": cold, "what": "untimed scans in front of the warm-up"},
                    "sync_error_lines": int(res.nsync_errors), "discontinuity_lines": int(res.ndiscontinuities),
                    "packets_counted": int(res.packets),
                    "pids_seen": int(np.count_nonzero(res.tables()[0])), "sharding": "independent streams, no exchange",
@@ -511,7 +637,7 @@ def run_ts(args, rank, world, local_rank, use_dist):
                                                f"itself is {nbytes} bytes"},
         "device": None,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = ts_cpu_baseline(gpu, ts, args.cpu_sample_gib or 2.0, period)
         except Exception as e:
@@ -595,10 +721,21 @@ def main():
                          "max of the ranks' times, the RCCL id): gloo by default — the data path's collectives are RCCL either "
                          "way (--backend nccl), but a second RCCL communicator, torch's, beside the one the step uses costs "
                          "the sweep kernel 1.3 %% and the step 10 us (measured at world size 1)")
+    ap.add_argument("--preheat", type=int, default=PREHEAT_STEPS,
+                    help="untimed steps in front of the --warmup steps of every leg (an idle MI355X runs its first ~10 launches "
+                         "5-7 %% slow); 0 = the warm-up steps alone.  The first five untimed steps are reported either way "
+                         "(config.cold_first_steps_ms)")
+    ap.add_argument("--full-json", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
+                    help="where the full record goes (every member leg whole, per-step arrays): stdout carries only the compact "
+                         "line the driver keeps (<= 6000 bytes)")
     ap.add_argument("--cpu-sample-gib", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline (+ graph) legs: no exact-sum member, no TS member, no -g CPU baseline")
+    ap.add_argument("--no-selftest", action="store_true",
+                    help="with peers (or under torchrun): skip the exchange's self-test in front of the timed work")
+    ap.add_argument("--all-legs", action="store_true",
+                    help="with more than one rank: also run the exact-sum and packet-scan members (default there: headline + graph)")
     ap.add_argument("--no-ts", action="store_true", help="leave the transport-stream member out of the plain invocation's line")
     ap.add_argument("--member-steps", type=int, default=20, help="steps of the exact / ts members of the plain invocation")
     ap.add_argument("--no-e2e", action="store_true",
@@ -639,10 +776,7 @@ def main():
     if args.workload == "ts":
         line = run_ts(args, rank, world, local_rank, use_dist)
         if rank == 0:
-            sys.stdout.flush()
-            os.dup2(real_stdout, 1)
-            print(json.dumps(line), flush=True)
-            os.dup2(2, 1)
+            emit(line, args.full_json, real_stdout)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -655,12 +789,20 @@ def main():
     gpu = pkg.PaprHip(local_rank)
     gpu.adopt(shard.data_ptr(), per_gpu, base_index=rank * per_gpu, keepalive=shard)
     gpu.generate(pkg.SynthSpec.spike(total, envelope=args.signal), rank * per_gpu, per_gpu)
+    if use_dist:
+        # a rank that waits longer than this for its peers cancels the exchange and the run ends with an error instead of
+        # hanging until the driver's own limit (include/papr_exchange.h)
+        os.environ.setdefault("PAPR_XCH_TIMEOUT_S", "120")
     if not use_dist:
         xch = exchange.Exchange.single()
     elif args.backend == "nccl":
         xch = exchange.Exchange.rccl(gpu, rank, world)      # ncclCommInitRank inside libpaprhip; collectives on its stream
     else:
         xch = exchange.Exchange.over_torch()                # the same C exchange code over gloo
+    if use_dist and not args.no_selftest:
+        # every collective of the step once, on tiny buffers with predictable contents, before anything is timed: rank 0
+        # prints one stderr line per collective with its microseconds; a failure names the collective and ends the run
+        xch.selftest(gpu, verbose=True)
     if args.exact:
         gpu.set_exact(True)
     one_sweep = not (args.two_pass or (args.exact and args.exact_two_pass))
@@ -673,8 +815,10 @@ def main():
     # The plain invocation (what the driver runs) carries every leg in its ONE line: configs[1] as the headline,
     # configs[2] under "graph", the same two tables with the reference's sequential sum reproduced (what bin/papr does
     # by default) under "exact", the transport-stream scan under "ts", the reference's own CPU time for both tables.
+    # With more than one rank the plain invocation times the headline and configs[2] only: every member leg holds
+    # collectives all ranks must enter behind its own pre-heat, minutes of extra work in front of the line (--all-legs).
     full = (args.mode == "both" and not args.exact and not args.two_pass and not args.force_miss and args.signal == "gauss"
-            and not args.headline_only)
+            and not args.headline_only and (world == 1 or args.all_legs))
     exact_lines = None
     if full:
         gpu.set_exact(True)
@@ -718,19 +862,22 @@ def main():
             line["exact"] = ex
             legs["exact"] = dict(leg_summary(exact_lines[0]), sum_is_the_reference_s=ex["sum_is_the_reference_s"])
             legs["exact_graph"] = dict(leg_summary(exact_lines[1]), sum_is_the_reference_s=ex["graph"]["sum_is_the_reference_s"])
-        if ts_line:
-            line["ts"] = ts_line
-            legs["ts"] = {"ms_per_step": round(ts_line["ms_per_step"], 4), "value": round(ts_line["value"], 1),
-                          "unit": ts_line["unit"], "kernel_ms": round(ts_line["roofline"]["kernel_ms"], 4),
-                          "frac": round(ts_line["roofline"]["frac"], 4), "step_ms": brief(ts_line["roofline"].get("step_ms"))}
-        if ts_damaged_line:
-            line["ts_damaged"] = ts_damaged_line
-            legs["ts_damage_1e-3"] = {"ms_per_step": round(ts_damaged_line["ms_per_step"], 4), "value": round(ts_damaged_line["value"], 1),
-                                      "unit": ts_damaged_line["unit"], "kernel_ms": round(ts_damaged_line["roofline"]["kernel_ms"], 4),
-                                      "frac": round(ts_damaged_line["roofline"]["frac"], 4),
-                                      "launches_per_scan": ts_damaged_line["config"]["launches_per_scan"],
-                                      "lines": ts_damaged_line["config"]["sync_error_lines"] + ts_damaged_line["config"]["discontinuity_lines"]}
-        if world == 1 and not args.no_cpu_baseline:
+        for tag, tl in (("ts", ts_line), ("ts_damaged", ts_damaged_line)):
+            if not tl:
+                continue
+            line[tag] = tl
+            legs[tag] = {"ms_per_step": round(tl["ms_per_step"], 4), "value": round(tl["value"], 1), "unit": tl["unit"],
+                         "kernel_ms": round(tl["roofline"]["kernel_ms"], 4), "frac": round(tl["roofline"]["frac"], 4),
+                         "step_ms": mmm(tl["roofline"].get("step_ms")), "launches_per_scan": tl["config"]["launches_per_scan"],
+                         "lines": tl["config"]["sync_error_lines"] + tl["config"]["discontinuity_lines"],
+                         "damage": args.damage if tag == "ts" else 1e-3}
+            cbt = tl.get("cpu_baseline")
+            if isinstance(cbt, dict) and "value" in cbt:
+                legs[tag]["cpu_Mpackets_s"] = round(cbt["value"], 2)
+                legs[tag]["gpu_report_identical"] = cbt.get("gpu_report_identical")
+        if not args.no_cpu_baseline:
+            # the reference program on ONE host core (it is single-threaded), on rank 0 — with peers too: the other ranks
+            # wait in the closing barrier (10-15 s)
             mode0 = modes[0]
             sample = args.cpu_sample_gib if args.cpu_sample_gib else (1.0 if mode0 == "graph" else 4.0)   # ~10-15 s of reference CPU time
             sample = min(sample, args.gib)
@@ -751,15 +898,14 @@ def main():
                 line["e2e"] = {"error": repr(e)}
             for tag in ("default", "graph"):
                 if isinstance(line["e2e"].get(tag), dict):
-                    legs["e2e_" + tag] = {k: line["e2e"][tag].get(k) for k in
-                                          ("seconds", "seconds_is", "open_s", "ingest_GBps", "ingest_frac_of_h2d_ceiling",
-                                           "all_stdout_identical")}
-        if legs:   # the driver's record keeps `roofline` whole and drops the members: their one-line summaries live here
+                    t = line["e2e"][tag]
+                    legs["e2e_" + tag] = {"seconds": round(t["seconds"], 4), "runs": E2E_RUNS, "open_s": t.get("open_s"),
+                                          "ingest_GBps": t.get("ingest_GBps"),
+                                          "ingest_frac_of_h2d_ceiling": t.get("ingest_frac_of_h2d_ceiling"),
+                                          "all_stdout_identical": t.get("all_stdout_identical")}
+        if legs:
             line["roofline"]["legs"] = legs
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        print(json.dumps(line), flush=True)
-        os.dup2(2, 1)
+        emit(line, args.full_json, real_stdout)
 
     if use_dist:
         dist.barrier()

@@ -31,7 +31,7 @@ MAX_LEVELS = 16384
 ABI_SYMBOLS = (
     "papr_hip_abi_version", "papr_hip_device_count", "papr_hip_open", "papr_hip_close",
     "papr_hip_last_error", "papr_hip_device_name", "papr_hip_set_tuning", "papr_hip_set_timing",
-    "papr_hip_get_timing", "papr_hip_get_timing_launches", "papr_file_samples", "papr_hip_load_file", "papr_hip_get_ingest_timing", "papr_hip_upload",
+    "papr_hip_get_timing", "papr_hip_get_timing_launches", "papr_file_samples", "papr_hip_load_file", "papr_hip_load_stream", "papr_hip_get_ingest_timing", "papr_hip_upload",
     "papr_hip_adopt", "papr_hip_generate", "papr_hip_download", "papr_hip_stats",
     "papr_stats_init", "papr_stats_merge", "papr_levels", "papr_hip_ccdf",
     "papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
@@ -201,6 +201,8 @@ def lib() -> C.CDLL:
     L.papr_hip_get_timing_launches.restype = i32
     L.papr_file_samples.argtypes = [C.c_char_p, C.POINTER(u64)]
     L.papr_hip_load_file.argtypes = [vp, C.c_char_p, u64, u64]
+    L.papr_hip_load_stream.argtypes = [vp, i32, C.POINTER(u64)]
+    L.papr_hip_load_stream.restype = i32
     L.papr_hip_get_ingest_timing.argtypes = [vp, C.POINTER(IngestTiming)]
     L.papr_hip_get_ingest_timing.restype = i32
     L.papr_hip_upload.argtypes = [vp, vp, u64, u64]
@@ -425,6 +427,12 @@ class PaprHip:
     def load_file(self, path: str, first_sample: int = 0, nsamples: int = NO_INDEX):
         self._chk(self._L.papr_hip_load_file(self._ctx, os.fsencode(path), first_sample, nsamples),
                   "papr_hip_load_file")
+
+    def load_stream(self, fd: int) -> int:
+        """papr_hip_load_stream: a pipe / FIFO / socket read once, to its end, into the (growing) shard; returns the samples."""
+        n = C.c_uint64(0)
+        self._chk(self._L.papr_hip_load_stream(self._ctx, fd, C.byref(n)), "papr_hip_load_stream")
+        return int(n.value)
 
     def estimate_file(self, path: str, first_sample: int = 0, nsamples: int = NO_INDEX) -> Stats:
         """papr_hip_estimate for a file range that is not loaded (yet)."""

@@ -6,6 +6,8 @@
 
 using namespace papr_rt;
 
+extern "C" int papr_exchange_selftest_once(papr_exchange *x, papr_hip_ctx *ctx);  // papr_exchange.cpp
+
 extern "C" {
 
 static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph, unsigned flags, papr_result *res, float *levels,
@@ -15,8 +17,13 @@ static int papr_hip_analyze_impl(papr_hip_ctx *ctx, papr_exchange *x, int graph,
         return PAPR_E_ARG;
     if (!ctx->loaded)
         return fail(ctx, PAPR_E_STATE, "papr_hip_analyze called before a shard was loaded");
+    int rc0 = PAPR_OK;
     memset(res, 0, sizeof(*res));
     ctx->trace.mark("enter");
+    if (x && (rc0 = papr_exchange_selftest_once(x, ctx)) != PAPR_OK) {  // PAPR_XCH_SELFTEST=1: once per handle
+        snprintf(ctx->err, sizeof(ctx->err), "%s", papr_exchange_last_error(x));
+        return rc0;
+    }
     auto xfail = [&](int rc) {  // an exchange failed: its text is the detail
         if (x)
             snprintf(ctx->err, sizeof(ctx->err), "exchange: %s", papr_exchange_last_error(x));

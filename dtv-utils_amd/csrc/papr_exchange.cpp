@@ -7,7 +7,10 @@
 #include "papr_runtime_internal.h"
 
 #include <atomic>
+#include <chrono>
+#include <thread>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>  // types and enums only: the functions are looked up with dlsym
 
 using namespace papr_rt;
@@ -81,6 +84,7 @@ struct LocalHub {
     std::vector<unsigned char> slots;  // world x bytes of the collective in flight
     size_t slot_bytes = 0;
     bool failed = false;  // a participant gave up (papr_exchange_abort): every collective fails from then on
+    double timeout_s = 0; // PAPR_XCH_TIMEOUT_S: a thread that waits longer than this for its peers cancels the exchange
     // papr_exchange_open_rccl_local: the id every thread's ncclCommInitRank joins with (papr_exchange_bind)
     bool want_rccl = false;
     ncclUniqueId uid{};
@@ -94,6 +98,11 @@ struct LocalHub {
             arrived = 0;
             generation++;
             cv.notify_all();
+        } else if (timeout_s > 0) {
+            if (!cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return generation != gen || failed; })) {
+                failed = true;  // (the peers that do arrive later find the exchange cancelled instead of waiting in turn)
+                cv.notify_all();
+            }
         } else {
             cv.wait(lk, [&] { return generation != gen || failed; });
         }
@@ -114,6 +123,20 @@ struct papr_exchange {
     bool want_rccl = false;        // papr_exchange_open_rccl_local: papr_exchange_bind still has to create `comm`
     ncclUniqueId solo_uid{};       // ... for a world of one (no hub)
     std::atomic<bool> aborted{false};
+    // `comm` is used (collectives queued) by its owner's thread and ended by whoever cancels the exchange: both under this
+    // mutex, `aborted` checked inside it, so that nothing is ever queued on a communicator ncclCommAbort has freed.  Only
+    // the owner's papr_exchange_close sets `comm` to null.
+    std::timed_mutex comm_m;
+    bool comm_ended = false;       // ncclCommAbort has run on `comm` (it is freed: papr_exchange_close must not destroy it)
+    char wd_err[256] = "";       // the watchdog's message (its own buffer: `err` belongs to the owner's thread)
+    // PAPR_XCH_TIMEOUT_S: since when this rank has been waiting for its peers (0: it is not), and in what
+    std::atomic<double> waiting_since{0.0};
+    const char *waiting_in = "";
+    double timeout_s = 0;
+    std::thread watchdog;
+    std::atomic<bool> watchdog_stop{false};
+    bool timed_out = false;
+    bool selftest_done = false;
     unsigned char *d_send = nullptr, *d_recv = nullptr;  // device staging
     unsigned char *h_send = nullptr, *h_recv = nullptr;  // pinned mirrors
     size_t cap_send = 0, cap_recv = 0;
@@ -164,13 +187,80 @@ int ensure_staging(papr_exchange *x, size_t send_bytes, size_t recv_bytes)
         if (e_ != hipSuccess)                                                                   \
             return xfail(x, PAPR_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_));         \
     } while (0)
+// Every RCCL call on x->comm: under the communicator's mutex, and never once the exchange was cancelled (the communicator
+// may be freed by then: papr_exchange_abort).
+const char *const kCancelled = "the exchange was cancelled (papr_exchange_abort): nothing is queued on its communicator";
 #define XNCCL(x, call)                                                                          \
     do {                                                                                        \
+        std::lock_guard<std::timed_mutex> g_((x)->comm_m);                                      \
+        if ((x)->aborted.load() || !(x)->comm)                                                  \
+            return xfail(x, PAPR_E_STATE, "%s", kCancelled);                                    \
         ncclResult_t r_ = (call);                                                               \
         if (r_ != ncclSuccess)                                                                  \
             return xfail(x, PAPR_E_HIP, "%s failed: %s", #call,                                 \
                          rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "RCCL error");   \
     } while (0)
+
+// PAPR_XCH_TIMEOUT_S: "this rank is waiting for its peers, since now, in <what>" for the length of a scope
+struct Waiting {
+    papr_exchange *x;
+    Waiting(papr_exchange *x_, const char *what) : x(x_)
+    {
+        if (x && x->timeout_s > 0) {
+            x->waiting_in = what;
+            x->waiting_since.store(now_s());
+        }
+    }
+    ~Waiting()
+    {
+        if (x && x->timeout_s > 0)
+            x->waiting_since.store(0.0);
+    }
+};
+
+// The watchdog of one handle: a rank that has waited longer than PAPR_XCH_TIMEOUT_S for its peers — in a host exchange's
+// wait, in the step's one wait behind in-stream collectives, in ncclCommInitRank — says so on stderr and cancels the
+// exchange (papr_exchange_abort: the wait returns with an error, the peers are released).  Inside ncclCommInitRank there
+// is no communicator to abort yet: the process is ended with status 254 — the only way out of a rendezvous that never
+// completes (PAPR_XCH_TIMEOUT_EXIT=0: only the message).
+void watchdog_main(papr_exchange *x)
+{
+    while (!x->watchdog_stop.load()) {
+        usleep(50 * 1000);
+        const double since = x->waiting_since.load();
+        if (since <= 0 || now_s() - since <= x->timeout_s)
+            continue;
+        const char *what = x->waiting_in;
+        snprintf(x->wd_err, sizeof(x->wd_err), "rank %d of %d waited more than %g s for its peers in %s (PAPR_XCH_TIMEOUT_S): "
+                 "the exchange is cancelled", x->rank, x->world, x->timeout_s, what);
+        x->timed_out = true;
+        fprintf(stderr, "papr exchange: %s\n", x->wd_err);
+        fflush(stderr);
+        x->waiting_since.store(0.0);
+        const bool in_init = !strcmp(what, "ncclCommInitRank");
+        papr_exchange_abort(x);
+        if (in_init && env_int("PAPR_XCH_TIMEOUT_EXIT", 1))
+            _exit(254);
+    }
+}
+
+void start_watchdog(papr_exchange *x)
+{
+    const char *e = getenv("PAPR_XCH_TIMEOUT_S");
+    const double t = e ? atof(e) : 0.0;
+    if (!(t > 0) || x->watchdog.joinable())
+        return;
+    x->timeout_s = t;
+    if (x->hub) {
+        std::lock_guard<std::mutex> g(x->hub->m);
+        x->hub->timeout_s = t;
+    }
+    try {
+        x->watchdog = std::thread(watchdog_main, x);
+    } catch (...) {
+        x->timeout_s = 0;  // (no thread: no watchdog; the hub's own timed waits still hold)
+    }
+}
 
 // recv = world x bytes_per_rank, in rank order
 int allgather_bytes(papr_exchange *x, const void *send, void *recv, size_t bytes_per_rank)
@@ -182,7 +272,7 @@ int allgather_bytes(papr_exchange *x, const void *send, void *recv, size_t bytes
     if (x->hub) {
         LocalHub &h = *x->hub;
         std::unique_lock<std::mutex> lk(h.m);
-        const char *gone = "another shard's thread gave up: the exchange is cancelled";
+        const char *gone = "another shard's thread gave up (or PAPR_XCH_TIMEOUT_S ran out): the exchange is cancelled";
         if (!h.barrier(lk))  // everyone has left the previous collective
             return xfail(x, PAPR_E_STATE, "%s", gone);
         if (h.slots.size() != bytes_per_rank * (size_t)h.world) {
@@ -216,9 +306,12 @@ int allgather_bytes(papr_exchange *x, const void *send, void *recv, size_t bytes
     XHIP(x, hipSetDevice(ctx->device));
     memcpy(x->h_send, send, bytes_per_rank);
     XHIP(x, hipMemcpyAsync(x->d_send, x->h_send, bytes_per_rank, hipMemcpyHostToDevice, ctx->stream));
+    Waiting w(x, "a host-level all-gather over RCCL");
     XNCCL(x, rccl()->AllGather(x->d_send, x->d_recv, bytes_per_rank, ncclUint8, x->comm, ctx->stream));
     XHIP(x, hipMemcpyAsync(x->h_recv, x->d_recv, total, hipMemcpyDeviceToHost, ctx->stream));
     XHIP(x, hipStreamSynchronize(ctx->stream));
+    if (x->aborted.load())
+        return xfail(x, PAPR_E_STATE, "%s", x->timed_out ? x->wd_err : kCancelled);
     memcpy(recv, x->h_recv, total);
     return PAPR_OK;
 }
@@ -258,9 +351,12 @@ int allreduce_u64(papr_exchange *x, uint64_t *buf, size_t count)
     XHIP(x, hipSetDevice(ctx->device));
     memcpy(x->h_send, buf, bytes);
     XHIP(x, hipMemcpyAsync(x->d_send, x->h_send, bytes, hipMemcpyHostToDevice, ctx->stream));
+    Waiting w(x, "a host-level all-reduce over RCCL");
     XNCCL(x, rccl()->AllReduce(x->d_send, x->d_recv, count, ncclUint64, ncclSum, x->comm, ctx->stream));
     XHIP(x, hipMemcpyAsync(x->h_recv, x->d_recv, bytes, hipMemcpyDeviceToHost, ctx->stream));
     XHIP(x, hipStreamSynchronize(ctx->stream));
+    if (x->aborted.load())
+        return xfail(x, PAPR_E_STATE, "%s", x->timed_out ? x->wd_err : kCancelled);
     memcpy(buf, x->h_recv, bytes);
     return PAPR_OK;
 }
@@ -271,6 +367,8 @@ extern "C" {
 
 const char *papr_exchange_last_error(const papr_exchange *x)
 {
+    if (x && x->timed_out && x->wd_err[0])
+        return x->wd_err;
     return x ? x->err : g_xch_open_error;
 }
 
@@ -320,6 +418,21 @@ int xch_allgather_host(papr_exchange *x, const void *send, void *recv, size_t by
 }
 int xch_rank(const papr_exchange *x) { return x ? x->rank : 0; }
 int xch_world(const papr_exchange *x) { return x ? x->world : 1; }
+// PAPR_XCH_TIMEOUT_S around the step's ONE wait behind in-stream collectives (papr_sweep_rt.cpp): a peer that never
+// enters its collective leaves this rank's stream waiting; the watchdog then cancels the exchange and the wait returns.
+void xch_wait_begin(papr_exchange *x, const char *what)
+{
+    if (x && x->timeout_s > 0) {
+        x->waiting_in = what;
+        x->waiting_since.store(now_s());
+    }
+}
+void xch_wait_end(papr_exchange *x)
+{
+    if (x && x->timeout_s > 0)
+        x->waiting_since.store(0.0);
+}
+bool xch_cancelled(const papr_exchange *x) { return x && (x->aborted.load() || x->timed_out); }
 
 namespace {
 // the stand-in: device -> host, the transport's own collective, host -> device (the stream is idle in between)
@@ -390,16 +503,22 @@ int xch_allgatherv_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev
     }
     if (!rccl()->Broadcast || !rccl()->GroupStart || !rccl()->GroupEnd)
         return xfail(x, PAPR_E_NO_DEVICE, "this RCCL has no ncclBroadcast / group calls");
-    XNCCL(x, rccl()->GroupStart());
-    for (int r = 0; r < world; r++) {
-        unsigned char *dst = (unsigned char *)recv_dev + offs[r];
-        const ncclResult_t rr = rccl()->Broadcast(r == me ? send_dev : (const void *)dst, dst, sizes[r], ncclUint8, r, x->comm, x->ctx->stream);
-        if (rr != ncclSuccess) {
-            (void)rccl()->GroupEnd();
-            return xfail(x, PAPR_E_HIP, "ncclBroadcast failed: %s", rccl()->GetErrorString ? rccl()->GetErrorString(rr) : "RCCL error");
+    {
+        std::lock_guard<std::timed_mutex> g(x->comm_m);  // (the whole group under the communicator's mutex)
+        if (x->aborted.load() || !x->comm)
+            return xfail(x, PAPR_E_STATE, "%s", kCancelled);
+        ncclResult_t rr = rccl()->GroupStart();
+        for (int r = 0; r < world && rr == ncclSuccess; r++) {
+            unsigned char *dst = (unsigned char *)recv_dev + offs[r];
+            rr = rccl()->Broadcast(r == me ? send_dev : (const void *)dst, dst, sizes[r], ncclUint8, r, x->comm, x->ctx->stream);
         }
+        const ncclResult_t re = rccl()->GroupEnd();
+        if (rr == ncclSuccess)
+            rr = re;
+        if (rr != ncclSuccess)
+            return xfail(x, PAPR_E_HIP, "the grouped ncclBroadcasts of the all-gather-v failed: %s",
+                         rccl()->GetErrorString ? rccl()->GetErrorString(rr) : "RCCL error");
     }
-    XNCCL(x, rccl()->GroupEnd());
     x->timing.in_stream_calls++;
     return PAPR_OK;
 }
@@ -436,11 +555,17 @@ int papr_exchange_open_rccl(papr_exchange **out, papr_hip_ctx *ctx, const void *
     }
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
-    const ncclResult_t r = rccl()->CommInitRank(&x->comm, world, uid, rank);
+    start_watchdog(x);
+    ncclResult_t r;
+    {
+        Waiting w(x, "ncclCommInitRank");
+        r = rccl()->CommInitRank(&x->comm, world, uid, rank);
+    }
     if (r != ncclSuccess) {
         xfail(nullptr, PAPR_E_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world,
               rccl()->GetErrorString ? rccl()->GetErrorString(r) : "RCCL error");
-        delete x;
+        x->comm = nullptr;
+        papr_exchange_close(x);
         return PAPR_E_HIP;
     }
     *out = x;
@@ -488,6 +613,9 @@ int papr_exchange_open_local(papr_exchange **xs, int n)
     }
     if (n == 1) {
         delete hub;
+    } else {
+        const char *e = getenv("PAPR_XCH_TIMEOUT_S");  // (threads that meet at the hub: its waits are timed themselves)
+        hub->timeout_s = e && atof(e) > 0 ? atof(e) : 0.0;
     }
     return PAPR_OK;
 }
@@ -528,20 +656,32 @@ int papr_exchange_bind(papr_exchange *x, papr_hip_ctx *ctx)
     // One communicator cannot hold two ranks of one device (bin/papr with PAPR_OVERSUBSCRIBE): the threads settle
     // through the hub whether every shard has a GPU of its own; if not, the handles stay what papr_exchange_open_local
     // made them.
+    // Every thread selects its device FIRST and the threads tell each other through the hub whether that worked: a thread
+    // that cannot go on must say so before anybody is inside ncclCommInitRank, which only returns when all ranks joined.
+    start_watchdog(x);
+    const bool dev_ok = hipSetDevice(ctx->device) == hipSuccess;
     if (x->hub) {
         std::vector<uint64_t> devs((size_t)x->world);
-        const uint64_t mine = (uint64_t)ctx->device;
+        const uint64_t mine = (uint64_t)(uint32_t)ctx->device | (dev_ok ? 0ull : 1ull << 32);
         int rc = allgather_bytes(x, &mine, devs.data(), sizeof(uint64_t));
         if (rc)
             return rc;
+        for (uint64_t d : devs)
+            if (d >> 32)
+                return dev_ok ? xfail(x, PAPR_E_STATE, "another shard's thread could not select its device (hipSetDevice(%d))", (int)(uint32_t)d)
+                              : xfail(x, PAPR_E_HIP, "hipSetDevice(%d) failed", ctx->device);
         std::sort(devs.begin(), devs.end());
         if (std::adjacent_find(devs.begin(), devs.end()) != devs.end())
             return PAPR_OK;
     }
-    if (hipSetDevice(ctx->device) != hipSuccess)
+    if (!dev_ok)
         return xfail(x, PAPR_E_HIP, "hipSetDevice(%d) failed", ctx->device);
     const ncclUniqueId uid = x->hub ? x->hub->uid : x->solo_uid;
-    const ncclResult_t r = rccl()->CommInitRank(&x->comm, x->world, uid, x->rank);  // (every thread is in here at once)
+    ncclResult_t r;
+    {
+        Waiting w(x, "ncclCommInitRank");
+        r = rccl()->CommInitRank(&x->comm, x->world, uid, x->rank);  // (every thread is in here at once)
+    }
     if (r != ncclSuccess) {
         x->comm = nullptr;
         return xfail(x, PAPR_E_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", x->rank, x->world,
@@ -560,28 +700,43 @@ void papr_exchange_abort(papr_exchange *x)
 {
     if (!x)
         return;
-    if (x->hub) {
-        std::vector<papr_exchange *> members;
-        {
-            std::lock_guard<std::mutex> g(x->hub->m);
-            x->hub->failed = true;
-            x->hub->cv.notify_all();
-            members = x->hub->members;
+    // End one member's communicator.  `aborted` first: its owner queues nothing more (XNCCL).  Then ncclCommAbort under the
+    // communicator's mutex — unless the owner holds it for longer than a moment, which means it is INSIDE an RCCL call
+    // waiting for a peer (the first collective of a kind connects the ranks and returns when all of them called it): that
+    // is the wait ncclCommAbort exists to end, so it is called without the mutex then.
+    auto end_comm = [](papr_exchange *m) {
+        m->aborted.store(true);
+        const bool got = m->comm_m.try_lock_for(std::chrono::milliseconds(500));
+        if (m->comm && !m->comm_ended && rccl() && rccl()->CommAbort) {
+            m->comm_ended = true;
+            (void)rccl()->CommAbort(m->comm);
         }
+        if (got)
+            m->comm_m.unlock();
+    };
+    if (x->hub) {
+        // under the hub's mutex: papr_exchange_close takes it to strike a handle off `members` before the handle is
+        // deleted, so every member seen here stays alive until this returns
+        std::lock_guard<std::mutex> g(x->hub->m);
+        x->hub->failed = true;
+        x->hub->cv.notify_all();
         // peers that wait inside (or for) an RCCL collective are released by aborting the communicators
-        for (papr_exchange *m : members)
-            if (m && m->comm && rccl() && rccl()->CommAbort && !m->aborted.exchange(true))
-                (void)rccl()->CommAbort(m->comm);
+        for (papr_exchange *m : x->hub->members)
+            if (m)
+                end_comm(m);
         return;
     }
-    if (x->comm && rccl() && rccl()->CommAbort && !x->aborted.exchange(true))
-        (void)rccl()->CommAbort(x->comm);  // (one process per GPU: the peers' collectives fail instead of waiting)
+    end_comm(x);  // (one process per GPU: the peers' collectives fail instead of waiting)
 }
 
 void papr_exchange_close(papr_exchange *x)
 {
     if (!x)
         return;
+    if (x->watchdog.joinable()) {
+        x->watchdog_stop.store(true);
+        x->watchdog.join();
+    }
     if (x->hub) {
         bool last;
         {
@@ -597,13 +752,173 @@ void papr_exchange_close(papr_exchange *x)
     }
     if (x->ctx)
         (void)hipSetDevice(x->ctx->device);
-    if (x->comm && rccl() && !x->aborted.load())
-        (void)rccl()->CommDestroy(x->comm);
+    {
+        std::lock_guard<std::timed_mutex> g(x->comm_m);
+        if (x->comm && rccl() && !x->comm_ended)
+            (void)rccl()->CommDestroy(x->comm);
+        x->comm = nullptr;  // (only here: the owner's close)
+    }
     if (x->d_send) (void)hipFree(x->d_send);
     if (x->d_recv) (void)hipFree(x->d_recv);
     if (x->h_send) (void)hipHostFree(x->h_send);
     if (x->h_recv) (void)hipHostFree(x->h_recv);
     delete x;
+}
+
+// ---- self-test ---------------------------------------------------------------------------------------------------
+// Every collective the sharded step uses, once, on tiny buffers with contents every rank can predict for every other
+// rank — so that a first run on N GPUs that goes wrong says WHICH collective did, instead of hanging in the step.
+namespace {
+inline unsigned char st_byte(int r, size_t i) { return (unsigned char)(0xA5u ^ (unsigned)(r * 37 + (int)i * 11 + 1)); }
+inline uint64_t st_word(int r, size_t k) { return (uint64_t)(r + 1) * 1000003ull + (uint64_t)k * k + 7; }
+inline size_t st_vsize(int r) { return 64 + 32 * (size_t)(r % 5); }  // (unequal on purpose)
+}  // namespace
+
+int papr_exchange_selftest(papr_exchange *x, papr_hip_ctx *ctx, int verbose)
+{
+    if (!x)
+        return PAPR_E_ARG;
+    const int world = x->world, me = x->rank;
+    const bool say = verbose && me == 0;
+    const char *transport = x->comm ? "RCCL" : x->hub ? "threads" : "caller's collectives";
+    auto bad = [&](const char *what, const char *detail) {
+        xfail(x, PAPR_E_STATE, "exchange self-test: %s FAILED on rank %d of %d (%s): %s", what, me, world, transport, detail);
+        fprintf(stderr, "papr %s\n", x->err);
+        char keep[256];
+        memcpy(keep, x->err, sizeof(keep));
+        papr_exchange_abort(x);  // the peers are not left waiting in the next collective
+        memcpy(x->err, keep, sizeof(keep));
+        return PAPR_E_STATE;
+    };
+    auto ok = [&](const char *what, double us) {
+        if (say)
+            fprintf(stderr, "papr exchange self-test: %-44s ok  %8.1f us  (%d rank%s, %s)\n", what, us, world, world == 1 ? "" : "s", transport);
+    };
+    constexpr size_t kRec = 96, kWords = 301;
+    std::vector<unsigned char> send, recv;
+    std::vector<uint64_t> words(kWords), want(kWords);
+    try {
+        send.resize(256);
+        recv.resize(256 * (size_t)world + 256);
+    } catch (...) {
+        return xfail(x, PAPR_E_NOMEM, "out of host memory");
+    }
+    for (size_t k = 0; k < kWords; k++) {
+        want[k] = 0;
+        for (int r = 0; r < world; r++)
+            want[k] += st_word(r, k);
+    }
+    // 1. host-level all-gather (the agreement, programs that outgrew their slot)
+    for (size_t i = 0; i < kRec; i++)
+        send[i] = st_byte(me, i);
+    double t0 = now_us();
+    int rc = allgather_bytes(x, send.data(), recv.data(), kRec);
+    if (rc)
+        return bad("host-level all-gather (96 B per rank)", x->err);
+    for (int r = 0; r < world; r++)
+        for (size_t i = 0; i < kRec; i++)
+            if (recv[(size_t)r * kRec + i] != st_byte(r, i))
+                return bad("host-level all-gather (96 B per rank)", "a rank's record arrived with other bytes than it sent");
+    ok("host-level all-gather (96 B per rank)", now_us() - t0);
+    // 2. host-level all-reduce
+    for (size_t k = 0; k < kWords; k++)
+        words[k] = st_word(me, k);
+    t0 = now_us();
+    rc = allreduce_u64(x, words.data(), kWords);
+    if (rc)
+        return bad("host-level all-reduce (301 x u64)", x->err);
+    if (!(world == 1 && (x->use_ops || !x->comm)) && words != want)
+        return bad("host-level all-reduce (301 x u64)", "the sums are not the sums of what the ranks sent");
+    ok("host-level all-reduce (301 x u64)", now_us() - t0);
+    if (!ctx || !xch_in_stream(x, ctx)) {
+        x->selftest_done = true;
+        return PAPR_OK;
+    }
+    // 3.-5. the in-stream collectives on device buffers (the single-wait step's)
+    size_t vtotal = 0;
+    std::vector<size_t> sizes((size_t)world), offs((size_t)world + 1);
+    for (int r = 0; r < world; r++) {
+        sizes[(size_t)r] = st_vsize(r);
+        offs[(size_t)r] = vtotal;
+        vtotal += (st_vsize(r) + 15) & ~(size_t)15;
+    }
+    offs[(size_t)world] = vtotal;
+    const size_t need = std::max<size_t>({kRec * (size_t)world, vtotal, kWords * 8}) + 256;
+    unsigned char *d_s = nullptr, *d_r = nullptr;
+    XHIP(x, hipSetDevice(ctx->device));
+    XHIP(x, hipMalloc((void **)&d_s, 4096));
+    if (hipMalloc((void **)&d_r, need) != hipSuccess) {
+        (void)hipFree(d_s);
+        return xfail(x, PAPR_E_NOMEM, "cannot allocate the self-test's device buffers");
+    }
+    std::vector<unsigned char> back(need);
+    auto run = [&](const char *what, const void *src, size_t src_bytes, size_t back_bytes, auto &&queue, auto &&check) -> int {
+        if (hipMemcpy(d_s, src, src_bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemset(d_r, 0, need) != hipSuccess)
+            return bad(what, "hipMemcpy to the device failed");
+        const double t = now_us();
+        int qrc = queue();
+        if (qrc)
+            return bad(what, x->err);
+        hipError_t e;
+        {
+            Waiting w(x, what);
+            e = hipStreamSynchronize(ctx->stream);
+        }
+        const double us = now_us() - t;
+        if (e != hipSuccess || x->aborted.load())
+            return bad(what, e != hipSuccess ? hipGetErrorString(e) : (x->timed_out ? x->wd_err : kCancelled));
+        if (hipMemcpy(back.data(), d_r, back_bytes, hipMemcpyDeviceToHost) != hipSuccess)
+            return bad(what, "hipMemcpy from the device failed");
+        if (!check())
+            return bad(what, "the device buffer does not hold what the ranks sent");
+        ok(what, us);
+        return PAPR_OK;
+    };
+    rc = run("in-stream all-gather (96 B per rank)", send.data(), kRec, kRec * (size_t)world,
+             [&] { return xch_allgather_dev(x, ctx, d_s, d_r, kRec); },
+             [&] {
+                 for (int r = 0; r < world; r++)
+                     for (size_t i = 0; i < kRec; i++)
+                         if (back[(size_t)r * kRec + i] != st_byte(r, i))
+                             return false;
+                 return true;
+             });
+    if (rc == PAPR_OK) {
+        std::vector<unsigned char> mine(st_vsize(me));
+        for (size_t i = 0; i < mine.size(); i++)
+            mine[i] = st_byte(me + 100, i);
+        rc = run("in-stream all-gather-v (64..192 B, unequal)", mine.data(), mine.size(), vtotal,
+                 [&] { return xch_allgatherv_dev(x, ctx, d_s, d_r, sizes.data(), offs.data()); },
+                 [&] {
+                     for (int r = 0; r < world; r++)
+                         for (size_t i = 0; i < sizes[(size_t)r]; i++)
+                             if (back[offs[(size_t)r] + i] != st_byte(r + 100, i))
+                                 return false;
+                     return true;
+                 });
+    }
+    if (rc == PAPR_OK) {
+        for (size_t k = 0; k < kWords; k++)
+            words[k] = st_word(me, k);
+        rc = run("in-stream all-reduce (301 x u64)", words.data(), kWords * 8, kWords * 8,
+                 [&] { return xch_allreduce_u64_dev(x, ctx, d_s, d_r, kWords); },
+                 [&] { return memcmp(back.data(), want.data(), kWords * 8) == 0; });
+    }
+    (void)hipFree(d_s);
+    (void)hipFree(d_r);
+    if (rc == PAPR_OK)
+        x->selftest_done = true;
+    return rc;
+}
+
+// PAPR_XCH_SELFTEST=1: once per handle, in front of the first step that has peers (papr_hip_analyze)
+int papr_exchange_selftest_once(papr_exchange *x, papr_hip_ctx *ctx)
+{
+    if (!x || x->selftest_done || !env_int("PAPR_XCH_SELFTEST", 0))
+        return PAPR_OK;
+    if (x->world == 1 && !x->comm)
+        return PAPR_OK;
+    return papr_exchange_selftest(x, ctx, 1);
 }
 
 int papr_exchange_stats(papr_exchange *x, const papr_stats *local, papr_stats *total, double *sum_before, papr_stats *all)

@@ -808,6 +808,134 @@ static int papr_hip_estimate_file_impl(papr_hip_ctx *ctx, const char *path, uint
     return PAPR_OK;
 }
 
+
+// ---- a stream that cannot be positioned (a FIFO, a pipe, a socket) ---------------------------------------------------
+// The reference fopen()s whatever it is given (papr.c:62, 93) and reads a pipe like a file, 64 KiB at a time, to its end:
+// pass 1 sees every sample.  Its length is only known at the end, so the shard grows as the bytes arrive: ONE reader
+// (this thread: read() fills a pinned staging buffer while the previous buffers' copies are on the link), the bytes land
+// in HBM where the file's would, and the tail rules (papr.c:102-103: a lone last float is paired with what the static
+// buffer still holds in its slot, stray bytes overwrite that float's low bytes) are applied from the bytes in HBM once
+// the length is known.  What the reference does NOT get from a pipe is its pass 2 (fseeko fails, EOF stays set:
+// papr.c:142-143 / 174-175): that is the caller's to reproduce (bin/papr prints zero counts).
+static int papr_hip_load_stream_impl(papr_hip_ctx *ctx, int fd, uint64_t *nsamples_out)
+{
+    if (!ctx || fd < 0)
+        return PAPR_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    memset(&ctx->ingest, 0, sizeof(ctx->ingest));
+    const double t_begin = now_s();
+    HIPCHK(ctx, make_staging(ctx));
+    release_shard(ctx);
+    const size_t slack = (size_t)PAPR_TILE_SAMPLES_MAX * 8;
+    unsigned char *dev = nullptr;
+    size_t cap = 0, total = 0;
+    std::vector<hipEvent_t> done((size_t)ctx->num_buf, nullptr);
+    auto cleanup = [&](int rc) {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (hipEvent_t e : done)
+            if (e)
+                (void)hipEventDestroy(e);
+        if (rc != PAPR_OK && dev)
+            (void)hipFree(dev);
+        return rc;
+    };
+    auto grow = [&](size_t need) -> int {  // HBM for `need` bytes of stream (+ slack): doubled, what is there moves over
+        if (need + slack <= cap)
+            return PAPR_OK;
+        if (need + slack > ctx->hbm_budget)
+            return fail(ctx, PAPR_E_NOMEM, "the stream is longer than the HBM budget (%zu MiB): a stream that cannot be read "
+                        "twice has to stay resident", ctx->hbm_budget >> 20);
+        size_t want = std::max<size_t>(cap * 2, (size_t)256 << 20);
+        while (want < need + slack)
+            want *= 2;
+        want = std::min(want, ctx->hbm_budget);
+        unsigned char *bigger = nullptr;
+        if (hipMalloc((void **)&bigger, want) != hipSuccess) {
+            (void)hipGetLastError();
+            want = need + slack;  // (no room for the doubled size: exactly what is needed now)
+            if (hipMalloc((void **)&bigger, want) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(ctx, PAPR_E_NOMEM, "hipMalloc(%zu bytes) for the growing shard failed", want);
+            }
+        }
+        if (dev) {
+            HIPCHK(ctx, hipMemcpyAsync(bigger, dev, total, hipMemcpyDeviceToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, hipFree(dev));
+        }
+        dev = bigger;
+        cap = want;
+        return PAPR_OK;
+    };
+    bool eof = false;
+    for (uint64_t k = 0; !eof; k++) {
+        const int b = (int)(k % (uint64_t)ctx->num_buf);
+        if (done[(size_t)b])
+            HIPCHK(ctx, hipEventSynchronize(done[(size_t)b]));  // (this buffer's last copy has left it)
+        unsigned char *host = (unsigned char *)ctx->h_stage[b];
+        size_t got = 0;
+        const double t_read = now_s();
+        while (got < ctx->stage_bytes) {
+            const ssize_t r = read(fd, host + got, ctx->stage_bytes - got);
+            if (r < 0 && errno == EINTR)
+                continue;
+            if (r < 0)
+                return cleanup(fail(ctx, PAPR_E_IO, "read from the stream failed: %s", strerror(errno)));
+            if (r == 0) {
+                eof = true;
+                break;
+            }
+            got += (size_t)r;
+        }
+        ctx->ingest.read_s += now_s() - t_read;
+        if (!got)
+            break;
+        int rc = grow(total + got);
+        if (rc)
+            return cleanup(rc);
+        if (hipMemcpyAsync(dev + total, host, got, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            return cleanup(fail(ctx, PAPR_E_HIP, "hipMemcpyAsync of a stream chunk failed"));
+        if (!done[(size_t)b] && hipEventCreateWithFlags(&done[(size_t)b], hipEventDisableTiming) != hipSuccess)
+            return cleanup(fail(ctx, PAPR_E_HIP, "hipEventCreate failed"));
+        HIPCHK(ctx, hipEventRecord(done[(size_t)b], ctx->stream));
+        total += got;
+        ctx->ingest.chunks++;
+    }
+    int rc = grow(total);  // (an empty stream still gets its slack: the kernels' lane loads stay in bounds)
+    if (rc)
+        return cleanup(rc);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // the reference's sample count and tail (as open_file_src derives them for a file of this length)
+    const uint64_t nfloats = total / 4, stray = total % 4;
+    const bool odd = (nfloats & 1u) != 0;
+    const uint64_t nsamples = (nfloats + 1) / 2;
+    if (odd) {
+        const uint64_t chunk = 16384, nfull = nfloats / chunk, rem = nfloats % chunk;
+        unsigned char bytes[4] = {0, 0, 0, 0};
+        if (nfull >= 1)
+            HIPCHK(ctx, hipMemcpy(bytes, dev + ((nfull - 1) * chunk + rem) * 4, 4, hipMemcpyDeviceToHost));
+        if (stray)
+            HIPCHK(ctx, hipMemcpy(bytes, dev + nfloats * 4, stray, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(dev + nfloats * 4, bytes, 4, hipMemcpyHostToDevice));
+    }
+    cleanup(PAPR_OK);
+    ctx->d_iq = (float *)dev;
+    ctx->owns_iq = true;
+    ctx->cap = (cap - slack) / 8;
+    ctx->n = nsamples;
+    ctx->base = 0;
+    ctx->loaded = ctx->resident = true;
+    ctx->shard_flags = odd ? PAPR_FLAG_ODD_TAIL : 0;
+    ctx->ingest.resident = 1;
+    ctx->ingest.reader_threads = 1;
+    ctx->ingest.file_passes = 1;
+    ctx->ingest.setup_s = 0;
+    ctx->ingest.drain_s = now_s() - t_begin - ctx->ingest.read_s;
+    if (nsamples_out)
+        *nsamples_out = nsamples;
+    return PAPR_OK;
+}
+
 int papr_hip_get_ingest_timing(const papr_hip_ctx *ctx, papr_hip_ingest_timing *out)
 {
     if (!ctx || !out)
@@ -824,6 +952,11 @@ int papr_hip_estimate_file(papr_hip_ctx *ctx, const char *path, uint64_t first_s
 int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples)
 {
     return guarded(ctx, [&] { return papr_hip_load_file_impl(ctx, path, first_sample, nsamples); });
+}
+
+int papr_hip_load_stream(papr_hip_ctx *ctx, int fd, uint64_t *nsamples)
+{
+    return guarded(ctx, [&] { return papr_hip_load_stream_impl(ctx, fd, nsamples); });
 }
 
 int papr_hip_load_file_sweep(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples,

@@ -458,6 +458,9 @@ int xch_allgather_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev,
 int xch_allgatherv_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev, void *recv_dev, const size_t *sizes,
                        const size_t *offs);
 int xch_allreduce_u64_dev(papr_exchange *x, papr_hip_ctx *ctx, const void *send_dev, void *recv_dev, size_t count);
+void xch_wait_begin(papr_exchange *x, const char *what);  // PAPR_XCH_TIMEOUT_S: this rank now waits for its peers ...
+void xch_wait_end(papr_exchange *x);                      // ... and no longer
+bool xch_cancelled(const papr_exchange *x);               // papr_exchange_abort has run (by a peer, or the watchdog)
 int run_exact_swept(papr_hip_ctx *ctx, double before, uint64_t n_total, const double *before_dev = nullptr,
                     const unsigned long long *n_total_dev = nullptr, unsigned char *slot_dev = nullptr, uint64_t slot_cap = 0);
 int mark_program_ready(papr_hip_ctx *ctx);

@@ -633,7 +633,10 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
                 return fail(ctx, xrc, "exchange: %s", papr_exchange_last_error(x));
             nmax = *std::max_element(all.begin(), all.end());
         }
-        ctx->xprog_slot = exact ? exact_program_slot_bytes(nmax) : 0;
+        const size_t new_slot = exact ? exact_program_slot_bytes(nmax) : 0;
+        if (new_slot != ctx->xprog_slot)
+            ctx->xprog_sizes.clear();  // (slots grown under another agreement belong to it: every rank starts again alike)
+        ctx->xprog_slot = new_slot;
         int prc = prepare();
         uint64_t ok = (prc == PAPR_OK && local_ok) ? 1u : 0u;
         const int xrc = papr_exchange_counts(x, &ok, 1);
@@ -831,9 +834,17 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
         XCHK(hipMemcpyAsync(ctx->h_xvec, d_xvec_sum, (size_t)kXvecWords * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     ctx->trace.mark("queued");
+    if (peers)
+        xch_wait_begin(x, "the step's one wait behind its in-stream collectives");
     run_overlap_work(ctx);  // (exact-sum mode: the program's replay, while the recount runs)
     ctx->trace.mark("overlap_done");
-    XCHK(hipStreamSynchronize(ctx->stream));
+    const hipError_t sync_e = hipStreamSynchronize(ctx->stream);
+    if (peers) {
+        xch_wait_end(x);
+        if (xch_cancelled(x))  // (a peer gave up, or PAPR_XCH_TIMEOUT_S ran out: whatever the stream holds is no result)
+            return leave(fail(ctx, PAPR_E_STATE, "exchange: %s", papr_exchange_last_error(x)));
+    }
+    XCHK(sync_e);
     ctx->trace.mark("synced");
 #undef XCHK
     ctx->program_pending = false;

@@ -676,6 +676,11 @@ uint64_t ts_hip_sync_error_count(const ts_hip_ctx *ctx)
     return ctx ? (uint64_t)ctx->errors.size() : 0;
 }
 
+size_t ts_hip_result_size(void)
+{
+    return sizeof(ts_scan_result);
+}
+
 uint64_t ts_hip_discontinuity_count(const ts_hip_ctx *ctx)
 {
     return ctx ? (uint64_t)ctx->discs.size() : 0;

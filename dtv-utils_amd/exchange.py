@@ -66,6 +66,8 @@ def _lib():
         L.papr_exchange_is_rccl.restype = i32
         L.papr_exchange_abort.argtypes = [vp]
         L.papr_exchange_abort.restype = None
+        L.papr_exchange_selftest.argtypes = [vp, vp, C.c_int]
+        L.papr_exchange_selftest.restype = C.c_int
         L.papr_exchange_close.argtypes = [vp]
         L.papr_exchange_close.restype = None
         L.papr_exchange_last_error.argtypes = [vp]
@@ -84,7 +86,7 @@ def _lib():
 ABI_SYMBOLS = ("papr_exchange_unique_id", "papr_exchange_open_rccl", "papr_exchange_open_ops", "papr_exchange_close",
                "papr_exchange_last_error", "papr_exchange_stats", "papr_exchange_counts", "papr_exchange_exact_sum",
                "papr_exchange_get_timing", "papr_exchange_open_local", "papr_exchange_abort",
-               "papr_exchange_open_rccl_local", "papr_exchange_bind", "papr_exchange_is_rccl")
+               "papr_exchange_open_rccl_local", "papr_exchange_bind", "papr_exchange_is_rccl", "papr_exchange_selftest")
 
 
 class Exchange:
@@ -140,6 +142,13 @@ class Exchange:
 
     def abort(self):
         self._L.papr_exchange_abort(self._x)
+
+    def selftest(self, gpu=None, verbose: bool = True):
+        """papr_exchange_selftest: every collective the sharded step uses, once, on tiny buffers with predictable contents
+        (all ranks call it together; rank 0 prints one stderr line per collective with its microseconds)."""
+        self._chk(self._L.papr_exchange_selftest(self._x, gpu._ctx if gpu is not None else None, int(verbose)),
+                  "papr_exchange_selftest")
+        return self
 
     @classmethod
     def rccl(cls, gpu, rank: int, world: int, group=None) -> "Exchange":

@@ -32,12 +32,14 @@
  * There is no CPU fallback: without a usable GPU the program exits 254.
  */
 #define _FILE_OFFSET_BITS 64
+#include <errno.h>
 #include <fcntl.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -52,6 +54,7 @@ typedef struct shard {
     papr_hip_ctx *ctx;
     papr_exchange *xch;
     int device, index, graph, exact, ingest_sweep;
+    int stream_fd;        /* >= 0: the input cannot be positioned (a FIFO, a pipe): read once from this descriptor */
     const char *path;
     uint64_t first, count;
     float *levels;        /* PAPR_HIP_MAX_LEVELS each */
@@ -104,7 +107,7 @@ static void *shard_thread(void *arg)
         return NULL;
     }
     s->t_open = now_s();
-    if (s->ingest_sweep == 1) {
+    if (s->ingest_sweep == 1 && s->stream_fd < 0) {
         /* "when the file is streamed": does any shard exceed its GPU's HBM budget?  (decided together: every thread
          * must take the same path through the exchanges) */
         uint64_t nofit = papr_hip_shard_fits(s->ctx, s->count) == 0 ? 1u : 0u;
@@ -115,7 +118,9 @@ static void *shard_thread(void *arg)
         }
         s->ingest_sweep = nofit > 0 ? 2 : 0;
     }
-    if (s->ingest_sweep) {
+    if (s->stream_fd >= 0) {
+        rc = papr_hip_load_stream(s->ctx, s->stream_fd, &s->count);
+    } else if (s->ingest_sweep) {
         /* one read of the FILE for both passes: a 1-in-64 sample of every shard gives the mean to ~1e-4, the level
          * table it implies is widened into bands, and pass 2 rides along with pass 1 on the ingest */
         papr_stats est, est_total;
@@ -189,11 +194,22 @@ int main(int argc, char **argv)
         fprintf(stderr, "Cannot open bitstream file <%s>\n", path);
         exit(-1);
     }
-    fclose(probe);
+    /* The reference reads whatever fopen() gave it (papr.c:93, 100-101).  An input that cannot be positioned — a FIFO, a
+     * pipe (`papr <(producer)`), a socket — is read ONCE, here through the descriptor that was just opened (a second open
+     * of a FIFO would be a second reader); the reference's own second pass finds such a stream at its end (fseeko fails and
+     * the EOF flag stays set: papr.c:142-143 / 174-175) and counts nothing, which is printed below as it prints it. */
+    int stream_fd = -1;
+    {
+        struct stat sb;
+        if (fstat(fileno(probe), &sb) == 0 && !S_ISREG(sb.st_mode) && lseek(fileno(probe), 0, SEEK_CUR) == (off_t)-1 && errno == ESPIPE)
+            stream_fd = fileno(probe);
+    }
+    if (stream_fd < 0)
+        fclose(probe);
 
     const double t0 = now_s();
     uint64_t nsamples = 0;
-    if (papr_file_samples(path, &nsamples) != PAPR_OK) {
+    if (stream_fd < 0 && papr_file_samples(path, &nsamples) != PAPR_OK) {
         fprintf(stderr, "Cannot open bitstream file <%s>\n", path);
         exit(-1);
     }
@@ -216,6 +232,8 @@ int main(int argc, char **argv)
         if (ngpu < 1)
             ngpu = 1;
     }
+    if (stream_fd >= 0)
+        ngpu = 1; /* (one reader, one shard: the length is known when the stream ends) */
     env = getenv("PAPR_OVERSUBSCRIBE");
     const int oversubscribe = env && atoi(env) > 0;
     if (ngpu > visible && !oversubscribe)
@@ -239,6 +257,7 @@ int main(int argc, char **argv)
         sh[g].path = path;
         sh[g].graph = graph;
         sh[g].exact = exact;
+        sh[g].stream_fd = stream_fd;
         sh[g].first = first;
         sh[g].count = first + per > nsamples ? nsamples - first : per;
         used++;
@@ -332,7 +351,12 @@ int main(int argc, char **argv)
     const double mean = r->mean;
     const float papr = r->papr;
     const int nlevels = r->nlevels;
-    const uint64_t *count = sh[0].counts;
+    uint64_t *count = sh[0].counts;
+    if (stream_fd >= 0) {
+        nsamples = total.n;
+        for (int j = 0; j < nlevels; j++) /* the reference's pass 2 over a stream it cannot rewind: at EOF at once */
+            count[j] = 0;
+    }
     if (exact && !r->exact_sum && isfinite(total.sum))
         /* stdout stays the reference's format; the mean (and, rarely, a threshold) now comes from the parallel tree
          * sum, which may differ from the reference's sequential sum in the last printed digit: say so */

@@ -62,6 +62,19 @@ int papr_exchange_is_rccl(const papr_exchange *x);
  * are already queued on the peers' streams.  No-op for caller-supplied collectives.  libpaprhip calls it itself when a
  * step fails locally after its collectives have begun (papr_hip_analyze: FAILURE WITH PEERS). */
 void papr_exchange_abort(papr_exchange *x);
+/* Self-test: every collective the sharded step uses, once, on tiny buffers whose contents every rank can predict for every
+ * other rank — host-level all-gather (96 B) and all-reduce (301 x u64), and, where the transport runs collectives in the
+ * context's stream (RCCL; PAPR_XCH_IN_STREAM=2: the stand-ins), the in-stream all-gather, the all-gather-v with unequal
+ * sizes (one group of ncclBroadcasts) and the all-reduce on device buffers.  All ranks call it together.  verbose: rank 0
+ * prints one stderr line per collective with its microseconds; a failure names the collective on the rank that saw it,
+ * cancels the exchange (papr_exchange_abort) and returns PAPR_E_STATE.  ctx may be NULL (host-level collectives only).
+ * PAPR_XCH_SELFTEST=1 makes papr_hip_analyze run it once per handle in front of its first step with peers (bin/papr,
+ * bench.py): a first run on N GPUs that goes wrong then says which collective did instead of hanging in the step.
+ * PAPR_XCH_TIMEOUT_S=<seconds> (off by default): a rank that waits longer than that for its peers — at the in-process hub,
+ * in a host-level exchange, in the step's one wait behind in-stream collectives — says so on stderr and cancels the
+ * exchange: the wait returns PAPR_E_STATE and the peers are released.  Inside ncclCommInitRank, where there is no
+ * communicator to abort yet, the process is ended with status 254 (PAPR_XCH_TIMEOUT_EXIT=0: only the message). */
+int papr_exchange_selftest(papr_exchange *x, papr_hip_ctx *ctx, int verbose);
 
 #ifdef __cplusplus
 }

@@ -41,7 +41,9 @@
 extern "C" {
 #endif
 
-#define PAPR_HIP_ABI_VERSION 4
+/* 5: ts_scan_result grew (continuity-counter lines), ts_format_report_all took two more arguments, the sum programs are
+ * version 3, papr_exchange_selftest / ts_hip_result_size were added: a caller built against version 4 must be rebuilt */
+#define PAPR_HIP_ABI_VERSION 5
 
 enum {
     PAPR_OK = 0,
@@ -99,6 +101,14 @@ int papr_file_samples(const char *path, uint64_t *nsamples);
  * buffer) is reproduced when the range includes the file's last sample.  The
  * copy to HBM is double-buffered and overlapped with the pass-1 kernel. */
 int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples);
+/* The whole of a stream that cannot be positioned — a FIFO, a pipe, a socket: the reference fopen()s and reads those like
+ * any file (papr.c:62, 93, 100-101) — read ONCE from the open descriptor `fd` to its end into this context's shard, which
+ * grows in HBM as the bytes arrive (one reader, pinned staging, the copies overlapped with the reads); the sample count
+ * and the odd-float / stray-byte tail follow from the length as for a file.  *nsamples receives the count (may be NULL).
+ * A stream longer than the HBM budget is PAPR_E_NOMEM (it cannot be read a second time).  What the reference makes of
+ * such an input in pass 2 — fseeko fails, EOF stays set, every level counts zero (papr.c:142-143 / 174-175) — is the
+ * caller's to reproduce: bin/papr prints zero counts. */
+int papr_hip_load_stream(papr_hip_ctx *ctx, int fd, uint64_t *nsamples);
 /* 1 if a shard of nsamples would be kept resident in HBM by papr_hip_load_file (it fits the context's HBM
  * budget: 90 % of the free memory at open, or PAPR_HBM_BUDGET_MB), 0 if it would be re-streamed from the file
  * for every further pass. */

@@ -138,6 +138,9 @@ int ts_hip_download(ts_hip_ctx *ctx, void *bytes, uint64_t first, uint64_t nbyte
  * second when its spans meet damage more than once per 3072 packets (out->launches and out->kernel_ms count both attempts;
  * TS_SCAN_FORM=auto|full|slots chooses, a context reads it when it is opened). */
 int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out);
+/* sizeof(ts_scan_result) as the LIBRARY was built (it has grown between ABI versions: papr_hip.h, PAPR_HIP_ABI_VERSION): a
+ * caller compares it with its own before it hands ts_hip_scan or ts_walk a buffer */
+size_t ts_hip_result_size(void);
 /* EVERY sync error of the last ts_hip_scan, in the order the reference prints them (ts_scan_result holds the first
  * TS_MAX_SYNC_ERRORS inline; a stream that locks one byte off a 4-byte grid yields one `skipped 1 bytes` line per 4096
  * packets, i.e. more than that from ~3 GB on): their number, and a copy of entries [first, first + n) */

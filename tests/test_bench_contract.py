@@ -11,12 +11,38 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
+LINE_LIMIT = 6000   # bytes: what the driver's record is known to keep whole (round 4's 22 KB line was not)
+
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
         "vs_baseline", "dtype", "data", "config", "roofline", "parity_in_run"}
 
 
-def check(line, steps, warmup):
+def run_bench(cmd, tmp_path, env=None):
+    """Run bench.py; returns (the compact stdout line parsed, the full record it wrote beside it).  The checks of
+    the line itself are the driver's: ONE line, short enough to be kept, parsable out of the last 8000 characters of
+    stdout + stderr, the headline repeated in its last 2000 characters."""
+    full_path = os.path.join(str(tmp_path), "bench_full.json")
+    p = subprocess.run(cmd + ["--full-json", full_path], capture_output=True, text=True, cwd=ROOT,
+                       env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = lines[0]
+    assert len(line.encode()) <= LINE_LIMIT, len(line)
     d = json.loads(line)
+    assert json.loads(p.stdout[-8000:].splitlines()[-1]) == d
+    tail = line[-2000:]
+    assert '"headline":' in tail
+    h = json.loads("{" + tail[tail.index('"headline":'):])["headline"]
+    assert h["value"] == d["value"] and h["ms_per_step"] == d["ms_per_step"] and h["roofline_frac"] == d["roofline"]["frac"]
+    assert list(d)[-1] == "headline"
+    with open(full_path) as f:
+        full = json.load(f)
+    assert abs(full["value"] - d["value"]) < 0.06 and full["steps"] == d["steps"]
+    return d, full
+
+
+def check(d, steps, warmup):
     assert KEYS <= set(d)
     assert d["steps"] == steps and d["warmup"] == warmup and d["n_gpus"] == 1
     assert d["unit"] == "Msamples/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
@@ -29,34 +55,59 @@ def check(line, steps, warmup):
     return d
 
 
-def test_single_process_line_with_cpu_baseline():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gib", "0.5", "--steps", "4", "--warmup", "1",
-                        "--cpu-sample-gib", "0.125"], capture_output=True, text=True, cwd=ROOT)
-    assert p.returncode == 0, p.stderr
-    lines = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, p.stdout
-    d = check(lines[0], 4, 1)
-    cb = d["cpu_baseline"]
-    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
-    assert cb["gpu_stdout_identical"] is True
-    # no --mode: configs[1] is the headline, configs[2] (papr -g) rides along in the same line
-    assert d["config"]["mode"] == "default" and d["graph"]["config"]["mode"] == "graph"
-    assert d["graph"]["config"]["levels"] > 5 * d["config"]["levels"] and d["graph"]["value"] > 0
-    assert d["graph"]["roofline"]["kernel"] == d["roofline"]["kernel"]
+def test_single_process_line_with_cpu_baseline(tmp_path):
+    d, full = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gib", "0.5", "--steps", "4", "--warmup", "1",
+                         "--cpu-sample-gib", "0.125"], tmp_path)
+    check(d, 4, 1)
+    for cb in (d["cpu_baseline"], d["cpu_baseline_graph"]):
+        assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0 and cb["nproc"] >= 1
+        assert cb["gpu_stdout_identical"] is True and "GiB" in cb["sample"]
+    assert d["headline"]["cpu_baseline_value"] == d["cpu_baseline"]["value"]
+    # no --mode: configs[1] is the headline, configs[2] (papr -g) rides along: whole in the full record, one line in `legs`
+    assert d["config"]["mode"] == "default" and full["graph"]["config"]["mode"] == "graph"
+    assert full["graph"]["config"]["levels"] > 5 * d["config"]["levels"] and full["graph"]["value"] > 0
+    assert full["graph"]["roofline"]["kernel"] == d["roofline"]["kernel"]
+    legs = d["roofline"]["legs"]
+    assert {"graph", "exact", "exact_graph", "ts", "ts_damaged", "e2e_default", "e2e_graph"} <= set(legs), sorted(legs)
+    for name in ("graph", "exact", "exact_graph", "ts", "ts_damaged"):
+        assert legs[name]["frac"] == d["roofline"][name + "_frac"] > 0 and legs[name]["ms_per_step"] > 0
+    assert legs["exact"]["kernel"] == "papr_sweep3_kernel" and len(legs["exact"]["step_ms"]) == 3
+    # the pre-heat is disclosed, and what the first untimed steps on the idle GPU cost
+    assert d["config"]["preheat_steps"] == 32 and len(d["config"]["cold_first_steps_ms"]) == 5
+    assert "all" not in d["roofline"]["step_ms"] and len(full["roofline"]["step_ms"]["all"]) == 4
     # 0.5 GiB has no recorded reference stdout: parity_in_run must say so rather than claim anything
-    assert d["parity_in_run"] is None and d["graph"]["parity_in_run"] is None
+    assert d["parity_in_run"] is None and full["graph"]["parity_in_run"] is None
 
 
-def test_full_size_line_checks_itself_against_the_reference_stdout():
+def test_the_drivers_command_prints_a_line_the_driver_can_keep(tmp_path):
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` verbatim, at full size, every leg: round 4's line was 22 KB and the
+    driver's record of it `parsed: null`.  run_bench() asserts the size, that the last 8000 characters of stdout parse, and
+    that the headline sits in the last 2000."""
+    d, full = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"], tmp_path)
+    check(d, 20, 5)
+    assert d["parity_in_run"] is True and d["cpu_baseline"]["kind"] in ("reference", "port")
+    legs = d["roofline"]["legs"]
+    for name in ("graph", "exact", "exact_graph"):
+        assert legs[name]["parity_in_run"] is True, name
+    assert legs["exact"]["sum_is_the_reference_s"] is True and legs["exact_graph"]["sum_is_the_reference_s"] is True
+    assert legs["ts"]["gpu_report_identical"] is True
+    assert legs["e2e_default"]["all_stdout_identical"] is True and legs["e2e_graph"]["all_stdout_identical"] is True
+    # --preheat 0: the warm-up steps alone, and the line says so
+    d0, _ = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "5", "--preheat", "0",
+                       "--headline-only", "--no-cpu-baseline"], tmp_path)
+    assert d0["config"]["preheat_steps"] == 0 and len(d0["config"]["cold_first_steps_ms"]) == 5
+
+
+def test_full_size_line_checks_itself_against_the_reference_stdout(tmp_path):
     """The driver's invocation (10 GiB, both tables): the line's own parity flags are computed from the recorded
     stdout of the reference program for the same stream and must be true in both modes."""
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1",
-                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-2000:]
-    d = check([l for l in p.stdout.splitlines() if l.strip()][0], 5, 1)
+    d, full = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline",
+                         "--no-ts"], tmp_path)
+    check(d, 5, 1)
     assert d["parity_in_run"] is True and d["parity_golden"] == "big_spike10g.default.txt"
-    assert d["graph"]["parity_in_run"] is True and d["graph"]["parity_golden"] == "big_spike10g.graph.txt"
-    assert d["config"]["one_sweep"]["steps_resolved_from_the_sweep"] == 5
+    assert full["graph"]["parity_in_run"] is True and full["graph"]["parity_golden"] == "big_spike10g.graph.txt"
+    assert d["roofline"]["legs"]["graph"]["parity_in_run"] is True
+    assert d["config"]["one_sweep"]["resolved"] == 5 and full["config"]["one_sweep"]["steps_resolved_from_the_sweep"] == 5
 
 
 def _free_port():
@@ -67,16 +118,13 @@ def _free_port():
 
 
 @pytest.mark.parametrize("extra", [[], ["--mode", "graph"], ["--two-pass"], ["--mode", "graph", "--exact"]], ids=str)
-def test_torchrun_single_rank_uses_rccl(extra):
+def test_torchrun_single_rank_uses_rccl(extra, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--gib", "0.5",
            "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *extra]
-    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, p.stdout
-    d = check(lines[0], 3, 1)
-    assert d["config"]["exchange"].startswith("RCCL")
+    compact, d = run_bench(cmd, tmp_path)
+    check(compact, 3, 1)
+    assert compact["config"]["exchange"].startswith("RCCL")
     assert d["config"]["exact_sequential_sum"] == ("--exact" in extra)
     if "--two-pass" in extra:
         assert d["config"]["one_sweep"] is None and d["config"]["reads_of_the_shard_per_step"] == 2
@@ -95,17 +143,16 @@ def test_torchrun_single_rank_uses_rccl(extra):
 
 
 def _run_bench(nproc, gib, extra, env=None):
+    """(the FULL record of the run; the compact line is checked on the way by run_bench)"""
+    import tempfile
     cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
     if nproc > 1:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
                "--backend", "gloo"]
-    cmd += ["--gpus", str(nproc), "--gib", str(gib), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", *extra]
-    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, **(env or {})))
-    assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, p.stdout
-    return json.loads(lines[0])
+    cmd += ["--gpus", str(nproc), "--gib", str(gib), "--steps", "2", "--warmup", "1", "--preheat", "2", "--no-cpu-baseline", *extra]
+    with tempfile.TemporaryDirectory() as tmp:
+        return run_bench(cmd, tmp, env)[1]
 
 
 @pytest.mark.parametrize("mode", ["default", "graph"])
@@ -185,16 +232,17 @@ def test_sharded_step_as_one_sequence_of_launches_with_real_worlds(mode):
 
 
 @pytest.mark.parametrize("extra", [[], ["--exact"]], ids=["tree", "exact"])
-def test_two_rank_bench_line_proves_itself_at_full_size(extra):
+def test_two_rank_bench_line_proves_itself_at_full_size(extra, tmp_path):
     """What a driver's 2-GPU run prints, on one GPU (two ranks over gloo share it): 2 x 10 GiB shards of the 20 GiB
     stream, `parity_in_run` = the run's report equals the REFERENCE's recorded stdout for that stream, both tables;
     with --exact also the reference's sequential sum over the two chained shards."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
-           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", *extra]
-    p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
-    assert p.returncode == 0, p.stderr[-2000:]
-    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+           "--steps", "2", "--warmup", "1", "--cpu-sample-gib", "0.25", *extra]
+    compact, d = run_bench(cmd, tmp_path)
+    # more than one rank: headline + configs[2] only, and rank 0 still times the reference on one host core
+    assert set(compact["roofline"]["legs"]) == {"graph"} and compact["cpu_baseline"]["value"] > 0
+    assert compact["cpu_baseline"]["gpu_stdout_identical"] is True
     assert d["n_gpus"] == 2 and d["config"]["samples_total"] == 2 * 1342177280
     assert d["parity_in_run"] is True and d["parity_golden"] == "big_spike20g.default.txt"
     assert d["graph"]["parity_in_run"] is True and d["graph"]["parity_golden"] == "big_spike20g.graph.txt"

@@ -38,7 +38,7 @@ def _golden(name):
 
 @pytest.mark.parametrize("extra", [[], ["--exact"], ["--collectives-on-device-buffers"], ["--exact", "--collectives-on-device-buffers"]],
                          ids=["tree", "exact", "tree, exchanges between the kernels", "exact, exchanges between the kernels"])
-def test_eight_rank_bench_line_proves_itself_at_full_size(extra, manifest):
+def test_eight_rank_bench_line_proves_itself_at_full_size(extra, manifest, tmp_path):
     """BASELINE configs[3] on the one GPU: 8 ranks x 10 GiB over gloo.  The third form takes the way an 8-GPU run over RCCL
     takes — the three exchanges as collectives on device buffers inside the step's sequence of launches — with the gloo
     callbacks standing in for ncclAllGather / ncclAllReduce (PAPR_XCH_IN_STREAM=2)."""
@@ -52,10 +52,17 @@ def test_eight_rank_bench_line_proves_itself_at_full_size(extra, manifest):
         pytest.skip(f"8 x 10 GiB shards + stashes need ~100 GiB of HBM; {free >> 30} GiB free")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo",
-           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", *extra]
+           "--steps", "2", "--warmup", "1", "--preheat", "4", "--no-cpu-baseline", "--no-e2e",
+           "--full-json", str(tmp_path / "full.json"), *extra]
     p = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
-    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+    # what an 8-GPU driver run would keep: ONE short line whose headline is the 80 GiB job's ...
+    line = [l for l in p.stdout.splitlines() if l.strip()][-1]
+    compact = json.loads(line)
+    assert len(line) <= 6000 and compact["n_gpus"] == 8 and compact["parity_in_run"] is True
+    assert compact["roofline"]["legs"]["graph"]["parity_in_run"] is True and set(compact["roofline"]["legs"]) == {"graph"}
+    # ... and the full record beside it
+    d = json.load(open(tmp_path / "full.json"))
     assert d["n_gpus"] == 8 and d["config"]["samples_total"] == 8 * 1342177280 == manifest["big_spike80g"]["nsamples"]
     if env.get("PAPR_XCH_IN_STREAM") == "2":
         assert d["exchange"]["in_stream_collectives"] >= 6 and d["exchange"]["stats"]["calls"] == 0, d["exchange"]
@@ -93,6 +100,31 @@ def _big_file_dir(need):
     return None
 
 
+def _make_big_file(orc, path, n, tmp_dir):
+    """The spike stream of n samples as a file, from the DEVICE generator (tools/mkcfile_gpu.py: a 256 GiB file took
+    oracle/mkcfile's 64 processes 315 s), and — the recorded stdouts were made from oracle/mkcfile's files — three 1 MiB
+    windows of it against oracle/mkcfile's own bytes for the same ranges."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import mkcfile_gpu
+    seconds = mkcfile_gpu.make(path, n)
+    assert os.path.getsize(path) == n * 8
+    win = 131072
+    probe = os.path.join(tmp_dir, f"papr_probe_{os.getpid()}.cfile")
+    try:
+        for first in (0, (n // 2) // 8192 * 8192 + 8192 * 3, n - win):
+            if os.path.exists(probe):
+                os.unlink(probe)
+            subprocess.check_call([orc.MKCFILE, probe, str(n), "--spike", "--part", str(first), str(win)])   # (a sparse file)
+            with open(probe, "rb") as f, open(path, "rb") as g:
+                f.seek(first * 8)
+                g.seek(first * 8)
+                assert f.read(win * 8) == g.read(win * 8), f"the device generator's bytes differ from oracle/mkcfile's at sample {first}"
+    finally:
+        if os.path.exists(probe):
+            os.unlink(probe)
+    return seconds
+
+
 @pytest.fixture(scope="module")
 def file40g(orc):
     n = 5368709120   # 40 GiB
@@ -100,17 +132,8 @@ def file40g(orc):
     if d is None:
         pytest.skip("no filesystem on this box has 44 GiB free")
     path = os.path.join(d, f"papr_big_spike40g_{os.getpid()}.cfile")
-    workers = min(32, os.cpu_count() or 8)
-    per = (n // workers + 8191) // 8192 * 8192
     try:
-        procs = []
-        for w in range(workers):
-            first = w * per
-            if first >= n:
-                break
-            procs.append(subprocess.Popen([orc.MKCFILE, path, str(n), "--spike", "--part", str(first), str(min(per, n - first))]))
-        assert all(p.wait() == 0 for p in procs)
-        assert os.path.getsize(path) == n * 8
+        _make_big_file(orc, path, n, "/tmp")
         yield path
     finally:
         if os.path.exists(path):
@@ -136,28 +159,26 @@ def test_40_gib_file_streams_once_under_a_4_gib_budget(pkg, file40g, manifest, g
     assert info["shards_swept"] == gpus and info["shards_resolved_from_sweep"] == gpus
 
 
-# ---- configs[4] at its own size: 256 GiB (opt-in: PAPR_TEST_256G=1; ~2 min on a box with 300 GiB of /dev/shm) ----------
+# ---- configs[4] at its own size: 256 GiB, whenever the box can hold the file in /dev/shm ------------------------------------
 
 @pytest.fixture(scope="module")
 def file256g(orc):
-    if os.environ.get("PAPR_TEST_256G", "0") != "1":
-        pytest.skip("the 256 GiB file is opt-in (PAPR_TEST_256G=1): 260 GiB of /dev/shm, two minutes")
     n = 34359738368   # 256 GiB = eight shards of 2^32 samples
     need = n * 8
+    if os.environ.get("PAPR_TEST_256G", "1") == "0":
+        pytest.skip("PAPR_TEST_256G=0")
     try:
         with open("/proc/meminfo") as f:
             avail = next(int(l.split()[1]) for l in f if l.startswith("MemAvailable")) * 1024
-        if shutil.disk_usage("/dev/shm").free < need + (16 << 30) or avail < need + (64 << 30):
-            pytest.skip("this box cannot hold a 256 GiB file in /dev/shm")
+        free = shutil.disk_usage("/dev/shm").free
     except OSError:
         pytest.skip("no /dev/shm")
+    if free < need + (16 << 30) or avail < need + (64 << 30):
+        pytest.skip(f"a 256 GiB file in /dev/shm needs {(need >> 30) + 64} GiB of available memory: this box has "
+                    f"{avail >> 30} GiB (and {free >> 30} GiB free in /dev/shm)")
     path = f"/dev/shm/papr_big_spike256g_{os.getpid()}.cfile"
-    workers = 64
-    per = n // workers
     try:
-        procs = [subprocess.Popen([orc.MKCFILE, path, str(n), "--spike", "--part", str(w * per), str(per)]) for w in range(workers)]
-        assert all(p.wait() == 0 for p in procs)
-        assert os.path.getsize(path) == need
+        _make_big_file(orc, path, n, "/tmp")
         yield path
     finally:
         if os.path.exists(path):

@@ -44,6 +44,7 @@ def _worker(rank, world, port, name, graph, out_dir):
     try:
         x = exchange.Exchange.over_torch()
         assert (x.rank, x.world, x.transport) == (rank, world, "gloo")
+        x.selftest(None, verbose=True)   # the host-level collectives once, with contents every rank can predict (no GPU here)
         floats = np.fromfile(golden_path(name), dtype=np.float32)
         n = floats.size // 2
         first, count = exchange.shard_range(n, rank, world, align=8192 if n >= 8192 * world else 2)
@@ -118,3 +119,75 @@ def test_shard_range_covers_axis_without_overlap(pkg):
                 assert first == pos and (first % 8192 == 0 or count == 0)
                 pos += count
             assert pos == n
+
+
+def _hub_threads(n, body):
+    """n threads of this process, one handle of papr_exchange_open_local each; returns what body(x) returned or raised."""
+    import threading
+    from dtv_utils_amd import exchange
+    xs = exchange.Exchange.local(n)
+    out = [None] * n
+
+    def run(r):
+        try:
+            out[r] = body(xs[r])
+        except Exception as e:   # noqa: BLE001 - handed to the test
+            out[r] = e
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(n)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+        assert not t.is_alive(), "a thread is still waiting at the hub"
+    for x in xs:
+        x.close()
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_selftest_over_the_thread_hub(pkg, world):
+    """papr_exchange_selftest on the in-process transport (what bin/papr's shard threads meet at): the host-level
+    all-gather and all-reduce with contents every rank can predict for every other rank."""
+    out = _hub_threads(world, lambda x: x.selftest(None, verbose=False) and "ok")
+    assert out == ["ok"] * world, out
+
+
+def test_a_rank_that_never_arrives_is_timed_out_not_waited_for(pkg, monkeypatch):
+    """PAPR_XCH_TIMEOUT_S: three of four threads enter a collective, the fourth never does.  Without the timeout they
+    would wait for ever; with it they give up after the limit, with PAPR_E_STATE and a message that says why — and the
+    late thread finds the exchange cancelled instead of waiting in turn."""
+    import time
+    monkeypatch.setenv("PAPR_XCH_TIMEOUT_S", "0.5")
+
+    def body(x):
+        if x.rank == 3:
+            time.sleep(2.0)
+        t0 = time.perf_counter()
+        try:
+            x.counts(np.arange(4, dtype=np.uint64))
+        except pkg.PaprError as e:
+            return (round(time.perf_counter() - t0, 1), str(e))
+        return "no error"
+    out = _hub_threads(4, body)
+    for r in range(3):
+        assert isinstance(out[r], tuple) and 0.4 <= out[r][0] <= 1.5 and "cancelled" in out[r][1], out
+    assert isinstance(out[3], tuple) and out[3][0] <= 0.2 and "cancelled" in out[3][1], out
+
+
+def test_abort_releases_the_threads_at_the_hub(pkg):
+    """papr_exchange_abort from one thread: the peers' pending collective returns PAPR_E_STATE (the members are
+    walked under the hub's mutex, a handle being closed meanwhile is not touched)."""
+    import time
+
+    def body(x):
+        if x.rank == 0:
+            time.sleep(0.3)
+            x.abort()
+            return "aborted"
+        try:
+            x.counts(np.arange(4, dtype=np.uint64))
+        except pkg.PaprError as e:
+            return str(e)
+        return "no error"
+    out = _hub_threads(3, body)
+    assert out[0] == "aborted" and all("cancelled" in o for o in out[1:]), out

@@ -135,6 +135,84 @@ def test_cli_vs_reference_binary_on_fresh_files(pkg, orc, tmp_path):
             assert (got.returncode, got.stdout, got.stderr) == (want.returncode, want.stdout, want.stderr), (n, extra, mode)
 
 
+def _through_a_fifo(cmd, path, fifo, writer_chunk=1 << 16):
+    """Run `cmd <fifo>` with the bytes of `path` written into the FIFO by a thread (in pieces no larger than a pipe's
+    buffer, like a producer would)."""
+    import threading
+    if os.path.exists(fifo):
+        os.unlink(fifo)
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(path, "rb") as src, open(fifo, "wb") as dst:
+            while True:
+                b = src.read(writer_chunk)
+                if not b:
+                    break
+                try:
+                    dst.write(b)
+                except BrokenPipeError:
+                    break
+    t = threading.Thread(target=feed)
+    t.start()
+    p = subprocess.run(cmd + [fifo], capture_output=True, timeout=120)
+    t.join(30)
+    os.unlink(fifo)
+    return p
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "papr")), reason="no compiled reference")
+def test_cli_on_a_stream_that_cannot_be_rewound_prints_what_the_reference_prints(pkg, orc, tmp_path):
+    """papr.c fopen()s anything (:62, :93).  On a FIFO its pass 1 sees every sample; its fseeko (:142 / :174) fails, EOF
+    stays set, pass 2 counts nothing: every percentage prints 0.00000000.  bin/papr reads the stream once into HBM
+    (papr_hip_load_stream) and prints the same — stdout, stderr and exit status against the reference binary fed through
+    a FIFO of its own; even, odd-float and stray-byte tails, an empty stream, both modes."""
+    fifo = str(tmp_path / "in.fifo")
+    cases = [(300000, ["--spike"]), (16384 * 3 + 77, ["--extra-floats", "1"]), (777777, ["--extra-floats", "1", "--extra-bytes", "3"]),
+             (5000, ["--extra-floats", "1", "--extra-bytes", "2"]), (2500000, ["--spike", "--seed", "99"]), (0, [])]
+    for n, extra in cases:
+        path = str(tmp_path / "f.cfile")
+        if n:
+            subprocess.check_call([orc.MKCFILE, path, str(n), *extra, *(["--seed", "4711"] if "--seed" not in extra else [])])
+        else:
+            open(path, "wb").close()
+        for mode in ([], ["-g"]):
+            want = _through_a_fifo([orc.REF_CLI, *mode], path, fifo)
+            got = _through_a_fifo([pkg.CLI_PATH, *mode], path, fifo)
+            assert (got.returncode, got.stdout, got.stderr) == (want.returncode, want.stdout, want.stderr), (n, extra, mode)
+            if n:   # the stream's pass 1 is the file's pass 1: same header lines, zero percentages
+                on_file = subprocess.run([orc.REF_CLI, *mode, path], capture_output=True).stdout
+                assert got.stdout != on_file and len(got.stdout.splitlines()) == len(on_file.splitlines())
+                assert b"0.00000000" in got.stdout
+
+
+def test_load_stream_grows_the_shard_and_keeps_the_bytes(pkg, gpu, tmp_path):
+    """papr_hip_load_stream through the ABI: a pipe fed 300 MiB + an odd tail (the shard is re-allocated on the way: it
+    starts at 256 MiB) holds exactly the file's samples, the phantom sample included."""
+    n = (300 << 20) // 8 + 12345
+    rng = np.random.default_rng(11)
+    iq = rng.standard_normal(2 * n + 1).astype(np.float32)   # odd float count
+    r, w = os.pipe()
+    import threading
+
+    def feed():
+        with os.fdopen(w, "wb") as f:
+            f.write(iq.tobytes())
+    t = threading.Thread(target=feed)
+    t.start()
+    got_n = gpu.load_stream(r)
+    t.join()
+    os.close(r)
+    path = str(tmp_path / "same.cfile")
+    iq.tofile(path)
+    assert got_n == n + 1
+    a = gpu.download(0, got_n)
+    st_stream = gpu.stats()
+    gpu.load_file(path)
+    assert np.array_equal(a.view(np.uint32), gpu.download(0, got_n).view(np.uint32))
+    assert st_stream.to_bytes() == gpu.stats().to_bytes()
+
+
 # ---- seeded random inputs vs the oracle, every launch geometry --------------------
 
 SIZES = [1, 2, 63, 64, 255, 4095, 4096, 4097, 8191, 12289, 100003, 1048576 + 5]

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Distil gpurun_out/<tag>/ (made by tools/collect_profiles.sh on the GPU box) into the tracked files under profiles/:
 
-  <tag>_bench_<run>.json             the bench.py lines of the session (full = the driver's command with every leg; default,
-                                     exact, twopass, ts, ts_damage, torchrun1, torchrun1_hostpath, bursty, constant, miss)
+  <tag>_bench_<run>.json             the full records of the session's bench.py runs (full = the driver's command with every
+                                     leg; default, exact, twopass, ts, ts_damage, torchrun1, torchrun1_hostpath, bursty,
+                                     constant, miss); <tag>_bench_full.line = the compact stdout line of the driver's command
   <tag>_kernel_stats_<run>.csv       rocprofv3 --kernel-trace --stats summary of `bench.py [flags] --steps 20 --warmup 3`
   <tag>_stats_<run>.json             the bench line printed under the profiler in that very run
   <tag>_kernel_durations.json        the dominant kernel's average duration per MODE out of the kernel trace (bench.py
@@ -86,7 +87,7 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     if not glob.glob(os.path.join(src, "stats_*")):  # (a gpurun call that found no box leaves nothing: do not write empty summaries)
         sys.exit(f"{src}: no collection to distil")
-    for f in glob.glob(os.path.join(src, "bench_*.json")):
+    for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "bench_full.line")):
         if os.path.getsize(f):
             shutil.copy(f, os.path.join(dst, f"{tag}_{os.path.basename(f)}"))
     durations, summary = {}, {
