@@ -61,6 +61,24 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v)
     return v;
 }
 
+// inclusive prefix sum over the wave's lanes (the same six DPP steps), of small counts
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v)
+{
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v)
+{
+    v = dpp_add_u32<0x111, 0xf, 0xf>(v);  // row_shr:1
+    v = dpp_add_u32<0x112, 0xf, 0xf>(v);  // row_shr:2
+    v = dpp_add_u32<0x114, 0xf, 0xf>(v);  // row_shr:4
+    v = dpp_add_u32<0x118, 0xf, 0xf>(v);  // row_shr:8
+    v = dpp_add_u32<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add_u32<0x143, 0xc, 0xf>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // ---- pass-2 binning helpers (see the comment block above papr_ccdf_kernel) -----------
 
 template <int BLOCK>

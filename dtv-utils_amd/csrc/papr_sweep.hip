@@ -732,7 +732,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep_kernel(const fl
         const uint2 e = lut_biased[clamp_cell(cell, cell_first, cell_last)];
         return e.x + (__float_as_uint(pw) >= e.y ? 1u : 0u);
     };
-    auto count_and_stash = [&](float pw, uint32_t k) {
+    auto count = [&](uint32_t k) {
         // bin 0 (below every band: not counted) adds to this lane's trash word instead of being skipped
         const unsigned long long nz = __ballot(k != 0u);
         const uint32_t a_bin = (uint32_t)(uintptr_t)(lds_u32 *)&my[k];
@@ -740,6 +740,9 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep_kernel(const fl
         uint32_t a;
         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a) : "v"(a_trash), "v"(a_bin), "s"(nz));
         (void)__hip_atomic_fetch_add((lds_u32 *)(uintptr_t)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto count_and_stash = [&](float pw, uint32_t k) {  // (one sample at a time: the shard's remainder)
+        count(k);
         ws.put(pw, (k & 1u) != 0u);
     };
 
@@ -768,10 +771,17 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep_kernel(const fl
 #pragma unroll
         for (int u = 0; u < 2 * U; u++)
             k[u] = bin_of(pw[u]);  // all LUT reads of the tile in flight together
+        // count every sample; the tile's in-band powers then go to the stash together (WaveStash::put_tile: slots per lane)
+        uint32_t flag[2 * U], cnt = 0;
 #pragma unroll
-        for (int u = 0; u < 2 * U; u++)
-            count_and_stash(pw[u], k[u]);
-        ws.spill_in_step(now, SLICE - (2 * U + 1) * kWave, (it + 1) * (uint32_t)(2 * TILE_F4));  // the next tile might not fit
+        for (int u = 0; u < 2 * U; u++) {
+            count(k[u]);
+            flag[u] = k[u] & 1u;
+            cnt += flag[u];
+        }
+        const uint32_t folded = (it + 1) * (uint32_t)(2 * TILE_F4);
+        ws.spill_in_step(now, SLICE - kWave, folded);  // (on the chip-wide ticks; put_tile makes the room the tile needs)
+        ws.put_tile(pw, flag, cnt, SLICE, folded);
     };
 
     const float4 *p = data + w.first * TILE_F4 + t;
@@ -888,7 +898,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         const uint2 e = lut_biased[clamp_cell(cell, cell_first, cell_last)];
         return e.x + (__float_as_uint(pw) >= e.y ? 1u : 0u);
     };
-    auto count_and_stash_masked = [&](float pw, uint32_t k, unsigned long long in_band) {
+    auto count_bin = [&](uint32_t k) {
         // bin 0 (below every band: not counted) adds to this lane's trash word instead of being skipped
         const unsigned long long nz = __ballot(k != 0u);
         const uint32_t a_bin = (uint32_t)(uintptr_t)(lds_u32 *)&my[k];
@@ -896,11 +906,11 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         uint32_t a;
         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(a) : "v"(a_trash), "v"(a_bin), "s"(nz));
         (void)__hip_atomic_fetch_add((lds_u32 *)(uintptr_t)a, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        ws.put_masked(pw, in_band);
     };
-    auto count_and_stash = [&](float pw, uint32_t k) { count_and_stash_masked(pw, k, __ballot((k & 1u) != 0u)); };
-
-    constexpr bool fine = FINE;
+    auto count_and_stash = [&](float pw, uint32_t k) {  // (one sample at a time: the launch's remainder)
+        count_bin(k);
+        ws.put(pw, (k & 1u) != 0u);
+    };
 
     const float4 *data = reinterpret_cast<const float4 *>(p.data);
     const uint64_t seg_stride = (uint64_t)gridDim.x * WAVES;
@@ -925,14 +935,27 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
     constexpr bool EARLY = DIRECT && FINE;
     typedef __attribute__((address_space(1))) const void gvoid;
     typedef __attribute__((address_space(3))) void lvoid;
+    // All eight rows off ONE scalar base and ONE M0: a row is 1024 bytes in memory and in the buffer alike, and the
+    // instruction's 13-bit immediate offset moves both addresses, so with the bases in the MIDDLE of the segment the rows are
+    // offsets -4096 ... +3072.  What depends on the lane is the swizzle, and that only has two values (even rows, odd rows):
+    // two vector offsets for the whole kernel.  (Per row, the form with explicit addresses cost a 64-bit vector addition, two
+    // scalar ones, a write of M0 and the wait states behind it.)
+    const uint32_t voff_even = 16u * ((lane & ~7u) | ((lane & 7u) ^ ((lane >> 4) & 7u)));          // xpose_slot's inverse for rows 0, 2, 4, 6
+    const uint32_t voff_odd = 16u * ((lane & ~7u) | ((lane & 7u) ^ (((lane >> 4) + 4u) & 7u)));   // ... and 1, 3, 5, 7
     auto load_seg_lds = [&](float4 *dst, uint64_t seg) {
-        const float4 *base = data + seg * SEG_F4;
-#pragma unroll
-        for (int r = 0; r < U; r++) {
-            const uint32_t slot = (uint32_t)r * kWave + lane;                         // where the hardware puts this lane's 16 bytes
-            const uint32_t f = (slot & ~7u) | ((slot & 7u) ^ ((slot >> 4) & 7u));   // xpose_slot's inverse: the float4 that lives there
-            __builtin_amdgcn_global_load_lds((gvoid *)(base + f), (lvoid *)(dst + r * kWave), 16, 0, 2 /* nt */);
-        }
+        const char *mid = reinterpret_cast<const char *>(uniform_u64((unsigned long long)(data + seg * SEG_F4 + 4 * kWave)));
+        lvoid *lmid = (lvoid *)(dst + 4 * kWave);
+#define PAPR_LDS_ROW(r) \
+        __builtin_amdgcn_global_load_lds((gvoid *)(mid + (((r) & 1) ? voff_odd : voff_even)), lmid, 16, ((r) - 4) * 1024, 2 /* nt */)
+        PAPR_LDS_ROW(0);
+        PAPR_LDS_ROW(1);
+        PAPR_LDS_ROW(2);
+        PAPR_LDS_ROW(3);
+        PAPR_LDS_ROW(4);
+        PAPR_LDS_ROW(5);
+        PAPR_LDS_ROW(6);
+        PAPR_LDS_ROW(7);
+#undef PAPR_LDS_ROW
     };
 
     double sum = 0.0;
@@ -1015,7 +1038,8 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         // room for the segment's 16 samples of every lane (and the trash words)?  Checked IN FRONT of the fold, behind the
         // next segment's loads: a spill's stores then have the fold's duration to drain before this wave waits for memory
         // again (vmcnt is in order and counts stores too)
-        ws.spill_in_step(now, fine ? SLICE - kWave : SLICE - (2 * U + 1) * kWave, (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
+        ws.spill_in_step(now, FINE ? SLICE - kWave : SLICE - (2 * U + 1) * kWave,
+                         (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
         if constexpr (!DIRECT) {
 #pragma unroll
             for (int j = 0; j < U; j++)
@@ -1047,24 +1071,21 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
             else
                 k[u] = bin_of(pw[u]);  // the LUT reads in flight together
         }
+        // Every sample is counted as its lookup comes back; the segment's in-band powers then go to the stash together, in
+        // slots handed out per lane (WaveStash::put_tile) — which also makes room for what the segment WILL put instead of
+        // its worst case (every sample of every lane in band: 4 KiB, most of a fine table's slice).
         if constexpr (FINE) {
-            // A fine table stashes ten times what the 1 dB one does, out of a slice that is half as large (the table takes
-            // the rest): keeping the segment's worst case free — every sample of every lane in band, 4 KiB — would leave a
-            // quarter of the slice to collect in, and the waves would spill every 40 us instead of every 80.  So the
-            // segment's ballots are taken first and room is made for what it WILL put.  (Not for the coarse table: all
-            // sixteen lookups then have to be back before the first count, 0.05 ms per launch.)
-            unsigned long long in_band[2 * U];
-            uint32_t need = 0;
+            uint32_t flag[2 * U], cnt = 0;
 #pragma unroll
             for (int u = 0; u < 2 * U; u++) {
-                in_band[u] = __ballot((k[u] & 1u) != 0u);
-                need += (uint32_t)__popcll(in_band[u]);
+                count_bin(k[u]);
+                flag[u] = k[u] & 1u;
+                cnt += flag[u];
             }
-            ws.reserve(need, SLICE, (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
-#pragma unroll
-            for (int u = 0; u < 2 * U; u++)
-                count_and_stash_masked(pw[u], k[u], in_band[u]);
+            ws.put_tile(pw, flag, cnt, SLICE, (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
         } else {
+            // (the coarse table puts five powers per segment: a slot per sample as it comes, nothing to wait for — with slots per
+            // lane this form was 1.2 % slower on one box and even on two: profiles/r05_ab_exact_stash_slots.txt)
 #pragma unroll
             for (int u = 0; u < 2 * U; u++)
                 count_and_stash(pw[u], k[u]);

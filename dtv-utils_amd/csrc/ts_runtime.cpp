@@ -11,16 +11,95 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+
+// A few host threads for the one part of a scan that is the host's and grows with the stream's damage: laying out and
+// merging the report's lines (129 000 of them for one damaged spot per 1000 packets in 10 GiB — 1.4 ms on one core, as long
+// as the scan kernel itself).  Fork / join: run(n, f) calls f(0) ... f(n - 1), the caller taking its share; the workers sleep
+// on a condition variable in between.  Started with the first scan that has enough lines to be worth a wake-up.
+struct ts_line_pool {
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable wake, done;
+    const std::function<void(int)> *job = nullptr;
+    int njobs = 0, pending = 0;
+    std::atomic<int> next{0};
+    uint64_t generation = 0;
+    bool stop = false;
+    void worker()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            wake.wait(lk, [&] { return stop || generation != seen; });
+            if (stop)
+                return;
+            seen = generation;
+            const std::function<void(int)> *f = job;
+            const int n = njobs;
+            lk.unlock();
+            for (int k = next.fetch_add(1); k < n; k = next.fetch_add(1))
+                (*f)(k);
+            lk.lock();
+            if (--pending == 0)
+                done.notify_one();
+        }
+    }
+    bool start(int nworkers)
+    {
+        try {
+            for (int k = 0; k < nworkers; k++)
+                workers.emplace_back([this] { worker(); });
+        } catch (...) {
+        }
+        return !workers.empty();
+    }
+    void run(int n, const std::function<void(int)> &f)
+    {
+        if (workers.empty() || n <= 1) {
+            for (int k = 0; k < n; k++)
+                f(k);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m);
+            job = &f;
+            njobs = n;
+            next.store(0);
+            pending = (int)workers.size();
+            generation++;
+        }
+        wake.notify_all();
+        for (int k = next.fetch_add(1); k < n; k = next.fetch_add(1))
+            f(k);
+        std::unique_lock<std::mutex> lk(m);
+        done.wait(lk, [&] { return pending == 0; });
+    }
+    ~ts_line_pool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m);
+            stop = true;
+        }
+        wake.notify_all();
+        for (std::thread &t : workers)
+            t.join();
+    }
+};
 
 struct ts_hip_ctx {
     int device = -1;
@@ -51,6 +130,8 @@ struct ts_hip_ctx {
     ts_event *h_events = nullptr;                           // pinned mirror of the event list (grows with it)
     size_t h_events_cap = 0;
     std::vector<unsigned char> line_scratch;                // the host's working copy of the lines, reused from scan to scan
+    ts_line_pool *pool = nullptr;                           // host threads for the lines of a damaged stream (lazily)
+    int pool_threads = -1;                                  // TS_HOST_THREADS (default: 8, at most the cores; 1: none)
     int spans = 0;                                          // spans of a scan with the full tables (one workgroup per CU)
     int spans_slots = 0;                                    // ... of the slot form (two per CU)
     int form = 0;                                           // 0: full tables, given up for the slot form when the stream is damaged;
@@ -199,6 +280,8 @@ void ts_hip_close(ts_hip_ctx *ctx)
         (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
+    delete ctx->pool;
+    ctx->pool = nullptr;
     release(ctx);
     if (ctx->d_lists) (void)hipFree(ctx->d_lists);
     if (ctx->d_recs) (void)hipFree(ctx->d_recs);
@@ -509,7 +592,7 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
             TSCHK(ctx, hipMemcpyAsync(ctx->h_events, ctx->d_events, (size_t)nev * sizeof(ts_event), hipMemcpyDeviceToHost, ctx->stream));
             TSCHK(ctx, hipStreamSynchronize(ctx->stream));
         }
-        const ts_event *ev_begin = ctx->h_events, *ev_end = ctx->h_events + nev;
+        const ts_event *ev_begin = ctx->h_events;
         const ts_span_out *so = ctx->h_span_out;
         auto takes = [&](const ts_event &e) {  // (else: an attempt the chain did not take)
             return e.span < nspans && so[e.span].attempt != 0 && so[e.span].attempt == (e.attempt & ~TS_EVENT_BRIDGE);
@@ -519,34 +602,107 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
         // within a span: ts_kernels.hip), and the few the linking below adds.  A counting sort over (span, run) — stable —
         // lays them out; the runs are then merged.  Nothing is sorted unless a run turns out not to be in order.
         auto run_of = [](const ts_event &e) { return (e.attempt & TS_EVENT_BRIDGE) ? (e.kind == TS_EV_BRIDGE_CC ? 0u : 1u) : 2u; };
-        std::vector<uint32_t> first(3 * (size_t)nspans + 1, 0);
-        for (const ts_event *pe = ev_begin; pe != ev_end; pe++)
-            if (takes(*pe))
-                first[3 * (size_t)pe->span + run_of(*pe) + 1]++;
-        for (size_t k = 0; k < 3 * (size_t)nspans; k++)
-            first[k + 1] += first[k];
-        const size_t nlines = first[3 * (size_t)nspans];
+        // Few lines: this thread alone.  Many (a damaged stream): T threads, each a range of the event list, then each a
+        // range of the spans; only the linking of the spans' continuity counters in between is serial (a few entries per span).
+        if (ctx->pool_threads < 0) {
+            const char *e = getenv("TS_HOST_THREADS");
+            const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+            ctx->pool_threads = std::max(1, std::min(e ? atoi(e) : 8, std::min(hw, 64)));
+        }
+        int T = 1;
+        if (nev >= 16384 && ctx->pool_threads > 1) {
+            if (!ctx->pool) {
+                ctx->pool = new ts_line_pool();
+                ctx->pool->start(ctx->pool_threads - 1);
+            }
+            T = (int)ctx->pool->workers.size() + 1;
+        }
+        auto parallel = [&](int n, const std::function<void(int)> &f) {
+            if (T > 1)
+                ctx->pool->run(n, f);
+            else
+                for (int k = 0; k < n; k++)
+                    f(k);
+        };
+        const size_t nb = 3 * (size_t)nspans;                       // buckets: (span, run)
+        const size_t per_chunk = ((size_t)nev + T - 1) / (size_t)T;  // events per thread
+        auto chunk = [&](int c, const ts_event *&b0, const ts_event *&e0) {
+            b0 = ev_begin + std::min<size_t>((size_t)c * per_chunk, nev);
+            e0 = ev_begin + std::min<size_t>((size_t)(c + 1) * per_chunk, nev);
+        };
+        // ---- a counting sort over (span, run), stable: per-thread counts, one prefix over (bucket, thread), the scatter ----
+        std::vector<uint32_t> counts((size_t)T * nb, 0);
+        parallel(T, [&](int c) {
+            const ts_event *b0, *e0;
+            chunk(c, b0, e0);
+            uint32_t *h = counts.data() + (size_t)c * nb;
+            for (const ts_event *pe = b0; pe != e0; pe++)
+                if (takes(*pe))
+                    h[3 * (size_t)pe->span + run_of(*pe)]++;
+        });
+        std::vector<uint32_t> first(nb + 1, 0);
+        {
+            uint32_t running = 0;
+            for (size_t k = 0; k < nb; k++) {
+                first[k] = running;
+                for (int c = 0; c < T; c++) {
+                    const uint32_t h = counts[(size_t)c * nb + k];
+                    counts[(size_t)c * nb + k] = running;  // (becomes: where thread c's first line of this bucket goes)
+                    running += h;
+                }
+            }
+            first[nb] = running;
+        }
+        const size_t nlines = first[nb];
         if (ctx->line_scratch.size() < nlines * sizeof(Line))
             ctx->line_scratch.resize(nlines * sizeof(Line) + (nlines * sizeof(Line)) / 4);
         Line *lines = reinterpret_cast<Line *>(ctx->line_scratch.data());
-        {
-            std::vector<uint32_t> at(first.begin(), first.end() - 1);
-            for (const ts_event *pe = ev_begin; pe != ev_end; pe++)
+        parallel(T, [&](int c) {
+            const ts_event *b0, *e0;
+            chunk(c, b0, e0);
+            uint32_t *at = counts.data() + (size_t)c * nb;
+            for (const ts_event *pe = b0; pe != e0; pe++)
                 if (takes(*pe)) {
                     const ts_event &e = *pe;
                     // (an event of a bridge carries TS_EVENT_BRIDGE and counts from the bridge's first packet)
                     const uint64_t num = ((e.attempt & TS_EVENT_BRIDGE) ? so[e.span].bridge_base : so[e.span].base) + e.at_rel;
                     lines[at[3 * (size_t)e.span + run_of(e)]++] = Line{2 * num + (e.kind == TS_EV_SYNC ? 1u : 0u), e.skipped, e.kind, e.info};
                 }
-        }
+        });
         auto by_key = [](const Line &a, const Line &b) { return a.key < b.key; };
         auto in_order = [&](Line *b, Line *e) {
             if (!std::is_sorted(b, e, by_key))
                 std::sort(b, e, by_key);  // (keys are unique: a packet has one line of each kind at most)
         };
-        // link the spans: continuity_counter[] as the reference would hold it at each span's start
+        // ---- every span's three runs in order, and how many lines of either kind it will print (by ranges of spans) ----
+        const int span_jobs = T > 1 ? std::min<int>((int)nspans, 4 * T) : 1;
+        auto span_range = [&](int j, uint32_t &k0, uint32_t &k1) {
+            k0 = (uint32_t)((uint64_t)nspans * (uint64_t)j / (uint64_t)span_jobs);
+            k1 = (uint32_t)((uint64_t)nspans * (uint64_t)(j + 1) / (uint64_t)span_jobs);
+        };
+        std::vector<uint32_t> nsync(nspans + 1, 0), ndisc(nspans + 1, 0);
+        parallel(span_jobs, [&](int j) {
+            uint32_t k0, k1;
+            span_range(j, k0, k1);
+            for (uint32_t k = k0; k < k1; k++) {
+                if (so[k].attempt == 0)
+                    continue;
+                Line *r0 = lines + first[3 * (size_t)k], *r1 = lines + first[3 * (size_t)k + 1], *r2 = lines + first[3 * (size_t)k + 2],
+                     *r3 = lines + first[3 * (size_t)k + 3];
+                in_order(r0, r1);
+                in_order(r1, r2);
+                in_order(r2, r3);
+                uint32_t ns = 0;
+                for (const Line *l = r1; l != r3; l++)
+                    ns += l->kind == TS_EV_SYNC ? 1u : 0u;
+                nsync[k] = ns;
+                ndisc[k] = (uint32_t)(r3 - r1) - ns;
+            }
+        });
+        // ---- link the spans (serial): continuity_counter[] as the reference would hold it at each span's start ----
         std::vector<uint8_t> cc_state(TS_PIDS, 0);  // last counter + 1, 0 = none yet
-        std::vector<Line> linked;
+        std::vector<Line> linked;                   // the lines the linking adds, span after span
+        std::vector<uint32_t> linked_first(nspans + 1, 0);
         // (spans with more PIDs than travel with the scan's one wait — garbage read as packets carries any PID —: the heads
         // of ALL lists once more, as long as the longest, in one copy)
         std::vector<ts_cc_entry> big;
@@ -559,22 +715,17 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
             TSCHK(ctx, hipMemcpy2D(big.data(), (size_t)max_ncc * sizeof(ts_cc_entry), ctx->d_cc_lists, (size_t)TS_PIDS * sizeof(ts_cc_entry),
                                    (size_t)max_ncc * sizeof(ts_cc_entry), nspans, hipMemcpyDeviceToHost));
         }
-        ctx->errors.reserve(nlines);
         for (uint32_t k = 0; k < nspans; k++) {
+            linked_first[k] = (uint32_t)linked.size();
             if (so[k].attempt == 0)
                 continue;
-            Line *r0 = lines + first[3 * (size_t)k], *r1 = lines + first[3 * (size_t)k + 1], *r2 = lines + first[3 * (size_t)k + 2],
-                 *r3 = lines + first[3 * (size_t)k + 3];
-            in_order(r0, r1);
-            in_order(r1, r2);
-            in_order(r2, r3);
-            linked.clear();
+            const Line *r0 = lines + first[3 * (size_t)k], *r1 = lines + first[3 * (size_t)k + 1];
             auto check = [&](uint32_t pid, uint32_t cc, uint64_t num) {
                 const uint32_t last = cc_state[pid];
                 if (last != 0 && pid != 0x1fffu && (last & 0xfu) != cc)
                     linked.push_back(Line{2 * num, 0, TS_EV_DISC, (pid << 8) | (cc << 4) | (last & 0xfu)});
             };
-            for (Line *l = r0; l != r1; l++) {  // the bridge's payload-carrying packets, in front of the span, one by one
+            for (const Line *l = r0; l != r1; l++) {  // the bridge's payload-carrying packets, in front of the span, one by one
                 const uint32_t pid = l->info >> 8, cc = (l->info >> 4) & 0xfu;
                 check(pid, cc, l->key / 2);
                 cc_state[pid] = (uint8_t)(cc + 1u);
@@ -584,32 +735,60 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
                 check(list[j].pid, list[j].first_cc, so[k].base + list[j].first_rel + 1);
             for (uint32_t j = 0; j < so[k].ncc; j++)
                 cc_state[list[j].pid] = (uint8_t)(list[j].last_cc + 1u);
-            in_order(linked.data(), linked.data() + linked.size());
-            // three-way merge of the bridge's lines, the span's lines and the linked ones
-            Line *a = r1, *b = r2;
-            const Line *c = linked.data(), *ce = c + linked.size();
-            for (;;) {
-                const Line *pick = nullptr;
-                int which = -1;
-                if (a != r2) { pick = a; which = 0; }
-                if (b != r3 && (!pick || b->key < pick->key)) { pick = b; which = 1; }
-                if (c != ce && (!pick || c->key < pick->key)) { pick = c; which = 2; }
-                if (!pick)
-                    break;
-                if (pick->kind == TS_EV_SYNC) {
-                    ctx->errors.push_back(ts_sync_error{pick->skipped, pick->key / 2});
-                } else {
-                    ts_discontinuity d{};
-                    d.at_packet = pick->key / 2;
-                    d.after_sync_errors = ctx->errors.size();
-                    d.pid = pick->info >> 8;
-                    d.received = (uint8_t)((pick->info >> 4) & 0xfu);
-                    d.expected = (uint8_t)(pick->info & 0xfu);
-                    ctx->discs.push_back(d);
-                }
-                if (which == 0) a++; else if (which == 1) b++; else c++;
+            in_order(linked.data() + linked_first[k], linked.data() + linked.size());
+            ndisc[k] += (uint32_t)(linked.size() - linked_first[k]);
+        }
+        linked_first[nspans] = (uint32_t)linked.size();
+        // where every span's lines go in the two lists (exclusive prefix sums)
+        {
+            uint32_t es = 0, ds = 0;
+            for (uint32_t k = 0; k <= nspans; k++) {
+                const uint32_t a = k < nspans ? nsync[k] : 0, d = k < nspans ? ndisc[k] : 0;
+                nsync[k] = es;
+                ndisc[k] = ds;
+                es += a;
+                ds += d;
             }
         }
+        ctx->errors.resize(nsync[nspans]);
+        ctx->discs.resize(ndisc[nspans]);
+        // ---- per span: the three-way merge of the bridge's lines, the span's lines and the linked ones, into place ----
+        parallel(span_jobs, [&](int j) {
+            uint32_t k0, k1;
+            span_range(j, k0, k1);
+            for (uint32_t k = k0; k < k1; k++) {
+                if (so[k].attempt == 0)
+                    continue;
+                const Line *a = lines + first[3 * (size_t)k + 1], *r2 = lines + first[3 * (size_t)k + 2], *b = r2,
+                           *r3 = lines + first[3 * (size_t)k + 3];
+                const Line *c = linked.data() + linked_first[k], *ce = linked.data() + linked_first[k + 1];
+                ts_sync_error *eo = ctx->errors.data() + nsync[k];
+                ts_discontinuity *dout = ctx->discs.data() + ndisc[k];
+                uint64_t errors_so_far = nsync[k];
+                for (;;) {
+                    const Line *pick = nullptr;
+                    int which = -1;
+                    if (a != r2) { pick = a; which = 0; }
+                    if (b != r3 && (!pick || b->key < pick->key)) { pick = b; which = 1; }
+                    if (c != ce && (!pick || c->key < pick->key)) { pick = c; which = 2; }
+                    if (!pick)
+                        break;
+                    if (pick->kind == TS_EV_SYNC) {
+                        *eo++ = ts_sync_error{pick->skipped, pick->key / 2};
+                        errors_so_far++;
+                    } else {
+                        ts_discontinuity d{};
+                        d.at_packet = pick->key / 2;
+                        d.after_sync_errors = errors_so_far;
+                        d.pid = pick->info >> 8;
+                        d.received = (uint8_t)((pick->info >> 4) & 0xfu);
+                        d.expected = (uint8_t)(pick->info & 0xfu);
+                        *dout++ = d;
+                    }
+                    if (which == 0) a++; else if (which == 1) b++; else c++;
+                }
+            }
+        });
         memcpy(out->cc_state, cc_state.data(), TS_PIDS);
         break;
     }
