@@ -64,6 +64,15 @@ struct ts_span_out {
     ts_cc_entry cc[TS_CC_OUT];
 };
 
+// Does the chain, arriving from the exit of span k - 1, reach span k?  Worked out for every span at once (ts_bridge_kernel)
+// in front of the merge, whose workgroups would otherwise each walk every bridge in front of their span themselves.
+struct ts_bridge_rec {
+    unsigned long long packets;  // state 2: packets the bridge counts in front of the span
+    uint32_t state;              // 0 not worked out (the merge walks itself); 1 the span starts where the one in front ended;
+                                 // 2 a bridge gets there; 3 nothing does (the chain ends in front of this span)
+    uint32_t pad;
+};
+
 struct ts_scan_params {
     const unsigned char *data;  // the stream, file offset 0 at data[0]
     uint64_t nbytes;
@@ -85,6 +94,7 @@ struct ts_scan_params {
     ts_cc_entry *cc_lists;      // per span: up to TS_PIDS entries
     ts_event *events;           // one list for the launch(es) of a scan, slots handed out by an atomic counter
     uint32_t event_cap;
+    ts_bridge_rec *bridges;     // per span (may be null: the merge works every bridge out itself)
     unsigned int *event_count;  // [0] events wanted so far (may run past event_cap: the host then repeats the scan with more room);
                                 // [1] a span of the slot form met more PIDs than it has slots (the host scans again, full tables)
                                 // [2] the full-table form gave a damaged stream up (the host scans again, slot form)
@@ -111,6 +121,9 @@ void ts_launch_scan(hipStream_t st, int blocks, const ts_scan_params &p);
 void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t from_span, uint64_t packet_base, const ts_walk_state &cur,
                      uint32_t *g_count, unsigned long long *g_first, unsigned long long *g_last, unsigned long long *span_base,
                      unsigned long long *span_bridge_base, uint32_t *span_attempt, ts_merge_out *out, ts_span_out *span_out);
+// the bridges in front of spans [from_span, nspans_total) — from_span's from the state `cur` the chain arrived with — every
+// span a workgroup of its own: in front of ts_launch_merge
+void ts_launch_bridges(hipStream_t st, const ts_scan_params &p, uint32_t from_span, const ts_walk_state &cur);
 void ts_launch_reset(hipStream_t st, uint32_t *g_count, unsigned long long *g_first, unsigned long long *g_last,
                      unsigned int *event_count, uint32_t *span_attempt, uint32_t nspans);
 void ts_launch_generate(hipStream_t st, void *out, uint64_t nunits, uint32_t unit, uint64_t seed, int hdmv);

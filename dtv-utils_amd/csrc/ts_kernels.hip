@@ -844,6 +844,98 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
     }
 }
 
+// The walker from the chain's state `cur` up to span k's entry (wave 0, all lanes in step): does it get there — on the very
+// byte, owing nothing?  quiet: nothing is applied (a dry run: what a bridge counts and reports must not be applied unless it
+// arrives); otherwise its packets go into the stream-wide tables, numbered from `base`, and its lines into the event list.
+__device__ bool bridge_walk(const ts_scan_params &p, uint32_t k, const ts_span_rec &r, const ts_walk_state &cur, uint64_t base,
+                            uint32_t lane, unsigned char *win, bool quiet, uint32_t *g_count, unsigned long long *g_first,
+                            unsigned long long *g_last, uint64_t *packets_out)
+{
+    DevWalk w;
+    w.data = p.data;
+    w.s_count = w.s_first = w.s_last = nullptr;
+    w.events = p.events;
+    w.event_count = p.event_count;
+    w.event_cap = p.event_cap;
+    w.span = k;
+    w.attempt = r.attempt | kBridgeEvent;
+    w.lane = lane;
+    w.win = win;
+    w.nbytes = p.nbytes;
+    w.g_count = g_count;
+    w.g_first = g_first;
+    w.g_last = g_last;
+    w.abs0 = base;
+    w.s_cc = nullptr;  // (a bridge's packets are reported one by one: the host checks their continuity)
+    w.s_ncc = nullptr;
+    w.cc_list = nullptr;
+    w.s_ev = nullptr;
+    w.s_slot = nullptr;
+    w.s_nslots = w.s_over = nullptr;
+    w.s_slot_pid = nullptr;
+    w.slot_limit = 0;
+    w.stop_at = r.entry + p.sync_offset;  // the span's first sync byte: where its own findings begin
+    w.quiet = quiet ? 1u : 0u;
+    w.packets = 0;
+    w.win_base = 0;
+    w.win_len = 0;
+    ts_walk_state s2 = cur;
+    bool arrived = false;
+    for (uint32_t steps = 0; steps < kBridgeSteps; steps++) {
+        const int rc = dev_walk_step(&s2, &w, p.nbytes, 1);
+        if (rc == 2) {  // the search ended on that very byte; what an earlier packet still owed would
+            arrived = s2.stale_af == 0;  // change how the span's first packet is taken: not the same stream
+            break;
+        }
+        if (rc == 0 || s2.pos > w.stop_at)
+            break;
+    }
+    // the line the reference prints when it locks there (xport.c:4324-4327): the span, which started clean, did not know of
+    // the bytes skipped in front of it
+    if (arrived && !quiet && s2.skipped)
+        dev_event(&w, s2.skipped, w.packets);
+    *packets_out = w.packets;
+    return arrived;
+}
+
+// Every span's bridge at once, one wave per span: the chain coming from the exit of the span in front — the usual case; the
+// merge kernel falls back to walking where it comes from somewhere else.  Dry runs only.
+__global__ __launch_bounds__(64) void ts_bridge_kernel(const ts_scan_params p, uint32_t from_span, ts_walk_state cur0)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_window[kWalkWindow];
+    const uint32_t k = from_span + blockIdx.x;
+    const ts_span_rec r = p.recs[k];
+    ts_walk_state cur = cur0;  // (span from_span: the state the chain arrived with)
+    bool explicit_ok = r.explicit_entry != 0;
+    if (k > from_span) {
+        const ts_span_rec q = p.recs[k - 1];
+        cur.pos = q.exit_pos;
+        cur.skipped = q.exit_skipped;
+        cur.stale_af = q.exit_stale_af;
+        cur.extra_pending = q.exit_extra;
+        explicit_ok = false;
+    }
+    const uint64_t B1 = (k + 1 == p.nspans_total || (uint64_t)(k + 1) * p.span_bytes > p.nbytes) ? p.nbytes : (uint64_t)(k + 1) * p.span_bytes;
+    uint32_t state = 0;
+    uint64_t packets = 0;
+    if (cur.pos < B1) {  // (else: the chain is past this span already — the merge's business)
+        const bool clean = cur.skipped == 0 && cur.stale_af == 0 && (!cur.hdmv || cur.extra_pending == 4u);
+        if (r.entry == cur.pos && (clean || explicit_ok))
+            state = 1;
+        else if (!r.explicit_entry && r.entry != TS_NO_ENTRY && cur.pos <= r.entry && r.entry - cur.pos <= kBridgeMax)
+            state = bridge_walk(p, k, r, cur, 0, threadIdx.x, s_window, true, nullptr, nullptr, nullptr, &packets) ? 2u : 3u;
+        else
+            state = 3;
+    }
+    if (threadIdx.x == 0) {
+        ts_bridge_rec b;
+        b.packets = packets;
+        b.state = state;
+        b.pad = 0;
+        p.bridges[k] = b;
+    }
+}
+
 // One workgroup per span from `from_span` on.  Every workgroup walks the chain of records for itself (a few hundred
 // entries): a span is taken if the chain arrives, clean, exactly where the span started (or the span was launched from
 // the very state the chain arrived with); a span the chain has already passed (the span in front ran on across it: a
@@ -865,67 +957,109 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
     __shared__ ts_span_rec s_recs[TS_MAX_SPANS];  // (the chain walk is a serial loop: out of LDS, not out of HBM)
     const uint32_t t = threadIdx.x;
     const uint32_t me = from_span + blockIdx.x;
-    __shared__ uint32_t s_broken;
-    __shared__ unsigned long long s_sum_before, s_sum_all, s_sum_block, s_sum_walks;
+    __shared__ uint32_t s_broken, s_bad;
+    __shared__ unsigned long long s_sum_before, s_sum_all, s_sum_block, s_sum_walks, s_my_bridge;
     for (uint32_t k = from_span + t; k < p.nspans_total; k += kMergeBlock)
         s_recs[k] = p.recs[k];
     if (t == 0) {
         s_broken = 0;
+        s_bad = p.nspans_total;
+        s_my_bridge = 0;
         s_sum_before = s_sum_all = s_sum_block = s_sum_walks = 0;
     }
     __syncthreads();
-    // The common case in parallel: every span started exactly where — clean — the one in front of it ended, inside its
-    // own range.  Then nothing has to be walked: a span's base is the sum of the packets in front of it.
-    {
+    // In parallel, link by link: span k is reached if it started exactly where — clean — the one in front of it ended,
+    // inside its own range (the common case: nothing has to be walked), or if ts_bridge_kernel found a bridge from there to
+    // its entry (a damaged stream: damage at a span's beginning, which its speculated entry skipped); the first span that is
+    // reached neither way ends the valid part.  A span's base is then a sum over the spans in front of it.  Only a link the
+    // bridge kernel did not work out (the chain already past a span: a stretch without a grid) sends wave 0 along the chain.
+    auto link = [&](uint32_t k, ts_walk_state &prev, unsigned long long &bridge_packets) -> uint32_t {
+        const ts_span_rec r = s_recs[k];
+        prev = cur0;
+        bool explicit_ok = r.explicit_entry != 0;
+        if (k > from_span) {
+            const ts_span_rec q = s_recs[k - 1];
+            prev.pos = q.exit_pos;
+            prev.skipped = q.exit_skipped;
+            prev.stale_af = q.exit_stale_af;
+            prev.extra_pending = q.exit_extra;
+            explicit_ok = false;
+        }
+        const uint64_t B1 = (k + 1 == p.nspans_total || (uint64_t)(k + 1) * p.span_bytes > p.nbytes) ? p.nbytes
+                                                                                                    : (uint64_t)(k + 1) * p.span_bytes;
+        const bool clean = prev.skipped == 0 && prev.stale_af == 0 && (!prev.hdmv || prev.extra_pending == 4u);
+        bridge_packets = 0;
+        if (prev.pos < B1 && r.entry == prev.pos && (clean || explicit_ok))
+            return 1u;
+        if (!p.bridges)
+            return 0u;
+        const ts_bridge_rec b = p.bridges[k];
+        if (b.state == 2u)
+            bridge_packets = b.packets;
+        return b.state == 1u ? 0u : b.state;  // (1 cannot be: the bridge kernel saw the same records)
+    };
+    for (uint32_t k = from_span + t; k < p.nspans_total; k += kMergeBlock) {
+        ts_walk_state prev;
+        unsigned long long bp;
+        const uint32_t st = link(k, prev, bp);
+        if (st == 0u)
+            s_broken = 1;
+        else if (st == 3u)
+            atomicMin(&s_bad, k);
+    }
+    __syncthreads();
+    if (!s_broken) {
+        const uint32_t valid = s_bad;  // spans [from_span, valid) are the chain
         unsigned long long before = 0, all = 0, blk = 0, wk = 0;
-        for (uint32_t k = from_span + t; k < p.nspans_total; k += kMergeBlock) {
+        for (uint32_t k = from_span + t; k < valid; k += kMergeBlock) {
             const ts_span_rec r = s_recs[k];
-            ts_walk_state prev = cur0;
-            bool explicit_ok = r.explicit_entry != 0;
-            if (k > from_span) {
-                const ts_span_rec q = s_recs[k - 1];
-                prev.pos = q.exit_pos;
-                prev.skipped = q.exit_skipped;
-                prev.stale_af = q.exit_stale_af;
-                prev.extra_pending = q.exit_extra;
-                explicit_ok = false;
-            }
-            const uint64_t B1 = (k + 1 == p.nspans_total || (uint64_t)(k + 1) * p.span_bytes > p.nbytes) ? p.nbytes
-                                                                                                        : (uint64_t)(k + 1) * p.span_bytes;
-            const bool clean = prev.skipped == 0 && prev.stale_af == 0 && (!prev.hdmv || prev.extra_pending == 4u);
-            if (!(prev.pos < B1 && r.entry == prev.pos && (clean || explicit_ok)))
-                s_broken = 1;
-            all += r.packets;
+            ts_walk_state prev;
+            unsigned long long bp;
+            const uint32_t st = link(k, prev, bp);
+            all += r.packets + bp;
             blk += r.block_packets;
-            wk += r.walks;
+            wk += r.walks + (st == 2u ? 1u : 0u);
             if (k < me)
-                before += r.packets;
+                before += r.packets + bp;
+            if (k == me)
+                s_my_bridge = bp;
         }
         atomicAdd(&s_sum_before, before);
         atomicAdd(&s_sum_all, all);
         atomicAdd(&s_sum_block, blk);
         atomicAdd(&s_sum_walks, wk);
-    }
-    __syncthreads();
-    if (!s_broken) {
+        __syncthreads();
         if (t == 0) {
-            s_taken = s_recs[me].attempt;
-            s_base = s_bridge_base = packet_base + s_sum_before;
+            s_taken = me < valid ? s_recs[me].attempt : 0u;
+            s_bridge_base = packet_base + s_sum_before;
+            s_base = s_bridge_base + s_my_bridge;
             if (blockIdx.x == 0) {
-                const ts_span_rec last = s_recs[p.nspans_total - 1];
-                out->valid_upto = p.nspans_total;
+                out->valid_upto = valid;
                 out->pad = p.event_count[2];  // the full-table form gave a damaged stream up (ts_scan_params::abort_walks)
                 out->packets = packet_base + s_sum_all;
                 ts_walk_state cur = cur0;
-                cur.pos = last.exit_pos;
-                cur.skipped = last.exit_skipped;
-                cur.stale_af = last.exit_stale_af;
-                cur.extra_pending = last.exit_extra;
+                if (valid > from_span) {
+                    const ts_span_rec last = s_recs[valid - 1];
+                    cur.pos = last.exit_pos;
+                    cur.skipped = last.exit_skipped;
+                    cur.stale_af = last.exit_stale_af;
+                    cur.extra_pending = last.exit_extra;
+                }
                 out->cur = cur;
                 out->block_packets = s_sum_block;
                 out->walks = s_sum_walks;
                 out->events = *p.event_count;
                 out->pad2 = p.event_count[1];  // a span of the slot form met more PIDs than it has slots
+            }
+        }
+        __syncthreads();
+        // the bridge in front of THIS span, for real: its packets into the stream-wide tables, its lines into the event list
+        if (t < 64u && me < valid) {
+            ts_walk_state prev;
+            unsigned long long bp;
+            if (link(me, prev, bp) == 2u) {
+                uint64_t walked = 0;
+                (void)bridge_walk(p, me, s_recs[me], prev, s_bridge_base, t, s_window, false, g_count, g_first, g_last, &walked);
             }
         }
     } else if (t < 64u) {
@@ -951,61 +1085,18 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
             const ts_span_rec r = s_recs[k];
             const bool clean = cur.skipped == 0 && cur.stale_af == 0 && (!cur.hdmv || cur.extra_pending == 4u);
             bool fits = r.entry == cur.pos && (clean || (r.explicit_entry && k == from_span));
-            uint64_t bridge_base = base;
+            uint64_t bridge_base = base, w_packets = 0;
             if (!fits && !r.explicit_entry && r.entry != TS_NO_ENTRY && cur.pos <= r.entry && r.entry - cur.pos <= kBridgeMax) {
-                DevWalk w;
-                w.data = p.data;
-                w.s_count = w.s_first = w.s_last = nullptr;
-                w.events = p.events;
-                w.event_count = p.event_count;
-                w.event_cap = p.event_cap;
-                w.span = k;
-                w.attempt = r.attempt | kBridgeEvent;
-                w.lane = t;
-                w.win = s_window;
-                w.nbytes = p.nbytes;
-                w.g_count = g_count;
-                w.g_first = g_first;
-                w.g_last = g_last;
-                w.abs0 = base;
-                w.s_cc = nullptr;  // (a bridge's packets are reported one by one: the host checks their continuity)
-                w.s_ncc = nullptr;
-                w.cc_list = nullptr;
-                w.s_ev = nullptr;
-                w.s_slot = nullptr;
-                w.s_nslots = w.s_over = nullptr;
-                w.s_slot_pid = nullptr;
-                w.slot_limit = 0;
-                w.stop_at = r.entry + p.sync_offset;  // the span's first sync byte: where its own findings begin
-                ts_walk_state s2 = cur;
-                for (int run = 0; run < 2; run++) {  // dry, then — if it arrives and the span is this workgroup's — for real
-                    w.quiet = run == 0 ? 1u : 0u;
-                    w.packets = 0;
-                    w.win_base = 0;
-                    w.win_len = 0;
-                    s2 = cur;
-                    bool arrived = false;
-                    for (uint32_t steps = 0; steps < kBridgeSteps; steps++) {
-                        const int rc = dev_walk_step(&s2, &w, p.nbytes, 1);
-                        if (rc == 2) {  // the search ended on that very byte; what an earlier packet still owed would
-                            arrived = s2.stale_af == 0;  // change how the span's first packet is taken: not the same stream
-                            break;
-                        }
-                        if (rc == 0 || s2.pos > w.stop_at)
-                            break;
-                    }
-                    if (!arrived)
-                        break;
+                // (a dry run first: what a bridge counts and reports must not be applied unless it arrives)
+                uint64_t bridge_packets = 0;
+                if (bridge_walk(p, k, r, cur, base, t, s_window, true, g_count, g_first, g_last, &bridge_packets)) {
                     fits = true;
-                    // the line the reference prints when it locks there (xport.c:4324-4327): the span, which started
-                    // clean, did not know of the bytes skipped in front of it
-                    if (run == 1 && s2.skipped)
-                        dev_event(&w, s2.skipped, w.packets);
-                    if (k != me)
-                        break;
+                    if (k == me)
+                        (void)bridge_walk(p, k, r, cur, base, t, s_window, false, g_count, g_first, g_last, &bridge_packets);
                 }
+                w_packets = bridge_packets;
                 if (fits) {
-                    base += w.packets;
+                    base += w_packets;
                     walks++;
                 }
             }
@@ -1162,6 +1253,12 @@ void ts_launch_merge(hipStream_t st, const ts_scan_params &p, uint32_t from_span
 {
     hipLaunchKernelGGL(ts_merge_kernel, dim3(p.nspans_total - from_span), dim3(kMergeBlock), 0, st, p, from_span, packet_base, cur,
                        g_count, g_first, g_last, span_base, span_bridge_base, span_attempt, out, span_out);
+}
+
+void ts_launch_bridges(hipStream_t st, const ts_scan_params &p, uint32_t from_span, const ts_walk_state &cur)
+{
+    if (p.bridges && p.nspans_total > from_span)
+        hipLaunchKernelGGL(ts_bridge_kernel, dim3(p.nspans_total - from_span), dim3(64), 0, st, p, from_span, cur);
 }
 
 void ts_launch_generate(hipStream_t st, void *out, uint64_t nunits, uint32_t unit, uint64_t seed, int hdmv)

@@ -24,76 +24,151 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 // A few host threads for the one part of a scan that is the host's and grows with the stream's damage: laying out and
-// merging the report's lines (129 000 of them for one damaged spot per 1000 packets in 10 GiB — 1.4 ms on one core, as long
-// as the scan kernel itself).  Fork / join: run(n, f) calls f(0) ... f(n - 1), the caller taking its share; the workers sleep
-// on a condition variable in between.  Started with the first scan that has enough lines to be worth a wake-up.
+// merging the report's lines (129 000 of them for one damaged spot per 1000 packets in 10 GiB).  The work comes as a BURST of
+// short fork / join rounds (count, scatter, order, merge: 50-100 us each), so the workers are woken once per scan — as soon as
+// the scan knows it has many lines, while the lines are still on their way over the link — and SPIN between the rounds (a
+// wake-up through a condition variable costs as much as a round); run(n, f) calls f(0) ... f(n - 1), the caller taking its
+// share.  Jobs are handed out by one atomic ticket that carries the round's number in its upper half, so that a worker that is
+// late for one round can never run a job of it with the next round's function.
 struct ts_line_pool {
     std::vector<std::thread> workers;
     std::mutex m;
-    std::condition_variable wake, done;
-    const std::function<void(int)> *job = nullptr;
-    int njobs = 0, pending = 0;
-    std::atomic<int> next{0};
-    uint64_t generation = 0;
+    std::condition_variable wake;
     bool stop = false;
+    std::atomic<bool> burst{false};
+    std::atomic<uint64_t> ticket{0};  // round << 32 | next job of that round
+    std::atomic<uint32_t> done{0};
+    const std::function<void(int)> *job = nullptr;  // of round (ticket >> 32): written before the ticket is
+    uint32_t njobs = 0, round = 0;
+    static void relax() { __builtin_ia32_pause(); }
     void worker()
     {
-        uint64_t seen = 0;
-        std::unique_lock<std::mutex> lk(m);
         for (;;) {
-            wake.wait(lk, [&] { return stop || generation != seen; });
-            if (stop)
-                return;
-            seen = generation;
-            const std::function<void(int)> *f = job;
-            const int n = njobs;
-            lk.unlock();
-            for (int k = next.fetch_add(1); k < n; k = next.fetch_add(1))
-                (*f)(k);
-            lk.lock();
-            if (--pending == 0)
-                done.notify_one();
+            {
+                std::unique_lock<std::mutex> lk(m);
+                wake.wait(lk, [&] { return stop || burst.load(); });
+                if (stop)
+                    return;
+            }
+            uint32_t my_round = 0xFFFFFFFFu, n = 0;
+            const std::function<void(int)> *f = nullptr;
+            while (burst.load(std::memory_order_acquire)) {
+                uint64_t t = ticket.load(std::memory_order_acquire);
+                if ((uint32_t)(t >> 32) == my_round && (uint32_t)t >= n) {
+                    relax();
+                    continue;  // (nothing left of the round this worker knows)
+                }
+                t = ticket.fetch_add(1, std::memory_order_acq_rel);
+                if ((uint32_t)(t >> 32) != my_round) {
+                    my_round = (uint32_t)(t >> 32);
+                    f = job;
+                    n = njobs;
+                }
+                if ((uint32_t)t < n) {
+                    (*f)((int)(uint32_t)t);
+                    done.fetch_add(1, std::memory_order_release);
+                }
+            }
         }
+    }
+    // The workers run on the cores that share the caller's L3 (one CCD): the rounds hand cache lines from thread to thread —
+    // events counted by one are scattered by it, lines scattered by eight are merged by others — and across CCDs or sockets
+    // that costs more than the threads save (measured on the 2-socket box: the scatter round 0.22 ms alone, 0.39 with four
+    // threads wherever the scheduler put them).
+    static bool l3_siblings(cpu_set_t *set)
+    {
+        const int cpu = sched_getcpu();
+        if (cpu < 0)
+            return false;
+        char path[128], text[4096];
+        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+        FILE *f = fopen(path, "r");
+        if (!f)
+            return false;
+        const bool got = fgets(text, sizeof(text), f) != nullptr;
+        fclose(f);
+        if (!got)
+            return false;
+        CPU_ZERO(set);
+        int n = 0;
+        for (char *q = text; *q && *q != '\n';) {  // "0-7,128-135"
+            char *end = nullptr;
+            const long a = strtol(q, &end, 10);
+            if (end == q)
+                return false;
+            long b = a;
+            q = end;
+            if (*q == '-') {
+                b = strtol(q + 1, &end, 10);
+                q = end;
+            }
+            for (long c = a; c <= b && c < CPU_SETSIZE; c++, n++)
+                CPU_SET((int)c, set);
+            if (*q == ',')
+                q++;
+        }
+        return n >= 2;
     }
     bool start(int nworkers)
     {
+        cpu_set_t near;
+        const bool pin = !(getenv("TS_HOST_PIN") && atoi(getenv("TS_HOST_PIN")) == 0) && l3_siblings(&near);
         try {
             for (int k = 0; k < nworkers; k++)
-                workers.emplace_back([this] { worker(); });
+                workers.emplace_back([this, pin, near] {
+                    if (pin)
+                        (void)sched_setaffinity(0, sizeof(near), &near);
+                    worker();
+                });
         } catch (...) {
         }
         return !workers.empty();
     }
+    void begin_burst()
+    {
+        if (workers.empty() || burst.load())
+            return;
+        {
+            std::lock_guard<std::mutex> g(m);
+            burst.store(true);
+        }
+        wake.notify_all();
+    }
+    void end_burst() { burst.store(false, std::memory_order_release); }
     void run(int n, const std::function<void(int)> &f)
     {
-        if (workers.empty() || n <= 1) {
+        if (workers.empty() || n <= 1 || !burst.load()) {
             for (int k = 0; k < n; k++)
                 f(k);
             return;
         }
-        {
-            std::lock_guard<std::mutex> g(m);
-            job = &f;
-            njobs = n;
-            next.store(0);
-            pending = (int)workers.size();
-            generation++;
+        job = &f;
+        njobs = (uint32_t)n;
+        done.store(0, std::memory_order_relaxed);
+        round++;
+        ticket.store((uint64_t)round << 32, std::memory_order_release);
+        for (;;) {
+            const uint64_t t = ticket.fetch_add(1, std::memory_order_acq_rel);
+            if ((uint32_t)t >= (uint32_t)n)
+                break;
+            f((int)(uint32_t)t);
+            done.fetch_add(1, std::memory_order_release);
         }
-        wake.notify_all();
-        for (int k = next.fetch_add(1); k < n; k = next.fetch_add(1))
-            f(k);
-        std::unique_lock<std::mutex> lk(m);
-        done.wait(lk, [&] { return pending == 0; });
+        while (done.load(std::memory_order_acquire) != (uint32_t)n)
+            relax();
     }
     ~ts_line_pool()
     {
         {
             std::lock_guard<std::mutex> g(m);
             stop = true;
+            burst.store(false);
         }
         wake.notify_all();
         for (std::thread &t : workers)
@@ -119,6 +194,7 @@ struct ts_hip_ctx {
     unsigned long long *d_span_bridge_base = nullptr;       // ... and of the first packet of the bridge in front of it
     uint32_t *d_span_attempt = nullptr;                     // per span: the attempt whose record the chain took (0: none)
     ts_cc_entry *d_cc_lists = nullptr;                      // per span: its PIDs' first / last continuity counter
+    ts_bridge_rec *d_bridges = nullptr;                     // per span: does the chain get there from the span in front (ts_bridge_kernel)
     ts_span_out *d_span_out = nullptr, *h_span_out = nullptr;  // per span: what the host needs of it (one D2H copy; pinned)
     ts_event *d_events = nullptr;                           // events (report lines) of the scan's launches
     uint32_t event_cap = 0;
@@ -137,6 +213,7 @@ struct ts_hip_ctx {
     int form = 0;                                           // 0: full tables, given up for the slot form when the stream is damaged;
                                                             // 1: full tables only; 2: slot form first (TS_SCAN_FORM=auto|full|slots)
     uint32_t slot_limit = 0;                                // (tests: TS_SCAN_SLOT_LIMIT)
+    int bridges_mode = -1;                                  // TS_SCAN_BRIDGES: 1 ts_bridge_kernel in front of every merge, 0 of none (tests)
     hipEvent_t ev_a = nullptr, ev_m = nullptr, ev_b = nullptr;
 };
 
@@ -152,6 +229,12 @@ int env_spans_per_cu()
 {
     const char *e = getenv("TS_SCAN_SLOT_SPANS_PER_CU");
     return e ? std::max(1, std::min(atoi(e), 4)) : 2;
+}
+
+int env_int_ts(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
 }
 
 int ts_fail(ts_hip_ctx *ctx, int code, const char *fmt, ...)
@@ -243,6 +326,7 @@ int ts_hip_open(ts_hip_ctx **out, int device)
         ctx->spans = ctx->spans_slots = std::max(1, std::min(atoi(e), TS_MAX_SPANS));
     if (const char *e = getenv("TS_SCAN_FORM"))
         ctx->form = !strcmp(e, "full") ? 1 : !strcmp(e, "slots") ? 2 : 0;
+    ctx->bridges_mode = env_int_ts("TS_SCAN_BRIDGES", -1);
     if (const char *e = getenv("TS_SCAN_SLOT_LIMIT"))
         ctx->slot_limit = (uint32_t)std::max(0, atoi(e));
     OPENCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -250,6 +334,7 @@ int ts_hip_open(ts_hip_ctx **out, int device)
     OPENCHK(hipMalloc((void **)&ctx->d_recs, TS_MAX_SPANS * sizeof(ts_span_rec)));
     OPENCHK(hipMalloc((void **)&ctx->d_cc_lists, (size_t)TS_MAX_SPANS * TS_PIDS * sizeof(ts_cc_entry)));
     OPENCHK(hipMalloc((void **)&ctx->d_span_out, TS_MAX_SPANS * sizeof(ts_span_out)));
+    OPENCHK(hipMalloc((void **)&ctx->d_bridges, TS_MAX_SPANS * sizeof(ts_bridge_rec)));
     OPENCHK(hipHostMalloc((void **)&ctx->h_span_out, TS_MAX_SPANS * sizeof(ts_span_out), hipHostMallocDefault));
     OPENCHK(hipMalloc((void **)&ctx->d_span_base, TS_MAX_SPANS * sizeof(unsigned long long)));
     OPENCHK(hipMalloc((void **)&ctx->d_span_bridge_base, TS_MAX_SPANS * sizeof(unsigned long long)));
@@ -287,6 +372,7 @@ void ts_hip_close(ts_hip_ctx *ctx)
     if (ctx->d_recs) (void)hipFree(ctx->d_recs);
     if (ctx->d_cc_lists) (void)hipFree(ctx->d_cc_lists);
     if (ctx->d_span_out) (void)hipFree(ctx->d_span_out);
+    if (ctx->d_bridges) (void)hipFree(ctx->d_bridges);
     if (ctx->h_span_out) (void)hipHostFree(ctx->h_span_out);
     if (ctx->h_events) (void)hipHostFree(ctx->h_events);
     if (ctx->d_span_base) (void)hipFree(ctx->d_span_base);
@@ -454,13 +540,37 @@ constexpr int kGaveUp = 2;           // the full-table form met a damaged stream
 constexpr uint32_t kAbortWalks = 4;
 
 // one scan in one form; what the forms tried before it cost goes into the result's `launches` and `kernel_ms`
+static double host_now_ms()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + 1e-6 * (double)ts.tv_nsec;
+}
+
 static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots, uint32_t abort_walks, uint32_t launches_before,
                      double ms_before, double merge_ms_before)
 {
+    // TS_HOST_TRACE=1: where a scan's wall time goes, one stderr line per attempt (host clock, ms)
+    static const bool trace = getenv("TS_HOST_TRACE") && atoi(getenv("TS_HOST_TRACE")) > 0;
+    const double t_enter = trace ? host_now_ms() : 0.0;
+    double t_synced = 0.0, t_events = 0.0, t_sorted = 0.0, t_linked = 0.0, t_counted = 0.0, t_scattered = 0.0;
+    const double t_memset0 = t_enter;
+    (void)t_memset0;
     memset(out, 0, sizeof(*out));
     out->bytes = ctx->n;
-    ctx->errors.clear();
-    ctx->discs.clear();
+    // (the two lists keep their size from scan to scan — resize() below then value-initialises only what is new — and are
+    // empty whenever a scan leaves early)
+    struct ListsGuard {
+        ts_hip_ctx *c;
+        bool keep;
+        ~ListsGuard()
+        {
+            if (!keep) {
+                c->errors.clear();
+                c->discs.clear();
+            }
+        }
+    } lists{ctx, false};
     if (ctx->n == 0)
         return PAPR_OK;
     const uint32_t stride = hdmv ? 192u : 188u, sync_offset = hdmv ? 4u : 0u;
@@ -498,6 +608,10 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
         p.events = ctx->d_events;
         p.event_cap = ctx->event_cap;
         p.event_count = ctx->d_event_count;
+        // the bridges between the spans, all at once in front of the merge: for the slot form — the damaged stream's, where
+        // most spans begin behind damage their speculated entry skipped — and for every launch that scans a span again; the
+        // full-table form's first launch (a stream in order: nothing to bridge) does without the extra launch
+        p.bridges = nullptr;
         ts_walk_state cur;
         ts_walk_init(&cur, hdmv);
         uint64_t packets = 0;
@@ -508,6 +622,8 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
             TSCHK(ctx, hipEventRecord(ctx->ev_a, ctx->stream));
             ts_launch_scan(ctx->stream, p.explicit_entry ? 1 : (int)nspans, p);
             TSCHK(ctx, hipEventRecord(ctx->ev_m, ctx->stream));
+            p.bridges = (slots || p.explicit_entry || ctx->bridges_mode > 0) && ctx->bridges_mode != 0 ? ctx->d_bridges : nullptr;
+            ts_launch_bridges(ctx->stream, p, from, cur);
             // ---- ... and the chain check + merge from there on
             ts_launch_merge(ctx->stream, p, from, packets, cur, ctx->d_count, ctx->d_first, ctx->d_last, ctx->d_span_base,
                             ctx->d_span_bridge_base, ctx->d_span_attempt, ctx->h_out_dev, ctx->d_span_out);
@@ -524,6 +640,8 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
             TSCHK(ctx, hipMemcpyAsync(ctx->h_span_out, ctx->d_span_out, (size_t)nspans * sizeof(ts_span_out), hipMemcpyDeviceToHost,
                                       ctx->stream));
             TSCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (trace)
+                t_synced = host_now_ms();
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ctx->ev_a, ctx->ev_m) == hipSuccess)
                 ms_total += ms;
@@ -534,6 +652,9 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
             if ((slots && mo.pad2) || (abort_walks && mo.pad)) {
                 out->kernel_ms = ms_before + ms_total;  // (what the dropped scan cost is part of the answer's cost)
                 out->merge_ms = merge_ms_before + ms_merge;
+                if (trace)
+                    fprintf(stderr, "ts scan (%s form, given up): enter->synced %.3f ms (scan kernel %.3f, merge kernel %.3f)\n",
+                            slots ? "slot" : "full-table", t_synced - t_enter, ms_total, ms_merge);
                 return slots ? kSlotsOverflowed : kGaveUp;  // (garbage read as packets carries any PID: the full tables take it)
             }
             out->gpu_packets += mo.block_packets;
@@ -588,10 +709,37 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
             TSCHK(ctx, hipHostMalloc((void **)&ctx->h_events, want * sizeof(ts_event), hipHostMallocDefault));
             ctx->h_events_cap = want;
         }
-        if (nev) {
+        if (nev)
             TSCHK(ctx, hipMemcpyAsync(ctx->h_events, ctx->d_events, (size_t)nev * sizeof(ts_event), hipMemcpyDeviceToHost, ctx->stream));
-            TSCHK(ctx, hipStreamSynchronize(ctx->stream));
+        // Few lines: this thread alone.  Many (a damaged stream): T threads, each a range of the event list, then each a
+        // range of the spans; only the linking of the spans' continuity counters in between is serial (a few entries per
+        // span).  The workers are woken HERE, while the lines cross the link.
+        if (ctx->pool_threads < 0) {
+            const char *e = getenv("TS_HOST_THREADS");
+            const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+            ctx->pool_threads = std::max(1, std::min(e ? atoi(e) : 8, std::min(hw, 64)));
         }
+        int burst_threads = 1;
+        if (nev >= 16384 && ctx->pool_threads > 1) {
+            if (!ctx->pool) {
+                ctx->pool = new ts_line_pool();
+                ctx->pool->start(ctx->pool_threads - 1);
+            }
+            if (!ctx->pool->workers.empty()) {
+                ctx->pool->begin_burst();
+                burst_threads = (int)ctx->pool->workers.size() + 1;
+            }
+        }
+        if (nev) {
+            const hipError_t se = hipStreamSynchronize(ctx->stream);
+            if (se != hipSuccess) {
+                if (ctx->pool)
+                    ctx->pool->end_burst();
+                return ts_fail(ctx, PAPR_E_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(se));
+            }
+        }
+        if (trace)
+            t_events = host_now_ms();
         const ts_event *ev_begin = ctx->h_events;
         const ts_span_out *so = ctx->h_span_out;
         auto takes = [&](const ts_event &e) {  // (else: an attempt the chain did not take)
@@ -602,21 +750,7 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
         // within a span: ts_kernels.hip), and the few the linking below adds.  A counting sort over (span, run) — stable —
         // lays them out; the runs are then merged.  Nothing is sorted unless a run turns out not to be in order.
         auto run_of = [](const ts_event &e) { return (e.attempt & TS_EVENT_BRIDGE) ? (e.kind == TS_EV_BRIDGE_CC ? 0u : 1u) : 2u; };
-        // Few lines: this thread alone.  Many (a damaged stream): T threads, each a range of the event list, then each a
-        // range of the spans; only the linking of the spans' continuity counters in between is serial (a few entries per span).
-        if (ctx->pool_threads < 0) {
-            const char *e = getenv("TS_HOST_THREADS");
-            const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
-            ctx->pool_threads = std::max(1, std::min(e ? atoi(e) : 8, std::min(hw, 64)));
-        }
-        int T = 1;
-        if (nev >= 16384 && ctx->pool_threads > 1) {
-            if (!ctx->pool) {
-                ctx->pool = new ts_line_pool();
-                ctx->pool->start(ctx->pool_threads - 1);
-            }
-            T = (int)ctx->pool->workers.size() + 1;
-        }
+        const int T = burst_threads;  // (the workers were woken when the scan learnt how many lines it has)
         auto parallel = [&](int n, const std::function<void(int)> &f) {
             if (T > 1)
                 ctx->pool->run(n, f);
@@ -624,6 +758,14 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
                 for (int k = 0; k < n; k++)
                     f(k);
         };
+        struct BurstEnd {  // (whatever way this scan leaves: the workers go back to sleep)
+            ts_line_pool *p;
+            ~BurstEnd()
+            {
+                if (p)
+                    p->end_burst();
+            }
+        } burst_end{T > 1 ? ctx->pool : nullptr};
         const size_t nb = 3 * (size_t)nspans;                       // buckets: (span, run)
         const size_t per_chunk = ((size_t)nev + T - 1) / (size_t)T;  // events per thread
         auto chunk = [&](int c, const ts_event *&b0, const ts_event *&e0) {
@@ -640,6 +782,8 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
                 if (takes(*pe))
                     h[3 * (size_t)pe->span + run_of(*pe)]++;
         });
+        if (trace)
+            t_counted = host_now_ms();
         std::vector<uint32_t> first(nb + 1, 0);
         {
             uint32_t running = 0;
@@ -669,6 +813,8 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
                     lines[at[3 * (size_t)e.span + run_of(e)]++] = Line{2 * num + (e.kind == TS_EV_SYNC ? 1u : 0u), e.skipped, e.kind, e.info};
                 }
         });
+        if (trace)
+            t_scattered = host_now_ms();
         auto by_key = [](const Line &a, const Line &b) { return a.key < b.key; };
         auto in_order = [&](Line *b, Line *e) {
             if (!std::is_sorted(b, e, by_key))
@@ -699,6 +845,8 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
                 ndisc[k] = (uint32_t)(r3 - r1) - ns;
             }
         });
+        if (trace)
+            t_sorted = host_now_ms();
         // ---- link the spans (serial): continuity_counter[] as the reference would hold it at each span's start ----
         std::vector<uint8_t> cc_state(TS_PIDS, 0);  // last counter + 1, 0 = none yet
         std::vector<Line> linked;                   // the lines the linking adds, span after span
@@ -752,6 +900,8 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
         }
         ctx->errors.resize(nsync[nspans]);
         ctx->discs.resize(ndisc[nspans]);
+        if (trace)
+            t_linked = host_now_ms();
         // ---- per span: the three-way merge of the bridge's lines, the span's lines and the linked ones, into place ----
         parallel(span_jobs, [&](int j) {
             uint32_t k0, k1;
@@ -792,6 +942,7 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
         memcpy(out->cc_state, cc_state.data(), TS_PIDS);
         break;
     }
+    lists.keep = true;
     out->nsync_errors = ctx->errors.size();
     for (size_t k = 0; k < ctx->errors.size() && k < TS_MAX_SYNC_ERRORS; k++)
         out->sync_errors[k] = ctx->errors[k];
@@ -810,6 +961,12 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
     }
     out->kernel_ms = ms_before + ms_total;
     out->merge_ms = merge_ms_before + ms_merge;
+    if (trace)
+        fprintf(stderr, "ts scan (%s form): enter->synced %.3f ms (scan kernels %.3f, merge kernels %.3f, %u launches), events here +%.3f, "
+                "lines counted +%.3f, scattered +%.3f, in order +%.3f, spans linked +%.3f, merged and copied out +%.3f; %zu lines\n", slots ? "slot" : "full-table",
+                t_synced - t_enter, ms_total, ms_merge, out->launches - launches_before, t_events - t_synced, t_counted - t_events,
+                t_scattered - t_counted, t_sorted - t_scattered,
+                t_linked - t_sorted, host_now_ms() - t_linked, ctx->errors.size() + ctx->discs.size());
     return PAPR_OK;
 }
 

@@ -40,8 +40,38 @@ class ScanResult(C.Structure):
                 ("bytes", C.c_uint64), ("gpu_packets", C.c_uint64), ("launches", C.c_uint32), ("walks", C.c_uint32),
                 ("kernel_ms", C.c_double), ("merge_ms", C.c_double)]
 
-    _all_errors = None   # every sync error of the scan (TsHip.scan attaches them when the inline list is not all of them)
-    _all_discs = None    # ... and every discontinuity
+    # Every sync error / discontinuity of the scan, when the inline lists are not all of them: fetched from the context
+    # (ts_hip_get_sync_errors / _discontinuities) when first asked for — the context holds them until its next scan.
+    _src = None          # (TsHip, the number of the scan) while the complete lists are still to be fetched
+    _errs = None
+    _discs = None
+
+    def _complete(self):
+        if self._src is None:
+            return
+        gpu, scan_id = self._src
+        self._src = None
+        if gpu._scan_id != scan_id or not gpu._ctx:
+            raise PaprError(-6, "ts_hip_get_sync_errors", "the complete lists are the context's LAST scan's: this result is older")
+        n, nd = int(self.nsync_errors), int(self.ndiscontinuities)
+        if n > MAX_SYNC_ERRORS:
+            errs = (SyncError * n)()
+            gpu._chk(gpu._L.ts_hip_get_sync_errors(gpu._ctx, 0, n, errs), "ts_hip_get_sync_errors")
+            self._errs = errs
+        if nd > MAX_DISCONTINUITIES:
+            discs = (Discontinuity * nd)()
+            gpu._chk(gpu._L.ts_hip_get_discontinuities(gpu._ctx, 0, nd, discs), "ts_hip_get_discontinuities")
+            self._discs = discs
+
+    @property
+    def _all_errors(self):
+        self._complete()
+        return self._errs
+
+    @property
+    def _all_discs(self):
+        self._complete()
+        return self._discs
 
     def report(self) -> bytes:
         """The reference's report lines (ts_format_report / ts_format_report_all): every sync error and discontinuity in
@@ -169,6 +199,7 @@ class TsHip:
             self._ctx = C.c_void_p()
             raise PaprError(rc, "ts_hip_open", detail)
         self._keepalive = None
+        self._scan_id = 0
 
     def close(self):
         if self._ctx:
@@ -218,16 +249,10 @@ class TsHip:
     def scan(self, hdmv: bool = False) -> ScanResult:
         res = ScanResult()
         self._chk(self._L.ts_hip_scan(self._ctx, int(hdmv), C.byref(res)), "ts_hip_scan")
-        n = int(self._L.ts_hip_sync_error_count(self._ctx))
-        assert n == int(res.nsync_errors)
-        if n > MAX_SYNC_ERRORS:   # the result holds the first 4096 inline; the reference prints every one
-            errs = (SyncError * n)()
-            self._chk(self._L.ts_hip_get_sync_errors(self._ctx, 0, n, errs), "ts_hip_get_sync_errors")
-            res._all_errors = errs
-        nd = int(self._L.ts_hip_discontinuity_count(self._ctx))
-        assert nd == int(res.ndiscontinuities)
-        if nd > MAX_DISCONTINUITIES:
-            discs = (Discontinuity * nd)()
-            self._chk(self._L.ts_hip_get_discontinuities(self._ctx, 0, nd, discs), "ts_hip_get_discontinuities")
-            res._all_discs = discs
+        self._scan_id += 1
+        if int(res.nsync_errors) > MAX_SYNC_ERRORS or int(res.ndiscontinuities) > MAX_DISCONTINUITIES:
+            # the result holds the first 4096 of either inline; the reference prints every one: the rest on demand
+            assert int(self._L.ts_hip_sync_error_count(self._ctx)) == int(res.nsync_errors)
+            assert int(self._L.ts_hip_discontinuity_count(self._ctx)) == int(res.ndiscontinuities)
+            res._src = (self, self._scan_id)
         return res

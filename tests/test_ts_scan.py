@@ -166,10 +166,16 @@ def test_scan_of_the_synthetic_stream_and_handover_counts(ts, gpu, tmp_path):
         gpu.load_file(str(tmp_path / "missing.ts"))
 
 
-@pytest.fixture(scope="module", params=["auto", "slots", "full"])
+@pytest.fixture(scope="module", params=["auto", "slots", "full", "full, bridges worked out at once", "slots, bridges walked by the merge"])
 def gpu_small_spans(ts, request):
-    """a context that cuts even the small fixtures into many spans (4 KiB each: 21 packets)"""
-    g = _with_env(ts, {"TS_SCAN_SPANS": "256", "TS_SCAN_MIN_SPAN": "4096", "TS_SCAN_FORM": request.param})
+    """a context that cuts even the small fixtures into many spans (4 KiB each: 21 packets).  The bridges between the spans are
+    worked out by ts_bridge_kernel in front of the merge for the slot form and for re-scanned spans, by the merge kernel itself
+    otherwise: the last two parameters swap that (TS_SCAN_BRIDGES)."""
+    form, _, how = request.param.partition(", ")
+    env = {"TS_SCAN_SPANS": "256", "TS_SCAN_MIN_SPAN": "4096", "TS_SCAN_FORM": form}
+    if how:
+        env["TS_SCAN_BRIDGES"] = "1" if "at once" in how else "0"
+    g = _with_env(ts, env)
     yield g
     g.close()
 
