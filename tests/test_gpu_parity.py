@@ -107,10 +107,18 @@ def test_cli_multi_shard_path(pkg, manifest, shards):
     """The multi-GPU code path of bin/papr (one context + thread per shard, ordered merge, chained
     exact-sum programs, summed counts), exercised by oversubscribing the one GPU of the test box."""
     env = dict(os.environ, PAPR_GPUS=str(shards), PAPR_OVERSUBSCRIBE="1")
-    for name in ("g1m", "ties", "spike20k", "chunk3odd", "tiny", "nan_order", "ofdm_dvbt2_clipped", "one", "empty"):
-        for graph in (False, True):
-            args = [pkg.CLI_PATH] + (["-g"] if graph else []) + [golden_path(name)]
-            p = subprocess.run(args, capture_output=True, env=env)
+
+    def one(case):
+        name, graph = case
+        args = [pkg.CLI_PATH] + (["-g"] if graph else []) + [golden_path(name)]
+        return case, subprocess.run(args, capture_output=True, env=env)
+
+    # (a run is a second of context set-up per shard around milliseconds of work: four of them side by side on the one GPU)
+    from concurrent.futures import ThreadPoolExecutor
+    cases = [(name, graph) for name in ("g1m", "ties", "spike20k", "chunk3odd", "tiny", "nan_order", "ofdm_dvbt2_clipped", "one", "empty")
+             for graph in (False, True)]
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        for (name, graph), p in pool.map(one, cases):
             assert p.returncode == 0 and p.stdout == golden_text(name, graph), (name, graph, shards, p.stderr)
 
 
