@@ -183,9 +183,12 @@ def step_summary(step_s):
     ms = np.asarray(step_s, dtype=np.float64) * 1e3
     if ms.size == 0:
         return None
-    return {"min": round(float(ms.min()), 4), "median": round(float(np.median(ms)), 4),
+    med = float(np.median(ms))
+    stalled = ms > 2.0 * med   # a step several times its median: the host's wait came back late (seen: 8-9 ms, one box in three)
+    return {"min": round(float(ms.min()), 4), "median": round(med, 4),
             "p90": round(float(np.percentile(ms, 90)), 4), "max": round(float(ms.max()), 4),
             "slowest": int(ms.argmax()), "n": int(ms.size),
+            "stalled": int(stalled.sum()), "stalled_ms": round(float((ms[stalled] - med).sum()), 3),
             "all": [round(float(v), 3) for v in ms[:64]]}
 
 
@@ -248,6 +251,11 @@ def compact_line(full, full_path):
         "traffic_source": (r.get("traffic_source") or "")[:60] or None, "traffic_stale": r.get("traffic_stale"),
         "step_ms": brief(r.get("step_ms")), "kernel_launch_ms": brief(r.get("kernel_launch_ms")),
         "step_ms_median": (r.get("step_ms") or {}).get("median"), "step_ms_max": (r.get("step_ms") or {}).get("max"),
+        # steps that took more than twice the median (the host's wait coming back late: 8-9 ms now and then on some boxes,
+        # the GPU clocking down behind it) and what they cost the timed region: `value` = total / elapsed includes them
+        "stalled_steps": (r.get("step_ms") or {}).get("stalled"), "stalled_ms": (r.get("step_ms") or {}).get("stalled_ms"),
+        "value_at_median_step": (_r(full["config"]["samples_total"] / ((r.get("step_ms") or {}).get("median") * 1e-3) / 1e6, 1)
+                                 if (r.get("step_ms") or {}).get("median") else None),
         "kernels_ms_per_step": _r(r.get("kernels_ms_per_step"), 5),
         "host_and_exchange_ms_per_step": _r(r.get("host_and_exchange_ms_per_step"), 5),
         "all_kernels_frac_of_peak": _r(k.get("all_kernels_frac_of_peak"), 4),

@@ -4,7 +4,7 @@
 # --kernel-trace only).  Every run keeps its stdout line (<run>.line) and its full record (<run>.json).  Writes gpurun_out/<tag>/; tools/summarize_profiles.py distils profiles/<tag>_*.
 #   gpurun -- 'bash tools/collect_profiles.sh r04'
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
