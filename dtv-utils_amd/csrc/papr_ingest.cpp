@@ -311,6 +311,8 @@ int stream_file(papr_hip_ctx *ctx, StreamPass pass, const CcdfPlan *plan, size_t
         if (env_int("PAPR_IO_URING", 1) != 0)
             ctx->uring = UringReader::create(256);
     }
+    if (ctx->uring && ctx->uring->poisoned())
+        return fail(ctx, PAPR_E_IO, "the io_uring reader was given up with reads the kernel did not give back: its staging buffers are not safe to reuse");
     UringReader *ring = fs.fd_direct >= 0 && ctx->uring && !ctx->uring->dead() ? ctx->uring : nullptr;  // (a ring that failed once: threads)
     if (timed)
         ctx->ingest.io_uring = ring ? 1 : 0;

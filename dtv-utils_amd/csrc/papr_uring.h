@@ -101,6 +101,7 @@ class UringReader {
 
     unsigned entries() const { return entries_; }
     bool dead() const { return dead_; }
+    bool poisoned() const { return poisoned_; }  // given up with requests the kernel would not give back: its buffers are not safe
 
   private:
     struct Req {
@@ -142,11 +143,34 @@ class UringReader {
             if (!reap())
                 usleep(100);
         }
+        // What the kernel still has after that must not complete into staging buffers the reader threads are about to reuse.
+        // close() alone does not see to that — the three ring mappings hold references to the ring's file, so the ring lives
+        // on behind the closed descriptor — hence: cancel everything synchronously (IORING_REGISTER_SYNC_CANCEL, Linux 6.0+),
+        // take the completions that produces, and only then let the ring go.  If requests are out even then (an older kernel,
+        // a device that does not answer), the ring says so (`poisoned()`): the ingest then fails instead of reading on into
+        // buffers a stray completion may still write.
+        if (!live_.empty() && fd_ >= 0) {
+            struct {
+                uint64_t addr;
+                int32_t fd;
+                uint32_t flags;
+                struct { int64_t tv_sec; long long tv_nsec; } timeout;
+                uint8_t opcode, pad[7];
+                uint64_t pad2[3];
+            } reg;
+            memset(&reg, 0, sizeof(reg));
+            reg.flags = 1u << 2;  // IORING_ASYNC_CANCEL_ANY
+            reg.timeout.tv_sec = 2;
+            (void)syscall(__NR_io_uring_register, fd_, 24 /* IORING_REGISTER_SYNC_CANCEL */, &reg, 1);
+            for (int spin = 0; spin < 20000 && !live_.empty(); spin++) {
+                if (!reap())
+                    usleep(100);
+            }
+        }
+        poisoned_ = !live_.empty();
         for (Req *r : live_)
             r->batch = &orphans_;
         live_.clear();
-        // closing the ring cancels (or waits for) whatever is still in flight: nothing writes into the staging buffers
-        // the reader threads take over from here
         if (fd_ >= 0) {
             close(fd_);
             fd_ = -1;
@@ -304,6 +328,7 @@ class UringReader {
     std::vector<Req *> live_;  // what the kernel has
     ReadBatch orphans_{};      // where completions of a given-up ring's stragglers go
     bool dead_ = false;
+    bool poisoned_ = false;
 };
 
 }  // namespace papr_rt
