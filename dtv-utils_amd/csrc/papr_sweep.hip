@@ -970,6 +970,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
     // the samples wait for the store's acknowledgement as well; a binade requested at the top of the loop would have the
     // wave stand still for a whole memory round trip with nothing of its own in flight).
     int E_next = PAPR_EXACT_AMBIG;
+    double2 D_prev = make_double2(0.0, 0.0);
     if (count) {
         E_next = tile_E[(p.seg_offset + seg0) >> 1];
         asm volatile("" ::: "memory");
@@ -978,7 +979,6 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         else
             load_seg(x, seg0);
     }
-    double2 D_prev = make_double2(0.0, 0.0);
     for (uint32_t it = 0; it < count; it++) {
         const uint64_t seg = seg0 + (uint64_t)it * seg_stride;
         const uint64_t now = __builtin_amdgcn_s_memrealtime();  // (for the spill check)
