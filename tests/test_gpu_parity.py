@@ -194,6 +194,35 @@ def test_cli_on_a_stream_that_cannot_be_rewound_prints_what_the_reference_prints
                 assert b"0.00000000" in got.stdout
 
 
+def test_cli_refuses_a_stream_longer_than_the_hbm_budget(pkg, orc, tmp_path):
+    """The one thing a stream cannot have here and can have with the reference: more bytes than the HBM budget (it cannot be
+    read a second time, so it has to stay resident).  An error with its reason, exit status 253 — not a crash, not a wrong
+    report."""
+    path, fifo = str(tmp_path / "f.cfile"), str(tmp_path / "in.fifo")
+    subprocess.check_call([orc.MKCFILE, path, str(40 << 20 >> 3), "--seed", "3"])   # 40 MiB
+    os.environ["PAPR_HBM_BUDGET_MB"] = "16"
+    try:
+        p = _through_a_fifo([pkg.CLI_PATH], path, fifo)
+    finally:
+        del os.environ["PAPR_HBM_BUDGET_MB"]
+    assert p.returncode == 253 and p.stdout == b"" and b"longer than the HBM budget" in p.stderr, (p.returncode, p.stderr)
+
+
+@pytest.mark.parametrize("env,lines", [(dict(PAPR_GPUS="1", PAPR_XCH="rccl"), 5), (dict(PAPR_GPUS="3", PAPR_OVERSUBSCRIBE="1"), 2),
+                                       (dict(PAPR_GPUS="3", PAPR_OVERSUBSCRIBE="1", PAPR_XCH_IN_STREAM="2"), 5)],
+                         ids=["RCCL, one rank", "three threads at the hub", "three threads, the hub standing in for the in-stream collectives"])
+def test_cli_runs_the_exchange_self_test_when_asked(pkg, env, lines):
+    """PAPR_XCH_SELFTEST=1: in front of its first step with peers bin/papr runs every collective the step uses once, on tiny
+    buffers with predictable contents, and rank 0 says so on stderr, one line per collective with its microseconds — what a
+    first run on N GPUs prints before anything else; stdout stays the reference's."""
+    p = subprocess.run([pkg.CLI_PATH, "-g", golden_path("g1m")], capture_output=True,
+                       env=dict(os.environ, PAPR_XCH_SELFTEST="1", PAPR_XCH_TIMEOUT_S="60", **env))
+    assert p.returncode == 0 and p.stdout == golden_text("g1m", True), p.stderr
+    said = [l for l in p.stderr.decode().splitlines() if l.startswith("papr exchange self-test:")]
+    assert len(said) == lines and all(" ok " in l and " us " in l for l in said), p.stderr.decode()
+    assert any("host-level all-gather" in l for l in said) and (lines < 5 or any("all-gather-v" in l for l in said))
+
+
 def test_load_stream_grows_the_shard_and_keeps_the_bytes(pkg, gpu, tmp_path):
     """papr_hip_load_stream through the ABI: a pipe fed 300 MiB + an odd tail (the shard is re-allocated on the way: it
     starts at 256 MiB) holds exactly the file's samples, the phantom sample included."""
