@@ -259,6 +259,8 @@ def compact_line(full, full_path):
         "kernels_ms_per_step": _r(r.get("kernels_ms_per_step"), 5),
         "host_and_exchange_ms_per_step": _r(r.get("host_and_exchange_ms_per_step"), 5),
         "all_kernels_frac_of_peak": _r(k.get("all_kernels_frac_of_peak"), 4),
+        "wg_finish_median_last_us": ([(r.get("wg_finish_us") or {}).get("median"), (r.get("wg_finish_us") or {}).get("last")]
+                                     if r.get("wg_finish_us") else None),
         "two_pass_equiv_frac": _r((r.get("survey_two_pass_equiv") or {}).get("frac"), 4),
         # the member legs' fractions of peak as plain numbers ...
         **{f"{name}_frac": leg.get("frac") for name, leg in legs.items() if leg.get("frac") is not None},
@@ -419,6 +421,13 @@ def run_mode(args, mode, env):
     xt = xch.timing().as_dict()
     if one_sweep:
         result["sweep_info"] = gpu.sweep_info().as_dict()
+        try:   # when the last sweep launch's persistent workgroups were done (papr_hip_get_wg_finish), us after the first
+            wf = gpu.wg_finish_us()
+            if wf.size:
+                result["wg_finish_us"] = {"workgroups": int(wf.size), "median": round(float(np.median(wf)), 1), "last": round(float(wf.max()), 1),
+                                          "per_xcd_mean": [round(float(wf[x::8].mean()), 1) for x in range(8)] if wf.size % 8 == 0 else None}
+        except Exception:
+            pass
     aux_steps = min(5, args.steps)
     kept = dict(result)
     gpu.set_timing(1)
@@ -522,6 +531,9 @@ def run_mode(args, mode, env):
                                                                      "papr_exact_seg_kernel<CCDF>": 2}.get(dom, 3)] / 1e3),
                          "kernels_ms_per_step": kernel_ms_per_step,
                          "host_and_exchange_ms_per_step": ms_per_step - kernel_ms_per_step,
+                         # how evenly the launch ends: its persistent workgroups' finish times after the first one's (the
+                         # kernels walk the shard with a skew between the XCDs, which do not read at one speed)
+                         "wg_finish_us": result.get("wg_finish_us"),
                          # SURVEY.md 8(d) prices a papr result at 16 B/sample (two reads: 500 000 Msamples/s = 100 %).  The
                          # sweep kernel does the work of both passes in ONE read, so `frac` above is priced on the 8 B/sample
                          # it actually moves; on the survey's two-pass convention the same launch retires 16 B/sample:

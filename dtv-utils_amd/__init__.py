@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "papr_hip_adopt", "papr_hip_generate", "papr_hip_download", "papr_hip_stats",
     "papr_stats_init", "papr_stats_merge", "papr_levels", "papr_hip_ccdf",
     "papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
-    "papr_hip_estimate", "papr_hip_stats_sweep", "papr_hip_get_sweep_info", "papr_guess_levels",
+    "papr_hip_estimate", "papr_hip_stats_sweep", "papr_hip_get_sweep_info", "papr_hip_get_wg_finish", "papr_guess_levels",
     "papr_hip_estimate_file", "papr_hip_load_file_sweep", "papr_hip_shard_fits",
     "papr_level_key", "papr_sweep_bands", "papr_sweep_resolve", "papr_hip_set_exact_hint",
     "papr_sweep_band_for", "papr_hip_set_band", "papr_hip_analyze", "papr_hip_sweep_variant_built",
@@ -235,6 +235,9 @@ def lib() -> C.CDLL:
     L.papr_hip_shard_fits.restype = i32
     L.papr_hip_load_file_sweep.argtypes = [vp, C.c_char_p, u64, u64, vp, i32]
     L.papr_hip_get_sweep_info.argtypes = [vp, C.POINTER(SweepInfo)]
+    if hasattr(L, "papr_hip_get_wg_finish"):   # (an older library under PAPR_LIB_PATH, side by side with this one: tools/lib_abn.sh)
+        L.papr_hip_get_wg_finish.argtypes = [vp, vp, i32]
+        L.papr_hip_get_wg_finish.restype = i32
     L.papr_hip_analyze.argtypes = [vp, vp, i32, C.c_uint, C.POINTER(Result), vp, vp, i32]
     L.papr_hip_analyze.restype = i32
     L.papr_sweep_band_for.argtypes = [C.POINTER(Stats)]
@@ -446,6 +449,17 @@ class PaprHip:
         lv = np.ascontiguousarray(guess_table, dtype=np.float32)
         self._chk(self._L.papr_hip_load_file_sweep(self._ctx, os.fsencode(path), first_sample, nsamples,
                                                    lv.ctypes.data_as(C.c_void_p), lv.size), "papr_hip_load_file_sweep")
+
+    def wg_finish_us(self) -> np.ndarray:
+        """papr_hip_get_wg_finish: when each workgroup of the last sweep launch was done, in microseconds after the first one."""
+        t = np.zeros(4096, dtype=np.uint32)
+        n = self._chk_pos(self._L.papr_hip_get_wg_finish(self._ctx, t.ctypes.data_as(C.c_void_p), t.size), "papr_hip_get_wg_finish")
+        t = t[:min(n, t.size)]
+        if t.size == 0:
+            return np.zeros(0)
+        d = (t - t.min()).astype(np.uint32)          # (modulo 2^32 ticks: the counter may wrap once in 43 s)
+        d = np.where(d > (1 << 31), (t - t.max()).astype(np.uint32), d) if d.max() > (1 << 31) else d
+        return d.astype(np.float64) / 100.0
 
     def shard_fits(self, nsamples: int) -> bool:
         return bool(self._chk_pos(self._L.papr_hip_shard_fits(self._ctx, nsamples), "papr_hip_shard_fits"))

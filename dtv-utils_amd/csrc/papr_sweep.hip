@@ -748,8 +748,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep_kernel(const fl
 
     double sum = 0.0;
     TileTrack tr = {{0.f, 0.f, 0.f, 0.f, 0.f}, {0, 0, 0, 0, 0}};
-    const TileWalk w = tile_walk(blockIdx.x, gridDim.x, ntiles, map);
-    auto fold = [&](const float4(&x)[U], uint32_t it) {
+    auto fold = [&](const float4(&x)[U], uint32_t tile, uint32_t it) {
         const uint64_t now = __builtin_amdgcn_s_memrealtime();  // (for the spill check at the end)
         float pw[2 * U];
 #pragma unroll
@@ -766,7 +765,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep_kernel(const fl
 #pragma unroll
         for (int u = 0; u < 2 * U; u++)
             sum += (double)pw[u];  // same order as papr_stats_kernel
-        track_tile<U>(tr, x, pw, it);
+        track_tile<U>(tr, x, pw, tile);  // (the tracker remembers the TILE: a lane meets its tiles in increasing order)
         uint32_t k[2 * U];
 #pragma unroll
         for (int u = 0; u < 2 * U; u++)
@@ -784,20 +783,25 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep_kernel(const fl
         ws.put_tile(pw, flag, cnt, SLICE, folded);
     };
 
-    const float4 *p = data + w.first * TILE_F4 + t;
-    const uint64_t step = w.stride * TILE_F4;
+    // which tiles: grid stride with the XCD skew (SkewWalk, papr_sweep_dev.h); `map` carries the skew's period in its upper bits
+    SkewWalk walk;
+    walk.init(blockIdx.x, gridDim.x, (uint32_t)map >> 8);
     float4 cur[U], nxt[U];
-    if (w.count)
-        load_tile<BLOCK, U, true>(cur, p);
-    for (uint32_t it = 0; it < w.count; it++) {
-        p += step;
-        if (it + 1 < w.count)
-            load_tile<BLOCK, U, true>(nxt, p);  // the next tile's loads fly while this one is folded
-        fold(cur, it);
+    uint64_t tile = walk.tile();
+    if (tile < ntiles)
+        load_tile<BLOCK, U, true>(cur, data + tile * TILE_F4 + t);
+    for (uint32_t it = 0; tile < ntiles; it++) {
+        walk.advance();
+        const uint64_t ntile = walk.tile();
+        if (ntile < ntiles)
+            load_tile<BLOCK, U, true>(nxt, data + ntile * TILE_F4 + t);  // the next tile's loads fly while this one is folded
+        fold(cur, (uint32_t)tile, it);
 #pragma unroll
         for (int u = 0; u < U; u++)
             cur[u] = nxt[u];
+        tile = ntile;
     }
+    const TileWalk w = {0, 1, 0};  // (sweep_record: tile = first + entry * stride — the trackers hold the tile itself)
     // sub-tile remainder of the shard: binned here (its pass-1 part is folded in by papr_stats_finalize)
     if (blockIdx.x == gridDim.x - 1) {
         for (uint32_t k0 = 0; k0 < tail_samples; k0 += BLOCK) {  // wave-uniform trip count
@@ -913,9 +917,13 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
     };
 
     const float4 *data = reinterpret_cast<const float4 *>(p.data);
-    const uint64_t seg_stride = (uint64_t)gridDim.x * WAVES;
-    const uint64_t seg0 = (uint64_t)blockIdx.x * WAVES + wave;
-    const uint32_t count = p.nsegs > seg0 ? (uint32_t)((p.nsegs - seg0 + seg_stride - 1) / seg_stride) : 0u;
+    // which segments: the workgroup's eight waves take the eight segments of a 64 KiB tile, wave w the w-th; the tiles grid
+    // stride with the XCD skew (SkewWalk, papr_sweep_dev.h).  A wave's segments come in increasing order.
+    SkewWalk walk;
+    walk.init(blockIdx.x, gridDim.x, p.xcd_skew);
+    constexpr uint64_t kNoSeg = ~0ull;
+    uint64_t seg = walk.tile() * WAVES + wave, prev_seg = kNoSeg;
+    uint32_t segs_done = 0;
     auto load_seg = [&](float4(&x)[U], uint64_t seg) {
         const unsigned long long base = uniform_u64((unsigned long long)(data + seg * SEG_F4));  // wave-uniform: scalar base
 #pragma unroll
@@ -971,16 +979,17 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
     // wave stand still for a whole memory round trip with nothing of its own in flight).
     int E_next = PAPR_EXACT_AMBIG;
     double2 D_prev = make_double2(0.0, 0.0);
-    if (count) {
-        E_next = tile_E[(p.seg_offset + seg0) >> 1];
+    if (seg < p.nsegs) {
+        E_next = tile_E[(p.seg_offset + seg) >> 1];
         asm volatile("" ::: "memory");
         if constexpr (DIRECT)
-            load_seg_lds(mine, seg0);
+            load_seg_lds(mine, seg);
         else
-            load_seg(x, seg0);
+            load_seg(x, seg);
     }
-    for (uint32_t it = 0; it < count; it++) {
-        const uint64_t seg = seg0 + (uint64_t)it * seg_stride;
+    while (seg < p.nsegs) {  // (wave-uniform; tiles only grow, so the first segment past the end is the end)
+        walk.advance();
+        const uint64_t nseg = walk.tile() * WAVES + wave;
         const uint64_t now = __builtin_amdgcn_s_memrealtime();  // (for the spill check)
         const int E = __builtin_amdgcn_readfirstlane(E_next);
         float4 y[U];
@@ -1018,19 +1027,19 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
                 e_lut[u] = lut_biased[clamp_cell(__float_as_int(pw[u]) >> shift, cell_first, cell_last)];
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (it && lane == kWave - 1)
-            seg_D[p.seg_offset + seg - seg_stride] = D_prev;
+        if (prev_seg != kNoSeg && lane == kWave - 1)
+            seg_D[p.seg_offset + prev_seg] = D_prev;
         asm volatile("" ::: "memory");
         // the registers are free again: the next segment's loads fly while this one is folded out of LDS — in front of
         // any spill store of this segment, so that a spill never stands between the wave and its next data
         // (same wave wrote and reads the buffer: LDS operations of one wave complete in order)
-        if (it + 1 < count) {
-            E_next = tile_E[(p.seg_offset + seg + seg_stride) >> 1];
+        if (nseg < p.nsegs) {
+            E_next = tile_E[(p.seg_offset + nseg) >> 1];
             asm volatile("" ::: "memory");
             if constexpr (DIRECT)
-                load_seg_lds(mine, seg + seg_stride);
+                load_seg_lds(mine, nseg);
             else
-                load_seg(x, seg + seg_stride);
+                load_seg(x, nseg);
         }
         const bool valid = E != PAPR_EXACT_AMBIG;
         const double m0 = valid ? pow2_f64(E) : 0.0, ulp = valid ? pow2_f64(E - 52) : 0.0, m1 = m0 + ulp;
@@ -1038,8 +1047,8 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         // room for the segment's 16 samples of every lane (and the trash words)?  Checked IN FRONT of the fold, behind the
         // next segment's loads: a spill's stores then have the fold's duration to drain before this wave waits for memory
         // again (vmcnt is in order and counts stores too)
-        ws.spill_in_step(now, FINE ? SLICE - kWave : SLICE - (2 * U + 1) * kWave,
-                         (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
+        segs_done++;
+        ws.spill_in_step(now, FINE ? SLICE - kWave : SLICE - (2 * U + 1) * kWave, segs_done * (uint32_t)(WAVES * 2 * SEG_F4));
         if constexpr (!DIRECT) {
 #pragma unroll
             for (int j = 0; j < U; j++)
@@ -1082,7 +1091,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
                 flag[u] = k[u] & 1u;
                 cnt += flag[u];
             }
-            ws.put_tile(pw, flag, cnt, SLICE, (it + 1) * (uint32_t)(WAVES * 2 * SEG_F4));
+            ws.put_tile(pw, flag, cnt, SLICE, segs_done * (uint32_t)(WAVES * 2 * SEG_F4));
         } else {
             // (the coarse table puts five powers per segment: a slot per sample as it comes, nothing to wait for — with slots per
             // lane this form was 1.2 % slower on one box and even on two: profiles/r05_ab_exact_stash_slots.txt)
@@ -1090,14 +1099,16 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
             for (int u = 0; u < 2 * U; u++)
                 count_and_stash(pw[u], k[u]);
         }
-        segmax_commit(tr, m, it);
+        segmax_commit(tr, m, (uint32_t)seg);  // (the tracker remembers the SEGMENT)
         // ---- the segment's pair ----
         const double d0 = x0 - m0, d1 = x1 - m1;  // exact: multiples of the ulp inside the binade (plain sums when no binade was given)
         sum += d0;
         D_prev = segment_pair(x0, x1, d0, d1, ulp);
+        prev_seg = seg;
+        seg = nseg;
     }
-    if (count && lane == kWave - 1)
-        seg_D[p.seg_offset + seg0 + (uint64_t)(count - 1) * seg_stride] = D_prev;
+    if (prev_seg != kNoSeg && lane == kWave - 1)
+        seg_D[p.seg_offset + prev_seg] = D_prev;
     // remainder of the launch: binned here (its pass-1 part is folded in by papr_stats_finalize, its exact-sum part
     // travels raw in the sum program)
     if (blockIdx.x == gridDim.x - 1) {
@@ -1112,7 +1123,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
     }
     ws.spill_if_above(0, ~0u);
 
-    sweep2_record<WAVES, U, true>(sum, tr, seg0, seg_stride, data, p.base_index, p.out);
+    sweep2_record<WAVES, U, true>(sum, tr, 0, 1, data, p.base_index, p.out);  // (segment = 0 + the tracker's entry * 1)
     hist_flush<BLOCK>(hist, nbins, P.copies, p.ghist);  // (starts with a barrier: every wave has spilled)
     if (t == 0) {
         p.seg_slots[blockIdx.x] = seg_fill;
@@ -1220,6 +1231,25 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
                        out, group_sums, block_sq);
 }
 
+// The XCD skew of the product kernels' walk (SkewWalk): in every R rounds of tiles the odd workgroups sit the last one out.
+// How much the odd XCDs lag depends on how much of a kernel's time is memory's: the tree-sum kernel (kind 0) wants R = 24 (its
+// odd workgroups fold 4.2 % less; measured -1.0 % / -1.9 % of kernel time for the two tables), the exact-sum kernel's 0.1 dB
+// form (kind 2) R = 48 (-1 %), its 1 dB form (kind 1) R = 96 (at 48 the EVEN workgroups finish last) — profiles/r05_xcd_skew.txt.
+// PAPR_XCD_SKEW=R overrides all three (0: plain grid stride).  Launches of fewer than four periods (a chunked ingest's) are
+// not skewed: nothing to even out.
+uint32_t papr_sweep_xcd_skew_rounds(uint64_t ntiles, int blocks, int kind)
+{
+    static const long forced = [] {
+        const char *e = getenv("PAPR_XCD_SKEW");
+        return e && *e ? atol(e) : -1L;
+    }();
+    const long v = forced >= 0 ? forced : (kind == 0 ? 24 : kind == 2 ? 48 : 96);
+    const uint32_t rounds = (uint32_t)(v < 2 ? 0 : (v > 4096 ? 4096 : v));
+    if (!rounds || blocks <= 0 || (blocks & 7) != 0 || ntiles < 4ull * rounds * (uint64_t)blocks)
+        return 0;
+    return rounds;
+}
+
 int papr_sweep_variant(int variant)
 {
     if (variant == PAPR_SWEEP_VARIANT)
@@ -1253,6 +1283,8 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
                        unsigned long long *seg_real, const papr_ccdf_params *Pdev)
 {
     if (variant == PAPR_SWEEP_VARIANT) {
+        // (the product kernel walks grid stride whatever `map` says, with the XCD skew: its period rides in map's upper bits)
+        map = (map & 0xFF) | (int)(papr_sweep_xcd_skew_rounds((uint64_t)ntiles, blocks, 0) << 8);
         launch_maybe_timed(papr_sweep_kernel, dim3(blocks), dim3(PAPR_SWEEP_THREADS), lds_bytes, st, (const float4 *)data, ntiles,
                            base_index, map, out, (const float2 *)tail, tail_samples, table, P, ghist, stash, seg_counts, seg_cap,
                            gave_up, seg_real, Pdev);
@@ -1300,6 +1332,7 @@ void papr_launch_sweep3(hipStream_t st, int variant, int blocks, size_t lds_byte
         return;
     papr_sweep2_params q = p;
     q.lds_bytes = (uint32_t)lds_bytes;
+    q.xcd_skew = papr_sweep_xcd_skew_rounds((p.nsegs + 7) / 8, blocks, q.fine_table ? 2 : 1);
     // (which form: the table's size is known to whoever planned it — the host, or papr_guess_bands_kernel through p.fine_hint)
     if (q.fine_table)
         launch_maybe_timed(papr_sweep3_kernel<true>, dim3(blocks), dim3(PAPR_SWEEP_THREADS), lds_bytes, st, q);

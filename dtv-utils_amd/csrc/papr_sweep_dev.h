@@ -275,6 +275,47 @@ struct WaveStash {
 };
 
 
+// WHICH tiles a persistent workgroup folds: grid stride — concurrently running workgroups read neighbouring tiles — with a
+// SKEW between the XCDs.  The chip's XCDs do not read at one speed: with equal shares the workgroups of XCDs 1, 3, 5, 7 finish
+// behind those of 0, 2, 4, 6 (a stripped read kernel: by 7 %; the sweep kernels: by 25-55 us of 1.6 ms — tools/wg_skew_probe.hip,
+// tools/wg_finish_probe.py, profiles/r05_xcd_skew.txt), and a launch lasts as long as its slowest workgroup.  So in every
+// period of R rounds the last round belongs to the even workgroups alone (workgroup b runs on XCD b mod 8): the odd ones fold
+// (R - 1) / R of what the even ones fold.  Still a fixed function of (workgroup, iteration): nothing is drawn at run time,
+// results do not depend on timing, a lane meets its tiles in increasing order.  (Handing the tiles out from a counter in
+// device memory evens the finish times out completely and costs per tile what that is worth: measured, not kept.)
+struct SkewWalk {
+    uint64_t base;        // first tile of the current period
+    uint64_t period;      // tiles per period: (R - 1) full rounds + one round of the even workgroups
+    uint32_t r, rounds_mine, full_rounds, nblocks, b;
+    __device__ __forceinline__ void init(uint32_t block, uint32_t blocks, uint32_t R)
+    {
+        b = block;
+        nblocks = blocks;
+        base = 0;
+        r = 0;
+        if (R < 2 || (blocks & 7u) != 0) {  // no skew: plain grid stride
+            full_rounds = 0xFFFFFFFFu;
+            rounds_mine = 0xFFFFFFFFu;
+            period = 0;
+        } else {
+            full_rounds = R - 1;
+            rounds_mine = (block & 1u) ? R - 1 : R;
+            period = (uint64_t)blocks * (R - 1) + blocks / 2;
+        }
+    }
+    __device__ __forceinline__ uint64_t tile() const
+    {
+        return base + (r < full_rounds ? (uint64_t)r * nblocks + b : (uint64_t)full_rounds * nblocks + (b >> 1));
+    }
+    __device__ __forceinline__ void advance()
+    {
+        if (++r == rounds_mine) {
+            r = 0;
+            base += period;
+        }
+    }
+};
+
 struct TileTrack {
     float best[5];     // peak power, re_pos, re_neg, im_pos, im_neg
     uint32_t iter[5];  // loop iteration in which `best` first appeared
@@ -395,7 +436,7 @@ __device__ __forceinline__ void sweep_record(double sum, const TileTrack &tr, co
             q.val[k] = win[k];
             q.idx[k] = win[k] != 0.f ? best_idx : 0;
         }
-        q.pad = 0;
+        q.pad = (uint32_t)__builtin_amdgcn_s_memrealtime();  // when this workgroup was done (100 MHz ticks: papr_hip_get_wg_finish)
         out[blockIdx.x] = q;
     }
 }
@@ -517,7 +558,7 @@ __device__ __forceinline__ void sweep2_record(double sum, const TileTrack &tr, u
             q.val[k] = win[k];
             q.idx[k] = win[k] != 0.f ? best_idx : 0;
         }
-        q.pad = 0;
+        q.pad = (uint32_t)__builtin_amdgcn_s_memrealtime();  // when this workgroup was done (100 MHz ticks: papr_hip_get_wg_finish)
         out[blockIdx.x] = q;
     }
 }

@@ -734,6 +734,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
         p.seg_offset = 0;
         p.fine_table = graph ? 1u : 0u;  // (the table is planned on the device: 301 bands for -g, 31 otherwise)
         time_begin_kernel(ctx, 3, ctx->n * 8);
+        ctx->sweep_blocks_last = (uint32_t)run.blocks;
         if (run.v3)
             papr_launch_sweep3(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, p);
         else
@@ -742,6 +743,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
     } else {
         const int map = effective_map(ctx, SWEEP, run.blocks);
         time_begin_kernel(ctx, 3, ctx->n * 8);
+        ctx->sweep_blocks_last = (uint32_t)run.blocks;
         papr_launch_sweep(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, ctx->d_iq, ntiles, ctx->base, map,
                           ctx->d_partials, ctx->d_iq + 2 * (ctx->n - tail), tail, ctx->d_table, none, ctx->d_sweep_hist,
                           ctx->d_stash, ctx->d_sweep_hist + kBinsMax, run.seg_cap, ctx->d_sweep_hist + kBinsMax + 2 * run.blocks,
@@ -1096,6 +1098,21 @@ static int papr_hip_stats_sweep_impl(papr_hip_ctx *ctx, const float *guess_level
         ctx->exact_valid = true;
     }
     return rc;
+}
+
+int papr_hip_get_wg_finish(papr_hip_ctx *ctx, uint32_t *ticks, int cap)
+{
+    if (!ctx || cap < 0 || (cap && !ticks))
+        return PAPR_E_ARG;
+    const uint32_t n = ctx->sweep_blocks_last;
+    if (!n || !ctx->d_partials || ctx->partials_cap < n)
+        return 0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<papr_partial> recs(n);
+    HIPCHK(ctx, hipMemcpy(recs.data(), ctx->d_partials, (size_t)n * sizeof(papr_partial), hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < n && (int)k < cap; k++)
+        ticks[k] = recs[k].pad;
+    return (int)n;
 }
 
 int papr_hip_get_sweep_info(const papr_hip_ctx *ctx, papr_hip_sweep_info *out)

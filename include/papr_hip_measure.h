@@ -120,6 +120,11 @@ typedef struct papr_hip_sweep_info {
     int reserved;
 } papr_hip_sweep_info;
 int papr_hip_get_sweep_info(const papr_hip_ctx *ctx, papr_hip_sweep_info *out);
+/* When every workgroup of the last single-wait step's sweep launch was done: the low 32 bits of the 100 MHz real-time counter
+ * (10 ns ticks) as each workgroup left, in workgroup order — the kernels are ONE persistent workgroup per CU over a static
+ * share of the shard, so the launch lasts as long as its slowest workgroup, and the spread says how much of it the others
+ * idle.  Returns the number of workgroups (writes min(that, cap) ticks), 0 if no sweep was launched, or a negative code. */
+int papr_hip_get_wg_finish(papr_hip_ctx *ctx, uint32_t *ticks, int cap);
 
 /* The GPU-free halves of the one-sweep bookkeeping — what the runtime itself calls, exported so that the
  * speculation's logic can be checked without a GPU (tests/test_sweep_host.py):
