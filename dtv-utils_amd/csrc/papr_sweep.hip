@@ -1233,7 +1233,7 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
 
 // The XCD skew of the product kernels' walk (SkewWalk): in every R rounds of tiles the odd workgroups sit the last one out.
 // How much the odd XCDs lag depends on how much of a kernel's time is memory's: the tree-sum kernel (kind 0) wants R = 24 (its
-// odd workgroups fold 4.2 % less; measured -1.0 % / -1.9 % of kernel time for the two tables), the exact-sum kernel's 0.1 dB
+// odd workgroups fold 4.2 % less: -1.0 ... -1.5 % of kernel time; R = 20 with the 0.1 dB table, kind 3: -1.6 ... -1.9 %), the exact-sum kernel's 0.1 dB
 // form (kind 2) R = 48 (-1 %), its 1 dB form (kind 1) R = 96 (at 48 the EVEN workgroups finish last) — profiles/r05_xcd_skew.txt.
 // PAPR_XCD_SKEW=R overrides all three (0: plain grid stride).  Launches of fewer than four periods (a chunked ingest's) are
 // not skewed: nothing to even out.
@@ -1243,7 +1243,7 @@ uint32_t papr_sweep_xcd_skew_rounds(uint64_t ntiles, int blocks, int kind)
         const char *e = getenv("PAPR_XCD_SKEW");
         return e && *e ? atol(e) : -1L;
     }();
-    const long v = forced >= 0 ? forced : (kind == 0 ? 24 : kind == 2 ? 48 : 96);
+    const long v = forced >= 0 ? forced : (kind == 0 ? 24 : kind == 3 ? 20 : kind == 2 ? 48 : 96);
     const uint32_t rounds = (uint32_t)(v < 2 ? 0 : (v > 4096 ? 4096 : v));
     if (!rounds || blocks <= 0 || (blocks & 7) != 0 || ntiles < 4ull * rounds * (uint64_t)blocks)
         return 0;
@@ -1284,7 +1284,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
 {
     if (variant == PAPR_SWEEP_VARIANT) {
         // (the product kernel walks grid stride whatever `map` says, with the XCD skew: its period rides in map's upper bits)
-        map = (map & 0xFF) | (int)(papr_sweep_xcd_skew_rounds((uint64_t)ntiles, blocks, 0) << 8);
+        map = (map & 0x7F) | (int)(papr_sweep_xcd_skew_rounds((uint64_t)ntiles, blocks, (map & 0x80) || P.nkeys > 128u ? 3 : 0) << 8);
         launch_maybe_timed(papr_sweep_kernel, dim3(blocks), dim3(PAPR_SWEEP_THREADS), lds_bytes, st, (const float4 *)data, ntiles,
                            base_index, map, out, (const float2 *)tail, tail_samples, table, P, ghist, stash, seg_counts, seg_cap,
                            gave_up, seg_real, Pdev);

@@ -741,7 +741,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
             papr_launch_sweep2(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, p);
         time_end_kernel(ctx);
     } else {
-        const int map = effective_map(ctx, SWEEP, run.blocks);
+        const int map = effective_map(ctx, SWEEP, run.blocks) | (graph ? 0x80 : 0);  // (0x80: the 0.1 dB table — its own XCD skew)
         time_begin_kernel(ctx, 3, ctx->n * 8);
         ctx->sweep_blocks_last = (uint32_t)run.blocks;
         papr_launch_sweep(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, ctx->d_iq, ntiles, ctx->base, map,
