@@ -32,11 +32,11 @@ $(CSRC)/ts_runtime$(X): $(CSRC)/ts_runtime.cpp $(CSRC)/ts_kernels.h include/ts_h
 $(CSRC)/papr_kernels$(X): $(CSRC)/papr_kernels.hip $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h $(CSRC)/papr_stream.h include/papr_synth.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/papr_sweep$(X): $(CSRC)/papr_sweep.hip $(CSRC)/papr_sweep_dev.h $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h $(CSRC)/papr_stream.h
+$(CSRC)/papr_sweep$(X): $(CSRC)/papr_sweep.hip $(CSRC)/papr_sweep_dev.h $(CSRC)/papr_skew_walk.h $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h $(CSRC)/papr_stream.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 # the laboratory: every other kernel form of the sweep (geometries, stash forms, ablations) — `make MEASURE=1` only
-$(CSRC)/measure/papr_sweep_lab$(X): $(CSRC)/measure/papr_sweep_lab.hip $(CSRC)/papr_sweep_dev.h $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h $(CSRC)/papr_stream.h
+$(CSRC)/measure/papr_sweep_lab$(X): $(CSRC)/measure/papr_sweep_lab.hip $(CSRC)/papr_sweep_dev.h $(CSRC)/papr_skew_walk.h $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h $(CSRC)/papr_stream.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/papr_exact$(X): $(CSRC)/papr_exact.hip $(CSRC)/papr_exact_format.h $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h $(CSRC)/papr_stream.h

@@ -11,6 +11,7 @@
 #include "papr_kernels.h"
 #include "papr_device.h"
 #include "papr_stream.h"
+#include "papr_skew_walk.h"
 
 namespace {
 
@@ -283,39 +284,6 @@ struct WaveStash {
 // (R - 1) / R of what the even ones fold.  Still a fixed function of (workgroup, iteration): nothing is drawn at run time,
 // results do not depend on timing, a lane meets its tiles in increasing order.  (Handing the tiles out from a counter in
 // device memory evens the finish times out completely and costs per tile what that is worth: measured, not kept.)
-struct SkewWalk {
-    uint64_t base;        // first tile of the current period
-    uint64_t period;      // tiles per period: (R - 1) full rounds + one round of the even workgroups
-    uint32_t r, rounds_mine, full_rounds, nblocks, b;
-    __device__ __forceinline__ void init(uint32_t block, uint32_t blocks, uint32_t R)
-    {
-        b = block;
-        nblocks = blocks;
-        base = 0;
-        r = 0;
-        if (R < 2 || (blocks & 7u) != 0) {  // no skew: plain grid stride
-            full_rounds = 0xFFFFFFFFu;
-            rounds_mine = 0xFFFFFFFFu;
-            period = 0;
-        } else {
-            full_rounds = R - 1;
-            rounds_mine = (block & 1u) ? R - 1 : R;
-            period = (uint64_t)blocks * (R - 1) + blocks / 2;
-        }
-    }
-    __device__ __forceinline__ uint64_t tile() const
-    {
-        return base + (r < full_rounds ? (uint64_t)r * nblocks + b : (uint64_t)full_rounds * nblocks + (b >> 1));
-    }
-    __device__ __forceinline__ void advance()
-    {
-        if (++r == rounds_mine) {
-            r = 0;
-            base += period;
-        }
-    }
-};
-
 struct TileTrack {
     float best[5];     // peak power, re_pos, re_neg, im_pos, im_neg
     uint32_t iter[5];  // loop iteration in which `best` first appeared

@@ -86,3 +86,27 @@ def test_resolve_equals_brute_force_whatever_the_guess(pkg, graph):
         o_got = pkg.sweep_resolve(keys, band_log2, above_band, other, o_stash)
         assert o_got is None or np.array_equal(o_got, o_want)
     assert resolved >= 40 and missed >= 10
+
+
+def test_the_kernels_walk_covers_every_tile_once(tmp_path):
+    """SkewWalk (csrc/papr_skew_walk.h: which tiles a persistent workgroup folds — grid stride with the odd XCDs' workgroups
+    sitting one round in R out) compiled for the host: every tile exactly once, a workgroup's tiles in increasing order (the
+    trackers' first-occurrence rule needs that), the shares in the ratio (R - 1) / R; the bench shard's geometry (163 840 tiles of
+    64 KiB, 256 workgroups) with every period the kernels use, odd sizes, no skew, a workgroup count the skew does not apply to."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "skew_harness")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(root, "dtv-utils_amd", "csrc"),
+                           os.path.join(root, "tests", "c", "skew_harness.cpp"), "-o", exe])
+    for ntiles, blocks, R in [(163840, 256, 24), (163840, 256, 20), (163840, 256, 48), (163840, 256, 96), (163841, 256, 24),
+                              (1000003, 256, 2), (12345, 64, 3), (255, 256, 24), (0, 256, 24), (163840, 256, 0), (9999, 250, 24),
+                              (4097, 8, 5)]:
+        p = subprocess.run([exe, str(ntiles), str(blocks), str(R)], capture_output=True, text=True)
+        assert p.returncode == 0 and p.stdout.startswith("ok"), (ntiles, blocks, R, p.stdout)
+        even, odd = (int(v) for v in p.stdout.split()[1:3])
+        assert even + odd == ntiles
+        if R >= 2 and blocks % 8 == 0 and ntiles >= 50 * R * blocks:   # (many whole periods: the shares are what they should be)
+            assert abs(odd / even - (R - 1) / R) < 2e-3, (ntiles, blocks, R, even, odd)
+        if R < 2 or blocks % 8:
+            assert abs(even - odd) <= blocks   # plain grid stride
