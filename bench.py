@@ -422,10 +422,11 @@ def run_mode(args, mode, env):
     if one_sweep:
         result["sweep_info"] = gpu.sweep_info().as_dict()
         try:   # when the last sweep launch's persistent workgroups were done (papr_hip_get_wg_finish), us after the first
-            wf = gpu.wg_finish_us()
+            wf, where = gpu.wg_finish()
             if wf.size:
                 result["wg_finish_us"] = {"workgroups": int(wf.size), "median": round(float(np.median(wf)), 1), "last": round(float(wf.max()), 1),
-                                          "per_xcd_mean": [round(float(wf[x::8].mean()), 1) for x in range(8)] if wf.size % 8 == 0 else None}
+                                          "per_xcd_mean": [round(float(wf[where == x].mean()), 1) if (where == x).any() else None for x in range(8)],
+                                          "xcd_of_first_workgroups": where[:8].tolist()}
         except Exception:
             pass
     aux_steps = min(5, args.steps)

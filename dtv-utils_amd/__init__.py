@@ -111,7 +111,7 @@ class SweepInfo(C.Structure):
     _fields_ = [("stash_samples", C.c_uint64), ("stash_capacity", C.c_uint64), ("estimate_samples", C.c_uint64),
                 ("swept", C.c_int), ("resolved", C.c_int), ("reason", C.c_int), ("band_log2", C.c_int),
                 ("exact_redo_tiles", C.c_uint32), ("gave_up", C.c_uint32), ("kernel_variant", C.c_int),
-                ("reserved", C.c_int)]
+                ("xcd_first", C.c_int)]
 
     def as_dict(self) -> dict:
         d = {name: getattr(self, name) for name, _ in self._fields_}
@@ -450,16 +450,22 @@ class PaprHip:
         self._chk(self._L.papr_hip_load_file_sweep(self._ctx, os.fsencode(path), first_sample, nsamples,
                                                    lv.ctypes.data_as(C.c_void_p), lv.size), "papr_hip_load_file_sweep")
 
-    def wg_finish_us(self) -> np.ndarray:
-        """papr_hip_get_wg_finish: when each workgroup of the last sweep launch was done, in microseconds after the first one."""
+    def wg_finish(self):
+        """papr_hip_get_wg_finish: (us after the first one, XCD) for each workgroup of the last sweep launch."""
         t = np.zeros(4096, dtype=np.uint32)
         n = self._chk_pos(self._L.papr_hip_get_wg_finish(self._ctx, t.ctypes.data_as(C.c_void_p), t.size), "papr_hip_get_wg_finish")
         t = t[:min(n, t.size)]
         if t.size == 0:
-            return np.zeros(0)
-        d = (t - t.min()).astype(np.uint32)          # (modulo 2^32 ticks: the counter may wrap once in 43 s)
-        d = np.where(d > (1 << 31), (t - t.max()).astype(np.uint32), d) if d.max() > (1 << 31) else d
-        return d.astype(np.float64) / 100.0
+            return np.zeros(0), np.zeros(0, dtype=np.uint32)
+        xcd = t >> 28
+        ticks = (t & 0x0FFFFFFF).astype(np.int64)
+        d = (ticks - ticks.min()) % (1 << 28)
+        if d.max() > (1 << 27):   # (the 28-bit counter wrapped inside the launch: measure from the largest gap)
+            d = (ticks - ticks.max()) % (1 << 28)
+        return d.astype(np.float64) / 100.0, xcd
+
+    def wg_finish_us(self) -> np.ndarray:
+        return self.wg_finish()[0]
 
     def shard_fits(self, nsamples: int) -> bool:
         return bool(self._chk_pos(self._L.papr_hip_shard_fits(self._ctx, nsamples), "papr_hip_shard_fits"))

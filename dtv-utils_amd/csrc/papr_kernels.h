@@ -236,6 +236,8 @@ void papr_launch_guess_bands(hipStream_t st, const papr_partial *est_partials, c
 #define PAPR_SWEEP_VARIANT 111
 #define PAPR_SWEEP3_VARIANT 131
 uint32_t papr_sweep_xcd_skew_rounds(uint64_t ntiles, int blocks, int kind);
+#define PAPR_MAP_EVEN_SLOW (1 << 30)  /* papr_launch_sweep's map: workgroup 0 sits on an odd XCD, the EVEN workgroups take the skew */
+void papr_launch_xcd_probe(hipStream_t st, unsigned long long *out);
 int papr_sweep_variant(int variant); /* the sweep geometry used for a variant id, or -1 */
 #define PAPR_SWEEP_VARIANT_IS_LUT2(v) (((v) >= 20 && (v) <= 29) || ((v) >= 70 && (v) <= 79) || (v) == 18 || (v) == 38) /* compact table: papr_sweep_kernel<LUT2>, papr_sweep_split_kernel */
 #define PAPR_SWEEP_VARIANT_IS_PERSISTENT(v) ((v) == PAPR_SWEEP_VARIANT || (v) == 40 || (v) == 114 || ((v) >= 120 && (v) <= 129) || ((v) >= 140 && (v) <= 154)) /* launched as ONE workgroup per CU (512 threads x 8 loads per lane) */
@@ -314,7 +316,8 @@ struct papr_sweep2_params {
     uint64_t seg_offset;          // index of the launch's first segment within the shard (chunked launches)
     uint32_t lds_bytes;           // papr_sweep3_kernel: the launch's dynamic LDS (set by its launch wrapper)
     uint32_t fine_table;          // papr_sweep3_kernel: more than 64 bands (the 0.1 dB table) — selects the kernel form
-    uint32_t xcd_skew;            // papr_sweep3_kernel: period of the walk's XCD skew in rounds (0: none; set by papr_launch_sweep3)
+    uint32_t xcd_skew;            // papr_sweep3_kernel: period of the walk's XCD skew in rounds (0: none; set by papr_launch_sweep3);
+                                  // bit 31 (the caller's): workgroup 0 sits on an odd XCD, the EVEN workgroups take the skew
 };
 int papr_sweep2_geometry(int variant, int *threads, uint64_t *seg_samples, size_t *lds_fixed, int *exact);
 // ---- the exact-sum sweep, third form (papr_sweep.hip: papr_sweep3_kernel) ----------------------------------------

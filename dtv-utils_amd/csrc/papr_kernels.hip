@@ -152,7 +152,7 @@ __global__ __launch_bounds__(PAPR_BLOCK) void papr_stats_finalize(const float2 *
             r.idx[k] = s.idx[k];
             r.val[k] = s.val[k];
         }
-        r.pad = 0;
+        r.pad = npartials ? partials[0].pad : 0;  // (a sweep's workgroup 0: when it was done, and on which XCD)
         *result = r;
         if (result_dev)
             *result_dev = r;  // (for papr_true_table_kernel: `result` is host memory)

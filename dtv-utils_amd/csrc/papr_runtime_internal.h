@@ -276,6 +276,7 @@ struct papr_hip_ctx {
     uint64_t sweep_stash_count = 0;
     uint64_t sweep_seg_cap = 0;                  // floats per stash segment
     uint32_t sweep_nsegs = 0, sweep_nbins = 0, sweep_seg_off = 0;
+    int xcd_first = -1;                  // XCD of the stream's workgroup 0 (probed once, then from every sweep's record); -1: not known
     uint32_t sweep_blocks_last = 0;      // workgroups of the last sweep launch (their records lead d_partials)
     papr_guess_out *d_guess = nullptr, *h_guess = nullptr, *h_guess_dev = nullptr;  // papr_guess_bands_kernel's output (device; mapped host)
     double *d_pow_tab = nullptr;  // [2][PAPR_POW_TABLE]: the host libm's pow(10, x_j) of the two level tables (papr_host.c)

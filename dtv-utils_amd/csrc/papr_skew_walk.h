@@ -14,9 +14,11 @@
 
 struct SkewWalk {
     uint64_t base;        // first tile of the current period
-    uint64_t period;      // tiles per period: (R - 1) full rounds + one round of the even workgroups
+    uint64_t period;      // tiles per period: (R - 1) full rounds + one round of the workgroups on the even XCDs
     uint32_t r, rounds_mine, full_rounds, nblocks, b;
-    PAPR_HD void init(uint32_t block, uint32_t blocks, uint32_t R)
+    // `slow`: the parity (block & 1) of the workgroups that sit the last round of every period out — those on the odd XCDs,
+    // whichever parity the queue's round-robin gave them this time (papr_sweep_rt.cpp: xcd_slow_parity)
+    PAPR_HD void init(uint32_t block, uint32_t blocks, uint32_t R, uint32_t slow = 1u)
     {
         b = block;
         nblocks = blocks;
@@ -28,7 +30,7 @@ struct SkewWalk {
             period = 0;
         } else {
             full_rounds = R - 1;
-            rounds_mine = (block & 1u) ? R - 1 : R;
+            rounds_mine = (block & 1u) == (slow & 1u) ? R - 1 : R;
             period = (uint64_t)blocks * (R - 1) + blocks / 2;
         }
     }

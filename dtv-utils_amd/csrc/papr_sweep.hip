@@ -785,7 +785,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep_kernel(const fl
 
     // which tiles: grid stride with the XCD skew (SkewWalk, papr_sweep_dev.h); `map` carries the skew's period in its upper bits
     SkewWalk walk;
-    walk.init(blockIdx.x, gridDim.x, (uint32_t)map >> 8);
+    walk.init(blockIdx.x, gridDim.x, ((uint32_t)map >> 8) & 0xFFFFu, (((uint32_t)map >> 30) & 1u) ^ 1u);
     float4 cur[U], nxt[U];
     uint64_t tile = walk.tile();
     if (tile < ntiles)
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
     // which segments: the workgroup's eight waves take the eight segments of a 64 KiB tile, wave w the w-th; the tiles grid
     // stride with the XCD skew (SkewWalk, papr_sweep_dev.h).  A wave's segments come in increasing order.
     SkewWalk walk;
-    walk.init(blockIdx.x, gridDim.x, p.xcd_skew);
+    walk.init(blockIdx.x, gridDim.x, p.xcd_skew & 0xFFFFu, (p.xcd_skew >> 31) ^ 1u);
     constexpr uint64_t kNoSeg = ~0ull;
     uint64_t seg = walk.tile() * WAVES + wave, prev_seg = kNoSeg;
     uint32_t segs_done = 0;
@@ -1231,7 +1231,20 @@ void papr_launch_estimate(hipStream_t st, int blocks, const void *data, uint64_t
                        out, group_sums, block_sq);
 }
 
-// The XCD skew of the product kernels' walk (SkewWalk): in every R rounds of tiles the odd workgroups sit the last one out.
+// Which XCD a queue's workgroup 0 lands on (the round-robin's start differs between queues: 6 in a plain process, 5 with RCCL's
+// queues beside ours — profiles/r05_xcd_skew.txt), asked once per context on its own stream (papr_sweep_rt.cpp: xcd_even_slow).
+__global__ void papr_xcd_probe_kernel(unsigned long long *out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *out = papr_xcc_id();
+}
+void papr_launch_xcd_probe(hipStream_t st, unsigned long long *out)
+{
+    hipLaunchKernelGGL(papr_xcd_probe_kernel, dim3(8), dim3(64), 0, st, out);
+}
+
+// The XCD skew of the product kernels' walk (SkewWalk): in every R rounds of tiles the workgroups on the odd XCDs sit the last
+// one out (the odd workgroups, or with PAPR_MAP_EVEN_SLOW / bit 31 of papr_sweep2_params::xcd_skew the even ones).
 // How much the odd XCDs lag depends on how much of a kernel's time is memory's: the tree-sum kernel (kind 0) wants R = 24 (its
 // odd workgroups fold 4.2 % less: -1.0 ... -1.5 % of kernel time; R = 20 with the 0.1 dB table, kind 3: -1.6 ... -1.9 %), the exact-sum kernel's 0.1 dB
 // form (kind 2) R = 48 (-1 %), its 1 dB form (kind 1) R = 96 (at 48 the EVEN workgroups finish last) — profiles/r05_xcd_skew.txt.
@@ -1284,7 +1297,7 @@ void papr_launch_sweep(hipStream_t st, int variant, int blocks, size_t lds_bytes
 {
     if (variant == PAPR_SWEEP_VARIANT) {
         // (the product kernel walks grid stride whatever `map` says, with the XCD skew: its period rides in map's upper bits)
-        map = (map & 0x7F) | (int)(papr_sweep_xcd_skew_rounds((uint64_t)ntiles, blocks, (map & 0x80) || P.nkeys > 128u ? 3 : 0) << 8);
+        map = (map & (0x7F | PAPR_MAP_EVEN_SLOW)) | (int)(papr_sweep_xcd_skew_rounds((uint64_t)ntiles, blocks, (map & 0x80) || P.nkeys > 128u ? 3 : 0) << 8);
         launch_maybe_timed(papr_sweep_kernel, dim3(blocks), dim3(PAPR_SWEEP_THREADS), lds_bytes, st, (const float4 *)data, ntiles,
                            base_index, map, out, (const float2 *)tail, tail_samples, table, P, ghist, stash, seg_counts, seg_cap,
                            gave_up, seg_real, Pdev);
@@ -1332,7 +1345,7 @@ void papr_launch_sweep3(hipStream_t st, int variant, int blocks, size_t lds_byte
         return;
     papr_sweep2_params q = p;
     q.lds_bytes = (uint32_t)lds_bytes;
-    q.xcd_skew = papr_sweep_xcd_skew_rounds((p.nsegs + 7) / 8, blocks, q.fine_table ? 2 : 1);
+    q.xcd_skew = (p.xcd_skew & 0x80000000u) | papr_sweep_xcd_skew_rounds((p.nsegs + 7) / 8, blocks, q.fine_table ? 2 : 1);
     // (which form: the table's size is known to whoever planned it — the host, or papr_guess_bands_kernel through p.fine_hint)
     if (q.fine_table)
         launch_maybe_timed(papr_sweep3_kernel<true>, dim3(blocks), dim3(PAPR_SWEEP_THREADS), lds_bytes, st, q);

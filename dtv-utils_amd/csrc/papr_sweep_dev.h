@@ -280,10 +280,15 @@ struct WaveStash {
 // SKEW between the XCDs.  The chip's XCDs do not read at one speed: with equal shares the workgroups of XCDs 1, 3, 5, 7 finish
 // behind those of 0, 2, 4, 6 (a stripped read kernel: by 7 %; the sweep kernels: by 25-55 us of 1.6 ms — tools/wg_skew_probe.hip,
 // tools/wg_finish_probe.py, profiles/r05_xcd_skew.txt), and a launch lasts as long as its slowest workgroup.  So in every
-// period of R rounds the last round belongs to the even workgroups alone (workgroup b runs on XCD b mod 8): the odd ones fold
-// (R - 1) / R of what the even ones fold.  Still a fixed function of (workgroup, iteration): nothing is drawn at run time,
+// period of R rounds the last round belongs to the workgroups on the even XCDs alone: the others fold (R - 1) / R of what they
+// fold.  Workgroup b runs on XCD (b + first) mod 8, `first` being the queue's (6 alone, 5 beside RCCL's queues): the host finds it
+// out (papr_sweep_rt.cpp: xcd_even_slow) and hands the kernels the PARITY to skew — one value for the whole launch, so that which
+// tiles are folded never depends on what a workgroup reads from its own hardware registers.  Still a fixed function of (workgroup, iteration): nothing is drawn at run time,
 // results do not depend on timing, a lane meets its tiles in increasing order.  (Handing the tiles out from a counter in
 // device memory evens the finish times out completely and costs per tile what that is worth: measured, not kept.)
+// the XCD this wave runs on (gfx940+: HW_REG_XCC_ID, bits 3:0)
+__device__ __forceinline__ uint32_t papr_xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu; }
+
 struct TileTrack {
     float best[5];     // peak power, re_pos, re_neg, im_pos, im_neg
     uint32_t iter[5];  // loop iteration in which `best` first appeared
@@ -404,7 +409,7 @@ __device__ __forceinline__ void sweep_record(double sum, const TileTrack &tr, co
             q.val[k] = win[k];
             q.idx[k] = win[k] != 0.f ? best_idx : 0;
         }
-        q.pad = (uint32_t)__builtin_amdgcn_s_memrealtime();  // when this workgroup was done (100 MHz ticks: papr_hip_get_wg_finish)
+        q.pad = ((uint32_t)__builtin_amdgcn_s_memrealtime() & 0x0FFFFFFFu) | (papr_xcc_id() << 28);  // when this workgroup was done (100 MHz ticks) and on which XCD (papr_hip_get_wg_finish)
         out[blockIdx.x] = q;
     }
 }
@@ -526,7 +531,7 @@ __device__ __forceinline__ void sweep2_record(double sum, const TileTrack &tr, u
             q.val[k] = win[k];
             q.idx[k] = win[k] != 0.f ? best_idx : 0;
         }
-        q.pad = (uint32_t)__builtin_amdgcn_s_memrealtime();  // when this workgroup was done (100 MHz ticks: papr_hip_get_wg_finish)
+        q.pad = ((uint32_t)__builtin_amdgcn_s_memrealtime() & 0x0FFFFFFFu) | (papr_xcc_id() << 28);  // when this workgroup was done (100 MHz ticks) and on which XCD (papr_hip_get_wg_finish)
         out[blockIdx.x] = q;
     }
 }

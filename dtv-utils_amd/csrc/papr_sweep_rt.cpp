@@ -365,6 +365,28 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
 //   ALL-REDUCE -> host.
 // Every rank then holds the same global numbers and takes the same decisions from them.  (Exact-sum mode with peers
 // keeps the host path: its programs are exchanged and chained on the host.)
+// Whether the EVEN workgroups of this context's stream sit on the odd — slower-reading — XCDs.  Workgroup b of a launch runs on
+// XCD (b + first) mod 8, and `first` is the queue's, not the device's (6 in a plain process, 5 once RCCL has queues of its
+// own: profiles/r05_xcd_skew.txt): asked of an 8-workgroup launch the first time, and from then on read out of every
+// sweep's record.  PAPR_XCD_PARITY=0|1 pins the answer (measurements).
+static bool xcd_even_slow(papr_hip_ctx *ctx)
+{
+    static const int pinned = env_int("PAPR_XCD_PARITY", -1);
+    if (pinned >= 0)
+        return pinned != 0;
+    if (ctx->xcd_first < 0) {
+        unsigned long long first = 0;
+        papr_launch_xcd_probe(ctx->stream, ctx->d_nan_key);
+        if (hipMemcpyAsync(&first, ctx->d_nan_key, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        ctx->xcd_first = (int)(first & 0xF);
+    }
+    return (ctx->xcd_first & 1) != 0;
+}
+
 int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max_db, float spoil, papr_stats *out, bool *done,
                       PeerStep *peer)
 {
@@ -700,6 +722,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
                             exact && !peers ? ctx->d_est_groups + 4 * ctx->est_groups_cap : nullptr, ctx->d_pow_tab);
     XCHK(hipGetLastError());
     const uint32_t tail = (uint32_t)(ctx->n - ntiles * run.tile);
+    const bool even_slow = xcd_even_slow(ctx);
     papr_ccdf_params none{};
     if (by_segments) {
         if (exact) {
@@ -733,6 +756,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
         p.seg_D = ctx->d_seg_D;
         p.seg_offset = 0;
         p.fine_table = graph ? 1u : 0u;  // (the table is planned on the device: 301 bands for -g, 31 otherwise)
+        p.xcd_skew = even_slow ? 0x80000000u : 0u;
         time_begin_kernel(ctx, 3, ctx->n * 8);
         ctx->sweep_blocks_last = (uint32_t)run.blocks;
         if (run.v3)
@@ -741,7 +765,7 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
             papr_launch_sweep2(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, p);
         time_end_kernel(ctx);
     } else {
-        const int map = effective_map(ctx, SWEEP, run.blocks) | (graph ? 0x80 : 0);  // (0x80: the 0.1 dB table — its own XCD skew)
+        const int map = effective_map(ctx, SWEEP, run.blocks) | (graph ? 0x80 : 0) | (even_slow ? PAPR_MAP_EVEN_SLOW : 0);  // (0x80: the 0.1 dB table — its own XCD skew)
         time_begin_kernel(ctx, 3, ctx->n * 8);
         ctx->sweep_blocks_last = (uint32_t)run.blocks;
         papr_launch_sweep(ctx->stream, run.variant, run.blocks, table_lds + run.stash_lds, ctx->d_iq, ntiles, ctx->base, map,
@@ -852,6 +876,8 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
     ctx->program_pending = false;
     if (peers && exact)
         ctx->exact_program_before = ctx->h_peer->before;
+    if (ctx->sweep_blocks_last >= 8)
+        ctx->xcd_first = (int)(ctx->h_result->pad >> 28);  // (where this stream's workgroup 0 ran: the next step's skew follows it)
     partial_to_stats(*ctx->h_result, ctx->n, out);
     out->flags |= ctx->shard_flags;
     if (peers) {
@@ -1120,6 +1146,7 @@ int papr_hip_get_sweep_info(const papr_hip_ctx *ctx, papr_hip_sweep_info *out)
     if (!ctx || !out)
         return PAPR_E_ARG;
     *out = ctx->sweep_info;
+    out->xcd_first = ctx->xcd_first;
     return PAPR_OK;
 }
 

@@ -117,11 +117,12 @@ typedef struct papr_hip_sweep_info {
                               * (constant-envelope captures); any > 0 shows as PAPR_SWEEP_STASH_FULL */
     int kernel_variant;      /* id of the kernel form the last sweep was launched as (papr_sweep.hip's tables); measurements
                               * quote it so that numbers taken with another form are recognised as stale */
-    int reserved;
+    int xcd_first;           /* XCD the context's stream puts workgroup 0 of a launch on (-1: not asked yet): its parity decides
+                              * which workgroups take the sweep kernels' XCD skew */
 } papr_hip_sweep_info;
 int papr_hip_get_sweep_info(const papr_hip_ctx *ctx, papr_hip_sweep_info *out);
-/* When every workgroup of the last single-wait step's sweep launch was done: the low 32 bits of the 100 MHz real-time counter
- * (10 ns ticks) as each workgroup left, in workgroup order — the kernels are ONE persistent workgroup per CU over a static
+/* When every workgroup of the last single-wait step's sweep launch was done, and where it ran: bits 27:0 the 100 MHz real-time
+ * counter (10 ns ticks) as the workgroup left, bits 31:28 the XCD it ran on (HW_REG_XCC_ID), in workgroup order — the kernels are ONE persistent workgroup per CU over a static
  * share of the shard, so the launch lasts as long as its slowest workgroup, and the spread says how much of it the others
  * idle.  Returns the number of workgroups (writes min(that, cap) ticks), 0 if no sweep was launched, or a negative code. */
 int papr_hip_get_wg_finish(papr_hip_ctx *ctx, uint32_t *ticks, int cap);

@@ -744,3 +744,59 @@ def test_timing_levels(pkg):
     for level in (1, 2):
         per_launch = seen[level][2] / 3
         assert 0.008 < per_launch < 1.0, seen
+
+
+_SKEW_SCRIPT = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as ge
+pkg = ge.load_package()
+n = (1 << 26) + 12345
+out = {}
+with pkg.PaprHip(0) as g:
+    g.generate(pkg.SynthSpec.spike(n, seed=2718), 0, n)
+    for exact in (False, True):
+        g.set_exact(exact)
+        for graph in (False, True):
+            for rep in range(2):   # (the second step's parity comes out of the first one's record)
+                res, table, counts = g.analyze(None, graph)
+            us, xcd = g.wg_finish()
+            info = g.sweep_info()
+            t = res.total
+            out["%d%d" % (exact, graph)] = dict(
+                sum=float(t.sum).hex(), mean=float(res.mean).hex(), papr=float(res.papr).hex(), swept=res.swept, resolved=res.resolved,
+                trackers=[[float(getattr(t, k)).hex(), int(getattr(t, k + "_idx"))] for k in ("peak", "re_pos", "re_neg", "im_pos", "im_neg")],
+                table=table.tobytes().hex()[:4096], counts=counts.tolist(), xcd=xcd.tolist(), xcd_first=info.xcd_first)
+print(json.dumps(out))
+"""
+
+
+def test_the_xcd_skew_changes_no_result_and_follows_the_queue(pkg, tmp_path):
+    """The sweep kernels' walk gives the workgroups on the odd XCDs one round in R less (papr_skew_walk.h) — which workgroups those
+    are is the queue's business (workgroup 0 on XCD 6 in a plain process, 5 with RCCL's queues beside: profiles/r05_xcd_skew.txt),
+    so the runtime asks (papr_hip_sweep_info.xcd_first) and follows every sweep's record.  Whatever the period and whichever
+    parity takes the skew, every result is the one of the plain grid stride, bit for bit; workgroups land on the XCDs round-robin
+    from the one the runtime believes in."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "skew.py"
+    script.write_text(_SKEW_SCRIPT)
+    runs = {}
+    for name, env in (("plain", dict(PAPR_XCD_SKEW="0")), ("default", dict()), ("odd slow", dict(PAPR_XCD_SKEW="3", PAPR_XCD_PARITY="0")),
+                      ("even slow", dict(PAPR_XCD_SKEW="3", PAPR_XCD_PARITY="1")), ("short period", dict(PAPR_XCD_SKEW="2"))):
+        p = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        assert p.returncode == 0, (name, p.stderr[-2000:])
+        runs[name] = json.loads(p.stdout.strip().splitlines()[-1])
+    for name, got in runs.items():
+        for mode, r in got.items():
+            xcd = np.array(r.pop("xcd"))
+            first = r.pop("xcd_first")
+            assert r["swept"] == 1 and r["resolved"] == 1, (name, mode)
+            assert np.array_equal(xcd, (np.arange(xcd.size) + xcd[0]) % 8), (name, mode, xcd[:16])
+            assert first == xcd[0], (name, mode, first, xcd[:8])
+            want = dict(runs["plain"][mode])
+            want.pop("xcd", None), want.pop("xcd_first", None)
+            assert r == want, (name, mode)

@@ -102,11 +102,13 @@ def test_the_kernels_walk_covers_every_tile_once(tmp_path):
     for ntiles, blocks, R in [(163840, 256, 24), (163840, 256, 20), (163840, 256, 48), (163840, 256, 96), (163841, 256, 24),
                               (1000003, 256, 2), (12345, 64, 3), (255, 256, 24), (0, 256, 24), (163840, 256, 0), (9999, 250, 24),
                               (4097, 8, 5)]:
-        p = subprocess.run([exe, str(ntiles), str(blocks), str(R)], capture_output=True, text=True)
-        assert p.returncode == 0 and p.stdout.startswith("ok"), (ntiles, blocks, R, p.stdout)
-        even, odd = (int(v) for v in p.stdout.split()[1:3])
-        assert even + odd == ntiles
-        if R >= 2 and blocks % 8 == 0 and ntiles >= 50 * R * blocks:   # (many whole periods: the shares are what they should be)
-            assert abs(odd / even - (R - 1) / R) < 2e-3, (ntiles, blocks, R, even, odd)
-        if R < 2 or blocks % 8:
-            assert abs(even - odd) <= blocks   # plain grid stride
+        for slow in (1, 0):   # (which parity of workgroups the queue put on the odd XCDs)
+            p = subprocess.run([exe, str(ntiles), str(blocks), str(R), str(slow)], capture_output=True, text=True)
+            assert p.returncode == 0 and p.stdout.startswith("ok"), (ntiles, blocks, R, slow, p.stdout)
+            even, odd = (int(v) for v in p.stdout.split()[1:3])
+            assert even + odd == ntiles
+            less, more = (odd, even) if slow else (even, odd)
+            if R >= 2 and blocks % 8 == 0 and ntiles >= 50 * R * blocks:   # (many whole periods: the shares are what they should be)
+                assert abs(less / more - (R - 1) / R) < 2e-3, (ntiles, blocks, R, slow, even, odd)
+            if R < 2 or blocks % 8:
+                assert abs(even - odd) <= blocks   # plain grid stride

@@ -2,6 +2,7 @@
 # Run ON THE GPU BOX (through gpurun): ONE library under several settings of the environment, alternating fresh processes,
 # `bench.py --headline-only` with the given flags; prints kernel / step time of both tables per setting and round.
 #   gpurun -- 'bash tools/env_ab.sh 4 PAPR_XCD_SKEW=0 PAPR_XCD_SKEW=48 PAPR_XCD_SKEW=24 -- --exact'
+# AB_TORCHRUN=1: every process as the driver launches ranks (torch.distributed.run, one rank: RCCL resident beside the step).
 set -u
 ROUNDS=$1; shift
 SETS=()
@@ -11,7 +12,8 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 for i in $(seq 1 "$ROUNDS"); do
   for S in "${SETS[@]}"; do
-    env $S python3 bench.py --headline-only --no-cpu-baseline --no-e2e --steps 20 --warmup 5 "$@" 2>/dev/null |
+    PY="python3"; [ "${AB_TORCHRUN:-0}" = 1 ] && PY="python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571"
+    env $S $PY bench.py --headline-only --no-cpu-baseline --no-e2e --steps 20 --warmup 5 "$@" 2>/dev/null |
       python3 -c "
 import json, sys
 b = json.loads(sys.stdin.readline()); r = b['roofline']; g = (r.get('legs') or {}).get('graph') or {}

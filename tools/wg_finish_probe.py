@@ -33,13 +33,15 @@ def main():
                 rows = []
                 for _ in range(6):
                     gpu.analyze(None, graph)
-                    rows.append(gpu.wg_finish_us())
+                    us, xcd = gpu.wg_finish()
+                    rows.append(us)
                 k_ms = gpu.timing_launches(3)
                 d = np.stack(rows)                     # steps x workgroups, us after the step's first finisher
                 last = d.max(axis=1)
                 per_xcd = np.stack([d[:, x::8].mean(axis=1) for x in range(8)], axis=1).mean(axis=0)
                 slow = np.argsort(d.mean(axis=0))[-5:][::-1]
-                print(f"{'exact' if exact else 'tree '} sum, {'0.1 dB' if graph else '1 dB  '} table: kernel {np.mean(k_ms) / 1e3:.4f} ms; "
+                where = "workgroup i on XCD (i + %d) mod 8" % int((xcd[0] - 0) % 8) if np.array_equal((xcd - xcd[0]) % 8, np.arange(xcd.size) % 8) else "XCDs of workgroups 0..15: %s" % xcd[:16].tolist()
+                print(f"[{where}] {'exact' if exact else 'tree '} sum, {'0.1 dB' if graph else '1 dB  '} table: kernel {np.mean(k_ms) / 1e3:.4f} ms; "
                       f"first -> last workgroup done: {last.mean():.1f} us (max {last.max():.1f}), median workgroup {np.median(d, axis=1).mean():.1f} us, "
                       f"p90 {np.percentile(d, 90, axis=1).mean():.1f} us; mean finish per XCD {np.round(per_xcd, 1).tolist()}; "
                       f"latest workgroups {slow.tolist()} at {np.round(d.mean(axis=0)[slow], 1).tolist()} us", flush=True)
