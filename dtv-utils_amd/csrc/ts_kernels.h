@@ -88,6 +88,8 @@ struct ts_scan_params {
     uint32_t slot_limit;        // slots a span may hand out (0: all it has; tests: few, to force the full-table scan)
     uint32_t abort_walks;       // full-table form: a span that has walked this often, more than once per 3072 packets, stops the
                                 // scan (every span) — the stream is damaged and the slot form's (0: never)
+    uint32_t lookahead;         // 1: at a partial block, ask for the walker's window and for the headers of the block behind the damage
+                                // before the block is committed (TS_SCAN_LOOKAHEAD=0: afterwards, one trip to memory at a time)
     ts_walk_state entry;
     ts_wg_entry *lists;         // per span: up to TS_PIDS entries
     ts_span_rec *recs;          // per span

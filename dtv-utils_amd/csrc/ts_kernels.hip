@@ -96,6 +96,8 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t *s_slot, uint32_t *s_nslots
 }
 
 constexpr uint32_t kWalkWindow = 4096;
+constexpr uint32_t kSpecBefore = 5;  // the look-ahead across a damaged spot covers a grid that moved by -kSpecBefore .. +3 bytes (16 bytes a lane)
+constexpr uint32_t kWinAhead = 1024;  // ... and this much of the walker's window (one 16-byte piece a lane)
 constexpr uint64_t kBridgeMax = 1u << 20;   // a bridge longer than this is the host's (a launch of the span from the true state)
 constexpr uint32_t kBridgeSteps = 8192;     // ... or one of more packets than this
 constexpr uint32_t kBridgeEvent = 0x80000000u;  // ts_event::attempt of a bridge's events (numbered from the bridge's first packet)
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
     struct {
         const unsigned char *data;
         uint64_t nbytes, span_bytes;
-        uint32_t first_span, nspans_total, stride, sync_offset, hdmv, attempt, explicit_entry, quirk_events, event_cap, slot_limit, abort_walks;
+        uint32_t first_span, nspans_total, stride, sync_offset, hdmv, attempt, explicit_entry, quirk_events, event_cap, slot_limit, abort_walks, lookahead;
         ts_wg_entry *lists;
         ts_span_rec *recs;
         ts_cc_entry *cc_lists;
@@ -391,6 +393,7 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
     p.event_cap = prm.event_cap;
     p.slot_limit = prm.slot_limit && prm.slot_limit < kSlots ? prm.slot_limit : kSlots;
     p.abort_walks = SLOTS ? 0u : prm.abort_walks;
+    p.lookahead = prm.lookahead;
     p.lists = prm.lists;
     p.recs = prm.recs;
     p.cc_lists = prm.cc_lists;
@@ -518,6 +521,15 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
     uint32_t walks = 0;
     uint64_t pre_pos = TS_NO_ENTRY;  // the position whose block's header words are in pre_w0 / pre_w1 already
     uint32_t pre_w0 = 0, pre_w1 = 0;
+    // Looking ahead across a damaged spot (below): the block behind it is expected one unit behind the first irregular one,
+    // give or take a few bytes — 16 bytes around this lane's sync byte there, asked for when the partial block is known ...
+    uint64_t spec_pos = TS_NO_ENTRY;  // the position those bytes were asked for (TS_NO_ENTRY: none)
+    uint32_t spec_w[4] = {0, 0, 0, 0};
+    bool spec_ok = false;
+    // ... and so is the head of the walker's window (wave 0: one 16-byte piece per lane)
+    uint64_t win_pre_base = 0;
+    uint32_t win_pre_len = 0;
+    uint4 win_pre = {0, 0, 0, 0};
     bool walk_next = false;
     for (;;) {
         const bool clean = walk_is_clean(st);
@@ -538,10 +550,22 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
                 w0 = pre_w0;
                 w1 = pre_w1;
             } else {
-                const uint64_t a = whole ? (sy & ~3ull) : 0ull;
-                w0 = *reinterpret_cast<const uint32_t *>(p.data + a);
-                w1 = *reinterpret_cast<const uint32_t *>(p.data + a + 4);
+                // (behind a walk: were this lane's bytes asked for in advance — kSpecBefore bytes early to 3 late?)
+                const int64_t D = (int64_t)(st.pos - spec_pos);
+                const bool hit = spec_pos != TS_NO_ENTRY && D >= -(int64_t)kSpecBefore && D <= 3 && spec_ok && whole;
+                if (hit) {
+                    const uint64_t q = spec_pos + (uint64_t)t * p.stride + p.sync_offset;
+                    const uint32_t o = (uint32_t)(sy - ((q - kSpecBefore) & ~3ull));  // 0 .. 11: bytes o .. o + 4 of the 16
+                    const uint32_t i = o >> 2;
+                    w0 = i == 0 ? spec_w[0] : i == 1 ? spec_w[1] : spec_w[2];
+                    w1 = i == 0 ? spec_w[1] : i == 1 ? spec_w[2] : spec_w[3];
+                } else {
+                    const uint64_t a = whole ? (sy & ~3ull) : 0ull;
+                    w0 = *reinterpret_cast<const uint32_t *>(p.data + a);
+                    w1 = *reinterpret_cast<const uint32_t *>(p.data + a + 4);
+                }
             }
+            spec_pos = TS_NO_ENTRY;
             const uint32_t sh = (uint32_t)(sy & 3u);
             const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh);  // bytes sy .. sy+3
             const uint32_t b4 = (w1 >> (8 * sh)) & 0xffu;                // byte sy+4 (sh <= 3: inside w1)
@@ -591,6 +615,32 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
                 pre_w0 = *reinterpret_cast<const uint32_t *>(p.data + na);
                 pre_w1 = *reinterpret_cast<const uint32_t *>(p.data + na + 4);
                 pre_pos = npos;
+            }
+            // A partial block: the walker is next, and behind it a block whose position only the walker knows.  Two dependent trips
+            // to memory with nothing to hide them — unless they are asked for NOW, while this block is committed: the walker's
+            // window (it starts at the irregular unit), and this lane's header in the block behind, guessed one unit further on
+            // with room for the grid to have moved (bytes inserted: up to 3; bytes missing: up to kSpecBefore).  A guess that
+            // does not hold costs nothing but its bytes: the block loads as before.
+            if (p.lookahead && take < nblk && p.nbytes >= kWalkWindow) {  // (workgroup-uniform; a stream of a few bytes has nothing to look ahead at)
+                const uint64_t P = st.pos + (uint64_t)take * p.stride;
+                spec_pos = P + p.stride;
+                const uint64_t q = spec_pos + (uint64_t)t * p.stride + p.sync_offset;
+                const uint64_t a = (q - kSpecBefore) & ~3ull;
+                spec_ok = a + 16u <= p.nbytes;
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(p.data + (spec_ok ? a : 0ull));
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    spec_w[k] = src[k];
+                if (wave == 0) {
+                    const uint32_t mis = (uint32_t)(((uintptr_t)p.data + P) & 15u);
+                    win_pre_len = 0;
+                    if (P >= mis && P < p.nbytes) {
+                        win_pre_base = P - mis;
+                        const uint64_t room = p.nbytes - win_pre_base;
+                        win_pre_len = room < kWinAhead ? (uint32_t)room & ~15u : kWinAhead;  // (whole 16-byte pieces only)
+                        win_pre = *reinterpret_cast<const uint4 *>(p.data + win_pre_base + (16u * lane < win_pre_len ? 16u * lane : 0u));
+                    }
+                }
             }
             // (the tables' entry of this lane's PID — a slot, in the slot form — wanted by the count and by the continuity check)
             const uint32_t ix = (t < take && (tei == 0 || ((b3 & 0x10u) != 0 && pid != 0u))) ? idx(pid) : 0u;
@@ -765,6 +815,14 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
             w.nbytes = p.nbytes;
             w.win_base = 0;
             w.win_len = 0;  // (nothing in the window yet: the first byte asked for brings it in)
+            if (win_pre_len && st.pos >= win_pre_base && st.pos < win_pre_base + win_pre_len) {  // ... unless it was asked for already
+                if (16u * lane < win_pre_len)
+                    *reinterpret_cast<uint4 *>(s_window + 16u * lane) = win_pre;
+                __builtin_amdgcn_wave_barrier();
+                w.win_base = win_pre_base;
+                w.win_len = win_pre_len;
+            }
+            win_pre_len = 0;
             w.g_count = nullptr;
             w.g_first = w.g_last = nullptr;
             w.abs0 = 0;

@@ -213,6 +213,7 @@ struct ts_hip_ctx {
     int form = 0;                                           // 0: full tables, given up for the slot form when the stream is damaged;
                                                             // 1: full tables only; 2: slot form first (TS_SCAN_FORM=auto|full|slots)
     uint32_t slot_limit = 0;                                // (tests: TS_SCAN_SLOT_LIMIT)
+    uint32_t lookahead = 1;                                 // TS_SCAN_LOOKAHEAD=0: a damaged spot's trips to memory one at a time (tests, measurements)
     int bridges_mode = -1;                                  // TS_SCAN_BRIDGES: 1 ts_bridge_kernel in front of every merge, 0 of none (tests)
     hipEvent_t ev_a = nullptr, ev_m = nullptr, ev_b = nullptr;
 };
@@ -327,6 +328,7 @@ int ts_hip_open(ts_hip_ctx **out, int device)
     if (const char *e = getenv("TS_SCAN_FORM"))
         ctx->form = !strcmp(e, "full") ? 1 : !strcmp(e, "slots") ? 2 : 0;
     ctx->bridges_mode = env_int_ts("TS_SCAN_BRIDGES", -1);
+    ctx->lookahead = env_int_ts("TS_SCAN_LOOKAHEAD", 1) != 0 ? 1u : 0u;
     if (const char *e = getenv("TS_SCAN_SLOT_LIMIT"))
         ctx->slot_limit = (uint32_t)std::max(0, atoi(e));
     OPENCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -601,6 +603,7 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
         p.slots = slots ? 1u : 0u;
         p.slot_limit = ctx->slot_limit;
         p.abort_walks = abort_walks;
+        p.lookahead = ctx->lookahead;
         ts_walk_init(&p.entry, hdmv);
         p.lists = ctx->d_lists;
         p.recs = ctx->d_recs;

@@ -166,15 +166,18 @@ def test_scan_of_the_synthetic_stream_and_handover_counts(ts, gpu, tmp_path):
         gpu.load_file(str(tmp_path / "missing.ts"))
 
 
-@pytest.fixture(scope="module", params=["auto", "slots", "full", "full, bridges worked out at once", "slots, bridges walked by the merge"])
+@pytest.fixture(scope="module", params=["auto", "slots", "full", "full, bridges worked out at once", "slots, bridges walked by the merge",
+                                        "slots, no look-ahead", "full, no look-ahead"])
 def gpu_small_spans(ts, request):
     """a context that cuts even the small fixtures into many spans (4 KiB each: 21 packets).  The bridges between the spans are
     worked out by ts_bridge_kernel in front of the merge for the slot form and for re-scanned spans, by the merge kernel itself
     otherwise: the last two parameters swap that (TS_SCAN_BRIDGES)."""
     form, _, how = request.param.partition(", ")
     env = {"TS_SCAN_SPANS": "256", "TS_SCAN_MIN_SPAN": "4096", "TS_SCAN_FORM": form}
-    if how:
+    if "bridges" in how:
         env["TS_SCAN_BRIDGES"] = "1" if "at once" in how else "0"
+    if "look-ahead" in how:   # (a damaged spot's window and the headers behind it asked for only when they are needed)
+        env["TS_SCAN_LOOKAHEAD"] = "0"
     g = _with_env(ts, env)
     yield g
     g.close()
@@ -265,6 +268,20 @@ def test_a_damaged_stream_is_given_up_for_the_slot_form(ts, tmp_path):
         host = open(path, "rb").read()
         g.upload(host)
         assert g.scan().report() == ts_oracle.report_lines(ts_oracle.scan_mem(host))
+    # Looking ahead across a damaged spot (the walker's window and the headers of the block behind asked for while the partial
+    # block is committed) is a matter of when bytes are asked for: with and without, in both forms, on a stream of the bench's
+    # kind whose spans are long enough for whole blocks on either side of every spot — and against the oracle
+    want = None
+    for form in ("slots", "full"):
+        for ahead in ("1", "0"):
+            with _with_env(ts, {"TS_SCAN_FORM": form, "TS_SCAN_LOOKAHEAD": ahead}) as g:
+                g.generate_damaged(8_000_000, 1000)
+                r = g.scan()
+                got = (r.report(), r.packets, r.sync_error_list(), r.discontinuity_list(), [x.tobytes() for x in r.tables()])
+                assert want is None or got == want, (form, ahead)
+                want = got
+                g.upload(host)
+                assert g.scan().report() == ts_oracle.report_lines(ts_oracle.scan_mem(host)), (form, ahead)
 
 
 @pytest.mark.gpu
