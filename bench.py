@@ -579,6 +579,7 @@ def run_ts(args, rank, world, local_rank, use_dist):
     else:
         gpu.generate(npackets, seed=0x7500001 + rank)
     res = None
+    first_launches = None
     preheat_steps = args.preheat
     cold = []
     for i in range(preheat_steps + args.warmup):   # (as run_mode: the idle GPU's first ~20 ms of load are slower)
@@ -586,6 +587,8 @@ def run_ts(args, rank, world, local_rank, use_dist):
         res = gpu.scan()
         if i < 5:
             cold.append(round((time.perf_counter() - t_c) * 1e3, 3))
+        if i == 0:
+            first_launches = int(res.launches)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -641,6 +644,9 @@ def run_ts(args, rank, world, local_rank, use_dist):
         "config": {"workload": f"xport -p packet scan (sync lock, per-PID count/first/last, continuity counters) on {args.gib:g} GiB synthetic "
                                f"MPEG-2 TS per GPU, HBM-resident, {world}xMI355X", "packets_per_gpu": npackets,
                    "bytes_per_gpu": nbytes, "launches_per_scan": int(res.launches), "walks_per_scan": int(res.walks),
+                   "launches_of_the_first_scan": first_launches,
+                   "form": "a context starts a scan in the form its last scan ended in: the first scan of a damaged stream tries the full "
+                           "tables and is given up for the slot form (launches_of_the_first_scan), the timed ones start in the slot form",
                    "damage": (f"one damaged spot every {period} packets (include/ts_synth.h: ts_synth_damaged_byte)" if period else None),
                    "preheat": {"steps": preheat_steps, "cold_first_steps_ms": cold, "what": "untimed scans in front of the warm-up"},
                    "sync_error_lines": int(res.nsync_errors), "discontinuity_lines": int(res.ndiscontinuities),

@@ -263,6 +263,10 @@ def test_a_damaged_stream_is_given_up_for_the_slot_form(ts, tmp_path):
             ca, cb = a.tables(), b.tables()
             assert all(np.array_equal(x, y) for x, y in zip(ca, cb))
             assert (a.launches > b.launches) == gives_up, (period, a.launches, b.launches)
+            if gives_up:   # the context remembers: the next scan starts in the slot form (and goes back when a stream is in order)
+                again = g.scan()
+                assert again.launches < a.launches and again.report() == a.report() and again.packets == a.packets
+                assert all(np.array_equal(x, y) for x, y in zip(again.tables(), ca))
         path = str(tmp_path / "d.ts")
         subprocess.check_call([os.path.join(ROOT, "oracle", "mkts"), path, "400000", "--damage", "500"])
         host = open(path, "rb").read()

@@ -17,6 +17,7 @@ $B $H --exact                        --full-json $O/bench_exact.json > $O/bench_
 $B $H --two-pass                     --full-json $O/bench_twopass.json > $O/bench_twopass.line 2> $O/bench_twopass.err
 $B --workload ts                     --full-json $O/bench_ts.json > $O/bench_ts.line 2> $O/bench_ts.err
 $B --workload ts --damage 1e-4       --full-json $O/bench_ts_damage.json > $O/bench_ts_damage.line 2> $O/bench_ts_damage.err
+$B --workload ts --damage 3e-4       --full-json $O/bench_ts_damage_3e-4.json > $O/bench_ts_damage_3e-4.line 2> $O/bench_ts_damage_3e-4.err
 $B --workload ts --damage 1e-3       --full-json $O/bench_ts_damage_1e-3.json > $O/bench_ts_damage_1e-3.line 2> $O/bench_ts_damage_1e-3.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
     $R/bench.py --gpus 1 $H --full-json $O/bench_torchrun1.json > $O/bench_torchrun1.line 2> $O/bench_torchrun1.err
