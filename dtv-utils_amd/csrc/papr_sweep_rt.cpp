@@ -237,6 +237,8 @@ int sweep_prepare(papr_hip_ctx *ctx, const float *guess_levels, int nlevels, uin
 
 // One launch of the sweep kernel over [data, data + n): full tiles by the grid, the sub-tile remainder binned by the
 // last workgroup (its pass-1 half belongs to papr_stats_finalize).  Histogram and stash segments accumulate over launches.
+static bool xcd_even_slow(papr_hip_ctx *ctx);
+
 int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint64_t n, uint64_t base_index, size_t slot,
                  int *nrecords)
 {
@@ -268,6 +270,7 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
         p.seg_D = ctx->d_seg_D;
         p.seg_offset = (base_index - ctx->base) / PAPR_EXACT_SEG_SAMPLES;
         p.fine_table = run.bands.P.nkeys > 128u ? 1u : 0u;
+        p.xcd_skew = xcd_even_slow(ctx) ? 0x80000000u : 0u;  // (which workgroups sit on the odd XCDs: the walk's skew is theirs)
         time_begin_kernel(ctx, 3, n * 8);
         if (run.v3)  // (a persistent workgroup: all of the CU's LDS — what the table leaves goes to the stash slices)
             papr_launch_sweep3(ctx->stream, run.variant, blocks,
@@ -280,7 +283,7 @@ int sweep_launch(papr_hip_ctx *ctx, const SweepRun &run, const float *data, uint
         return PAPR_OK;
     }
     const int blocks = (int)std::min<uint64_t>((uint64_t)run.blocks, std::max<uint64_t>(ntiles, 1));
-    const int map = effective_map(ctx, SWEEP, blocks);
+    const int map = effective_map(ctx, SWEEP, blocks) | (xcd_even_slow(ctx) ? PAPR_MAP_EVEN_SLOW : 0);
     int rc = ensure_partials(ctx, slot + (size_t)blocks + 1);
     if (rc)
         return rc;

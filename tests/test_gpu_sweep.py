@@ -764,10 +764,17 @@ with pkg.PaprHip(0) as g:
             us, xcd = g.wg_finish()
             info = g.sweep_info()
             t = res.total
+            # (the same through the calls one by one — papr_hip_stats_sweep's own launch takes the skew too)
+            est = g.estimate()
+            g.set_band(pkg.band_for(est))
+            st = g.stats_sweep(pkg.guess_levels(est, graph))
+            counts2 = g.ccdf(pkg.levels(st, graph)[2])
             out["%d%d" % (exact, graph)] = dict(
                 sum=float(t.sum).hex(), mean=float(res.mean).hex(), papr=float(res.papr).hex(), swept=res.swept, resolved=res.resolved,
                 trackers=[[float(getattr(t, k)).hex(), int(getattr(t, k + "_idx"))] for k in ("peak", "re_pos", "re_neg", "im_pos", "im_neg")],
-                table=table.tobytes().hex()[:4096], counts=counts.tolist(), xcd=xcd.tolist(), xcd_first=info.xcd_first)
+                table=table.tobytes().hex()[:4096], counts=counts.tolist(), xcd=xcd.tolist(), xcd_first=info.xcd_first,
+                by_hand=[None if exact else float(st.sum).hex(), int(st.peak_idx), counts2.tolist()])   # (exact mode: this call's sum is the kernel's
+                # own running total of the segments' pairs, whatever order its workgroups met them in — the result's sum is the program's)
 print(json.dumps(out))
 """
 
