@@ -333,3 +333,62 @@ def test_scan_error_states(ts):
         assert res.packets == 0 and res.report() == b"" and res.launches == 0
         with pytest.raises(Exception):
             g.generate_damaged(1000, 30)   # not a multiple of 4 * period
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hdmv", [False, True], ids=["188", "192"])
+def test_long_spans_with_random_damage_equal_the_oracle(ts, hdmv):
+    """Spans as long as the bench's (thousands of packets: whole blocks on either side of a damaged spot, so the look-ahead has
+    something to be right or wrong about) with damage of every kind at random places — bytes inserted (1 ... 400, some of them
+    0x47), bytes missing (1 ... 400), sync bytes overwritten, bytes overwritten with false sync bytes, whole packets gone — in
+    all three forms, looking ahead and not, against the oracle."""
+    rng = np.random.default_rng(20260930 + int(hdmv))
+    unit = 192 if hdmv else 188
+    npackets = 1_200_000
+    with ts.TsHip(0) as g:
+        g.generate(npackets, seed=0x7500001 + 77, hdmv=hdmv)
+        clean = np.frombuffer(g.download(0, npackets * unit), dtype=np.uint8)
+    places = np.sort(rng.choice(npackets - 8, size=900, replace=False) + 4)
+    parts, at = [], 0
+    for k in places:
+        cut = int(k) * unit + int(rng.integers(0, unit))
+        parts.append(clean[at:cut])
+        kind = int(rng.integers(0, 6))
+        if kind == 0:     # garbage inserted
+            junk = rng.integers(0, 256, size=int(rng.integers(1, 401)), dtype=np.uint8)
+            parts.append(junk)
+            at = cut
+        elif kind == 1:   # bytes missing
+            at = cut + int(rng.integers(1, 401))
+        elif kind == 2:   # the next sync byte overwritten
+            nxt = (int(k) + 1) * unit + (4 if hdmv else 0)
+            parts.append(clean[cut:nxt])
+            parts.append(np.array([int(rng.integers(0, 256))], dtype=np.uint8))
+            at = nxt + 1
+        elif kind == 3:   # a run overwritten, false sync bytes in it
+            n = int(rng.integers(1, 600))
+            junk = rng.integers(0, 256, size=n, dtype=np.uint8)
+            junk[rng.integers(0, n, size=max(1, n // 40))] = 0x47
+            parts.append(junk)
+            at = cut + n
+        elif kind == 4:   # whole packets gone (the grid stays)
+            at = cut + unit * int(rng.integers(1, 4))
+        else:             # a few bytes inserted: the grid moves by 1 ... 7
+            parts.append(rng.integers(0, 256, size=int(rng.integers(1, 8)), dtype=np.uint8))
+            at = cut
+    parts.append(clean[at:])
+    data = np.concatenate(parts).tobytes()
+    ref = ts_oracle.scan_mem(data, hdmv)
+    want = ts_oracle.report_lines(ref)
+    for form in ("auto", "slots", "full"):
+        for ahead in ("1", "0"):
+            for spans in ("256", "24"):   # (4 700 packets a span: a few blocks; 50 000: dozens of whole blocks between the spots)
+                with _with_env(ts, {"TS_SCAN_FORM": form, "TS_SCAN_LOOKAHEAD": ahead, "TS_SCAN_SPANS": spans}) as g:
+                    g.upload(data)
+                    res = g.scan(hdmv)
+                    how = (form, ahead, spans)
+                    assert res.report() == want, how
+                    cnt, first, last = res.tables()
+                    assert res.packets == ref["packets"] and np.array_equal(cnt, ref["count"]) and \
+                        np.array_equal(first, ref["first"]) and np.array_equal(last, ref["last"]), how
+                    assert res.sync_error_list() == ref["sync_errors"] and res.discontinuity_list() == ref["discontinuities"], how
