@@ -42,10 +42,18 @@ struct ts_line_pool {
     std::condition_variable wake;
     bool stop = false;
     std::atomic<bool> burst{false};
-    std::atomic<uint64_t> ticket{0};  // round << 32 | next job of that round
+    // round << 48 | jobs of that round << 32 | next job: ONE word says which round a ticket belongs to, how many jobs it has and
+    // which one this is — a worker never combines a ticket of one round with the job count or the function of another (it did,
+    // once: `njobs` and `job` were read after the ticket, the main thread had moved on in between, and a stale ticket below
+    // the NEW count ran one of the new round's jobs a second time: holes in the report and a `done` that overshot)
+    std::atomic<uint64_t> ticket{0};
     std::atomic<uint32_t> done{0};
-    const std::function<void(int)> *job = nullptr;  // of round (ticket >> 32): written before the ticket is
-    uint32_t njobs = 0, round = 0;
+    // the function of round r is jobs[r & 1]: written before the round's ticket is, and not again before round r + 2 — by
+    // which time every job of round r has long been counted in `done`
+    const std::function<void(int)> *jobs[2] = {nullptr, nullptr};
+    uint32_t round = 0;
+    static constexpr uint32_t kMaxJobs = 0xFFFFu;
+    static uint32_t jobs_of(uint64_t t) { return (uint32_t)(t >> 32) & 0xFFFFu; }
     static void relax() { __builtin_ia32_pause(); }
     void worker()
     {
@@ -56,22 +64,16 @@ struct ts_line_pool {
                 if (stop)
                     return;
             }
-            uint32_t my_round = 0xFFFFFFFFu, n = 0;
-            const std::function<void(int)> *f = nullptr;
             while (burst.load(std::memory_order_acquire)) {
                 uint64_t t = ticket.load(std::memory_order_acquire);
-                if ((uint32_t)(t >> 32) == my_round && (uint32_t)t >= n) {
+                if ((uint32_t)t >= jobs_of(t)) {
                     relax();
-                    continue;  // (nothing left of the round this worker knows)
+                    continue;  // (nothing left of this round)
                 }
                 t = ticket.fetch_add(1, std::memory_order_acq_rel);
-                if ((uint32_t)(t >> 32) != my_round) {
-                    my_round = (uint32_t)(t >> 32);
-                    f = job;
-                    n = njobs;
-                }
-                if ((uint32_t)t < n) {
-                    (*f)((int)(uint32_t)t);
+                const uint32_t idx = (uint32_t)t;
+                if (idx < jobs_of(t)) {
+                    (*jobs[(t >> 48) & 1u])((int)idx);
                     done.fetch_add(1, std::memory_order_release);
                 }
             }
@@ -143,16 +145,15 @@ struct ts_line_pool {
     void end_burst() { burst.store(false, std::memory_order_release); }
     void run(int n, const std::function<void(int)> &f)
     {
-        if (workers.empty() || n <= 1 || !burst.load()) {
+        if (workers.empty() || n <= 1 || (uint32_t)n > kMaxJobs || !burst.load()) {
             for (int k = 0; k < n; k++)
                 f(k);
             return;
         }
-        job = &f;
-        njobs = (uint32_t)n;
-        done.store(0, std::memory_order_relaxed);
         round++;
-        ticket.store((uint64_t)round << 32, std::memory_order_release);
+        jobs[round & 1u] = &f;
+        done.store(0, std::memory_order_relaxed);
+        ticket.store(((uint64_t)(round & 0xFFFFu) << 48) | ((uint64_t)(uint32_t)n << 32), std::memory_order_release);
         for (;;) {
             const uint64_t t = ticket.fetch_add(1, std::memory_order_acq_rel);
             if ((uint32_t)t >= (uint32_t)n)
@@ -1022,6 +1023,35 @@ int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
 uint64_t ts_hip_sync_error_count(const ts_hip_ctx *ctx)
 {
     return ctx ? (uint64_t)ctx->errors.size() : 0;
+}
+
+int ts_host_pool_selftest(int threads, int rounds)
+{
+    ts_line_pool pool;
+    if (threads > 1)
+        pool.start(threads - 1);
+    pool.begin_burst();
+    std::vector<std::atomic<uint32_t>> ran(64);
+    int bad = 0;
+    uint64_t x = 88172645463325252ull;
+    for (int r = 1; r <= rounds && !bad; r++) {
+        x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+        const int n = 1 + (int)(x % 64u);  // (the counts jump about: a stale ticket of a short round lies inside a long one)
+        for (auto &c : ran)
+            c.store(0, std::memory_order_relaxed);
+        const std::function<void(int)> f = [&](int k) {
+            ran[(size_t)k].fetch_add(1, std::memory_order_relaxed);
+            if ((x >> (k & 31)) & 1u)
+                for (volatile int spin = 0; spin < 200; spin++) {
+                }
+        };
+        pool.run(n, f);
+        for (int k = 0; k < 64; k++)
+            if (ran[(size_t)k].load() != (k < n ? 1u : 0u))
+                bad = r;
+    }
+    pool.end_burst();
+    return bad;
 }
 
 size_t ts_hip_result_size(void)

@@ -19,7 +19,7 @@ MAX_DISCONTINUITIES = 4096
 ABI_SYMBOLS = ("ts_walk_init", "ts_walk_is_clean", "ts_walk", "ts_format_report", "ts_format_report_all", "ts_hip_open", "ts_hip_close",
                "ts_hip_last_error", "ts_hip_upload", "ts_hip_load_file", "ts_hip_adopt", "ts_hip_generate", "ts_hip_generate_damaged",
                "ts_hip_download", "ts_hip_scan", "ts_hip_sync_error_count", "ts_hip_get_sync_errors", "ts_hip_discontinuity_count",
-               "ts_hip_get_discontinuities", "ts_hip_result_size")
+               "ts_hip_get_discontinuities", "ts_hip_result_size", "ts_host_pool_selftest")
 
 
 class SyncError(C.Structure):
@@ -152,6 +152,8 @@ def _lib():
         L.ts_hip_generate_damaged.restype = i32
         L.ts_hip_download.argtypes = [vp, vp, u64, u64]
         L.ts_hip_scan.argtypes = [vp, i32, C.POINTER(ScanResult)]
+        L.ts_host_pool_selftest.argtypes = [C.c_int, C.c_int]
+        L.ts_host_pool_selftest.restype = C.c_int
         L.ts_hip_result_size.argtypes = []
         L.ts_hip_result_size.restype = C.c_size_t
         if L.ts_hip_result_size() != C.sizeof(ScanResult):   # (ts_hip_scan writes the LIBRARY's struct into the caller's buffer)

@@ -149,6 +149,10 @@ int ts_hip_get_sync_errors(const ts_hip_ctx *ctx, uint64_t first, uint64_t n, ts
 /* ... and every discontinuity */
 uint64_t ts_hip_discontinuity_count(const ts_hip_ctx *ctx);
 int ts_hip_get_discontinuities(const ts_hip_ctx *ctx, uint64_t first, uint64_t n, ts_discontinuity *out);
+/* The host threads that lay out the report's lines of a damaged stream, checked on their own (no GPU): `rounds` rounds of
+ * 1 ... 64 jobs through `threads` threads (the caller's included), each job must run exactly once in its own round.  Returns 0,
+ * or the number of the first round in which one did not (tests/test_ts_scan.py). */
+int ts_host_pool_selftest(int threads, int rounds);
 
 #ifdef __cplusplus
 }
