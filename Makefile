@@ -26,7 +26,7 @@ $(CSRC)/ts_host$(X): $(CSRC)/ts_host.c $(CSRC)/ts_walk_core.h include/ts_hip.h
 $(CSRC)/ts_kernels$(X): $(CSRC)/ts_kernels.hip $(CSRC)/ts_kernels.h $(CSRC)/ts_walk_core.h include/ts_hip.h include/ts_synth.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/ts_runtime$(X): $(CSRC)/ts_runtime.cpp $(CSRC)/ts_kernels.h include/ts_hip.h include/papr_hip.h
+$(CSRC)/ts_runtime$(X): $(CSRC)/ts_runtime.cpp $(CSRC)/ts_kernels.h $(CSRC)/ts_line_pool.h include/ts_hip.h include/papr_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/papr_kernels$(X): $(CSRC)/papr_kernels.hip $(CSRC)/papr_kernels.h $(CSRC)/papr_device.h $(CSRC)/papr_stream.h include/papr_synth.h

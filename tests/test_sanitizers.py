@@ -83,3 +83,48 @@ def test_oracle_under_sanitizers(san_dir):
             want = golden_text(name, graph)
             if b"nan" not in want:   # which NaN sign a compiler's operand order produces differs between -O1 and
                 assert p.stdout == want, name   # the reference's -O2 build; the sanitizer run is about memory safety
+
+
+# ---- the threaded host code under ThreadSanitizer ------------------------------------------------------------------------
+TSAN = ["-fsanitize=thread", "-g", "-O1", "-std=c++17"]
+
+
+def run_tsan(cmd, timeout=600, **env):
+    p = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **env))
+    assert "ThreadSanitizer" not in p.stderr, p.stderr[-4000:]
+    return p
+
+
+def test_line_pool_under_thread_sanitizer(tmp_path):
+    """The packet scan's host threads (ts_line_pool.h: spinning workers, jobs from one atomic ticket) under ThreadSanitizer:
+    rounds of 1 ... 64 jobs, every job exactly once, no report.  (The pool's first form failed this by never returning.)"""
+    exe = tmp_path / "pool_tsan"
+    subprocess.check_call(["g++", *TSAN, "-I" + os.path.join(ROOT, "dtv-utils_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "c", "pool_harness.cpp"), "-o", str(exe), "-lpthread"])
+    for threads, rounds in ((8, 20000), (3, 20000), (2, 5000)):
+        p = run_tsan([exe, threads, rounds])
+        assert p.returncode == 0 and p.stdout.strip() == "0", (threads, rounds, p.stdout, p.stderr[-2000:])
+
+
+def test_in_process_exchange_under_thread_sanitizer(tmp_path):
+    """The in-process exchange (the hub that bin/papr's per-GPU threads meet at) under ThreadSanitizer: host-level collectives
+    checked round after round, the self-test's collectives, then one thread cancels the exchange while the others wait in
+    one.  (Without PAPR_XCH_TIMEOUT_S: gcc 11's libtsan does not know pthread_cond_clockwait and reports every timed wait.)"""
+    rocm_inc = "/opt/rocm/include"
+    if not os.path.exists(os.path.join(rocm_inc, "rccl", "rccl.h")) or not os.path.exists("/opt/rocm/lib/libamdhip64.so"):
+        pytest.skip("no ROCm headers here")
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "dtv-utils_amd", "csrc"), "-I" + rocm_inc]
+    objs = []
+    for src, cc, std in (("papr_exchange.cpp", "g++", ["-std=c++17"]), ("papr_host.c", "gcc", [])):
+        obj = tmp_path / (src + ".o")
+        subprocess.check_call([cc, "-fsanitize=thread", "-g", "-O1", *std, "-fPIC", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", *inc, "-c",
+                               os.path.join(ROOT, "dtv-utils_amd", "csrc", src), "-o", str(obj)])
+        objs.append(str(obj))
+    exe = tmp_path / "hub_tsan"
+    subprocess.check_call(["g++", *TSAN, "-D__HIP_PLATFORM_AMD__", *inc, os.path.join(ROOT, "tests", "c", "hub_harness.cpp"), *objs, "-o", str(exe),
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64", "-lpthread", "-ldl", "-lm"])
+    env = {k: v for k, v in os.environ.items() if k != "PAPR_XCH_TIMEOUT_S"}
+    for threads, rounds in ((8, 1500), (3, 1500), (2, 500)):
+        p = subprocess.run([str(exe), str(threads), str(rounds)], capture_output=True, text=True, timeout=600, env=env)
+        assert "ThreadSanitizer" not in p.stderr, p.stderr[-4000:]
+        assert p.returncode == 0 and p.stdout.strip() == "ok", (threads, rounds, p.stdout, p.stderr[-2000:])
