@@ -1,0 +1,43 @@
+#!/bin/bash
+# bin/papr with its host code under ThreadSanitizer (the reader threads of the ingest, the per-shard threads and their hub, the
+# packet scan's line pool): build here (`tools/tsan_cli.sh build`: cross-compiles, no GPU), run ON THE GPU BOX
+# (`gpurun -- 'bash tools/tsan_cli.sh run'`).  The HIP / HSA runtimes are not instrumented and report races of their own (their
+# internal threads against API calls): tools/tsan_filter.py counts the reports in which one of the two accesses is in OUR code.
+#   resident exact | streamed -g | three shards on one GPU over the in-process hub | three shards streamed
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$R"
+C=dtv-utils_amd/csrc
+if [ "${1:-run}" = build ]; then
+  make lib >/dev/null || exit 1
+  mkdir -p scratch/tsan bin
+  FL="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$C -I/opt/rocm/include -Xarch_host -fsanitize=thread"
+  for f in papr_runtime papr_ingest papr_sweep_rt papr_exact_rt ts_runtime papr_exchange papr_analyze; do
+    /opt/rocm/bin/hipcc $FL -c $C/$f.cpp -o scratch/tsan/$f.o || exit 1
+  done
+  CL=/opt/rocm/lib/llvm/bin/clang
+  $CL -O1 -g -fPIC -ffp-contract=off -fsanitize=thread -Iinclude -I$C -c $C/papr_host.c -o scratch/tsan/papr_host.o || exit 1
+  $CL -O1 -g -fPIC -ffp-contract=off -fsanitize=thread -Iinclude -I$C -c $C/ts_host.c -o scratch/tsan/ts_host.o || exit 1
+  $CL -O1 -g -ffp-contract=off -fsanitize=thread -Iinclude -c dtv-utils_amd/host/papr_main.c -o scratch/tsan/papr_main.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fsanitize=thread scratch/tsan/*.o $C/papr_kernels.o $C/papr_sweep.o $C/papr_exact.o $C/ts_kernels.o \
+      -o bin/papr_tsan -lm -lpthread -ldl || exit 1
+  echo "built bin/papr_tsan"
+  exit 0
+fi
+F=/dev/shm/tsan.cfile
+oracle/mkcfile $F 300000007 --spike --extra-floats 1 >/dev/null
+ref=$(bin/papr $F | md5sum); refg=$(bin/papr -g $F | md5sum)
+export TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=4"
+run() {
+  name=$1; want=$2; shift 2
+  timeout 300 env PAPR_TEARDOWN=1 "$@" > /tmp/tsan_out.txt 2> /tmp/tsan_err.txt
+  got=$(md5sum < /tmp/tsan_out.txt)
+  echo "=== $name: stdout $([ "$got" = "$want" ] && echo identical to bin/papr\'s || echo DIFFERS)"
+  python3 tools/tsan_filter.py /tmp/tsan_err.txt
+}
+run "resident, exact sum" "$ref" bin/papr_tsan $F
+run "streamed (512 MiB of HBM), -g" "$refg" PAPR_HBM_BUDGET_MB=512 bin/papr_tsan -g $F
+run "three shards on one GPU, in-process hub" "$ref" PAPR_GPUS=3 PAPR_OVERSUBSCRIBE=1 PAPR_XCH=threads bin/papr_tsan $F
+run "three shards on one GPU, RCCL refused (one device): hub" "$ref" PAPR_GPUS=3 PAPR_OVERSUBSCRIBE=1 bin/papr_tsan $F
+run "three shards, streamed, -g" "$refg" PAPR_GPUS=3 PAPR_OVERSUBSCRIBE=1 PAPR_HBM_BUDGET_MB=256 bin/papr_tsan -g $F
+rm -f $F
