@@ -86,7 +86,7 @@ struct ts_scan_params {
     uint32_t quirk_events;      // 0: every read-boundary quirk goes to the walker (tests)
     uint32_t slots;             // 1: the slot form of the scan kernel (512 threads, per-slot tables: two spans per CU); 0: full tables
     uint32_t slot_limit;        // slots a span may hand out (0: all it has; tests: few, to force the full-table scan)
-    uint32_t abort_walks;       // full-table form: a span that has walked this often, more than once per 3072 packets, stops the
+    uint32_t abort_walks;       // full-table form: a span that has walked this often, more than once per 6144 packets, stops the
                                 // scan (every span) — the stream is damaged and the slot form's (0: never)
     uint32_t lookahead;         // 1: at a partial block, ask for the walker's window and for the headers of the block behind the damage
                                 // before the block is committed (TS_SCAN_LOOKAHEAD=0: afterwards, one trip to memory at a time)

@@ -35,6 +35,7 @@ constexpr int kMergeBlock = 256;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr int kEntrySyncs = 8;  // sync bytes in a row, at the stride, that make a position a span's speculated entry
 constexpr uint32_t kEntryBytes = 16384;  // ... looked for in the span's first 16 KiB
+constexpr uint32_t kEntryLater = 6;      // packets a span that begins in damage enters behind the first such position
 
 // ---- the walker on the device: ts_walk_core.h with these hooks, run by wave 0 with all 64 lanes in step ----
 // The walker reads the stream through a WINDOW in LDS: 4 KiB brought in by one cooperative load (four 16-byte loads per
@@ -507,6 +508,30 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
             }
             return;
         }
+        // Nothing regular in the span's first stride-ful of bytes: there is damage right here, and the chain — the reference's
+        // state machine coming out of it: a false sync byte in a payload, a bogus packet, another search — need not be back on
+        // the grid at the FIRST position behind which eight sync bytes line up.  kEntryLater packets further on it almost
+        // always is: the span enters there (if the sync bytes still line up), and what lies in front is the bridge's.
+        if (s_cand >= p.stride) {  // (workgroup-uniform)
+            const uint64_t later = (uint64_t)s_cand + (uint64_t)kEntryLater * p.stride;
+            const uint64_t sy = B0 + later + p.sync_offset;
+            bool ok = B0 + later < B1;
+            if (t < (uint32_t)kEntrySyncs) {
+                const uint64_t at = sy + (uint64_t)t * p.stride;
+                if (at < p.nbytes && p.data[at] != 0x47u)
+                    atomicOr(&s_entries, 1u);  // (s_entries is not in use yet: cleared again below)
+            }
+            __syncthreads();
+            if (s_entries != 0u)
+                ok = false;
+            __syncthreads();
+            if (t == 0) {
+                s_entries = 0;
+                if (ok)
+                    s_cand = (uint32_t)later;
+            }
+            __syncthreads();
+        }
         if (t == 0)
             s_st.pos = B0 + s_cand;
     }
@@ -790,9 +815,9 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
         walk_next = false;
         walks++;
         // The full-table form gives a damaged stream up: one workgroup per CU has nothing to run while a damaged spot's three
-        // dependent trips to memory are under way; the slot form (two spans per CU) has.  More than one walk in 3072
+        // dependent trips to memory are under way; the slot form (two spans per CU) has.  More than one walk in 6144
         // packets, abort_walks walks into the span: every span stops, the host scans again in the slot form.
-        if (p.abort_walks && walks >= p.abort_walks && (uint64_t)walks * 3072u > packets) {  // (workgroup-uniform)
+        if (p.abort_walks && walks >= p.abort_walks && (uint64_t)walks * 6144u > packets) {  // (workgroup-uniform)
             if (t == 0)
                 atomicOr(p.event_count + 2, 1u);
             break;

@@ -395,7 +395,7 @@ int ts_hip_download(ts_hip_ctx *ctx, void *bytes, uint64_t first, uint64_t nbyte
 // scan_with: nothing of the scan stands —
 constexpr int kSlotsOverflowed = 1;  // a span met more PIDs than the slot form has slots
 constexpr int kGaveUp = 2;           // the full-table form met a damaged stream (abort_walks)
-constexpr uint32_t kAbortWalks = 4;
+constexpr uint32_t kAbortWalks = 8;  // (four until the rate went from one walk in 3072 packets to one in 6144: a spot that takes two walks made four of them in a span's first 24576 packets even at one spot in 10000)
 
 // one scan in one form; what the forms tried before it cost goes into the result's `launches` and `kernel_ms`
 static double host_now_ms()
@@ -526,6 +526,13 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
                 return ts_fail(ctx, PAPR_E_INTERNAL, "the span chain does not converge (span %u)", mo.valid_upto);
             // the chain arrived in front of span `valid_upto` somewhere else (or in another state) than the span assumed:
             // that span once more, from the true state
+            if (trace) {  // (why: where the chain stands, and where the span thought it would)
+                ts_span_rec r{};
+                (void)hipMemcpy(&r, ctx->d_recs + mo.valid_upto, sizeof(r), hipMemcpyDeviceToHost);
+                fprintf(stderr, "ts scan: span %u of %u again: the chain stands at %llu (skipped %llu, stale_af %u), the span [%llu, ...) entered at %lld = chain %+lld\n",
+                        mo.valid_upto, nspans, (unsigned long long)cur.pos, (unsigned long long)cur.skipped, cur.stale_af,
+                        (unsigned long long)((uint64_t)mo.valid_upto * span_bytes), (long long)r.entry, (long long)(r.entry - cur.pos));
+            }
             from = mo.valid_upto;
             p.first_span = from;
             p.explicit_entry = 1;
@@ -833,12 +840,12 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
 {
     // The full-table form (one 1024-thread workgroup per CU) is the faster one on a stream that is in order (by 4 %), the
     // slot form (two spans per CU) on a damaged one (one damaged packet in 10000: even; in 3000: by a quarter; in 1000: by
-    // half): the scan starts in the first and, if a span meets damage more often than once in 3072 packets (four
+    // half): the scan starts in the first and, if a span meets damage more often than once in 6144 packets (with the look-ahead across damaged spots the two forms are even at about that rate) (four
     // walks in: the first twentieth of a span or less), is done again in the second — which itself hands a stream with more PIDs
     // in a span than it has slots back to the first.
     // A context remembers: after a stream that was given up for the slot form the next scan STARTS in the slot form (a capture's
     // next file is damaged like the last one; the attempt that is given up costs 0.1-0.4 ms), until a scan in the slot form
-    // walks less than once in 6144 packets.
+    // walks less than once in 12288 packets.
     int rc = PAPR_OK;
     out->launches = 0;
     out->kernel_ms = out->merge_ms = 0.0;
@@ -851,7 +858,7 @@ static int ts_hip_scan_impl(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out)
     if (ctx->form != 1) {
         rc = scan_with(ctx, hdmv, out, true, 0, out->launches, out->kernel_ms, out->merge_ms);
         if (rc != kSlotsOverflowed) {
-            if (rc == PAPR_OK && ctx->form == 0 && (uint64_t)out->walks * 6144u < out->packets)
+            if (rc == PAPR_OK && ctx->form == 0 && (uint64_t)out->walks * 12288u < out->packets)
                 ctx->start_slots = false;  // (in order again: the full tables are the faster form)
             return rc;
         }

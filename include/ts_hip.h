@@ -135,7 +135,7 @@ int ts_hip_download(ts_hip_ctx *ctx, void *bytes, uint64_t first, uint64_t nbyte
 /* One complete scan of the resident stream (what `xport -p[h]` reports: xport.c:241-250, 2842-2889, 4317-4373).  The kernel has
  * two forms with the same result: full per-PID tables, one span of the stream per CU — the faster one on a stream that is in
  * order — and per-slot tables, two spans per CU, for damaged streams; a scan starts in the first and is done again in the
- * second when its spans meet damage more than once per 3072 packets (out->launches and out->kernel_ms count both attempts;
+ * second when its spans meet damage more than once per 6144 packets (out->launches and out->kernel_ms count both attempts;
  * TS_SCAN_FORM=auto|full|slots chooses, a context reads it when it is opened). */
 int ts_hip_scan(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out);
 /* sizeof(ts_scan_result) as the LIBRARY was built (it has grown between ABI versions: papr_hip.h, PAPR_HIP_ABI_VERSION): a

@@ -261,7 +261,7 @@ def test_more_pids_than_slots_falls_back_to_the_full_tables(ts, env, many):
 
 @pytest.mark.gpu
 def test_a_damaged_stream_is_given_up_for_the_slot_form(ts, tmp_path):
-    """The default scan starts in the full-table form; spans that meet damage more often than once in 3072 packets stop it
+    """The default scan starts in the full-table form; spans that meet damage more often than once in 6144 packets stop it
     and the slot form does the stream (one launch more, the same report); an occasional damaged spot does not."""
     with _with_env(ts, {"TS_SCAN_FORM": "auto"}) as g, _with_env(ts, {"TS_SCAN_FORM": "full"}) as f:
         for n, period, gives_up in ((2_000_000, 500, True), (2_000_000, 50000, False)):
