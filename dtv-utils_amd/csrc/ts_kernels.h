@@ -27,6 +27,10 @@ struct ts_span_rec {
     uint32_t attempt;        // id of the launch that wrote this record (its events carry the same)
     uint32_t explicit_entry; // 1: started from a walker state handed in by the host, clean or not
     uint32_t ncc, pad;       // entries in its continuity list
+    uint32_t first_take;     // packets its very first block committed (0: it began with the walker): as many of its first packets are
+    uint32_t pad3;           // plain packets on its grid, one lane each — what ts_overlap_packets may hand back to the span in front
+    uint64_t exit_run_start; // where the run of packets it consumed back to back (each starting where the one in front ended, whole)
+                             // up to its exit began: a span behind whose entry lies on that run was entered by THIS span's packets
 };
 #define TS_NO_ENTRY 0xFFFFFFFFFFFFFFFFull
 #define TS_EVENT_BRIDGE 0x80000000u /* ts_event::attempt: written by a bridge of ts_merge_kernel */
@@ -61,6 +65,8 @@ struct ts_span_out {
     unsigned long long base, bridge_base;  // stream-wide number of the span's (of its bridge's) first packet - 1
     uint32_t attempt;                      // the attempt whose record was taken (0: the span was not taken)
     uint32_t ncc;                          // entries in its continuity list
+    uint32_t dup, pad;                     // its first `dup` packets were the span's in front already (that span ended un-clean on the
+                                           // boundary and took them along): counted once, their lines and continuity checks dropped here
     ts_cc_entry cc[TS_CC_OUT];
 };
 
@@ -69,7 +75,8 @@ struct ts_span_out {
 struct ts_bridge_rec {
     unsigned long long packets;  // state 2: packets the bridge counts in front of the span
     uint32_t state;              // 0 not worked out (the merge walks itself); 1 the span starts where the one in front ended;
-                                 // 2 a bridge gets there; 3 nothing does (the chain ends in front of this span)
+                                 // 2 a bridge gets there; 3 nothing does (the chain ends in front of this span);
+                                 // 4 the chain stands `packets` whole packets BEHIND the span's entry, on its grid (ts_overlap_packets)
     uint32_t pad;
 };
 
@@ -90,6 +97,8 @@ struct ts_scan_params {
                                 // scan (every span) — the stream is damaged and the slot form's (0: never)
     uint32_t lookahead;         // 1: at a partial block, ask for the walker's window and for the headers of the block behind the damage
                                 // before the block is committed (TS_SCAN_LOOKAHEAD=0: afterwards, one trip to memory at a time)
+    uint32_t overlap;           // 1: a span whose first packets the span in front took along is kept (ts_overlap_packets);
+                                // TS_SCAN_OVERLAP=0: it is scanned again from the chain's state, as before round 5 (tests)
     ts_walk_state entry;
     ts_wg_entry *lists;         // per span: up to TS_PIDS entries
     ts_span_rec *recs;          // per span

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
     extern __shared__ __attribute__((aligned(16))) uint32_t ts_smem[];  // 3 x NT words (full tables: 96 KiB, one workgroup per CU)
     uint32_t *s_count = ts_smem, *s_first = ts_smem + NT, *s_last = ts_smem + 2 * NT;
     __shared__ ts_walk_state s_st;
-    __shared__ unsigned long long s_packets, s_block_packets;
+    __shared__ unsigned long long s_packets, s_block_packets, s_run_start;
     __shared__ uint32_t s_stop, s_walks, s_entries, s_cand, s_ncc, s_ev[2], s_evbase, s_nid, s_evn[kScanBlock / 64];
     __shared__ unsigned char s_cc[NT];  // per PID: last continuity counter + 1 (0: no payload packet in this span yet)
     // the slot form: PID -> slot + 1 (0: none yet), the slots' PIDs, slots handed out, "more PIDs than slots"
@@ -504,6 +504,8 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
                 r.attempt = p.attempt;
                 r.explicit_entry = 0;
                 r.ncc = r.pad = 0;
+                r.first_take = r.pad3 = 0;
+                r.exit_run_start = TS_NO_ENTRY;
                 p.recs[span] = r;
             }
             return;
@@ -544,6 +546,9 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
     uint64_t packets = 0, block_packets = 0;
     uint32_t units_seen = 0;  // units the blocks of this span have looked at so far: block-independent indices for s_stop
     uint32_t walks = 0;
+    uint32_t first_take = kNone;     // packets the span's very first block committed (kNone: no block yet)
+    uint64_t run_start = st.pos;     // where the packets consumed back to back up to here began (blocks go on with a run, a walker's
+                                     // packet that does not start where the one in front ended — or ends early — begins a new one)
     uint64_t pre_pos = TS_NO_ENTRY;  // the position whose block's header words are in pre_w0 / pre_w1 already
     uint32_t pre_w0 = 0, pre_w1 = 0;
     // Looking ahead across a damaged spot (below): the block behind it is expected one unit behind the first irregular one,
@@ -627,6 +632,8 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
                 break;  // (workgroup-uniform; nothing of this scan will be used)
             const uint32_t stop = s_stop - units_seen;  // (kNone - units_seen >= nblk: a span looks at < 2^32 - 1024 units)
             const uint32_t take = stop < nblk ? stop : nblk;  // units in front of the first irregular one
+            if (first_take == kNone)
+                first_take = walks == 0 && packets == 0 ? take : 0u;
             // A whole block taken: the next block's header words are asked for NOW — they fly while this block's packets are
             // committed and its continuity counters go through the workgroup's table in turn (below), which is then not
             // on the scan's critical path
@@ -863,9 +870,14 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
             w.s_slot_pid = s_slot_pid;
             w.slot_limit = p.slot_limit;
             ts_walk_state s2 = st;
+            uint64_t rs = run_start;
             for (;;) {
+                const uint64_t before = s2.pos;
+                const bool owed = s2.skipped != 0;
                 if (!dev_walk_step(&s2, &w, p.nbytes, 1))
                     break;  // the stream ended in front of the next packet (s2.pos == nbytes)
+                if (owed || s2.pos != before + p.stride)  // (bytes skipped in front of this packet, or it ended early: a new run begins
+                    rs = s2.pos >= p.stride ? s2.pos - p.stride : s2.pos;  // with it — at the unit it fills if it is a whole one)
                 if (s2.pos >= p.nbytes)
                     break;
                 if (walk_is_clean(s2) && (s2.pos >= B1 || s2.pos + p.sync_offset >= p.nbytes || dev_byte(&w, s2.pos + p.sync_offset) == 0x47u))
@@ -874,12 +886,14 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
             if (lane == 0) {
                 s_st = s2;
                 s_packets = w.packets;
+                s_run_start = rs;
                 s_stop = kNone;
             }
         }
         __syncthreads();
         st = s_st;
         packets = s_packets;
+        run_start = s_run_start;
     }
     __syncthreads();
     if (t == 0) {
@@ -923,8 +937,45 @@ __global__ __launch_bounds__(BLOCK) void ts_scan_kernel(const ts_scan_params prm
         r.nlist = s_entries;
         r.attempt = p.attempt;
         r.explicit_entry = p.explicit_entry;
+        r.first_take = first_take == kNone ? 0u : first_take;  // (the same in every thread)
+        r.pad3 = 0;
+        r.exit_run_start = run_start;
         p.recs[span] = r;
     }
+}
+
+// The chain arrives BEHIND the entry a span assumed — by whole packets, on the span's grid, owing nothing: the span in front
+// ended un-clean on the boundary (an adaptation field that ran over, bytes skipped) and, by the reference's rules, took the
+// first packet(s) that start in this span along before it was clean.  The span counted the same packets, plain ones its first
+// block committed one lane each (none of them a read-boundary quirk: those print a line of their own): they are counted once
+// — this span's numbering starts that many packets earlier, the merge takes one off their PIDs' counts, the host drops their
+// lines and continuity checks here — instead of the whole span being scanned again by one workgroup (0.7-1.0 ms; 20 of the 26
+// spans scanned again in 40 damaged streams were this case, all of them by one packet).  Returns that number of packets, or 0.
+// `run_start`: ts_span_rec::exit_run_start of the span the chain comes out of (TS_NO_ENTRY: not known — a state the host handed in).
+constexpr uint32_t kOverlapMax = 8;
+__device__ uint32_t ts_overlap_packets(const ts_scan_params &p, const ts_span_rec &r, const ts_walk_state &cur, uint64_t run_start, uint64_t B1)
+{
+    if (!p.overlap || r.explicit_entry || r.entry == TS_NO_ENTRY || cur.pos <= r.entry || cur.pos >= B1)
+        return 0u;
+    // (the chain's last packets must BE this span's first: consumed back to back from a unit start on the span's grid at or in
+    // front of its entry — a state machine that came through here on a bogus packet's grid and merely ended on this one has
+    // counted other packets)
+    if (run_start == TS_NO_ENTRY || run_start > r.entry || (r.entry - run_start) % p.stride != 0)
+        return 0u;
+    if (cur.skipped != 0 || cur.stale_af != 0 || (cur.hdmv && cur.extra_pending != 4u))
+        return 0u;
+    const uint64_t d = cur.pos - r.entry;
+    if (d % p.stride != 0 || d / p.stride > kOverlapMax)
+        return 0u;
+    const uint32_t m = (uint32_t)(d / p.stride);
+    if (m > r.first_take || (uint64_t)m > r.packets)
+        return 0u;
+    for (uint32_t i = 0; i < m; i++) {
+        const uint64_t sy = r.entry + (uint64_t)i * p.stride + p.sync_offset;
+        if (((sy + 187) & (TS_READ_CHUNK - 1)) == 0)
+            return 0u;  // (a read-boundary quirk candidate: its own line, its own rules)
+    }
+    return m;
 }
 
 // The walker from the chain's state `cur` up to span k's entry (wave 0, all lanes in step): does it get there — on the very
@@ -1007,6 +1058,8 @@ __global__ __launch_bounds__(64) void ts_bridge_kernel(const ts_scan_params p, u
             state = 1;
         else if (!r.explicit_entry && r.entry != TS_NO_ENTRY && cur.pos <= r.entry && r.entry - cur.pos <= kBridgeMax)
             state = bridge_walk(p, k, r, cur, 0, threadIdx.x, s_window, true, nullptr, nullptr, nullptr, &packets) ? 2u : 3u;
+        else if ((packets = ts_overlap_packets(p, r, cur, k > from_span ? p.recs[k - 1].exit_run_start : TS_NO_ENTRY, B1)) != 0)
+            state = 4;
         else
             state = 3;
     }
@@ -1040,13 +1093,14 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
     __shared__ ts_span_rec s_recs[TS_MAX_SPANS];  // (the chain walk is a serial loop: out of LDS, not out of HBM)
     const uint32_t t = threadIdx.x;
     const uint32_t me = from_span + blockIdx.x;
-    __shared__ uint32_t s_broken, s_bad;
+    __shared__ uint32_t s_broken, s_bad, s_dup;
     __shared__ unsigned long long s_sum_before, s_sum_all, s_sum_block, s_sum_walks, s_my_bridge;
     for (uint32_t k = from_span + t; k < p.nspans_total; k += kMergeBlock)
         s_recs[k] = p.recs[k];
     if (t == 0) {
         s_broken = 0;
         s_bad = p.nspans_total;
+        s_dup = 0;
         s_my_bridge = 0;
         s_sum_before = s_sum_all = s_sum_block = s_sum_walks = 0;
     }
@@ -1074,11 +1128,17 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
         bridge_packets = 0;
         if (prev.pos < B1 && r.entry == prev.pos && (clean || explicit_ok))
             return 1u;
-        if (!p.bridges)
-            return 0u;
+        if (!p.bridges) {  // (no bridge kernel in front: only what needs no walk is decided here)
+            const uint32_t m = ts_overlap_packets(p, r, prev, k > from_span ? s_recs[k - 1].exit_run_start : TS_NO_ENTRY, B1);
+            if (m)
+                bridge_packets = 0ull - m;  // (the span's numbering starts m packets EARLIER: the chain has counted them)
+            return m ? 4u : 0u;
+        }
         const ts_bridge_rec b = p.bridges[k];
         if (b.state == 2u)
             bridge_packets = b.packets;
+        else if (b.state == 4u)
+            bridge_packets = 0ull - b.packets;
         return b.state == 1u ? 0u : b.state;  // (1 cannot be: the bridge kernel saw the same records)
     };
     for (uint32_t k = from_span + t; k < p.nspans_total; k += kMergeBlock) {
@@ -1104,8 +1164,10 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
             wk += r.walks + (st == 2u ? 1u : 0u);
             if (k < me)
                 before += r.packets + bp;
-            if (k == me)
+            if (k == me) {
                 s_my_bridge = bp;
+                s_dup = st == 4u ? (uint32_t)(0ull - bp) : 0u;
+            }
         }
         atomicAdd(&s_sum_before, before);
         atomicAdd(&s_sum_all, all);
@@ -1155,8 +1217,9 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
         // the span's entry, or dirty, or nowhere near) does the host launch the span again.
         ts_walk_state cur = cur0;
         uint64_t base = packet_base, blockp = 0, walks = 0;
-        uint32_t k = from_span, taken_me = 0;
+        uint32_t k = from_span, taken_me = 0, dup_me = 0;
         uint64_t base_me = 0, bridge_me = 0;
+        uint64_t chain_run = TS_NO_ENTRY;  // ts_span_rec::exit_run_start of the span the chain last came out of (ts_overlap_packets)
         for (; k < p.nspans_total; k++) {
             const uint64_t B1 = (k + 1 == p.nspans_total || (uint64_t)(k + 1) * p.span_bytes > p.nbytes) ? p.nbytes
                                                                                                         : (uint64_t)(k + 1) * p.span_bytes;
@@ -1183,6 +1246,15 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
                     walks++;
                 }
             }
+            if (!fits) {  // (... or behind it by whole packets the span in front took along: counted once)
+                const uint32_t m = ts_overlap_packets(p, r, cur, chain_run, B1);
+                if (m) {
+                    fits = true;
+                    base -= m;
+                    if (k == me)
+                        dup_me = m;
+                }
+            }
             if (!fits)
                 break;
             if (k == me) {
@@ -1197,11 +1269,13 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
             cur.skipped = r.exit_skipped;
             cur.stale_af = r.exit_stale_af;
             cur.extra_pending = r.exit_extra;
+            chain_run = r.exit_run_start;
         }
         if (t == 0) {
             s_taken = k > me ? taken_me : 0u;  // (k <= me: the chain broke in front of this span)
             s_base = base_me;
             s_bridge_base = bridge_me;
+            s_dup = dup_me;
             if (blockIdx.x == 0) {
                 out->valid_upto = k;
                 out->pad = p.event_count[2];
@@ -1231,6 +1305,8 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
             so->bridge_base = s_bridge_base;
             so->attempt = taken;
             so->ncc = ncc;
+            so->dup = taken ? s_dup : 0u;
+            so->pad = 0;
         }
         const ts_cc_entry *cl = p.cc_lists + (size_t)me * TS_PIDS;
         for (uint32_t k = t; k < ncc && k < TS_CC_OUT; k += kMergeBlock)
@@ -1245,6 +1321,13 @@ __global__ __launch_bounds__(kMergeBlock) void ts_merge_kernel(const ts_scan_par
         atomicAdd(&g_count[e.pid], e.count);
         atomicMin(&g_first[e.pid], base + e.first + 1);
         atomicMax(&g_last[e.pid], base + e.last + 1);
+    }
+    // (packets the span in front counted already: once is enough — their numbers are the same from either side, so first / last stand)
+    if (t < s_dup) {
+        const uint64_t sy = s_recs[me].entry + (uint64_t)t * p.stride + p.sync_offset;
+        const uint32_t b1 = p.data[sy + 1], b2 = p.data[sy + 2];
+        if ((b1 & 0x80u) == 0)
+            atomicSub(&g_count[((b1 & 0x1fu) << 8) | b2], 1u);
     }
 }
 

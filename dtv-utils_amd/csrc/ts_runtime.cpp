@@ -69,6 +69,7 @@ struct ts_hip_ctx {
                                                             // 1: full tables only; 2: slot form first (TS_SCAN_FORM=auto|full|slots)
     bool start_slots = false;                               // form 0: the last scan was given up for the slot form — start there
     uint32_t slot_limit = 0;                                // (tests: TS_SCAN_SLOT_LIMIT)
+    uint32_t overlap = 1;                                   // TS_SCAN_OVERLAP=0: a span the one in front reached into is scanned again (tests)
     uint32_t lookahead = 1;                                 // TS_SCAN_LOOKAHEAD=0: a damaged spot's trips to memory one at a time (tests, measurements)
     int bridges_mode = -1;                                  // TS_SCAN_BRIDGES: 1 ts_bridge_kernel in front of every merge, 0 of none (tests)
     hipEvent_t ev_a = nullptr, ev_m = nullptr, ev_b = nullptr;
@@ -185,6 +186,7 @@ int ts_hip_open(ts_hip_ctx **out, int device)
         ctx->form = !strcmp(e, "full") ? 1 : !strcmp(e, "slots") ? 2 : 0;
     ctx->bridges_mode = env_int_ts("TS_SCAN_BRIDGES", -1);
     ctx->lookahead = env_int_ts("TS_SCAN_LOOKAHEAD", 1) != 0 ? 1u : 0u;
+    ctx->overlap = env_int_ts("TS_SCAN_OVERLAP", 1) != 0 ? 1u : 0u;
     if (const char *e = getenv("TS_SCAN_SLOT_LIMIT"))
         ctx->slot_limit = (uint32_t)std::max(0, atoi(e));
     OPENCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -460,6 +462,7 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
         p.slot_limit = ctx->slot_limit;
         p.abort_walks = abort_walks;
         p.lookahead = ctx->lookahead;
+        p.overlap = ctx->overlap;
         ts_walk_init(&p.entry, hdmv);
         p.lists = ctx->d_lists;
         p.recs = ctx->d_recs;
@@ -609,12 +612,21 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
         const ts_event *ev_begin = ctx->h_events;
         const ts_span_out *so = ctx->h_span_out;
         auto takes = [&](const ts_event &e) {  // (else: an attempt the chain did not take)
-            return e.span < nspans && so[e.span].attempt != 0 && so[e.span].attempt == (e.attempt & ~TS_EVENT_BRIDGE);
+            if (!(e.span < nspans && so[e.span].attempt != 0 && so[e.span].attempt == (e.attempt & ~TS_EVENT_BRIDGE)))
+                return false;
+            // (the span's first `dup` packets were the span's in front already, which printed their lines: ts_overlap_packets)
+            // (a discontinuity carries its packet's number within the span; a sync error the count in front of it — and no plain packet has one)
+            return (e.attempt & TS_EVENT_BRIDGE) != 0 || e.kind != TS_EV_DISC || e.at_rel > so[e.span].dup;
         };
         // Every span's lines come in three runs, each in the reference's order already: what the merge kernel's bridge in
         // front of it reported, what the span itself reported (the event list's slots are handed out in stream order
         // within a span: ts_kernels.hip), and the few the linking below adds.  A counting sort over (span, run) — stable —
         // lays them out; the runs are then merged.  Nothing is sorted unless a run turns out not to be in order.
+        if (trace)
+            for (uint32_t k = 0; k < nspans; k++)
+                if (so[k].dup)
+                    fprintf(stderr, "ts scan: span %u starts %u packet(s) inside the span in front's last walk (its numbering from %llu)\n", k, so[k].dup,
+                            (unsigned long long)so[k].base);
         auto run_of = [](const ts_event &e) { return (e.attempt & TS_EVENT_BRIDGE) ? (e.kind == TS_EV_BRIDGE_CC ? 0u : 1u) : 2u; };
         const int T = burst_threads;  // (the workers were woken when the scan learnt how many lines it has)
         auto parallel = [&](int n, const std::function<void(int)> &f) {
@@ -746,7 +758,8 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
             }
             const ts_cc_entry *list = so[k].ncc > TS_CC_OUT ? big.data() + (size_t)k * max_ncc : so[k].cc;
             for (uint32_t j = 0; j < so[k].ncc; j++)
-                check(list[j].pid, list[j].first_cc, so[k].base + list[j].first_rel + 1);
+                if (list[j].first_rel >= so[k].dup)  // (else: the very packet the span in front left the counter at)
+                    check(list[j].pid, list[j].first_cc, so[k].base + list[j].first_rel + 1);
             for (uint32_t j = 0; j < so[k].ncc; j++)
                 cc_state[list[j].pid] = (uint8_t)(list[j].last_cc + 1u);
             in_order(linked.data() + linked_first[k], linked.data() + linked.size());

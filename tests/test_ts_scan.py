@@ -402,3 +402,34 @@ def test_long_spans_with_random_damage_equal_the_oracle(ts, hdmv):
                     assert res.packets == ref["packets"] and np.array_equal(cnt, ref["count"]) and \
                         np.array_equal(first, ref["first"]) and np.array_equal(last, ref["last"]), how
                     assert res.sync_error_list() == ref["sync_errors"] and res.discontinuity_list() == ref["discontinuities"], how
+
+
+@pytest.mark.gpu
+def test_a_span_the_one_in_front_reached_into_is_not_scanned_again(ts):
+    """A span that ends un-clean on its boundary takes, by the reference's rules, the first packet(s) that start in the next span
+    along.  That span counted them too: instead of scanning it again from the chain's state (one workgroup over the whole span),
+    the merge counts them once (ts_overlap_packets: the chain must stand whole packets behind the span's entry, on its grid,
+    having consumed exactly those packets back to back).  Streams of the bench's kind where that happens (and one where the
+    chain merely ENDS on the next span's grid, which must not be taken for it: period 40): same report, same tables as with
+    TS_SCAN_OVERLAP=0 and as the oracle's where the oracle is quick; fewer launches."""
+    fewer = 0
+    for period, n in ((1500, 56_490_000), (500, 36_732_000), (700, 34_459_600), (1000, 20_224_000), (40, 280_000)):
+        n = n // (4 * period) * (4 * period)
+        got = {}
+        for overlap in ("1", "0"):
+            with _with_env(ts, {"TS_SCAN_FORM": "slots" if period > 40 else "full", "TS_SCAN_OVERLAP": overlap}) as g:
+                g.generate_damaged(n, period, seed=0x7500001 + n % 97)
+                g.scan()
+                r = g.scan()
+                got[overlap] = (r.report(), r.packets, [x.tobytes() for x in r.tables()], r.sync_error_list(), r.discontinuity_list())
+                launches = r.launches
+                if overlap == "1":
+                    with_overlap = launches
+                    if n < 1_000_000:
+                        host = g.download(0, n * 188 - n // (4 * period))
+                        ref = ts_oracle.scan_mem(host)
+                        assert r.report() == ts_oracle.report_lines(ref) and r.discontinuity_list() == ref["discontinuities"]
+        assert got["1"] == got["0"], (period, n)
+        assert with_overlap <= launches
+        fewer += with_overlap < launches
+    assert fewer >= 3
