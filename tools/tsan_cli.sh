@@ -3,7 +3,8 @@
 # packet scan's line pool): build here (`tools/tsan_cli.sh build`: cross-compiles, no GPU), run ON THE GPU BOX
 # (`gpurun -- 'bash tools/tsan_cli.sh run'`).  The HIP / HSA runtimes are not instrumented and report races of their own (their
 # internal threads against API calls): tools/tsan_filter.py counts the reports in which one of the two accesses is in OUR code.
-#   resident exact | streamed -g | three shards on one GPU over the in-process hub | three shards streamed
+#   resident exact | streamed -g | three shards on one GPU over the in-process hub | three shards streamed | the packet scan
+#   (tests/c/ts_scan_harness.cpp through the C ABI: a damaged stream scanned again and again, every report the first one's)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
@@ -21,7 +22,10 @@ if [ "${1:-run}" = build ]; then
   $CL -O1 -g -ffp-contract=off -fsanitize=thread -Iinclude -c dtv-utils_amd/host/papr_main.c -o scratch/tsan/papr_main.o || exit 1
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -fsanitize=thread scratch/tsan/*.o $C/papr_kernels.o $C/papr_sweep.o $C/papr_exact.o $C/ts_kernels.o \
       -o bin/papr_tsan -lm -lpthread -ldl || exit 1
-  echo "built bin/papr_tsan"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -Iinclude -Xarch_host -fsanitize=thread -c tests/c/ts_scan_harness.cpp -o scratch/tsan/ts_scan_harness.o2 || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fsanitize=thread scratch/tsan/ts_scan_harness.o2 $(ls scratch/tsan/*.o | grep -v papr_main.o) \
+      $C/papr_kernels.o $C/papr_sweep.o $C/papr_exact.o $C/ts_kernels.o -o bin/ts_tsan -lm -lpthread -ldl || exit 1
+  echo "built bin/papr_tsan bin/ts_tsan"
   exit 0
 fi
 F=/dev/shm/tsan.cfile
@@ -41,3 +45,9 @@ run "three shards on one GPU, in-process hub" "$ref" PAPR_GPUS=3 PAPR_OVERSUBSCR
 run "three shards on one GPU, RCCL refused (one device): hub" "$ref" PAPR_GPUS=3 PAPR_OVERSUBSCRIBE=1 bin/papr_tsan $F
 run "three shards, streamed, -g" "$refg" PAPR_GPUS=3 PAPR_OVERSUBSCRIBE=1 PAPR_HBM_BUDGET_MB=256 bin/papr_tsan -g $F
 rm -f $F
+# the packet scan: a damaged stream's report lines are laid out by the host's line pool (eight spinning threads), scan after scan
+for SPEC in "8000000 500 12" "57000000 1000 6"; do
+  timeout 300 env TS_SCAN_FORM=auto bin/ts_tsan $SPEC > /tmp/tsan_out.txt 2> /tmp/tsan_err.txt
+  echo "=== packet scan, $(cat /tmp/tsan_out.txt)"
+  python3 tools/tsan_filter.py /tmp/tsan_err.txt
+done
