@@ -248,7 +248,8 @@ def compact_line(full, full_path):
         "frac": _r(r["achieved"], 2) / r["peak"],   # (of the rounded figure beside it, exactly)
         "traffic": _r(r.get("traffic"), 0), "kernel": r["kernel"], "kernel_ms": _r(r["kernel_ms"], 5),
         "algorithmic_bytes_per_launch": r.get("algorithmic_bytes_per_launch"), "kernel_variant": r.get("kernel_variant"),
-        "traffic_source": (r.get("traffic_source") or "")[:60] or None, "traffic_stale": r.get("traffic_stale"),
+        "traffic_source": (r.get("traffic_source") or "")[:90] or None, "traffic_stale": r.get("traffic_stale"),
+        "traffic_over_algorithmic": _r(r.get("traffic_over_algorithmic"), 4), "traffic_measured_s": r.get("traffic_measured_s"),
         "step_ms": brief(r.get("step_ms")), "kernel_launch_ms": brief(r.get("kernel_launch_ms")),
         "step_ms_median": (r.get("step_ms") or {}).get("median"), "step_ms_max": (r.get("step_ms") or {}).get("max"),
         # steps that took more than twice the median (the host's wait coming back late: 8-9 ms now and then on some boxes,
@@ -279,6 +280,9 @@ def compact_line(full, full_path):
                          "nproc": cb.get("nproc"), "sample": cb.get("sample_short") or cb["sample"][:120],
                          "gpu_stdout_identical": cb.get("gpu_stdout_identical"),
                          "O3_avx2_value": _r(best.get("value"), 3) if best else None}
+    for key in ("weak", "strong"):   # more than one rank: both readings of the scaling target
+        if isinstance(full.get(key), dict):
+            line[key] = {k: v for k, v in full[key].items() if k not in ("step_ms", "kernel_launch_ms")}
     for key in ("parity_in_run", "parity_golden", "report_sha256", "device"):
         line[key] = full.get(key)
     line["full"] = full_path
@@ -490,14 +494,15 @@ def run_mode(args, mode, env):
                 pass
         # in-run parity: what this run would print, against what the REFERENCE printed for the same global stream
         report = pkg.format_report(result["total"], result["mean"], result["papr"], result["counts"], graph).encode()
-        golden, golden_name = golden_report(world, args.gib, graph) if args.signal == "gauss" else (None, None)
+        golden, golden_name = (golden_report(env.get("golden_world", world), args.gib, graph)
+                               if args.signal == "gauss" and env.get("golden_world", world) else (None, None))
         parity = None if golden is None else (report == golden)
         line = {
             "metric": "IQ Msamples/s + achieved HBM GB/s (% of peak), 10 GiB cfile, 1/2/4/8 GPU",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": env.get("scaling", "weak"), "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"papr {'-g ' if graph else ''}on {args.gib:g} GiB synthetic gr_complex IQ per GPU "
+            "config": {"workload": f"papr {'-g ' if graph else ''}on {per_gpu * 8 / (1 << 30):g} GiB synthetic gr_complex IQ per GPU "
                                    f"({'0.1 dB CCDF' if graph else 'peak+mean+1 dB histogram'}), HBM-resident, "
                                    f"{world}xMI355X",
                        "mode": args.mode, "signal": args.signal, "forced_miss": bool(args.force_miss),
@@ -584,6 +589,7 @@ def run_ts(args, rank, world, local_rank, use_dist):
     cold = []
     for i in range(preheat_steps + args.warmup):   # (as run_mode: the idle GPU's first ~20 ms of load are slower)
         t_c = time.perf_counter()
+        res = None
         res = gpu.scan()
         if i < 5:
             cold.append(round((time.perf_counter() - t_c) * 1e3, 3))
@@ -600,6 +606,7 @@ def run_ts(args, rank, world, local_rank, use_dist):
     t_prev = t0
     kernel_ms = merge_ms = 0.0
     for i in range(args.steps):
+        res = None   # (a result somebody still holds is given its complete lists before the next scan: nobody holds this one)
         res = gpu.scan()
         kernel_ms += res.kernel_ms
         merge_ms += res.merge_ms
@@ -712,6 +719,158 @@ def ts_cpu_baseline(gpu, ts, sample_gib: float, period: int = 0):
             os.unlink(path)
 
 
+def traffic_child(args):
+    """`bench.py --traffic-child` (run by live_traffic under rocprofv3 --pmc): the step itself and nothing else — the shard
+    generated on the device (its generate kernel writes exactly the stream: the WRITE_SIZE calibration), one untimed step and
+    two counted ones of the 1 dB table, then the same of the 0.1 dB table.  Prints nothing."""
+    pkg = ge.load_package()
+    from dtv_utils_amd import exchange
+    per_gpu = int(args.gib * (1 << 30)) // 8 // 8192 * 8192
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    shard = torch.empty(per_gpu * 8 + 65536, dtype=torch.uint8, device=device)
+    gpu = pkg.PaprHip(0)
+    gpu.adopt(shard.data_ptr(), per_gpu, base_index=0, keepalive=shard)
+    gpu.generate(pkg.SynthSpec.spike(per_gpu, envelope=args.signal), 0, per_gpu)
+    if args.exact:
+        gpu.set_exact(True)
+    xch = exchange.Exchange.single()
+    for graph in (False, True):
+        for _ in range(3):
+            gpu.analyze(xch, graph)
+    torch.cuda.synchronize()
+    gpu.close()
+
+
+def live_traffic(args, kernel, nbytes):
+    """HBM traffic of the dominant kernel measured IN THIS RUN (outside the timed region, outside `value`): the same step in
+    a child process under `rocprofv3 --pmc`, one counter per pass with --kernel-trace only, collected and corrected as
+    MI355X_MICROARCH.md's HBM section prescribes — FETCH_SIZE (KiB) tallies each 128-byte request of a 16 B/lane stream at
+    64 bytes on gfx950: x2; WRITE_SIZE is calibrated on the generate kernel of the same pass, which writes exactly the
+    stream.  Returns {"default": bytes per launch, "graph": ...} + the source text, or None (no rocprofv3 on the box, or a
+    pass that left no counters: the caller keeps profiles/pmc_traffic.json's constant and says so)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rp:
+        return None
+    tmp = tempfile.mkdtemp(prefix="papr_traffic_", dir="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--traffic-child", "--gib", str(args.gib), "--signal", args.signal]
+            if args.exact:
+                cmd.append("--exact")
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+            p = subprocess.run(cmd, capture_output=True, timeout=600, cwd="/tmp", env=dict(env, TMPDIR="/tmp"))
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                rows += [r for r in csv.DictReader(open(f, newline="")) if r.get("Counter_Name") == counter]
+            if p.returncode != 0 or not rows:
+                return None
+            rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+            dom = [float(r["Counter_Value"]) for r in rows if kernel + "<" in r["Kernel_Name"] or kernel + "(" in r["Kernel_Name"]]
+            gen = [float(r["Counter_Value"]) for r in rows if "papr_generate_kernel" in r["Kernel_Name"]]
+            if len(dom) != 6 or not gen:
+                return None
+            # (three launches per table: the first one, on the idle GPU, is not counted)
+            vals[counter] = {"default": sum(dom[1:3]) / 2, "graph": sum(dom[4:6]) / 2, "generate": gen[0]}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    wfac = nbytes / (vals["WRITE_SIZE"]["generate"] * 1024) if vals["WRITE_SIZE"]["generate"] else 0.0
+    out = {}
+    for m in ("default", "graph"):
+        rd = 2.0 * vals["FETCH_SIZE"][m] * 1024
+        wr = vals["WRITE_SIZE"][m] * 1024 * wfac
+        out[m] = {"traffic": rd + wr, "read": rd, "write": wr}
+    out["source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, a pass each (--kernel-trace only) over a child "
+                     "process running the same step; x2 gfx950 correction on the reads, writes calibrated on the generate kernel")
+    out["write_calibration_factor"] = wfac
+    return out
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N ...` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): this process
+    becomes the launcher.  N copies of the same command line, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+    torch.distributed.run would set them, rendezvous on 127.0.0.1), rank 0 on this process's stdout — it prints the ONE line —
+    and every other rank's stdout on stderr.  Fewer visible GPUs than ranks is refused in one stderr line before anything is
+    started (unless --backend gloo: ranks share GPUs round-robin, the code path and not a measurement).  A rank that fails
+    takes the others down with it (exact PIDs), and the exchange's watchdog (PAPR_XCH_TIMEOUT_S) turns a lost rank into that."""
+    import signal
+    n = args.gpus
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible == 0:
+        print("bench.py: needs a GPU: the papr product has no CPU path", file=sys.stderr)
+        return 3
+    if args.backend != "gloo" and visible < n:
+        print(f"bench.py: --gpus {n} but {visible} GPU(s) visible: one rank per GPU over RCCL needs {n} devices "
+              f"(--backend gloo lets ranks share a GPU: the N>1 code path, not a measurement)", file=sys.stderr)
+        return 3
+    env = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               PAPR_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=None if r == 0 else sys.stderr.fileno()))
+
+    def stop_all(sig=signal.SIGTERM):
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    q.send_signal(sig)
+                except OSError:
+                    pass
+
+    def on_signal(signum, _frame):
+        stop_all(signum)
+        raise SystemExit(128 + signum)
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, on_signal)
+    deadline = time.monotonic() + float(os.environ.get("PAPR_BENCH_LAUNCH_TIMEOUT_S", "3600"))
+    rc = 0
+    try:
+        while True:
+            states = [q.poll() for q in procs]
+            bad = [(r, c) for r, c in enumerate(states) if c not in (None, 0)]
+            if bad:
+                r, rc = bad[0]
+                print(f"bench.py: rank {r} of {n} ended with status {rc}: stopping the other ranks", file=sys.stderr)
+                break
+            if all(c == 0 for c in states):
+                return 0
+            if time.monotonic() > deadline:
+                print("bench.py: the ranks did not finish inside PAPR_BENCH_LAUNCH_TIMEOUT_S: stopping them", file=sys.stderr)
+                rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        stop_all()
+        t_end = time.monotonic() + 5.0
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+                q.wait()
+    return rc if 0 < rc < 256 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -763,12 +922,24 @@ def main():
                     help="with peers (or under torchrun): skip the exchange's self-test in front of the timed work")
     ap.add_argument("--all-legs", action="store_true",
                     help="with more than one rank: also run the exact-sum and packet-scan members (default there: headline + graph)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="keep roofline.traffic at the constant of profiles/pmc_traffic.json instead of measuring it in this run "
+                         "(two rocprofv3 --pmc passes over a child process behind the timed region: ~30 s)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-strong", action="store_true",
+                    help="with more than one rank: leave the strong-scaling member out (the --gib stream cut into N shards, "
+                         "beside the weak headline where every rank has --gib of its own)")
     ap.add_argument("--no-ts", action="store_true", help="leave the transport-stream member out of the plain invocation's line")
     ap.add_argument("--member-steps", type=int, default=20, help="steps of the exact / ts members of the plain invocation")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the end-to-end leg (the drop-in CLI on a file in /dev/shm -> stdout; PCIe-inclusive, reported "
                          "under \"e2e\", never as `value`)")
     args = ap.parse_args()
+    if args.traffic_child:
+        return traffic_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's N=1 command with --gpus N: no launcher around us, so be one (one rank per GPU, rank 0 prints the line)
+        sys.exit(launch_ranks(args))
 
     # stdout carries exactly ONE line (the JSON): library chatter during set-up (e.g. the RCCL
     # version banner printed at communicator creation) is routed to stderr until then
@@ -782,13 +953,16 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus > 1 launch with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the papr product has no CPU path")
     if args.backend == "gloo":
         args.control = "gloo"
     if args.backend == "gloo":
         local_rank %= torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but {torch.cuda.device_count()} GPU(s) are visible: one "
+                         f"rank per GPU over RCCL (--backend gloo lets ranks share a GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ   # under torchrun even N=1 goes through RCCL
@@ -839,6 +1013,19 @@ def main():
     lines = [run_mode(args, m, env) for m in modes]
     GRAPH_KEYS = ("value", "unit", "ms_per_step", "config", "roofline", "kernels", "parity_in_run", "parity_golden",
                   "report_sha256")
+    # Strong scaling beside the weak headline (BASELINE.json quotes the metric on "10 GiB cfile, 1/2/4/8 GPU", which reads
+    # either way): the SAME --gib stream cut into `world` shards, every rank --gib / world of it.  Same shard memory, same
+    # context, same exchange; for 10 GiB the report is checked against the reference's recorded stdout of the 10 GiB stream.
+    strong_lines = None
+    if world > 1 and not args.no_strong and not args.two_pass and not args.force_miss:
+        whole = int(args.gib * (1 << 30)) // 8 // 8192 * 8192
+        per_s = whole // world // 8192 * 8192
+        if per_s >= 8192:
+            total_s = per_s * world
+            gpu.adopt(shard.data_ptr(), per_s, base_index=rank * per_s, keepalive=shard)
+            gpu.generate(pkg.SynthSpec.spike(total_s, envelope=args.signal), rank * per_s, per_s)
+            env_s = dict(env, per_gpu=per_s, total=total_s, scaling="strong", golden_world=1 if total_s == whole else 0)
+            strong_lines = [run_mode(args, m, env_s) for m in modes]
     # The plain invocation (what the driver runs) carries every leg in its ONE line: configs[1] as the headline,
     # configs[2] under "graph", the same two tables with the reference's sequential sum reproduced (what bin/papr does
     # by default) under "exact", the transport-stream scan under "ts", the reference's own CPU time for both tables.
@@ -870,6 +1057,22 @@ def main():
         if len(lines) > 1:   # configs[2] rides along: same shard, same code path, the 0.1 dB table
             line["graph"] = {k: lines[1][k] for k in GRAPH_KEYS}
             legs["graph"] = leg_summary(lines[1])
+        if world > 1:
+            # both readings of "1/2/4/8 GPU" in one line: `weak` repeats the headline's numbers, `strong` is the --gib stream
+            # cut into `world` shards.  speedup_vs_n1 is the driver's to compute from its own N=1 run: left null.
+            def scaling_member(ls):
+                m = dict(leg_summary(ls[0]), scaling=ls[0]["scaling"], n_gpus=world,
+                         gib_per_gpu=round(ls[0]["config"]["samples_per_gpu"] * 8 / (1 << 30), 6),
+                         gib_total=round(ls[0]["config"]["samples_total"] * 8 / (1 << 30), 6),
+                         parity_golden=ls[0]["parity_golden"], speedup_vs_n1=None)
+                if len(ls) > 1:
+                    g = leg_summary(ls[1])
+                    m["graph"] = {k: g[k] for k in ("ms_per_step", "value", "kernel_ms", "frac", "parity_in_run")}
+                return m
+            line["weak"] = scaling_member(lines)
+            if strong_lines:
+                line["strong"] = scaling_member(strong_lines)
+                line["strong_full"] = strong_lines
         if exact_lines:
             want_sum = None
             try:
@@ -930,6 +1133,26 @@ def main():
                                           "ingest_GBps": t.get("ingest_GBps"),
                                           "ingest_frac_of_h2d_ceiling": t.get("ingest_frac_of_h2d_ceiling"),
                                           "all_stdout_identical": t.get("all_stdout_identical")}
+        if (world == 1 and not args.no_live_traffic and not args.two_pass and not args.force_miss and not args.exact_two_pass
+                and args.mode == "both" and line["roofline"]["kernel"].startswith("papr_sweep")):
+            # roofline.traffic measured in THIS run (outside the timed region): the constant from profiles/ stays only when
+            # rocprofv3 is not on the box or its pass leaves nothing, and `traffic_source` says which it is
+            t0 = time.perf_counter()
+            lt = live_traffic(args, line["roofline"]["kernel"], per_gpu * 8)
+            if lt:
+                for leg, m in ((line, "default"), (line.get("graph"), "graph")):
+                    if leg:
+                        r = leg["roofline"]
+                        r["traffic_profile_constant"] = r.get("traffic")
+                        r["traffic"], r["traffic_source"], r["traffic_stale"] = lt[m]["traffic"], lt["source"], None
+                        r["traffic_read"], r["traffic_write"] = lt[m]["read"], lt[m]["write"]
+                        r["traffic_over_algorithmic"] = lt[m]["traffic"] / r["algorithmic_bytes_per_launch"]
+                line["roofline"]["traffic_measured_s"] = round(time.perf_counter() - t0, 1)
+                if "graph" in legs:
+                    legs["graph"]["traffic"] = round(lt["graph"]["traffic"])
+            else:
+                line["roofline"]["traffic_source"] = ("NOT measured in this run (no rocprofv3 pass): " +
+                                                      (line["roofline"].get("traffic_source") or "no figure"))[:200]
         if legs:
             line["roofline"]["legs"] = legs
         emit(line, args.full_json, real_stdout)

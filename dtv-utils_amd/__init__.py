@@ -31,7 +31,7 @@ MAX_LEVELS = 16384
 ABI_SYMBOLS = (
     "papr_hip_abi_version", "papr_hip_device_count", "papr_hip_open", "papr_hip_close",
     "papr_hip_last_error", "papr_hip_device_name", "papr_hip_set_tuning", "papr_hip_set_timing",
-    "papr_hip_get_timing", "papr_hip_get_timing_launches", "papr_file_samples", "papr_hip_load_file", "papr_hip_load_stream", "papr_hip_get_ingest_timing", "papr_hip_upload",
+    "papr_hip_get_timing", "papr_hip_get_timing_launches", "papr_file_samples", "papr_hip_load_file", "papr_hip_load_stream", "papr_hip_stream_stats", "papr_exact_chain_continue", "papr_hip_get_ingest_timing", "papr_hip_upload",
     "papr_hip_adopt", "papr_hip_generate", "papr_hip_download", "papr_hip_stats",
     "papr_stats_init", "papr_stats_merge", "papr_levels", "papr_hip_ccdf",
     "papr_hip_set_exact", "papr_hip_exact_program", "papr_hip_ccdf_exact", "papr_exact_chain",
@@ -203,6 +203,10 @@ def lib() -> C.CDLL:
     L.papr_hip_load_file.argtypes = [vp, C.c_char_p, u64, u64]
     L.papr_hip_load_stream.argtypes = [vp, i32, C.POINTER(u64)]
     L.papr_hip_load_stream.restype = i32
+    L.papr_hip_stream_stats.argtypes = [vp, i32, C.POINTER(Stats), C.POINTER(i32), C.POINTER(u64)]
+    L.papr_hip_stream_stats.restype = i32
+    L.papr_exact_chain_continue.argtypes = [C.POINTER(C.c_double), C.POINTER(vp), C.POINTER(C.c_size_t), i32]
+    L.papr_exact_chain_continue.restype = i32
     L.papr_hip_get_ingest_timing.argtypes = [vp, C.POINTER(IngestTiming)]
     L.papr_hip_get_ingest_timing.restype = i32
     L.papr_hip_upload.argtypes = [vp, vp, u64, u64]
@@ -337,6 +341,20 @@ def exact_chain(programs: Sequence[bytes]) -> float:
     return out.value
 
 
+def exact_chain_continue(start: float, programs: Sequence[bytes]) -> float:
+    """papr_exact_chain_continue: the same replay from the accumulator `start` the earlier programs left."""
+    L = lib()
+    n = len(programs)
+    bufs = [C.create_string_buffer(p, len(p)) for p in programs]
+    ptrs = (C.c_void_p * max(n, 1))(*[C.cast(b, C.c_void_p) for b in bufs])
+    sizes = (C.c_size_t * max(n, 1))(*[len(p) for p in programs])
+    acc = C.c_double(start)
+    rc = L.papr_exact_chain_continue(C.byref(acc), ptrs, sizes, n)
+    if rc:
+        raise PaprError(rc, "papr_exact_chain_continue", "malformed program" if rc == -3 else "exact-sum invariant violated")
+    return acc.value
+
+
 def file_samples(path: str) -> int:
     n = C.c_uint64()
     rc = lib().papr_file_samples(os.fsencode(path), C.byref(n))
@@ -436,6 +454,13 @@ class PaprHip:
         n = C.c_uint64(0)
         self._chk(self._L.papr_hip_load_stream(self._ctx, fd, C.byref(n)), "papr_hip_load_stream")
         return int(n.value)
+
+    def stream_stats(self, fd: int):
+        """papr_hip_stream_stats: pass 1 over a pipe / FIFO / socket of any length, window by window; returns
+        (the stream's Stats, whether .sum is the reference's sequential sum, windows reduced)."""
+        st, ex, w = Stats(), i32(0), u64(0)
+        self._chk(self._L.papr_hip_stream_stats(self._ctx, fd, C.byref(st), C.byref(ex), C.byref(w)), "papr_hip_stream_stats")
+        return st, bool(ex.value), int(w.value)
 
     def estimate_file(self, path: str, first_sample: int = 0, nsamples: int = NO_INDEX) -> Stats:
         """papr_hip_estimate for a file range that is not loaded (yet)."""

@@ -8,6 +8,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <memory>
 #include <thread>
 #include <dlfcn.h>
 #include <unistd.h>
@@ -110,9 +111,30 @@ struct LocalHub {
     }
 };
 
+// papr_exchange_open_rccl_local_async: what the n set-up threads and the n handles share.  The threads hold it through a
+// shared_ptr and never touch a handle: one that is still inside ncclCommInitRank when its handle has given up on it (and is
+// closed, or the process leaves) finds its memory alive.
+struct BindShared {
+    std::mutex m;
+    std::condition_variable cv;
+    int world = 0;
+    bool uid_ready = false, failed = false, abandoned = false;
+    ncclUniqueId uid{};
+    char why[200] = "";
+    struct Rank {
+        int device = 0;
+        bool done = false, ok = false, taken = false;
+        ncclComm_t comm = nullptr;
+        double t_begin = 0, t_end = 0;
+    };
+    std::vector<Rank> ranks;
+};
+
 struct papr_exchange {
     int rank = 0, world = 1;
     LocalHub *hub = nullptr;
+    std::shared_ptr<BindShared> bind;  // communicators coming up beside the ingest (papr_exchange_adopt_rccl takes them)
+    std::atomic<int> pins{0};          // papr_exchange_abort is working on this handle outside the hub's mutex: close waits
     char err[256] = "";
     // caller-supplied transport
     papr_exchange_ops ops{};
@@ -127,15 +149,15 @@ struct papr_exchange {
     // mutex, `aborted` checked inside it, so that nothing is ever queued on a communicator ncclCommAbort has freed.  Only
     // the owner's papr_exchange_close sets `comm` to null.
     std::timed_mutex comm_m;
-    bool comm_ended = false;       // ncclCommAbort has run on `comm` (it is freed: papr_exchange_close must not destroy it)
+    std::atomic<bool> comm_ended{false};  // ncclCommAbort has run on `comm` (it is freed: papr_exchange_close must not destroy it)
     char wd_err[256] = "";       // the watchdog's message (its own buffer: `err` belongs to the owner's thread)
     // PAPR_XCH_TIMEOUT_S: since when this rank has been waiting for its peers (0: it is not), and in what
     std::atomic<double> waiting_since{0.0};
-    const char *waiting_in = "";
+    std::atomic<const char *> waiting_in{""};
     double timeout_s = 0;
     std::thread watchdog;
     std::atomic<bool> watchdog_stop{false};
-    bool timed_out = false;
+    std::atomic<bool> timed_out{false};  // (set with release ordering AFTER wd_err is written: whoever sees it may read the text)
     bool selftest_done = false;
     unsigned char *d_send = nullptr, *d_recv = nullptr;  // device staging
     unsigned char *h_send = nullptr, *h_recv = nullptr;  // pinned mirrors
@@ -207,7 +229,7 @@ struct Waiting {
     Waiting(papr_exchange *x_, const char *what) : x(x_)
     {
         if (x && x->timeout_s > 0) {
-            x->waiting_in = what;
+            x->waiting_in.store(what);
             x->waiting_since.store(now_s());
         }
     }
@@ -230,10 +252,10 @@ void watchdog_main(papr_exchange *x)
         const double since = x->waiting_since.load();
         if (since <= 0 || now_s() - since <= x->timeout_s)
             continue;
-        const char *what = x->waiting_in;
+        const char *what = x->waiting_in.load();
         snprintf(x->wd_err, sizeof(x->wd_err), "rank %d of %d waited more than %g s for its peers in %s (PAPR_XCH_TIMEOUT_S): "
                  "the exchange is cancelled", x->rank, x->world, x->timeout_s, what);
-        x->timed_out = true;
+        x->timed_out.store(true, std::memory_order_release);
         fprintf(stderr, "papr exchange: %s\n", x->wd_err);
         fflush(stderr);
         x->waiting_since.store(0.0);
@@ -311,7 +333,7 @@ int allgather_bytes(papr_exchange *x, const void *send, void *recv, size_t bytes
     XHIP(x, hipMemcpyAsync(x->h_recv, x->d_recv, total, hipMemcpyDeviceToHost, ctx->stream));
     XHIP(x, hipStreamSynchronize(ctx->stream));
     if (x->aborted.load())
-        return xfail(x, PAPR_E_STATE, "%s", x->timed_out ? x->wd_err : kCancelled);
+        return xfail(x, PAPR_E_STATE, "%s", x->timed_out.load(std::memory_order_acquire) ? x->wd_err : kCancelled);
     memcpy(recv, x->h_recv, total);
     return PAPR_OK;
 }
@@ -356,7 +378,7 @@ int allreduce_u64(papr_exchange *x, uint64_t *buf, size_t count)
     XHIP(x, hipMemcpyAsync(x->h_recv, x->d_recv, bytes, hipMemcpyDeviceToHost, ctx->stream));
     XHIP(x, hipStreamSynchronize(ctx->stream));
     if (x->aborted.load())
-        return xfail(x, PAPR_E_STATE, "%s", x->timed_out ? x->wd_err : kCancelled);
+        return xfail(x, PAPR_E_STATE, "%s", x->timed_out.load(std::memory_order_acquire) ? x->wd_err : kCancelled);
     memcpy(buf, x->h_recv, bytes);
     return PAPR_OK;
 }
@@ -691,6 +713,182 @@ int papr_exchange_bind(papr_exchange *x, papr_hip_ctx *ctx)
     return PAPR_OK;
 }
 
+// ---- the communicators coming up BESIDE the ingest (bin/papr) ------------------------------------------------------------
+// ncclCommInitRank costs seconds around a step of milliseconds and the first collective is only needed once the shards are
+// loaded: n detached threads (rank 0 first loads librccl and makes the id) select their devices and join the communicator
+// while the shards' own threads open their contexts and ingest.  The handles are papr_exchange_open_local's until
+// papr_exchange_adopt_rccl — host-level exchanges meet at the hub all along — and stay that if RCCL is missing, fails, or is
+// not up in time: a fall-back with one line on stderr, never an error.
+static void bind_thread_main(std::shared_ptr<BindShared> sp, int r)
+{
+    BindShared &b = *sp;
+    auto finish = [&](bool ok, ncclComm_t comm, const char *why) {
+        std::lock_guard<std::mutex> g(b.m);
+        BindShared::Rank &me = b.ranks[(size_t)r];
+        me.done = true;
+        me.ok = ok;
+        me.comm = comm;
+        me.t_end = now_s();
+        if (!ok && !b.failed) {
+            b.failed = true;
+            snprintf(b.why, sizeof(b.why), "%s", why);
+        }
+        if (ok && b.abandoned && comm && rccl() && rccl()->CommAbort) {  // nobody will take it any more
+            (void)rccl()->CommAbort(comm);
+            me.comm = nullptr;
+        }
+        b.cv.notify_all();
+    };
+    {
+        std::lock_guard<std::mutex> g(b.m);
+        b.ranks[(size_t)r].t_begin = now_s();
+    }
+    const char *inject = getenv("PAPR_XCH_BIND_FAIL");  // tests: "all", or the rank that fails
+    const bool injected = inject && inject[0] && (!strcmp(inject, "all") || atoi(inject) == r);
+    const int delay_ms = env_int("PAPR_XCH_BIND_DELAY_MS", 0);  // tests: a set-up that is not ready in time
+    if (delay_ms > 0)
+        usleep((useconds_t)delay_ms * 1000);
+    if (r == 0) {
+        RcclApi *api = injected ? nullptr : rccl();
+        ncclUniqueId uid{};
+        if (!api || api->GetUniqueId(&uid) != ncclSuccess)
+            return finish(false, nullptr, injected ? "an injected failure (PAPR_XCH_BIND_FAIL)" : !api ? "librccl.so could not be loaded" : "ncclGetUniqueId failed");
+        std::lock_guard<std::mutex> g(b.m);
+        b.uid = uid;
+        b.uid_ready = true;
+        b.cv.notify_all();
+    } else {
+        std::unique_lock<std::mutex> lk(b.m);
+        b.cv.wait(lk, [&] { return b.uid_ready || b.failed || b.abandoned; });
+        if (!b.uid_ready) {
+            lk.unlock();
+            return finish(false, nullptr, "another rank's set-up failed");
+        }
+    }
+    if (injected)
+        return finish(false, nullptr, "an injected failure (PAPR_XCH_BIND_FAIL)");
+    if (hipSetDevice(b.ranks[(size_t)r].device) != hipSuccess)
+        return finish(false, nullptr, "hipSetDevice failed in the set-up thread");
+    ncclComm_t comm = nullptr;
+    const ncclResult_t rr = rccl()->CommInitRank(&comm, b.world, b.uid, r);  // (returns when every rank has joined)
+    if (rr != ncclSuccess) {
+        char why[200];
+        snprintf(why, sizeof(why), "ncclCommInitRank(rank %d of %d) failed: %s", r, b.world,
+                 rccl()->GetErrorString ? rccl()->GetErrorString(rr) : "RCCL error");
+        return finish(false, nullptr, why);
+    }
+    finish(true, comm, "");
+}
+
+int papr_exchange_open_rccl_local_async(papr_exchange **xs, int n, const int *devices)
+{
+    if (!xs || n < 1 || !devices)
+        return PAPR_E_ARG;
+    int rc = papr_exchange_open_local(xs, n);
+    if (rc)
+        return rc;
+    // one communicator cannot hold two ranks of one device (PAPR_OVERSUBSCRIBE): such shards meet at the hub
+    std::vector<int> devs(devices, devices + n);
+    std::sort(devs.begin(), devs.end());
+    if (std::adjacent_find(devs.begin(), devs.end()) != devs.end() && !env_int("PAPR_XCH_BIND_SHARED_OK", 0))  // (tests: the
+        return PAPR_OK;                                                           // agreement path on a box with one GPU)
+    try {
+        auto sp = std::make_shared<BindShared>();
+        sp->world = n;
+        sp->ranks.resize((size_t)n);
+        for (int r = 0; r < n; r++)
+            sp->ranks[(size_t)r].device = devices[r];
+        if (n > 1)
+            xs[0]->hub->members.assign(xs, xs + n);  // (papr_exchange_abort ends every member's communicator)
+        for (int r = 0; r < n; r++)
+            xs[r]->bind = sp;
+        for (int r = 0; r < n; r++)
+            std::thread(bind_thread_main, sp, r).detach();
+    } catch (...) {  // no thread / no memory: whatever was started fails alone; the handles stay the hub's
+        for (int r = 0; r < n; r++)
+            if (xs[r]->bind) {
+                std::lock_guard<std::mutex> g(xs[r]->bind->m);
+                xs[r]->bind->failed = true;
+                snprintf(xs[r]->bind->why, sizeof(xs[r]->bind->why), "the set-up threads could not be started");
+                xs[r]->bind->cv.notify_all();
+            }
+    }
+    return PAPR_OK;
+}
+
+int papr_exchange_adopt_rccl(papr_exchange *x, papr_hip_ctx *ctx, double timeout_s, double *setup_s, double *waited_s)
+{
+    if (setup_s)
+        *setup_s = 0.0;
+    if (waited_s)
+        *waited_s = 0.0;
+    if (!x || !ctx)
+        return PAPR_E_ARG;
+    if (!x->bind)
+        return PAPR_OK;  // (nothing is coming up: another transport, shards that share a device, or adopted already)
+    std::shared_ptr<BindShared> sp = x->bind;
+    BindShared &b = *sp;
+    const double t0 = now_s();
+    uint64_t mine = 0;  // 1: this rank's communicator is there
+    char why[200] = "";
+    {
+        std::unique_lock<std::mutex> lk(b.m);
+        BindShared::Rank &me = b.ranks[(size_t)x->rank];
+        auto ready = [&] { return me.done || b.failed; };
+        if (timeout_s > 0)
+            b.cv.wait_for(lk, std::chrono::duration<double>(timeout_s), ready);
+        mine = me.done && me.ok && !b.failed ? 1 : 0;
+        if (b.failed)
+            snprintf(why, sizeof(why), "%s", b.why);
+        else if (!me.done)
+            snprintf(why, sizeof(why), "ncclCommInitRank was not done %s", timeout_s > 0 ? "within PAPR_XCH_BIND_TIMEOUT_S" : "when the shards were loaded");
+        if (setup_s && me.done)
+            *setup_s = me.t_end - me.t_begin;
+    }
+    if (waited_s)
+        *waited_s = now_s() - t0;
+    // every shard's thread is here: RCCL for all of them or for none
+    uint64_t all = mine;
+    if (x->hub) {
+        std::vector<uint64_t> flags((size_t)x->world);
+        int rc = allgather_bytes(x, &mine, flags.data(), sizeof(uint64_t));
+        if (rc)
+            return rc;
+        for (uint64_t f : flags)
+            all &= f;
+    }
+    ncclComm_t comm = nullptr;
+    {
+        std::lock_guard<std::mutex> g(b.m);
+        BindShared::Rank &me = b.ranks[(size_t)x->rank];
+        if (me.done && me.comm && !me.taken) {
+            comm = me.comm;
+            me.taken = true;
+        }
+        if (!all)
+            b.abandoned = true;  // (a communicator that still arrives is ended by the thread that made it)
+        b.cv.notify_all();
+    }
+    x->bind.reset();
+    if (all && comm) {
+        x->comm = comm;
+        x->ctx = ctx;
+        x->use_ops = x->world > 1;  // (a world of one runs its collectives through RCCL: no identity short cut)
+        start_watchdog(x);
+        return PAPR_OK;
+    }
+    if (comm && rccl() && rccl()->CommAbort) {  // (not destroy: that may wait for peers that never joined)
+        (void)hipSetDevice(ctx->device);
+        (void)rccl()->CommAbort(comm);
+    }
+    if (x->rank == 0) {
+        fprintf(stderr, "papr: RCCL set-up did not complete (%s): the shards' results meet at the in-process hub instead\n",
+                why[0] ? why : "another shard's communicator is missing");
+        fflush(stderr);
+    }
+    return PAPR_OK;
+}
+
 int papr_exchange_is_rccl(const papr_exchange *x)
 {
     return x && x->comm ? 1 : 0;
@@ -707,23 +905,44 @@ void papr_exchange_abort(papr_exchange *x)
     auto end_comm = [](papr_exchange *m) {
         m->aborted.store(true);
         const bool got = m->comm_m.try_lock_for(std::chrono::milliseconds(500));
-        if (m->comm && !m->comm_ended && rccl() && rccl()->CommAbort) {
-            m->comm_ended = true;
+        // (`comm` is written by its owner before any collective and by its close; read here without the mutex only when the
+        // owner sits inside an RCCL call and will not touch it)
+        if (m->comm && !m->comm_ended.exchange(true) && rccl() && rccl()->CommAbort)
             (void)rccl()->CommAbort(m->comm);
-        }
         if (got)
             m->comm_m.unlock();
     };
     if (x->hub) {
-        // under the hub's mutex: papr_exchange_close takes it to strike a handle off `members` before the handle is
-        // deleted, so every member seen here stays alive until this returns
-        std::lock_guard<std::mutex> g(x->hub->m);
-        x->hub->failed = true;
-        x->hub->cv.notify_all();
+        // The hub's mutex only for as long as it takes to mark the exchange cancelled and to PIN the members
+        // (papr_exchange_close strikes a handle off `members` under the same mutex and then waits for its pins to go before
+        // it deletes the handle): the communicators are ended outside it — up to 500 ms each when an owner sits inside an
+        // RCCL call — so that peers entering a hub barrier or closing are not held up for that long.
+        std::vector<papr_exchange *> todo;
+        {
+            std::lock_guard<std::mutex> g(x->hub->m);
+            x->hub->failed = true;
+            x->hub->cv.notify_all();
+            try {
+                for (papr_exchange *m : x->hub->members)
+                    if (m) {
+                        todo.push_back(m);
+                        m->pins.fetch_add(1);
+                    }
+            } catch (...) {  // (no memory for the list: end them under the mutex after all)
+                for (papr_exchange *m : todo)
+                    m->pins.fetch_sub(1);
+                todo.clear();
+                for (papr_exchange *m : x->hub->members)
+                    if (m)
+                        end_comm(m);
+                return;
+            }
+        }
         // peers that wait inside (or for) an RCCL collective are released by aborting the communicators
-        for (papr_exchange *m : x->hub->members)
-            if (m)
-                end_comm(m);
+        for (papr_exchange *m : todo) {
+            end_comm(m);
+            m->pins.fetch_sub(1);
+        }
         return;
     }
     end_comm(x);  // (one process per GPU: the peers' collectives fail instead of waiting)
@@ -749,6 +968,12 @@ void papr_exchange_close(papr_exchange *x)
         if (last)
             delete x->hub;
         x->hub = nullptr;
+    }
+    while (x->pins.load() > 0)  // (a papr_exchange_abort that pinned this handle is still ending its communicator)
+        usleep(200);
+    if (x->bind) {  // set-up threads this handle never adopted: a communicator that still arrives is theirs to end
+        std::lock_guard<std::mutex> g(x->bind->m);
+        x->bind->abandoned = true;
     }
     if (x->ctx)
         (void)hipSetDevice(x->ctx->device);
@@ -866,7 +1091,7 @@ int papr_exchange_selftest(papr_exchange *x, papr_hip_ctx *ctx, int verbose)
         }
         const double us = now_us() - t;
         if (e != hipSuccess || x->aborted.load())
-            return bad(what, e != hipSuccess ? hipGetErrorString(e) : (x->timed_out ? x->wd_err : kCancelled));
+            return bad(what, e != hipSuccess ? hipGetErrorString(e) : (x->timed_out.load(std::memory_order_acquire) ? x->wd_err : kCancelled));
         if (hipMemcpy(back.data(), d_r, back_bytes, hipMemcpyDeviceToHost) != hipSuccess)
             return bad(what, "hipMemcpy from the device failed");
         if (!check())

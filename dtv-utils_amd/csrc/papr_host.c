@@ -355,9 +355,23 @@ static void add_raw_tile(double *S, const papr_exact_raw_rec *r)
 
 int papr_exact_chain(const void *const *programs, const size_t *bytes, int nprograms, double *sum_out)
 {
-    if (!programs || !bytes || !sum_out || nprograms < 0)
+    if (!sum_out)
         return PAPR_E_ARG;
     double S = 0.0;
+    const int rc = papr_exact_chain_continue(&S, programs, bytes, nprograms);
+    if (rc == PAPR_OK)
+        *sum_out = S;
+    return rc;
+}
+
+/* the same replay from a running sum the caller carries: a stream reduced window by window (papr_hip_stream_stats) replays each
+ * window's program as soon as it exists, from the accumulator the windows before it left */
+int papr_exact_chain_continue(double *sum_inout, const void *const *programs, const size_t *bytes, int nprograms)
+{
+    double *sum_out = sum_inout;
+    if (!programs || !bytes || !sum_inout || nprograms < 0 || !(*sum_inout >= 0.0))
+        return PAPR_E_ARG;
+    double S = *sum_inout;
     for (int k = 0; k < nprograms; k++) {
         const unsigned char *p = (const unsigned char *)programs[k], *end = p + bytes[k];
         papr_exact_header h;

@@ -861,9 +861,12 @@ static int papr_hip_load_stream_impl(papr_hip_ctx *ctx, int fd, uint64_t *nsampl
             }
         }
         if (dev) {
-            HIPCHK(ctx, hipMemcpyAsync(bigger, dev, total, hipMemcpyDeviceToDevice, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            HIPCHK(ctx, hipFree(dev));
+            if (hipMemcpyAsync(bigger, dev, total, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                (void)hipFree(bigger);
+                return fail(ctx, PAPR_E_HIP, "moving the growing shard failed");
+            }
+            (void)hipFree(dev);
         }
         dev = bigger;
         cap = want;
@@ -872,8 +875,8 @@ static int papr_hip_load_stream_impl(papr_hip_ctx *ctx, int fd, uint64_t *nsampl
     bool eof = false;
     for (uint64_t k = 0; !eof; k++) {
         const int b = (int)(k % (uint64_t)ctx->num_buf);
-        if (done[(size_t)b])
-            HIPCHK(ctx, hipEventSynchronize(done[(size_t)b]));  // (this buffer's last copy has left it)
+        if (done[(size_t)b] && hipEventSynchronize(done[(size_t)b]) != hipSuccess)  // (this buffer's last copy has left it)
+            return cleanup(fail(ctx, PAPR_E_HIP, "hipEventSynchronize failed"));
         unsigned char *host = (unsigned char *)ctx->h_stage[b];
         size_t got = 0;
         const double t_read = now_s();
@@ -899,14 +902,16 @@ static int papr_hip_load_stream_impl(papr_hip_ctx *ctx, int fd, uint64_t *nsampl
             return cleanup(fail(ctx, PAPR_E_HIP, "hipMemcpyAsync of a stream chunk failed"));
         if (!done[(size_t)b] && hipEventCreateWithFlags(&done[(size_t)b], hipEventDisableTiming) != hipSuccess)
             return cleanup(fail(ctx, PAPR_E_HIP, "hipEventCreate failed"));
-        HIPCHK(ctx, hipEventRecord(done[(size_t)b], ctx->stream));
+        if (hipEventRecord(done[(size_t)b], ctx->stream) != hipSuccess)
+            return cleanup(fail(ctx, PAPR_E_HIP, "hipEventRecord failed"));
         total += got;
         ctx->ingest.chunks++;
     }
     int rc = grow(total);  // (an empty stream still gets its slack: the kernels' lane loads stay in bounds)
     if (rc)
         return cleanup(rc);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return cleanup(fail(ctx, PAPR_E_HIP, "hipStreamSynchronize failed"));
     // the reference's sample count and tail (as open_file_src derives them for a file of this length)
     const uint64_t nfloats = total / 4, stray = total % 4;
     const bool odd = (nfloats & 1u) != 0;
@@ -914,11 +919,10 @@ static int papr_hip_load_stream_impl(papr_hip_ctx *ctx, int fd, uint64_t *nsampl
     if (odd) {
         const uint64_t chunk = 16384, nfull = nfloats / chunk, rem = nfloats % chunk;
         unsigned char bytes[4] = {0, 0, 0, 0};
-        if (nfull >= 1)
-            HIPCHK(ctx, hipMemcpy(bytes, dev + ((nfull - 1) * chunk + rem) * 4, 4, hipMemcpyDeviceToHost));
-        if (stray)
-            HIPCHK(ctx, hipMemcpy(bytes, dev + nfloats * 4, stray, hipMemcpyDeviceToHost));
-        HIPCHK(ctx, hipMemcpy(dev + nfloats * 4, bytes, 4, hipMemcpyHostToDevice));
+        if ((nfull >= 1 && hipMemcpy(bytes, dev + ((nfull - 1) * chunk + rem) * 4, 4, hipMemcpyDeviceToHost) != hipSuccess) ||
+            (stray && hipMemcpy(bytes, dev + nfloats * 4, stray, hipMemcpyDeviceToHost) != hipSuccess) ||
+            hipMemcpy(dev + nfloats * 4, bytes, 4, hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup(fail(ctx, PAPR_E_HIP, "building the phantom sample failed"));
     }
     cleanup(PAPR_OK);
     ctx->d_iq = (float *)dev;
@@ -937,6 +941,179 @@ static int papr_hip_load_stream_impl(papr_hip_ctx *ctx, int fd, uint64_t *nsampl
         *nsamples_out = nsamples;
     return PAPR_OK;
 }
+
+// ---- the same stream, of ANY length -----------------------------------------------------------------------------------
+// papr.c:100-129 reads a FIFO of any length in 64 KiB of memory; what it keeps is pass 1's few scalars.  So does this: the
+// stream crosses ONE window of HBM (at most the budget, 256 MiB by default).  A full window is a resident shard for as long
+// as it takes to reduce it — papr_hip_stats, and in exact-sum mode the window's sum program built from the EXACT running
+// sum in front of it (known: the windows are reduced in stream order) and replayed at once (papr_exact_chain_continue),
+// so the sum stays the reference's accumulator bit for bit — then the next bytes land on the same memory.  The 64 KiB in
+// front of the window keep the previous window's last reference chunk: the phantom sample of an odd float count takes its
+// partner from 16384 floats before the stream's end (papr.c:102-103 with the static buffer), wherever a window ended.
+// Pass 2 over such an input counts nothing in the reference (fseeko fails, EOF stays set: papr.c:142-143 / 174-175), so no
+// sample is needed a second time.
+static int papr_hip_stream_stats_impl(papr_hip_ctx *ctx, int fd, papr_stats *total_out, int *exact_out, uint64_t *windows_out)
+{
+    if (!ctx || fd < 0 || !total_out)
+        return PAPR_E_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    memset(&ctx->ingest, 0, sizeof(ctx->ingest));
+    const double t_begin = now_s();
+    HIPCHK(ctx, make_staging(ctx));
+    release_shard(ctx);
+    const size_t slack = (size_t)PAPR_TILE_SAMPLES_MAX * 8, keep = 65536, group = (size_t)2 << 20;
+    if (ctx->hbm_budget < keep + slack + keep)
+        return fail(ctx, PAPR_E_NOMEM, "an HBM budget of %zu bytes holds no window of the stream", ctx->hbm_budget);
+    size_t window = std::min<size_t>((size_t)std::max(1, env_int("PAPR_STREAM_WINDOW_MB", 256)) << 20, ctx->hbm_budget - keep - slack);
+    window = window >= group ? window / group * group : window / keep * keep;  // whole groups of the sum program, or whole chunks
+    unsigned char *buf = nullptr;
+    if (hipMalloc((void **)&buf, keep + window + slack) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, PAPR_E_NOMEM, "hipMalloc(%zu bytes) for the stream's window failed", keep + window + slack);
+    }
+    unsigned char *dev = buf + keep;
+    std::vector<hipEvent_t> done((size_t)ctx->num_buf, nullptr);
+    auto cleanup = [&](int rc) {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (hipEvent_t e : done)
+            if (e)
+                (void)hipEventDestroy(e);
+        ctx->d_iq = nullptr;  // (the window was never the context's to free)
+        release_shard(ctx);
+        (void)hipFree(buf);
+        return rc;
+    };
+    if (hipMemsetAsync(buf, 0, keep, ctx->stream) != hipSuccess)
+        return cleanup(fail(ctx, PAPR_E_HIP, "hipMemsetAsync failed"));
+    papr_stats total;
+    papr_stats_init(&total);
+    double S = 0.0;              // the reference's accumulator after the windows reduced so far
+    bool exact_ok = ctx->exact;  // (until a window's sum is not finite or its program cannot be built: the tree sum stands in)
+    uint64_t base = 0, windows = 0;
+    size_t fill = 0, bytes_total = 0;
+    // one window of `nsamples` samples (the bytes are in HBM): stats, and the exact running sum carried across it
+    auto reduce_window = [&](uint64_t nsamples, bool odd) -> int {
+        ctx->d_iq = (float *)dev;
+        ctx->owns_iq = false;
+        ctx->cap = window / 8;
+        ctx->n = nsamples;
+        ctx->base = base;
+        ctx->loaded = ctx->resident = true;
+        ctx->have_file_stats = false;
+        ctx->exact_valid = ctx->sweep_valid = ctx->exact_swept = ctx->est_groups_valid = ctx->exact_program_launched = false;
+        ctx->shard_flags = odd ? PAPR_FLAG_ODD_TAIL : 0;
+        papr_stats st;
+        int rc = papr_hip_stats(ctx, &st);
+        if (rc)
+            return rc;
+        if (exact_ok && !(std::isfinite(st.sum) && std::isfinite(S)))
+            exact_ok = false;  // (NaN / Inf in the stream: the sum is NaN / Inf whatever the order)
+        if (exact_ok) {
+            const void *prog = nullptr;
+            size_t nbytes = 0;
+            rc = papr_hip_exact_program(ctx, S, base + nsamples, &prog, &nbytes);
+            if (rc == PAPR_OK) {
+                const void *progs[1] = {prog};
+                rc = papr_exact_chain_continue(&S, progs, &nbytes, 1);
+            }
+            if (rc == PAPR_E_HIP || rc == PAPR_E_NOMEM)
+                return rc;
+            if (rc != PAPR_OK)
+                exact_ok = false;  // an invariant of the emulation did not hold (never expected): the parallel sum stands in
+        }
+        if (windows == 0)
+            total = st;
+        else
+            papr_stats_merge(&total, &st);
+        windows++;
+        base += nsamples;
+        return PAPR_OK;
+    };
+    bool eof = false;
+    for (uint64_t k = 0; !eof; k++) {
+        const int b = (int)(k % (uint64_t)ctx->num_buf);
+        if (done[(size_t)b] && hipEventSynchronize(done[(size_t)b]) != hipSuccess)  // (this buffer's last copy has left it)
+            return cleanup(fail(ctx, PAPR_E_HIP, "hipEventSynchronize failed"));
+        unsigned char *host = (unsigned char *)ctx->h_stage[b];
+        size_t got = 0;
+        const double t_read = now_s();
+        while (got < ctx->stage_bytes) {
+            const ssize_t r = read(fd, host + got, ctx->stage_bytes - got);
+            if (r < 0 && errno == EINTR)
+                continue;
+            if (r < 0)
+                return cleanup(fail(ctx, PAPR_E_IO, "read from the stream failed: %s", strerror(errno)));
+            if (r == 0) {
+                eof = true;
+                break;
+            }
+            got += (size_t)r;
+        }
+        ctx->ingest.read_s += now_s() - t_read;
+        for (size_t off = 0; off < got;) {  // (a staging buffer may end one window and begin the next)
+            const size_t part = std::min(got - off, window - fill);
+            if (hipMemcpyAsync(dev + fill, host + off, part, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                return cleanup(fail(ctx, PAPR_E_HIP, "hipMemcpyAsync of a stream chunk failed"));
+            fill += part;
+            off += part;
+            bytes_total += part;
+            if (fill == window) {
+                // a full window in the middle of the stream: whole samples, no tail rule
+                int rc = reduce_window(window / 8, false);
+                if (rc)
+                    return cleanup(rc);
+                if (hipMemcpyAsync(buf, dev + window - keep, keep, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                    return cleanup(fail(ctx, PAPR_E_HIP, "keeping the window's last chunk failed"));
+                fill = 0;
+            }
+        }
+        if (got) {
+            if (!done[(size_t)b] && hipEventCreateWithFlags(&done[(size_t)b], hipEventDisableTiming) != hipSuccess)
+                return cleanup(fail(ctx, PAPR_E_HIP, "hipEventCreate failed"));
+            if (hipEventRecord(done[(size_t)b], ctx->stream) != hipSuccess)
+                return cleanup(fail(ctx, PAPR_E_HIP, "hipEventRecord failed"));
+            ctx->ingest.chunks++;
+        }
+    }
+    // the stream's end: the reference's sample count and tail, from the stream's whole length (windows are multiples of 8
+    // bytes, so the last window's floats have the stream's parity)
+    if (fill || windows == 0) {
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return cleanup(fail(ctx, PAPR_E_HIP, "hipStreamSynchronize failed"));
+        const uint64_t nfloats = bytes_total / 4, stray = bytes_total % 4, lfloats = fill / 4;
+        const bool odd = (nfloats & 1u) != 0;
+        if (odd) {
+            unsigned char bytes[4] = {0, 0, 0, 0};
+            // partner = the stream's float 16384 before its end, if the stream has that many: in the window, or in the chunk kept
+            // in front of it
+            if ((nfloats >= 16384 && hipMemcpy(bytes, dev + (ptrdiff_t)lfloats * 4 - 65536, 4, hipMemcpyDeviceToHost) != hipSuccess) ||
+                (stray && hipMemcpy(bytes, dev + lfloats * 4, stray, hipMemcpyDeviceToHost) != hipSuccess) ||
+                hipMemcpy(dev + lfloats * 4, bytes, 4, hipMemcpyHostToDevice) != hipSuccess)
+                return cleanup(fail(ctx, PAPR_E_HIP, "building the phantom sample failed"));
+        }
+        int rc = reduce_window((lfloats + 1) / 2, odd);
+        if (rc)
+            return cleanup(rc);
+    }
+    if (exact_ok)
+        total.sum = S;
+    *total_out = total;
+    if (exact_out)
+        *exact_out = exact_ok ? 1 : 0;
+    if (windows_out)
+        *windows_out = windows;
+    const double read_s = ctx->ingest.read_s;
+    const uint64_t chunks = ctx->ingest.chunks;
+    cleanup(PAPR_OK);
+    ctx->ingest.read_s = read_s;
+    ctx->ingest.chunks = chunks;
+    ctx->ingest.resident = 0;
+    ctx->ingest.reader_threads = 1;
+    ctx->ingest.file_passes = 1;
+    ctx->ingest.drain_s = now_s() - t_begin - read_s;
+    return PAPR_OK;
+}
+
 
 int papr_hip_get_ingest_timing(const papr_hip_ctx *ctx, papr_hip_ingest_timing *out)
 {
@@ -959,6 +1136,11 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
 int papr_hip_load_stream(papr_hip_ctx *ctx, int fd, uint64_t *nsamples)
 {
     return guarded(ctx, [&] { return papr_hip_load_stream_impl(ctx, fd, nsamples); });
+}
+
+int papr_hip_stream_stats(papr_hip_ctx *ctx, int fd, papr_stats *total, int *exact_sum, uint64_t *windows)
+{
+    return guarded(ctx, [&] { return papr_hip_stream_stats_impl(ctx, fd, total, exact_sum, windows); });
 }
 
 int papr_hip_load_file_sweep(papr_hip_ctx *ctx, const char *path, uint64_t first_sample, uint64_t nsamples,

@@ -372,6 +372,12 @@ int sweep_collect(papr_hip_ctx *ctx, const SweepRun &run)
 // XCD (b + first) mod 8, and `first` is the queue's, not the device's (6 in a plain process, 5 once RCCL has queues of its
 // own: profiles/r05_xcd_skew.txt): asked of an 8-workgroup launch the first time, and from then on read out of every
 // sweep's record.  PAPR_XCD_PARITY=0|1 pins the answer (measurements).
+// REPRODUCIBILITY: the parity is probed from the hardware (it differs between a plain process and one with RCCL's
+// queues beside the step's) and decides which workgroups sit a round out — coverage and every integer result are the same
+// either way, and so is the exact-sum mode's sum (the reference's accumulator, whatever the walk); but the TREE sum
+// (PAPR_EXACT_SUM=0 / papr_hip_set_exact(0)) groups the workgroups' double sums by the walk, so its last bits can differ
+// between two runs of the same input that probed different parities.  PAPR_XCD_PARITY=0|1 pins the parity — and with it
+// the tree sum, bit for bit — at the cost of the skew sitting on the wrong XCDs half of the time (+2 % kernel time).
 static bool xcd_even_slow(papr_hip_ctx *ctx)
 {
     static const int pinned = env_int("PAPR_XCD_PARITY", -1);

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -103,10 +104,29 @@ struct ts_line_pool {
         }
         return n >= 2;
     }
+    // How many CPUs the CALLER may run on (taskset / numactl / a launcher's binding): the pool never has more threads than that.
+    static int allowed_cpus()
+    {
+        cpu_set_t mine;
+        if (sched_getaffinity(0, sizeof(mine), &mine) != 0)
+            return 0;
+        return CPU_COUNT(&mine);
+    }
     bool start(int nworkers)
     {
-        cpu_set_t near;
-        const bool pin = !(getenv("TS_HOST_PIN") && atoi(getenv("TS_HOST_PIN")) == 0) && l3_siblings(&near);
+        cpu_set_t near, mine;
+        bool pin = !(getenv("TS_HOST_PIN") && atoi(getenv("TS_HOST_PIN")) == 0) && l3_siblings(&near);
+        // ... inside the caller's own affinity mask only: a CPU binding the user (or a launcher) chose is never widened, and
+        // with fewer than two CPUs left in the intersection the workers are not pinned at all
+        if (pin && sched_getaffinity(0, sizeof(mine), &mine) == 0) {
+            CPU_AND(&near, &near, &mine);
+            pin = CPU_COUNT(&near) >= 2;
+        } else {
+            pin = false;
+        }
+        const int allowed = allowed_cpus();
+        if (allowed > 0)
+            nworkers = std::min(nworkers, std::max(0, allowed - 1));
         try {
             for (int k = 0; k < nworkers; k++)
                 workers.emplace_back([this, pin, near] {

@@ -62,6 +62,10 @@ def _lib():
         L.papr_exchange_open_rccl_local.restype = i32
         L.papr_exchange_bind.argtypes = [vp, vp]
         L.papr_exchange_bind.restype = i32
+        L.papr_exchange_open_rccl_local_async.argtypes = [C.POINTER(vp), i32, C.POINTER(i32)]
+        L.papr_exchange_open_rccl_local_async.restype = i32
+        L.papr_exchange_adopt_rccl.argtypes = [vp, vp, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.papr_exchange_adopt_rccl.restype = i32
         L.papr_exchange_is_rccl.argtypes = [vp]
         L.papr_exchange_is_rccl.restype = i32
         L.papr_exchange_abort.argtypes = [vp]
@@ -86,7 +90,8 @@ def _lib():
 ABI_SYMBOLS = ("papr_exchange_unique_id", "papr_exchange_open_rccl", "papr_exchange_open_ops", "papr_exchange_close",
                "papr_exchange_last_error", "papr_exchange_stats", "papr_exchange_counts", "papr_exchange_exact_sum",
                "papr_exchange_get_timing", "papr_exchange_open_local", "papr_exchange_abort",
-               "papr_exchange_open_rccl_local", "papr_exchange_bind", "papr_exchange_is_rccl", "papr_exchange_selftest")
+               "papr_exchange_open_rccl_local", "papr_exchange_bind",
+               "papr_exchange_open_rccl_local_async", "papr_exchange_adopt_rccl", "papr_exchange_is_rccl", "papr_exchange_selftest")
 
 
 class Exchange:
@@ -129,6 +134,26 @@ class Exchange:
         if rc:
             raise PaprError(rc, "papr_exchange_open_rccl_local", L.papr_exchange_last_error(None).decode())
         return [cls(C.c_void_p(xs[r]), r, n, "threads+RCCL") for r in range(n)]
+
+    @classmethod
+    def rccl_local_async(cls, devices) -> List["Exchange"]:
+        """papr_exchange_open_rccl_local_async: hub handles at once, the communicators coming up in threads of their own;
+        adopt(gpu, timeout_s) later takes them — or leaves the handles the hub's."""
+        L = _lib()
+        n = len(devices)
+        xs = (C.c_void_p * n)()
+        rc = L.papr_exchange_open_rccl_local_async(xs, n, (C.c_int * n)(*devices))
+        if rc:
+            raise PaprError(rc, "papr_exchange_open_rccl_local_async", L.papr_exchange_last_error(None).decode())
+        return [cls(C.c_void_p(xs[r]), r, n, "threads(+RCCL when it is up)") for r in range(n)]
+
+    def adopt(self, gpu, timeout_s: float = 30.0):
+        """papr_exchange_adopt_rccl: (set-up seconds of this rank's thread, seconds this call waited)."""
+        setup, waited = C.c_double(), C.c_double()
+        self._chk(self._L.papr_exchange_adopt_rccl(self._x, gpu._ctx, timeout_s, C.byref(setup), C.byref(waited)),
+                  "papr_exchange_adopt_rccl")
+        self._keep = gpu
+        return setup.value, waited.value
 
     def bind(self, gpu):
         """papr_exchange_bind: ncclCommInitRank on gpu's device (all ranks at once); no-op for the other transports."""

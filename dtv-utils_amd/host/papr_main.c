@@ -57,6 +57,8 @@ typedef struct shard {
     int stream_fd;        /* >= 0: the input cannot be positioned (a FIFO, a pipe): read once from this descriptor */
     const char *path;
     uint64_t first, count;
+    double bind_timeout_s, xch_setup_s, xch_waited_s; /* RCCL set-up beside the ingest: how long it may be waited for; what it took */
+    uint64_t stream_windows; /* stream_fd >= 0: windows of HBM the stream crossed (papr_hip_stream_stats) */
     float *levels;        /* PAPR_HIP_MAX_LEVELS each */
     uint64_t *counts;
     papr_result res;
@@ -99,13 +101,6 @@ static void *shard_thread(void *arg)
         return NULL;
     }
     papr_hip_set_exact(s->ctx, s->exact);
-    rc = papr_exchange_bind(s->xch, s->ctx); /* RCCL transport: ncclCommInitRank, every shard's thread at once */
-    if (rc != PAPR_OK) {
-        s->rc = rc;
-        snprintf(s->err, sizeof(s->err), "exchange: %s (code %d)", papr_exchange_last_error(s->xch), rc);
-        papr_exchange_abort(s->xch);
-        return NULL;
-    }
     s->t_open = now_s();
     if (s->ingest_sweep == 1 && s->stream_fd < 0) {
         /* "when the file is streamed": does any shard exceed its GPU's HBM budget?  (decided together: every thread
@@ -119,7 +114,25 @@ static void *shard_thread(void *arg)
         s->ingest_sweep = nofit > 0 ? 2 : 0;
     }
     if (s->stream_fd >= 0) {
-        rc = papr_hip_load_stream(s->ctx, s->stream_fd, &s->count);
+        /* an input that cannot be rewound, of any length (papr.c:100-129 reads it in 64 KiB of memory): pass 1 over windows
+         * of HBM, the sequential sum carried exactly from window to window; the reference's pass 2 finds such a stream at its
+         * end and counts nothing (papr.c:142-143 / 174-175), so nothing is kept */
+        rc = papr_hip_stream_stats(s->ctx, s->stream_fd, &s->res.total, &s->res.exact_sum, &s->stream_windows);
+        if (rc != PAPR_OK) {
+            shard_fail(s, rc, "ingest");
+            return NULL;
+        }
+        s->count = s->res.total.n;
+        papr_hip_get_ingest_timing(s->ctx, &s->ingest);
+        s->t_loaded = now_s();
+        s->res.nlevels = papr_levels(&s->res.total, s->graph, &s->res.mean, &s->res.papr, s->levels, PAPR_HIP_MAX_LEVELS);
+        if (s->res.nlevels > PAPR_HIP_MAX_LEVELS) {
+            s->rc = PAPR_E_LIMIT;
+            snprintf(s->err, sizeof(s->err), "analysis: %d levels exceed the table (code %d)", s->res.nlevels, PAPR_E_LIMIT);
+            return NULL;
+        }
+        s->t_done = now_s();
+        return NULL;
     } else if (s->ingest_sweep) {
         /* one read of the FILE for both passes: a 1-in-64 sample of every shard gives the mean to ~1e-4, the level
          * table it implies is widened into bands, and pass 2 rides along with pass 1 on the ingest */
@@ -149,6 +162,16 @@ static void *shard_thread(void *arg)
     }
     papr_hip_get_ingest_timing(s->ctx, &s->ingest);
     s->t_loaded = now_s();
+    /* The RCCL communicators have been coming up in threads of their own since main() (ncclCommInitRank is seconds around a
+     * step of milliseconds; every exchange up to here met at the in-process hub): take them now, all shards or none —
+     * librccl missing, a failed or unfinished set-up is one line on stderr and the hub, never an error */
+    rc = papr_exchange_adopt_rccl(s->xch, s->ctx, s->bind_timeout_s, &s->xch_setup_s, &s->xch_waited_s);
+    if (rc != PAPR_OK) {
+        s->rc = rc;
+        snprintf(s->err, sizeof(s->err), "exchange: %s (code %d)", papr_exchange_last_error(s->xch), rc);
+        papr_exchange_abort(s->xch);
+        return NULL;
+    }
     rc = papr_hip_analyze(s->ctx, s->xch, s->graph, 0, &s->res, s->levels, s->counts, PAPR_HIP_MAX_LEVELS);
     if (rc != PAPR_OK) {
         shard_fail(s, rc, "analysis");
@@ -274,18 +297,22 @@ int main(int argc, char **argv)
      * there is more than one GPU — or when asked to; otherwise, or when librccl cannot be loaded, at the in-process hub */
     env = getenv("PAPR_XCH");
     const int rccl_forced = env && strcmp(env, "rccl") == 0;
-    const int rccl_wanted = rccl_forced || (ngpu > 1 && !(env && strcmp(env, "threads") == 0));
-    int xrc = rccl_wanted ? papr_exchange_open_rccl_local(xs, ngpu) : PAPR_E_STATE;
-    if (rccl_forced && xrc != PAPR_OK) {
-        fprintf(stderr, "papr: PAPR_XCH=rccl: %s\n", papr_exchange_last_error(NULL));
-        return 253;
-    }
-    if (xrc != PAPR_OK && papr_exchange_open_local(xs, ngpu) != PAPR_OK) {
+    const int rccl_auto = env && strcmp(env, "auto") == 0; /* RCCL only if it is up when the shards are loaded: no wait at all */
+    const int rccl_wanted = (rccl_forced || (ngpu > 1 && !(env && strcmp(env, "threads") == 0))) && stream_fd < 0;
+    int devices[MAX_GPUS];
+    for (int g = 0; g < ngpu; g++)
+        devices[g] = sh[g].device;
+    /* (the set-up threads start here: librccl, the id and ncclCommInitRank run beside papr_hip_open and the ingest) */
+    const int xrc = rccl_wanted ? papr_exchange_open_rccl_local_async(xs, ngpu, devices) : papr_exchange_open_local(xs, ngpu);
+    if (xrc != PAPR_OK) {
         fprintf(stderr, "papr: out of memory\n");
         return 253;
     }
+    env = getenv("PAPR_XCH_BIND_TIMEOUT_S");
+    const double bind_timeout_s = rccl_auto ? 0.0 : (env && atof(env) > 0 ? atof(env) : 30.0);
     for (int g = 0; g < ngpu; g++) {
         sh[g].xch = xs[g];
+        sh[g].bind_timeout_s = bind_timeout_s;
         sh[g].ingest_sweep = one_sweep;
         sh[g].levels = (float *)malloc(PAPR_HIP_MAX_LEVELS * sizeof(float));
         sh[g].counts = (uint64_t *)calloc(PAPR_HIP_MAX_LEVELS, sizeof(uint64_t));
@@ -298,7 +325,7 @@ int main(int argc, char **argv)
     /* stdout carries the reference's text and nothing else: RCCL prints a version banner there when a communicator is
      * created, so while the shards work (nothing of ours is printed before they are done) fd 1 points at /dev/null */
     int saved_stdout = -1;
-    if (xrc == PAPR_OK) {
+    if (rccl_wanted) {
         fflush(stdout);
         saved_stdout = dup(1);
         const int nul = open("/dev/null", O_WRONLY);
@@ -328,10 +355,16 @@ int main(int argc, char **argv)
     shard_thread(&sh[0]);
     for (int g = 1; g < ngpu; g++)
         pthread_join(th[g], NULL);
+    /* (fd 1 stays on /dev/null: a set-up thread that was not waited for may still be inside RCCL; the report goes out through
+     * the descriptor that was saved) */
+    FILE *out = stdout;
     if (saved_stdout >= 0) {
         fflush(stdout);
-        dup2(saved_stdout, 1);
-        close(saved_stdout);
+        out = fdopen(saved_stdout, "w");
+        if (!out) {
+            dup2(saved_stdout, 1);
+            out = stdout;
+        }
     }
     for (int g = 0; g < ngpu; g++)
         if (sh[g].rc != PAPR_OK && sh[g].rc != PAPR_E_STATE) { /* (E_STATE: cancelled because another shard failed) */
@@ -365,23 +398,23 @@ int main(int argc, char **argv)
     /* ---- output, byte for byte the reference's (papr.c:132-135,154-161 / 186-190) ---- */
     const long long offset = (long long)total.n;
     if (!graph) {
-        printf("Peak magnitude = %f\n", sqrt(total.peak));
-        printf("average power = %lf, peak power = %f @ %lld\n\n", mean, total.peak, (long long)total.peak_idx * 8);
-        printf("Maximum PAPR = %f\n", papr);
+        fprintf(out, "Peak magnitude = %f\n", sqrt(total.peak));
+        fprintf(out, "average power = %lf, peak power = %f @ %lld\n\n", mean, total.peak, (long long)total.peak_idx * 8);
+        fprintf(out, "Maximum PAPR = %f\n", papr);
         for (int j = 0; j < nlevels; j++)
-            printf("percentage above %d dB = %0.8f\n", j, ((float)(long long)count[j] / (float)offset) * 100.0);
-        printf("\n");
-        printf("peak real positive = %f, peak imaginary positive = %f\n", total.re_pos, total.im_pos);
-        printf("peak real negative = %f, peak imaginary negative = %f\n\n", total.re_neg, total.im_neg);
-        printf("peak real positive @ %lld, peak imaginary positive @ %lld\n", (long long)total.re_pos_idx * 8,
+            fprintf(out, "percentage above %d dB = %0.8f\n", j, ((float)(long long)count[j] / (float)offset) * 100.0);
+        fprintf(out, "\n");
+        fprintf(out, "peak real positive = %f, peak imaginary positive = %f\n", total.re_pos, total.im_pos);
+        fprintf(out, "peak real negative = %f, peak imaginary negative = %f\n\n", total.re_neg, total.im_neg);
+        fprintf(out, "peak real positive @ %lld, peak imaginary positive @ %lld\n", (long long)total.re_pos_idx * 8,
                ((long long)total.im_pos_idx * 8) + 1);
-        printf("peak real negative @ %lld, peak imaginary negative @ %lld\n", (long long)total.re_neg_idx * 8,
+        fprintf(out, "peak real negative @ %lld, peak imaginary negative @ %lld\n", (long long)total.re_neg_idx * 8,
                ((long long)total.im_neg_idx * 8) + 1);
     } else {
         for (int j = 0; j < nlevels; j++)
-            printf("%0.8f\n", ((float)(long long)count[j] / (float)offset) * 100.0);
+            fprintf(out, "%0.8f\n", ((float)(long long)count[j] / (float)offset) * 100.0);
     }
-    fflush(stdout);
+    fflush(out);
 
     env = getenv("PAPR_STATS");
     if (env && atoi(env) > 0) {
@@ -394,16 +427,22 @@ int main(int argc, char **argv)
             if (sh[g].t_open > t_open) t_open = sh[g].t_open;
             if (sh[g].t_loaded > t_loaded) t_loaded = sh[g].t_loaded;
         }
+        double xch_setup_s = 0.0, xch_waited_s = 0.0; /* the slowest shard's RCCL set-up, the longest wait for one */
+        for (int g = 0; g < ngpu; g++) {
+            if (sh[g].xch_setup_s > xch_setup_s) xch_setup_s = sh[g].xch_setup_s;
+            if (sh[g].xch_waited_s > xch_waited_s) xch_waited_s = sh[g].xch_waited_s;
+        }
         const papr_hip_ingest_timing *it = &sh[0].ingest;
         fprintf(stderr,
                 "{\"samples\": %llu, \"bytes\": %llu, \"gpus\": %d, \"exchange\": \"%s\", \"levels\": %d, \"open_s\": %.6f, "
-                "\"shards_swept\": %d, \"shards_resolved_from_sweep\": %d, "
+                "\"shards_swept\": %d, \"shards_resolved_from_sweep\": %d, \"stream_windows\": %llu, \"exchange_setup_s\": %.6f, \"exchange_wait_s\": %.6f, "
                 "\"ingest_pass1_s\": %.6f, \"exact_sum\": %d, \"exact_redo_tiles\": %u, \"analysis_s\": %.6f, \"total_s\": %.6f, "
                 "\"msamples_per_s\": %.3f, \"ingest_GBps\": %.2f, \"gpu0_ingest\": {\"setup_s\": %.4f, \"read_s\": %.4f, "
                 "\"buffer_wait_s\": %.4f, \"issue_s\": %.4f, \"drain_s\": %.4f, \"chunks\": %llu, \"reader_threads\": %d, "
                 "\"resident\": %d, \"o_direct\": %d, \"numa_bound\": %d, \"io_uring\": %d, \"file_passes\": %d}}\n",
                 (unsigned long long)nsamples, (unsigned long long)nsamples * 8, ngpu,
                 papr_exchange_is_rccl(xs[0]) ? "rccl" : (ngpu > 1 ? "threads" : "none"), nlevels, t_open - t0, swept, resolved,
+                (unsigned long long)sh[0].stream_windows, xch_setup_s, xch_waited_s,
                 t_loaded - t_open, r->exact_sum, r->exact_redo_tiles, t2 - t_loaded, t3 - t0, (double)nsamples / (t3 - t0) / 1e6,
                 (double)nsamples * 8 / (t_loaded - t_open) / 1e9, it->setup_s, it->read_s, it->buffer_wait_s, it->issue_s,
                 it->drain_s, (unsigned long long)it->chunks, it->reader_threads, it->resident, it->o_direct, it->numa_bound, it->io_uring, it->file_passes);

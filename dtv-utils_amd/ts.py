@@ -6,6 +6,7 @@ HIP library or a GPU the calls raise.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -49,9 +50,9 @@ class ScanResult(C.Structure):
     def _complete(self):
         if self._src is None:
             return
-        gpu, scan_id = self._src
+        gpu, scan_id = self._src[0](), self._src[1]
         self._src = None
-        if gpu._scan_id != scan_id or not gpu._ctx:
+        if gpu is None or gpu._scan_id != scan_id or not gpu._ctx:
             raise PaprError(-6, "ts_hip_get_sync_errors", "the complete lists are the context's LAST scan's: this result is older")
         n, nd = int(self.nsync_errors), int(self.ndiscontinuities)
         if n > MAX_SYNC_ERRORS:
@@ -202,9 +203,19 @@ class TsHip:
             raise PaprError(rc, "ts_hip_open", detail)
         self._keepalive = None
         self._scan_id = 0
+        self._last_lazy = None
+
+    def _settle_last_result(self):
+        """The complete lists of a result are the context's until its next scan: a result somebody still holds gets them now
+        (a result nobody holds any more costs nothing)."""
+        last = self._last_lazy() if self._last_lazy is not None else None
+        self._last_lazy = None
+        if last is not None and last._src is not None:
+            last._complete()
 
     def close(self):
         if self._ctx:
+            self._settle_last_result()
             self._L.ts_hip_close(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -249,6 +260,7 @@ class TsHip:
         return out.tobytes()
 
     def scan(self, hdmv: bool = False) -> ScanResult:
+        self._settle_last_result()
         res = ScanResult()
         self._chk(self._L.ts_hip_scan(self._ctx, int(hdmv), C.byref(res)), "ts_hip_scan")
         self._scan_id += 1
@@ -256,5 +268,6 @@ class TsHip:
             # the result holds the first 4096 of either inline; the reference prints every one: the rest on demand
             assert int(self._L.ts_hip_sync_error_count(self._ctx)) == int(res.nsync_errors)
             assert int(self._L.ts_hip_discontinuity_count(self._ctx)) == int(res.ndiscontinuities)
-            res._src = (self, self._scan_id)
+            res._src = (weakref.ref(self), self._scan_id)
+            self._last_lazy = weakref.ref(res)
         return res

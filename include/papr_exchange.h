@@ -55,6 +55,20 @@ int papr_exchange_open_local(papr_exchange **xs, int n);
  * papr_exchange_bind is a no-op for handles of the other transports; papr_exchange_is_rccl tells what a handle became. */
 int papr_exchange_open_rccl_local(papr_exchange **xs, int n);
 int papr_exchange_bind(papr_exchange *x, papr_hip_ctx *ctx);
+/* The same with the communicators coming up BESIDE the ingest — what bin/papr does: ncclCommInitRank costs seconds around a
+ * step of milliseconds, and the first collective is only needed when the shards are loaded.  _open_rccl_local_async returns
+ * at once with n handles that are papr_exchange_open_local's (host-level exchanges meet at the hub from the start) and has
+ * started n threads that load librccl, select devices[r] and join the communicator; it does not fail for want of RCCL.
+ * Every shard's thread later calls papr_exchange_adopt_rccl(x, ctx, ...) — all n at the same point of their sequence: it
+ * waits up to timeout_s (0: not at all) for this rank's communicator, the threads agree through the hub, and either ALL
+ * handles take their communicators (papr_exchange_is_rccl: the step's exchanges are collectives on the contexts' streams
+ * from then on) or none does — librccl missing, a failed or slow ncclCommInitRank: rank 0 says why in one line on stderr
+ * and the handles stay the hub's.  Always PAPR_OK unless the hub itself was cancelled.  *setup_s: how long this rank's
+ * set-up thread ran (0 if it is not done), *waited_s: how long this call waited for it.  Shards that share a device:
+ * no threads are started, adopt is a no-op.  (Tests: PAPR_XCH_BIND_FAIL=all|<rank> injects a failure,
+ * PAPR_XCH_BIND_DELAY_MS a slow set-up.) */
+int papr_exchange_open_rccl_local_async(papr_exchange **xs, int n, const int *devices);
+int papr_exchange_adopt_rccl(papr_exchange *x, papr_hip_ctx *ctx, double timeout_s, double *setup_s, double *waited_s);
 int papr_exchange_is_rccl(const papr_exchange *x);
 /* A rank that cannot go on cancels the exchange so that its peers are released instead of waiting for it: the threads of
  * the in-process transports get PAPR_E_STATE from their pending and future exchange calls, and RCCL communicators — this

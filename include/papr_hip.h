@@ -41,9 +41,10 @@
 extern "C" {
 #endif
 
-/* 5: ts_scan_result grew (continuity-counter lines), ts_format_report_all took two more arguments, the sum programs are
+/* 6: papr_hip_stream_stats, papr_exact_chain_continue, papr_exchange_open_rccl_local_async / _adopt_rccl were added (nothing changed shape).
+ * 5: ts_scan_result grew (continuity-counter lines), ts_format_report_all took two more arguments, the sum programs are
  * version 3, papr_exchange_selftest / ts_hip_result_size were added: a caller built against version 4 must be rebuilt */
-#define PAPR_HIP_ABI_VERSION 5
+#define PAPR_HIP_ABI_VERSION 6
 
 enum {
     PAPR_OK = 0,
@@ -105,10 +106,20 @@ int papr_hip_load_file(papr_hip_ctx *ctx, const char *path, uint64_t first_sampl
  * any file (papr.c:62, 93, 100-101) — read ONCE from the open descriptor `fd` to its end into this context's shard, which
  * grows in HBM as the bytes arrive (one reader, pinned staging, the copies overlapped with the reads); the sample count
  * and the odd-float / stray-byte tail follow from the length as for a file.  *nsamples receives the count (may be NULL).
- * A stream longer than the HBM budget is PAPR_E_NOMEM (it cannot be read a second time).  What the reference makes of
+ * A stream longer than the HBM budget is PAPR_E_NOMEM here (the shard has to stay resident for further passes; pass 1 alone
+ * of a stream of any length: papr_hip_stream_stats).  What the reference makes of
  * such an input in pass 2 — fseeko fails, EOF stays set, every level counts zero (papr.c:142-143 / 174-175) — is the
  * caller's to reproduce: bin/papr prints zero counts. */
 int papr_hip_load_stream(papr_hip_ctx *ctx, int fd, uint64_t *nsamples);
+/* Pass 1 (papr.c:100-129) over such a stream of ANY length: the reference reads a FIFO in 64 KiB of memory and keeps a
+ * handful of scalars, and pass 2 counts nothing for an input it cannot rewind (papr.c:142-143 / 174-175) — no sample is needed
+ * twice.  The stream crosses ONE window of HBM (min(budget, PAPR_STREAM_WINDOW_MB = 256 MiB)); every full window is reduced as a
+ * resident shard — papr_hip_stats and, in exact-sum mode (papr_hip_set_exact), the window's sum program built from the exact
+ * accumulator in front of it and replayed at once — and overwritten by the bytes that follow.  *total = the whole stream's
+ * pass-1 record (indices global; n includes the phantom sample), *exact_sum = 1 if total->sum is the reference's accumulator
+ * bit for bit (0: the parallel sum — exact mode off, or the stream holds NaN / Inf, for which every order gives the same
+ * non-finite sum), *windows = how many windows were reduced.  The context holds no shard afterwards. */
+int papr_hip_stream_stats(papr_hip_ctx *ctx, int fd, papr_stats *total, int *exact_sum, uint64_t *windows);
 /* 1 if a shard of nsamples would be kept resident in HBM by papr_hip_load_file (it fits the context's HBM
  * budget: 90 % of the free memory at open, or PAPR_HBM_BUDGET_MB), 0 if it would be re-streamed from the file
  * for every further pass. */
@@ -156,6 +167,9 @@ int papr_hip_exact_program(papr_hip_ctx *ctx, double before, uint64_t n_total, c
 int papr_hip_ccdf_exact(papr_hip_ctx *ctx, const float *levels, int nlevels, uint64_t *counts_above, double before,
                         uint64_t n_total, const void **program, size_t *bytes);
 int papr_exact_chain(const void *const *programs, const size_t *bytes, int nprograms, double *sum_out);
+/* The same replay continued from *sum_inout (the accumulator every earlier program left; 0.0 in front of the first): on
+ * PAPR_OK *sum_inout is the accumulator behind the last program given, otherwise it is unchanged. */
+int papr_exact_chain_continue(double *sum_inout, const void *const *programs, const size_t *bytes, int nprograms);
 
 /* ---- one-sweep mode: pass 1 and pass 2 in ONE read of the shard ----------------------
  * papr.c reads the file twice because its thresholds are mean * 10^(dB/10) (papr.c:131-141)

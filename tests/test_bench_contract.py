@@ -248,3 +248,47 @@ def test_two_rank_bench_line_proves_itself_at_full_size(extra, tmp_path):
     assert d["graph"]["parity_in_run"] is True and d["graph"]["parity_golden"] == "big_spike20g.graph.txt"
     if extra:
         assert d["config"]["sum_hex"] == "0x1.aaaa011478022p+31" and d["config"]["exact_sequential_sum"]
+
+
+def test_gpus_n_without_a_launcher_runs_n_ranks_by_itself(tmp_path):
+    """`python3 bench.py --gpus 2 --backend gloo --steps 3 --warmup 1` verbatim — no torchrun around it: bench.py is its own
+    launcher (one rank per GPU; here two ranks share the one GPU over gloo), rank 0 prints the ONE line, and that line
+    carries both readings of BASELINE's "10 GiB cfile, 1/2/4/8 GPU": `weak` (every rank its own 10 GiB: the headline) and
+    `strong` (the 10 GiB stream cut into two shards), each checked against the reference's recorded stdout."""
+    d, full = run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3",
+                         "--warmup", "1"], tmp_path)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["samples_total"] == 2 * 1342177280 and d["parity_in_run"] is True
+    assert d["parity_golden"] == "big_spike20g.default.txt" and d["cpu_baseline"]["value"] > 0
+    w, s = d["weak"], d["strong"]
+    assert w["scaling"] == "weak" and w["n_gpus"] == 2 and w["gib_per_gpu"] == 10 and w["gib_total"] == 20
+    assert w["ms_per_step"] == round(d["ms_per_step"], 4) and w["frac"] == round(d["roofline"]["frac"], 4)
+    assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["gib_per_gpu"] == 5 and s["gib_total"] == 10
+    for m in (w, s):
+        assert m["speedup_vs_n1"] is None and m["ms_per_step"] > 0 and 0 < m["frac"] < 1 and m["parity_in_run"] is True
+        assert m["graph"]["parity_in_run"] is True and m["graph"]["ms_per_step"] > 0
+    assert s["parity_golden"] == "big_spike10g.default.txt"
+    # (two ranks on one GPU take turns: the strong member's step covers the same 10 GiB a 1-GPU step does)
+    assert full["strong_full"][0]["config"]["samples_total"] == 1342177280 and full["strong_full"][0]["scaling"] == "strong"
+
+
+def test_gpus_n_over_rccl_with_fewer_gpus_is_refused_at_once():
+    """The same command over RCCL (the default backend) needs one GPU per rank: with fewer visible it says so in one
+    stderr line and exits non-zero before a single rank is started — no hang, nothing on stdout."""
+    import time
+    import torch
+    n = torch.cuda.device_count() + 1
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=120)
+    dt = time.perf_counter() - t0
+    assert p.returncode not in (0, None) and p.stdout.strip() == ""
+    lines = [l for l in p.stderr.splitlines() if l.startswith("bench.py:")]
+    assert len(lines) == 1 and f"--gpus {n}" in lines[0] and "visible" in lines[0], p.stderr[-500:]
+    assert dt < 10.0, dt
+    # ... and under a launcher that started the ranks anyway, the rank without a GPU of its own says so
+    env = dict(os.environ, WORLD_SIZE=str(n), RANK=str(n - 1), LOCAL_RANK=str(n - 1), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=120)
+    assert p.returncode != 0 and "GPU(s) are visible" in p.stderr and p.stdout.strip() == ""

@@ -137,6 +137,24 @@ def test_chain_replays_the_sequential_sum(pkg, orc, case):
         assert pkg.exact_chain([build_program(a)[0], build_program(b, before)[0]]) == want
 
 
+def test_chain_continued_window_by_window(pkg, orc):
+    """papr_exact_chain_continue (what papr_hip_stream_stats does for a stream that crosses one window of HBM many times):
+    every window's program is built from the EXACT accumulator in front of it and replayed at once; the accumulator behind
+    the last window is the oracle's sequential sum of the whole stream, whatever the windows' size."""
+    rng = np.random.default_rng(5)
+    n = 5 * GROUP * TILE // 4 + 333
+    iq = (rng.standard_normal(2 * n) * np.exp2(np.repeat(np.linspace(-6, 4, n), 2))).astype(np.float32)
+    want = orc.run_mem(iq, False)["sum"]
+    for window in (8192, 8192 * 5, GROUP * TILE):
+        S = 0.0
+        for first in range(0, n, window):
+            S = pkg.exact_chain_continue(S, [build_program(iq[2 * first:2 * min(n, first + window)], S)[0]])
+        assert S == want, window
+    assert pkg.exact_chain_continue(want, []) == want
+    with pytest.raises(pkg.PaprError):
+        pkg.exact_chain_continue(float("nan"), [])
+
+
 def test_chain_rejects_malformed_programs(pkg):
     rng = np.random.default_rng(1)
     iq = rng.standard_normal(2 * 100000).astype(np.float32)   # 48 tiles: one group, the later tiles safe

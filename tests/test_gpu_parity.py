@@ -102,6 +102,46 @@ def test_cli_over_rccl_reproduces_reference_stdout(pkg, manifest, exact):
         assert stats["exchange"] == "rccl" and stats["gpus"] == 1
 
 
+@pytest.mark.parametrize("env,why", [
+    (dict(PAPR_GPUS="1", PAPR_XCH="rccl", PAPR_XCH_BIND_FAIL="all"), "an injected failure"),
+    (dict(PAPR_GPUS="1", PAPR_XCH="auto", PAPR_XCH_BIND_DELAY_MS="4000"), "was not done when the shards were loaded"),
+    (dict(PAPR_GPUS="1", PAPR_XCH="rccl", PAPR_XCH_BIND_DELAY_MS="4000", PAPR_XCH_BIND_TIMEOUT_S="0.5"), "within PAPR_XCH_BIND_TIMEOUT_S"),
+    (dict(PAPR_GPUS="3", PAPR_OVERSUBSCRIBE="1", PAPR_XCH_BIND_SHARED_OK="1", PAPR_XCH_BIND_FAIL="all"), "an injected failure"),
+    (dict(PAPR_GPUS="3", PAPR_OVERSUBSCRIBE="1", PAPR_XCH_BIND_SHARED_OK="1", PAPR_XCH_BIND_FAIL="1", PAPR_XCH_BIND_TIMEOUT_S="5"),
+     "an injected failure"),
+], ids=["the set-up fails", "auto: not up in time", "waited for, too slow", "three shards, all fail", "three shards, one fails: the others are left inside ncclCommInitRank"])
+def test_cli_survives_an_rccl_setup_that_fails_or_is_late(pkg, manifest, env, why):
+    """The communicators come up in threads of their own beside the ingest (papr_exchange_open_rccl_local_async) and are
+    taken when the shards are loaded (papr_exchange_adopt_rccl) — all shards or none.  A set-up that fails (injected behind
+    PAPR_XCH_BIND_FAIL), is not up when it is needed (PAPR_XCH=auto never waits) or not within PAPR_XCH_BIND_TIMEOUT_S is ONE
+    line on stderr and the in-process hub: stdout, exit status and the rest of stderr are the reference's."""
+    for name in ("g1m", "odd"):
+        for graph in (False, True):
+            p = subprocess.run([pkg.CLI_PATH] + (["-g"] if graph else []) + [golden_path(name)], capture_output=True,
+                               env=dict(os.environ, PAPR_STATS="1", **env), timeout=120)
+            want = manifest[name]["graph" if graph else "default"]
+            assert p.returncode == want["rc"] and p.stdout == golden_text(name, graph), (name, graph, p.stderr)
+            lines = p.stderr.decode().splitlines()
+            said = [l for l in lines if l.startswith("papr: RCCL set-up did not complete")]
+            assert len(said) == 1 and why in said[0] and "in-process hub" in said[0], lines
+            stats = json.loads(lines[-1])
+            assert stats["exchange"] != "rccl" and stats["exact_sum"] == 1
+            rest = [l for l in lines[:-1] if l not in said]
+            assert "\n".join(rest) + ("\n" if rest else "") == want["stderr"]
+
+
+def test_cli_takes_rccl_when_it_is_up_and_says_what_the_set_up_cost(pkg, manifest):
+    """... and when the set-up completes — waited for (PAPR_XCH=rccl), or simply there in time (PAPR_XCH=auto with an ingest
+    that takes longer than ncclCommInitRank: here made so with PAPR_XCH_BIND_TIMEOUT_S unused and a generous file) — the
+    step's exchanges cross RCCL and PAPR_STATS prices the set-up: how long the thread ran, how long the shard waited."""
+    p = subprocess.run([pkg.CLI_PATH, golden_path("g1m")], capture_output=True, timeout=120,
+                       env=dict(os.environ, PAPR_STATS="1", PAPR_GPUS="1", PAPR_XCH="rccl"))
+    assert p.returncode == 0 and p.stdout == golden_text("g1m", False), p.stderr
+    stats = json.loads(p.stderr.decode().splitlines()[-1])
+    assert stats["exchange"] == "rccl" and stats["exchange_setup_s"] > 0 and 0 <= stats["exchange_wait_s"] <= stats["exchange_setup_s"] + 0.05
+    assert stats["exchange_wait_s"] < stats["total_s"]
+
+
 @pytest.mark.parametrize("shards", [2, 3, 8])
 def test_cli_multi_shard_path(pkg, manifest, shards):
     """The multi-GPU code path of bin/papr (one context + thread per shard, ordered merge, chained
@@ -143,7 +183,7 @@ def test_cli_vs_reference_binary_on_fresh_files(pkg, orc, tmp_path):
             assert (got.returncode, got.stdout, got.stderr) == (want.returncode, want.stdout, want.stderr), (n, extra, mode)
 
 
-def _through_a_fifo(cmd, path, fifo, writer_chunk=1 << 16):
+def _through_a_fifo(cmd, path, fifo, writer_chunk=1 << 16, env=None):
     """Run `cmd <fifo>` with the bytes of `path` written into the FIFO by a thread (in pieces no larger than a pipe's
     buffer, like a producer would)."""
     import threading
@@ -163,7 +203,7 @@ def _through_a_fifo(cmd, path, fifo, writer_chunk=1 << 16):
                     break
     t = threading.Thread(target=feed)
     t.start()
-    p = subprocess.run(cmd + [fifo], capture_output=True, timeout=120)
+    p = subprocess.run(cmd + [fifo], capture_output=True, timeout=120, env=env)
     t.join(30)
     os.unlink(fifo)
     return p
@@ -194,18 +234,82 @@ def test_cli_on_a_stream_that_cannot_be_rewound_prints_what_the_reference_prints
                 assert b"0.00000000" in got.stdout
 
 
-def test_cli_refuses_a_stream_longer_than_the_hbm_budget(pkg, orc, tmp_path):
-    """The one thing a stream cannot have here and can have with the reference: more bytes than the HBM budget (it cannot be
-    read a second time, so it has to stay resident).  An error with its reason, exit status 253 — not a crash, not a wrong
-    report."""
-    path, fifo = str(tmp_path / "f.cfile"), str(tmp_path / "in.fifo")
-    subprocess.check_call([orc.MKCFILE, path, str(40 << 20 >> 3), "--seed", "3"])   # 40 MiB
-    os.environ["PAPR_HBM_BUDGET_MB"] = "16"
-    try:
-        p = _through_a_fifo([pkg.CLI_PATH], path, fifo)
-    finally:
-        del os.environ["PAPR_HBM_BUDGET_MB"]
-    assert p.returncode == 253 and p.stdout == b"" and b"longer than the HBM budget" in p.stderr, (p.returncode, p.stderr)
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "papr")), reason="no compiled reference")
+def test_cli_on_a_stream_longer_than_the_hbm_budget_prints_what_the_reference_prints(pkg, orc, tmp_path):
+    """papr.c:100-129 reads a FIFO of ANY length in 64 KiB of memory; so does bin/papr in one window of HBM
+    (papr_hip_stream_stats): 40 MiB through a FIFO under a 16 MiB budget (three windows), both modes — even, odd-float and
+    stray-byte tails, a stream that ends ON a window's end, and a last window of ONE float whose phantom partner lies in the
+    chunk kept from the window before — stdout, stderr and exit status against the reference binary fed through a FIFO of
+    its own, the mean from the reference's sequential sum (`exact_sum: 1`) carried from window to window."""
+    import json
+    fifo = str(tmp_path / "in.fifo")
+    mib = (1 << 20) // 8
+    cases = [(40 * mib, ["--spike"]), (40 * mib, ["--extra-floats", "1"]), (40 * mib + 12345, ["--extra-floats", "1", "--extra-bytes", "3"]),
+             (28 * mib, []), (14 * mib, ["--extra-floats", "1"]), (14 * mib, ["--extra-floats", "1", "--extra-bytes", "1"]),
+             (33 * mib + 1, ["--extra-bytes", "2"])]
+    env = dict(os.environ, PAPR_HBM_BUDGET_MB="16", PAPR_STATS="1")
+    for n, extra in cases:
+        path = str(tmp_path / "f.cfile")
+        subprocess.check_call([orc.MKCFILE, path, str(n), *extra, "--seed", "3"])
+        for mode in ([], ["-g"]):
+            want = _through_a_fifo([orc.REF_CLI, *mode], path, fifo)
+            got = _through_a_fifo([pkg.CLI_PATH, *mode], path, fifo, env=env)
+            err = got.stderr.decode().splitlines()
+            info = json.loads(err[-1])
+            assert (got.returncode, got.stdout, "\n".join(err[:-1]).encode()) == (want.returncode, want.stdout, want.stderr), (n, extra, mode)
+            assert info["exact_sum"] == 1 and info["stream_windows"] >= 2 and info["bytes"] >= n * 8, info
+            on_file = subprocess.run([orc.REF_CLI, *mode, path], capture_output=True).stdout
+            assert len(got.stdout.splitlines()) == len(on_file.splitlines()) and b"0.00000000" in got.stdout
+            if not mode:   # pass 1's lines are the file's, the percentages are the stream's zeros
+                assert got.stdout.splitlines()[:4] == on_file.splitlines()[:4]
+
+
+def test_stream_stats_window_by_window_is_the_files_pass1(pkg, orc, tmp_path):
+    """papr_hip_stream_stats through the ABI: a pipe fed 70 MiB + an odd tail under windows of 8 MiB gives the record
+    papr_hip_stats gives for the same bytes as one resident shard (trackers and indices bit for bit), and in exact-sum
+    mode the ORACLE's sequential sum bit for bit; with NaN in the stream it says the sum is not the emulation's."""
+    import threading
+    n = (70 << 20) // 8 + 4321
+    rng = np.random.default_rng(12)
+    iq = (rng.standard_normal(2 * n + 1) * 0.7).astype(np.float32)   # odd float count
+    iq[2 * (n // 3)] = 9.5      # a peak in the middle of a window
+    iq[2 * (n // 3) + 7 * 2] = 9.5   # ... and its tie further on: the first index wins across windows too
+    path = str(tmp_path / "same.cfile")
+    iq.tofile(path)
+    want = orc.run_file(path, False)
+
+    def through_a_pipe(data, exact):
+        r, w = os.pipe()
+
+        def feed():
+            with os.fdopen(w, "wb") as f:
+                f.write(data)
+        t = threading.Thread(target=feed)
+        t.start()
+        os.environ["PAPR_STREAM_WINDOW_MB"] = "8"
+        try:
+            with pkg.PaprHip(0) as g:
+                g.set_exact(exact)
+                out = g.stream_stats(r)
+        finally:
+            del os.environ["PAPR_STREAM_WINDOW_MB"]
+        t.join()
+        os.close(r)
+        return out
+    st, exact, windows = through_a_pipe(iq.tobytes(), True)
+    assert exact and windows == 9 and st.n == n + 1 == want["n"]
+    assert st.sum == want["sum"], (st.sum.hex(), float(want["sum"]).hex())
+    with pkg.PaprHip(0) as g:
+        g.load_file(path)
+        whole = g.stats()
+    for k in ("n", "peak", "peak_idx", "re_pos", "re_neg", "im_pos", "im_neg", "re_pos_idx", "re_neg_idx", "im_pos_idx", "im_neg_idx", "flags"):
+        assert getattr(st, k) == getattr(whole, k), k
+    assert st.peak_idx == n // 3
+    st2, exact2, _ = through_a_pipe(iq.tobytes(), False)
+    assert not exact2 and abs(st2.sum - want["sum"]) <= 1e-12 * want["sum"]
+    iq[2 * (n // 2) + 1] = np.nan
+    st3, exact3, _ = through_a_pipe(iq.tobytes(), True)
+    assert not exact3 and np.isnan(st3.sum) and (st3.flags & 1)
 
 
 @pytest.mark.parametrize("env,lines", [(dict(PAPR_GPUS="1", PAPR_XCH="rccl"), 5), (dict(PAPR_GPUS="3", PAPR_OVERSUBSCRIBE="1"), 2),
