@@ -77,11 +77,15 @@ bin/papr: $(PKG)/host/papr_main.c include/papr_hip.h include/papr_exchange.h inc
 oracle:
 	$(MAKE) -C oracle all
 
-tools: bin/hbm_read_probe bin/ingest_probe bin/work_probe bin/stride_read_probe bin/h2d_contention_probe bin/zero_copy_probe bin/wg_skew_probe bin/ts_stride_probe bin/xcd_affinity_probe
+tools: bin/hbm_read_probe bin/ingest_probe bin/work_probe bin/stride_read_probe bin/h2d_contention_probe bin/zero_copy_probe bin/wg_skew_probe bin/ts_stride_probe bin/xcd_affinity_probe bin/exact_form_probe
 
 bin/stride_read_probe: tools/stride_read_probe.hip
 	@mkdir -p bin
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Wno-unused-result -Wno-unused-value $< -o $@
+
+bin/exact_form_probe: tools/exact_form_probe.hip
+	@mkdir -p bin
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -Wno-unused-result -Wno-unused-value $< -o $@
 
 bin/xcd_affinity_probe: tools/xcd_affinity_probe.hip
 	@mkdir -p bin
@@ -116,7 +120,7 @@ bin/work_probe: tools/work_probe.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -Wno-unused-result -Wno-unused-value $< -o $@
 
 clean:
-	rm -f $(CSRC)/*.o $(CSRC)/measure/*.o $(PKG)/libpaprhip.so build_measure/libpaprhip.so bin/papr bin/hbm_read_probe bin/ingest_probe bin/work_probe bin/stride_read_probe bin/h2d_contention_probe bin/zero_copy_probe bin/wg_skew_probe bin/ts_stride_probe bin/xcd_affinity_probe
+	rm -f $(CSRC)/*.o $(CSRC)/measure/*.o $(PKG)/libpaprhip.so build_measure/libpaprhip.so bin/papr bin/hbm_read_probe bin/ingest_probe bin/work_probe bin/stride_read_probe bin/h2d_contention_probe bin/zero_copy_probe bin/wg_skew_probe bin/ts_stride_probe bin/xcd_affinity_probe bin/exact_form_probe
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib cli oracle tools clean

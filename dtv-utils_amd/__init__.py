@@ -458,7 +458,7 @@ class PaprHip:
     def stream_stats(self, fd: int):
         """papr_hip_stream_stats: pass 1 over a pipe / FIFO / socket of any length, window by window; returns
         (the stream's Stats, whether .sum is the reference's sequential sum, windows reduced)."""
-        st, ex, w = Stats(), i32(0), u64(0)
+        st, ex, w = Stats(), C.c_int(0), C.c_uint64(0)
         self._chk(self._L.papr_hip_stream_stats(self._ctx, fd, C.byref(st), C.byref(ex), C.byref(w)), "papr_hip_stream_stats")
         return st, bool(ex.value), int(w.value)
 

@@ -921,8 +921,7 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
     // stride with the XCD skew (SkewWalk, papr_sweep_dev.h).  A wave's segments come in increasing order.
     SkewWalk walk;
     walk.init(blockIdx.x, gridDim.x, p.xcd_skew & 0xFFFFu, (p.xcd_skew >> 31) ^ 1u);
-    constexpr uint64_t kNoSeg = ~0ull;
-    uint64_t seg = walk.tile() * WAVES + wave, prev_seg = kNoSeg;
+    uint64_t seg = walk.tile() * WAVES + wave;
     uint32_t segs_done = 0;
     auto load_seg = [&](float4(&x)[U], uint64_t seg) {
         const unsigned long long base = uniform_u64((unsigned long long)(data + seg * SEG_F4));  // wave-uniform: scalar base
@@ -978,7 +977,30 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
     // the samples wait for the store's acknowledgement as well; a binade requested at the top of the loop would have the
     // wave stand still for a whole memory round trip with nothing of its own in flight).
     int E_next = PAPR_EXACT_AMBIG;
-    double2 D_prev = make_double2(0.0, 0.0);
+    // The segments' pairs leave the wave SIXTY-FOUR AT A TIME.  A 16-byte store per segment — one lane, 0.2 % of the bytes —
+    // cost the kernel 5 % (tools/exact_form_probe.hip, profiles/r06_exact_form_probe.txt: the transposition, the two fp64
+    // chains and the whole composition together are free beside a plain read, 0.875 of peak; with the store 0.835): on gfx9
+    // a store counts in vmcnt like a load, so the wait for the next segment's samples at the top of every fold was also a
+    // wait for the previous pair's write acknowledgement.  The pair (valid in lane 63) is handed to lane j of a per-lane
+    // register instead (four v_readlane, one compare, five selects; j = the segment's number in its batch), and a full batch goes
+    // out as ONE scattered store of 64 pairs where the single store used to sit.
+    double2 D_keep = make_double2(0.0, 0.0);
+    uint32_t seg_keep = 0, nkept = 0;  // (nkept: wave-uniform)
+    auto keep_pair = [&](const double2 D, uint32_t seg_index) {
+        const uint32_t j = __builtin_amdgcn_readfirstlane(nkept);
+        const bool mine_now = lane == j;  // (one compare, five selects of a scalar: v_writelane takes one SGPR only on gfx9)
+        const int xl = __builtin_amdgcn_readlane(__double2loint(D.x), kWave - 1), xh = __builtin_amdgcn_readlane(__double2hiint(D.x), kWave - 1);
+        const int yl = __builtin_amdgcn_readlane(__double2loint(D.y), kWave - 1), yh = __builtin_amdgcn_readlane(__double2hiint(D.y), kWave - 1);
+        D_keep.x = mine_now ? __hiloint2double(xh, xl) : D_keep.x;
+        D_keep.y = mine_now ? __hiloint2double(yh, yl) : D_keep.y;
+        seg_keep = mine_now ? seg_index : seg_keep;
+        nkept = j + 1;
+    };
+    auto flush_pairs = [&]() {
+        if (lane < nkept)
+            seg_D[seg_keep] = D_keep;
+        nkept = 0;
+    };
     if (seg < p.nsegs) {
         E_next = tile_E[(p.seg_offset + seg) >> 1];
         asm volatile("" ::: "memory");
@@ -1027,8 +1049,8 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
                 e_lut[u] = lut_biased[clamp_cell(__float_as_int(pw[u]) >> shift, cell_first, cell_last)];
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (prev_seg != kNoSeg && lane == kWave - 1)
-            seg_D[p.seg_offset + prev_seg] = D_prev;
+        if (nkept == kWave)  // (wave-uniform: once in 64 segments)
+            flush_pairs();
         asm volatile("" ::: "memory");
         // the registers are free again: the next segment's loads fly while this one is folded out of LDS — in front of
         // any spill store of this segment, so that a spill never stands between the wave and its next data
@@ -1103,12 +1125,10 @@ __global__ __launch_bounds__(PAPR_SWEEP_THREADS) void papr_sweep3_kernel(const p
         // ---- the segment's pair ----
         const double d0 = x0 - m0, d1 = x1 - m1;  // exact: multiples of the ulp inside the binade (plain sums when no binade was given)
         sum += d0;
-        D_prev = segment_pair(x0, x1, d0, d1, ulp);
-        prev_seg = seg;
+        keep_pair(segment_pair(x0, x1, d0, d1, ulp), (uint32_t)(p.seg_offset + seg));
         seg = nseg;
     }
-    if (prev_seg != kNoSeg && lane == kWave - 1)
-        seg_D[p.seg_offset + prev_seg] = D_prev;
+    flush_pairs();
     // remainder of the launch: binned here (its pass-1 part is folded in by papr_stats_finalize, its exact-sum part
     // travels raw in the sum program)
     if (blockIdx.x == gridDim.x - 1) {

@@ -60,6 +60,7 @@ struct ts_hip_ctx {
     std::vector<ts_discontinuity> discs;                    // every discontinuity of the last scan, in stream order
     ts_event *h_events = nullptr;                           // pinned mirror of the event list (grows with it)
     size_t h_events_cap = 0;
+    uint32_t nev_last = 0;                                  // how many events the last scan had: as many cross the link inside the next scan's ONE wait (TS_SCAN_EVENTS_AHEAD=0: never)
     std::vector<unsigned char> line_scratch;                // the host's working copy of the lines, reused from scan to scan
     ts_line_pool *pool = nullptr;                           // host threads for the lines of a damaged stream (lazily)
     int pool_threads = -1;                                  // TS_HOST_THREADS (default: 8, at most the cores; 1: none)
@@ -478,6 +479,7 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
         ts_walk_init(&cur, hdmv);
         uint64_t packets = 0;
         uint32_t from = 0;
+        uint32_t ahead = 0;  // events already on the host when the last launch's wait returned
         out->launches = launches_before;
         for (;;) {
             // ---- scan (every span from its speculated entry; or ONE span again, from the state the chain arrived with) ...
@@ -501,6 +503,16 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
             // (... and every span's numbering base and the head of its continuity list: the host links the spans)
             TSCHK(ctx, hipMemcpyAsync(ctx->h_span_out, ctx->d_span_out, (size_t)nspans * sizeof(ts_span_out), hipMemcpyDeviceToHost,
                                       ctx->stream));
+            // The report's lines in the SAME wait: how many there are is only known behind it, but a capture's next scan has
+            // about as many as its last (a context's scans are of one stream, or of files damaged alike), so that many events
+            // (+ an eighth) cross the link now; what is missing afterwards — or everything, for a first scan — is fetched
+            // behind the wait as before.  A guess that was too large copies slots nobody reads.
+            ahead = 0;
+            if (ctx->nev_last && ctx->h_events && !(getenv("TS_SCAN_EVENTS_AHEAD") && atoi(getenv("TS_SCAN_EVENTS_AHEAD")) == 0)) {
+                ahead = (uint32_t)std::min<size_t>({(size_t)ctx->nev_last + ctx->nev_last / 8 + 256, ctx->h_events_cap, (size_t)ctx->event_cap});
+                if (ahead)
+                    TSCHK(ctx, hipMemcpyAsync(ctx->h_events, ctx->d_events, (size_t)ahead * sizeof(ts_event), hipMemcpyDeviceToHost, ctx->stream));
+            }
             TSCHK(ctx, hipStreamSynchronize(ctx->stream));
             if (trace)
                 t_synced = host_now_ms();
@@ -574,12 +586,16 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
             if (ctx->h_events) (void)hipHostFree(ctx->h_events);
             ctx->h_events = nullptr;
             ctx->h_events_cap = 0;
+            ahead = 0;  // (what crossed ahead went with the old buffer)
             const size_t want = std::max<size_t>((size_t)nev + nev / 4, 1u << 16);
             TSCHK(ctx, hipHostMalloc((void **)&ctx->h_events, want * sizeof(ts_event), hipHostMallocDefault));
             ctx->h_events_cap = want;
         }
-        if (nev)
-            TSCHK(ctx, hipMemcpyAsync(ctx->h_events, ctx->d_events, (size_t)nev * sizeof(ts_event), hipMemcpyDeviceToHost, ctx->stream));
+        ctx->nev_last = nev;
+        const bool fetch_more = nev > ahead;  // (the events the wait did not bring: all of them for a context's first scan)
+        if (fetch_more)
+            TSCHK(ctx, hipMemcpyAsync(ctx->h_events + ahead, ctx->d_events + ahead, (size_t)(nev - ahead) * sizeof(ts_event), hipMemcpyDeviceToHost,
+                                      ctx->stream));
         // Few lines: this thread alone.  Many (a damaged stream): T threads, each a range of the event list, then each a
         // range of the spans; only the linking of the spans' continuity counters in between is serial (a few entries per
         // span).  The workers are woken HERE, while the lines cross the link.
@@ -599,7 +615,7 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
                 burst_threads = (int)ctx->pool->workers.size() + 1;
             }
         }
-        if (nev) {
+        if (fetch_more) {
             const hipError_t se = hipStreamSynchronize(ctx->stream);
             if (se != hipSuccess) {
                 if (ctx->pool)

@@ -13,9 +13,12 @@
  *   PAPR_GPUS=N        use N GPUs (default: one per 2 GiB of input, at most all visible)
  *   PAPR_OVERSUBSCRIBE=1  let PAPR_GPUS exceed the visible GPUs (shard g runs on GPU g mod visible);
  *                      for exercising the multi-shard path on a small machine
- *   PAPR_XCH=rccl|threads  how the shards' partial results meet: RCCL collectives on device buffers over xGMI, queued
- *                      on each GPU's stream (the default with more than one GPU, when librccl loads and every shard has
- *                      a GPU of its own; =rccl also runs them for a single shard), or the plain in-process hub
+ *   PAPR_XCH=rccl|auto|threads  how the shards' partial results meet: RCCL collectives on device buffers over xGMI, queued
+ *                      on each GPU's stream (the default with more than one GPU when every shard has a GPU of its own;
+ *                      =rccl also runs them for a single shard), or the plain in-process hub (=threads).  The communicators
+ *                      come up in threads of their own BESIDE the ingest and are taken when the shards are loaded: waited
+ *                      for up to PAPR_XCH_BIND_TIMEOUT_S (30) seconds, or — =auto — only if they are up by then; librccl
+ *                      missing, a set-up that fails or is late: one line on stderr and the hub, same stdout
  *   PAPR_STATS=1       one JSON line with sizes and timings on stderr
  *   PAPR_TEARDOWN=1    close the contexts and let the runtime's exit handlers run (default: _exit once the answer
  *                      is printed — the orderly way costs ~90 ms for a 10 GiB shard)
@@ -298,7 +301,7 @@ int main(int argc, char **argv)
     env = getenv("PAPR_XCH");
     const int rccl_forced = env && strcmp(env, "rccl") == 0;
     const int rccl_auto = env && strcmp(env, "auto") == 0; /* RCCL only if it is up when the shards are loaded: no wait at all */
-    const int rccl_wanted = (rccl_forced || (ngpu > 1 && !(env && strcmp(env, "threads") == 0))) && stream_fd < 0;
+    const int rccl_wanted = (rccl_forced || rccl_auto || (ngpu > 1 && !(env && strcmp(env, "threads") == 0))) && stream_fd < 0;
     int devices[MAX_GPUS];
     for (int g = 0; g < ngpu; g++)
         devices[g] = sh[g].device;

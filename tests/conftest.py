@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# PAPR_TEST_FULL=1: the randomised suites at their full length and every rank count / fixture in the transports' matrices
+# (what rounds 1-5 ran every time: +2 minutes on the GPU box).  The default tier keeps every TEST and trims the repetitions
+# inside the soak-like ones: half of the random packet streams, rank counts 2 and 8 of (2, 4, 8), a third of the fixtures
+# through RCCL at world size 1 (all of them go through the CLI in test_cli_reproduces_reference_stdout either way).
+FULL_TIER = os.environ.get("PAPR_TEST_FULL", "0") not in ("", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 

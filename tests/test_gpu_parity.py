@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, golden_names, golden_path, golden_text
+from conftest import FULL_TIER, ROOT, golden_names, golden_path, golden_text
 
 pytestmark = pytest.mark.gpu
 
@@ -91,7 +91,10 @@ def test_cli_over_rccl_reproduces_reference_stdout(pkg, manifest, exact):
     # (a run is ~2 s of communicator set-up around milliseconds of work: six of them side by side on the one GPU)
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=6) as pool:
-        results = list(pool.map(one, [(name, graph) for name in golden_names() for graph in (False, True)]))
+        names = golden_names()
+        if not FULL_TIER:   # every third fixture + the ones with a path of their own (the CLI test above runs all of them)
+            names = sorted(set(names[::3]) | {n for n in names if n in ("empty", "odd", "oddb", "stray3", "ties", "g1m", "zeros", "nan_order", "inf_nan", "one", "overflow")})
+        results = list(pool.map(one, [(name, graph) for name in names for graph in (False, True)]))
     for (name, graph), p in results:
         want = manifest[name]["graph" if graph else "default"]
         assert p.returncode == want["rc"], (name, graph, p.stderr)
@@ -201,7 +204,7 @@ def _through_a_fifo(cmd, path, fifo, writer_chunk=1 << 16, env=None):
                     dst.write(b)
                 except BrokenPipeError:
                     break
-    t = threading.Thread(target=feed)
+    t = threading.Thread(target=feed, daemon=True)
     t.start()
     p = subprocess.run(cmd + [fifo], capture_output=True, timeout=120, env=env)
     t.join(30)
@@ -272,8 +275,8 @@ def test_stream_stats_window_by_window_is_the_files_pass1(pkg, orc, tmp_path):
     n = (70 << 20) // 8 + 4321
     rng = np.random.default_rng(12)
     iq = (rng.standard_normal(2 * n + 1) * 0.7).astype(np.float32)   # odd float count
-    iq[2 * (n // 3)] = 9.5      # a peak in the middle of a window
-    iq[2 * (n // 3) + 7 * 2] = 9.5   # ... and its tie further on: the first index wins across windows too
+    for k in (n // 3, n // 3 + 7, 2 * (n // 3)):   # a peak in the middle of a window, and its ties further on and three windows
+        iq[2 * k], iq[2 * k + 1] = 9.5, 0.0       # later: the first index wins across windows too
     path = str(tmp_path / "same.cfile")
     iq.tofile(path)
     want = orc.run_file(path, False)
@@ -282,9 +285,12 @@ def test_stream_stats_window_by_window_is_the_files_pass1(pkg, orc, tmp_path):
         r, w = os.pipe()
 
         def feed():
-            with os.fdopen(w, "wb") as f:
-                f.write(data)
-        t = threading.Thread(target=feed)
+            try:
+                with os.fdopen(w, "wb") as f:
+                    f.write(data)
+            except BrokenPipeError:
+                pass
+        t = threading.Thread(target=feed, daemon=True)   # (a failure below must not leave the session waiting for the writer)
         t.start()
         os.environ["PAPR_STREAM_WINDOW_MB"] = "8"
         try:
@@ -293,8 +299,8 @@ def test_stream_stats_window_by_window_is_the_files_pass1(pkg, orc, tmp_path):
                 out = g.stream_stats(r)
         finally:
             del os.environ["PAPR_STREAM_WINDOW_MB"]
-        t.join()
-        os.close(r)
+            os.close(r)      # (a writer still blocked on a full pipe gets EPIPE and ends)
+        t.join(30)
         return out
     st, exact, windows = through_a_pipe(iq.tobytes(), True)
     assert exact and windows == 9 and st.n == n + 1 == want["n"]
@@ -337,13 +343,18 @@ def test_load_stream_grows_the_shard_and_keeps_the_bytes(pkg, gpu, tmp_path):
     import threading
 
     def feed():
-        with os.fdopen(w, "wb") as f:
-            f.write(iq.tobytes())
-    t = threading.Thread(target=feed)
+        try:
+            with os.fdopen(w, "wb") as f:
+                f.write(iq.tobytes())
+        except BrokenPipeError:
+            pass
+    t = threading.Thread(target=feed, daemon=True)
     t.start()
-    got_n = gpu.load_stream(r)
-    t.join()
-    os.close(r)
+    try:
+        got_n = gpu.load_stream(r)
+    finally:
+        os.close(r)
+    t.join(30)
     path = str(tmp_path / "same.cfile")
     iq.tofile(path)
     assert got_n == n + 1

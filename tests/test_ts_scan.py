@@ -17,7 +17,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT
+from conftest import FULL_TIER, GOLDEN, ROOT
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -126,7 +126,7 @@ def test_scan_reproduces_reference_lines(ts, gpu, name):
 @pytest.mark.gpu
 def test_scan_equals_oracle_on_random_damaged_streams(ts, gpu):
     rng = np.random.default_rng(4242)
-    for t in range(120):
+    for t in range(120 if FULL_TIER else 60):
         kw = random_stream_kwargs(t, rng)
         kw["npackets"] = int(kw["npackets"] * rng.choice([1, 1, 8, 40]))   # some streams long enough for every workgroup
         data = ts_streams.make_stream(**kw)
@@ -212,7 +212,7 @@ def test_scan_in_many_small_spans_reproduces_reference_lines(ts, gpu_small_spans
 def test_scan_in_small_spans_equals_oracle_on_random_damaged_streams(ts, gpu_small_spans):
     rng = np.random.default_rng(777)
     relaunched = 0
-    for t in range(120):
+    for t in range(120 if FULL_TIER else 60):
         kw = random_stream_kwargs(t, rng)
         kw["npackets"] = int(kw["npackets"] * rng.choice([1, 4, 16]))
         data = ts_streams.make_stream(**kw)
