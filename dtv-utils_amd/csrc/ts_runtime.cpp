@@ -60,7 +60,7 @@ struct ts_hip_ctx {
     std::vector<ts_discontinuity> discs;                    // every discontinuity of the last scan, in stream order
     ts_event *h_events = nullptr;                           // pinned mirror of the event list (grows with it)
     size_t h_events_cap = 0;
-    uint32_t nev_last = 0;                                  // how many events the last scan had: as many cross the link inside the next scan's ONE wait (TS_SCAN_EVENTS_AHEAD=0: never)
+    bool events_on_host = false;                            // the event list IS pinned host memory the kernels write through the link (TS_SCAN_EVENTS_HOST=1)
     std::vector<unsigned char> line_scratch;                // the host's working copy of the lines, reused from scan to scan
     ts_line_pool *pool = nullptr;                           // host threads for the lines of a damaged stream (lazily)
     int pool_threads = -1;                                  // TS_HOST_THREADS (default: 8, at most the cores; 1: none)
@@ -148,6 +148,42 @@ const char *ts_hip_last_error(const ts_hip_ctx *ctx)
     return ctx ? ctx->err : g_ts_open_error;
 }
 
+// the event list: device memory + a pinned mirror that grows with what a scan needs, or (events_on_host) ONE pinned, mapped
+// buffer that is both — d_events is then its device-side address and no copy is ever made
+static void free_events(ts_hip_ctx *ctx)
+{
+    if (ctx->events_on_host) {  // (d_events is the device-side address of the same buffer)
+        if (ctx->h_events) (void)hipHostFree(ctx->h_events);
+    } else {
+        if (ctx->d_events) (void)hipFree(ctx->d_events);
+        if (ctx->h_events) (void)hipHostFree(ctx->h_events);
+    }
+    ctx->d_events = ctx->h_events = nullptr;
+    ctx->event_cap = 0;
+    ctx->h_events_cap = 0;
+}
+static hipError_t alloc_events(ts_hip_ctx *ctx, size_t cap)
+{
+    free_events(ctx);
+    hipError_t e;
+    if (ctx->events_on_host) {
+        e = hipHostMalloc((void **)&ctx->h_events, cap * sizeof(ts_event), hipHostMallocMapped);
+        if (e == hipSuccess)
+            e = hipHostGetDevicePointer((void **)&ctx->d_events, ctx->h_events, 0);
+        if (e == hipSuccess)
+            ctx->h_events_cap = cap;
+    } else {
+        e = hipMalloc((void **)&ctx->d_events, cap * sizeof(ts_event));
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        free_events(ctx);
+        return e;
+    }
+    ctx->event_cap = (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu);
+    return hipSuccess;
+}
+
 int ts_hip_open(ts_hip_ctx **out, int device)
 {
     if (!out)
@@ -204,8 +240,11 @@ int ts_hip_open(ts_hip_ctx **out, int device)
     ctx->d_first = reinterpret_cast<unsigned long long *>(ctx->d_count + TS_PIDS);
     ctx->d_last = ctx->d_first + TS_PIDS;
     OPENCHK(hipMalloc((void **)&ctx->d_event_count, 4 * sizeof(unsigned int)));  // [0] events wanted, [1] a span overflowed its PID slots, [2] damaged: the slot form's
-    OPENCHK(hipMalloc((void **)&ctx->d_events, (size_t)kEventCapInitial * sizeof(ts_event)));
-    ctx->event_cap = kEventCapInitial;
+    // The report's lines are only ever WRITTEN by the kernels (32 bytes a line, a few MB for a badly damaged stream): with
+    // TS_SCAN_EVENTS_HOST=1 the list is pinned host memory and the lines cross the link as posted writes while the scan
+    // runs, instead of as a copy behind it (0.09 ms for 129 000 lines) — see alloc_events
+    ctx->events_on_host = env_int_ts("TS_SCAN_EVENTS_HOST", 1) != 0;
+    OPENCHK(alloc_events(ctx, kEventCapInitial));
     OPENCHK(hipHostMalloc((void **)&ctx->h_out, sizeof(ts_merge_out), hipHostMallocMapped));
     OPENCHK(hipHostGetDevicePointer((void **)&ctx->h_out_dev, ctx->h_out, 0));
     OPENCHK(hipHostMalloc(&ctx->h_tables, TS_PIDS * (sizeof(uint32_t) + 2 * sizeof(unsigned long long)), hipHostMallocDefault));
@@ -235,12 +274,11 @@ void ts_hip_close(ts_hip_ctx *ctx)
     if (ctx->d_span_out) (void)hipFree(ctx->d_span_out);
     if (ctx->d_bridges) (void)hipFree(ctx->d_bridges);
     if (ctx->h_span_out) (void)hipHostFree(ctx->h_span_out);
-    if (ctx->h_events) (void)hipHostFree(ctx->h_events);
+    free_events(ctx);
     if (ctx->d_span_base) (void)hipFree(ctx->d_span_base);
     if (ctx->d_span_bridge_base) (void)hipFree(ctx->d_span_bridge_base);
     if (ctx->d_span_attempt) (void)hipFree(ctx->d_span_attempt);
     if (ctx->d_count) (void)hipFree(ctx->d_count);
-    if (ctx->d_events) (void)hipFree(ctx->d_events);
     if (ctx->d_event_count) (void)hipFree(ctx->d_event_count);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     if (ctx->h_tables) (void)hipHostFree(ctx->h_tables);
@@ -479,7 +517,7 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
         ts_walk_init(&cur, hdmv);
         uint64_t packets = 0;
         uint32_t from = 0;
-        uint32_t ahead = 0;  // events already on the host when the last launch's wait returned
+        uint32_t ahead = 0;  // events already on the host when the last launch's wait returned (events_on_host: all of them)
         out->launches = launches_before;
         for (;;) {
             // ---- scan (every span from its speculated entry; or ONE span again, from the state the chain arrived with) ...
@@ -503,16 +541,6 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
             // (... and every span's numbering base and the head of its continuity list: the host links the spans)
             TSCHK(ctx, hipMemcpyAsync(ctx->h_span_out, ctx->d_span_out, (size_t)nspans * sizeof(ts_span_out), hipMemcpyDeviceToHost,
                                       ctx->stream));
-            // The report's lines in the SAME wait: how many there are is only known behind it, but a capture's next scan has
-            // about as many as its last (a context's scans are of one stream, or of files damaged alike), so that many events
-            // (+ an eighth) cross the link now; what is missing afterwards — or everything, for a first scan — is fetched
-            // behind the wait as before.  A guess that was too large copies slots nobody reads.
-            ahead = 0;
-            if (ctx->nev_last && ctx->h_events && !(getenv("TS_SCAN_EVENTS_AHEAD") && atoi(getenv("TS_SCAN_EVENTS_AHEAD")) == 0)) {
-                ahead = (uint32_t)std::min<size_t>({(size_t)ctx->nev_last + ctx->nev_last / 8 + 256, ctx->h_events_cap, (size_t)ctx->event_cap});
-                if (ahead)
-                    TSCHK(ctx, hipMemcpyAsync(ctx->h_events, ctx->d_events, (size_t)ahead * sizeof(ts_event), hipMemcpyDeviceToHost, ctx->stream));
-            }
             TSCHK(ctx, hipStreamSynchronize(ctx->stream));
             if (trace)
                 t_synced = host_now_ms();
@@ -559,15 +587,9 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
         if (nev > ctx->event_cap) {  // more sync errors than the list held: make room for all of them and scan again
             if (round > 0)
                 return ts_fail(ctx, PAPR_E_INTERNAL, "the sync-error list overflowed twice (%u events)", nev);
-            (void)hipFree(ctx->d_events);
-            ctx->d_events = nullptr;
-            ctx->event_cap = 0;
             const size_t want = (size_t)nev + (size_t)nev / 4 + 1024;
-            if (hipMalloc((void **)&ctx->d_events, want * sizeof(ts_event)) != hipSuccess) {
-                (void)hipGetLastError();
+            if (alloc_events(ctx, want) != hipSuccess)
                 return ts_fail(ctx, PAPR_E_NOMEM, "cannot allocate the sync-error list (%zu events)", want);
-            }
-            ctx->event_cap = (uint32_t)std::min<size_t>(want, 0xFFFFFFFFu);
             out->gpu_packets = 0;
             out->walks = 0;
             continue;
@@ -582,7 +604,9 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
             uint64_t skipped;
             uint32_t kind, info;
         };
-        if (nev > ctx->h_events_cap) {  // (pinned: a pageable destination made this copy the longest part of a damaged scan)
+        if (ctx->events_on_host)
+            ahead = nev;  // (they are here: the kernels wrote them through the link, the scan's wait saw them arrive)
+        if (!ctx->events_on_host && nev > ctx->h_events_cap) {  // (pinned: a pageable destination made this copy the longest part of a damaged scan)
             if (ctx->h_events) (void)hipHostFree(ctx->h_events);
             ctx->h_events = nullptr;
             ctx->h_events_cap = 0;
@@ -591,7 +615,6 @@ static int scan_with(ts_hip_ctx *ctx, int hdmv, ts_scan_result *out, bool slots,
             TSCHK(ctx, hipHostMalloc((void **)&ctx->h_events, want * sizeof(ts_event), hipHostMallocDefault));
             ctx->h_events_cap = want;
         }
-        ctx->nev_last = nev;
         const bool fetch_more = nev > ahead;  // (the events the wait did not bring: all of them for a context's first scan)
         if (fetch_more)
             TSCHK(ctx, hipMemcpyAsync(ctx->h_events + ahead, ctx->d_events + ahead, (size_t)(nev - ahead) * sizeof(ts_event), hipMemcpyDeviceToHost,
