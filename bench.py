@@ -754,8 +754,8 @@ def live_traffic(args, kernel, nbytes):
     import shutil
     import tempfile
     rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if not rp:
-        return None
+    if not rp or any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_")) for k in os.environ):
+        return None   # (no profiler on the box — or this run is itself being profiled: no profiler inside a profiler)
     tmp = tempfile.mkdtemp(prefix="papr_traffic_", dir="/tmp")
     vals = {}
     try:

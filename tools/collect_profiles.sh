@@ -4,13 +4,13 @@
 # --kernel-trace only).  Every run keeps its stdout line (<run>.line) and its full record (<run>.json).  Writes gpurun_out/<tag>/; tools/summarize_profiles.py distils profiles/<tag>_*.
 #   gpurun -- 'bash tools/collect_profiles.sh r04'
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
-H="--headline-only --no-cpu-baseline --no-e2e"
+H="--headline-only --no-cpu-baseline --no-e2e --no-live-traffic"
 ( time $B --full-json $O/bench_full.json > $O/bench_full.line 2> $O/bench_full.err ) 2> $O/bench_full.time     # the driver's command: every leg in one line
 $B $H                                --full-json $O/bench_default.json > $O/bench_default.line 2> $O/bench_default.err
 $B $H --exact                        --full-json $O/bench_exact.json > $O/bench_exact.line 2> $O/bench_exact.err
@@ -27,6 +27,9 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.
     $R/bench.py --gpus 1 $H --exact --full-json $O/bench_torchrun1_exact.json > $O/bench_torchrun1_exact.line 2> $O/bench_torchrun1_exact.err
 PAPR_XCH_IN_STREAM=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 \
     $R/bench.py --gpus 1 $H --full-json $O/bench_torchrun1_hostpath.json > $O/bench_torchrun1_hostpath.line 2> $O/bench_torchrun1_hostpath.err
+# `python bench.py --gpus 2` with no launcher around it: bench.py starts its own ranks (here two ranks share the one GPU over gloo: the code path
+# and the line's shape — weak + strong members — not a measurement)
+$B --gpus 2 --backend gloo --steps 10 --warmup 2 --no-cpu-baseline --full-json $O/bench_selflaunch_n2_gloo.json > $O/bench_selflaunch_n2_gloo.line 2> $O/bench_selflaunch_n2_gloo.err
 for SIG in bursty constant; do $B $H --signal $SIG --full-json $O/bench_$SIG.json > $O/bench_$SIG.line 2> $O/bench_$SIG.err; done
 $B $H --force-miss --full-json $O/bench_miss.json > $O/bench_miss.line 2> $O/bench_miss.err
 for RUN in "default:$H" "exact:$H --exact" "ts:--workload ts --no-cpu-baseline"; do

@@ -222,6 +222,158 @@ __global__ __launch_bounds__(kThreads) void form_kernel(const float4 *__restrict
         atomicAdd(out, sum);
 }
 
+// ---- geometry: the same per-sample work at two occupancies --------------------------------------------------------------
+// The product kernel in ONE more stripped form, with pass 2's per-sample work put back in (a 28 KiB one-edge-per-cell table in
+// LDS: a ds_read_b64 lookup, a compare, an LDS atomic on one of 4 x 64 bins; five integer-max trackers), in two geometries:
+//   A  8 waves per CU, a wave owns a 1024-sample segment at a time (8 KiB of LDS per wave, 16 samples per lane): the product's
+//   B  16 waves per CU, a wave takes its segment as two halves of 512 samples through a 4 KiB buffer (8 samples per lane, the
+//      halves' pairs composed in registers): the same 64 KiB of transpose buffers and bytes in flight, twice the waves to hide
+//      a wave's LDS round trips and waits behind
+template <int WAVES, int UU>
+__global__ __launch_bounds__(WAVES * 64) void geom_kernel(const float4 *__restrict__ data, uint64_t nsegs, int E, const uint2 *__restrict__ table,
+                                                           uint32_t ncells, uint32_t cell_lo, uint32_t shift, double *__restrict__ out,
+                                                           unsigned long long *__restrict__ ghist)
+{
+    constexpr int HALVES = 8 / UU;  // batches per 1024-sample segment
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint2 *tab = reinterpret_cast<uint2 *>(smem);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(tab + ncells);
+    float4 *xpose = reinterpret_cast<float4 *>(hist + 4 * 64);
+    const uint32_t t = threadIdx.x, lane = t & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(t / kWave);
+    for (uint32_t k = t; k < ncells; k += WAVES * 64)
+        tab[k] = table[k];
+    for (uint32_t k = t; k < 4 * 64; k += WAVES * 64)
+        hist[k] = 0;
+    __syncthreads();
+    float4 *mine = xpose + wave * (kWave * UU);
+    uint32_t *my = hist + (wave & 3u) * 64;
+    typedef __attribute__((address_space(1))) const void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    // UU = 8: the product's swizzle (two vector offsets); UU = 4: slot(run, w) = run * 4 + (w ^ ((run >> 2) & 3)), ONE vector offset
+    const uint32_t voff_even = UU == 8 ? 16u * ((lane & ~7u) | ((lane & 7u) ^ ((lane >> 4) & 7u))) : 16u * ((lane & ~3u) | ((lane & 3u) ^ ((lane >> 4) & 3u)));
+    const uint32_t voff_odd = UU == 8 ? 16u * ((lane & ~7u) | ((lane & 7u) ^ (((lane >> 4) + 4u) & 7u))) : voff_even;
+    auto load_batch = [&](float4 *dst, uint64_t batch) {  // batch: UU * 64 float4 (UU KiB) of the stream
+        const char *mid = reinterpret_cast<const char *>(uniform_u64((unsigned long long)(data + batch * (uint64_t)(UU * kWave) + (UU / 2) * kWave)));
+        lvoid *lmid = (lvoid *)(dst + (UU / 2) * kWave);
+#define ROW(r) __builtin_amdgcn_global_load_lds((gvoid *)(mid + (((r) & 1) ? voff_odd : voff_even)), lmid, 16, ((r) - UU / 2) * 1024, 2)
+        ROW(0); ROW(1); ROW(2); ROW(3);
+        if (UU == 8) { ROW(4); ROW(5); ROW(6); ROW(7); }
+#undef ROW
+    };
+    const uint64_t nbatches = nsegs * HALVES, stride = (uint64_t)gridDim.x * WAVES;
+    // a wave's batches: segment (it * grid + block) * WAVES + wave, its HALVES batches one after the other
+    uint64_t seg = (uint64_t)blockIdx.x * WAVES + wave;
+    int half = 0;
+    double sum = 0.0;
+    int32_t best[5] = {0, 0, 0, INT32_MIN, INT32_MIN};
+    const double m0 = pow2_f64(E), ulp = pow2_f64(E - 52), m1 = m0 + ulp;
+    const int32_t cfirst = (int32_t)cell_lo, clast = (int32_t)(cell_lo + ncells - 1);
+    double2 D_acc = make_double2(0.0, 0.0);
+    uint32_t map_acc = 2u;  // identity
+    if (seg < nsegs)
+        load_batch(mine, seg * HALVES);
+    while (seg < nsegs) {
+        uint64_t nseg = seg;
+        int nhalf = half + 1;
+        if (nhalf == HALVES) {
+            nhalf = 0;
+            nseg = seg + stride;
+        }
+        float4 y[UU];
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < UU; j++)
+            y[j] = UU == 8 ? mine[xpose_slot((int)lane, j)] : mine[(int)lane * 4 + (j ^ (((int)lane >> 2) & 3))];
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        asm volatile("" ::: "memory");
+        if (nseg < nsegs)
+            load_batch(mine, nseg * HALVES + nhalf);
+        float pw[2 * UU];
+#pragma unroll
+        for (int u = 0; u < UU; u++) {
+            typedef float f32x2v __attribute__((ext_vector_type(2)));
+            const f32x2v a = {y[u].x, y[u].y}, b = {y[u].z, y[u].w};
+            const f32x2v aa = a * a, bb = b * b;
+            asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u]) : "v"(aa.x), "v"(aa.y));
+            asm("v_add_f32 %0, %1, %2" : "=v"(pw[2 * u + 1]) : "v"(bb.x), "v"(bb.y));
+            // trackers (integer max on bit patterns, as the product's SegMax)
+            const int32_t pa = __float_as_int(pw[2 * u]), pb = __float_as_int(pw[2 * u + 1]);
+            best[0] = max(best[0], max(pa, pb));
+            best[1] = max(best[1], max(__float_as_int(y[u].x), __float_as_int(y[u].z)));
+            best[2] = max(best[2], max(__float_as_int(y[u].y), __float_as_int(y[u].w)));
+            best[3] = max(best[3], max(__float_as_int(-y[u].x), __float_as_int(-y[u].z)));
+            best[4] = max(best[4], max(__float_as_int(-y[u].y), __float_as_int(-y[u].w)));
+        }
+        uint2 e_lut[2 * UU];
+#pragma unroll
+        for (int u = 0; u < 2 * UU; u++) {
+            int32_t cell = __float_as_int(pw[u]) >> shift;
+            cell = cell < cfirst ? cfirst : (cell > clast ? clast : cell);
+            e_lut[u] = tab[cell - cfirst];
+        }
+        double x0 = m0, x1 = m1;
+#pragma unroll
+        for (int u = 0; u < 2 * UU; u++) {
+            const double v = (double)pw[u];
+            x0 += v;
+            x1 += v;
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * UU; u++) {
+            const uint32_t k = e_lut[u].x + (__float_as_uint(pw[u]) >= e_lut[u].y ? 1u : 0u);
+            (void)__hip_atomic_fetch_add((lds_u32 *)&my[k & 63u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const double d0 = x0 - m0, d1 = x1 - m1;
+        sum += d0;
+        // the batch's pair and its parity map, composed onto the segment's
+        {
+            const unsigned long long A = __ballot((__double2loint(x0) & 1) != 0), B = __ballot((__double2loint(x1) & 1) != 0);
+            const unsigned long long up = __ballot(d1 > d0), dn = __ballot(d1 < d0);
+            const unsigned long long C = ~(A ^ B), N = A & ~B;
+            unsigned long long px = N;
+            px ^= px << 1; px ^= px << 2; px ^= px << 4; px ^= px << 8; px ^= px << 16; px ^= px << 32;
+            const unsigned long long incl = px;
+            px <<= 1;
+            const unsigned long long Z = ~C, Y = (A ^ px) & C;
+            const unsigned long long fwd = (Z + (Y << 1)) ^ Z, has = (Z + (C << 1)) ^ Z;
+            const unsigned long long odd0 = px ^ fwd, odd1 = odd0 ^ ~has;
+            const int k0 = __popcll(up & odd0) - __popcll(dn & odd0), k1 = __popcll(up & odd1) - __popcll(dn & odd1);
+            const double S = wave_sum_to_lane63(d0);
+            const double2 Db = make_double2(S + (double)k0 * ulp, S + (double)k1 * ulp);
+            // exit parity of the batch for entry parity p: lane 63's map applied to the parity it is entered with
+            const uint32_t e0 = (uint32_t)(((odd0 >> 63) & 1ull) ? (B >> 63) & 1ull : (A >> 63) & 1ull);
+            const uint32_t e1 = (uint32_t)(((odd1 >> 63) & 1ull) ? (B >> 63) & 1ull : (A >> 63) & 1ull);
+            (void)incl;
+            // compose: the segment so far (D_acc, map_acc), then this batch
+            const uint32_t a0 = map_acc & 1u, a1 = (map_acc >> 1) & 1u;
+            D_acc = make_double2(D_acc.x + (a0 ? Db.y : Db.x), D_acc.y + (a1 ? Db.y : Db.x));
+            map_acc = (a0 ? e1 : e0) | ((a1 ? e1 : e0) << 1);
+        }
+        if (nhalf == 0) {  // the segment is complete: its pair would be kept for the batched store
+            sum += lane == kWave - 1 ? D_acc.y * 1e-30 : 0.0;
+            D_acc = make_double2(0.0, 0.0);
+            map_acc = 2u;
+        }
+        seg = nseg;
+        half = nhalf;
+    }
+    (void)nbatches;
+    int32_t b = best[0] ^ best[1] ^ best[2] ^ best[3] ^ best[4];
+    sum += (double)(b & 1) * 1e-30;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        sum += __shfl_down(sum, off, kWave);
+    if (lane == 0)
+        atomicAdd(out, sum);
+    __syncthreads();
+    for (uint32_t k = t; k < 64; k += WAVES * 64)
+        atomicAdd(&ghist[k], (unsigned long long)hist[k] + hist[64 + k] + hist[128 + k] + hist[192 + k]);
+}
+
+
 __global__ __launch_bounds__(kThreads) void plain_kernel(const float4 *__restrict__ data, uint64_t ntiles, double *__restrict__ out)
 {
     float acc = 0.f;
@@ -341,6 +493,59 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < a.size(); i++)
             bad += a[i].x != b[i].x || a[i].y != b[i].y;
         printf("# ... forms 2 and 5 disagree on %zu\n", bad);
+    }
+    // ---- geometry A / B with pass 2's per-sample work in it ----
+    {
+        const uint32_t shift = 15, cell_lo = (0x3A800000u >> shift), ncells = 3584;  // 2^-10 ... 2^4 in cells of 2^15 bit patterns: 28 KiB
+        std::vector<uint2> h_tab(ncells);
+        for (uint32_t c = 0; c < ncells; c++) {  // ~one bin per 112 cells (32 bins), the threshold in the middle of every 112th cell
+            h_tab[c].x = c / 112u;
+            h_tab[c].y = (c % 112u == 111u) ? (((cell_lo + c) << shift) + (1u << (shift - 1))) : 0xFFFFFFFFu;
+        }
+        uint2 *d_tab;
+        unsigned long long *d_hist;
+        hipMalloc(&d_tab, ncells * sizeof(uint2));
+        hipMalloc(&d_hist, 64 * 8);
+        hipMemcpy(d_tab, h_tab.data(), ncells * sizeof(uint2), hipMemcpyHostToDevice);
+        const size_t lds_a = ncells * 8 + 4 * 64 * 4 + (size_t)8 * 8192, lds_b = ncells * 8 + 4 * 64 * 4 + (size_t)16 * 4096;
+        hipFuncSetAttribute((const void *)geom_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+        hipFuncSetAttribute((const void *)geom_kernel<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        const char *gnames[2] = {"A: 8 waves per CU x 1024-sample segments (the product's geometry), pass 2's per-sample work in it",
+                                 "B: 16 waves per CU x two 512-sample halves per segment through a 4 KiB buffer, the same work"};
+        unsigned long long hsum[2] = {0, 0};
+        for (int rep = 0; rep < 2; rep++)
+            for (int g = 0; g < 2; g++) {
+                std::vector<float> ms;
+                for (int it = 0; it < 25; it++) {
+                    hipMemsetAsync(out, 0, 8, 0);
+                    hipMemsetAsync(d_hist, 0, 64 * 8, 0);
+                    hipEventRecord(e0, 0);
+                    if (g == 0)
+                        geom_kernel<8, 8><<<wgs, 512, lds_a>>>(data, nsegs, E, d_tab, ncells, cell_lo, shift, out, d_hist);
+                    else
+                        geom_kernel<16, 4><<<wgs, 1024, lds_b>>>(data, nsegs, E, d_tab, ncells, cell_lo, shift, out, d_hist);
+                    hipEventRecord(e1, 0);
+                    hipEventSynchronize(e1);
+                    float t;
+                    hipEventElapsedTime(&t, e0, e1);
+                    if (it >= 5)
+                        ms.push_back(t);
+                }
+                unsigned long long hh[64];
+                hipMemcpy(hh, d_hist, sizeof(hh), hipMemcpyDeviceToHost);
+                hsum[g] = 0;
+                for (int k = 0; k < 64; k++)
+                    hsum[g] += hh[k] * (unsigned long long)(k + 1);
+                std::sort(ms.begin(), ms.end());
+                double mean = 0;
+                for (float v : ms)
+                    mean += v;
+                mean /= ms.size();
+                printf("pass %d geometry %-112s  min %.4f  median %.4f  mean %.4f ms  = %.0f GB/s = %.3f of 8 TB/s   (hist checksum %llu)%s\n", rep, gnames[g],
+                       ms.front(), ms[ms.size() / 2], mean, bytes / (mean * 1e-3) / 1e9, bytes / (mean * 1e-3) / 1e9 / 8000.0, hsum[g],
+                       hipGetLastError() == hipSuccess ? "" : "  LAUNCH ERROR");
+            }
+        printf("# histograms of A and B %s\n", hsum[0] == hsum[1] ? "agree" : "DIFFER");
     }
     return 0;
 }
