@@ -811,6 +811,24 @@ static int papr_hip_estimate_file_impl(papr_hip_ctx *ctx, const char *path, uint
 }
 
 
+// A pipe holds 64 KiB by default: a reader that empties it 16 times per MiB spends its time being woken.  As much as an
+// unprivileged process may ask for (fs.pipe-max-size, 1 MiB by default); not a pipe, or refused: as it was.
+static void widen_pipe(int fd)
+{
+#ifdef F_SETPIPE_SZ
+    long want = 1 << 20;
+    if (FILE *f = fopen("/proc/sys/fs/pipe-max-size", "r")) {
+        long v = 0;
+        if (fscanf(f, "%ld", &v) == 1 && v >= 65536)
+            want = std::min<long>(v, 16 << 20);
+        fclose(f);
+    }
+    (void)fcntl(fd, F_SETPIPE_SZ, (int)want);
+#else
+    (void)fd;
+#endif
+}
+
 // ---- a stream that cannot be positioned (a FIFO, a pipe, a socket) ---------------------------------------------------
 // The reference fopen()s whatever it is given (papr.c:62, 93) and reads a pipe like a file, 64 KiB at a time, to its end:
 // pass 1 sees every sample.  Its length is only known at the end, so the shard grows as the bytes arrive: ONE reader
@@ -828,6 +846,7 @@ static int papr_hip_load_stream_impl(papr_hip_ctx *ctx, int fd, uint64_t *nsampl
     const double t_begin = now_s();
     HIPCHK(ctx, make_staging(ctx));
     release_shard(ctx);
+    widen_pipe(fd);
     const size_t slack = (size_t)PAPR_TILE_SAMPLES_MAX * 8;
     unsigned char *dev = nullptr;
     size_t cap = 0, total = 0;
@@ -961,6 +980,7 @@ static int papr_hip_stream_stats_impl(papr_hip_ctx *ctx, int fd, papr_stats *tot
     const double t_begin = now_s();
     HIPCHK(ctx, make_staging(ctx));
     release_shard(ctx);
+    widen_pipe(fd);
     const size_t slack = (size_t)PAPR_TILE_SAMPLES_MAX * 8, keep = 65536, group = (size_t)2 << 20;
     if (ctx->hbm_budget < keep + slack + keep)
         return fail(ctx, PAPR_E_NOMEM, "an HBM budget of %zu bytes holds no window of the stream", ctx->hbm_budget);

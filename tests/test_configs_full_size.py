@@ -159,6 +159,35 @@ def test_40_gib_file_streams_once_under_a_4_gib_budget(pkg, file40g, manifest, g
     assert info["shards_swept"] == gpus and info["shards_resolved_from_sweep"] == gpus
 
 
+def test_40_gib_through_a_fifo_is_the_files_pass_1_with_the_references_sum(pkg, file40g, manifest):
+    """An input that cannot be rewound, at full size: the 40 GiB file through a FIFO into `bin/papr` (`cat file > fifo`).  The
+    stream crosses one 256 MiB window of HBM 160 times; what is printed must be the reference's recording for the FILE with
+    every percentage zero (papr.c:142-143: pass 2 finds a stream at its end) — the `average power` line included, i.e. the
+    reference's sequential double sum over 5.4e9 samples, carried exactly from window to window."""
+    fifo = os.path.join("/tmp", f"papr_fifo_{os.getpid()}")
+    if os.path.exists(fifo):
+        os.unlink(fifo)
+    os.mkfifo(fifo)
+    try:
+        feeder = subprocess.Popen(f"exec cat '{file40g}' > '{fifo}'", shell=True)
+        p = subprocess.run([pkg.CLI_PATH, fifo], capture_output=True, env=dict(os.environ, PAPR_STATS="1"), timeout=900)
+        feeder.wait(timeout=60)
+    finally:
+        os.unlink(fifo)
+    assert p.returncode == 0, p.stderr[-2000:]
+    want = _golden("big_spike40g.default.txt").splitlines()
+    got = p.stdout.splitlines()
+    assert len(got) == len(want) == manifest["big_spike40g"]["default"]["lines"]
+    for g, w in zip(got, want):
+        if w.startswith(b"percentage above"):
+            assert g == w.split(b"=")[0] + b"= 0.00000000", (g, w)
+        else:
+            assert g == w, (g, w)
+    info = json.loads(p.stderr.decode().splitlines()[-1])
+    assert info["samples"] == manifest["big_spike40g"]["nsamples"] and info["exact_sum"] == 1
+    assert info["stream_windows"] == 160 and info["gpu0_ingest"]["resident"] == 0
+
+
 # ---- configs[4] at its own size: 256 GiB, whenever the box can hold the file in /dev/shm ------------------------------------
 
 @pytest.fixture(scope="module")
