@@ -972,9 +972,11 @@ static int papr_hip_ccdf_impl(papr_hip_ctx *ctx, const float *levels, int nlevel
         return PAPR_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CcdfPlan plan;
+    ctx->trace.mark("ccdf_enter");
     int rc = plan_ccdf(ctx, levels, nlevels, &plan);
     if (rc)
         return rc;
+    ctx->trace.mark("ccdf_planned");
     const uint32_t m = plan.P.nkeys;
     if (m == 0 || ctx->n == 0) {
         for (int j = 0; j < nlevels; j++)
@@ -984,6 +986,7 @@ static int papr_hip_ccdf_impl(papr_hip_ctx *ctx, const float *levels, int nlevel
     if (ctx->sweep_valid) {  // the one-sweep pass already decided everything outside the bands
         bool done = false;
         rc = resolve_from_sweep(ctx, plan, levels, nlevels, counts_above, &done);
+        ctx->trace.mark("ccdf_resolved");
         if (rc || done)
             return rc;
     }

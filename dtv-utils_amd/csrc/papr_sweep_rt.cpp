@@ -882,6 +882,10 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
     XCHK(sync_e);
     ctx->trace.mark("synced");
 #undef XCHK
+    struct LeaveMark {  // (where the host's microseconds behind the wait go: PAPR_HOST_TRACE=1)
+        papr_hip_ctx *c;
+        ~LeaveMark() { c->trace.mark("fused_leave"); }
+    } leave_mark{ctx};
     ctx->program_pending = false;
     if (peers && exact)
         ctx->exact_program_before = ctx->h_peer->before;
