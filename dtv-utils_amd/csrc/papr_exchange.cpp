@@ -141,6 +141,7 @@ struct papr_exchange {
     bool use_ops = false;
     // RCCL transport
     papr_hip_ctx *ctx = nullptr;
+    int device = -1;               // ctx's device, kept: papr_exchange_close must not look into a context its caller has closed already
     ncclComm_t comm = nullptr;
     bool want_rccl = false;        // papr_exchange_open_rccl_local: papr_exchange_bind still has to create `comm`
     ncclUniqueId solo_uid{};       // ... for a world of one (no hub)
@@ -571,6 +572,7 @@ int papr_exchange_open_rccl(papr_exchange **out, papr_hip_ctx *ctx, const void *
     x->rank = rank;
     x->world = world;
     x->ctx = ctx;
+    x->device = ctx->device;
     if (hipSetDevice(ctx->device) != hipSuccess) {
         delete x;
         return xfail(nullptr, PAPR_E_HIP, "hipSetDevice(%d) failed", ctx->device);
@@ -710,6 +712,7 @@ int papr_exchange_bind(papr_exchange *x, papr_hip_ctx *ctx)
                      rccl()->GetErrorString ? rccl()->GetErrorString(r) : "RCCL error");
     }
     x->ctx = ctx;
+    x->device = ctx->device;
     return PAPR_OK;
 }
 
@@ -873,6 +876,7 @@ int papr_exchange_adopt_rccl(papr_exchange *x, papr_hip_ctx *ctx, double timeout
     if (all && comm) {
         x->comm = comm;
         x->ctx = ctx;
+        x->device = ctx->device;
         x->use_ops = x->world > 1;  // (a world of one runs its collectives through RCCL: no identity short cut)
         start_watchdog(x);
         return PAPR_OK;
@@ -975,8 +979,8 @@ void papr_exchange_close(papr_exchange *x)
         std::lock_guard<std::mutex> g(x->bind->m);
         x->bind->abandoned = true;
     }
-    if (x->ctx)
-        (void)hipSetDevice(x->ctx->device);
+    if (x->device >= 0)  // (the context itself may be gone: bin/papr with PAPR_TEARDOWN=1 closed it first — found by ThreadSanitizer, round 6)
+        (void)hipSetDevice(x->device);
     {
         std::lock_guard<std::timed_mutex> g(x->comm_m);
         if (x->comm && rccl() && !x->comm_ended)

@@ -463,8 +463,8 @@ int main(int argc, char **argv)
     for (int g = 0; g < ngpu; g++) {
         free(sh[g].counts);
         free(sh[g].levels);
+        papr_exchange_close(xs[g]); /* (the exchange's communicator lives on the context's device: the exchange goes first) */
         papr_hip_close(sh[g].ctx);
-        papr_exchange_close(xs[g]);
     }
     return 0;
 }

@@ -34,7 +34,7 @@ typedef struct papr_exchange_ops {
 int papr_exchange_unique_id(void *id /* PAPR_EXCHANGE_ID_BYTES */);
 int papr_exchange_open_rccl(papr_exchange **x, papr_hip_ctx *ctx, const void *id, int rank, int world);
 int papr_exchange_open_ops(papr_exchange **x, const papr_exchange_ops *ops, int rank, int world);
-void papr_exchange_close(papr_exchange *x);
+void papr_exchange_close(papr_exchange *x); /* before or after papr_hip_close of the context it was opened / bound with: either order */
 const char *papr_exchange_last_error(const papr_exchange *x); /* x may be NULL: last open error */
 int papr_exchange_stats(papr_exchange *x, const papr_stats *local, papr_stats *total, double *sum_before,
                         papr_stats *all /* world records in rank order, or NULL */);

@@ -2,8 +2,8 @@
 """A randomised soak of bin/papr ON THE GPU BOX against the compiled reference (oracle/_ref/papr; the oracle port where it is
 absent): N random cfiles (1000 ... 24 million samples, random seed and scale, the bench's spikes or none, 0-1 stray floats and 0-3
 stray bytes at the end) through the CLI resident, streamed (a few MiB of HBM: the one-sweep ingest, its reader threads and
-chunks), as three shards on one GPU over the in-process hub, and as three streamed shards — default and -g each: stdout must be
-the reference's, byte for byte.   gpurun -- 'python tools/cli_soak.py 40'"""
+chunks), as three shards on one GPU over the in-process hub, as three streamed shards, and through a FIFO (windows of HBM of a
+random size, against the reference through a FIFO of its own) — default and -g each: stdout must be the reference's, byte for byte.   gpurun -- 'python tools/cli_soak.py 40'"""
 import os
 import subprocess
 import sys
@@ -43,6 +43,22 @@ def main():
                 if p.returncode != 0 or p.stdout != want:
                     bad += 1
                     print("MISMATCH", it, n, " ".join(args[3:]), mode, name, env, "rc", p.returncode, p.stderr[-300:], flush=True)
+            # ... and as a stream that cannot be rewound: through a FIFO, one window of HBM of a random size (round 6), against the
+            # reference fed through a FIFO of its own (its pass 2 counts nothing there: papr.c:142-143)
+            fifo = "/dev/shm/cli_soak.fifo"
+            outs = []
+            for prog, env in ((ref, {}), (cli, {"PAPR_STREAM_WINDOW_MB": str(int(rng.integers(2, 40)))})):
+                if os.path.exists(fifo):
+                    os.unlink(fifo)
+                os.mkfifo(fifo)
+                feeder = subprocess.Popen(f"exec cat '{path}' > '{fifo}'", shell=True)
+                outs.append(subprocess.run([prog] + mode + [fifo], capture_output=True, env=dict(os.environ, **env), timeout=300))
+                feeder.wait(timeout=60)
+                os.unlink(fifo)
+            runs += 1
+            if outs[1].returncode != outs[0].returncode or outs[1].stdout != outs[0].stdout or outs[1].stderr != outs[0].stderr:
+                bad += 1
+                print("MISMATCH", it, n, " ".join(args[3:]), mode, "through a FIFO", "rc", outs[1].returncode, outs[1].stderr[-300:], flush=True)
         if it % 10 == 9:
             print("...", it + 1, "files,", runs, "runs,", bad, "mismatches", flush=True)
     os.unlink(path)

@@ -44,6 +44,16 @@ run "streamed (512 MiB of HBM), -g" "$refg" PAPR_HBM_BUDGET_MB=512 bin/papr_tsan
 run "three shards on one GPU, in-process hub" "$ref" PAPR_GPUS=3 PAPR_OVERSUBSCRIBE=1 PAPR_XCH=threads bin/papr_tsan $F
 run "three shards on one GPU, RCCL refused (one device): hub" "$ref" PAPR_GPUS=3 PAPR_OVERSUBSCRIBE=1 bin/papr_tsan $F
 run "three shards, streamed, -g" "$refg" PAPR_GPUS=3 PAPR_OVERSUBSCRIBE=1 PAPR_HBM_BUDGET_MB=256 bin/papr_tsan -g $F
+# round 6: the communicators coming up in threads of their own beside the ingest (papr_exchange_open_rccl_local_async / _adopt_rccl) —
+# taken, failed, late, and three shards of which one fails while the others sit in ncclCommInitRank — and a stream through a FIFO
+run "one shard, RCCL taken when the shard is loaded" "$ref" PAPR_GPUS=1 PAPR_XCH=rccl bin/papr_tsan $F
+run "one shard, RCCL set-up fails: hub" "$ref" PAPR_GPUS=1 PAPR_XCH=rccl PAPR_XCH_BIND_FAIL=all bin/papr_tsan $F
+run "one shard, RCCL late (auto): hub" "$ref" PAPR_GPUS=1 PAPR_XCH=auto PAPR_XCH_BIND_DELAY_MS=20000 bin/papr_tsan $F
+run "three shards, one set-up fails, the others abandoned" "$ref" PAPR_GPUS=3 PAPR_OVERSUBSCRIBE=1 PAPR_XCH_BIND_SHARED_OK=1 PAPR_XCH_BIND_FAIL=1 PAPR_XCH_BIND_TIMEOUT_S=5 bin/papr_tsan $F
+rm -f /tmp/tsan.fifo; mkfifo /tmp/tsan.fifo
+( cat $F > /tmp/tsan.fifo & ) ; reff=$(oracle/_ref/papr /tmp/tsan.fifo 2>/dev/null | md5sum)
+( cat $F > /tmp/tsan.fifo & ) ; run "a stream through a FIFO, windows of 64 MiB" "$reff" PAPR_STREAM_WINDOW_MB=64 bin/papr_tsan /tmp/tsan.fifo
+rm -f /tmp/tsan.fifo
 rm -f $F
 # the packet scan: a damaged stream's report lines are laid out by the host's line pool (eight spinning threads), scan after scan
 for SPEC in "8000000 500 12" "57000000 1000 6"; do
