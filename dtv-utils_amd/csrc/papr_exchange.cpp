@@ -143,6 +143,7 @@ struct papr_exchange {
     papr_hip_ctx *ctx = nullptr;
     int device = -1;               // ctx's device, kept: papr_exchange_close must not look into a context its caller has closed already
     ncclComm_t comm = nullptr;
+    std::atomic<bool> has_comm{false};  // `comm` is there (set behind it, by its owner): what papr_exchange_abort asks before it takes comm_m
     bool want_rccl = false;        // papr_exchange_open_rccl_local: papr_exchange_bind still has to create `comm`
     ncclUniqueId solo_uid{};       // ... for a world of one (no hub)
     std::atomic<bool> aborted{false};
@@ -592,6 +593,7 @@ int papr_exchange_open_rccl(papr_exchange **out, papr_hip_ctx *ctx, const void *
         papr_exchange_close(x);
         return PAPR_E_HIP;
     }
+    x->has_comm.store(true, std::memory_order_release);
     *out = x;
     return PAPR_OK;
 }
@@ -713,6 +715,7 @@ int papr_exchange_bind(papr_exchange *x, papr_hip_ctx *ctx)
     }
     x->ctx = ctx;
     x->device = ctx->device;
+    x->has_comm.store(true, std::memory_order_release);
     return PAPR_OK;
 }
 
@@ -875,6 +878,7 @@ int papr_exchange_adopt_rccl(papr_exchange *x, papr_hip_ctx *ctx, double timeout
     x->bind.reset();
     if (all && comm) {
         x->comm = comm;
+        x->has_comm.store(true, std::memory_order_release);
         x->ctx = ctx;
         x->device = ctx->device;
         x->use_ops = x->world > 1;  // (a world of one runs its collectives through RCCL: no identity short cut)
@@ -908,6 +912,8 @@ void papr_exchange_abort(papr_exchange *x)
     // is the wait ncclCommAbort exists to end, so it is called without the mutex then.
     auto end_comm = [](papr_exchange *m) {
         m->aborted.store(true);
+        if (!m->has_comm.load(std::memory_order_acquire))
+            return;  // (a handle of the hub alone: nothing to end, no mutex to take)
         const bool got = m->comm_m.try_lock_for(std::chrono::milliseconds(500));
         // (`comm` is written by its owner before any collective and by its close; read here without the mutex only when the
         // owner sits inside an RCCL call and will not touch it)

@@ -2,7 +2,8 @@
 // -fsanitize=thread by tests/test_sanitizers.py: `threads` threads run `rounds` rounds of the exchange's host-level collectives
 // (papr_exchange_stats, papr_exchange_counts, the self-test's all-gather / all-reduce with ctx = NULL), check what comes back,
 // then one of them cancels the exchange while the others wait in a collective (papr_exchange_abort: everyone is released with
-// PAPR_E_STATE), and all close.  Prints "ok" or what went wrong.  No GPU: the two runtime helpers the exchange links against are
+// PAPR_E_STATE), and all close.  A third argument "async": the handles are papr_exchange_open_rccl_local_async's and are adopted
+// first (see main).  Prints "ok" or what went wrong.  No GPU: the two runtime helpers the exchange links against are
 // supplied here.
 #include <atomic>
 #include <chrono>
@@ -29,11 +30,18 @@ int env_int(const char *name, int dflt)
 
 int main(int argc, char **argv)
 {
-    if (argc != 3)
+    if (argc != 3 && argc != 4)
         return 2;
     const int n = atoi(argv[1]), rounds = atoi(argv[2]);
+    // "async": the handles come from papr_exchange_open_rccl_local_async — n set-up threads beside these — with the set-up made
+    // to fail (PAPR_XCH_BIND_FAIL=all in the environment: no RCCL, no GPU is touched); every thread then adopts (all agree
+    // through the hub that nobody has a communicator), and the handles must be the hub's for everything that follows
+    const bool async = argc == 4 && !strcmp(argv[3], "async");
     std::vector<papr_exchange *> xs((size_t)n);
-    if (papr_exchange_open_local(xs.data(), n) != PAPR_OK) {
+    std::vector<int> devices((size_t)n);
+    for (int r = 0; r < n; r++)
+        devices[(size_t)r] = r;
+    if ((async ? papr_exchange_open_rccl_local_async(xs.data(), n, devices.data()) : papr_exchange_open_local(xs.data(), n)) != PAPR_OK) {
         printf("open failed: %s\n", papr_exchange_last_error(nullptr));
         return 1;
     }
@@ -42,6 +50,15 @@ int main(int argc, char **argv)
     for (int r = 0; r < n; r++)
         th.emplace_back([&, r] {
             papr_exchange *x = xs[(size_t)r];
+            if (async) {
+                double setup = -1.0, waited = -1.0;
+                // (the context is only looked into when a communicator is taken or ended: none exists here)
+                if (papr_exchange_adopt_rccl(x, reinterpret_cast<papr_hip_ctx *>(&bad), 30.0, &setup, &waited) != PAPR_OK || papr_exchange_is_rccl(x) ||
+                    waited < 0.0)
+                    bad = 7;
+                if (papr_exchange_adopt_rccl(x, reinterpret_cast<papr_hip_ctx *>(&bad), 30.0, nullptr, nullptr) != PAPR_OK)  // (a second call: nothing pending)
+                    bad = 8;
+            }
             for (int k = 0; k < rounds && !bad.load(); k++) {
                 papr_stats mine;
                 memset(&mine, 0, sizeof(mine));

@@ -128,3 +128,13 @@ def test_in_process_exchange_under_thread_sanitizer(tmp_path):
         p = subprocess.run([str(exe), str(threads), str(rounds)], capture_output=True, text=True, timeout=600, env=env)
         assert "ThreadSanitizer" not in p.stderr, p.stderr[-4000:]
         assert p.returncode == 0 and p.stdout.strip() == "ok", (threads, rounds, p.stdout, p.stderr[-2000:])
+    # round 6: the handles of papr_exchange_open_rccl_local_async — n set-up threads of their own beside the callers — with the
+    # set-up made to fail (no RCCL, no GPU touched): every caller adopts, all agree through the hub that nobody has a
+    # communicator, rank 0 says so in one line, and the handles are the hub's for the same rounds of collectives and the abort
+    for threads, rounds in ((8, 300), (2, 300), (1, 50)):
+        p = subprocess.run([str(exe), str(threads), str(rounds), "async"], capture_output=True, text=True, timeout=600,
+                           env=dict(env, PAPR_XCH_BIND_FAIL="all"))
+        assert "ThreadSanitizer" not in p.stderr, p.stderr[-4000:]
+        assert p.returncode == 0 and p.stdout.strip() == "ok", (threads, rounds, p.stdout, p.stderr[-2000:])
+        said = [l for l in p.stderr.splitlines() if l.startswith("papr: RCCL set-up did not complete")]
+        assert len(said) == 1 and "injected" in said[0], p.stderr[-1000:]
