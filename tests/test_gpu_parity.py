@@ -365,6 +365,56 @@ def test_load_stream_grows_the_shard_and_keeps_the_bytes(pkg, gpu, tmp_path):
     assert st_stream.to_bytes() == gpu.stats().to_bytes()
 
 
+def test_load_stream_beyond_the_budget_is_an_error_that_leaves_the_context_usable(pkg, orc, tmp_path):
+    """papr_hip_load_stream keeps the WHOLE stream resident (for a caller who wants pass 2 of it): beyond the HBM budget it is
+    PAPR_E_NOMEM — through its clean-up (the growing shard and the events are given back) — and the context then
+    loads and analyses a file as if nothing had happened; papr_hip_stream_stats takes the same stream in windows."""
+    import threading
+    n = (40 << 20) // 8
+    path = str(tmp_path / "f.cfile")
+    subprocess.check_call([orc.MKCFILE, path, str(n), "--seed", "5", "--spike"])
+    data = open(path, "rb").read()
+    want = orc.run_file(path, False)
+
+    def pipe_with(data):
+        r, w = os.pipe()
+
+        def feed():
+            try:
+                with os.fdopen(w, "wb") as f:
+                    f.write(data)
+            except BrokenPipeError:
+                pass
+        t = threading.Thread(target=feed, daemon=True)
+        t.start()
+        return r, t
+    os.environ["PAPR_HBM_BUDGET_MB"] = "16"
+    try:
+        with pkg.PaprHip(0) as g:
+            g.set_exact(True)
+            r, t = pipe_with(data)
+            try:
+                with pytest.raises(pkg.PaprError) as e:
+                    g.load_stream(r)
+            finally:
+                os.close(r)
+            t.join(30)
+            assert e.value.code == -4 and "HBM budget" in str(e.value)
+            r, t = pipe_with(data)
+            try:
+                st, exact, windows = g.stream_stats(r)
+            finally:
+                os.close(r)
+            t.join(30)
+            assert exact and windows == 3 and st.n == n and st.sum == want["sum"] and st.peak_idx == want["peak_idx"]
+            g.load_file(golden_path("g1m"))          # (a shard again, in the same context)
+            res, table, counts = g.analyze(None, False)
+            ref = orc.run_file(golden_path("g1m"), False)
+            assert res.total.n == ref["n"] and res.total.sum == ref["sum"] and res.exact_sum == 1
+    finally:
+        del os.environ["PAPR_HBM_BUDGET_MB"]
+
+
 # ---- seeded random inputs vs the oracle, every launch geometry --------------------
 
 SIZES = [1, 2, 63, 64, 255, 4095, 4096, 4097, 8191, 12289, 100003, 1048576 + 5]
