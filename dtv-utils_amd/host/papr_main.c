@@ -18,7 +18,7 @@
  *                      =rccl also runs them for a single shard), or the plain in-process hub (=threads).  The communicators
  *                      come up in threads of their own BESIDE the ingest and are taken when the shards are loaded: waited
  *                      for up to PAPR_XCH_BIND_TIMEOUT_S (30) seconds, or — =auto — only if they are up by then; librccl
- *                      missing, a set-up that fails or is late: one line on stderr and the hub, same stdout
+ *                      missing, a set-up that fails or is late: the hub, same stdout (and, when RCCL was asked for by name, one line on stderr)
  *   PAPR_STATS=1       one JSON line with sizes and timings on stderr
  *   PAPR_TEARDOWN=1    close the contexts and let the runtime's exit handlers run (default: _exit once the answer
  *                      is printed — the orderly way costs ~90 ms for a 10 GiB shard)
@@ -60,6 +60,7 @@ typedef struct shard {
     int stream_fd;        /* >= 0: the input cannot be positioned (a FIFO, a pipe): read once from this descriptor */
     const char *path;
     uint64_t first, count;
+    int say_fallback;     /* PAPR_XCH=rccl|auto: a set-up that fails or is late is said on stderr; by default stderr stays the reference's */
     double bind_timeout_s, xch_setup_s, xch_waited_s; /* RCCL set-up beside the ingest: how long it may be waited for; what it took */
     uint64_t stream_windows; /* stream_fd >= 0: windows of HBM the stream crossed (papr_hip_stream_stats) */
     float *levels;        /* PAPR_HIP_MAX_LEVELS each */
@@ -175,6 +176,8 @@ static void *shard_thread(void *arg)
         papr_exchange_abort(s->xch);
         return NULL;
     }
+    if (s->say_fallback && s->index == 0 && !papr_exchange_is_rccl(s->xch) && papr_exchange_last_error(s->xch)[0])
+        fprintf(stderr, "papr: %s\n", papr_exchange_last_error(s->xch)); /* (only when PAPR_XCH asked for RCCL by name) */
     rc = papr_hip_analyze(s->ctx, s->xch, s->graph, 0, &s->res, s->levels, s->counts, PAPR_HIP_MAX_LEVELS);
     if (rc != PAPR_OK) {
         shard_fail(s, rc, "analysis");
@@ -316,6 +319,7 @@ int main(int argc, char **argv)
     for (int g = 0; g < ngpu; g++) {
         sh[g].xch = xs[g];
         sh[g].bind_timeout_s = bind_timeout_s;
+        sh[g].say_fallback = rccl_forced || rccl_auto;
         sh[g].ingest_sweep = one_sweep;
         sh[g].levels = (float *)malloc(PAPR_HIP_MAX_LEVELS * sizeof(float));
         sh[g].counts = (uint64_t *)calloc(PAPR_HIP_MAX_LEVELS, sizeof(uint64_t));

@@ -62,8 +62,8 @@ int papr_exchange_bind(papr_exchange *x, papr_hip_ctx *ctx);
  * Every shard's thread later calls papr_exchange_adopt_rccl(x, ctx, ...) — all n at the same point of their sequence: it
  * waits up to timeout_s (0: not at all) for this rank's communicator, the threads agree through the hub, and either ALL
  * handles take their communicators (papr_exchange_is_rccl: the step's exchanges are collectives on the contexts' streams
- * from then on) or none does — librccl missing, a failed or slow ncclCommInitRank: rank 0 says why in one line on stderr
- * and the handles stay the hub's.  Always PAPR_OK unless the hub itself was cancelled.  *setup_s: how long this rank's
+ * from then on) or none does — librccl missing, a failed or slow ncclCommInitRank: the handles stay the hub's and
+ * papr_exchange_last_error(x) says why (nothing is printed: bin/papr prints it when RCCL was asked for by name).  Always PAPR_OK unless the hub itself was cancelled.  *setup_s: how long this rank's
  * set-up thread ran (0 if it is not done), *waited_s: how long this call waited for it.  Shards that share a device:
  * no threads are started, adopt is a no-op.  (Tests: PAPR_XCH_BIND_FAIL=all|<rank> injects a failure,
  * PAPR_XCH_BIND_DELAY_MS a slow set-up.) */

@@ -56,6 +56,8 @@ int main(int argc, char **argv)
                 if (papr_exchange_adopt_rccl(x, reinterpret_cast<papr_hip_ctx *>(&bad), 30.0, &setup, &waited) != PAPR_OK || papr_exchange_is_rccl(x) ||
                     waited < 0.0)
                     bad = 7;
+                if (r == 0)  // (the library prints nothing: why there is no communicator is the handle's last error)
+                    fprintf(stderr, "papr: %s\n", papr_exchange_last_error(x));
                 if (papr_exchange_adopt_rccl(x, reinterpret_cast<papr_hip_ctx *>(&bad), 30.0, nullptr, nullptr) != PAPR_OK)  // (a second call: nothing pending)
                     bad = 8;
             }
