@@ -784,6 +784,24 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
         time_end_kernel(ctx);
     }
     XCHK(hipGetLastError());
+    // Exact-sum mode, alone: the sum program FIRST — the pairs the sweep built, the true prefix, the refuted tiles rebuilt, groups,
+    // gather: nothing of it needs pass 1's record — so that the host's replay of it (0.07 ms) has the finalize kernel, the
+    // table, the recount and the copy to run beside (round 6: the chain used to sit behind the finalize kernel, and 40 us of
+    // the replay stood in the open)
+    const bool exact_chain_first = exact && !peers && env_int("PAPR_EXACT_CHAIN_FIRST", 1) != 0;
+    auto queue_exact_chain = [&]() -> int {
+        const int xrc = run_exact_swept(ctx, 0.0, ctx->n);
+        if (xrc)
+            return xrc;
+        ctx->exact_program_launched = true;
+        ctx->exact_program_before = 0.0;
+        return PAPR_OK;
+    };
+    if (exact_chain_first) {
+        rc = queue_exact_chain();
+        if (rc)
+            return leave(rc);
+    }
     // pass 1's record (tail + merge of the workgroups' records) — and, on the way, the sweep's bins and segment counters
     // into mapped host memory (sweep_fetch without a copy in the stream; PAPR_FUSED_COPIES=1 keeps the copies) ...
     const bool by_kernel = env_int("PAPR_FUSED_COPIES", 0) == 0;
@@ -796,13 +814,11 @@ int stats_sweep_fused(papr_hip_ctx *ctx, papr_exchange *x, int graph, double max
                                (uint32_t)run.blocks, ctx->h_result_dev, ctx->d_result_copy, ctx->d_sweep_hist,
                                ctx->h_sweep_hist_dev, by_kernel ? kBinsMax + 2u * (uint32_t)run.blocks + 1u : 0u);
     XCHK(hipGetLastError());
-    if (exact && !peers) {
+    if (exact && !peers && !exact_chain_first) {
         // ... the sum program from the pairs the sweep built (true prefix, the refuted tiles rebuilt, groups, gather) ...
-        rc = run_exact_swept(ctx, 0.0, ctx->n);
+        rc = queue_exact_chain();
         if (rc)
             return leave(rc);
-        ctx->exact_program_launched = true;
-        ctx->exact_program_before = 0.0;
     }
     // ... and, speculatively, what follows from the record: the reference's level table with the device's libm, the
     // recount LUT for it, and the recount of the stash — so that the step's second half needs no launch + wait round
